@@ -1,0 +1,137 @@
+"""Exact integer-lattice restatements of the GEOS predicates the reference calls
+(TEST INFRASTRUCTURE; **parity unpinned**: shapely/GEOS cannot be installed in
+the build container -- truth tables in tests/golden/geos_truth.py are derived by
+hand from the OGC Simple Features / DE-9IM definitions).
+
+All coordinates are integer lattice indices (|v| < 2**15), so every orientation
+determinant is exact in int64.
+"""
+import numpy as np
+
+
+def orient(ax, ay, bx, by, cx, cy):
+    """sign-carrying cross product (b-a) x (c-a), exact in int64."""
+    return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax)
+
+
+def _strictly_between(px, py, qx, qy, ax, ay):
+    """a collinear with p,q assumed; a strictly inside the open segment (p,q)."""
+    dx, dy = qx - px, qy - py
+    t = (ax - px) * dx + (ay - py) * dy            # projection * |pq|^2
+    return (t > 0) & (t < dx * dx + dy * dy)
+
+
+def chord_touches_contour(p, q, contour):
+    """shapely ``LineString([p, q]).touches(LineString(contour))`` for a chord whose
+    two end points are vertices of ``contour`` (streamer_index.py:192-198).
+
+    DE-9IM ``touches``: the geometries meet, but their interiors do not.  The
+    chord's interior is the open segment (p,q); the contour's interior is the whole
+    polyline minus its two end vertices.  p and q lie on the contour, so the
+    geometries always meet; the predicate is therefore
+    ``not (open chord meets contour minus {end vertices})``.
+    """
+    c = np.asarray(contour, dtype=np.int64)
+    px, py = int(p[0]), int(p[1])
+    qx, qy = int(q[0]), int(q[1])
+    ax, ay = c[:-1, 0], c[:-1, 1]
+    bx, by = c[1:, 0], c[1:, 1]
+    n = len(c)
+    d1 = orient(px, py, qx, qy, ax, ay)
+    d2 = orient(px, py, qx, qy, bx, by)
+    d3 = orient(ax, ay, bx, by, px, py)
+    d4 = orient(ax, ay, bx, by, qx, qy)
+    proper = (((d1 > 0) & (d2 < 0)) | ((d1 < 0) & (d2 > 0))) & (((d3 > 0) & (d4 < 0)) | ((d3 < 0) & (d4 > 0)))
+    idx = np.arange(n - 1)
+    a_end = idx == 0
+    b_end = idx == n - 2
+    col = (d1 == 0) & (d2 == 0)
+    a_in = (d1 == 0) & _strictly_between(px, py, qx, qy, ax, ay)
+    b_in = (d2 == 0) & _strictly_between(px, py, qx, qy, bx, by)
+    vertex_hit = (~col) & ((a_in & ~a_end) | (b_in & ~b_end))
+    # collinear overlap of positive length: compare parameter intervals along the chord
+    dx, dy = qx - px, qy - py
+    L = dx * dx + dy * dy
+    ta = (ax - px) * dx + (ay - py) * dy
+    tb = (bx - px) * dx + (by - py) * dy
+    lo = np.maximum(np.minimum(ta, tb), 0)
+    hi = np.minimum(np.maximum(ta, tb), L)
+    overlap = col & (hi > lo)
+    return not bool(np.any(proper | vertex_hit | overlap))
+
+
+def segments_intersect(p1, q1, p2, q2):
+    """shapely ``LineString([p1,q1]).intersects(LineString([p2,q2]))``: closed segments share a point
+    (streamer_index.py:233-236)."""
+    p1x, p1y, q1x, q1y = int(p1[0]), int(p1[1]), int(q1[0]), int(q1[1])
+    p2x, p2y, q2x, q2y = int(p2[0]), int(p2[1]), int(q2[0]), int(q2[1])
+    d1 = orient(p1x, p1y, q1x, q1y, p2x, p2y)
+    d2 = orient(p1x, p1y, q1x, q1y, q2x, q2y)
+    d3 = orient(p2x, p2y, q2x, q2y, p1x, p1y)
+    d4 = orient(p2x, p2y, q2x, q2y, q1x, q1y)
+    if ((d1 > 0 and d2 < 0) or (d1 < 0 and d2 > 0)) and ((d3 > 0 and d4 < 0) or (d3 < 0 and d4 > 0)):
+        return True
+
+    def on(ax, ay, bx, by, cx, cy):   # c on closed segment [a,b], collinearity known
+        return min(ax, bx) <= cx <= max(ax, bx) and min(ay, by) <= cy <= max(ay, by)
+
+    if d1 == 0 and on(p1x, p1y, q1x, q1y, p2x, p2y):
+        return True
+    if d2 == 0 and on(p1x, p1y, q1x, q1y, q2x, q2y):
+        return True
+    if d3 == 0 and on(p2x, p2y, q2x, q2y, p1x, p1y):
+        return True
+    if d4 == 0 and on(p2x, p2y, q2x, q2y, q1x, q1y):
+        return True
+    return False
+
+
+def polygon_cells(poly, r, width, height):
+    """Lattice points ``(x in [0,width), y in [0,height))`` contained in
+    ``Polygon(poly).buffer(r)`` (index_utils.py:37-51, sjoin predicate 'contains').
+
+    For lattice polygons and r <= 1/2 this is exactly
+    ``{p : winding(p) != 0  or  dist(p, boundary) < r}``: a
+    lattice point off a lattice segment is never at distance exactly r, and the only
+    lattice point within r of a vertex is the vertex itself, so GEOS' 8-segment
+    quarter-circle approximation cannot change membership.  For r > 1/2 the round
+    caps matter and the true-circle distance is used (unpinned against GEOS).
+
+    Returns (xs, ys) sorted by (y, x).
+    """
+    v = np.asarray(poly, dtype=np.int64)
+    if len(v) and (v[0] == v[-1]).all() and len(v) > 1:
+        v = v[:-1]
+    n = len(v)
+    pad = int(np.ceil(r))
+    x0 = max(int(v[:, 0].min()) - pad, 0)
+    x1 = min(int(v[:, 0].max()) + pad, width - 1)
+    y0 = max(int(v[:, 1].min()) - pad, 0)
+    y1 = min(int(v[:, 1].max()) + pad, height - 1)
+    gx, gy = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1))
+    wind = np.zeros(gx.shape, dtype=np.int64)
+    near = np.zeros(gx.shape, dtype=bool)
+    r2 = float(r) * float(r)
+    for k in range(n):
+        ax, ay = v[k]
+        bx, by = v[(k + 1) % n]
+        # winding number by signed crossings of the ray to +x (half-open rule on y)
+        cr = orient(ax, ay, bx, by, gx, gy)
+        up = (ay <= gy) & (by > gy) & (cr > 0)
+        dn = (ay > gy) & (by <= gy) & (cr < 0)
+        wind += up.astype(np.int64) - dn.astype(np.int64)
+        # squared distance to the closed segment, exact rational compare: d^2 < r^2
+        dx, dy = bx - ax, by - ay
+        L = dx * dx + dy * dy
+        t = (gx - ax) * dx + (gy - ay) * dy
+        if L == 0:
+            d2 = ((gx - ax) ** 2 + (gy - ay) ** 2).astype(np.float64)
+        else:
+            da = ((gx - ax) ** 2 + (gy - ay) ** 2).astype(np.float64)
+            db = ((gx - bx) ** 2 + (gy - by) ** 2).astype(np.float64)
+            dl = (cr.astype(np.float64) ** 2) / float(L)
+            d2 = np.where(t <= 0, da, np.where(t >= L, db, dl))
+        near |= d2 < r2
+    inside = (wind != 0) | near
+    ys, xs = np.nonzero(inside)
+    return xs + x0, ys + y0

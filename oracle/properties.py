@@ -1,0 +1,162 @@
+"""calculate_properties / transform_polygons restated on numpy arrays (TEST INFRASTRUCTURE).
+
+Follows wavebreaking/utils/index_utils.py:35-184.  GEOS-dependent pieces
+(buffer+contains, seam split) are **parity unpinned** -- see oracle/geom.py.
+"""
+import numpy as np
+
+from . import geom
+
+
+def area_weights(lat, dlon, dlat):
+    """index_utils.py:58-62"""
+    area_cell = np.round(6371 * 2 * np.pi / (360 / ((dlon + dlat) / 2))) ** 2
+    return np.cos(np.radians(np.asarray(lat, dtype=np.float64))) * area_cell
+
+
+def event_cells(polygon, dlon, dlat, width, nlat):
+    """index_utils.py:37-51: lattice points contained in polygon.buffer((dlon+dlat)/4)."""
+    return geom.polygon_cells(polygon, ((dlon + dlat) / 2) / 2, width, nlat)
+
+
+def event_sums(xs, ys, t, data, intensity, weight_lat, nlon):
+    """index_utils.py:63-102 for one event.
+
+    ``areas``, ``x_com``, ``y_com`` use the canonical row order shared with the HIP path
+    (per-row exact integer counts, rows ascending, one rounding per multiply and per add)
+    because ``com`` truncates their ratio (:105-110) and is compared bit-exactly;
+    ``mean_var`` / ``intensity`` are compared to 1e-6 relative and may be summed in any order."""
+    areas = 0.0
+    x_com = 0.0
+    y_com = 0.0
+    mean_var = 0.0
+    inten = 0.0
+    for y in np.unique(ys):
+        m = ys == y
+        w = float(weight_lat[y])
+        n = int(np.count_nonzero(m))
+        sx = int(xs[m].sum())
+        areas = areas + w * float(n)
+        x_com = x_com + w * float(sx)
+        y_com = y_com + w * float(int(y) * n)
+        mean_var += w * float(np.sum(data[t, y, xs[m] % nlon].astype(np.float64)))
+        if intensity is not None:
+            inten += w * float(np.sum(intensity[t, y, xs[m] % nlon].astype(np.float64)))
+    return areas, mean_var, inten, x_com, y_com
+
+
+def calculate_properties(events, data, intensity, lat, lon, periodic_add):
+    """Rows with the reference's property columns, plus the raw sums (``_sums``) and the
+    cell list (``_cells``) for parity checks."""
+    lat = np.asarray(lat, dtype=np.float64)
+    lon = np.asarray(lon, dtype=np.float64)
+    nlon, nlat = len(lon), len(lat)
+    dlon = abs(np.unique(np.diff(lon)))[0]
+    dlat = abs(np.unique(np.diff(lat)))[0]
+    width = nlon + int(periodic_add / dlon)
+    w = area_weights(lat, dlon, dlat)
+    out = []
+    for ev in events:
+        xs, ys = event_cells(ev["polygon"], dlon, dlat, width, nlat)
+        areas, mv, it, xc, yc = event_sums(xs, ys, ev["_t"], data, intensity, w, nlon)
+        com = (lon[int(xc / areas) % nlon], lat[int(yc / areas)])                      # :105-111
+        row = dict(date=ev["date"], level=ev["level"], com=com,
+                   mean_var=np.round(mv / areas, 2), intensity=np.round(it / areas, 2),
+                   event_area=np.round(areas, 2))                                      # :113-120
+        if "orientation" in ev:
+            row["orientation"] = ev["orientation"]
+        row["_sums"] = (areas, mv, it, xc, yc)
+        row["_cells"] = (xs, ys)
+        row["_t"] = ev["_t"]
+        out.append(row)
+    return out
+
+
+# --------------------------------------------------------------------------- transform_polygons
+
+def _clip_halfplane(ring, L, keep_le):
+    """Pieces of the closed ring (n,2 float) on one side of the vertical line x = L
+    (closed half-plane).  Proper multi-piece split: boundary chains on the kept side are
+    re-connected along the line by pairing the line points sorted by y."""
+    v = np.asarray(ring, dtype=np.float64)
+    n = len(v)
+
+    def inside(p):
+        return p[0] <= L if keep_le else p[0] >= L
+
+    ins = [inside(p) for p in v]
+    if all(ins):
+        return [v]
+    if not any(ins):
+        return []
+    # rotate so that we start on an outside vertex
+    s = ins.index(False)
+    order = [(s + k) % n for k in range(n)]
+    chains = []
+    cur = None
+    for k in range(n):
+        a, b = v[order[k]], v[order[(k + 1) % n]]
+        ia, ib = ins[order[k]], ins[order[(k + 1) % n]]
+        if not ia and ib:                      # entering
+            t = (L - a[0]) / (b[0] - a[0])
+            cur = [np.array([L, a[1] + t * (b[1] - a[1])]), b.copy()]
+        elif ia and ib:
+            cur.append(b.copy())
+        elif ia and not ib:                    # leaving
+            t = (L - a[0]) / (b[0] - a[0])
+            cur.append(np.array([L, a[1] + t * (b[1] - a[1])]))
+            chains.append(cur)
+            cur = None
+    # pair the line points by y
+    pts = []
+    for ci, ch in enumerate(chains):
+        pts.append((ch[0][1], 0, ci))          # entry
+        pts.append((ch[-1][1], 1, ci))         # exit
+    pts.sort(key=lambda p: (p[0], p[1]))
+    partner = {}
+    for k in range(0, len(pts) - 1, 2):
+        partner[(pts[k][1], pts[k][2])] = (pts[k + 1][1], pts[k + 1][2])
+        partner[(pts[k + 1][1], pts[k + 1][2])] = (pts[k][1], pts[k][2])
+    used = [False] * len(chains)
+    pieces = []
+    for c0 in range(len(chains)):
+        if used[c0]:
+            continue
+        piece = []
+        c = c0
+        guard = 0
+        while not used[c] and guard <= len(chains):
+            used[c] = True
+            piece.extend(chains[c])
+            kind, nxt = partner.get((1, c), (0, c))
+            c = nxt
+            guard += 1
+        piece = np.asarray(piece)
+        if len(piece) >= 3 and abs(ring_area(piece)) > 0:
+            pieces.append(piece)
+    return pieces
+
+
+def ring_area(r):
+    r = np.asarray(r, dtype=np.float64)
+    x, y = r[:, 0], r[:, 1]
+    return 0.5 * float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))
+
+
+def transform_polygon(polygon, lat, lon):
+    """index_utils.py:129-173 for one event: list of rings in (lon, lat) coordinates
+    (one ring = Polygon, several = MultiPolygon, none = empty Polygon)."""
+    lat = np.asarray(lat, dtype=np.float64)
+    lon = np.asarray(lon, dtype=np.float64)
+    nlon = len(lon)
+    coords = np.asarray(polygon).astype("int")
+
+    def to_lonlat(c):
+        c = np.asarray(c).astype("int")                                    # :135 (truncation)
+        return np.c_[lon[c[:, 0] % nlon], lat[c[:, 1]]]                     # :139-146
+
+    if not (coords[:, 0] >= nlon).any():                                    # :136
+        return [to_lonlat(coords)]
+    # :148-173: drop the strip nlon-1 < x < nlon, keep what is left on either side
+    pieces = _clip_halfplane(coords, nlon - 1, True) + _clip_halfplane(coords, nlon, False)
+    return [to_lonlat(p) for p in pieces]

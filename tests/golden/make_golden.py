@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Generate the golden vectors that pin the oracle to the third-party libraries
+the reference calls.  Fixtures are DATA (inputs + expected outputs); this script
+is how they were made.  Nothing from /root/reference is imported or copied.
+
+Run in the build container (the two interpreters hold different libraries):
+
+    /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py skimage   # scikit-image 0.18.3
+    python3 tests/golden/make_golden.py sklearn                             # scikit-learn 1.7.2
+    python3 tests/golden/make_golden.py pandas                              # pandas 2.3.3
+
+Outputs: tests/golden/contours_cases.npz, contours_random.npz, haversine.npz,
+pandas_rules.npz (all < 200 KB).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _pack(list_of_arrays):
+    """ragged list of (n,2) arrays -> (concatenated, offsets)."""
+    off = np.zeros(len(list_of_arrays) + 1, dtype=np.int64)
+    for i, a in enumerate(list_of_arrays):
+        off[i + 1] = off[i] + len(a)
+    cat = np.concatenate(list_of_arrays, axis=0) if list_of_arrays else np.zeros((0, 2))
+    return cat, off
+
+
+def _smooth(rng, shape, passes):
+    a = rng.standard_normal(shape)
+    for _ in range(passes):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5.0
+    return a
+
+
+def fields():
+    """Named small fields covering the nasty cases of SURVEY.md section 7 step 1."""
+    rng = np.random.RandomState(12345)
+    out = {}
+    # 1. random smoothed fields of several shapes (closed loops, edge-cut loops, saddles)
+    for n, (shape, passes) in enumerate([((12, 17), 1), ((14, 23), 2), ((33, 40), 3), ((24, 64), 2),
+                                         ((40, 96), 4), ((9, 9), 0), ((20, 31), 1), ((64, 48), 5)]):
+        out["smooth%d" % n] = (_smooth(rng, shape, passes).astype(np.float32).astype(np.float64), 0.0)
+    # 2. NaN border rows as calculate_smoothed_field leaves them (spatial.py:106-107) + NaN cells inside
+    a = _smooth(rng, (30, 44), 2)
+    a[[0, 1, -2, -1], :] = np.nan
+    out["nanrows"] = (a, 0.05)
+    a = _smooth(rng, (26, 37), 1)
+    a[rng.randint(0, 26, 12), rng.randint(0, 37, 12)] = np.nan
+    out["nancells"] = (a, -0.02)
+    # 3. checkerboard: every interior square is a saddle (cases 6 / 9)
+    yy, xx = np.mgrid[0:10, 0:13]
+    out["checker"] = (((yy + xx) % 2).astype(np.float64) + 0.25 * rng.rand(10, 13), 0.6)
+    # 4. periodic extension exactly as contour_index.py:94-100 does it (jet + cutoffs; pad = 1/3 of nlon)
+    lat = np.linspace(-60, 60, 41)[:, None]
+    lon = np.linspace(0, 360, 48, endpoint=False)[None, :]
+    jet = lat + 14 * np.sin(np.radians(3 * lon)) + 9 * np.cos(np.radians(5 * lon + 40)) - 10
+    bump = 25 * np.exp(-(((lat - 35) / 6.0) ** 2 + ((lon - 20) / 9.0) ** 2))
+    hole = -25 * np.exp(-(((lat + 30) / 5.0) ** 2 + ((lon - 340) / 8.0) ** 2))
+    base = (jet - bump - hole).astype(np.float32).astype(np.float64)
+    out["periodic"] = (np.concatenate([base, base[:, :16]], axis=1), 2.0)
+    # 5. float32-valued folded field with steep gradients (f32 -> f64 cast path)
+    a = (8 * np.tanh(_smooth(rng, (36, 50), 2) * 6)).astype(np.float32).astype(np.float64)
+    out["steep"] = (a, 2.0)
+    # 6. 2x2 and thin shapes
+    out["tiny"] = (np.array([[1.0, 4.0], [1.0, 1.0]]), 2.0)
+    out["thin_row"] = (_smooth(rng, (2, 29), 0), 0.1)
+    out["thin_col"] = (_smooth(rng, (31, 2), 0), -0.1)
+    # 7. all below / all above (no contours)
+    out["empty"] = (np.zeros((7, 8)), 1.0)
+    return out
+
+
+def make_skimage():
+    from skimage.measure import find_contours
+    from skimage.measure._find_contours_cy import _get_contour_segments
+    import skimage
+
+    # (a) the 16 binary squares: case table
+    seg_from, seg_to, seg_case = [], [], []
+    for case in range(16):
+        a = np.array([[case & 1, (case >> 1) & 1], [(case >> 2) & 1, (case >> 3) & 1]], dtype=float)
+        for f, t in _get_contour_segments(a, 0.5, False, mask=None):
+            seg_case.append(case)
+            seg_from.append(f)
+            seg_to.append(t)
+    np.savez_compressed(os.path.join(HERE, "contours_cases.npz"), case=np.array(seg_case),
+                        p_from=np.array(seg_from), p_to=np.array(seg_to),
+                        skimage_version=np.array(skimage.__version__))
+
+    # (b) named fields: raw segment list + assembled contours
+    store = {"skimage_version": np.array(skimage.__version__)}
+    names = []
+    for name, (a, level) in fields().items():
+        names.append(name)
+        segs = _get_contour_segments(a.astype(np.double), float(level), False, mask=None)
+        sf = np.array([s[0] for s in segs]).reshape(-1, 2)
+        st = np.array([s[1] for s in segs]).reshape(-1, 2)
+        cont = find_contours(a, level)
+        cat, off = _pack([np.asarray(c) for c in cont])
+        store[name + "__field"] = a
+        store[name + "__level"] = np.array(level)
+        store[name + "__seg_from"] = sf
+        store[name + "__seg_to"] = st
+        store[name + "__pts"] = cat
+        store[name + "__off"] = off
+    store["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "contours_random.npz"), **store)
+    print("skimage goldens written:", names)
+
+
+def make_sklearn():
+    import sklearn
+    from sklearn.metrics import DistanceMetric
+
+    dist = DistanceMetric.get_metric("haversine")
+    rng = np.random.RandomState(777)
+    # lattice-like coordinates as the streamer index sees them (streamer_index.py:124-130): [lat, lon] deg
+    lat = np.round(rng.uniform(-89, 89, 60) * 4) / 4
+    lon = np.round(rng.uniform(-180, 179.75, 60) * 4) / 4
+    coords = np.c_[lat, lon]
+    geo = dist.pairwise(np.radians(coords)) * 6371
+    # a contour-like path: consecutive neighbours one lattice step apart
+    steps = rng.randint(-1, 2, size=(300, 2))
+    steps[(steps == 0).all(1)] = (1, 0)
+    path = np.cumsum(steps, axis=0) * 0.25 + np.array([40.0, -30.0])
+    gm = dist.pairwise(np.radians(path)) * 6371
+    on = np.insert(np.diagonal(gm, 1), 0, 0)                      # streamer_index.py:133
+    on_mat = np.triu(np.tile(on, (len(on), 1)), k=1)             # :134
+    cont = np.cumsum(on_mat, axis=1)                             # :135
+    np.savez_compressed(os.path.join(HERE, "haversine.npz"), coords=coords, geo=geo, path=path,
+                        path_on=on, path_geo_row0=gm[0], path_cont_rows=cont[[0, 7, 150]],
+                        sklearn_version=np.array(sklearn.__version__))
+    print("sklearn goldens written")
+
+
+def make_pandas():
+    import pandas as pd
+
+    rng = np.random.RandomState(99)
+    store = {"pandas_version": np.array(pd.__version__)}
+    # (a) streamer check_duplicates rule (streamer_index.py:160-183) on synthetic base-point frames
+    nlon = 36
+    for n in range(6):
+        m = 14
+        x1 = rng.randint(0, 10, m)
+        y1 = rng.randint(0, 4, m)
+        x2 = x1 + rng.randint(1, 6, m)
+        y2 = rng.randint(0, 4, m)
+        # append periodic twins of a random subset (exactly one twin each)
+        tw = rng.choice(m, 5, replace=False)
+        df = pd.DataFrame({"x1": np.r_[x1, x1[tw] + nlon], "y1": np.r_[y1, y1[tw]],
+                           "x2": np.r_[x2, x2[tw] + nlon], "y2": np.r_[y2, y2[tw]]})
+        df = df.drop_duplicates().sort_values(["x1", "y1", "x2", "y2"]).reset_index(drop=True)
+        # unique rows only (a frame of candidate pairs never repeats a pair)
+        temp = pd.concat([df.x1 % nlon, df.y1, df.x2 % nlon, df.y2], axis=1)
+        temp = temp[temp.duplicated(keep=False)]
+        if len(temp) == 0:
+            check = []
+        else:
+            groups = temp.groupby(list(temp)).apply(lambda x: tuple(x.index)).tolist()
+            if len({len(g) for g in groups}) != 1:
+                continue
+            check = list(np.asarray(groups)[:, 1])
+        keep = df.drop(check).index.values
+        store["dup%d__frame" % n] = df.values
+        store["dup%d__keep" % n] = keep
+    store["dup_nlon"] = np.array(nlon)
+    # (b) overturning labels (overturning_index.py:123-134)
+    for n in range(6):
+        x = np.sort(rng.randint(0, 60, 90))
+        lons, counts = np.unique(x, return_counts=True)
+        ot = pd.DataFrame({"lon": lons[counts >= 3]})
+        for rg in (5.0, 2.0):
+            ot2 = ot.copy()
+            ot2["label"] = (ot2.diff() > rg / 1.0).cumsum()
+            if len(ot2) == 0:
+                mm = np.zeros((0, 2), dtype=int)
+            else:
+                g = ot2.groupby("label").agg(["min", "max"]).astype("int").reset_index(drop=True)
+                mm = g.values
+            store["ot%d_rg%d__x" % (n, int(rg))] = x
+            store["ot%d_rg%d__minmax" % (n, int(rg))] = mm
+    # (c) numpy rounding rules the contour index relies on (contour_index.py:111,155)
+    v = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 3.4999999999999996, 2.5000000000000004, 1e-17, 7.5, 8.5])
+    store["round_in"] = v
+    store["round_out"] = np.round(v).astype("int")
+    m = np.array([12.345, 0.125, 0.375, 100.005, 45.675, 33.33333333])
+    store["round2_in"] = m
+    store["round2_out"] = np.round(m, 2)
+    np.savez_compressed(os.path.join(HERE, "pandas_rules.npz"), **store)
+    print("pandas goldens written")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else ""
+    {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas}[which]()

@@ -1,0 +1,145 @@
+"""The oracle against the golden vectors of the third-party libraries the reference calls
+(CPU only).  These tests are what makes the oracle trustworthy as the parity checker."""
+import numpy as np
+import pytest
+
+from oracle import contours as oc
+from oracle import geom, indices, marching, properties
+from tests.golden import geos_truth
+
+
+def test_case_table_matches_skimage(golden_dir):
+    g = np.load(golden_dir + "/contours_cases.npz")
+    k = 0
+    for case in range(16):
+        a = np.array([[case & 1, (case >> 1) & 1], [(case >> 2) & 1, (case >> 3) & 1]], dtype=float)
+        seg = marching.contour_segments(a, 0.5)
+        for s in range(len(seg["r"])):
+            assert g["case"][k] == case
+            assert np.array_equal(seg["p_from"][s], g["p_from"][k])
+            assert np.array_equal(seg["p_to"][s], g["p_to"][k])
+            k += 1
+    assert k == len(g["case"])
+
+
+def test_find_contours_bit_exact_vs_skimage(golden_dir):
+    g = np.load(golden_dir + "/contours_random.npz")
+    total = 0
+    for name in g["names"]:
+        a, lv = g[name + "__field"], float(g[name + "__level"])
+        seg = marching.contour_segments(a, lv)
+        assert np.array_equal(seg["p_from"].reshape(-1, 2), g[name + "__seg_from"]), name
+        assert np.array_equal(seg["p_to"].reshape(-1, 2), g[name + "__seg_to"]), name
+        cont = marching.find_contours(a, lv)
+        off, pts = g[name + "__off"], g[name + "__pts"]
+        assert len(cont) == len(off) - 1, name
+        for i, c in enumerate(cont):
+            assert np.array_equal(c, pts[off[i]:off[i + 1]]), (name, i)
+        total += len(cont)
+    assert total > 400
+
+
+def test_tiny_example_from_survey():
+    # [[1,4],[1,1]], level 2 -> ((0.6667,1) -> (0,0.3333))
+    c = marching.find_contours(np.array([[1.0, 4.0], [1.0, 1.0]]), 2.0)
+    assert len(c) == 1
+    assert np.allclose(c[0], [[2 / 3, 1.0], [0.0, 1 / 3]])
+
+
+def test_haversine_formula_vs_sklearn(golden_dir):
+    g = np.load(golden_dir + "/haversine.npz")
+    geo = indices.haversine_formula(np.radians(g["coords"])) * 6371
+    assert np.allclose(geo, g["geo"], rtol=0, atol=1e-9)
+    assert np.array_equal(np.diag(geo), np.zeros(len(geo)))
+    # along-contour distance: sequential row cumsum of `on` (streamer_index.py:133-135)
+    on = g["path_on"]
+    for row, i in zip(g["path_cont_rows"], [0, 7, 150]):
+        acc, ref = 0.0, np.zeros(len(on))
+        for j in range(i + 1, len(on)):
+            acc = acc + on[j]
+            ref[j] = acc
+        assert np.array_equal(ref, row)
+
+
+def test_streamer_duplicate_rule_vs_pandas(golden_dir):
+    g = np.load(golden_dir + "/pandas_rules.npz")
+    nlon = int(g["dup_nlon"])
+    seen = 0
+    for n in range(6):
+        if "dup%d__frame" % n not in g:
+            continue
+        fr = g["dup%d__frame" % n]
+        # build a fake contour whose vertex k is frame point k (two vertices per pair)
+        xy = np.concatenate([fr[:, 0:2], fr[:, 2:4]], axis=0)
+        ij = np.c_[np.arange(len(fr)), np.arange(len(fr)) + len(fr)]
+        kept = indices._f_duplicates(ij, xy, nlon)
+        assert np.array_equal(kept[:, 0], g["dup%d__keep" % n])
+        seen += 1
+    assert seen >= 3
+
+
+def test_overturning_labels_vs_pandas(golden_dir):
+    g = np.load(golden_dir + "/pandas_rules.npz")
+    for n in range(6):
+        for rg in (5, 2):
+            x = g["ot%d_rg%d__x" % (n, rg)]
+            assert np.array_equal(indices.overturning_groups(x, float(rg), 1.0), g["ot%d_rg%d__minmax" % (n, rg)])
+
+
+def test_rounding_rules(golden_dir):
+    g = np.load(golden_dir + "/pandas_rules.npz")
+    assert np.array_equal(np.rint(g["round_in"]).astype(int), g["round_out"])
+    xy, closed = oc.round_dedupe(np.array([[0.5, 1.5], [0.4, 2.5], [1.5, 2.5], [0.5, 1.5]]))
+    # rows round to (0,2),(0,2),(2,2),(0,2): first occurrences kept, (row,col)->(x,y)
+    assert xy.tolist() == [[2, 0], [2, 2]] and closed
+
+
+def test_combine_shared_reference_known_answer():
+    # tests/test_wavebreaking.py:101-104
+    assert indices.combine_shared([[1, 2, 3], [2, 3, 4], [5, 6]]) == [[1, 2, 3, 4], [5, 6]]
+
+
+@pytest.mark.parametrize("row", geos_truth.TOUCHES)
+def test_touches_truth_table(row):
+    contour, i, j, expect, why = row
+    c = np.array(contour)
+    assert geom.chord_touches_contour(c[i], c[j], c) is expect, why
+
+
+@pytest.mark.parametrize("row", geos_truth.INTERSECTS)
+def test_intersects_truth_table(row):
+    p1, q1, p2, q2, expect = row
+    assert geom.segments_intersect(p1, q1, p2, q2) is expect
+    assert geom.segments_intersect(p2, q2, p1, q1) is expect
+
+
+@pytest.mark.parametrize("row", geos_truth.CELLS)
+def test_buffer_contains_truth_table(row):
+    poly, r, expect = row
+    xs, ys = geom.polygon_cells(np.array(poly), r, 64, 64)
+    assert sorted(zip(xs.tolist(), ys.tolist())) == sorted(expect)
+
+
+def test_contour_periodic_duplicates_and_columns():
+    # a cutoff inside the periodic overlap appears twice; the later copy goes (contour_index.py:119-147)
+    a = np.array([[10, 5], [11, 5], [11, 6], [10, 6]])
+    items = [a, a + np.array([36, 0]), np.array([[3, 1], [4, 1], [4, 2], [3, 2], [2, 2]])]
+    assert oc.check_duplicates(items, 36) == {1}
+    # a partial copy (subset, shorter) goes whichever comes first
+    assert oc.check_duplicates([a[:3] + np.array([36, 0]), a], 36) == {0}
+
+
+def test_seam_split_areas():
+    lat = np.arange(-5.0, 6.0)
+    lon = np.arange(-18.0, 18.0) * 10.0       # nlon = 36
+    # rectangle x 34..38, y 2..4 straddles the seam: left piece 34..35, right piece 36..38 -> lon[0..2]
+    rings = properties.transform_polygon(np.array([[34, 2], [38, 2], [38, 4], [34, 4]]), lat, lon)
+    areas = sorted(abs(properties.ring_area(r)) for r in rings)
+    assert len(rings) == 2
+    assert np.allclose(areas, [10.0 * 2, 20.0 * 2])
+    # entirely right of the seam: one ring, shifted
+    rings = properties.transform_polygon(np.array([[37, 2], [39, 2], [39, 4], [37, 4]]), lat, lon)
+    assert len(rings) == 1 and rings[0][:, 0].min() == lon[1]
+    # not touching the seam: untouched
+    rings = properties.transform_polygon(np.array([[3, 2], [5, 2], [5, 4]]), lat, lon)
+    assert len(rings) == 1 and np.array_equal(rings[0][:, 0], lon[[3, 5, 5]])
