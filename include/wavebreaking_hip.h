@@ -1,0 +1,128 @@
+/* wavebreaking_hip.h -- C ABI of the MI355X-native WaveBreaking hot path.
+ *
+ * The reference (skaderli/WaveBreaking 0.3.8) is pure Python and has no FFI layer; its boundary for
+ * this path is the Python call surface
+ *
+ *     wavebreaking.calculate_contours      wavebreaking/indices/contour_index.py:45-51
+ *     wavebreaking.calculate_streamers     wavebreaking/indices/streamer_index.py:44-57
+ *     wavebreaking.calculate_overturnings  wavebreaking/indices/overturning_index.py:40-53
+ *     wavebreaking.calculate_cutoffs       wavebreaking/indices/cutoff_index.py:33-45
+ *
+ * The functions below are what a ctypes binding inside those four functions calls instead of the
+ * per-time-step Python loops (INTEGRATION.md shows the stub).  Plain pointers and sizes only; no C++
+ * or torch types.  All functions return 0 on success, non-zero on error (text via wb_last_error);
+ * nothing throws across the boundary.  A context owns one HIP stream and is single-threaded; use one
+ * context per GPU / process.
+ *
+ * Conventions: field is (time, lat, lon), C-contiguous, lat and lon ASCENDING
+ * (data_utils.py:196-213 is applied by the caller), float32 or float64; every decision is taken in
+ * float64 like skimage.measure.find_contours does (contour_index.py:103).  Lattice coordinates are
+ * int32 indices into the periodically extended grid (x in [0, nlon + int(periodic_add/dlon)),
+ * y in [0, nlat)), exactly the reference's "index coordinates" (original_coordinates=False).
+ */
+#ifndef WAVEBREAKING_HIP_H
+#define WAVEBREAKING_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wb_ctx wb_ctx;
+typedef struct wb_batch wb_batch;
+
+typedef struct wb_params {
+    int32_t nt, nlat, nlon;
+    int32_t dtype;            /* 0 = float32, 1 = float64 */
+    int32_t on_device;        /* 1: field / intensity are device pointers, 0: host pointers (copied) */
+    const void* field;        /* [nt][nlat][nlon] */
+    const void* intensity;    /* same shape and dtype, or NULL (index_utils.py:77-89) */
+    const double* lat;        /* host [nlat], degrees, ascending */
+    const double* lon;        /* host [nlon], degrees, ascending */
+    int32_t nlevels;          /* <= 4 */
+    const double* levels;     /* host [nlevels] (index_utils.py:238-258) */
+    double periodic_add;      /* degrees (contour_index.py:50) */
+    double dlon, dlat;        /* data_utils.py:129-144 */
+    double geo_dis, cont_dis;             /* streamer_index.py:51-52 */
+    double range_group, ot_min_exp;       /* overturning_index.py:47-48 */
+    double co_min_exp;                    /* cutoff_index.py:40 */
+    int32_t want_cells;       /* also return the grid cells of every event */
+    int32_t cap_seg;          /* 0 = automatic: per-(step,level) segment capacity, grown on overflow */
+    int32_t cap_pairs;        /* 0 = automatic: per-contour candidate base-point pair capacity */
+} wb_params;
+
+/* contour table: contour_index.py:158-169 in index coordinates */
+typedef struct wb_contour_table {
+    int64_t n;                /* contours */
+    const int32_t* step;      /* time index inside the batch */
+    const int32_t* level_idx;
+    const int32_t* closed;    /* contour_index.py:109 */
+    const int32_t* nux;       /* len(set(x)); exp_lon = nux * dlon (contour_index.py:154) */
+    const int64_t* sum_y;     /* mean_lat = round(sum_y / npts, 2) (contour_index.py:155) */
+    const int32_t* npts;
+    const int64_t* offset;    /* first point in x / y */
+    int64_t npoints;
+    const int32_t* x;
+    const int32_t* y;
+} wb_contour_table;
+
+enum { WB_STREAMERS = 0, WB_OVERTURNINGS = 1, WB_CUTOFFS = 2 };
+
+/* event table, one per index; rows in the reference's frame order (time, level, contour, event) */
+typedef struct wb_event_table {
+    int64_t n;
+    const int32_t* step;
+    const int32_t* level_idx;
+    const int64_t* contour;   /* row of the contour table the event was cut from */
+    const int32_t* ind1;      /* streamers: polygon = contour[ind1 .. ind2] (streamer_index.py:269-272) */
+    const int32_t* ind2;      /* cutoffs: 0 .. npts-1 (cutoff_index.py:96) */
+    const int32_t* box;       /* [n][4] overturnings: min_lon, min_lat, max_lon, max_lat (overturning_index.py:210-213) */
+    const int32_t* orientation; /* overturnings: 0 cyclonic, 1 anticyclonic (overturning_index.py:199-202) */
+    const double* sums;       /* [n][5]: sum(areas), sum(areas*data), sum(areas*intensity), sum(areas*x), sum(areas*y)
+                                 (index_utils.py:94-102); com / mean_var / intensity / event_area follow on the host */
+    const int32_t* ncells;
+    const int64_t* cell_offset; /* into cell_x / cell_y, or NULL when want_cells == 0 */
+    const int32_t* cell_x;
+    const int32_t* cell_y;
+} wb_event_table;
+
+#define WB_STATUS_OVERFLOW_SEG 1u
+#define WB_STATUS_LEVEL_HIT 2u     /* a cell equals a level exactly: edge linking != skimage's coordinate joins */
+#define WB_STATUS_HAS_NAN 4u
+#define WB_STATUS_HASH_FULL 8u
+#define WB_STATUS_OVERFLOW_PAIRS 16u
+
+int wb_create(int device_id, wb_ctx** ctx);
+void wb_destroy(wb_ctx* ctx);
+const char* wb_last_error(wb_ctx* ctx);
+const char* wb_backend(void);                       /* "hip" for the product library */
+
+/* phase 1: contours of every (time step, level) of the batch (contour_index.py:87-156) */
+int wb_contours(wb_ctx* ctx, const wb_params* p, wb_batch** batch);
+int wb_batch_max_nux(wb_batch* b);                  /* local max of len(set(x)); all-reduce(max) it across ranks */
+/* phase 2: indices.  global_max_nux plays contours.exp_lon.max() (streamer_index.py:106);
+   which = bit mask 1 streamers | 2 overturnings | 4 cutoffs */
+int wb_indices(wb_batch* b, int global_max_nux, int which);
+
+int wb_get_contours(wb_batch* b, wb_contour_table* out);
+int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
+int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */
+int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont);            /* threshold guard-band re-evaluations */
+/* per-stage device times of the last wb_contours / wb_indices calls, measured with HIP events on the
+   context's stream: names is a NUL-separated list */
+int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);
+void wb_free_batch(wb_batch* b);
+
+/* device memory + synthetic ERA5-shaped PV for the benchmark */
+void* wb_dev_alloc(wb_ctx* ctx, uint64_t bytes);
+void wb_dev_free(wb_ctx* ctx, void* p);
+int wb_memcpy_h2d(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int wb_memcpy_d2h(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, int nlat, int nlon,
+                  const double* lat, const double* lon, const double* wave_params /* [7][5] */, double eps,
+                  uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

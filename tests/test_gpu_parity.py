@@ -1,0 +1,94 @@
+"""GPU: the HIP path through the C ABI against the oracle (bit-exact contours, event end points, cells;
+1e-6 relative on the data sums) + size-independent properties at BASELINE.json's full grid size."""
+import numpy as np
+import pytest
+
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    lib = _hip.Library()
+    assert lib.backend == "hip"
+    c = _hip.Context(0, lib)
+    yield c
+    c.close()
+
+
+def test_full_parity_1deg(ctx):
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(10, 6, lat, lon, eps=0.3)
+    inten = synth.pv_field(10, 6, lat, lon, eps=0.0, seed=20241)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(6), [-2, 2], intensity=inten)
+    assert len(ref["streamers"]) > 10 and got["band"] == (0, 0) and not got["status"].any()
+
+
+def test_demo_shaped_config0(ctx):
+    lat, lon = synth.grid(1.0, lat_min=-89.0, lat_max=89.0)
+    pv = synth.pv_field(0, 1, lat, lon, eps=0.1)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2], intensity=pv)
+
+
+def test_nan_rows_f64_three_levels(ctx):
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(3, 3, lat, lon, eps=0.2).astype(np.float64)
+    pv[:, [0, 1, -2, -1], :] = np.nan
+    pv[1, 30:33, 20:26] = np.nan
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(3), [2, -2, 1.5])
+    assert (got["status"] & _hip.STATUS_HAS_NAN).all()
+
+
+@pytest.mark.parametrize("padd", [0, 57, 360])
+def test_periodic_add_variants(ctx, padd):
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(5, 2, lat, lon, eps=0.3)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2], periodic_add=padd)
+
+
+def test_quarter_degree_parity(ctx):
+    # BASELINE.json configs[2] grid (1440 x 721), both levels, all three indices; 2 steps keep the oracle in seconds
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(7, 2, lat, lon, eps=0.3)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [-2, 2], intensity=pv)
+    assert max(len(c["geometry"]) for c in ref["contours"]) > 2000
+
+
+def test_capacity_retry_paths(ctx):
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(2, 2, lat, lon, eps=0.3)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [-2, 2], cap_seg=1024, cap_pairs=16)
+
+
+def test_device_generator_and_batch_invariance(ctx):
+    """Full-size property: a time step's events do not depend on what else is in the batch, and the
+    device generator's field gives the same catalogue as the oracle run on the copied-back field."""
+    lat, lon = synth.grid(0.25)
+    nt = 24
+    nbytes = nt * lat.size * lon.size * 4
+    d = ctx.alloc(nbytes)
+    ctx.synth_fill(d, np.float32, 100, nt, lat, lon, synth.wave_params(), 0.3, synth.SEED)
+    b = ctx.contours(d, lat, lon, [-2, 2], 0.25, 0.25, device_shape=(nt, lat.size, lon.size), device_dtype=np.float32,
+                     want_cells=False)
+    b.indices()
+    big = {k: b.events(i) for k, i in (("s", 0), ("o", 1), ("c", 2))}
+    bigc = b.contour_table()
+    assert not (b.status() & ~np.uint32(_hip.STATUS_HAS_NAN)).any()
+    b.close()
+    # steps 5 and 17 alone, from the copied-back field, through the ABI and through the oracle
+    for t in (5, 17):
+        host = ctx.to_host(d, (1, lat.size, lon.size), np.float32, offset_bytes=t * lat.size * lon.size * 4)
+        synth.assert_no_level_hits(host, [-2, 2])
+        got, ref = helpers.full_parity(ctx, host, lat, lon, synth.times(1), [-2, 2], want_cells=False)
+        for key, kind in (("s", "streamers"), ("o", "overturnings"), ("c", "cutoffs")):
+            m = big[key]["step"] == t
+            assert m.sum() == got[kind]["step"].size
+            assert np.array_equal(big[key]["sums"][m], got[kind]["sums"])
+            assert np.array_equal(big[key]["ind1"][m], got[kind]["ind1"])
+            assert np.array_equal(big[key]["box"][m], got[kind]["box"])
+        m = bigc["step"] == t
+        assert np.array_equal(bigc["npts"][m], got["contours"]["npts"])
+    ctx.free(d)

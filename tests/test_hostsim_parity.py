@@ -1,0 +1,105 @@
+"""CPU: the kernel sources compiled for the host (-DWB_HOSTSIM, test infrastructure) driven through the
+same C ABI and ctypes binding as the product, against the oracle.  Catches logic errors in the kernels,
+the ABI marshalling and the retry paths without a GPU; WB_PFOR iteration order is also reversed to expose
+order dependence (= races) inside a phase."""
+import numpy as np
+import pytest
+
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+
+
+@pytest.fixture(scope="module")
+def sim():
+    lib = helpers.hostsim_library()
+    assert lib.backend == "hostsim"
+    ctx = _hip.Context(0, lib)
+    yield lib, ctx
+    lib.lib.wb_hostsim_set_reverse(0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_full_parity_1deg_two_levels(sim, reverse):
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(reverse)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(10, 3, lat, lon, eps=0.3)
+    inten = synth.pv_field(10, 3, lat, lon, eps=0.0, seed=20241)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(3), [-2, 2], intensity=inten)
+    assert len(ref["streamers"]) > 5 and len(ref["overturnings"]) > 5 and len(ref["cutoffs"]) > 5
+    assert got["band"] == (0, 0) and not got["status"].any()
+
+
+def test_demo_shaped_config0(sim):
+    # BASELINE.json configs[0]: demo-data shape 360 x 179 (lat -89..89), one step, level 2, all three indices
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(0)
+    lat, lon = synth.grid(1.0, lat_min=-89.0, lat_max=89.0)
+    assert lat.size == 179 and lon.size == 360
+    pv = synth.pv_field(0, 1, lat, lon, eps=0.1)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2], intensity=pv)
+
+
+def test_nan_rows_f64_and_three_levels(sim):
+    lib, ctx = sim
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(3, 2, lat, lon, eps=0.2).astype(np.float64)
+    pv[:, [0, 1, -2, -1], :] = np.nan          # calculate_smoothed_field leaves NaN border rows (spatial.py:106-107)
+    pv[1, 30:33, 20:26] = np.nan
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2, -2, 1.5])
+    assert (got["status"] & _hip.STATUS_HAS_NAN).all()
+
+
+@pytest.mark.parametrize("padd", [0, 57, 360])
+def test_periodic_add_variants(sim, padd):
+    lib, ctx = sim
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(5, 2, lat, lon, eps=0.3)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2], periodic_add=padd)
+
+
+def test_quarter_degree_one_step(sim):
+    lib, ctx = sim
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(7, 1, lat, lon, eps=0.3)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2], intensity=pv)
+    assert max(len(c["geometry"]) for c in ref["contours"]) > 2000
+
+
+def test_capacity_retry_paths(sim):
+    # tiny capacities force the segment- and pair-overflow retries; results must not change
+    lib, ctx = sim
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(2, 2, lat, lon, eps=0.3)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [-2, 2], cap_seg=1024, cap_pairs=16)
+
+
+def test_level_hit_is_flagged(sim):
+    lib, ctx = sim
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(0, 1, lat, lon, eps=0.0)
+    pv[0, 50, 10] = 2.0
+    got = helpers.run_abi(ctx, pv, lat, lon, [2.0])
+    assert got["status"][0] & _hip.STATUS_LEVEL_HIT
+
+
+def test_empty_field_gives_empty_tables(sim):
+    lib, ctx = sim
+    lat, lon = synth.grid(2.5)
+    pv = np.zeros((2, lat.size, lon.size), dtype=np.float32)
+    got = helpers.run_abi(ctx, pv, lat, lon, [2.0])
+    assert got["contours"]["step"].size == 0
+    for k in ("streamers", "overturnings", "cutoffs"):
+        assert got[k]["step"].size == 0
+
+
+def test_bad_arguments_fail_loudly(sim):
+    lib, ctx = sim
+    lat, lon = synth.grid(2.5)
+    pv = np.zeros((1, lat.size, lon.size), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        ctx.contours(pv, lat, lon, [1, 2, 3, 4, 5], 2.5, 2.5)          # more than 4 levels
+    with pytest.raises(RuntimeError):
+        ctx.contours(pv, lat, lon, [2], 2.5, 2.5, periodic_add=400)   # > 360 degrees

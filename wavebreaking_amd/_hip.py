@@ -1,0 +1,286 @@
+"""ctypes binding of the C ABI in include/wavebreaking_hip.h.
+
+The product library is ``wavebreaking_amd/csrc/libwb_hip.so`` (hipcc, gfx950).  There is no CPU
+fallback: if the library is missing or reports a backend other than "hip" this module raises.
+(The test suite drives the same binding class against the host-simulation build of the same
+sources by passing an explicit path and ``allow_hostsim=True``; nothing in the package does.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwb_hip.so")
+
+
+class WbParams(C.Structure):
+    _fields_ = [
+        ("nt", C.c_int32), ("nlat", C.c_int32), ("nlon", C.c_int32), ("dtype", C.c_int32), ("on_device", C.c_int32),
+        ("field", C.c_void_p), ("intensity", C.c_void_p), ("lat", C.POINTER(C.c_double)), ("lon", C.POINTER(C.c_double)),
+        ("nlevels", C.c_int32), ("levels", C.POINTER(C.c_double)),
+        ("periodic_add", C.c_double), ("dlon", C.c_double), ("dlat", C.c_double),
+        ("geo_dis", C.c_double), ("cont_dis", C.c_double), ("range_group", C.c_double), ("ot_min_exp", C.c_double),
+        ("co_min_exp", C.c_double), ("want_cells", C.c_int32), ("cap_seg", C.c_int32), ("cap_pairs", C.c_int32),
+    ]
+
+
+class WbContourTable(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("step", C.POINTER(C.c_int32)), ("level_idx", C.POINTER(C.c_int32)),
+        ("closed", C.POINTER(C.c_int32)), ("nux", C.POINTER(C.c_int32)), ("sum_y", C.POINTER(C.c_int64)),
+        ("npts", C.POINTER(C.c_int32)), ("offset", C.POINTER(C.c_int64)), ("npoints", C.c_int64),
+        ("x", C.POINTER(C.c_int32)), ("y", C.POINTER(C.c_int32)),
+    ]
+
+
+class WbEventTable(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("step", C.POINTER(C.c_int32)), ("level_idx", C.POINTER(C.c_int32)),
+        ("contour", C.POINTER(C.c_int64)), ("ind1", C.POINTER(C.c_int32)), ("ind2", C.POINTER(C.c_int32)),
+        ("box", C.POINTER(C.c_int32)), ("orientation", C.POINTER(C.c_int32)), ("sums", C.POINTER(C.c_double)),
+        ("ncells", C.POINTER(C.c_int32)), ("cell_offset", C.POINTER(C.c_int64)),
+        ("cell_x", C.POINTER(C.c_int32)), ("cell_y", C.POINTER(C.c_int32)),
+    ]
+
+
+STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
+STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS = 1, 2, 4, 8, 16
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
+
+
+class Library:
+    """One loaded copy of the C ABI."""
+
+    def __init__(self, path=None, allow_hostsim=False):
+        path = LIB_PATH if path is None else path
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "wavebreaking_amd: HIP library %s not found -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.lib = lib = C.CDLL(path)
+        lib.wb_backend.restype = C.c_char_p
+        self.backend = lib.wb_backend().decode()
+        if self.backend != "hip" and not allow_hostsim:
+            raise RuntimeError("wavebreaking_amd: %s is a %r build, refusing to use it as the product path" % (path, self.backend))
+        lib.wb_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.wb_destroy.argtypes = [C.c_void_p]
+        lib.wb_last_error.argtypes = [C.c_void_p]
+        lib.wb_last_error.restype = C.c_char_p
+        lib.wb_contours.argtypes = [C.c_void_p, C.POINTER(WbParams), C.POINTER(C.c_void_p)]
+        lib.wb_batch_max_nux.argtypes = [C.c_void_p]
+        lib.wb_indices.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
+        lib.wb_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbEventTable)]
+        lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
+        lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.wb_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
+        lib.wb_free_batch.argtypes = [C.c_void_p]
+        lib.wb_dev_alloc.argtypes = [C.c_void_p, C.c_uint64]
+        lib.wb_dev_alloc.restype = C.c_void_p
+        lib.wb_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.wb_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        lib.wb_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        lib.wb_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                      C.c_uint64]
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+class Context:
+    """wb_ctx: one HIP stream on one device."""
+
+    def __init__(self, device=0, library=None):
+        self.L = default_library() if library is None else library
+        h = C.c_void_p()
+        if self.L.lib.wb_create(int(device), C.byref(h)) != 0:
+            raise RuntimeError("wavebreaking_amd: wb_create(device=%d) failed -- no usable MI355X visible" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.lib.wb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return self.L.lib.wb_last_error(self.h).decode()
+
+    # -- device memory helpers (bench / tests)
+    def alloc(self, nbytes):
+        p = self.L.lib.wb_dev_alloc(self.h, int(nbytes))
+        if not p:
+            raise MemoryError("wb_dev_alloc(%d) failed: %s" % (nbytes, self.error()))
+        return p
+
+    def free(self, p):
+        self.L.lib.wb_dev_free(self.h, C.c_void_p(p))
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        if self.L.lib.wb_memcpy_h2d(self.h, C.c_void_p(p), arr.ctypes.data_as(C.c_void_p), arr.nbytes) != 0:
+            raise RuntimeError("h2d failed")
+        return p
+
+    def to_host(self, p, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        if self.L.lib.wb_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(p + offset_bytes), out.nbytes) != 0:
+            raise RuntimeError("d2h failed")
+        return out
+
+    def synth_fill(self, dev_ptr, dtype, t0, nt, lat, lon, wave_params, eps, seed):
+        lat = np.ascontiguousarray(lat, dtype=np.float64)
+        lon = np.ascontiguousarray(lon, dtype=np.float64)
+        wp = np.ascontiguousarray(wave_params, dtype=np.float64)
+        assert wp.shape == (7, 5)
+        dp = C.POINTER(C.c_double)
+        rc = self.L.lib.wb_synth_fill(self.h, C.c_void_p(dev_ptr), 0 if np.dtype(dtype) == np.float32 else 1, int(t0),
+                                      int(nt), lat.size, lon.size, lat.ctypes.data_as(dp), lon.ctypes.data_as(dp),
+                                      wp.ctypes.data_as(dp), float(eps), int(seed))
+        if rc != 0:
+            raise RuntimeError("wb_synth_fill failed: " + self.error())
+
+    # -- the hot path
+    def contours(self, field, lat, lon, levels, dlon, dlat, periodic_add=120.0, intensity=None, geo_dis=800.0,
+                 cont_dis=1500.0, range_group=5.0, ot_min_exp=5.0, co_min_exp=5.0, want_cells=False,
+                 device_shape=None, device_dtype=None, cap_seg=0, cap_pairs=0):
+        """Phase 1.  ``field`` is a numpy array (time, lat, lon) or, with ``device_shape``/``device_dtype``,
+        an integer device pointer.  Returns a Batch."""
+        keep = []
+        p = WbParams()
+        if device_shape is not None:
+            nt, nlat, nlon = device_shape
+            dt = np.dtype(device_dtype)
+            p.on_device = 1
+            p.field = C.c_void_p(int(field))
+            p.intensity = C.c_void_p(int(intensity)) if intensity is not None else None
+        else:
+            field = np.ascontiguousarray(field)
+            if field.dtype not in (np.float32, np.float64):
+                field = field.astype(np.float64)
+            dt = field.dtype
+            nt, nlat, nlon = field.shape
+            keep.append(field)
+            p.on_device = 0
+            p.field = field.ctypes.data_as(C.c_void_p)
+            if intensity is not None:
+                intensity = np.ascontiguousarray(intensity, dtype=dt)
+                assert intensity.shape == field.shape
+                keep.append(intensity)
+                p.intensity = intensity.ctypes.data_as(C.c_void_p)
+        lat = np.ascontiguousarray(lat, dtype=np.float64)
+        lon = np.ascontiguousarray(lon, dtype=np.float64)
+        lev = np.ascontiguousarray(levels, dtype=np.float64)
+        assert lat.size == nlat and lon.size == nlon
+        dp = C.POINTER(C.c_double)
+        p.nt, p.nlat, p.nlon = int(nt), int(nlat), int(nlon)
+        p.dtype = 0 if dt == np.float32 else 1
+        p.lat, p.lon, p.levels = lat.ctypes.data_as(dp), lon.ctypes.data_as(dp), lev.ctypes.data_as(dp)
+        p.nlevels = lev.size
+        p.periodic_add, p.dlon, p.dlat = float(periodic_add), float(dlon), float(dlat)
+        p.geo_dis, p.cont_dis = float(geo_dis), float(cont_dis)
+        p.range_group, p.ot_min_exp, p.co_min_exp = float(range_group), float(ot_min_exp), float(co_min_exp)
+        p.want_cells = 1 if want_cells else 0
+        p.cap_seg, p.cap_pairs = int(cap_seg), int(cap_pairs)
+        h = C.c_void_p()
+        if self.L.lib.wb_contours(self.h, C.byref(p), C.byref(h)) != 0:
+            raise RuntimeError("wb_contours failed: " + self.error())
+        return Batch(self, h, int(nt), lev.size, want_cells)
+
+
+class Batch:
+    """wb_batch: the contours of one resident batch of time steps, then its index events."""
+
+    def __init__(self, ctx, h, nt, nlev, want_cells):
+        self.ctx, self.h, self.nt, self.nlev, self.want_cells = ctx, h, nt, nlev, want_cells
+
+    def close(self):
+        if self.h:
+            self.ctx.L.lib.wb_free_batch(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def max_nux(self):
+        return int(self.ctx.L.lib.wb_batch_max_nux(self.h))
+
+    def indices(self, global_max_nux=None, streamers=True, overturnings=True, cutoffs=True):
+        g = self.max_nux() if global_max_nux is None else int(global_max_nux)
+        which = (1 if streamers else 0) | (2 if overturnings else 0) | (4 if cutoffs else 0)
+        if self.ctx.L.lib.wb_indices(self.h, g, which) != 0:
+            raise RuntimeError("wb_indices failed: " + self.ctx.error())
+
+    def contour_table(self):
+        t = WbContourTable()
+        if self.ctx.L.lib.wb_get_contours(self.h, C.byref(t)) != 0:
+            raise RuntimeError("wb_get_contours failed: " + self.ctx.error())
+        n, m = t.n, t.npoints
+        return dict(step=_arr(t.step, n, np.int32), level_idx=_arr(t.level_idx, n, np.int32),
+                    closed=_arr(t.closed, n, np.int32).astype(bool), nux=_arr(t.nux, n, np.int32),
+                    sum_y=_arr(t.sum_y, n, np.int64), npts=_arr(t.npts, n, np.int32), offset=_arr(t.offset, n, np.int64),
+                    x=_arr(t.x, m, np.int32), y=_arr(t.y, m, np.int32))
+
+    def events(self, kind):
+        t = WbEventTable()
+        if self.ctx.L.lib.wb_get_events(self.h, int(kind), C.byref(t)) != 0:
+            raise RuntimeError("wb_get_events failed: " + self.ctx.error())
+        n = t.n
+        out = dict(step=_arr(t.step, n, np.int32), level_idx=_arr(t.level_idx, n, np.int32),
+                   contour=_arr(t.contour, n, np.int64), ind1=_arr(t.ind1, n, np.int32), ind2=_arr(t.ind2, n, np.int32),
+                   box=_arr(t.box, 4 * n, np.int32).reshape(-1, 4), orientation=_arr(t.orientation, n, np.int32),
+                   sums=_arr(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=_arr(t.ncells, n, np.int32))
+        if self.want_cells and t.cell_offset:
+            off = _arr(t.cell_offset, n + 1, np.int64)
+            out["cell_offset"] = off
+            out["cell_x"] = _arr(t.cell_x, off[-1] if n else 0, np.int32)
+            out["cell_y"] = _arr(t.cell_y, off[-1] if n else 0, np.int32)
+        return out
+
+    def status(self):
+        p = C.POINTER(C.c_uint32)()
+        n = C.c_int64()
+        self.ctx.L.lib.wb_get_status(self.h, C.byref(p), C.byref(n))
+        return _arr(p, n.value, np.uint32)
+
+    def band_hits(self):
+        g, c = C.c_int64(), C.c_int64()
+        self.ctx.L.lib.wb_get_band_hits(self.h, C.byref(g), C.byref(c))
+        return int(g.value), int(c.value)
+
+    def timings(self):
+        names = C.c_char_p()
+        ms = C.POINTER(C.c_float)()
+        n = C.c_int()
+        self.ctx.L.lib.wb_get_timings(self.h, C.byref(names), C.byref(ms), C.byref(n))
+        out = []
+        addr = C.cast(names, C.c_void_p).value
+        for i in range(n.value):
+            s = C.string_at(addr)
+            addr += len(s) + 1
+            out.append((s.decode(), float(ms[i])))
+        return out

@@ -1,0 +1,906 @@
+// wb_api.hip -- the C ABI (include/wavebreaking_hip.h): buffer management, kernel sequencing, result
+// marshalling.  Compiled by hipcc for gfx950 into libwb_hip.so (the product) and, with -DWB_HOSTSIM
+// by g++, into tests/_hostsim/libwb_hostsim.so (test infrastructure: same sources, kernels executed
+// block by block on the host under ASan/UBSan; never loaded by the package).
+#include "../../include/wavebreaking_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "wb_core.h"
+#include "wb_indices.h"
+#include "wb_props.h"
+#include "wb_scan.h"
+#include "wb_trace.h"
+
+#if defined(WB_HOSTSIM)
+int wb_hostsim_reverse = 0;
+extern "C" void wb_hostsim_set_reverse(int r) { wb_hostsim_reverse = r; }
+#define WB_LAUNCH(kernel, grid, block, ...)                                       \
+    do {                                                                          \
+        const int wb_g_ = (int)(grid);                                            \
+        for (int wb_b_ = 0; wb_b_ < wb_g_; ++wb_b_) kernel(wb_b_, wb_g_, __VA_ARGS__); \
+    } while (0)
+#else
+#define WB_LAUNCH(kernel, grid, block, ...) \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(block), 0, ctx->stream, __VA_ARGS__)
+#endif
+
+// ------------------------------------------------------------------------------------------------ context
+struct wb_ctx {
+    int device = 0;
+    std::string err;
+#if !defined(WB_HOSTSIM)
+    hipStream_t stream = nullptr;
+#endif
+};
+
+static int wb_fail(wb_ctx* c, const std::string& m) {
+    if (c) c->err = m;
+    return 1;
+}
+
+#if defined(WB_HOSTSIM)
+static void* dmalloc(wb_ctx*, size_t bytes) { return malloc(bytes ? bytes : 1); }
+static void dfree(wb_ctx*, void* p) { free(p); }
+static int dmemset(wb_ctx*, void* p, int v, size_t bytes) { memset(p, v, bytes); return 0; }
+static int h2d(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
+static int d2h(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
+static int dsync(wb_ctx*) { return 0; }
+#else
+static void* dmalloc(wb_ctx* c, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        c->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
+        return nullptr;
+    }
+    return p;
+}
+static void dfree(wb_ctx*, void* p) { if (p) (void)hipFree(p); }
+static int dmemset(wb_ctx* c, void* p, int v, size_t bytes) { return hipMemsetAsync(p, v, bytes, c->stream) != hipSuccess; }
+static int h2d(wb_ctx* c, void* d, const void* s, size_t b) {
+    return hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
+}
+static int d2h(wb_ctx* c, void* d, const void* s, size_t b) {
+    return hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
+}
+static int dsync(wb_ctx* c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string("HIP error: ") + hipGetErrorString(e); return 1; }
+    return 0;
+}
+#endif
+
+// stage timer: HIP events on the context's stream (host simulation: zeros)
+struct WbTimer {
+    std::vector<std::string> names;
+    std::vector<float> ms;
+#if !defined(WB_HOSTSIM)
+    std::vector<hipEvent_t> ev0, ev1;
+#endif
+    void begin(wb_ctx* c, const char* name) {
+        names.push_back(name);
+#if !defined(WB_HOSTSIM)
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        ev0.push_back(a);
+        ev1.push_back(b);
+        (void)hipEventRecord(a, c->stream);
+#else
+        (void)c;
+#endif
+    }
+    void end(wb_ctx* c) {
+#if !defined(WB_HOSTSIM)
+        (void)hipEventRecord(ev1.back(), c->stream);
+#else
+        (void)c;
+#endif
+    }
+    void collect() {
+        ms.assign(names.size(), 0.f);
+#if !defined(WB_HOSTSIM)
+        for (size_t i = 0; i < ev0.size(); ++i) {
+            (void)hipEventSynchronize(ev1[i]);
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, ev0[i], ev1[i]);
+            ms[i] = t;
+            (void)hipEventDestroy(ev0[i]);
+            (void)hipEventDestroy(ev1[i]);
+        }
+        ev0.clear();
+        ev1.clear();
+#endif
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ batch
+struct wb_batch {
+    wb_ctx* ctx = nullptr;
+    wb_params p;
+    std::vector<double> lat, lon, levels;
+    int W = 0, padd = 0, njobs = 0, cap_seg = 0, hash_size = 0;
+    std::vector<void*> owned;       // device allocations to free
+    const void* d_field = nullptr;
+    const void* d_intensity = nullptr;
+    // phase 1
+    uint32_t *segk = nullptr, *segf = nullptr, *segt = nullptr, *rowptr = nullptr, *status = nullptr;
+    int* nseg = nullptr;
+    uint32_t *cpts = nullptr, *cown = nullptr;
+    int *c_off = nullptr, *c_len = nullptr, *c_closed = nullptr, *c_nux = nullptr, *c_sumy = nullptr, *ncont = nullptr;
+    int* d_max_nux = nullptr;
+    std::vector<void*> phase1_scratch;
+    int max_nux = 0;
+    std::vector<int> h_ncont;
+    std::vector<uint32_t> h_status;
+    // tables on the device
+    double *d_lat = nullptr, *d_latrad = nullptr, *d_lonrad = nullptr, *d_sphi2 = nullptr, *d_cphi2 = nullptr,
+           *d_cphi = nullptr, *d_slam2 = nullptr, *d_clam2 = nullptr, *d_wlat = nullptr;
+    // phase 2
+    int nsel = 0, ncut = 0;
+    int *sel_job = nullptr, *sel_cont = nullptr, *cut_job = nullptr, *cut_cont = nullptr;
+    long long band[2] = {0, 0};
+    // host result tables
+    bool have_contours = false;
+    std::vector<int32_t> ct_step, ct_level, ct_closed, ct_nux, ct_npts, ct_x, ct_y;
+    std::vector<int64_t> ct_sumy, ct_off, ct_base;   // ct_base[job] = first contour row of the job
+    struct Ev {
+        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, cx, cy;
+        std::vector<int64_t> contour, celloff;
+        std::vector<double> sums;
+    } ev[3];
+    WbTimer timer;
+    std::string timer_names;
+};
+
+template <class T>
+static T* balloc(wb_batch* b, size_t n) {
+    void* p = dmalloc(b->ctx, n * sizeof(T));
+    if (p) b->owned.push_back(p);
+    return (T*)p;
+}
+static void bfree_one(wb_batch* b, void* p) {
+    for (size_t i = 0; i < b->owned.size(); ++i)
+        if (b->owned[i] == p) { b->owned.erase(b->owned.begin() + i); break; }
+    dfree(b->ctx, p);
+}
+template <class T>
+static T* upload(wb_batch* b, const std::vector<T>& v) {
+    T* d = balloc<T>(b, v.size());
+    if (d && !v.empty()) h2d(b->ctx, d, v.data(), v.size() * sizeof(T));
+    return d;
+}
+
+static int next_pow2(long long v) {
+    long long p = 1;
+    while (p < v) p <<= 1;
+    return (int)p;
+}
+
+extern "C" {
+
+const char* wb_backend(void) {
+#if defined(WB_HOSTSIM)
+    return "hostsim";
+#else
+    return "hip";
+#endif
+}
+
+int wb_create(int device_id, wb_ctx** out) {
+    wb_ctx* c = new wb_ctx();
+    c->device = device_id;
+#if !defined(WB_HOSTSIM)
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device_id) {
+        delete c;
+        return 1;
+    }
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return 1;
+    }
+#endif
+    *out = c;
+    return 0;
+}
+
+void wb_destroy(wb_ctx* c) {
+    if (!c) return;
+#if !defined(WB_HOSTSIM)
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+#endif
+    delete c;
+}
+
+const char* wb_last_error(wb_ctx* c) { return c ? c->err.c_str() : "no context"; }
+
+void* wb_dev_alloc(wb_ctx* c, uint64_t bytes) { return dmalloc(c, (size_t)bytes); }
+void wb_dev_free(wb_ctx* c, void* p) { dfree(c, p); }
+int wb_memcpy_h2d(wb_ctx* c, void* d, const void* s, uint64_t b) { return h2d(c, d, s, (size_t)b); }
+int wb_memcpy_d2h(wb_ctx* c, void* d, const void* s, uint64_t b) { return d2h(c, d, s, (size_t)b); }
+
+void wb_free_batch(wb_batch* b) {
+    if (!b) return;
+    for (void* p : b->owned) dfree(b->ctx, p);
+    delete b;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ phase 1
+static int run_phase1(wb_batch* b) {
+    wb_ctx* ctx = b->ctx;
+    const wb_params& p = b->p;
+    const int J = b->njobs, cap = b->cap_seg, nlat = p.nlat;
+    b->hash_size = next_pow2(8LL * cap);
+    const size_t per = (size_t)J * cap;
+    b->segk = balloc<uint32_t>(b, per);
+    b->segf = balloc<uint32_t>(b, per);
+    b->segt = balloc<uint32_t>(b, per);
+    b->rowptr = balloc<uint32_t>(b, (size_t)J * nlat);
+    b->nseg = balloc<int>(b, J);
+    b->status = balloc<uint32_t>(b, J);
+    b->cpts = balloc<uint32_t>(b, 2 * per);
+    b->cown = balloc<uint32_t>(b, 2 * per);
+    b->c_off = balloc<int>(b, per);
+    b->c_len = balloc<int>(b, per);
+    b->c_closed = balloc<int>(b, per);
+    b->c_nux = balloc<int>(b, per);
+    b->c_sumy = balloc<int>(b, per);
+    b->ncont = balloc<int>(b, J);
+    b->d_max_nux = balloc<int>(b, 1);
+    if (!b->d_max_nux) return 1;
+    WbTraceArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    std::vector<void*>& sc = b->phase1_scratch;
+    for (int i = 0; i < 10; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
+    ta.rawpt = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawpt);
+    ta.rawcid = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawcid);
+    ta.keep = balloc<int>(b, (size_t)J * (2 * cap + 1)); sc.push_back(ta.keep);
+    ta.hkey = balloc<unsigned long long>(b, (size_t)J * b->hash_size); sc.push_back(ta.hkey);
+    ta.hval = balloc<uint32_t>(b, (size_t)J * b->hash_size); sc.push_back(ta.hval);
+    if (!ta.hval) return 1;
+    dmemset(ctx, b->status, 0, (size_t)J * sizeof(uint32_t));
+    dmemset(ctx, b->d_max_nux, 0, sizeof(int));
+    dmemset(ctx, b->nseg, 0, (size_t)J * sizeof(int));
+
+    WbScanArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.nt = p.nt; sa.nlat = nlat; sa.nlon = p.nlon; sa.W = b->W; sa.padd = b->padd; sa.nlev = p.nlevels; sa.cap_seg = cap;
+    sa.field = b->d_field;
+    for (int l = 0; l < p.nlevels; ++l) sa.levels[l] = b->levels[l];
+    sa.segk = b->segk; sa.segf = b->segf; sa.segt = b->segt; sa.rowptr = b->rowptr; sa.nseg = b->nseg; sa.status = b->status;
+    b->timer.begin(ctx, "scan");
+#if defined(WB_HOSTSIM)
+    if (p.dtype == 0) wb_scan_host<float>(sa); else wb_scan_host<double>(sa);
+#else
+    {
+        const size_t esz = p.dtype == 0 ? 4 : 8;
+        const size_t shmem = 2 * (size_t)b->W * esz + 2 * (size_t)p.nlevels * 64 * sizeof(int);
+        if (p.dtype == 0) hipLaunchKernelGGL(wb_k_scan<float>, dim3(p.nt), dim3(256), shmem, ctx->stream, sa);
+        else hipLaunchKernelGGL(wb_k_scan<double>, dim3(p.nt), dim3(256), shmem, ctx->stream, sa);
+    }
+#endif
+    b->timer.end(ctx);
+
+    ta.njobs = J; ta.nlat = nlat; ta.nlon = p.nlon; ta.W = b->W; ta.cap_seg = cap; ta.hash_size = b->hash_size;
+    ta.segk = b->segk; ta.segf = b->segf; ta.segt = b->segt; ta.rowptr = b->rowptr; ta.nseg = b->nseg;
+    ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
+    ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.max_nux = b->d_max_nux;
+    b->timer.begin(ctx, "trace");
+    WB_LAUNCH(wb_k_trace, J, 256, ta);
+    b->timer.end(ctx);
+    if (dsync(ctx)) return 1;
+    return 0;
+}
+
+extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
+    if (!ctx || !pp || !out) return 1;
+    const wb_params& p = *pp;
+    if (p.nt <= 0 || p.nlat < 2 || p.nlon < 2) return wb_fail(ctx, "bad dimensions");
+    if (p.nlevels < 1 || p.nlevels > WB_MAX_LEVELS) return wb_fail(ctx, "between 1 and 4 contour levels per call");
+    if (!(p.dlon > 0) || !(p.dlat > 0)) return wb_fail(ctx, "dlon and dlat must be positive");
+    const int padd = (int)(p.periodic_add / p.dlon);     // contour_index.py:97
+    if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
+    const int W = p.nlon + padd;
+    if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large: nlon + periodic columns <= 4096, nlat <= 32767");
+#if !defined(WB_HOSTSIM)
+    if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
+#endif
+    wb_batch* b = new wb_batch();
+    b->ctx = ctx;
+    b->p = p;
+    b->lat.assign(p.lat, p.lat + p.nlat);
+    b->lon.assign(p.lon, p.lon + p.nlon);
+    b->levels.assign(p.levels, p.levels + p.nlevels);
+    b->p.lat = b->lat.data();
+    b->p.lon = b->lon.data();
+    b->p.levels = b->levels.data();
+    b->W = W;
+    b->padd = padd;
+    b->njobs = p.nt * p.nlevels;
+    const size_t esz = p.dtype == 0 ? 4 : 8;
+    const size_t fbytes = (size_t)p.nt * p.nlat * p.nlon * esz;
+    if (p.on_device) {
+        b->d_field = p.field;
+        b->d_intensity = p.intensity;
+    } else {
+        void* d = dmalloc(ctx, fbytes);
+        if (!d) { delete b; return 1; }
+        b->owned.push_back(d);
+        h2d(ctx, d, p.field, fbytes);
+        b->d_field = d;
+        if (p.intensity) {
+            void* di = dmalloc(ctx, fbytes);
+            if (!di) { wb_free_batch(b); return 1; }
+            b->owned.push_back(di);
+            h2d(ctx, di, p.intensity, fbytes);
+            b->d_intensity = di;
+        }
+    }
+    int cap = p.cap_seg > 0 ? p.cap_seg : next_pow2(8LL * W);
+    if (cap < 1024) cap = 1024;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        b->cap_seg = cap;
+        b->timer = WbTimer();
+        if (run_phase1(b)) { std::string e = ctx->err; wb_free_batch(b); return wb_fail(ctx, e); }
+        std::vector<int> nseg(b->njobs);
+        d2h(ctx, nseg.data(), b->nseg, nseg.size() * sizeof(int));
+        int mx = 0;
+        for (int v : nseg) mx = v > mx ? v : mx;
+        if (mx <= cap) break;
+        // overflow: free everything phase 1 allocated (the field copies stay) and retry with room to spare
+        std::vector<void*> keep;
+        for (void* q : b->owned) {
+            if (q == b->d_field || q == b->d_intensity) keep.push_back(q); else dfree(ctx, q);
+        }
+        b->owned = keep;
+        b->phase1_scratch.clear();
+        cap = next_pow2((long long)mx + mx / 4);
+        if (attempt == 5) { wb_free_batch(b); return wb_fail(ctx, "segment capacity overflow"); }
+    }
+    b->h_ncont.resize(b->njobs);
+    b->h_status.resize(b->njobs);
+    d2h(ctx, b->h_ncont.data(), b->ncont, b->njobs * sizeof(int));
+    d2h(ctx, b->h_status.data(), b->status, b->njobs * sizeof(uint32_t));
+    d2h(ctx, &b->max_nux, b->d_max_nux, sizeof(int));
+    // phase-1 scratch is dead now
+    for (void* q : b->phase1_scratch) bfree_one(b, q);
+    b->phase1_scratch.clear();
+    bfree_one(b, b->segk); bfree_one(b, b->segf); bfree_one(b, b->segt); bfree_one(b, b->rowptr); bfree_one(b, b->cown);
+    b->segk = b->segf = b->segt = b->rowptr = b->cown = nullptr;
+    b->ct_base.assign(b->njobs + 1, 0);
+    for (int j = 0; j < b->njobs; ++j) b->ct_base[j + 1] = b->ct_base[j] + b->h_ncont[j];
+    *out = b;
+    return 0;
+}
+
+extern "C" int wb_batch_max_nux(wb_batch* b) { return b ? b->max_nux : 0; }
+
+extern "C" int wb_get_status(wb_batch* b, const uint32_t** st, int64_t* n) {
+    if (!b) return 1;
+    d2h(b->ctx, b->h_status.data(), b->status, b->njobs * sizeof(uint32_t));
+    *st = b->h_status.data();
+    *n = b->njobs;
+    return 0;
+}
+
+extern "C" int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont) {
+    if (!b) return 1;
+    *geo = b->band[0];
+    *cont = b->band[1];
+    return 0;
+}
+
+extern "C" int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n) {
+    if (!b) return 1;
+    b->timer_names.clear();
+    for (auto& s : b->timer.names) { b->timer_names += s; b->timer_names.push_back('\0'); }
+    *names = b->timer_names.c_str();
+    *ms = b->timer.ms.data();
+    *n = (int)b->timer.ms.size();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ contour table
+struct WbPackArgs {
+    int njobs, cap_seg, nlev;
+    const int* ncont; const int* c_off; const int* c_len; const int* c_closed; const int* c_nux; const int* c_sumy;
+    const uint32_t* cpts;
+    const long long* cbase;    // [njobs] first contour row
+    const long long* pbase;    // [njobs] first point
+    int* o_step; int* o_level; int* o_closed; int* o_nux; int* o_npts; long long* o_sumy; long long* o_off;
+    int* o_x; int* o_y;
+};
+WB_KERNEL(wb_k_job_npts, int njobs, int cap_seg, const int* ncont, const int* c_len, long long* npts) {
+    const int job = WB_BLOCK_ID;
+    if (job >= njobs) return;
+    WB_SINGLE
+    long long s = 0;
+    for (int k = 0; k < ncont[job]; ++k) s += c_len[(size_t)job * cap_seg + k];
+    npts[job] = s;
+    WB_END_SINGLE
+}
+WB_KERNEL(wb_k_pack_contours, WbPackArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const size_t jb = (size_t)job * a.cap_seg;
+    const int C = a.ncont[job];
+    WB_SINGLE
+    long long run = a.pbase[job];
+    for (int k = 0; k < C; ++k) {
+        const long long row = a.cbase[job] + k;
+        a.o_step[row] = job / a.nlev;
+        a.o_level[row] = job % a.nlev;
+        a.o_closed[row] = a.c_closed[jb + k];
+        a.o_nux[row] = a.c_nux[jb + k];
+        a.o_npts[row] = a.c_len[jb + k];
+        a.o_sumy[row] = a.c_sumy[jb + k];
+        a.o_off[row] = run;
+        run += a.c_len[jb + k];
+    }
+    WB_END_SINGLE
+    for (int k = 0; k < C; ++k) {
+        const long long dst = a.o_off[a.cbase[job] + k];
+        const uint32_t* src = a.cpts + 2 * jb + a.c_off[jb + k];
+        WB_PFOR(i, a.c_len[jb + k])
+            a.o_x[dst + i] = wb_pt_x(src[i]);
+            a.o_y[dst + i] = wb_pt_y(src[i]);
+        WB_END_PFOR
+    }
+}
+
+static int fetch_contours(wb_batch* b) {
+    if (b->have_contours) return 0;
+    wb_ctx* ctx = b->ctx;
+    const int J = b->njobs;
+    const long long NC = b->ct_base[J];
+    long long* d_npts = balloc<long long>(b, J);
+    b->timer.begin(ctx, "pack_contours");
+    WB_LAUNCH(wb_k_job_npts, J, 64, J, b->cap_seg, b->ncont, b->c_len, d_npts);
+    std::vector<long long> npts(J), pbase(J + 1, 0), cbase(b->ct_base.begin(), b->ct_base.end());
+    d2h(ctx, npts.data(), d_npts, J * sizeof(long long));
+    for (int j = 0; j < J; ++j) pbase[j + 1] = pbase[j] + npts[j];
+    const long long NP = pbase[J];
+    long long* d_cbase = upload(b, cbase);
+    long long* d_pbase = upload(b, pbase);
+    WbPackArgs a;
+    a.njobs = J; a.cap_seg = b->cap_seg; a.nlev = b->p.nlevels;
+    a.ncont = b->ncont; a.c_off = b->c_off; a.c_len = b->c_len; a.c_closed = b->c_closed; a.c_nux = b->c_nux;
+    a.c_sumy = b->c_sumy; a.cpts = b->cpts; a.cbase = d_cbase; a.pbase = d_pbase;
+    a.o_step = balloc<int>(b, NC); a.o_level = balloc<int>(b, NC); a.o_closed = balloc<int>(b, NC);
+    a.o_nux = balloc<int>(b, NC); a.o_npts = balloc<int>(b, NC); a.o_sumy = balloc<long long>(b, NC);
+    a.o_off = balloc<long long>(b, NC); a.o_x = balloc<int>(b, NP); a.o_y = balloc<int>(b, NP);
+    if (!a.o_y) return 1;
+    WB_LAUNCH(wb_k_pack_contours, J, 256, a);
+    b->ct_step.resize(NC); b->ct_level.resize(NC); b->ct_closed.resize(NC); b->ct_nux.resize(NC);
+    b->ct_npts.resize(NC); b->ct_sumy.resize(NC); b->ct_off.resize(NC); b->ct_x.resize(NP); b->ct_y.resize(NP);
+    if (NC) {
+        d2h(ctx, b->ct_step.data(), a.o_step, NC * 4); d2h(ctx, b->ct_level.data(), a.o_level, NC * 4);
+        d2h(ctx, b->ct_closed.data(), a.o_closed, NC * 4); d2h(ctx, b->ct_nux.data(), a.o_nux, NC * 4);
+        d2h(ctx, b->ct_npts.data(), a.o_npts, NC * 4); d2h(ctx, b->ct_sumy.data(), a.o_sumy, NC * 8);
+        d2h(ctx, b->ct_off.data(), a.o_off, NC * 8);
+    }
+    if (NP) { d2h(ctx, b->ct_x.data(), a.o_x, NP * 4); d2h(ctx, b->ct_y.data(), a.o_y, NP * 4); }
+    b->timer.end(ctx);
+    if (dsync(ctx)) return 1;
+    void* tmp[] = {d_npts, d_cbase, d_pbase, a.o_step, a.o_level, a.o_closed, a.o_nux, a.o_npts, a.o_sumy, a.o_off, a.o_x, a.o_y};
+    for (void* q : tmp) bfree_one(b, q);
+    b->have_contours = true;
+    return 0;
+}
+
+extern "C" int wb_get_contours(wb_batch* b, wb_contour_table* o) {
+    if (!b || !o) return 1;
+    if (fetch_contours(b)) return 1;
+    b->timer.collect();
+    o->n = (int64_t)b->ct_step.size();
+    o->step = b->ct_step.data(); o->level_idx = b->ct_level.data(); o->closed = b->ct_closed.data();
+    o->nux = b->ct_nux.data(); o->sum_y = (const int64_t*)b->ct_sumy.data(); o->npts = b->ct_npts.data();
+    o->offset = (const int64_t*)b->ct_off.data(); o->npoints = (int64_t)b->ct_x.size();
+    o->x = b->ct_x.data(); o->y = b->ct_y.data();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ phase 2
+struct WbEvFillArgs {
+    int nsel, ncut, cap_ev;
+    const int* sel_job; const int* sel_cont; const int* cut_job; const int* cut_cont;
+    const int* ev_n; const int* ev_ind; const int* sbase;   // streamers
+    const int* ot_n; const int* ot_box; const int* ot_orient; const int* obase;   // overturnings
+    const int* c_len; int cap_seg;
+    int* ev;   // [NE][8]
+    int off_s, off_o, off_c;
+};
+WB_KERNEL(wb_k_fill_events, WbEvFillArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s < a.nsel) {
+        if (a.ev_n) {
+            WB_PFOR(e, a.ev_n[s])
+                int* d = a.ev + (size_t)(a.off_s + a.sbase[s] + e) * 8;
+                d[0] = WB_EV_STREAMER; d[1] = a.sel_job[s]; d[2] = a.sel_cont[s];
+                d[3] = a.ev_ind[((size_t)s * a.cap_ev + e) * 2]; d[4] = a.ev_ind[((size_t)s * a.cap_ev + e) * 2 + 1];
+                d[5] = 0; d[6] = 0; d[7] = 0;
+            WB_END_PFOR
+        }
+        if (a.ot_n) {
+            WB_PFOR(e, a.ot_n[s])
+                int* d = a.ev + (size_t)(a.off_o + a.obase[s] + e) * 8;
+                const int* bx = a.ot_box + ((size_t)s * WB_OT_CAP + e) * 4;
+                d[0] = WB_EV_OVERTURNING; d[1] = a.sel_job[s]; d[2] = a.sel_cont[s];
+                d[3] = bx[0]; d[4] = bx[1]; d[5] = bx[2]; d[6] = bx[3];
+                d[7] = a.ot_orient[(size_t)s * WB_OT_CAP + e];
+            WB_END_PFOR
+        }
+    } else {
+        const int c = s - a.nsel;
+        if (c < a.ncut) {
+            WB_SINGLE
+            int* d = a.ev + (size_t)(a.off_c + c) * 8;
+            d[0] = WB_EV_CUTOFF; d[1] = a.cut_job[c]; d[2] = a.cut_cont[c];
+            d[3] = 0; d[4] = a.c_len[(size_t)a.cut_job[c] * a.cap_seg + a.cut_cont[c]] - 1; d[5] = 0; d[6] = 0; d[7] = 0;
+            WB_END_SINGLE
+        }
+    }
+}
+
+static void make_tables(wb_batch* b) {
+    if (b->d_lat) return;
+    const wb_params& p = b->p;
+    std::vector<double> latrad(p.nlat), sphi2(p.nlat), cphi2(p.nlat), cphi(p.nlat), wlat(p.nlat);
+    std::vector<double> lonrad(p.nlon), slam2(p.nlon), clam2(p.nlon);
+    // index_utils.py:58-62
+    const double area_cell = pow(rint(6371.0 * 2.0 * M_PI / (360.0 / ((p.dlon + p.dlat) / 2.0))), 2.0);
+    for (int y = 0; y < p.nlat; ++y) {
+        latrad[y] = b->lat[y] * (M_PI / 180.0);    // np.radians
+        sphi2[y] = sin(0.5 * latrad[y]);
+        cphi2[y] = cos(0.5 * latrad[y]);
+        cphi[y] = cos(latrad[y]);
+        wlat[y] = cos(latrad[y]) * area_cell;
+    }
+    for (int x = 0; x < p.nlon; ++x) {
+        lonrad[x] = b->lon[x] * (M_PI / 180.0);
+        slam2[x] = sin(0.5 * lonrad[x]);
+        clam2[x] = cos(0.5 * lonrad[x]);
+    }
+    b->d_lat = upload(b, b->lat);
+    b->d_latrad = upload(b, latrad); b->d_lonrad = upload(b, lonrad);
+    b->d_sphi2 = upload(b, sphi2); b->d_cphi2 = upload(b, cphi2); b->d_cphi = upload(b, cphi);
+    b->d_slam2 = upload(b, slam2); b->d_clam2 = upload(b, clam2); b->d_wlat = upload(b, wlat);
+}
+
+extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
+    if (!b) return 1;
+    wb_ctx* ctx = b->ctx;
+    const wb_params& p = b->p;
+    const int J = b->njobs, cap = b->cap_seg;
+#if !defined(WB_HOSTSIM)
+    if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
+#endif
+    make_tables(b);
+    std::vector<void*> tmp;   // device scratch of this call
+    auto talloc = [&](size_t bytes) { void* q = dmalloc(ctx, bytes); if (q) { b->owned.push_back(q); tmp.push_back(q); } return q; };
+
+    // ---- selection
+    WbSelectArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.njobs = J; sa.cap_seg = cap; sa.gmax = gmax; sa.dlon = p.dlon; sa.co_min_exp = p.co_min_exp;
+    sa.ncont = b->ncont; sa.c_nux = b->c_nux; sa.c_closed = b->c_closed;
+    int* d_nsel = (int*)talloc(J * sizeof(int));
+    int* d_ncut = (int*)talloc(J * sizeof(int));
+    int* d_tot = (int*)talloc(2 * sizeof(int));
+    if (!d_tot) return 1;
+    sa.nsel = d_nsel; sa.ncut = d_ncut;
+    b->timer.begin(ctx, "select");
+    WB_LAUNCH(wb_k_select_count, J, 64, sa);
+    WB_LAUNCH(wb_k_scan_jobs, 1, 256, J, d_nsel, d_ncut, d_tot);
+    int tot[2] = {0, 0};
+    d2h(ctx, tot, d_tot, sizeof(tot));
+    b->nsel = tot[0];
+    b->ncut = (which & 4) ? tot[1] : 0;
+    const int nsel = b->nsel, ncut = b->ncut;
+    b->sel_job = (int*)talloc((nsel + 1) * sizeof(int)); b->sel_cont = (int*)talloc((nsel + 1) * sizeof(int));
+    b->cut_job = (int*)talloc((tot[1] + 1) * sizeof(int)); b->cut_cont = (int*)talloc((tot[1] + 1) * sizeof(int));
+    if (!b->cut_cont) return 1;
+    sa.selbase = d_nsel; sa.cutbase = d_ncut;
+    sa.sel_job = b->sel_job; sa.sel_cont = b->sel_cont; sa.cut_job = b->cut_job; sa.cut_cont = b->cut_cont;
+    WB_LAUNCH(wb_k_select_fill, J, 64, sa);
+    b->timer.end(ctx);
+
+    // ---- overturnings
+    int *ot_n = nullptr, *ot_box = nullptr, *ot_orient = nullptr;
+    if ((which & 2) && nsel > 0) {
+        ot_n = (int*)talloc(nsel * sizeof(int));
+        ot_box = (int*)talloc((size_t)nsel * WB_OT_CAP * 4 * sizeof(int));
+        ot_orient = (int*)talloc((size_t)nsel * WB_OT_CAP * sizeof(int));
+        if (!ot_orient) return 1;
+        WbOverturnArgs oa;
+        memset(&oa, 0, sizeof(oa));
+        oa.nsel = nsel; oa.cap_seg = cap; oa.nlon = p.nlon; oa.W = b->W;
+        oa.rg_over_dlon = p.range_group / p.dlon; oa.minexp_over_dlon = p.ot_min_exp / p.dlon;
+        oa.sel_job = b->sel_job; oa.sel_cont = b->sel_cont; oa.c_off = b->c_off; oa.c_len = b->c_len; oa.cpts = b->cpts;
+        oa.lat = b->d_lat; oa.ot_n = ot_n; oa.ot_box = ot_box; oa.ot_orient = ot_orient; oa.status = b->status;
+        b->timer.begin(ctx, "overturn");
+        WB_LAUNCH(wb_k_overturn, nsel, 256, oa);
+        b->timer.end(ctx);
+    }
+
+    // ---- streamers
+    int *ev_n = nullptr, *ev_ind = nullptr;
+    const int cap_ev = 256;
+    if ((which & 1) && nsel > 0) {
+        // longest selected contour (sets the tiling of the all-pairs kernel)
+        std::vector<int> h_sj(nsel), h_sc(nsel);
+        d2h(ctx, h_sj.data(), b->sel_job, nsel * sizeof(int));
+        d2h(ctx, h_sc.data(), b->sel_cont, nsel * sizeof(int));
+        int* d_lenprobe = (int*)talloc(sizeof(int));
+        (void)d_lenprobe;
+        int cap_pairs = p.cap_pairs > 0 ? p.cap_pairs : 65536;
+        int* d_band = (int*)talloc(2 * sizeof(int));
+        ev_n = (int*)talloc(nsel * sizeof(int));
+        ev_ind = (int*)talloc((size_t)nsel * cap_ev * 2 * sizeof(int));
+        WbStreamerArgs st;
+        memset(&st, 0, sizeof(st));
+        st.nsel = nsel; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.cap_ev = cap_ev;
+        st.geo_dis = p.geo_dis; st.cont_dis = p.cont_dis;
+        { const double sv = sin(p.geo_dis / (2.0 * 6371.0)); st.hthr = sv * sv; }
+        st.sel_job = b->sel_job; st.sel_cont = b->sel_cont; st.c_off = b->c_off; st.c_len = b->c_len; st.cpts = b->cpts;
+        st.lat_rad = b->d_latrad; st.lon_rad = b->d_lonrad; st.sphi2 = b->d_sphi2; st.cphi2 = b->d_cphi2; st.cphi = b->d_cphi;
+        st.slam2 = b->d_slam2; st.clam2 = b->d_clam2;
+        st.on = (double*)talloc((size_t)nsel * 2 * cap * sizeof(double));
+        st.pre = (double*)talloc((size_t)nsel * 2 * cap * sizeof(double));
+        st.npairs = (int*)talloc(nsel * sizeof(int));
+        st.stage = (int*)talloc(nsel * sizeof(int));
+        st.nalive = (int*)talloc(nsel * sizeof(int));
+        st.rowmax = (int*)talloc((size_t)nsel * 2 * cap * sizeof(int));
+        st.rowaux = (int*)talloc((size_t)nsel * 2 * cap * sizeof(int));
+        st.ev_ind = ev_ind; st.ev_n = ev_n; st.band_hits = d_band; st.status = b->status;
+        if (!st.rowaux || !ev_ind) return 1;
+        // the largest contour length bounds the tiles; c_len lives on the device: take it from the host copy of
+        // the contour table if present, else from a small reduction on the host over sel (c_len D2H per sel)
+        int maxN = 0;
+        {
+            std::vector<int> lens(nsel);
+            for (int s = 0; s < nsel; ++s)
+                d2h(ctx, &lens[s], b->c_len + (size_t)h_sj[s] * cap + h_sc[s], sizeof(int));
+            for (int v : lens) maxN = v > maxN ? v : maxN;
+        }
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            st.cap_pairs = cap_pairs;
+            st.hash_size = next_pow2(2LL * cap_pairs);
+            if (st.hash_size < next_pow2(4LL * cap)) st.hash_size = next_pow2(4LL * cap);
+            st.pairs = (unsigned long long*)talloc((size_t)nsel * cap_pairs * 8);
+            st.alive = (int*)talloc((size_t)nsel * cap_pairs * sizeof(int));
+            st.hkey = (unsigned long long*)talloc((size_t)nsel * st.hash_size * 8);
+            st.hval = (unsigned long long*)talloc((size_t)nsel * st.hash_size * 8);
+            if (!st.hval) return 1;
+            dmemset(ctx, d_band, 0, 2 * sizeof(int));
+            b->timer.begin(ctx, "streamer_prep");
+            WB_LAUNCH(wb_k_streamer_prep, nsel, 256, st);
+            b->timer.end(ctx);
+            const int tiles = (maxN + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+            b->timer.begin(ctx, "streamer_pairs");
+            if (tiles > 0) WB_LAUNCH(wb_k_streamer_pairs, (long long)nsel * tiles, 256, st, tiles);
+            b->timer.end(ctx);
+            std::vector<int> np(nsel);
+            d2h(ctx, np.data(), st.npairs, nsel * sizeof(int));
+            int mx = 0;
+            for (int v : np) mx = v > mx ? v : mx;
+            if (mx > cap_pairs && attempt < 3) {
+                bfree_one(b, st.pairs); bfree_one(b, st.alive); bfree_one(b, st.hkey); bfree_one(b, st.hval);
+                for (void* q : {(void*)st.pairs, (void*)st.alive, (void*)st.hkey, (void*)st.hval})
+                    for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == q) { tmp.erase(tmp.begin() + i); break; }
+                cap_pairs = next_pow2((long long)mx + mx / 8);
+                b->timer.names.pop_back(); b->timer.names.pop_back();
+#if !defined(WB_HOSTSIM)
+                b->timer.ev0.pop_back(); b->timer.ev0.pop_back(); b->timer.ev1.pop_back(); b->timer.ev1.pop_back();
+#endif
+                continue;
+            }
+            b->timer.begin(ctx, "streamer_f1");
+            WB_LAUNCH(wb_k_streamer_f1, nsel, 256, st);
+            b->timer.end(ctx);
+            const int chunks = ((mx < cap_pairs ? mx : cap_pairs) + WB_F2_PAIRS - 1) / WB_F2_PAIRS;
+            b->timer.begin(ctx, "streamer_f2");
+            if (chunks > 0) WB_LAUNCH(wb_k_streamer_f2, (long long)nsel * chunks, 256, st, chunks);
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "streamer_f34");
+            WB_LAUNCH(wb_k_streamer_f34, nsel, 256, st);
+            b->timer.end(ctx);
+            int band[2];
+            d2h(ctx, band, d_band, sizeof(band));
+            b->band[0] = band[0];
+            b->band[1] = band[1];
+            break;
+        }
+    }
+
+    // ---- event list (streamers, overturnings, cutoffs), then cells + sums
+    std::vector<int> h_evn(nsel, 0), h_otn(nsel, 0), sbase(nsel + 1, 0), obase(nsel + 1, 0);
+    if (ev_n) d2h(ctx, h_evn.data(), ev_n, nsel * sizeof(int));
+    if (ot_n) d2h(ctx, h_otn.data(), ot_n, nsel * sizeof(int));
+    for (int s = 0; s < nsel; ++s) { sbase[s + 1] = sbase[s] + h_evn[s]; obase[s + 1] = obase[s] + h_otn[s]; }
+    const int NS = sbase[nsel], NO = obase[nsel], NCU = ncut, NE = NS + NO + NCU;
+    std::vector<int> h_ev((size_t)NE * 8 + 8, 0);
+    std::vector<double> h_sums((size_t)NE * 5 + 5, 0.0);
+    std::vector<int> h_nc(NE + 1, 0);
+    std::vector<long long> h_coff(NE + 1, 0);
+    std::vector<uint32_t> h_cells;
+    if (NE > 0) {
+        int* d_sbase = (int*)talloc((nsel + 1) * sizeof(int));
+        int* d_obase = (int*)talloc((nsel + 1) * sizeof(int));
+        int* d_ev = (int*)talloc((size_t)NE * 8 * sizeof(int));
+        if (!d_ev) return 1;
+        h2d(ctx, d_sbase, sbase.data(), (nsel + 1) * sizeof(int));
+        h2d(ctx, d_obase, obase.data(), (nsel + 1) * sizeof(int));
+        WbEvFillArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.nsel = nsel; fa.ncut = NCU; fa.cap_ev = cap_ev;
+        fa.sel_job = b->sel_job; fa.sel_cont = b->sel_cont; fa.cut_job = b->cut_job; fa.cut_cont = b->cut_cont;
+        fa.ev_n = ev_n; fa.ev_ind = ev_ind; fa.sbase = d_sbase; fa.ot_n = ot_n; fa.ot_box = ot_box; fa.ot_orient = ot_orient;
+        fa.obase = d_obase; fa.c_len = b->c_len; fa.cap_seg = cap; fa.ev = d_ev; fa.off_s = 0; fa.off_o = NS; fa.off_c = NS + NO;
+        b->timer.begin(ctx, "fill_events");
+        WB_LAUNCH(wb_k_fill_events, nsel + NCU, 64, fa);
+        b->timer.end(ctx);
+
+        WbPropsArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        const double r = ((p.dlon + p.dlat) / 2.0) / 2.0;     // index_utils.py:48-50
+        pa.nev = NE; pa.nslots = NE < 256 ? NE : 256; pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
+        pa.nlev = p.nlevels; pa.dtype = p.dtype; pa.want_cells = p.want_cells; pa.pad = (int)ceil(r); pa.r2 = r * r;
+        pa.ev = d_ev; pa.c_off = b->c_off; pa.c_len = b->c_len; pa.cpts = b->cpts; pa.data = b->d_field;
+        pa.intensity = b->d_intensity; pa.wlat = b->d_wlat;
+        pa.cells = (int*)talloc((size_t)pa.nslots * b->W * p.nlat * sizeof(int));
+        pa.rowacc = (double*)talloc((size_t)pa.nslots * 4 * p.nlat * sizeof(double));
+        pa.ev_sums = (double*)talloc((size_t)NE * 5 * sizeof(double));
+        pa.ev_ncells = (int*)talloc((size_t)NE * sizeof(int));
+        pa.cell_count = (unsigned long long*)talloc(sizeof(unsigned long long));
+        pa.ev_cell_off = (long long*)talloc((size_t)NE * sizeof(long long));
+        if (!pa.ev_cell_off) return 1;
+        dmemset(ctx, pa.cell_count, 0, sizeof(unsigned long long));
+        unsigned long long cell_cap = p.want_cells ? (unsigned long long)NE * 4096ull : 0ull;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            pa.cell_cap = cell_cap;
+            pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
+            if (cell_cap && !pa.cell_pool) return 1;
+            dmemset(ctx, pa.cell_count, 0, sizeof(unsigned long long));
+            b->timer.begin(ctx, "props");
+            WB_LAUNCH(wb_k_props, pa.nslots, 256, pa);
+            b->timer.end(ctx);
+            unsigned long long used = 0;
+            d2h(ctx, &used, pa.cell_count, sizeof(used));
+            if (!p.want_cells || used <= cell_cap) { h_cells.resize((size_t)used); break; }
+            cell_cap = used;   // second pass with the exact size
+            b->timer.names.pop_back();
+#if !defined(WB_HOSTSIM)
+            b->timer.ev0.pop_back(); b->timer.ev1.pop_back();
+#endif
+        }
+        b->timer.begin(ctx, "events_d2h");
+        d2h(ctx, h_ev.data(), d_ev, (size_t)NE * 8 * sizeof(int));
+        d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
+        d2h(ctx, h_nc.data(), pa.ev_ncells, (size_t)NE * sizeof(int));
+        if (p.want_cells) {
+            d2h(ctx, h_coff.data(), pa.ev_cell_off, (size_t)NE * sizeof(long long));
+            if (!h_cells.empty()) d2h(ctx, h_cells.data(), pa.cell_pool, h_cells.size() * sizeof(uint32_t));
+        }
+        b->timer.end(ctx);
+    }
+    if (dsync(ctx)) return 1;
+
+    // ---- host tables
+    for (int kind = 0; kind < 3; ++kind) {
+        wb_batch::Ev& t = b->ev[kind];
+        t = wb_batch::Ev();
+        const int lo = kind == 0 ? 0 : (kind == 1 ? NS : NS + NO), hi = kind == 0 ? NS : (kind == 1 ? NS + NO : NE);
+        for (int e = lo; e < hi; ++e) {
+            const int* d = &h_ev[(size_t)e * 8];
+            const int job = d[1];
+            t.step.push_back(job / p.nlevels);
+            t.level.push_back(job % p.nlevels);
+            t.contour.push_back(b->ct_base[job] + d[2]);
+            if (kind == WB_OVERTURNINGS) {
+                t.ind1.push_back(0); t.ind2.push_back(0);
+                t.box.insert(t.box.end(), d + 3, d + 7);
+                t.orient.push_back(d[7]);
+            } else {
+                t.ind1.push_back(d[3]); t.ind2.push_back(d[4]);
+                t.box.insert(t.box.end(), 4, 0);
+                t.orient.push_back(0);
+            }
+            t.sums.insert(t.sums.end(), &h_sums[(size_t)e * 5], &h_sums[(size_t)e * 5] + 5);
+            t.ncells.push_back(h_nc[e]);
+            if (p.want_cells) {
+                t.celloff.push_back((int64_t)t.cx.size());
+                const long long off = h_coff[e];
+                for (int c = 0; c < h_nc[e] && off >= 0; ++c) {
+                    const uint32_t v = h_cells[(size_t)off + c];
+                    t.cx.push_back(wb_pt_x(v));
+                    t.cy.push_back(wb_pt_y(v));
+                }
+            }
+        }
+        if (p.want_cells) t.celloff.push_back((int64_t)t.cx.size());
+    }
+    for (void* q : tmp) bfree_one(b, q);
+    b->sel_job = b->sel_cont = b->cut_job = b->cut_cont = nullptr;
+    b->timer.collect();
+    return 0;
+}
+
+extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
+    if (!b || !o || kind < 0 || kind > 2) return 1;
+    wb_batch::Ev& t = b->ev[kind];
+    o->n = (int64_t)t.step.size();
+    o->step = t.step.data(); o->level_idx = t.level.data(); o->contour = t.contour.data();
+    o->ind1 = t.ind1.data(); o->ind2 = t.ind2.data(); o->box = t.box.data(); o->orientation = t.orient.data();
+    o->sums = t.sums.data(); o->ncells = t.ncells.data();
+    o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
+    o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ synthetic PV
+struct WbSynthArgs {
+    void* field; int dtype; long long t0; int nt, nlat, nlon; const double* lat; const double* lon;
+    double par[7][5]; double eps; unsigned long long seed;
+};
+WB_HD inline unsigned long long wb_synth_key(unsigned long long seed, unsigned long long stream, unsigned long long a,
+                                             unsigned long long bb) {
+    unsigned long long k = wb_mix64(seed * 0x100000001B3ull + stream);
+    k = wb_mix64(k ^ a);
+    k = wb_mix64(k ^ bb);
+    return k;
+}
+WB_KERNEL(wb_k_synth, WbSynthArgs a) {
+    // one workgroup per (time step, latitude row); see oracle/synth.py for the formula
+    const int n = WB_BLOCK_ID / a.nlat, j = WB_BLOCK_ID - n * a.nlat;
+    const double t = (double)(a.t0 + n);
+    const double la = a.lat[j], phi = fabs(la), phir = phi * (M_PI / 180.0);
+    const double sgn = la > 0 ? 1.0 : (la < 0 ? -1.0 : 0.0);
+    WB_PFOR(i, a.nlon)
+        const double lam = a.lon[i] * (M_PI / 180.0);
+        double D = 0.0;
+        for (int m = 0; m < 7; ++m) {
+            const double k = (double)(m + 3);
+            const double ph = la < 0 ? a.par[m][4] : a.par[m][1];
+            D += a.par[m][0] * cos(k * lam + ph + a.par[m][3] * t + a.par[m][2] * k * (phir - 0.8));
+        }
+        double v = 2.0 + 6.0 * tanh((phi + D - 45.0) / 6.0);
+        double pv = sgn * (v > 0.0 ? v : 0.0);
+        if (a.eps != 0.0) {
+            const unsigned long long cell = (unsigned long long)j * (unsigned long long)a.nlon + (unsigned long long)i;
+            const unsigned long long h = wb_synth_key(a.seed, 6, (unsigned long long)(a.t0 + n), cell);
+            pv += a.eps * (2.0 * ((double)(h >> 11) * (1.0 / 9007199254740992.0)) - 1.0);
+        }
+        const size_t idx = ((size_t)n * a.nlat + j) * a.nlon + i;
+        if (a.dtype == 0) ((float*)a.field)[idx] = (float)pv; else ((double*)a.field)[idx] = pv;
+    WB_END_PFOR
+}
+
+extern "C" int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, int nlat, int nlon,
+                             const double* lat, const double* lon, const double* wave_params, double eps, uint64_t seed) {
+    if (!ctx || !dev_field) return 1;
+    double* d_lat = (double*)dmalloc(ctx, nlat * sizeof(double));
+    double* d_lon = (double*)dmalloc(ctx, nlon * sizeof(double));
+    if (!d_lon) return 1;
+    h2d(ctx, d_lat, lat, nlat * sizeof(double));
+    h2d(ctx, d_lon, lon, nlon * sizeof(double));
+    WbSynthArgs a;
+    a.field = dev_field; a.dtype = dtype; a.t0 = t0; a.nt = nt; a.nlat = nlat; a.nlon = nlon; a.lat = d_lat; a.lon = d_lon;
+    memcpy(a.par, wave_params, sizeof(a.par));
+    a.eps = eps; a.seed = seed;
+    WB_LAUNCH(wb_k_synth, (long long)nt * nlat, 256, a);
+    const int rc = dsync(ctx);
+    dfree(ctx, d_lat);
+    dfree(ctx, d_lon);
+    return rc;
+}

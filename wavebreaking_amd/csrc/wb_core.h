@@ -1,0 +1,125 @@
+// wb_core.h -- arithmetic shared by every kernel: marching-squares case logic, crossing
+// coordinates, exact integer lattice predicates.  Pure functions, host+device.
+//
+// Reference semantics restated (file:line under the reference tree):
+//   * skimage.measure.find_contours as called at wavebreaking/indices/contour_index.py:103
+//     (case table / crossing formula: SURVEY.md 8a row C2, pinned by tests/golden/contours_*.npz)
+//   * np.round(...).astype(int) at contour_index.py:111  -> round-half-even of the f64 SUM c0+f
+//   * LineString.touches / intersects at streamer_index.py:197,234 -> exact int64 orientation tests
+#pragma once
+#include "wb_spmd.h"
+
+#define WB_NIL 0xFFFFFFFFu
+
+enum { WB_TOP = 0, WB_RIGHT = 1, WB_BOTTOM = 2, WB_LEFT = 3 };
+
+// segment table: case -> (from_side, to_side) for sub-segment 0 and 1; nibble-packed
+// entry = from0 | to0<<2 | from1<<4 | to1<<6 ; number of segments in WB_NSEG.
+//  1:(T->L) 2:(R->T) 3:(R->L) 4:(L->B) 5:(T->B) 6:(R->T),(L->B) 7:(R->B)
+//  8:(B->R) 9:(T->L),(B->R) 10:(B->T) 11:(B->L) 12:(L->R) 13:(T->R) 14:(L->T)
+WB_HD inline int wb_case_nseg(int c) { return (c == 0 || c == 15) ? 0 : ((c == 6 || c == 9) ? 2 : 1); }
+// sides T=0 R=1 B=2 L=3, two bits per case (packed so that no constant array lands in scratch)
+WB_HD inline int wb_seg_from(int c, int sub) {
+    if (sub) return c == 6 ? WB_LEFT : WB_BOTTOM;     // 6:(L->B)  9:(B->R)
+    return (int)((0x33a25350u >> (2 * c)) & 3u);
+}
+WB_HD inline int wb_seg_to(int c, int sub) {
+    if (sub) return c == 6 ? WB_BOTTOM : WB_RIGHT;
+    return (int)((0x05cd8accu >> (2 * c)) & 3u);
+}
+
+// crossing fraction, exactly skimage's _get_fraction (float64)
+WB_HD inline double wb_fraction(double a, double b, double level) {
+    return (a == b) ? 0.0 : (level - a) / (b - a);
+}
+
+// round half to even of a non-negative-ish double -> int (np.round(x).astype(int))
+WB_HD inline int wb_rint(double v) { return (int)rint(v); }
+
+// lattice point (x | y<<16) of the crossing on `side` of the square with upper-left corner (r,c)
+WB_HD inline uint32_t wb_crossing_point(int side, int r, int c, double ul, double ur, double ll, double lr,
+                                        double level) {
+    double pr, pc;
+    if (side == WB_TOP) {
+        pr = (double)r;
+        pc = (double)c + wb_fraction(ul, ur, level);
+    } else if (side == WB_BOTTOM) {
+        pr = (double)(r + 1);
+        pc = (double)c + wb_fraction(ll, lr, level);
+    } else if (side == WB_LEFT) {
+        pr = (double)r + wb_fraction(ul, ll, level);
+        pc = (double)c;
+    } else {
+        pr = (double)r + wb_fraction(ur, lr, level);
+        pc = (double)(c + 1);
+    }
+    return (uint32_t)wb_rint(pc) | ((uint32_t)wb_rint(pr) << 16);
+}
+
+WB_HD inline int wb_pt_x(uint32_t p) { return (int)(p & 0xFFFFu); }
+WB_HD inline int wb_pt_y(uint32_t p) { return (int)(p >> 16); }
+
+// segment key: ((r*W + c) << 1 | sub) | case << 27   (r*W+c < 2^26)
+WB_HD inline uint32_t wb_seg_key(int r, int c, int W, int sub, int cs) {
+    return ((uint32_t)(r * W + c) << 1) | (uint32_t)sub | ((uint32_t)cs << 27);
+}
+WB_HD inline int wb_key_sq(uint32_t k) { return (int)((k & 0x07FFFFFFu) >> 1); }
+WB_HD inline int wb_key_sub(uint32_t k) { return (int)(k & 1u); }
+WB_HD inline int wb_key_case(uint32_t k) { return (int)(k >> 27) & 15; }
+
+// ------------------------------------------------------------------ integer predicates
+WB_HD inline int64_t wb_orient(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t cx, int64_t cy) {
+    return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+}
+WB_HD inline bool wb_opposite(int64_t a, int64_t b) { return (a > 0 && b < 0) || (a < 0 && b > 0); }
+
+// Does the OPEN chord (p,q) meet the closed contour segment [a,b] in a point that is interior to
+// the contour?  a_end / b_end: a (b) is an end vertex of the contour polyline (contour boundary).
+// This is the per-segment term of `not chord.touches(contour)`, streamer_index.py:192-198.
+WB_HD inline bool wb_chord_hits_segment(int px, int py, int qx, int qy, int ax, int ay, int bx, int by,
+                                        bool a_end, bool b_end) {
+    const int64_t d1 = wb_orient(px, py, qx, qy, ax, ay);
+    const int64_t d2 = wb_orient(px, py, qx, qy, bx, by);
+    const int64_t dx = qx - px, dy = qy - py;
+    const int64_t L = dx * dx + dy * dy;
+    const int64_t ta = (int64_t)(ax - px) * dx + (int64_t)(ay - py) * dy;
+    const int64_t tb = (int64_t)(bx - px) * dx + (int64_t)(by - py) * dy;
+    if (d1 == 0 && d2 == 0) {  // collinear: overlap of positive length
+        int64_t lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
+        if (lo < 0) lo = 0;
+        if (hi > L) hi = L;
+        return hi > lo;
+    }
+    const int64_t d3 = wb_orient(ax, ay, bx, by, px, py);
+    const int64_t d4 = wb_orient(ax, ay, bx, by, qx, qy);
+    if (wb_opposite(d1, d2) && wb_opposite(d3, d4)) return true;  // proper crossing
+    if (d1 == 0 && ta > 0 && ta < L && !a_end) return true;        // contour vertex on the open chord
+    if (d2 == 0 && tb > 0 && tb < L && !b_end) return true;
+    return false;
+}
+
+WB_HD inline bool wb_on_closed(int ax, int ay, int bx, int by, int cx, int cy) {
+    return (ax < bx ? ax : bx) <= cx && cx <= (ax < bx ? bx : ax) && (ay < by ? ay : by) <= cy &&
+           cy <= (ay < by ? by : ay);
+}
+// closed segments [p1,q1] and [p2,q2] share a point (streamer_index.py:233-236, `intersects`)
+WB_HD inline bool wb_segments_intersect(int p1x, int p1y, int q1x, int q1y, int p2x, int p2y, int q2x, int q2y) {
+    const int64_t d1 = wb_orient(p1x, p1y, q1x, q1y, p2x, p2y);
+    const int64_t d2 = wb_orient(p1x, p1y, q1x, q1y, q2x, q2y);
+    const int64_t d3 = wb_orient(p2x, p2y, q2x, q2y, p1x, p1y);
+    const int64_t d4 = wb_orient(p2x, p2y, q2x, q2y, q1x, q1y);
+    if (wb_opposite(d1, d2) && wb_opposite(d3, d4)) return true;
+    if (d1 == 0 && wb_on_closed(p1x, p1y, q1x, q1y, p2x, p2y)) return true;
+    if (d2 == 0 && wb_on_closed(p1x, p1y, q1x, q1y, q2x, q2y)) return true;
+    if (d3 == 0 && wb_on_closed(p2x, p2y, q2x, q2y, p1x, p1y)) return true;
+    if (d4 == 0 && wb_on_closed(p2x, p2y, q2x, q2y, q1x, q1y)) return true;
+    return false;
+}
+
+// 64-bit mix for the open-addressing tables (splitmix64 finaliser)
+WB_HD inline uint64_t wb_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}

@@ -1,0 +1,605 @@
+// wb_indices.h -- phase 2 kernels: contour selection, overturning index, streamer index,
+// cutoff selection.  Host-simulable SPMD bodies (wb_spmd.h).
+//
+// Reference restated (file:line under the reference tree):
+//   selection      streamer_index.py:104-108, overturning_index.py:103-107, cutoff_index.py:87-93
+//   overturning    overturning_index.py:120-218
+//   streamer       streamer_index.py:119-272 (N x N test :130-139, |dx|>120 drop :157, four filters :160-264)
+#pragma once
+#include "wb_core.h"
+#include "wb_trace.h"
+
+// ------------------------------------------------------------------------------------------------
+// selection
+struct WbSelectArgs {
+    int njobs, cap_seg, gmax;      // gmax: global max of the distinct-x count (exp_lon.max() / dlon)
+    double dlon, co_min_exp;
+    const int* ncont;              // [njobs]
+    const int* c_nux;              // [njobs][cap_seg]
+    const int* c_closed;
+    int* nsel;                     // [njobs] number of contours with nux == gmax
+    int* ncut;                     // [njobs] number of cutoff contours
+    // second pass
+    const int* selbase;            // [njobs] exclusive scans of the above
+    const int* cutbase;
+    int* sel_job;                  // [total sel]
+    int* sel_cont;                 // [total sel] contour index inside the job
+    int* cut_job;
+    int* cut_cont;
+};
+
+WB_HD inline bool wb_is_cutoff(int nux, int closed, int gmax, double dlon, double min_exp) {
+    // cutoff_index.py:89-93: exp_lon < max & exp_lon >= min_exp & closed, exp_lon = len(set(x)) * dlon
+    return nux < gmax && ((double)nux * dlon >= min_exp) && closed;
+}
+
+WB_KERNEL(wb_k_select_count, WbSelectArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const size_t jb = (size_t)job * a.cap_seg;
+    WB_SINGLE
+    int s = 0, c = 0;
+    for (int k = 0; k < a.ncont[job]; ++k) {
+        if (a.c_nux[jb + k] == a.gmax) ++s;
+        if (wb_is_cutoff(a.c_nux[jb + k], a.c_closed[jb + k], a.gmax, a.dlon, a.co_min_exp)) ++c;
+    }
+    a.nsel[job] = s;
+    a.ncut[job] = c;
+    WB_END_SINGLE
+}
+
+WB_KERNEL(wb_k_scan_jobs, int n, int* a0, int* a1, int* totals) {
+    // single workgroup: in-place exclusive scans over the per-job counts
+    const int t0 = wb_block_scan_excl(a0, n);
+    const int t1 = wb_block_scan_excl(a1, n);
+    WB_SINGLE
+    totals[0] = t0;
+    totals[1] = t1;
+    WB_END_SINGLE
+}
+
+WB_KERNEL(wb_k_select_fill, WbSelectArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const size_t jb = (size_t)job * a.cap_seg;
+    WB_SINGLE
+    int s = a.selbase[job], c = a.cutbase[job];
+    for (int k = 0; k < a.ncont[job]; ++k) {
+        if (a.c_nux[jb + k] == a.gmax) { a.sel_job[s] = job; a.sel_cont[s] = k; ++s; }
+        if (wb_is_cutoff(a.c_nux[jb + k], a.c_closed[jb + k], a.gmax, a.dlon, a.co_min_exp)) {
+            a.cut_job[c] = job; a.cut_cont[c] = k; ++c;
+        }
+    }
+    WB_END_SINGLE
+}
+
+// ------------------------------------------------------------------------------------------------
+// overturning index, one workgroup per selected contour
+#define WB_OT_CAP 256        // groups per contour (>= W / (range_group/dlon + 1))
+#define WB_MAXW 4100
+
+struct WbOverturnArgs {
+    int nsel, cap_seg, nlon, W;
+    double rg_over_dlon;       // range_group / dlon
+    double minexp_over_dlon;   // min_exp / dlon
+    const int* sel_job;
+    const int* sel_cont;
+    const int* c_off;
+    const int* c_len;
+    const uint32_t* cpts;      // [njobs][2*cap_seg]
+    const double* lat;         // [nlat] degrees
+    // out, per selected contour
+    int* ot_n;                 // [nsel]
+    int* ot_box;               // [nsel][WB_OT_CAP][4] min_lon, min_lat, max_lon, max_lat (index units)
+    int* ot_orient;            // [nsel][WB_OT_CAP]    0 cyclonic, 1 anticyclonic
+    uint32_t* status;          // [njobs]
+};
+
+// set(range(a0, b0+1) % nlon) subset of set(range(a1, b1+1) % nlon)   (overturning_index.py:141-151)
+WB_HD inline bool wb_arc_subset(int a0, int b0, int a1, int b1, int nlon) {
+    const int l0 = b0 - a0 + 1, l1 = b1 - a1 + 1;
+    if (l1 >= nlon) return true;
+    if (l0 > l1) return false;  // also covers l0 >= nlon > l1
+    int off = (a0 - a1) % nlon;
+    if (off < 0) off += nlon;
+    return off + l0 <= l1;
+}
+
+WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    WB_SHARED(int, hist, WB_MAXW);
+    WB_SHARED(int, gmin, WB_OT_CAP);
+    WB_SHARED(int, gmax, WB_OT_CAP);
+    WB_SHARED(int, gdrop, WB_OT_CAP);
+    WB_SHARED(int, ylo, WB_OT_CAP);
+    WB_SHARED(int, yhi, WB_OT_CAP);
+    WB_SHARED(int, ifirst, WB_OT_CAP);
+    WB_SHARED(int, ilast, WB_OT_CAP);
+    WB_SHARED(int, gcount, 2);
+    int* box = a.ot_box + (size_t)s * WB_OT_CAP * 4;
+    int* orient = a.ot_orient + (size_t)s * WB_OT_CAP;
+
+    WB_PFOR(x, a.W)
+        hist[x] = 0;
+    WB_END_PFOR
+    WB_PFOR(i, N)
+        wb_atomic_add(&hist[wb_pt_x(pts[i])], 1);
+    WB_END_PFOR
+    // (1)-(3) longitudes visited >= 3 times, labelled by gaps > range_group/dlon, min/max per label
+    WB_SINGLE
+    int G = 0, prev = 0;
+    bool have = false, overflow = false;
+    for (int x = 0; x < a.W; ++x) {
+        if (hist[x] >= 3) {
+            if (!have || (double)(x - prev) > a.rg_over_dlon) {
+                if (G < WB_OT_CAP) { gmin[G] = x; gmax[G] = x; ++G; } else overflow = true;
+            } else if (!overflow) {
+                gmax[G - 1] = x;
+            }
+            have = true;
+            prev = x;
+        }
+    }
+    gcount[0] = G;
+    if (overflow) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+    WB_END_SINGLE
+    int G = gcount[0];
+    // check_duplicates (:136-162)
+    WB_PFOR(g, G)
+        gdrop[g] = 0;
+    WB_END_PFOR
+    WB_PFOR(pair, (int64_t)G * G)
+        const int g0 = (int)(pair / G), g1 = (int)(pair - (int64_t)g0 * G);
+        if (g0 != g1 && wb_arc_subset(gmin[g0], gmax[g0], gmin[g1], gmax[g1], a.nlon)) {
+            const int l0 = gmax[g0] - gmin[g0] + 1, l1 = gmax[g1] - gmin[g1] + 1;
+            const int d = (l0 == l1) ? (g0 > g1 ? g0 : g1) : (l0 < l1 ? g0 : g1);
+            gdrop[d] = 1;
+        }
+    WB_END_PFOR
+    // compaction; check_expansion (:164-166) only runs while rows remain (:185-188) -- same result
+    WB_SINGLE
+    int m = 0;
+    for (int g = 0; g < G; ++g) {
+        if (gdrop[g]) continue;
+        if (!((double)(gmax[g] - gmin[g]) >= a.minexp_over_dlon)) continue;
+        gmin[m] = gmin[g];
+        gmax[m] = gmax[g];
+        ++m;
+    }
+    gcount[1] = m;
+    WB_END_SINGLE
+    G = gcount[1];
+    // find_lat_expansion (:168-180) and the two orientation probes (:192-197)
+    WB_PFOR(g, G)
+        ylo[g] = 0x7FFFFFFF;
+        yhi[g] = -1;
+        ifirst[g] = 0x7FFFFFFF;
+        ilast[g] = -1;
+    WB_END_PFOR
+    WB_PFOR(i, N)
+        const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
+        for (int g = 0; g < G; ++g) {
+            if (x >= gmin[g] && x <= gmax[g]) {
+                wb_atomic_min(&ylo[g], y);
+                wb_atomic_max(&yhi[g], y);
+                if (x == gmin[g]) wb_atomic_min(&ifirst[g], (int)i);
+                if (x == gmax[g]) wb_atomic_max(&ilast[g], (int)i);
+            }
+        }
+    WB_END_PFOR
+    WB_PFOR(g, G)
+        const double lat_west = a.lat[wb_pt_y(pts[ifirst[g]])];
+        const double lat_east = a.lat[wb_pt_y(pts[ilast[g]])];
+        orient[g] = (fabs(lat_west) <= fabs(lat_east)) ? 0 : 1;
+        box[4 * g + 0] = gmin[g];
+        box[4 * g + 1] = ylo[g];
+        box[4 * g + 2] = gmax[g];
+        box[4 * g + 3] = yhi[g];
+    WB_END_PFOR
+    WB_SINGLE
+    a.ot_n[s] = G;
+    WB_END_SINGLE
+}
+
+// ------------------------------------------------------------------------------------------------
+// streamer index
+struct WbStreamerArgs {
+    int nsel, cap_seg, nlon, nlat, cap_pairs, cap_ev, hash_size;  // hash_size: pow2 >= 2*cap_pairs
+    double geo_dis, cont_dis;
+    double hthr;               // sin^2(geo_dis / (2*6371))
+    const int* sel_job;
+    const int* sel_cont;
+    const int* c_off;
+    const int* c_len;
+    const uint32_t* cpts;
+    // per-latitude / per-longitude tables (host libm): radians, sin(phi/2), cos(phi/2), cos(phi), ...
+    const double* lat_rad;     // [nlat]
+    const double* lon_rad;     // [nlon]
+    const double* sphi2;       // [nlat] sin(lat_rad/2)
+    const double* cphi2;       // [nlat] cos(lat_rad/2)
+    const double* cphi;        // [nlat] cos(lat_rad)
+    const double* slam2;       // [nlon] sin(lon_rad/2)
+    const double* clam2;       // [nlon] cos(lon_rad/2)
+    // per selected contour
+    double* on;                // [nsel][2*cap_seg] on[k] = d(k-1, k) * 6371, on[0] = 0
+    double* pre;               // [nsel][2*cap_seg] inclusive prefix of on
+    unsigned long long* pairs; // [nsel][cap_pairs] (ind1 << 32 | ind2)
+    int* alive;                // [nsel][cap_pairs]
+    int* npairs;               // [nsel]
+    int* stage;                // [nsel] how many of the four routines have been applied
+    int* nalive;               // [nsel] rows left after the last applied routine
+    unsigned long long* hkey;  // [nsel][hash_size]
+    unsigned long long* hval;  // [nsel][hash_size]
+    int* rowmax;               // [nsel][2*cap_seg]
+    int* rowaux;               // [nsel][2*cap_seg]
+    int* ev_ind;               // [nsel][cap_ev][2]
+    int* ev_n;                 // [nsel]
+    int* band_hits;            // [2] pairs inside the geo / cont guard bands (re-evaluated exactly)
+    uint32_t* status;          // [njobs]
+};
+
+// sklearn's haversine on radians, float64 (streamer_index.py:130): 2 asin(sqrt(sin^2 + cos cos sin^2))
+WB_HD inline double wb_haversine(double la1, double lo1, double la2, double lo2) {
+    const double s0 = sin(0.5 * (la1 - la2));
+    const double s1 = sin(0.5 * (lo1 - lo2));
+    return 2.0 * asin(sqrt(s0 * s0 + cos(la1) * cos(la2) * s1 * s1));
+}
+
+#define WB_GEO_BAND 1e-11     // relative guard band on h = sin^2(d/2R) around its threshold
+#define WB_CONT_BAND 1e-6     // absolute guard band (km) on the along-contour distance
+
+// per selected contour: on[] and its prefix (streamer_index.py:133)
+WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    double* on = a.on + (size_t)s * 2 * a.cap_seg;
+    double* pre = a.pre + (size_t)s * 2 * a.cap_seg;
+    WB_PFOR(i, N)
+        double d = 0.0;
+        if (i > 0) {
+            const uint32_t p0 = pts[i - 1], p1 = pts[i];
+            d = wb_haversine(a.lat_rad[wb_pt_y(p0)], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[wb_pt_y(p1)],
+                             a.lon_rad[wb_pt_x(p1) % a.nlon]) * 6371.0;
+        }
+        on[i] = d;
+    WB_END_PFOR
+    WB_SINGLE
+    double run = 0.0;
+    for (int i = 0; i < N; ++i) {
+        run = run + on[i];
+        pre[i] = run;
+    }
+    a.npairs[s] = 0;
+    a.stage[s] = 0;
+    a.ev_n[s] = 0;
+    WB_END_SINGLE
+}
+
+// all-pairs test; grid = nsel * tiles, each workgroup owns WB_PAIR_ROWS rows i and sweeps j > i
+#define WB_PAIR_ROWS 16
+
+struct WbPairGrid { int tiles; };
+
+WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
+    const int s = WB_BLOCK_ID / tiles, tile = WB_BLOCK_ID - s * tiles;
+    if (s >= a.nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    const double* on = a.on + (size_t)s * 2 * a.cap_seg;
+    const double* pre = a.pre + (size_t)s * 2 * a.cap_seg;
+    unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    const int i0 = tile * WB_PAIR_ROWS;
+    for (int ii = 0; ii < WB_PAIR_ROWS; ++ii) {
+        const int i = i0 + ii;
+        if (i >= N - 1) break;
+        const uint32_t pi = pts[i];
+        const int xi = wb_pt_x(pi), yi = wb_pt_y(pi), xim = xi % a.nlon;
+        const double spi = a.sphi2[yi], cpi = a.cphi2[yi], ci = a.cphi[yi];
+        const double sli = a.slam2[xim], cli = a.clam2[xim];
+        const double prei = pre[i];
+        WB_PFOR(jj, N - 1 - i)
+            const int j = i + 1 + (int)jj;
+            const uint32_t pj = pts[j];
+            const int xj = wb_pt_x(pj), yj = wb_pt_y(pj), xjm = xj % a.nlon;
+            int dx = xi - xj;
+            if (dx < 0) dx = -dx;
+            if (dx > 120) continue;                                   // streamer_index.py:157
+            // sin((phi_i - phi_j)/2), sin((lam_i - lam_j)/2) by the subtraction formulas
+            const double sa = spi * a.cphi2[yj] - cpi * a.sphi2[yj];
+            const double sb = sli * a.clam2[xjm] - cli * a.slam2[xjm];
+            const double h = sa * sa + ci * a.cphi[yj] * (sb * sb);
+            bool near_geo;
+            if (fabs(h - a.hthr) <= WB_GEO_BAND * a.hthr) {            // guard band: evaluate as sklearn does
+                wb_atomic_add(&a.band_hits[0], 1);
+                const double geo = wb_haversine(a.lat_rad[yi], a.lon_rad[xim], a.lat_rad[yj], a.lon_rad[xjm]) * 6371.0;
+                near_geo = geo < a.geo_dis;
+            } else {
+                near_geo = h < a.hthr;
+            }
+            if (!near_geo) continue;
+            double cont = pre[j] - prei;
+            if (fabs(cont - a.cont_dis) <= WB_CONT_BAND) {            // guard band: sequential row cumsum (:135)
+                wb_atomic_add(&a.band_hits[1], 1);
+                double acc = 0.0;
+                for (int m = i + 1; m <= j; ++m) acc = acc + on[m];
+                cont = acc;
+            }
+            if (!(cont > a.cont_dis)) continue;
+            const int slot = wb_atomic_add(&a.npairs[s], 1);
+            if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
+        WB_END_PFOR
+    }
+}
+
+// routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264
+WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    int* alive = a.alive + (size_t)s * a.cap_pairs;
+    unsigned long long* hkey = a.hkey + (size_t)s * a.hash_size;
+    unsigned long long* hval = a.hval + (size_t)s * a.hash_size;
+    const int hmask = a.hash_size - 1;
+    WB_SHARED(int, cnt, 1);
+    int P = a.npairs[s];
+    if (P > a.cap_pairs) {
+        WB_SINGLE
+        wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+        a.nalive[s] = 0;
+        a.stage[s] = 4;
+        WB_END_SINGLE
+        return;
+    }
+    WB_PFOR(p, P)
+        alive[p] = 1;
+    WB_END_PFOR
+    if (P <= 1) {
+        WB_SINGLE
+        a.nalive[s] = P;
+        a.stage[s] = 0;   // no routine applied: `while len(df_bp.index) > 1`
+        WB_END_SINGLE
+        return;
+    }
+    WB_PFOR(q, a.hash_size)
+        hkey[q] = WB_HEMPTY;
+        hval[q] = WB_HEMPTY;
+    WB_END_PFOR
+    WB_PFOR(p, P)
+        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
+        const uint32_t pi = pts[i], pj = pts[j];
+        const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
+                                       ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
+                                       ((unsigned long long)wb_pt_y(pj) << 48);
+        int fresh;
+        const int slot = wb_hash_insert(hkey, hmask, key, &fresh);
+        if (slot >= 0) wb_atomic_min(&hval[slot], pairs[p]);
+    WB_END_PFOR
+    WB_SINGLE
+    cnt[0] = 0;
+    WB_END_SINGLE
+    WB_PFOR(p, P)
+        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
+        const uint32_t pi = pts[i], pj = pts[j];
+        const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
+                                       ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
+                                       ((unsigned long long)wb_pt_y(pj) << 48);
+        const int slot = wb_hash_find(hkey, hmask, key);
+        // of the pairs that coincide after x mod nlon the first (in frame order = (ind1, ind2) order) stays
+        if (slot >= 0 && hval[slot] != pairs[p]) alive[p] = 0;
+        else wb_atomic_add(&cnt[0], 1);
+    WB_END_PFOR
+    WB_SINGLE
+    a.nalive[s] = cnt[0];
+    a.stage[s] = 1;
+    WB_END_SINGLE
+}
+
+// routine 2: check_intersections (:185-200). grid = nsel * chunks; a workgroup takes WB_F2_PAIRS pairs
+#define WB_F2_PAIRS 8
+WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, int chunks) {
+    const int s = WB_BLOCK_ID / chunks, chunk = WB_BLOCK_ID - s * chunks;
+    if (s >= a.nsel) return;
+    if (a.stage[s] != 1 || a.nalive[s] <= 1) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    int* alive = a.alive + (size_t)s * a.cap_pairs;
+    const int P = a.npairs[s];
+    WB_SHARED(int, hit, 1);
+    for (int pp = 0; pp < WB_F2_PAIRS; ++pp) {
+        const int p = chunk * WB_F2_PAIRS + pp;
+        if (p >= P) break;
+        if (!alive[p]) continue;
+        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
+        const int px = wb_pt_x(pts[i]), py = wb_pt_y(pts[i]), qx = wb_pt_x(pts[j]), qy = wb_pt_y(pts[j]);
+        WB_SINGLE
+        hit[0] = 0;
+        WB_END_SINGLE
+        WB_PFOR(m, N - 1)
+            const uint32_t pa = pts[m], pb = pts[m + 1];
+            if (wb_chord_hits_segment(px, py, qx, qy, wb_pt_x(pa), wb_pt_y(pa), wb_pt_x(pb), wb_pt_y(pb), m == 0,
+                                      m == N - 2))
+                hit[0] = 1;
+        WB_END_PFOR
+        if (hit[0]) {
+            WB_SINGLE
+            alive[p] = 2;   // 2 = rejected by routine 2 (turned into 0 by f3)
+            WB_END_SINGLE
+        }
+    }
+}
+
+// routines 3 and 4: check_overlapping (:202-222), check_groups (:224-251), then the polygons' end points
+WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    const double* pre = a.pre + (size_t)s * 2 * a.cap_seg;
+    const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    int* alive = a.alive + (size_t)s * a.cap_pairs;
+    int* rowmax = a.rowmax + (size_t)s * 2 * a.cap_seg;   // per ind1: largest surviving ind2
+    int* aux = a.rowaux + (size_t)s * 2 * a.cap_seg;
+    int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
+    unsigned long long* best = a.hval + (size_t)s * a.hash_size;  // reused: per group best value / index
+    WB_SHARED(int, cnt, 2);
+    const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
+    int stage = a.stage[s];
+    int nal = a.nalive[s];
+
+    if (stage == 1 && nal > 1) {   // finish routine 2's bookkeeping
+        WB_SINGLE
+        cnt[0] = 0;
+        WB_END_SINGLE
+        WB_PFOR(p, P)
+            if (alive[p] == 2) alive[p] = 0;
+            if (alive[p]) wb_atomic_add(&cnt[0], 1);
+        WB_END_PFOR
+        nal = cnt[0];
+        stage = 2;
+    }
+    if (stage == 2 && nal > 1) {   // routine 3: a pair inside another pair's [ind1, ind2] range goes
+        WB_PFOR(i, N)
+            rowmax[i] = -1;
+        WB_END_PFOR
+        WB_PFOR(p, P)
+            if (alive[p]) wb_atomic_max(&rowmax[(int)(pairs[p] >> 32)], (int)(pairs[p] & 0xFFFFFFFFull));
+        WB_END_PFOR
+        WB_SINGLE
+        int run = -1;                 // aux[i] = max ind2 over rows < i
+        for (int i = 0; i < N; ++i) {
+            aux[i] = run;
+            if (rowmax[i] > run) run = rowmax[i];
+        }
+        cnt[0] = 0;
+        WB_END_SINGLE
+        WB_PFOR(p, P)
+            if (alive[p]) {
+                const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
+                if (j != rowmax[i] || aux[i] >= j) alive[p] = 0;
+                else wb_atomic_add(&cnt[0], 1);
+            }
+        WB_END_PFOR
+        nal = cnt[0];
+        stage = 3;
+    }
+
+    // survivors in (ind1, ind2) order.  After routine 3 there is at most one per row; before it
+    // (early exits) there is at most one survivor in total.
+    WB_PFOR(i, N)
+        rowmax[i] = -1;
+    WB_END_PFOR
+    WB_PFOR(p, P)
+        if (alive[p] == 1) rowmax[(int)(pairs[p] >> 32)] = (int)(pairs[p] & 0xFFFFFFFFull);
+    WB_END_PFOR
+    WB_PFOR(i, N)
+        aux[i] = rowmax[i] >= 0 ? 1 : 0;
+    WB_END_PFOR
+    const int M = wb_block_scan_excl(aux, N);   // aux[i] = rank of row i among survivors
+    int* mi = (int*)a.hkey + (size_t)s * a.hash_size * 2;          // [M] ind1 of survivor m  (reuses the table)
+    int* mj = mi + M;                                                // [M] ind2
+    int* lab = mj + M;                                               // [M] group label
+    WB_PFOR(i, N)
+        if (rowmax[i] >= 0) {
+            mi[aux[i]] = (int)i;
+            mj[aux[i]] = rowmax[i];
+        }
+    WB_END_PFOR
+
+    if (stage == 3 && nal > 1) {   // routine 4: group chords that intersect; keep the longest of each group
+        WB_PFOR(m, M)
+            lab[m] = (int)m;
+        WB_END_PFOR
+        for (int iter = 0; iter < M; ++iter) {
+            WB_SINGLE
+            cnt[1] = 0;
+            WB_END_SINGLE
+            WB_PFOR(pair, (int64_t)M * M)
+                const int m1 = (int)(pair / M), m2 = (int)(pair - (int64_t)m1 * M);
+                if (m1 < m2 && lab[m1] != lab[m2]) {
+                    const uint32_t a1 = pts[mi[m1]], b1 = pts[mj[m1]], a2 = pts[mi[m2]], b2 = pts[mj[m2]];
+                    if (wb_segments_intersect(wb_pt_x(a1), wb_pt_y(a1), wb_pt_x(b1), wb_pt_y(b1), wb_pt_x(a2), wb_pt_y(a2),
+                                              wb_pt_x(b2), wb_pt_y(b2))) {
+                        // hook the larger root under the smaller one (labels are roots after the shortcut pass)
+                        const int l1 = lab[m1], l2 = lab[m2];
+                        if (l1 != l2) {
+                            wb_atomic_min(&lab[l1 > l2 ? l1 : l2], l1 < l2 ? l1 : l2);
+                            cnt[1] = 1;
+                        }
+                    }
+                }
+            WB_END_PFOR
+            WB_PFOR(m, M)   // shortcut labels to their root
+                int l = lab[m];
+                while (lab[l] != l) l = lab[l];
+                lab[m] = l;
+            WB_END_PFOR
+            if (!cnt[1]) break;
+        }
+        // per group: max of on[ind1 : ind2+1].sum()  (= pre[ind2] - pre[ind1-1]); ties -> lowest member
+        WB_PFOR(m, M)
+            best[m] = 0ull;
+            best[M + m] = WB_HEMPTY;
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
+            unsigned long long bits;
+            memcpy(&bits, &v, 8);
+            wb_atomic_max(&best[lab[m]], bits);
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
+            unsigned long long bits;
+            memcpy(&bits, &v, 8);
+            if (bits == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
+        WB_END_PFOR
+        const int Gn = wb_block_scan_excl(aux, M);
+        WB_PFOR(m, M)
+            if (lab[m] == (int)m && aux[m] < a.cap_ev) {
+                const int w = (int)best[M + m];
+                ev[2 * aux[m] + 0] = mi[w];
+                ev[2 * aux[m] + 1] = mj[w];
+            }
+        WB_END_PFOR
+        WB_SINGLE
+        a.ev_n[s] = Gn < a.cap_ev ? Gn : a.cap_ev;
+        if (Gn > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+        a.stage[s] = 4;
+        a.nalive[s] = Gn;
+        WB_END_SINGLE
+    } else {
+        WB_PFOR(m, M)
+            if (m < a.cap_ev) {
+                ev[2 * m + 0] = mi[m];
+                ev[2 * m + 1] = mj[m];
+            }
+        WB_END_PFOR
+        WB_SINGLE
+        a.ev_n[s] = M < a.cap_ev ? M : a.cap_ev;
+        if (M > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+        a.stage[s] = stage;
+        a.nalive[s] = nal;
+        WB_END_SINGLE
+    }
+}

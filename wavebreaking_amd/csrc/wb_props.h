@@ -1,0 +1,207 @@
+// wb_props.h -- event cells and area-weighted sums (one workgroup per event, persistent over events).
+//
+// Restates wavebreaking/utils/index_utils.py:35-102 (calculate_properties): the cells of an event are
+// the lattice points contained in polygon.buffer((dlon+dlat)/4) (:37-51); on a lattice polygon that is
+// {winding != 0} U {distance to the boundary < r} (oracle/geom.py).  The polygon is
+// rasterised by scanline crossing counts (signed, suffix-summed per row), the rim by exact
+// point-segment distance tests around every edge; sums follow :58-102.
+//
+// Sum order contract shared with the oracle (oracle/properties.py:event_sums): areas, x_com, y_com are
+// accumulated over rows in ascending y from exact per-row integer counts, one rounding per multiply and
+// one per add (no FMA contraction), because `com` truncates their ratio (:105-110).
+#pragma once
+#include "wb_core.h"
+
+#if !defined(WB_HOSTSIM)
+#pragma clang fp contract(off)
+#endif
+
+enum { WB_EV_STREAMER = 0, WB_EV_OVERTURNING = 1, WB_EV_CUTOFF = 2 };
+
+struct WbPropsArgs {
+    int nev, nslots, nlat, nlon, W, cap_seg, nlev, dtype, want_cells, pad;
+    double r2;                  // buffer radius squared, ((dlon+dlat)/4)^2 in index units
+    const int* ev;              // [nev][8]: kind, job, contour, a0..a3, orientation
+    const int* c_off;
+    const int* c_len;
+    const uint32_t* cpts;
+    const void* data;           // [nt][nlat][nlon]
+    const void* intensity;      // or NULL
+    const double* wlat;         // [nlat] cos(radians(lat)) * area_cell   (:58-62)
+    int* cells;                 // [nslots][W*nlat]
+    double* rowacc;             // [nslots][4][nlat]
+    double* ev_sums;            // [nev][5]: areas, mean_var, intensity, x_com, y_com  (sums, :94-102)
+    int* ev_ncells;             // [nev]
+    unsigned long long* cell_count;  // [1] bump allocator of the cell pool
+    unsigned long long cell_cap;
+    uint32_t* cell_pool;        // (x | y<<16)
+    long long* ev_cell_off;     // [nev]
+};
+
+WB_HD inline double wb_load_field(const void* p, size_t idx, int dtype) {
+    return dtype == 0 ? (double)((const float*)p)[idx] : ((const double*)p)[idx];
+}
+
+WB_DEV inline uint32_t wb_event_vertex(const int* d, const uint32_t* pts, int k) {
+    const int kind = d[0];
+    if (kind == WB_EV_STREAMER) return pts[d[3] + k];
+    if (kind == WB_EV_CUTOFF) return pts[k];
+    // shapely.geometry.box(minx, miny, maxx, maxy): (maxx,miny),(maxx,maxy),(minx,maxy),(minx,miny)
+    const int x = (k == 0 || k == 1) ? d[5] : d[3];
+    const int y = (k == 1 || k == 2) ? d[6] : d[4];
+    return (uint32_t)x | ((uint32_t)y << 16);
+}
+
+WB_KERNEL(wb_k_props, WbPropsArgs a) {
+    WB_SHARED(int, bb, 4);
+    WB_SHARED(long long, sh_off, 1);
+    const int slot = WB_BLOCK_ID;
+    int* cells = a.cells + (size_t)slot * a.W * a.nlat;
+    double* rowacc = a.rowacc + (size_t)slot * 4 * a.nlat;
+    for (int e = WB_BLOCK_ID; e < a.nev; e += WB_GRID_DIM) {
+        const int* d = a.ev + (size_t)e * 8;
+        const int kind = d[0], job = d[1], cont = d[2];
+        const size_t jb = (size_t)job * a.cap_seg;
+        const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + cont];
+        const int n = (kind == WB_EV_STREAMER) ? (d[4] - d[3] + 1) : (kind == WB_EV_CUTOFF ? a.c_len[jb + cont] : 4);
+        const size_t tbase = (size_t)(job / a.nlev) * a.nlat * a.nlon;
+
+        WB_SINGLE
+        bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
+        WB_END_SINGLE
+        WB_PFOR(k, n)
+            const uint32_t v = wb_event_vertex(d, pts, (int)k);
+            wb_atomic_min(&bb[0], wb_pt_x(v));
+            wb_atomic_min(&bb[1], wb_pt_y(v));
+            wb_atomic_max(&bb[2], wb_pt_x(v));
+            wb_atomic_max(&bb[3], wb_pt_y(v));
+        WB_END_PFOR
+        const int x0 = bb[0] - a.pad < 0 ? 0 : bb[0] - a.pad;
+        const int y0 = bb[1] - a.pad < 0 ? 0 : bb[1] - a.pad;
+        const int x1 = bb[2] + a.pad > a.W - 1 ? a.W - 1 : bb[2] + a.pad;
+        const int y1 = bb[3] + a.pad > a.nlat - 1 ? a.nlat - 1 : bb[3] + a.pad;
+        const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
+        WB_PFOR(idx, (int64_t)rows * cols)
+            cells[idx] = 0;
+        WB_END_PFOR
+        // A: signed crossing counts.  Edge a->b spanning row y (half-open in y) covers all x < x_cross.
+        WB_PFOR(k, n)
+            const uint32_t va = wb_event_vertex(d, pts, (int)k), vb = wb_event_vertex(d, pts, (int)((k + 1) % n));
+            const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+            if (ay != by) {
+                const int sgn = by > ay ? 1 : -1;
+                const int ylo = ay < by ? ay : by, yhi = ay < by ? by : ay;
+                for (int y = ylo; y < yhi; ++y) {
+                    long long num = (long long)(y - ay) * (bx - ax), den = by - ay;
+                    if (den < 0) { num = -num; den = -den; }
+                    const long long cdiv = num >= 0 ? (num + den - 1) / den : -((-num) / den);
+                    long long ecol = (long long)ax + cdiv - 1;          // last lattice x strictly left of the crossing
+                    if (ecol >= x0) {
+                        if (ecol > x1) ecol = x1;
+                        wb_atomic_add(&cells[(size_t)(y - y0) * cols + (int)(ecol - x0)], sgn);
+                    }
+                }
+            }
+        WB_END_PFOR
+        // B: suffix sums -> winding number != 0
+        WB_PFOR(rr, rows)
+            int run = 0;
+            int* row = cells + (size_t)rr * cols;
+            for (int x = cols - 1; x >= 0; --x) {
+                run += row[x];
+                row[x] = run != 0 ? 1 : 0;
+            }
+        WB_END_PFOR
+        // C: rim: lattice points closer than r to an edge (boundary points included: d = 0)
+        WB_PFOR(k, n)
+            const uint32_t va = wb_event_vertex(d, pts, (int)k), vb = wb_event_vertex(d, pts, (int)((k + 1) % n));
+            const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+            int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
+            int ey0 = (ay < by ? ay : by) - a.pad, ey1 = (ay < by ? by : ay) + a.pad;
+            if (ex0 < x0) ex0 = x0;
+            if (ex1 > x1) ex1 = x1;
+            if (ey0 < y0) ey0 = y0;
+            if (ey1 > y1) ey1 = y1;
+            const long long dx = bx - ax, dy = by - ay, L = dx * dx + dy * dy;
+            for (int y = ey0; y <= ey1; ++y)
+                for (int x = ex0; x <= ex1; ++x) {
+                    const long long t = (long long)(x - ax) * dx + (long long)(y - ay) * dy;
+                    bool near;
+                    if (L == 0 || t <= 0) {
+                        near = (double)((long long)(x - ax) * (x - ax) + (long long)(y - ay) * (y - ay)) < a.r2;
+                    } else if (t >= L) {
+                        near = (double)((long long)(x - bx) * (x - bx) + (long long)(y - by) * (y - by)) < a.r2;
+                    } else {
+                        const long long cr = dx * (long long)(y - ay) - dy * (long long)(x - ax);
+                        near = ((double)cr * (double)cr) / (double)L < a.r2;
+                    }
+                    if (near) cells[(size_t)(y - y0) * cols + (x - x0)] = 1;
+                }
+        WB_END_PFOR
+        // D: per-row counts and sums
+        WB_PFOR(rr, rows)
+            const int y = y0 + (int)rr;
+            const int* row = cells + (size_t)rr * cols;
+            long long cnt = 0, sx = 0;
+            double sv = 0.0, si = 0.0;
+            for (int x = 0; x < cols; ++x) {
+                if (row[x]) {
+                    const int gx = x0 + x;
+                    ++cnt;
+                    sx += gx;
+                    const size_t idx = tbase + (size_t)y * a.nlon + (size_t)(gx % a.nlon);
+                    sv += wb_load_field(a.data, idx, a.dtype);
+                    if (a.intensity) si += wb_load_field(a.intensity, idx, a.dtype);
+                }
+            }
+            rowacc[0 * a.nlat + y] = (double)cnt;
+            rowacc[1 * a.nlat + y] = (double)sx;
+            rowacc[2 * a.nlat + y] = sv;
+            rowacc[3 * a.nlat + y] = si;
+        WB_END_PFOR
+        WB_SINGLE
+        double areas = 0.0, mv = 0.0, it = 0.0, xc = 0.0, yc = 0.0;
+        long long nc = 0;
+        for (int y = y0; y <= y1; ++y) {
+            const double cnt = rowacc[0 * a.nlat + y];
+            if (cnt == 0.0) continue;
+            const double w = a.wlat[y];
+            areas = areas + w * cnt;
+            xc = xc + w * rowacc[1 * a.nlat + y];
+            yc = yc + w * ((double)y * cnt);
+            mv = mv + w * rowacc[2 * a.nlat + y];
+            it = it + w * rowacc[3 * a.nlat + y];
+            nc += (long long)cnt;
+        }
+        a.ev_sums[(size_t)e * 5 + 0] = areas;
+        a.ev_sums[(size_t)e * 5 + 1] = mv;
+        a.ev_sums[(size_t)e * 5 + 2] = it;
+        a.ev_sums[(size_t)e * 5 + 3] = xc;
+        a.ev_sums[(size_t)e * 5 + 4] = yc;
+        a.ev_ncells[e] = (int)nc;
+        long long off = -1;
+        if (a.want_cells) {
+            off = (long long)wb_atomic_add(a.cell_count, (unsigned long long)nc);
+            if ((unsigned long long)off + (unsigned long long)nc > a.cell_cap) off = -1;
+            // per-row start offsets (rows ascending, x ascending inside a row)
+            long long run = off;
+            for (int y = y0; y <= y1; ++y) {
+                const double cnt = rowacc[0 * a.nlat + y];
+                rowacc[0 * a.nlat + y] = (double)run;
+                run += (long long)cnt;
+            }
+            a.ev_cell_off[e] = off;
+        }
+        sh_off[0] = off;
+        WB_END_SINGLE
+        if (a.want_cells && sh_off[0] >= 0) {
+            WB_PFOR(rr, rows)
+                const int y = y0 + (int)rr;
+                const int* row = cells + (size_t)rr * cols;
+                long long o = (long long)rowacc[0 * a.nlat + y];
+                for (int x = 0; x < cols; ++x)
+                    if (row[x]) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
+            WB_END_PFOR
+        }
+    }
+}

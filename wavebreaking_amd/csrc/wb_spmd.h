@@ -1,0 +1,122 @@
+// wb_spmd.h -- the thin SPMD layer every kernel body is written against.
+//
+// Product build (hipcc, gfx950): a kernel is a __global__ function, WB_PFOR is a
+// block-strided loop followed by __syncthreads(), atomics are HIP atomics, scans use
+// 64-wide wave shuffles + LDS.
+//
+// Host-simulation build (-DWB_HOSTSIM, g++ with ASan/UBSan; TEST INFRASTRUCTURE ONLY,
+// built into tests/_hostsim/ and never loaded by the package): a kernel is a plain
+// function run once per block index, WB_PFOR runs its iterations one after another in
+// ascending -- or, with WB_HOSTSIM_REVERSE, descending -- order (a phase whose result
+// depends on that order has a race), atomics are plain read-modify-writes.  This is how
+// the irregular kernels are debugged in the GPU-less build container.
+#pragma once
+#include <stdint.h>
+
+#if defined(WB_HOSTSIM)
+// ---------------------------------------------------------------- host simulation
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#define WB_HD
+#define WB_DEV
+#define WB_KERNEL(name, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
+#define WB_BLOCK_ID wb_block_id
+#define WB_GRID_DIM wb_grid_dim
+#define WB_NT 1
+#define WB_TID 0
+extern int wb_hostsim_reverse;
+#define WB_PFOR(i, n)                                                                    \
+    for (int64_t wb_k_##i = 0, wb_n_##i = (int64_t)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
+        const int64_t i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;
+#define WB_END_PFOR }
+#define WB_SINGLE {
+#define WB_END_SINGLE }
+#define WB_SYNC() ((void)0)
+#define WB_SHARED(type, name, n) type name[n]
+template <class T> static inline T wb_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T wb_atomic_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T wb_atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T wb_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T wb_atomic_cas(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+static inline int wb_popc32(uint32_t v) { return __builtin_popcount(v); }
+static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
+
+// in-place exclusive scan of a[0..n); returns the total
+static inline int wb_block_scan_excl(int* a, int n) {
+    int run = 0;
+    for (int i = 0; i < n; ++i) { int v = a[i]; a[i] = run; run += v; }
+    return run;
+}
+
+#else
+// ---------------------------------------------------------------- HIP / gfx950
+#include <hip/hip_runtime.h>
+#define WB_HD __host__ __device__
+#define WB_DEV __device__
+#define WB_KERNEL(name, ...) __global__ void name(__VA_ARGS__)
+#define WB_BLOCK_ID ((int)blockIdx.x)
+#define WB_GRID_DIM ((int)gridDim.x)
+#define WB_NT ((int)blockDim.x)
+#define WB_TID ((int)threadIdx.x)
+#define WB_PFOR(i, n)                                                              \
+    {                                                                              \
+        for (int64_t i = WB_TID, wb_n_##i = (int64_t)(n); i < wb_n_##i; i += WB_NT) {
+#define WB_END_PFOR \
+        }           \
+        __syncthreads(); \
+    }
+#define WB_SINGLE if (WB_TID == 0) {
+#define WB_END_SINGLE \
+    }                 \
+    __syncthreads();
+#define WB_SYNC() __syncthreads()
+#define WB_SHARED(type, name, n) __shared__ type name[n]
+template <class T> __device__ inline T wb_atomic_add(T* p, T v) { return atomicAdd(p, v); }
+template <class T> __device__ inline T wb_atomic_min(T* p, T v) { return atomicMin(p, v); }
+template <class T> __device__ inline T wb_atomic_max(T* p, T v) { return atomicMax(p, v); }
+template <class T> __device__ inline T wb_atomic_or(T* p, T v) { return atomicOr(p, v); }
+template <class T> __device__ inline T wb_atomic_cas(T* p, T cmp, T v) { return atomicCAS(p, cmp, v); }
+__device__ inline int wb_popc32(uint32_t v) { return __popc(v); }
+__device__ inline int wb_popc64(uint64_t v) { return __popcll(v); }
+
+// 64-wide inclusive wave scan (gfx950 wavefront = 64)
+__device__ inline int wb_wave_scan_incl(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// in-place exclusive scan of a[0..n) (global or LDS), all threads of the block call it;
+// returns the total to every thread.  Chunks of blockDim.x elements, running carry.
+__device__ inline int wb_block_scan_excl(int* a, int n) {
+    __shared__ int wb_scan_wave[16];
+    __shared__ int wb_scan_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    if (tid == 0) wb_scan_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + tid;
+        const int v = (i < n) ? a[i] : 0;
+        const int inc = wb_wave_scan_incl(v);
+        if (lane == 63) wb_scan_wave[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wb_scan_wave[w];
+        const int carry = wb_scan_carry;
+        if (i < n) a[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < nw; ++w) tot += wb_scan_wave[w];
+            wb_scan_carry = carry + tot;
+        }
+        __syncthreads();
+    }
+    return wb_scan_carry;
+}
+#endif
