@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py -- timesteps/s of the WaveBreaking hot path on synthetic ERA5-shaped 0.25 degree PV.
+
+One "step" = one pass of the whole hot path (contours of every (time step, level) + streamer,
+overturning and cutoff indices + event/contour tables back in host memory) over ONE resident batch of
+`--nt` synthetic time steps per GPU (default 1460 = one year 6-hourly, BASELINE.json configs[2]).
+Inputs are generated on the device and are resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: time steps are sharded across ranks (weak scaling: every rank owns --nt steps of the synthetic
+40-year record, rank r starting at r*nt), one all-reduce(max) of the distinct-longitude count
+(contours.exp_lon.max() over the whole frame, streamer_index.py:106) and one gather of the event tables
+to rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+HBM_MEASURED = 6.29e12     # float4 copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nt", type=int, default=int(os.environ.get("WB_BENCH_NT", 1460)), help="time steps per GPU per pass")
+    ap.add_argument("--dlon", type=float, default=0.25)
+    ap.add_argument("--eps", type=float, default=0.0, help="cell noise amplitude (0 = smoothed PV, 0.3 = rough)")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 4)),
+                    help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-intensity", action="store_true")
+    return ap.parse_args()
+
+
+def gather_events(tables, rank, world, dist, torch, device):
+    """One gather of the event tables to rank 0 (counts first, then the payload)."""
+    payload = np.concatenate([np.asarray(t, dtype=np.float64).ravel() for t in tables]) if tables else np.zeros(0)
+    n = torch.tensor([payload.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(mx, dtype=torch.float64, device=device)
+    buf[: payload.size] = torch.from_numpy(payload).to(device)
+    out = [torch.zeros(mx, dtype=torch.float64, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank == 0:
+        return [o[: int(s.item())].cpu().numpy() for o, s in zip(out, sizes)]
+    return None
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from oracle import synth
+    from wavebreaking_amd import _hip
+
+    ctx = _hip.Context(local)
+    lat, lon = synth.grid(a.dlon)
+    nlat, nlon, nt = lat.size, lon.size, a.nt
+    levels = [-2.0, 2.0]
+    t0 = rank * nt
+    par = synth.wave_params()
+    fbytes = nt * nlat * nlon * 4
+    d_pv = ctx.alloc(fbytes)
+    ctx.synth_fill(d_pv, np.float32, t0, nt, lat, lon, par, a.eps, synth.SEED)
+    d_int = None
+    if not a.no_intensity:
+        d_int = ctx.alloc(fbytes)
+        ctx.synth_fill(d_int, np.float32, t0, nt, lat, lon, synth.wave_params(20241), a.eps, 20241)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stage_ms = {}
+    counts = {}
+
+    def one_pass(collect=False):
+        b = ctx.contours(d_pv, lat, lon, levels, a.dlon, a.dlon, intensity=d_int, device_shape=(nt, nlat, nlon),
+                         device_dtype=np.float32, want_cells=False)
+        g = b.max_nux()
+        if world > 1:
+            gt = torch.tensor([g], dtype=torch.int32, device=device)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            g = int(gt.item())
+        b.indices(g)
+        ct = b.contour_table()
+        ev = [b.events(k) for k in (0, 1, 2)]
+        if world > 1:
+            tabs = []
+            for e in ev:
+                tabs += [e["step"] + t0, e["level_idx"], e["ind1"], e["ind2"], e["box"], e["orientation"], e["sums"]]
+            gathered = gather_events(tabs, rank, world, dist, torch, device)
+        if collect:
+            for name, ms in b.timings():
+                stage_ms.setdefault(name, []).append(ms)
+            counts.update(contours=int(ct["step"].size), contour_points=int(ct["x"].size),
+                          streamers=int(ev[0]["step"].size), overturnings=int(ev[1]["step"].size),
+                          cutoffs=int(ev[2]["step"].size), band_hits=b.band_hits(),
+                          status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0)
+        b.close()
+        return ev
+
+    for _ in range(a.warmup):
+        one_pass()
+    barrier()
+    tic = time.perf_counter()
+    for _ in range(a.steps):
+        one_pass(collect=True)
+    barrier()
+    dt = time.perf_counter() - tic
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / a.steps
+        value = world * nt * a.steps / dt
+        bytes_per_ts = nlat * nlon * 4                         # PV read once (f32)
+        scan_ms = float(np.mean(stage_ms.get("scan", [float("nan")])))
+        achieved = nt * bytes_per_ts / (scan_ms * 1e-3) / 1e9   # GB/s, live HIP-event duration of the scan kernel
+        out = {
+            "metric": "timesteps/s (0.25deg global PV, contours + streamer/overturning/cutoff indices)",
+            "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "0.25deg global PV (1440x721 f32), %d 6-hourly steps per GPU, levels [-2,2], "
+                                   "streamers+overturnings+cutoffs, intensity field %s (BASELINE.json configs[2])"
+                                   % (nt, "off" if a.no_intensity else "on"),
+                       "nt_per_gpu": nt, "grid": [nlat, nlon], "levels": levels, "eps": a.eps,
+                       "parallelism": "time-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
+                         "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
+            "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
+            "counts": counts,
+        }
+        if world == 1 and a.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
+    """The oracle (kind 'port': numpy restatement of the reference, single thread) on a bounded sample of the
+    SAME device-generated workload; the sampled steps' event counts must equal the GPU's."""
+    from oracle import api as oapi
+    from oracle import synth
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    nlat, nlon = lat.size, lon.size
+    idx = sorted(set(int(round(i)) for i in np.linspace(0, nt - 1, nsample)))
+    ev = one_pass()
+    t_cpu = 0.0
+    ok = True
+    for t in idx:
+        pv = ctx.to_host(d_pv, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4)
+        it = ctx.to_host(d_int, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4) if d_int else None
+        tic = time.perf_counter()
+        ref = oapi.run_all(pv, levels, lat, lon, synth.times(1), intensity=it)
+        t_cpu += time.perf_counter() - tic
+        for k, name in enumerate(("streamers", "overturnings", "cutoffs")):
+            ok &= int((ev[k]["step"] == t).sum()) == len(ref[name])
+    return {"value": len(idx) / t_cpu, "unit": "timesteps/s", "cores": 1, "kind": "port",
+            "sample": "steps %s of the same device-generated batch, oracle.api.run_all (numpy, 1 thread), %.1f s"
+                      % (idx, t_cpu), "event_counts_match_gpu": bool(ok)}
+
+
+if __name__ == "__main__":
+    main()

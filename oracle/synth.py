@@ -21,6 +21,7 @@ import numpy as np
 
 MASK64 = (1 << 64) - 1
 SEED = 20240
+AVOID_LEVELS = (-2.0, 2.0)
 
 
 def splitmix64(x):
@@ -89,6 +90,7 @@ def noise(seed, t, nlat, nlon):
 
 def pv_field(t0, nt, lat, lon, eps=0.0, seed=SEED, dtype=np.float32):
     """(nt, nlat, nlon) synthetic PV, time index t0 .. t0+nt-1."""
+    dtype = np.dtype(dtype).type
     par = wave_params(seed)
     phi = np.abs(lat)[:, None]
     phir = np.radians(phi)
@@ -106,7 +108,12 @@ def pv_field(t0, nt, lat, lon, eps=0.0, seed=SEED, dtype=np.float32):
         pv = sgn * np.maximum(0.0, 2.0 + 6.0 * np.tanh((phi + D - 45.0) / 6.0))
         if eps:
             pv = pv + eps * noise(seed, t0 + n, lat.size, lon.size)
-        out[n] = pv.astype(dtype)
+        v = pv.astype(dtype)
+        # generator contract: no cell equals a contour level exactly.  2 + 6 tanh(x) rounds
+        # to exactly 2.0f for |x| < 1e-8, so such cells are moved one ulp up (same rule on the device).
+        for lv in AVOID_LEVELS:
+            v = np.where(v == dtype(lv), np.nextafter(dtype(lv), dtype(np.inf)), v)
+        out[n] = v
     return out
 
 

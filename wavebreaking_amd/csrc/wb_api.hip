@@ -82,12 +82,13 @@ struct WbTimer {
     std::vector<std::string> names;
     std::vector<float> ms;
 #if !defined(WB_HOSTSIM)
-    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<hipEvent_t> ev0, ev1;   // parallel to names; nullptr once collected
 #endif
     void begin(wb_ctx* c, const char* name) {
         names.push_back(name);
+        ms.push_back(0.f);
 #if !defined(WB_HOSTSIM)
-        hipEvent_t a, b;
+        hipEvent_t a = nullptr, b = nullptr;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
         ev0.push_back(a);
@@ -104,17 +105,35 @@ struct WbTimer {
         (void)c;
 #endif
     }
+    void drop_last() {   // forget the most recent stage (a retried launch)
+#if !defined(WB_HOSTSIM)
+        if (ev0.back()) { (void)hipEventSynchronize(ev1.back()); (void)hipEventDestroy(ev0.back()); (void)hipEventDestroy(ev1.back()); }
+        ev0.pop_back();
+        ev1.pop_back();
+#endif
+        names.pop_back();
+        ms.pop_back();
+    }
     void collect() {
-        ms.assign(names.size(), 0.f);
 #if !defined(WB_HOSTSIM)
         for (size_t i = 0; i < ev0.size(); ++i) {
+            if (!ev0[i]) continue;
             (void)hipEventSynchronize(ev1[i]);
             float t = 0.f;
             (void)hipEventElapsedTime(&t, ev0[i], ev1[i]);
             ms[i] = t;
             (void)hipEventDestroy(ev0[i]);
             (void)hipEventDestroy(ev1[i]);
+            ev0[i] = nullptr;
+            ev1[i] = nullptr;
         }
+#endif
+    }
+    void clear() {
+        collect();
+        names.clear();
+        ms.clear();
+#if !defined(WB_HOSTSIM)
         ev0.clear();
         ev1.clear();
 #endif
@@ -350,7 +369,7 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
     if (cap < 1024) cap = 1024;
     for (int attempt = 0; attempt < 6; ++attempt) {
         b->cap_seg = cap;
-        b->timer = WbTimer();
+        b->timer.clear();
         if (run_phase1(b)) { std::string e = ctx->err; wb_free_batch(b); return wb_fail(ctx, e); }
         std::vector<int> nseg(b->njobs);
         d2h(ctx, nseg.data(), b->nseg, nseg.size() * sizeof(int));
@@ -402,6 +421,7 @@ extern "C" int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont) {
 
 extern "C" int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n) {
     if (!b) return 1;
+    b->timer.collect();
     b->timer_names.clear();
     for (auto& s : b->timer.names) { b->timer_names += s; b->timer_names.push_back('\0'); }
     *names = b->timer_names.c_str();
@@ -552,6 +572,14 @@ WB_KERNEL(wb_k_fill_events, WbEvFillArgs a) {
     }
 }
 
+WB_KERNEL(wb_k_sel_maxlen, int nsel, int cap_seg, const int* sel_job, const int* sel_cont, const int* c_len, int* out) {
+    const int base = WB_BLOCK_ID * 256;
+    WB_PFOR(k, 256)
+        const int s = base + (int)k;
+        if (s < nsel) wb_atomic_max(out, c_len[(size_t)sel_job[s] * cap_seg + sel_cont[s]]);
+    WB_END_PFOR
+}
+
 static void make_tables(wb_batch* b) {
     if (b->d_lat) return;
     const wb_params& p = b->p;
@@ -637,12 +665,6 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     int *ev_n = nullptr, *ev_ind = nullptr;
     const int cap_ev = 256;
     if ((which & 1) && nsel > 0) {
-        // longest selected contour (sets the tiling of the all-pairs kernel)
-        std::vector<int> h_sj(nsel), h_sc(nsel);
-        d2h(ctx, h_sj.data(), b->sel_job, nsel * sizeof(int));
-        d2h(ctx, h_sc.data(), b->sel_cont, nsel * sizeof(int));
-        int* d_lenprobe = (int*)talloc(sizeof(int));
-        (void)d_lenprobe;
         int cap_pairs = p.cap_pairs > 0 ? p.cap_pairs : 65536;
         int* d_band = (int*)talloc(2 * sizeof(int));
         ev_n = (int*)talloc(nsel * sizeof(int));
@@ -664,14 +686,14 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         st.rowaux = (int*)talloc((size_t)nsel * 2 * cap * sizeof(int));
         st.ev_ind = ev_ind; st.ev_n = ev_n; st.band_hits = d_band; st.status = b->status;
         if (!st.rowaux || !ev_ind) return 1;
-        // the largest contour length bounds the tiles; c_len lives on the device: take it from the host copy of
-        // the contour table if present, else from a small reduction on the host over sel (c_len D2H per sel)
+        // the longest selected contour bounds the tiling of the all-pairs kernel
         int maxN = 0;
         {
-            std::vector<int> lens(nsel);
-            for (int s = 0; s < nsel; ++s)
-                d2h(ctx, &lens[s], b->c_len + (size_t)h_sj[s] * cap + h_sc[s], sizeof(int));
-            for (int v : lens) maxN = v > maxN ? v : maxN;
+            int* d_maxlen = (int*)talloc(sizeof(int));
+            if (!d_maxlen) return 1;
+            dmemset(ctx, d_maxlen, 0, sizeof(int));
+            WB_LAUNCH(wb_k_sel_maxlen, (nsel + 255) / 256, 256, nsel, cap, b->sel_job, b->sel_cont, b->c_len, d_maxlen);
+            d2h(ctx, &maxN, d_maxlen, sizeof(int));
         }
         for (int attempt = 0; attempt < 4; ++attempt) {
             st.cap_pairs = cap_pairs;
@@ -699,10 +721,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 for (void* q : {(void*)st.pairs, (void*)st.alive, (void*)st.hkey, (void*)st.hval})
                     for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == q) { tmp.erase(tmp.begin() + i); break; }
                 cap_pairs = next_pow2((long long)mx + mx / 8);
-                b->timer.names.pop_back(); b->timer.names.pop_back();
-#if !defined(WB_HOSTSIM)
-                b->timer.ev0.pop_back(); b->timer.ev0.pop_back(); b->timer.ev1.pop_back(); b->timer.ev1.pop_back();
-#endif
+                b->timer.drop_last();
+                b->timer.drop_last();
                 continue;
             }
             b->timer.begin(ctx, "streamer_f1");
@@ -779,10 +799,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             d2h(ctx, &used, pa.cell_count, sizeof(used));
             if (!p.want_cells || used <= cell_cap) { h_cells.resize((size_t)used); break; }
             cell_cap = used;   // second pass with the exact size
-            b->timer.names.pop_back();
-#if !defined(WB_HOSTSIM)
-            b->timer.ev0.pop_back(); b->timer.ev1.pop_back();
-#endif
+            b->timer.drop_last();
         }
         b->timer.begin(ctx, "events_d2h");
         d2h(ctx, h_ev.data(), d_ev, (size_t)NE * 8 * sizeof(int));
@@ -882,7 +899,17 @@ WB_KERNEL(wb_k_synth, WbSynthArgs a) {
             pv += a.eps * (2.0 * ((double)(h >> 11) * (1.0 / 9007199254740992.0)) - 1.0);
         }
         const size_t idx = ((size_t)n * a.nlat + j) * a.nlon + i;
-        if (a.dtype == 0) ((float*)a.field)[idx] = (float)pv; else ((double*)a.field)[idx] = pv;
+        // generator contract: no cell equals +-2 exactly (moved one ulp up, as oracle/synth.py does)
+        if (a.dtype == 0) {
+            float f = (float)pv;
+            if (f == 2.0f) f = nextafterf(2.0f, INFINITY);
+            if (f == -2.0f) f = nextafterf(-2.0f, INFINITY);
+            ((float*)a.field)[idx] = f;
+        } else {
+            if (pv == 2.0) pv = nextafter(2.0, (double)INFINITY);
+            if (pv == -2.0) pv = nextafter(-2.0, (double)INFINITY);
+            ((double*)a.field)[idx] = pv;
+        }
     WB_END_PFOR
 }
 
