@@ -43,22 +43,6 @@ def parse():
     return ap.parse_args()
 
 
-def gather_events(tables, rank, world, dist, torch, device):
-    """One gather of the event tables to rank 0 (counts first, then the payload)."""
-    payload = np.concatenate([np.asarray(t, dtype=np.float64).ravel() for t in tables]) if tables else np.zeros(0)
-    n = torch.tensor([payload.size], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    mx = int(max(int(s.item()) for s in sizes))
-    buf = torch.zeros(mx, dtype=torch.float64, device=device)
-    buf[: payload.size] = torch.from_numpy(payload).to(device)
-    out = [torch.zeros(mx, dtype=torch.float64, device=device) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, out, dst=0)
-    if rank == 0:
-        return [o[: int(s.item())].cpu().numpy() for o, s in zip(out, sizes)]
-    return None
-
-
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -76,6 +60,7 @@ def main():
 
     from oracle import synth
     from wavebreaking_amd import _hip
+    from wavebreaking_amd import distributed as wd
 
     ctx = _hip.Context(local)
     lat, lon = synth.grid(a.dlon)
@@ -102,19 +87,12 @@ def main():
     def one_pass(collect=False):
         b = ctx.contours(d_pv, lat, lon, levels, a.dlon, a.dlon, intensity=d_int, device_shape=(nt, nlat, nlon),
                          device_dtype=np.float32, want_cells=False)
-        g = b.max_nux()
-        if world > 1:
-            gt = torch.tensor([g], dtype=torch.int32, device=device)
-            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-            g = int(gt.item())
+        g = wd.global_max_nux(b.max_nux(), dist if world > 1 else None)     # exchange (1): one int32 all-reduce(max)
         b.indices(g)
         ct = b.contour_table()
         ev = [b.events(k) for k in (0, 1, 2)]
-        if world > 1:
-            tabs = []
-            for e in ev:
-                tabs += [e["step"] + t0, e["level_idx"], e["ind1"], e["ind2"], e["box"], e["orientation"], e["sums"]]
-            gathered = gather_events(tabs, rank, world, dist, torch, device)
+        if world > 1:                                                          # exchange (2): one gather to rank 0
+            wd.gather_event_tables([wd.pack_events(e, step_offset=t0) for e in ev], dist, dst=0)
         if collect:
             for name, ms in b.timings():
                 stage_ms.setdefault(name, []).append(ms)

@@ -99,6 +99,12 @@ const char* wb_backend(void);                       /* "hip" for the product lib
 
 /* phase 1: contours of every (time step, level) of the batch (contour_index.py:87-156) */
 int wb_contours(wb_ctx* ctx, const wb_params* p, wb_batch** batch);
+/* phase 1, alternative: a contour frame computed earlier and possibly filtered by the caller
+   (decorator_contour_calculation, contour_index.py:197-249); row k has npts[k] points at x/y[offset[k]...],
+   step[k] = index of its date in the data's time axis.  Events come back in frame-row order. */
+int wb_batch_from_contours(wb_ctx* ctx, const wb_params* p, int64_t n, const int32_t* step, const int32_t* level_idx,
+                           const int32_t* closed, const int64_t* offset, const int32_t* npts, const int32_t* x,
+                           const int32_t* y, wb_batch** batch);
 int wb_batch_max_nux(wb_batch* b);                  /* local max of len(set(x)); all-reduce(max) it across ranks */
 /* phase 2: indices.  global_max_nux plays contours.exp_lon.max() (streamer_index.py:106);
    which = bit mask 1 streamers | 2 overturnings | 4 cutoffs */

@@ -1,0 +1,36 @@
+"""CPU: the C-ABI library loads and exports every symbol include/wavebreaking_hip.h declares (no compute
+calls without a GPU), and nothing in the shipped package imports the oracle."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "wavebreaking_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    lib_path = g.build()
+    lib = ctypes.CDLL(lib_path)
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), "libwb_hip.so does not export " + s
+    lib.wb_backend.restype = ctypes.c_char_p
+    assert lib.wb_backend() == b"hip"
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "wavebreaking_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "oracle/" in src and f.endswith(".py") and "import" in src.split("oracle/")[0][-40:]:
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,100 @@
+"""N > 1 path on CPU: two processes (gloo), each running its time shard through the host-simulation
+library, one all-reduce(max) + one gather; rank 0's concatenated catalogue must equal the single-process
+catalogue of the whole record."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+from wavebreaking_amd import distributed as wd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+from wavebreaking_amd import distributed as wd
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+NT = 5
+lat, lon = synth.grid(2.5)
+first, count = wd.shard(NT, rank, world)
+pv = synth.pv_field(first, count, lat, lon, eps=0.2)
+if rank == 1:
+    pv[:, 20:30, :] = 0.0          # rank 1's steps lose their southern full-span contour ...
+ctx = _hip.Context(0, helpers.hostsim_library())
+b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 2.5, 2.5)
+g = wd.global_max_nux(b.max_nux(), dist)
+b.indices(g)
+tabs = [wd.pack_events(b.events(k), step_offset=first) for k in (0, 1, 2)]
+out = wd.gather_event_tables(tabs, dist, dst=0)
+if rank == 0:
+    np.savez(sys.argv[2], s=out[0], o=out[1], c=out[2], g=g)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_time_sharding_matches_single_process(tmp_path):
+    helpers.build_hostsim()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "rank0.npz"
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+
+    # single process over the whole record (same modification of the second shard)
+    NT = 5
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(0, NT, lat, lon, eps=0.2)
+    first1, _ = wd.shard(NT, 1, 2)
+    pv[first1:, 20:30, :] = 0.0
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 2.5, 2.5)
+    assert int(got["g"]) == b.max_nux()
+    b.indices()
+    for key, kind in (("s", 0), ("o", 1), ("c", 2)):
+        ref = wd.pack_events(b.events(kind))
+        m = got[key]
+        assert m.shape == ref.shape and m.shape[0] > 0
+        cols = [c for c in range(18) if c != 2]           # contour row numbers are shard-local
+        assert np.array_equal(m[:, cols], ref[:, cols])
+    # round trip of the packing
+    e = b.events(0)
+    u = wd.unpack_events(wd.pack_events(e))
+    for k in ("step", "ind1", "ind2", "box", "sums", "ncells"):
+        assert np.array_equal(u[k], e[k])
+
+
+def test_shard_covers_everything():
+    for nt in (1, 7, 1460, 58440):
+        for world in (1, 2, 3, 8):
+            blocks = [wd.shard(nt, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == nt
+            assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))

@@ -1,0 +1,179 @@
+"""The reference-shaped Python surface (calculate_* with xarray-like input, frame output) against the
+oracle; reads like the reference's own tests/test_wavebreaking.py.  CPU: through the host-simulation
+library; GPU (-m gpu): through libwb_hip.so."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import wavebreaking_amd as wb
+from oracle import api as oapi
+from oracle import properties as oprop
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip, engine
+from wavebreaking_amd.utils.data_utils import check_argument_types, get_dimension_attributes
+from wavebreaking_amd.utils.index_utils import combine_shared, iterate_contour_levels, iterate_time_dimension
+
+
+def _field(nt=3, dlon=1.0, eps=0.2, descending_lat=False, seed=synth.SEED):
+    lat, lon = synth.grid(dlon)
+    tm = synth.times(nt, start="1959-06-01T00")
+    pv = synth.pv_field(0, nt, lat, lon, eps=eps, seed=seed)
+    coords = {"time": tm, "lat": wb.gridfield.Coord(lat, {"units": "degrees_north"}),
+              "lon": wb.gridfield.Coord(lon, {"units": "degrees_east"})}
+    f = wb.GridField(pv, ("time", "lat", "lon"), coords, name="PV")
+    if descending_lat:
+        f = f.sortby("lat", ascending=False)
+    return f, pv, lat, lon, tm
+
+
+def _ring_area(r):
+    r = np.asarray(r)
+    return abs(oprop.ring_area(r))
+
+
+def _check_events(frame, ref_rows, cols):
+    assert frame.columns.to_list() == cols
+    assert len(frame) == len(ref_rows)
+    for (_, row), r in zip(frame.iterrows(), ref_rows):
+        assert np.datetime64(row["date"]) == r["date"]
+        assert row["level"] == r["level"]
+        assert tuple(row["com"]) == tuple(r["com"])
+        assert abs(row["mean_var"] - r["mean_var"]) <= 0.0100001 and abs(row["intensity"] - r["intensity"]) <= 0.0100001
+        assert row["event_area"] == r["event_area"]
+        if "orientation" in r:
+            assert row["orientation"] == r["orientation"]
+        got = sorted(p.area for p in row["geometry"].geoms) if not row["geometry"].is_empty else []
+        want = sorted(_ring_area(g) for g in r["geometry"])
+        assert np.allclose(got, want, rtol=1e-6)
+
+
+def _run_all(use):
+    data, pv, lat, lon, tm = _field()
+    inten_np = synth.pv_field(0, 3, lat, lon, eps=0.0, seed=20241)
+    inten = wb.GridField(inten_np, data.dims, data.coords)
+    ref = oapi.run_all(pv, [2], lat, lon, tm, intensity=inten_np)
+
+    # -- test_contour_index of the reference (tests/test_wavebreaking.py:148-177)
+    contours_coords = wb.calculate_contours(data=data, contour_levels=2, periodic_add=120, original_coordinates=True)
+    contours_index = wb.calculate_contours(data=data, contour_levels=2, periodic_add=120, original_coordinates=False)
+    cols = ["date", "level", "closed", "exp_lon", "mean_lat", "geometry"]
+    assert contours_coords.columns.to_list() == cols and contours_index.columns.to_list() == cols
+    full = contours_index[contours_index.exp_lon == 480]
+    assert len(full) >= 3
+    assert min(np.asarray(full.iloc[0].geometry.coords.xy).T[:, 0]) == 0
+    fullc = contours_coords[contours_coords.exp_lon == 360]
+    assert min(np.asarray(fullc.iloc[0].geometry.coords.xy).T[:, 0]) == -180
+    assert len(contours_index) == len(ref["contours"])
+    for (_, row), r in zip(contours_index.iterrows(), ref["contours"]):
+        assert np.array_equal(np.asarray(row.geometry.coords), r["geometry"])
+        assert row.exp_lon == r["exp_lon"] and row.mean_lat == r["mean_lat"] and row.closed == r["closed"]
+    refc = oapi.calculate_contours(pv, 2, lat, lon, tm, 120, True)
+    for (_, row), r in zip(contours_coords.iterrows(), refc):
+        assert np.array_equal(np.asarray(row.geometry.coords), r["geometry"])
+        assert row.exp_lon == r["exp_lon"] and row.mean_lat == r["mean_lat"]
+
+    ev_cols = ["date", "level", "com", "mean_var", "intensity", "event_area", "geometry"]
+    streamers = wb.calculate_streamers(data=data, contour_levels=2, geo_dis=800, cont_dis=1500, intensity=inten,
+                                       periodic_add=120)
+    _check_events(streamers, ref["streamers"], ev_cols)
+    overturnings = wb.calculate_overturnings(data=data, contour_levels=2, range_group=5, min_exp=5, intensity=inten,
+                                             periodic_add=120)
+    _check_events(overturnings, ref["overturnings"], ev_cols[:-1] + ["orientation", "geometry"])
+    cutoffs = wb.calculate_cutoffs(data=data, contour_levels=2, min_exp=5, intensity=inten, periodic_add=120)
+    _check_events(cutoffs, ref["cutoffs"], ev_cols)
+
+    # contours= computed earlier and handed in (decorator_contour_calculation, contour_index.py:209-245)
+    s2 = wb.calculate_streamers(data=data, contour_levels=2, contours=contours_index, intensity=inten)
+    _check_events(s2, ref["streamers"], ev_cols)
+    c2 = wb.calculate_cutoffs(data=data, contour_levels=2, contours=contours_index, intensity=inten)
+    _check_events(c2, ref["cutoffs"], ev_cols)
+    with pytest.raises(ValueError):
+        wb.calculate_streamers(data=data, contour_levels=2, contours=contours_coords)      # original coordinates
+    with pytest.raises(TypeError):
+        wb.calculate_streamers(data=data, contour_levels=2, contours="nope")
+
+    # descending latitude is sorted first (data_utils.py:196-213), two levels keep the (time, level) order
+    data_d, *_ = _field(descending_lat=True)
+    ref2 = oapi.run_all(pv, [-2, 2], lat, lon, tm)
+    o2 = wb.calculate_overturnings(data_d, [-2, 2])
+    _check_events(o2, ref2["overturnings"], ev_cols[:-1] + ["orientation", "geometry"])
+
+
+@pytest.fixture
+def hostsim_engine(monkeypatch):
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    monkeypatch.setitem(engine._contexts, 0, ctx)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    yield
+    ctx.close()
+
+
+def test_public_functions_against_oracle_hostsim(hostsim_engine):
+    _run_all("hostsim")
+
+
+@pytest.mark.gpu
+def test_public_functions_against_oracle_gpu():
+    engine._contexts.clear()
+    _run_all("hip")
+
+
+def test_check_argument_types():
+    # tests/test_wavebreaking.py:58-63
+    @check_argument_types(["data"], [wb.gridfield.data_array_types()])
+    def to_be_decorated(data, *args, **kwargs):
+        return None
+
+    with pytest.raises(TypeError, match="data has to be a"):
+        to_be_decorated("")
+    with pytest.raises(TypeError):
+        wb.calculate_contours("", 2)
+
+
+def test_get_dimension_attributes():
+    # tests/test_wavebreaking.py:65-79
+    data, *_ = _field()
+
+    @get_dimension_attributes("data")
+    def to_be_decorated(data, *args, **kwargs):
+        assert kwargs["time_name"] == "time" and kwargs["lon_name"] == "lon" and kwargs["lat_name"] == "lat"
+        assert kwargs["ntime"] == 3 and kwargs["nlon"] == 360 and kwargs["nlat"] == 181
+        assert kwargs["dlon"] == 1 and kwargs["dlat"] == 1
+
+    to_be_decorated(data)
+    irregular = wb.GridField(np.zeros((1, 3, 4)), coords={"lat": [0, 1, 3], "lon": [0, 1, 2, 3]})
+    with pytest.raises(ValueError, match="No regular grid"):
+        to_be_decorated(irregular)
+    four = wb.GridField(np.zeros((1, 2, 3, 4)), ("time", "lev", "lat", "lon"))
+    with pytest.raises(ValueError, match="Unexpected dimension"):
+        to_be_decorated(four)
+
+
+def test_iteration_decorators_and_combine_shared():
+    # tests/test_wavebreaking.py:83-104
+    data, *_ = _field()
+
+    @get_dimension_attributes("data")
+    @iterate_time_dimension
+    def by_time(data, contour_levels, *args, **kwargs):
+        return pd.DataFrame([kwargs["step"]], columns=["time"])
+
+    assert by_time(data, 2)["time"].to_list() == list(pd.to_datetime(data["time"].values))
+
+    @get_dimension_attributes("data")
+    @iterate_contour_levels
+    def by_level(data, contour_levels, *args, **kwargs):
+        return pd.DataFrame([kwargs["level"]], columns=["levels"])
+
+    assert by_level(data, [-2, 2]).equals(pd.DataFrame([-2, 2], columns=["levels"]))
+    assert combine_shared([[1, 2, 3], [2, 3, 4], [5, 6]]) == [[1, 2, 3, 4], [5, 6]]
+
+
+def test_product_refuses_to_run_without_the_hip_library(monkeypatch, tmp_path):
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(_hip, "_default", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _hip.default_library()
+    with pytest.raises(RuntimeError, match="refusing"):
+        _hip.Library(helpers.build_hostsim())          # a host-simulation build is never accepted as the product

@@ -1,7 +1,13 @@
 """wavebreaking_amd -- MI355X-native implementation of the WaveBreaking hot path.
 
-Same call surface as the reference package for this path
-(wavebreaking/__init__.py:31-34): calculate_contours, calculate_streamers,
-calculate_overturnings, calculate_cutoffs.
+Same call surface as the reference package for this path (wavebreaking/__init__.py:31-34):
+calculate_contours, calculate_streamers, calculate_overturnings, calculate_cutoffs -- xarray.DataArray
+(or wavebreaking_amd.GridField) in, GeoDataFrame (or pandas.DataFrame when geopandas is absent) out.
 """
 __version__ = "0.1.0"
+
+from wavebreaking_amd.gridfield import GridField  # noqa: F401
+from wavebreaking_amd.indices.contour_index import calculate_contours  # noqa: F401
+from wavebreaking_amd.indices.cutoff_index import calculate_cutoffs  # noqa: F401
+from wavebreaking_amd.indices.overturning_index import calculate_overturnings  # noqa: F401
+from wavebreaking_amd.indices.streamer_index import calculate_streamers  # noqa: F401

@@ -73,6 +73,9 @@ class Library:
         lib.wb_last_error.argtypes = [C.c_void_p]
         lib.wb_last_error.restype = C.c_char_p
         lib.wb_contours.argtypes = [C.c_void_p, C.POINTER(WbParams), C.POINTER(C.c_void_p)]
+        i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        lib.wb_batch_from_contours.argtypes = [C.c_void_p, C.POINTER(WbParams), C.c_int64, i32p, i32p, i32p, i64p, i32p,
+                                               i32p, i32p, C.POINTER(C.c_void_p)]
         lib.wb_batch_max_nux.argtypes = [C.c_void_p]
         lib.wb_indices.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
@@ -162,11 +165,8 @@ class Context:
             raise RuntimeError("wb_synth_fill failed: " + self.error())
 
     # -- the hot path
-    def contours(self, field, lat, lon, levels, dlon, dlat, periodic_add=120.0, intensity=None, geo_dis=800.0,
-                 cont_dis=1500.0, range_group=5.0, ot_min_exp=5.0, co_min_exp=5.0, want_cells=False,
-                 device_shape=None, device_dtype=None, cap_seg=0, cap_pairs=0):
-        """Phase 1.  ``field`` is a numpy array (time, lat, lon) or, with ``device_shape``/``device_dtype``,
-        an integer device pointer.  Returns a Batch."""
+    def _params(self, field, lat, lon, levels, dlon, dlat, periodic_add, intensity, geo_dis, cont_dis, range_group,
+                ot_min_exp, co_min_exp, want_cells, device_shape, device_dtype, cap_seg, cap_pairs):
         keep = []
         p = WbParams()
         if device_shape is not None:
@@ -192,6 +192,7 @@ class Context:
         lat = np.ascontiguousarray(lat, dtype=np.float64)
         lon = np.ascontiguousarray(lon, dtype=np.float64)
         lev = np.ascontiguousarray(levels, dtype=np.float64)
+        keep += [lat, lon, lev]
         assert lat.size == nlat and lon.size == nlon
         dp = C.POINTER(C.c_double)
         p.nt, p.nlat, p.nlon = int(nt), int(nlat), int(nlon)
@@ -203,10 +204,41 @@ class Context:
         p.range_group, p.ot_min_exp, p.co_min_exp = float(range_group), float(ot_min_exp), float(co_min_exp)
         p.want_cells = 1 if want_cells else 0
         p.cap_seg, p.cap_pairs = int(cap_seg), int(cap_pairs)
+        return p, keep, int(nt), lev.size
+
+    def contours(self, field, lat, lon, levels, dlon, dlat, periodic_add=120.0, intensity=None, geo_dis=800.0,
+                 cont_dis=1500.0, range_group=5.0, ot_min_exp=5.0, co_min_exp=5.0, want_cells=False,
+                 device_shape=None, device_dtype=None, cap_seg=0, cap_pairs=0):
+        """Phase 1.  ``field`` is a numpy array (time, lat, lon) or, with ``device_shape``/``device_dtype``,
+        an integer device pointer.  Returns a Batch."""
+        p, keep, nt, nlev = self._params(field, lat, lon, levels, dlon, dlat, periodic_add, intensity, geo_dis, cont_dis,
+                                         range_group, ot_min_exp, co_min_exp, want_cells, device_shape, device_dtype,
+                                         cap_seg, cap_pairs)
         h = C.c_void_p()
         if self.L.lib.wb_contours(self.h, C.byref(p), C.byref(h)) != 0:
             raise RuntimeError("wb_contours failed: " + self.error())
-        return Batch(self, h, int(nt), lev.size, want_cells)
+        return Batch(self, h, nt, nlev, want_cells)
+
+    def batch_from_contours(self, table, field, lat, lon, levels, dlon, dlat, periodic_add=120.0, intensity=None,
+                            geo_dis=800.0, cont_dis=1500.0, range_group=5.0, ot_min_exp=5.0, co_min_exp=5.0,
+                            want_cells=False, device_shape=None, device_dtype=None, cap_pairs=0):
+        """Phase 1 from a contour frame computed earlier: ``table`` has step, level_idx, closed, offset, npts, x, y."""
+        p, keep, nt, nlev = self._params(field, lat, lon, levels, dlon, dlat, periodic_add, intensity, geo_dis, cont_dis,
+                                         range_group, ot_min_exp, co_min_exp, want_cells, device_shape, device_dtype,
+                                         0, cap_pairs)
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        step, lvl, closed, npts = i32(table["step"]), i32(table["level_idx"]), i32(table["closed"]), i32(table["npts"])
+        off = np.ascontiguousarray(table["offset"], dtype=np.int64)
+        x, y = i32(table["x"]), i32(table["y"])
+        i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        h = C.c_void_p()
+        rc = self.L.lib.wb_batch_from_contours(self.h, C.byref(p), step.size, step.ctypes.data_as(i32p),
+                                               lvl.ctypes.data_as(i32p), closed.ctypes.data_as(i32p),
+                                               off.ctypes.data_as(i64p), npts.ctypes.data_as(i32p),
+                                               x.ctypes.data_as(i32p), y.ctypes.data_as(i32p), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("wb_batch_from_contours failed: " + self.error())
+        return Batch(self, h, nt, nlev, want_cells)
 
 
 class Batch:

@@ -166,6 +166,9 @@ struct wb_batch {
     int nsel = 0, ncut = 0;
     int *sel_job = nullptr, *sel_cont = nullptr, *cut_job = nullptr, *cut_cont = nullptr;
     long long band[2] = {0, 0};
+    // batches built from a user-supplied contour frame: one job per contour row
+    std::vector<int> job_step, job_level;
+    int* d_job_step = nullptr;
     // host result tables
     bool have_contours = false;
     std::vector<int32_t> ct_step, ct_level, ct_closed, ct_nux, ct_npts, ct_x, ct_y;
@@ -512,6 +515,9 @@ static int fetch_contours(wb_batch* b) {
     if (NP) { d2h(ctx, b->ct_x.data(), a.o_x, NP * 4); d2h(ctx, b->ct_y.data(), a.o_y, NP * 4); }
     b->timer.end(ctx);
     if (dsync(ctx)) return 1;
+    if (!b->job_step.empty())
+        for (int j = 0; j < J; ++j)
+            for (long long r = b->ct_base[j]; r < b->ct_base[j + 1]; ++r) { b->ct_step[r] = b->job_step[j]; b->ct_level[r] = b->job_level[j]; }
     void* tmp[] = {d_npts, d_cbase, d_pbase, a.o_step, a.o_level, a.o_closed, a.o_nux, a.o_npts, a.o_sumy, a.o_off, a.o_x, a.o_y};
     for (void* q : tmp) bfree_one(b, q);
     b->have_contours = true;
@@ -777,7 +783,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         pa.nev = NE; pa.nslots = NE < 256 ? NE : 256; pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
         pa.nlev = p.nlevels; pa.dtype = p.dtype; pa.want_cells = p.want_cells; pa.pad = (int)ceil(r); pa.r2 = r * r;
         pa.ev = d_ev; pa.c_off = b->c_off; pa.c_len = b->c_len; pa.cpts = b->cpts; pa.data = b->d_field;
-        pa.intensity = b->d_intensity; pa.wlat = b->d_wlat;
+        pa.intensity = b->d_intensity; pa.wlat = b->d_wlat; pa.job_step = b->d_job_step;
         pa.cells = (int*)talloc((size_t)pa.nslots * b->W * p.nlat * sizeof(int));
         pa.rowacc = (double*)talloc((size_t)pa.nslots * 4 * p.nlat * sizeof(double));
         pa.ev_sums = (double*)talloc((size_t)NE * 5 * sizeof(double));
@@ -821,8 +827,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         for (int e = lo; e < hi; ++e) {
             const int* d = &h_ev[(size_t)e * 8];
             const int job = d[1];
-            t.step.push_back(job / p.nlevels);
-            t.level.push_back(job % p.nlevels);
+            t.step.push_back(b->job_step.empty() ? job / p.nlevels : b->job_step[job]);
+            t.level.push_back(b->job_level.empty() ? job % p.nlevels : b->job_level[job]);
             t.contour.push_back(b->ct_base[job] + d[2]);
             if (kind == WB_OVERTURNINGS) {
                 t.ind1.push_back(0); t.ind2.push_back(0);
@@ -862,6 +868,104 @@ extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
     o->sums = t.sums.data(); o->ncells = t.ncells.data();
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ user-supplied contours
+// decorator_contour_calculation (contour_index.py:197-249): the index functions also accept a contour frame
+// computed earlier (and possibly filtered by the user).  One job per contour row keeps the frame's row order.
+extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t n, const int32_t* step,
+                                      const int32_t* level_idx, const int32_t* closed, const int64_t* offset,
+                                      const int32_t* npts, const int32_t* x, const int32_t* y, wb_batch** out) {
+    if (!ctx || !pp || !out || n < 0) return 1;
+    const wb_params& p = *pp;
+    if (!(p.dlon > 0) || !(p.dlat > 0)) return wb_fail(ctx, "dlon and dlat must be positive");
+    const int padd = (int)(p.periodic_add / p.dlon);
+    if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
+    const int W = p.nlon + padd;
+    if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large");
+#if !defined(WB_HOSTSIM)
+    if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
+#endif
+    int maxn = 1;
+    for (int64_t k = 0; k < n; ++k) {
+        if (npts[k] < 1) return wb_fail(ctx, "empty contour in frame");
+        if (step[k] < 0 || step[k] >= p.nt) return wb_fail(ctx, "contour date not found in data");
+        maxn = npts[k] > maxn ? npts[k] : maxn;
+        for (int i = 0; i < npts[k]; ++i) {
+            const int xx = x[offset[k] + i], yy = y[offset[k] + i];
+            if (xx < 0 || xx >= W || yy < 0 || yy >= p.nlat) return wb_fail(ctx, "contour point outside the (extended) grid");
+        }
+    }
+    wb_batch* b = new wb_batch();
+    b->ctx = ctx;
+    b->p = p;
+    b->lat.assign(p.lat, p.lat + p.nlat);
+    b->lon.assign(p.lon, p.lon + p.nlon);
+    b->levels.assign(p.levels, p.levels + p.nlevels);
+    b->p.lat = b->lat.data(); b->p.lon = b->lon.data(); b->p.levels = b->levels.data();
+    b->W = W; b->padd = padd;
+    const int J = (int)n;
+    b->njobs = J;
+    const int cap = next_pow2((maxn + 1) / 2 < 4 ? 4 : (maxn + 1) / 2);
+    b->cap_seg = cap;
+    const size_t esz = p.dtype == 0 ? 4 : 8;
+    const size_t fbytes = (size_t)p.nt * p.nlat * p.nlon * esz;
+    if (p.on_device) {
+        b->d_field = p.field;
+        b->d_intensity = p.intensity;
+    } else {
+        void* d = dmalloc(ctx, fbytes);
+        if (!d) { delete b; return 1; }
+        b->owned.push_back(d);
+        h2d(ctx, d, p.field, fbytes);
+        b->d_field = d;
+        if (p.intensity) {
+            void* di = dmalloc(ctx, fbytes);
+            if (!di) { wb_free_batch(b); return 1; }
+            b->owned.push_back(di);
+            h2d(ctx, di, p.intensity, fbytes);
+            b->d_intensity = di;
+        }
+    }
+    std::vector<uint32_t> h_pts((size_t)J * 2 * cap, 0);
+    std::vector<int> h_off((size_t)J * cap, 0), h_len((size_t)J * cap, 0), h_cl((size_t)J * cap, 0), h_nux((size_t)J * cap, 0),
+        h_sy((size_t)J * cap, 0), h_nc(J, 1);
+    std::vector<char> seen(W);
+    b->job_step.resize(J);
+    b->job_level.resize(J);
+    b->max_nux = 0;
+    for (int j = 0; j < J; ++j) {
+        std::fill(seen.begin(), seen.end(), 0);
+        int nux = 0;
+        long long sy = 0;
+        for (int i = 0; i < npts[j]; ++i) {
+            const int xx = x[offset[j] + i], yy = y[offset[j] + i];
+            h_pts[(size_t)j * 2 * cap + i] = (uint32_t)xx | ((uint32_t)yy << 16);
+            if (!seen[xx]) { seen[xx] = 1; ++nux; }
+            sy += yy;
+        }
+        h_len[(size_t)j * cap] = npts[j];
+        h_cl[(size_t)j * cap] = closed[j] ? 1 : 0;
+        h_nux[(size_t)j * cap] = nux;
+        h_sy[(size_t)j * cap] = (int)sy;
+        b->job_step[j] = step[j];
+        b->job_level[j] = level_idx[j];
+        if (nux > b->max_nux) b->max_nux = nux;
+    }
+    b->cpts = upload(b, h_pts);
+    b->c_off = upload(b, h_off); b->c_len = upload(b, h_len); b->c_closed = upload(b, h_cl);
+    b->c_nux = upload(b, h_nux); b->c_sumy = upload(b, h_sy); b->ncont = upload(b, h_nc);
+    b->d_job_step = upload(b, b->job_step);
+    b->status = balloc<uint32_t>(b, J > 0 ? J : 1);
+    if (!b->status) { wb_free_batch(b); return 1; }
+    dmemset(ctx, b->status, 0, (size_t)(J > 0 ? J : 1) * sizeof(uint32_t));
+    b->h_ncont = h_nc;
+    b->h_status.assign(J, 0);
+    b->ct_base.assign(J + 1, 0);
+    for (int j = 0; j < J; ++j) b->ct_base[j + 1] = j + 1;
+    if (dsync(ctx)) { wb_free_batch(b); return 1; }
+    *out = b;
     return 0;
 }
 

@@ -27,6 +27,7 @@ struct WbPropsArgs {
     const uint32_t* cpts;
     const void* data;           // [nt][nlat][nlon]
     const void* intensity;      // or NULL
+    const int* job_step;        // [njobs] time index of a job, or NULL: job / nlev
     const double* wlat;         // [nlat] cos(radians(lat)) * area_cell   (:58-62)
     int* cells;                 // [nslots][W*nlat]
     double* rowacc;             // [nslots][4][nlat]
@@ -64,7 +65,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         const size_t jb = (size_t)job * a.cap_seg;
         const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + cont];
         const int n = (kind == WB_EV_STREAMER) ? (d[4] - d[3] + 1) : (kind == WB_EV_CUTOFF ? a.c_len[jb + cont] : 4);
-        const size_t tbase = (size_t)(job / a.nlev) * a.nlat * a.nlon;
+        const size_t tbase = (size_t)(a.job_step ? a.job_step[job] : job / a.nlev) * a.nlat * a.nlon;
 
         WB_SINGLE
         bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;

@@ -1,0 +1,94 @@
+"""Glue between the reference-shaped Python functions and the C ABI: one cached context per device,
+array extraction, level chunking (the ABI takes up to 4 levels per pass), frame <-> table conversion."""
+import os
+
+import numpy as np
+
+from wavebreaking_amd import _hip
+from wavebreaking_amd.utils import data_utils as du
+
+_contexts = {}
+MAX_LEVELS = 4
+
+
+def get_context(device=None):
+    """The process-wide context of ``device`` (default: LOCAL_RANK, else 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", 0))
+    if device not in _contexts:
+        _contexts[device] = _hip.Context(device)      # raises if libwb_hip.so is missing: no CPU fallback
+    return _contexts[device]
+
+
+def as_levels(contour_levels):
+    """index_utils.py:247-250"""
+    try:
+        iter(contour_levels)
+    except Exception:
+        contour_levels = [contour_levels]
+    return list(contour_levels)
+
+
+class Prepared:
+    """Oriented numpy views of a call's inputs."""
+
+    def __init__(self, data, intensity, kwargs):
+        data = du.correct_dimension_orientation(data, **kwargs)
+        self.values, self.times, self.lat, self.lon = du.as_time_lat_lon(data, **kwargs)
+        self.intensity = None
+        if intensity is not None:
+            if not isinstance(intensity, type(data)) and not hasattr(intensity, "dims"):
+                raise TypeError("intensity has to be a " + str(type(data))[8:-2] + "!")
+            intensity = du.correct_dimension_orientation(intensity, **kwargs)
+            self.intensity = du.as_time_lat_lon(intensity, **kwargs)[0]
+            if self.intensity.shape != self.values.shape:
+                raise ValueError("intensity must have the shape of data")
+        self.nlon, self.nlat = len(self.lon), len(self.lat)
+        self.dlon, self.dlat = float(kwargs["dlon"]), float(kwargs["dlat"])
+
+
+def contour_batches(prep, levels, periodic_add, params, want_cells=False):
+    """[(batch, level positions)]: one ABI batch per group of <= 4 levels."""
+    ctx = get_context()
+    out = []
+    for lo in range(0, len(levels), MAX_LEVELS):
+        pos = list(range(lo, min(lo + MAX_LEVELS, len(levels))))
+        b = ctx.contours(prep.values, prep.lat, prep.lon, [float(levels[i]) for i in pos], prep.dlon, prep.dlat,
+                         periodic_add=periodic_add, intensity=prep.intensity, want_cells=want_cells, **params)
+        out.append((b, pos))
+    return out
+
+
+def _time_key(t):
+    if hasattr(t, "to_datetime64"):          # pandas.Timestamp (what a datetime64 column hands back)
+        t = t.to_datetime64()
+    if isinstance(t, np.datetime64):
+        return ("M", int(t.astype("datetime64[ns]").astype(np.int64)))
+    return ("O", t.item() if hasattr(t, "item") else t)
+
+
+def frame_to_table(contours, times, levels):
+    """A reference-shaped contour frame (index coordinates) -> the ABI's contour table."""
+    tkey = {_time_key(t): i for i, t in enumerate(np.asarray(times))}
+    step, lvl, closed, npts, xs, ys = [], [], [], [], [], []
+    level_list = list(levels)
+    has_closed = "closed" in contours.columns
+    for _, row in contours.iterrows():
+        k = _time_key(row["date"])
+        if k not in tkey:
+            raise ValueError("contour date {} not found in data".format(row["date"]))
+        step.append(tkey[k])
+        if row["level"] not in level_list:
+            level_list.append(row["level"])
+        lvl.append(level_list.index(row["level"]))
+        closed.append(bool(row["closed"]) if has_closed else False)
+        c = np.asarray(row["geometry"].coords)
+        xs.append(c[:, 0].astype(np.int32))
+        ys.append(c[:, 1].astype(np.int32))
+        npts.append(len(c))
+    off = (np.cumsum(npts) - np.asarray(npts)) if npts else np.zeros(0, dtype=np.int64)
+    table = dict(step=np.asarray(step, dtype=np.int32), level_idx=np.asarray(lvl, dtype=np.int32),
+                 closed=np.asarray(closed, dtype=np.int32), npts=np.asarray(npts, dtype=np.int32),
+                 offset=np.asarray(off, dtype=np.int64),
+                 x=np.concatenate(xs) if xs else np.zeros(0, np.int32), y=np.concatenate(ys) if ys else np.zeros(0, np.int32))
+    return table, level_list

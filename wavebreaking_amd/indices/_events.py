@@ -1,0 +1,75 @@
+"""Shared tail of the three index functions: run phase 2 on the batch(es), turn the ABI's event tables
+into the reference's frame (calculate_properties + transform_polygons, index_utils.py:35-184)."""
+import numpy as np
+
+from wavebreaking_amd import _hip, engine
+from wavebreaking_amd import gridfield as _gf
+from wavebreaking_amd.utils import index_utils as iu
+
+DIM_KEYS = ("time_name", "lon_name", "lat_name", "ntime", "nlon", "nlat", "dlon", "dlat")
+
+
+def run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max=None):
+    """kind: _hip.STREAMERS / OVERTURNINGS / CUTOFFS.  Returns the reference-shaped frame."""
+    dim_kwargs = {k: kwargs[k] for k in DIM_KEYS}
+    prep = engine.Prepared(data, intensity, dim_kwargs)
+    state = kwargs.get("_wb_state")
+    ctx = engine.get_context()
+    if state is not None and contours is kwargs.get("contours") and len(contours) == state["nrows"] and intensity is None:
+        batches, levels = state["batches"], state["levels"]          # contours computed by the decorator: reuse
+    else:
+        if state is not None:
+            for b, _ in state["batches"]:
+                b.close()
+        levels = engine.as_levels(contour_levels)
+        if state is not None and contours is kwargs.get("contours"):
+            # same contours, but the index needs the intensity field on the device too
+            batches = engine.contour_batches(prep, levels, periodic_add, params)
+        else:
+            table, levels = engine.frame_to_table(contours, prep.times, levels)
+            b = ctx.batch_from_contours(table, prep.values, prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
+                                        prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=prep.intensity,
+                                        **params)
+            batches = [(b, None)]
+    g = max(b.max_nux() for b, _ in batches) if batches else 0          # contours.exp_lon.max(), streamer_index.py:106
+    if global_max is not None:
+        g = max(g, int(global_max))
+    which = {_hip.STREAMERS: dict(streamers=True, overturnings=False, cutoffs=False),
+             _hip.OVERTURNINGS: dict(streamers=False, overturnings=True, cutoffs=False),
+             _hip.CUTOFFS: dict(streamers=False, overturnings=False, cutoffs=True)}[kind]
+    rows = []
+    for bi, (b, pos) in enumerate(batches):
+        b.indices(g, **which)
+        ev = b.events(kind)
+        ct = b.contour_table()
+        for k in range(ev["step"].size):
+            lvl = ev["level_idx"][k]
+            rows.append((int(ev["step"][k]) if pos is not None else k, pos[int(lvl)] if pos is not None else int(lvl), bi, k))
+        batches[bi] = (b, pos, ev, ct)
+    if len(batches) > 1:
+        rows.sort(key=lambda r: (r[0], r[1]))
+    cols = dict(date=[], level=[])
+    polys, sums, orient = [], [], []
+    for _, lpos, bi, k in rows:
+        b, pos, ev, ct = batches[bi]
+        c = int(ev["contour"][k])
+        o = int(ct["offset"][c])
+        cols["date"].append(prep.times[int(ev["step"][k])])
+        cols["level"].append(levels[lpos])
+        if kind == _hip.OVERTURNINGS:
+            x0, y0, x1, y1 = (int(v) for v in ev["box"][k])
+            polys.append(np.array([[x1, y0], [x1, y1], [x0, y1], [x0, y0]]))      # shapely box(), ccw
+            orient.append("cyclonic" if ev["orientation"][k] == 0 else "anticyclonic")
+        else:
+            i1, i2 = int(ev["ind1"][k]), int(ev["ind2"][k])
+            polys.append(np.c_[ct["x"][o + i1:o + i2 + 1], ct["y"][o + i1:o + i2 + 1]])
+        sums.append(ev["sums"][k])
+    for b, *_ in batches:
+        b.close()
+    if len(rows) == 0:
+        return _gf.empty_frame()                                          # streamer_index.py:278-279
+    com, mean_var, inten, area = iu.properties_from_sums(np.asarray(sums), prep.lon, prep.lat, prep.nlon)
+    cols.update(com=com, mean_var=mean_var, intensity=inten, event_area=area)   # index_utils.py:113-120
+    if kind == _hip.OVERTURNINGS:
+        cols["orientation"] = orient
+    return _gf.make_frame(cols, iu.transform_polygons(polys, prep.lon, prep.lat, prep.nlon))
