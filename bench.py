@@ -84,23 +84,34 @@ def main():
     stage_ms = {}
     counts = {}
 
+    wall = {}
+
     def one_pass(collect=False):
+        w0 = time.perf_counter()
         b = ctx.contours(d_pv, lat, lon, levels, a.dlon, a.dlon, intensity=d_int, device_shape=(nt, nlat, nlon),
                          device_dtype=np.float32, want_cells=False)
+        w1 = time.perf_counter()
         g = wd.global_max_nux(b.max_nux(), dist if world > 1 else None)     # exchange (1): one int32 all-reduce(max)
         b.indices(g)
-        ct = b.contour_table()
-        ev = [b.events(k) for k in (0, 1, 2)]
+        w2 = time.perf_counter()
+        ev = [b.events(k) for k in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
+        w3 = time.perf_counter()
         if world > 1:                                                          # exchange (2): one gather to rank 0
             wd.gather_event_tables([wd.pack_events(e, step_offset=t0) for e in ev], dist, dst=0)
+        w4 = time.perf_counter()
         if collect:
             for name, ms in b.timings():
                 stage_ms.setdefault(name, []).append(ms)
-            counts.update(contours=int(ct["step"].size), contour_points=int(ct["x"].size),
+            counts.update(polygon_vertices=int(sum(e["poly_x"].size for e in ev)),
                           streamers=int(ev[0]["step"].size), overturnings=int(ev[1]["step"].size),
                           cutoffs=int(ev[2]["step"].size), band_hits=b.band_hits(),
                           status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0)
         b.close()
+        w5 = time.perf_counter()
+        if collect:
+            for k, v in (("contours_call", w1 - w0), ("indices_call", w2 - w1), ("tables_call", w3 - w2),
+                         ("gather", w4 - w3), ("free", w5 - w4)):
+                wall.setdefault(k, []).append(1e3 * v)
         return ev
 
     for _ in range(a.warmup):
@@ -137,6 +148,7 @@ def main():
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
                          "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
             "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
+            "host_wall_ms": {k: float(np.mean(v)) for k, v in wall.items()},
             "counts": counts,
         }
         if world == 1 and a.cpu_sample > 0:

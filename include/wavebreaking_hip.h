@@ -84,6 +84,9 @@ typedef struct wb_event_table {
     const int64_t* cell_offset; /* into cell_x / cell_y, or NULL when want_cells == 0 */
     const int32_t* cell_x;
     const int32_t* cell_y;
+    const int64_t* poly_offset; /* [n+1] polygon vertices in index coordinates (streamers, cutoffs; overturnings: */
+    const int32_t* poly_x;      /*  the 4 box corners in shapely.geometry.box order), so that the event table   */
+    const int32_t* poly_y;      /*  is self-contained and the contour table need not be fetched                 */
 } wb_event_table;
 
 #define WB_STATUS_OVERFLOW_SEG 1u

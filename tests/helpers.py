@@ -83,6 +83,8 @@ def compare_events(got, contours, ref_rows, kind, levels, rtol=1e-6):
             i1, i2 = int(got["ind1"][k]), int(got["ind2"][k])
             poly = np.c_[contours["x"][o + i1:o + i2 + 1], contours["y"][o + i1:o + i2 + 1]]
         assert np.array_equal(poly, r["_polygon"]), (kind, k)
+        a, b = got["poly_offset"][k], got["poly_offset"][k + 1]
+        assert np.array_equal(np.c_[got["poly_x"][a:b], got["poly_y"][a:b]], r["_polygon"]), (kind, k)
         # cells: bit-exact
         xs, ys = r["_cells"]
         assert got["ncells"][k] == len(xs), (kind, k)

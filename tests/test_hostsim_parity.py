@@ -77,12 +77,20 @@ def test_capacity_retry_paths(sim):
 
 
 def test_level_hit_is_flagged(sim):
+    # a cell that equals the level AND sits on the contour puts a crossing on a grid vertex
     lib, ctx = sim
     lat, lon = synth.grid(2.5)
     pv = synth.pv_field(0, 1, lat, lon, eps=0.0)
-    pv[0, 50, 10] = 2.0
+    j, i = np.argwhere((pv[0, :, :-1] < 2.0) & (pv[0, :, 1:] > 2.0))[0]
+    pv[0, j, i] = 2.0
     got = helpers.run_abi(ctx, pv, lat, lon, [2.0])
     assert got["status"][0] & _hip.STATUS_LEVEL_HIT
+    # a hit far away from any crossing changes nothing and is not reported
+    pv = synth.pv_field(0, 1, lat, lon, eps=0.0)
+    pv[0, 36, 5] = 2.0
+    pv[0, 35:38, 4:7] = np.minimum(pv[0, 35:38, 4:7], 2.0)
+    got2 = helpers.run_abi(ctx, pv, lat, lon, [2.0])
+    assert not (got2["status"][0] & _hip.STATUS_LEVEL_HIT)
 
 
 def test_empty_field_gives_empty_tables(sim):

@@ -41,6 +41,7 @@ class WbEventTable(C.Structure):
         ("box", C.POINTER(C.c_int32)), ("orientation", C.POINTER(C.c_int32)), ("sums", C.POINTER(C.c_double)),
         ("ncells", C.POINTER(C.c_int32)), ("cell_offset", C.POINTER(C.c_int64)),
         ("cell_x", C.POINTER(C.c_int32)), ("cell_y", C.POINTER(C.c_int32)),
+        ("poly_offset", C.POINTER(C.c_int64)), ("poly_x", C.POINTER(C.c_int32)), ("poly_y", C.POINTER(C.c_int32)),
     ]
 
 
@@ -286,6 +287,10 @@ class Batch:
                    contour=_arr(t.contour, n, np.int64), ind1=_arr(t.ind1, n, np.int32), ind2=_arr(t.ind2, n, np.int32),
                    box=_arr(t.box, 4 * n, np.int32).reshape(-1, 4), orientation=_arr(t.orientation, n, np.int32),
                    sums=_arr(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=_arr(t.ncells, n, np.int32))
+        poff = _arr(t.poly_offset, n + 1, np.int64)
+        out["poly_offset"] = poff
+        out["poly_x"] = _arr(t.poly_x, poff[-1] if n else 0, np.int32)
+        out["poly_y"] = _arr(t.poly_y, poff[-1] if n else 0, np.int32)
         if self.want_cells and t.cell_offset:
             off = _arr(t.cell_offset, n + 1, np.int64)
             out["cell_offset"] = off

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -37,8 +38,25 @@ struct wb_ctx {
     std::string err;
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
+    // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
+    // (measured: 0.7 ms for the first pass's ~40 allocations, 350 ms for every later pass), so blocks are
+    // kept for the life of the context and handed out again by size
+    std::multimap<size_t, void*> pool;        // free blocks by size
+    std::map<void*, size_t> live;             // blocks handed out
+    // pinned staging buffer for large device<->host copies.  Copying straight into pageable memory makes the
+    // runtime register those pages with the GPU; when the caller frees them the kernel driver's MMU notifier
+    // evicts and restores the process's queues (measured: ~20 ms stall on the next dispatch).
+    void* pin = nullptr;
+    size_t pin_bytes = 0;
 #endif
 };
+
+#include <chrono>
+static double wb_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool wb_debug() { static int v = -1; if (v < 0) v = getenv("WB_DEBUG_TIMING") ? 1 : 0; return v == 1; }
+#define WB_TICK(label) do { if (wb_debug()) { double t_ = wb_now_ms(); fprintf(stderr, "[wb] %-28s %9.3f ms\n", label, t_ - wb_t0_); wb_t0_ = t_; } } while (0)
 
 static int wb_fail(wb_ctx* c, const std::string& m) {
     if (c) c->err = m;
@@ -54,19 +72,82 @@ static int d2h(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); ret
 static int dsync(wb_ctx*) { return 0; }
 #else
 static void* dmalloc(wb_ctx* c, size_t bytes) {
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-        c->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
-        return nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    auto it = c->pool.lower_bound(bytes);
+    if (it != c->pool.end() && it->first <= bytes + bytes / 4 + 4096) {   // close enough: reuse
+        void* p = it->second;
+        c->live[p] = it->first;
+        c->pool.erase(it);
+        return p;
     }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        // out of memory: give the cached blocks back and try once more
+        for (auto& kv : c->pool) (void)hipFree(kv.second);
+        c->pool.clear();
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            c->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
+            return nullptr;
+        }
+    }
+    c->live[p] = bytes;
     return p;
 }
-static void dfree(wb_ctx*, void* p) { if (p) (void)hipFree(p); }
-static int dmemset(wb_ctx* c, void* p, int v, size_t bytes) { return hipMemsetAsync(p, v, bytes, c->stream) != hipSuccess; }
+static void dfree(wb_ctx* c, void* p) {
+    if (!p) return;
+    auto it = c->live.find(p);
+    if (it == c->live.end()) { (void)hipFree(p); return; }
+    c->pool.insert({it->second, p});
+    c->live.erase(it);
+}
+// zero / byte fill as our own kernel on the context's stream (hipMemsetAsync showed ~20 ms stalls on the first
+// call of every pass on this stack)
+__global__ void wb_k_fill(unsigned char* p, int v, size_t bytes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += stride) p[i] = (unsigned char)v;
+}
+static int dmemset(wb_ctx* c, void* p, int v, size_t bytes) {
+    if (!bytes) return 0;
+    size_t blocks = (bytes + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(wb_k_fill, dim3((unsigned)blocks), dim3(256), 0, c->stream, (unsigned char*)p, v, bytes);
+    return 0;
+}
+#define WB_PIN_THRESHOLD (256u << 10)
+static void* wb_pin(wb_ctx* c, size_t bytes) {
+    if (c->pin_bytes >= bytes) return c->pin;
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr;
+    c->pin_bytes = 0;
+    size_t want = (size_t)32 << 20;
+    while (want < bytes && want < ((size_t)256 << 20)) want <<= 1;
+    if (hipHostMalloc(&c->pin, want, hipHostMallocDefault) != hipSuccess) { c->pin = nullptr; return nullptr; }
+    c->pin_bytes = want;
+    return c->pin;
+}
 static int h2d(wb_ctx* c, void* d, const void* s, size_t b) {
+    if (b > WB_PIN_THRESHOLD && wb_pin(c, b < ((size_t)256 << 20) ? b : ((size_t)256 << 20))) {
+        for (size_t o = 0; o < b; o += c->pin_bytes) {
+            const size_t n = b - o < c->pin_bytes ? b - o : c->pin_bytes;
+            memcpy(c->pin, (const char*)s + o, n);
+            if (hipMemcpyAsync((char*)d + o, c->pin, n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+        }
+        return 0;
+    }
     return hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
 }
 static int d2h(wb_ctx* c, void* d, const void* s, size_t b) {
+    if (b > WB_PIN_THRESHOLD && wb_pin(c, b < ((size_t)256 << 20) ? b : ((size_t)256 << 20))) {
+        for (size_t o = 0; o < b; o += c->pin_bytes) {
+            const size_t n = b - o < c->pin_bytes ? b - o : c->pin_bytes;
+            if (hipMemcpyAsync(c->pin, (const char*)s + o, n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+            memcpy((char*)d + o, c->pin, n);
+        }
+        return 0;
+    }
     return hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
 }
 static int dsync(wb_ctx* c) {
@@ -150,8 +231,10 @@ struct wb_batch {
     const void* d_field = nullptr;
     const void* d_intensity = nullptr;
     // phase 1
-    uint32_t *segk = nullptr, *segf = nullptr, *segt = nullptr, *rowptr = nullptr, *status = nullptr;
-    int* nseg = nullptr;
+    uint32_t *stg_k = nullptr, *status = nullptr;
+    void* stg_v = nullptr;
+    int* stg_n = nullptr;
+    int nstrips = 0, cap_strip = 0;
     uint32_t *cpts = nullptr, *cown = nullptr;
     int *c_off = nullptr, *c_len = nullptr, *c_closed = nullptr, *c_nux = nullptr, *c_sumy = nullptr, *ncont = nullptr;
     int* d_max_nux = nullptr;
@@ -174,8 +257,8 @@ struct wb_batch {
     std::vector<int32_t> ct_step, ct_level, ct_closed, ct_nux, ct_npts, ct_x, ct_y;
     std::vector<int64_t> ct_sumy, ct_off, ct_base;   // ct_base[job] = first contour row of the job
     struct Ev {
-        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, cx, cy;
-        std::vector<int64_t> contour, celloff;
+        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, cx, cy, px, py;
+        std::vector<int64_t> contour, celloff, polyoff;
         std::vector<double> sums;
     } ev[3];
     WbTimer timer;
@@ -237,6 +320,10 @@ int wb_create(int device_id, wb_ctx** out) {
 void wb_destroy(wb_ctx* c) {
     if (!c) return;
 #if !defined(WB_HOSTSIM)
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool) (void)hipFree(kv.second);
+    for (auto& kv : c->live) (void)hipFree(kv.first);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 #endif
     delete c;
@@ -251,8 +338,11 @@ int wb_memcpy_d2h(wb_ctx* c, void* d, const void* s, uint64_t b) { return d2h(c,
 
 void wb_free_batch(wb_batch* b) {
     if (!b) return;
+    double wb_t0_ = wb_now_ms();
     for (void* p : b->owned) dfree(b->ctx, p);
+    WB_TICK("free_batch device");
     delete b;
+    WB_TICK("free_batch host");
 }
 
 }  // extern "C"
@@ -262,13 +352,14 @@ static int run_phase1(wb_batch* b) {
     wb_ctx* ctx = b->ctx;
     const wb_params& p = b->p;
     const int J = b->njobs, cap = b->cap_seg, nlat = p.nlat;
+    const int NS = b->nstrips, caps = b->cap_strip;
+    double wb_t0_ = wb_now_ms();
     b->hash_size = next_pow2(8LL * cap);
     const size_t per = (size_t)J * cap;
-    b->segk = balloc<uint32_t>(b, per);
-    b->segf = balloc<uint32_t>(b, per);
-    b->segt = balloc<uint32_t>(b, per);
-    b->rowptr = balloc<uint32_t>(b, (size_t)J * nlat);
-    b->nseg = balloc<int>(b, J);
+    const size_t pers = (size_t)J * NS * caps;
+    b->stg_k = balloc<uint32_t>(b, pers);
+    b->stg_v = balloc<unsigned char>(b, pers * 4 * (p.dtype == 0 ? 4 : 8));
+    b->stg_n = balloc<int>(b, (size_t)J * NS);
     b->status = balloc<uint32_t>(b, J);
     b->cpts = balloc<uint32_t>(b, 2 * per);
     b->cown = balloc<uint32_t>(b, 2 * per);
@@ -284,48 +375,70 @@ static int run_phase1(wb_batch* b) {
     memset(&ta, 0, sizeof(ta));
     std::vector<void*>& sc = b->phase1_scratch;
     for (int i = 0; i < 10; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
+    for (int i = 0; i < 3; ++i) { ta.mseg[i] = balloc<uint32_t>(b, per); sc.push_back(ta.mseg[i]); }
     ta.rawpt = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawpt);
     ta.rawcid = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawcid);
     ta.keep = balloc<int>(b, (size_t)J * (2 * cap + 1)); sc.push_back(ta.keep);
     ta.hkey = balloc<unsigned long long>(b, (size_t)J * b->hash_size); sc.push_back(ta.hkey);
     ta.hval = balloc<uint32_t>(b, (size_t)J * b->hash_size); sc.push_back(ta.hval);
     if (!ta.hval) return 1;
+    WB_TICK("phase1 allocations");
+    if (wb_debug()) { dsync(ctx); WB_TICK("phase1 pre-sync"); }
     dmemset(ctx, b->status, 0, (size_t)J * sizeof(uint32_t));
+    WB_TICK("phase1 memset launch call");
+    if (wb_debug()) { dsync(ctx); WB_TICK("phase1 memset status sync"); }
     dmemset(ctx, b->d_max_nux, 0, sizeof(int));
-    dmemset(ctx, b->nseg, 0, (size_t)J * sizeof(int));
+    dmemset(ctx, b->stg_n, 0, (size_t)J * NS * sizeof(int));
+    if (wb_debug()) { dsync(ctx); WB_TICK("phase1 memsets+sync"); }
 
     WbScanArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.nt = p.nt; sa.nlat = nlat; sa.nlon = p.nlon; sa.W = b->W; sa.padd = b->padd; sa.nlev = p.nlevels; sa.cap_seg = cap;
+    sa.nt = p.nt; sa.nlat = nlat; sa.nlon = p.nlon; sa.W = b->W; sa.nlev = p.nlevels; sa.nstrips = NS; sa.cap_strip = caps;
     sa.field = b->d_field;
     for (int l = 0; l < p.nlevels; ++l) sa.levels[l] = b->levels[l];
-    sa.segk = b->segk; sa.segf = b->segf; sa.segt = b->segt; sa.rowptr = b->rowptr; sa.nseg = b->nseg; sa.status = b->status;
+    sa.stg_k = b->stg_k; sa.stg_v = b->stg_v; sa.stg_n = b->stg_n; sa.status = b->status;
     b->timer.begin(ctx, "scan");
 #if defined(WB_HOSTSIM)
     if (p.dtype == 0) wb_scan_host<float>(sa); else wb_scan_host<double>(sa);
 #else
     {
         const size_t esz = p.dtype == 0 ? 4 : 8;
-        const size_t shmem = 2 * (size_t)b->W * esz + 2 * (size_t)p.nlevels * 64 * sizeof(int);
-        if (p.dtype == 0) hipLaunchKernelGGL(wb_k_scan<float>, dim3(p.nt), dim3(256), shmem, ctx->stream, sa);
-        else hipLaunchKernelGGL(wb_k_scan<double>, dim3(p.nt), dim3(256), shmem, ctx->stream, sa);
+        // float4 / double4 row loads need 4-column granularity and a 16 / 32 byte aligned base
+        const bool vec = (p.nlon % 4 == 0) && (b->W % 4 == 0) && (((uintptr_t)b->d_field) % (4 * esz) == 0);
+        long long nwg = ((long long)p.nt * NS + 3) / 4;
+        if (nwg > 256 * 8) nwg = 256 * 8;                 // persistent: 8 workgroups (32 waves) per CU
+        const dim3 grid((unsigned)nwg), block(256);
+#define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan<T, V, N>), grid, block, 0, ctx->stream, sa)
+#define WB_SCAN_N(T, V) \
+        switch (p.nlevels) { case 1: WB_SCAN_LAUNCH(T, V, 1); break; case 2: WB_SCAN_LAUNCH(T, V, 2); break; \
+                             case 3: WB_SCAN_LAUNCH(T, V, 3); break; default: WB_SCAN_LAUNCH(T, V, 4); break; }
+        if (p.dtype == 0) { if (vec) { WB_SCAN_N(float, true) } else { WB_SCAN_N(float, false) } }
+        else { if (vec) { WB_SCAN_N(double, true) } else { WB_SCAN_N(double, false) } }
+#undef WB_SCAN_N
+#undef WB_SCAN_LAUNCH
     }
 #endif
     b->timer.end(ctx);
+    if (wb_debug()) { dsync(ctx); WB_TICK("phase1 scan+sync"); }
 
     ta.njobs = J; ta.nlat = nlat; ta.nlon = p.nlon; ta.W = b->W; ta.cap_seg = cap; ta.hash_size = b->hash_size;
-    ta.segk = b->segk; ta.segf = b->segf; ta.segt = b->segt; ta.rowptr = b->rowptr; ta.nseg = b->nseg;
+    ta.nstrips = NS; ta.cap_strip = caps;
+    ta.stg_k = b->stg_k; ta.stg_v = b->stg_v; ta.stg_n = b->stg_n; ta.dtype = p.dtype; ta.nlev = p.nlevels;
+    for (int l = 0; l < p.nlevels; ++l) ta.levels[l] = b->levels[l];
     ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
     ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.max_nux = b->d_max_nux;
     b->timer.begin(ctx, "trace");
     WB_LAUNCH(wb_k_trace, J, 256, ta);
     b->timer.end(ctx);
+    WB_TICK("phase1 launches");
     if (dsync(ctx)) return 1;
+    WB_TICK("phase1 sync");
     return 0;
 }
 
 extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
     if (!ctx || !pp || !out) return 1;
+    double wb_tc_ = wb_now_ms();
     const wb_params& p = *pp;
     if (p.nt <= 0 || p.nlat < 2 || p.nlon < 2) return wb_fail(ctx, "bad dimensions");
     if (p.nlevels < 1 || p.nlevels > WB_MAX_LEVELS) return wb_fail(ctx, "between 1 and 4 contour levels per call");
@@ -368,17 +481,29 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
             b->d_intensity = di;
         }
     }
+    b->nstrips = (W - 1 + WB_STRIP - 1) / WB_STRIP;
+    if (b->nstrips < 1) b->nstrips = 1;
     int cap = p.cap_seg > 0 ? p.cap_seg : next_pow2(8LL * W);
     if (cap < 1024) cap = 1024;
+    int caps = b->nstrips > 2 ? cap / 4 : (b->nstrips > 1 ? cap / 2 : cap);
     for (int attempt = 0; attempt < 6; ++attempt) {
         b->cap_seg = cap;
+        b->cap_strip = caps;
         b->timer.clear();
         if (run_phase1(b)) { std::string e = ctx->err; wb_free_batch(b); return wb_fail(ctx, e); }
-        std::vector<int> nseg(b->njobs);
-        d2h(ctx, nseg.data(), b->nseg, nseg.size() * sizeof(int));
-        int mx = 0;
-        for (int v : nseg) mx = v > mx ? v : mx;
-        if (mx <= cap) break;
+        std::vector<int> nseg((size_t)b->njobs * b->nstrips);
+        d2h(ctx, nseg.data(), b->stg_n, nseg.size() * sizeof(int));
+        int mx = 0, mxs = 0;
+        for (int j = 0; j < b->njobs; ++j) {
+            int tot = 0;
+            for (int q = 0; q < b->nstrips; ++q) {
+                const int v = nseg[(size_t)j * b->nstrips + q];
+                tot += v;
+                mxs = v > mxs ? v : mxs;
+            }
+            mx = tot > mx ? tot : mx;
+        }
+        if (mx <= cap && mxs <= caps) break;
         // overflow: free everything phase 1 allocated (the field copies stay) and retry with room to spare
         std::vector<void*> keep;
         for (void* q : b->owned) {
@@ -386,7 +511,9 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
         }
         b->owned = keep;
         b->phase1_scratch.clear();
-        cap = next_pow2((long long)mx + mx / 4);
+        if (mx > cap) cap = next_pow2((long long)mx + mx / 4);
+        if (mxs > caps) caps = next_pow2((long long)mxs + mxs / 4);
+        if (caps > cap) caps = cap;
         if (attempt == 5) { wb_free_batch(b); return wb_fail(ctx, "segment capacity overflow"); }
     }
     b->h_ncont.resize(b->njobs);
@@ -395,13 +522,18 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
     d2h(ctx, b->h_status.data(), b->status, b->njobs * sizeof(uint32_t));
     d2h(ctx, &b->max_nux, b->d_max_nux, sizeof(int));
     // phase-1 scratch is dead now
+    double wb_t0_ = wb_now_ms();
     for (void* q : b->phase1_scratch) bfree_one(b, q);
     b->phase1_scratch.clear();
-    bfree_one(b, b->segk); bfree_one(b, b->segf); bfree_one(b, b->segt); bfree_one(b, b->rowptr); bfree_one(b, b->cown);
-    b->segk = b->segf = b->segt = b->rowptr = b->cown = nullptr;
+    bfree_one(b, b->stg_k); bfree_one(b, b->stg_v); bfree_one(b, b->stg_n); bfree_one(b, b->cown);
+    b->stg_k = b->cown = nullptr;
+    b->stg_v = nullptr;
+    b->stg_n = nullptr;
+    WB_TICK("phase1 frees");
     b->ct_base.assign(b->njobs + 1, 0);
     for (int j = 0; j < b->njobs; ++j) b->ct_base[j + 1] = b->ct_base[j] + b->h_ncont[j];
     *out = b;
+    if (wb_debug()) fprintf(stderr, "[wb] wb_contours total            %9.3f ms\n", wb_now_ms() - wb_tc_);
     return 0;
 }
 
@@ -586,6 +718,21 @@ WB_KERNEL(wb_k_sel_maxlen, int nsel, int cap_seg, const int* sel_job, const int*
     WB_END_PFOR
 }
 
+// event polygons: vertices of every event, back to back (x | y<<16)
+WB_KERNEL(wb_k_pack_polys, int nev, int cap_seg, const int* ev, const long long* poff, const int* c_off, const uint32_t* cpts,
+          uint32_t* out) {
+    for (int e = WB_BLOCK_ID; e < nev; e += WB_GRID_DIM) {
+        const int* d = ev + (size_t)e * 8;
+        const size_t jb = (size_t)d[1] * cap_seg;
+        const uint32_t* pts = cpts + 2 * jb + c_off[jb + d[2]];
+        const int n = (int)(poff[e + 1] - poff[e]);
+        uint32_t* dst = out + poff[e];
+        WB_PFOR(k, n)
+            dst[k] = wb_event_vertex(d, pts, (int)k);
+        WB_END_PFOR
+    }
+}
+
 static void make_tables(wb_batch* b) {
     if (b->d_lat) return;
     const wb_params& p = b->p;
@@ -759,7 +906,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     std::vector<double> h_sums((size_t)NE * 5 + 5, 0.0);
     std::vector<int> h_nc(NE + 1, 0);
     std::vector<long long> h_coff(NE + 1, 0);
-    std::vector<uint32_t> h_cells;
+    std::vector<uint32_t> h_cells, h_poly;
+    std::vector<long long> h_poff(NE + 1, 0);
     if (NE > 0) {
         int* d_sbase = (int*)talloc((nsel + 1) * sizeof(int));
         int* d_obase = (int*)talloc((nsel + 1) * sizeof(int));
@@ -809,6 +957,20 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         }
         b->timer.begin(ctx, "events_d2h");
         d2h(ctx, h_ev.data(), d_ev, (size_t)NE * 8 * sizeof(int));
+        // polygon vertices of all events in one packed transfer
+        for (int e = 0; e < NE; ++e) {
+            const int* d = &h_ev[(size_t)e * 8];
+            h_poff[e + 1] = h_poff[e] + (d[0] == WB_EV_OVERTURNING ? 4 : d[4] - d[3] + 1);
+        }
+        {
+            long long* d_poff = (long long*)talloc((NE + 1) * sizeof(long long));
+            uint32_t* d_poly = (uint32_t*)talloc((size_t)(h_poff[NE] + 1) * sizeof(uint32_t));
+            if (!d_poly) return 1;
+            h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
+            WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_poly);
+            h_poly.resize((size_t)h_poff[NE]);
+            if (!h_poly.empty()) d2h(ctx, h_poly.data(), d_poly, h_poly.size() * sizeof(uint32_t));
+        }
         d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
         d2h(ctx, h_nc.data(), pa.ev_ncells, (size_t)NE * sizeof(int));
         if (p.want_cells) {
@@ -840,6 +1002,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 t.orient.push_back(0);
             }
             t.sums.insert(t.sums.end(), &h_sums[(size_t)e * 5], &h_sums[(size_t)e * 5] + 5);
+            t.polyoff.push_back((int64_t)t.px.size());
+            for (long long q = h_poff[e]; q < h_poff[e + 1]; ++q) {
+                t.px.push_back(wb_pt_x(h_poly[(size_t)q]));
+                t.py.push_back(wb_pt_y(h_poly[(size_t)q]));
+            }
             t.ncells.push_back(h_nc[e]);
             if (p.want_cells) {
                 t.celloff.push_back((int64_t)t.cx.size());
@@ -852,6 +1019,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             }
         }
         if (p.want_cells) t.celloff.push_back((int64_t)t.cx.size());
+        t.polyoff.push_back((int64_t)t.px.size());
     }
     for (void* q : tmp) bfree_one(b, q);
     b->sel_job = b->sel_cont = b->cut_job = b->cut_cont = nullptr;
@@ -868,6 +1036,8 @@ extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
     o->sums = t.sums.data(); o->ncells = t.ncells.data();
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
+    if (t.polyoff.empty()) t.polyoff.push_back(0);
+    o->poly_offset = t.polyoff.data(); o->poly_x = t.px.data(); o->poly_y = t.py.data();
     return 0;
 }
 

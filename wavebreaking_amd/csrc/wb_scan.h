@@ -1,43 +1,60 @@
 // wb_scan.h -- kernel 1: marching-squares scan of the field (THE HBM-bound kernel).
 //
-// One workgroup per time step streams the (nlat, nlon) field row by row, exactly once, for all
-// contour levels at once.  Two consecutive rows of the periodically extended field
-// (contour_index.py:94-100: columns nlon..W-1 repeat columns 0..padd-1) live in LDS; every lane
-// owns one 2x2 square per 64-square group, classifies it (case = ul>lvl | ur>lvl<<1 | ll>lvl<<2 |
-// lr>lvl<<3, squares with a NaN corner skipped), and the rare squares that carry a segment are
-// compacted in raster order with wave ballots + one wave scan over the per-group counts.  Each
-// emitted segment carries its key (square, sub-segment, case) and the two crossing points already
-// rounded half-to-even on the f64 sum c0 + (lvl - v0)/(v1 - v0) (contour_index.py:111).
+// Work decomposition: the extended row of W-1 squares is cut into strips of 256 squares; ONE WAVE
+// streams one strip of one time step top to bottom, for all contour levels at once, with no LDS and
+// no barrier (persistent waves loop over (time step, strip) work items).  A lane owns 4 consecutive
+// squares per row (one float4 / double4 load, 1 KiB per wave-load, each field value loaded from HBM once; the periodic columns nlon..W-1 of
+// contour_index.py:94-100 are re-reads of columns 0..padd-1 that hit L2).  The previous row stays in
+// registers together with its horizontal pair-wise min/max, so a square costs two min, two max and two
+// compares per level:
 //
-// Algorithmic HBM traffic: nlat*nlon*sizeof(T) read per time step (+ ~12 B per segment written).
+//     crossing in the square  <=>  max(corners) > lvl  and not  min(corners) > lvl
+//
+// evaluated in the field's own precision against  lvl_lo = largest T <= level.  That is EXACT, not a
+// conservative filter: for a T-valued v, (double)v > level  <=>  v > lvl_lo, which is skimage's strict
+// `>` on the float64 copy (contour_index.py:103).  Only when some lane of the wave sees a crossing does
+// the wave take the emit path: per-square case, ballots for raster-order offsets inside the strip; the
+// segment's key and corner values are stored (the f64 crossing coordinate c0 + (lvl - v0)/(v1 - v0) and
+// its round-half-even, contour_index.py:111, are evaluated when the trace kernel merges the strips).
+// Squares with a NaN corner are skipped like skimage does.
+//
+// Output: per (job, strip) a list of segments in raster order (key, from point, to point); the trace
+// kernel merges the <= 16 sorted strip lists of a job by rank (wb_trace.h, P0).
+//
+// Algorithmic HBM traffic: nlat*nlon*sizeof(T) per time step (+ 4+4*sizeof(T) B per segment, < 1 %).
 #pragma once
 #include "wb_core.h"
-#include "wb_trace.h"
 
 #define WB_MAX_LEVELS 4
+#define WB_STRIP 256          // squares per strip = 64 lanes x 4 squares
+#define WB_MAX_STRIPS 16      // W <= 4096
+
+#define WB_ST_OVERFLOW_SEG 1u   // more segments than capacity: job skipped, host retries with a larger cap
+#define WB_ST_LEVEL_HIT 2u      // some cell equals the level exactly (edge linking != skimage's coordinate joins)
+#define WB_ST_HAS_NAN 4u
+#define WB_ST_HASH_FULL 8u
+#define WB_ST_OVERFLOW_PAIRS 16u
 
 struct WbScanArgs {
-    int nt, nlat, nlon, W, padd, nlev, cap_seg;
+    int nt, nlat, nlon, W, nlev, nstrips, cap_strip;
     const void* field;      // [nt][nlat][nlon], T
     double levels[WB_MAX_LEVELS];
-    uint32_t* segk;         // [nt*nlev][cap_seg]
-    uint32_t* segf;
-    uint32_t* segt;
-    uint32_t* rowptr;       // [nt*nlev][nlat]
-    int* nseg;              // [nt*nlev]
-    uint32_t* status;       // [nt*nlev]
+    uint32_t* stg_k;        // [njobs][nstrips][cap_strip] key
+    void* stg_v;            // [njobs][nstrips][cap_strip][4] corner values ul, ur, ll, lr (T)
+    int* stg_n;             // [njobs][nstrips] segments found (may exceed cap_strip: overflow)
+    uint32_t* status;       // [njobs]
 };
 
+// a segment is stored as its key + the four corner values of its square; the crossing coordinates
+// (f64 divisions) are evaluated by the trace kernel's merge phase, which keeps this kernel's registers low
 template <typename T>
-WB_HD inline void wb_emit_square(const WbScanArgs& a, int job, int r, int c, int cs, int ns, double ul, double ur,
-                                 double ll, double lr, double level, int idx) {
-    const size_t jb = (size_t)job * a.cap_seg;
+WB_HD inline void wb_store_square(uint32_t* stg_k, T* stg_v, int cap_strip, int W, int r, int c, int cs, int ns, T ul, T ur,
+                                  T ll, T lr, int idx) {
     for (int sub = 0; sub < ns; ++sub) {
-        if (idx + sub < a.cap_seg) {
-            const int fs = wb_seg_from(cs, sub), ts = wb_seg_to(cs, sub);
-            a.segk[jb + idx + sub] = wb_seg_key(r, c, a.W, sub, cs);
-            a.segf[jb + idx + sub] = wb_crossing_point(fs, r, c, ul, ur, ll, lr, level);
-            a.segt[jb + idx + sub] = wb_crossing_point(ts, r, c, ul, ur, ll, lr, level);
+        if (idx + sub < cap_strip) {
+            stg_k[idx + sub] = wb_seg_key(r, c, W, sub, cs);
+            T* v = stg_v + (size_t)(idx + sub) * 4;
+            v[0] = ul; v[1] = ur; v[2] = ll; v[3] = lr;
         }
     }
 }
@@ -48,7 +65,7 @@ WB_HD inline int wb_square_case(double ul, double ur, double ll, double lr, doub
 }
 
 #if defined(WB_HOSTSIM)
-// serial statement of the same scan (host simulation only)
+// serial statement of the same scan with the same output layout (host simulation only)
 template <typename T>
 void wb_scan_host(const WbScanArgs& a) {
     for (int t = 0; t < a.nt; ++t) {
@@ -56,197 +73,192 @@ void wb_scan_host(const WbScanArgs& a) {
         for (int l = 0; l < a.nlev; ++l) {
             const int job = t * a.nlev + l;
             const double level = a.levels[l];
-            int run = 0;
             uint32_t st = 0;
             for (int r = 0; r < a.nlat; ++r)
                 for (int c = 0; c < a.nlon; ++c) {
                     const double v = (double)f[(size_t)r * a.nlon + c];
                     if (v != v) st |= WB_ST_HAS_NAN;
-                    if (v == level) st |= WB_ST_LEVEL_HIT;
                 }
-            for (int r = 0; r < a.nlat - 1; ++r) {
-                a.rowptr[(size_t)job * a.nlat + r] = (uint32_t)run;
-                for (int c = 0; c < a.W - 1; ++c) {
-                    const double ul = (double)f[(size_t)r * a.nlon + c % a.nlon];
-                    const double ur = (double)f[(size_t)r * a.nlon + (c + 1) % a.nlon];
-                    const double ll = (double)f[(size_t)(r + 1) * a.nlon + c % a.nlon];
-                    const double lr = (double)f[(size_t)(r + 1) * a.nlon + (c + 1) % a.nlon];
-                    const int cs = wb_square_case(ul, ur, ll, lr, level);
-                    const int ns = wb_case_nseg(cs);
-                    if (ns) wb_emit_square<T>(a, job, r, c, cs, ns, ul, ur, ll, lr, level, run);
-                    run += ns;
+            for (int s = 0; s < a.nstrips; ++s) {
+                const size_t base = ((size_t)job * a.nstrips + s) * a.cap_strip;
+                int run = 0;
+                for (int r = 0; r < a.nlat - 1; ++r) {
+                    for (int c = s * WB_STRIP; c < (s + 1) * WB_STRIP && c < a.W - 1; ++c) {
+                        const double ul = (double)f[(size_t)r * a.nlon + c % a.nlon];
+                        const double ur = (double)f[(size_t)r * a.nlon + (c + 1) % a.nlon];
+                        const double ll = (double)f[(size_t)(r + 1) * a.nlon + c % a.nlon];
+                        const double lr = (double)f[(size_t)(r + 1) * a.nlon + (c + 1) % a.nlon];
+                        const int cs = wb_square_case(ul, ur, ll, lr, level);
+                        const int ns = wb_case_nseg(cs);
+                        if (ns) wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, a.W, r, c, cs, ns, (T)ul, (T)ur, (T)ll, (T)lr, run);
+                        run += ns;
+                    }
                 }
+                a.stg_n[job * a.nstrips + s] = run;
             }
-            a.rowptr[(size_t)job * a.nlat + a.nlat - 1] = (uint32_t)run;
-            a.nseg[job] = run;
             a.status[job] = st;
         }
     }
 }
 #else
 // ------------------------------------------------------------------------------------------------
-// gfx950 kernel.  blockDim.x = 256 (4 waves); dynamic LDS = 2*W*sizeof(T) + 2*nlev*64*sizeof(int).
-// Limit: ceil((W-1)/64) <= 64 groups per row, i.e. W <= 4097.
-#define WB_SCAN_PF 8   // row prefetch depth in registers: covers nlon <= 8*256
+// gfx950 kernel: blockDim.x = 256 = 4 independent persistent waves.
+//   VEC  : rows are read with one 16 / 32 byte load per lane (needs nlon % 4 == 0, W % 4 == 0, aligned base)
+//   NLEV : number of contour levels (compile time, so the level loops vanish)
+template <typename T> struct WbVec4;
+template <> struct WbVec4<float> { typedef float4 type; };
+template <> struct WbVec4<double> { typedef double4 type; };
 
-template <typename T>
+// largest T <= level
+template <typename T> __device__ inline T wb_level_lo(double level);
+template <> __device__ inline float wb_level_lo<float>(double level) {
+    float f = (float)level;                     // round to nearest
+    if ((double)f > level) f = nextafterf(f, -INFINITY);
+    return f;
+}
+template <> __device__ inline double wb_level_lo<double>(double level) { return level; }
+
+// plain v_min / v_max (IEEE minNum/maxNum: a NaN operand is ignored); written as asm so that hipcc does not
+// wrap every call in canonicalising v_max x,x (cdna_hip_programming.md, Appendix B GEMM note)
+__device__ inline float wb_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline float wb_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline double wb_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline double wb_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// value of the next lane (lane 63 gets 0): DPP wave shift, one VALU op per dword, no LDS
+__device__ inline float wb_shl1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+__device__ inline double wb_shl1(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T, bool VEC, int NLEV>
 __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wb_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
-    const int W = a.W, nlon = a.nlon, nlat = a.nlat, nlev = a.nlev, padd = a.padd;
-    T* rowbuf[2];
-    rowbuf[0] = (T*)wb_smem;
-    rowbuf[1] = rowbuf[0] + W;
-    int* cnt = (int*)(rowbuf[1] + W);  // [2][nlev][64] double-buffered per-group segment counts
-    const T* f = (const T*)a.field + (size_t)t * nlat * nlon;
-    const int NG = (W - 1 + 63) >> 6;  // 64-square groups per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NS = a.nstrips;
+    const int W = a.W, nlon = a.nlon, nlat = a.nlat;
     const unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nwork = a.nt * NS;
 
-    int base[WB_MAX_LEVELS];
-    uint32_t st[WB_MAX_LEVELS];
-    double lev[WB_MAX_LEVELS];
+    T lvl[NLEV];
 #pragma unroll
-    for (int l = 0; l < WB_MAX_LEVELS; ++l) {
-        base[l] = 0;
-        st[l] = 0;
-        lev[l] = (l < nlev) ? a.levels[l] : 0.0;
-    }
+    for (int l = 0; l < NLEV; ++l) lvl[l] = wb_level_lo<T>(a.levels[l]);
 
-    // rows 0 and 1 -> LDS
-    for (int rr = 0; rr < 2 && rr < nlat; ++rr) {
-        for (int j = tid; j < nlon; j += 256) {
-            const T v = f[(size_t)rr * nlon + j];
-            rowbuf[rr][j] = v;
-            if (j < padd) rowbuf[rr][nlon + j] = v;
-            const double dv = (double)v;
+    for (int g = blockIdx.x * 4 + wave; g < nwork; g += gridDim.x * 4) {     // work item = (time step, strip)
+        const int t = g / NS, s = g - t * NS;
+        const T* f = (const T*)a.field + (size_t)t * nlat * nlon;
+        const int c0 = s * WB_STRIP + 4 * lane;
+        unsigned inmask = 0;                                  // bit k: square c0+k exists
 #pragma unroll
-            for (int l = 0; l < WB_MAX_LEVELS; ++l)
-                if (l < nlev) st[l] |= (dv != dv ? WB_ST_HAS_NAN : 0u) | (dv == lev[l] ? WB_ST_LEVEL_HIT : 0u);
-        }
-    }
-    for (int e = tid; e < 2 * nlev * 64; e += 256) cnt[e] = 0;
-    __syncthreads();
+        for (int k = 0; k < 4; ++k) inmask |= (c0 + k < W - 1) ? (1u << k) : 0u;
+        // column offsets inside a row; out-of-range lanes read a clamped (valid, ignored) address
+        int cm = c0 >= nlon ? c0 - nlon : c0;
+        if (cm > nlon - 4) cm = nlon - 4;
+        int ch = c0 + 4;
+        ch = ch >= nlon ? ch - nlon : ch;
+        if (ch > nlon - 1) ch = nlon - 1;
+        bool nanflag = false;
 
-    for (int r = 0; r < nlat - 1; ++r) {
-        const T* top = rowbuf[r & 1];
-        const T* bot = rowbuf[(r + 1) & 1];
-        int* cn = cnt + (r & 1) * nlev * 64;
-
-        // prefetch row r+2 into registers (consumed after the barrier)
-        T pf[WB_SCAN_PF];
-        const bool have_next = (r + 2 < nlat);
-        if (have_next) {
+        T p[5], n[5], pmin[4], pmax[4];
+        T nh = (T)0;                                          // lane 63: halo of the row held in n[0..3]
+        // a row load = the lane's 4 columns + (lane 63 only) the first column of the next strip.  The halo
+        // of the other lanes is the next lane's first column; it is fetched with a DPP wave shift only when
+        // the row is consumed, so the load itself stays in flight for a whole iteration (prefetch).
+        auto load_row = [&](int r, T v[4], T& h) {
+            const T* row = f + (size_t)r * nlon;
+            if (VEC) {
+                const typename WbVec4<T>::type q = *reinterpret_cast<const typename WbVec4<T>::type*>(row + cm);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
 #pragma unroll
-            for (int m = 0; m < WB_SCAN_PF; ++m) {
-                const int j = tid + 256 * m;
-                if (j < nlon) pf[m] = f[(size_t)(r + 2) * nlon + j];
-            }
-        }
-
-        // classify: one square per lane per group, ballots give the per-group counts
-        for (int g = wave; g < NG; g += 4) {
-            const int c = g * 64 + lane;
-            const bool in = c < W - 1;
-            const double ul = in ? (double)top[c] : 0.0, ur = in ? (double)top[c + 1] : 0.0;
-            const double ll = in ? (double)bot[c] : 0.0, lr = in ? (double)bot[c + 1] : 0.0;
-#pragma unroll
-            for (int l = 0; l < WB_MAX_LEVELS; ++l) {
-                if (l < nlev) {
-                    const int ns = in ? wb_case_nseg(wb_square_case(ul, ur, ll, lr, lev[l])) : 0;
-                    const unsigned long long m1 = __ballot(ns >= 1), m2 = __ballot(ns == 2);
-                    if (lane == 0) cn[l * 64 + g] = __popcll(m1) + __popcll(m2);
+                for (int k = 0; k < 4; ++k) {
+                    int c = c0 + k;
+                    c = c >= nlon ? c - nlon : c;
+                    v[k] = row[c > nlon - 1 ? nlon - 1 : c];
                 }
             }
-        }
-        __syncthreads();
+            if (lane == 63) h = row[ch];
+        };
 
-        // every wave scans the <=64 group counts of each level (lane = group)
-        int gpre[WB_MAX_LEVELS], rowtot[WB_MAX_LEVELS];
-        int any = 0;
+        {
+            T h0 = (T)0;
+            load_row(0, p, h0);
+            const T sh = wb_shl1(p[0]);                       // unconditional: every lane must be active for the DPP read
+            p[4] = (lane == 63) ? h0 : sh;
+        }
+        nanflag |= (p[0] + p[1] + p[2] + p[3]) != (p[0] + p[1] + p[2] + p[3]);
 #pragma unroll
-        for (int l = 0; l < WB_MAX_LEVELS; ++l) {
-            gpre[l] = 0;
-            rowtot[l] = 0;
-            if (l < nlev) {
-                const int v = (lane < NG) ? cn[l * 64 + lane] : 0;
-                const int inc = wb_wave_scan_incl(v);
-                gpre[l] = inc - v;
-                rowtot[l] = __shfl(inc, 63, 64);
-                any |= rowtot[l];
+        for (int k = 0; k < 4; ++k) { pmin[k] = wb_min(p[k], p[k + 1]); pmax[k] = wb_max(p[k], p[k + 1]); }
+        if (nlat > 1) load_row(1, n, nh);
+        T q[4], qh = (T)0;                                    // row r+2, in flight
+        if (nlat > 2) load_row(2, q, qh);
+
+        for (int r = 0; r < nlat - 1; ++r) {
+            T x[4], xh = (T)0;                                // prefetch row r+3: two rows are always in flight
+            const bool more = r + 3 < nlat;
+            if (more) load_row(r + 3, x, xh);
+            const T nsh = wb_shl1(n[0]);                      // (a lane that sits out would hand its neighbour `old`)
+            n[4] = (lane == 63) ? nh : nsh;
+            {   // a NaN anywhere poisons the sum (an inf - inf pair would too; PV fields carry neither)
+                const T sum = n[0] + n[1] + n[2] + n[3];
+                nanflag |= sum != sum;
             }
-        }
-        if (tid == 0) {
+            T nmin[4], nmax[4];
+            unsigned cmask = 0;
 #pragma unroll
-            for (int l = 0; l < WB_MAX_LEVELS; ++l)
-                if (l < nlev) a.rowptr[(size_t)(t * nlev + l) * nlat + r] = (uint32_t)base[l];
-        }
-        if (any) {  // rare path: this row carries segments
-            for (int g = wave; g < NG; g += 4) {
-                const int c = g * 64 + lane;
-                const bool in = c < W - 1;
-                const double ul = in ? (double)top[c] : 0.0, ur = in ? (double)top[c + 1] : 0.0;
-                const double ll = in ? (double)bot[c] : 0.0, lr = in ? (double)bot[c + 1] : 0.0;
+            for (int k = 0; k < 4; ++k) {
+                nmin[k] = wb_min(n[k], n[k + 1]);
+                nmax[k] = wb_max(n[k], n[k + 1]);
+                const T lo = wb_min(pmin[k], nmin[k]), hi = wb_max(pmax[k], nmax[k]);
 #pragma unroll
-                for (int l = 0; l < WB_MAX_LEVELS; ++l) {
-                    if (l < nlev) {
-                        const int goff = __shfl(gpre[l], g, 64);
-                        const int cs = in ? wb_square_case(ul, ur, ll, lr, lev[l]) : 0;
-                        const int ns = wb_case_nseg(cs);
-                        const unsigned long long m1 = __ballot(ns >= 1), m2 = __ballot(ns == 2);
-                        if (ns) {
-                            const int rank = __popcll(m1 & ltmask) + __popcll(m2 & ltmask);
-                            wb_emit_square<T>(a, t * nlev + l, r, c, cs, ns, ul, ur, ll, lr, lev[l],
-                                              base[l] + goff + rank);
-                        }
+                for (int l = 0; l < NLEV; ++l) cmask |= ((hi > lvl[l]) && !(lo > lvl[l])) ? (1u << k) : 0u;
+            }
+            if (__any((cmask & inmask) != 0)) {  // rare: some square of this strip row carries a segment (or a NaN)
+#pragma unroll 1
+                for (int l = 0; l < NLEV; ++l) {
+                    const int job = t * NLEV + l;
+                    const size_t base = ((size_t)job * NS + s) * a.cap_strip;
+                    const T lv = wb_level_lo<T>(a.levels[l]);
+                    const int off = a.stg_n[job * NS + s];     // strip cursor lives in memory
+                    int cs[4], ns[4], below = 0, total = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const T ul = p[k], ur = p[k + 1], ll = n[k], lr = n[k + 1];
+                        const bool ok = ((inmask >> k) & 1u) && ul == ul && ur == ur && ll == ll && lr == lr;
+                        // v > lvl_lo in T  <=>  (double)v > level : skimage's strict compare on the float64 copy
+                        cs[k] = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
+                        ns[k] = wb_case_nseg(cs[k]);
+                        const unsigned long long m1 = __ballot(ns[k] >= 1), m2 = __ballot(ns[k] == 2);
+                        below += __popcll(m1 & ltmask) + __popcll(m2 & ltmask);
+                        total += __popcll(m1) + __popcll(m2);
                     }
+                    int mine = off + below;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (ns[k])
+                            wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs[k], ns[k],
+                                               p[k], p[k + 1], n[k], n[k + 1], mine);
+                        mine += ns[k];
+                    }
+                    if (lane == 0) a.stg_n[job * NS + s] = off + total;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) p[k] = n[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pmin[k] = nmin[k]; pmax[k] = nmax[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { n[k] = q[k]; q[k] = x[k]; }
+            nh = qh;
+            qh = xh;
         }
+        if (__any(nanflag && (c0 < W)) && lane == 0) {
 #pragma unroll
-        for (int l = 0; l < WB_MAX_LEVELS; ++l) base[l] += rowtot[l];
-
-        // row r+2 replaces row r in LDS (everyone is past the barrier, nobody reads `top` any more
-        // except the emit path above, which this thread has finished; other threads' emit reads are
-        // protected by the barrier below only for the NEXT iteration -> write after a second barrier)
-        __syncthreads();
-        if (have_next) {
-            T* dst = rowbuf[r & 1];
-#pragma unroll
-            for (int m = 0; m < WB_SCAN_PF; ++m) {
-                const int j = tid + 256 * m;
-                if (j < nlon) {
-                    const T v = pf[m];
-                    dst[j] = v;
-                    if (j < padd) dst[nlon + j] = v;
-                    const double dv = (double)v;
-#pragma unroll
-                    for (int l = 0; l < WB_MAX_LEVELS; ++l)
-                        if (l < nlev) st[l] |= (dv != dv ? WB_ST_HAS_NAN : 0u) | (dv == lev[l] ? WB_ST_LEVEL_HIT : 0u);
-                }
-            }
-            for (int j = tid + 256 * WB_SCAN_PF; j < nlon; j += 256) {  // very wide grids: late loads
-                const T v = f[(size_t)(r + 2) * nlon + j];
-                dst[j] = v;
-                if (j < padd) dst[nlon + j] = v;
-                const double dv = (double)v;
-#pragma unroll
-                for (int l = 0; l < WB_MAX_LEVELS; ++l)
-                    if (l < nlev) st[l] |= (dv != dv ? WB_ST_HAS_NAN : 0u) | (dv == lev[l] ? WB_ST_LEVEL_HIT : 0u);
-            }
-        }
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int l = 0; l < WB_MAX_LEVELS; ++l) {
-        if (l < nlev) {
-            const int job = t * nlev + l;
-            if (st[l]) atomicOr(&a.status[job], st[l]);
-            if (tid == 0) {
-                a.rowptr[(size_t)job * nlat + nlat - 1] = (uint32_t)base[l];
-                a.nseg[job] = base[l];
-            }
+            for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
         }
     }
 }

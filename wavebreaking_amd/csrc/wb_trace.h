@@ -12,21 +12,18 @@
 //   * :154-155  number of distinct x (-> exp_lon) and sum of y (-> mean_lat).
 #pragma once
 #include "wb_core.h"
-
-#define WB_ST_OVERFLOW_SEG 1u   // more segments than cap_seg: job skipped, host retries with a larger cap
-#define WB_ST_LEVEL_HIT 2u      // some cell equals the level exactly (edge linking != skimage's coordinate joins)
-#define WB_ST_HAS_NAN 4u
-#define WB_ST_HASH_FULL 8u
-#define WB_ST_OVERFLOW_PAIRS 16u
+#include "wb_scan.h"
 
 struct WbTraceArgs {
     int njobs, nlat, nlon, W, cap_seg, hash_size;  // hash_size: power of two >= 8*cap_seg
-    // from the scan kernel, per job
-    const uint32_t* segk;    // [njobs][cap_seg] key
-    const uint32_t* segf;    // [njobs][cap_seg] lattice point of the from-crossing
-    const uint32_t* segt;    // [njobs][cap_seg] lattice point of the to-crossing
-    const uint32_t* rowptr;  // [njobs][nlat]   first segment of square-row r; [nlat-1] = total
-    const int* nseg;         // [njobs]
+    int nstrips, cap_strip;
+    // from the scan kernel, per (job, strip): raster-ordered segment lists
+    const uint32_t* stg_k;   // [njobs][nstrips][cap_strip] key
+    const void* stg_v;       // [njobs][nstrips][cap_strip][4] corner values (float or double)
+    int dtype, nlev;
+    double levels[WB_MAX_LEVELS];
+    const int* stg_n;        // [njobs][nstrips]
+    uint32_t* mseg[3];       // [njobs][cap_seg] merged key / from / to (scratch)
     // scratch, per job
     uint32_t* w[10];         // 10 arrays [njobs][cap_seg]
     uint32_t* rawpt;         // [njobs][2*cap_seg]
@@ -82,10 +79,9 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     const int cap = a.cap_seg;
     const int W = a.W;
     const size_t jb = (size_t)job * cap;
-    const uint32_t* segk = a.segk + jb;
-    const uint32_t* segf = a.segf + jb;
-    const uint32_t* segt = a.segt + jb;
-    const uint32_t* rowptr = a.rowptr + (size_t)job * a.nlat;
+    uint32_t* segk = a.mseg[0] + jb;
+    uint32_t* segf = a.mseg[1] + jb;
+    uint32_t* segt = a.mseg[2] + jb;
     uint32_t* succ = a.w[0] + jb;
     uint32_t* pred = a.w[1] + jb;
     uint32_t* jA = a.w[2] + jb;
@@ -110,8 +106,16 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     int* c_nux = a.c_nux + jb;
     int* c_sumy = a.c_sumy + jb;
 
-    int n = a.nseg[job];
-    if (n > cap) {  // overflow: the scan kernel kept counting but stopped writing
+    // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
+    //          position in its own list plus the number of smaller keys in every other list
+    int n = 0;
+    bool over = false;
+    for (int s = 0; s < a.nstrips; ++s) {
+        const int c = a.stg_n[job * a.nstrips + s];
+        if (c > a.cap_strip) over = true;
+        n += c;
+    }
+    if (over || n > cap) {  // overflow: the scan kernel kept counting but stopped writing
         WB_SINGLE
         wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_SEG);
         a.ncont[job] = 0;
@@ -124,6 +128,42 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         WB_END_SINGLE
         return;
     }
+    for (int s = 0; s < a.nstrips; ++s) {
+        const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
+        const int cnt = a.stg_n[job * a.nstrips + s];
+        WB_PFOR(i, cnt)
+            const uint32_t key = a.stg_k[sb + i];
+            const uint32_t kk = key & 0x07FFFFFFu;
+            int dest = (int)i;
+            for (int s2 = 0; s2 < a.nstrips; ++s2) {
+                if (s2 == s) continue;
+                const uint32_t* other = a.stg_k + ((size_t)job * a.nstrips + s2) * a.cap_strip;
+                int lo = 0, hi = a.stg_n[job * a.nstrips + s2];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((other[mid] & 0x07FFFFFFu) < kk) lo = mid + 1; else hi = mid;
+                }
+                dest += lo;
+            }
+            // crossing coordinates of the segment's two end points, rounded half-to-even (contour_index.py:111)
+            double ul, ur, ll, lr;
+            if (a.dtype == 0) {
+                const float* v = (const float*)a.stg_v + (sb + i) * 4;
+                ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
+            } else {
+                const double* v = (const double*)a.stg_v + (sb + i) * 4;
+                ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
+            }
+            const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
+            const double level = a.levels[job % a.nlev];
+            // a corner that equals the level puts the crossing ON a grid vertex: skimage's coordinate joins and
+            // the edge linking used here may then differ -> flag the job
+            if (ul == level || ur == level || ll == level || lr == level) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_HIT);
+            segk[dest] = key;
+            segf[dest] = wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level);
+            segt[dest] = wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level);
+        WB_END_PFOR
+    }
 
     // ---- P0: init
     WB_PFOR(i, n)
@@ -132,7 +172,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     WB_END_PFOR
 
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
-    //          the edge this one ends on (binary search in that square-row's CSR range)
+    //          the edge this one ends on (binary search by square key in the merged list)
     WB_PFOR(i, n)
         const uint32_t k = segk[i];
         const int sq = wb_key_sq(k), r = sq / W, c = sq - r * W;
@@ -145,13 +185,13 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         const int want = ts ^ 2;  // opposite side
         uint32_t s = WB_NIL;
         if (rr >= 0 && rr < a.nlat - 1 && cc >= 0 && cc < W - 1) {
-            int lo = (int)rowptr[rr], hi = (int)rowptr[rr + 1];
+            int lo = 0, hi = n;
             const int target = rr * W + cc;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (wb_key_sq(segk[mid]) < target) lo = mid + 1; else hi = mid;
             }
-            if (lo < (int)rowptr[rr + 1] && wb_key_sq(segk[lo]) == target) {
+            if (lo < n && wb_key_sq(segk[lo]) == target) {
                 const int cs2 = wb_key_case(segk[lo]);
                 if (wb_seg_from(cs2, 0) == want) s = (uint32_t)lo;
                 else if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) s = (uint32_t)lo + 1;

@@ -41,7 +41,7 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     for bi, (b, pos) in enumerate(batches):
         b.indices(g, **which)
         ev = b.events(kind)
-        ct = b.contour_table()
+        ct = None
         for k in range(ev["step"].size):
             lvl = ev["level_idx"][k]
             rows.append((int(ev["step"][k]) if pos is not None else k, pos[int(lvl)] if pos is not None else int(lvl), bi, k))
@@ -52,17 +52,12 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     polys, sums, orient = [], [], []
     for _, lpos, bi, k in rows:
         b, pos, ev, ct = batches[bi]
-        c = int(ev["contour"][k])
-        o = int(ct["offset"][c])
         cols["date"].append(prep.times[int(ev["step"][k])])
         cols["level"].append(levels[lpos])
+        a, e = int(ev["poly_offset"][k]), int(ev["poly_offset"][k + 1])
+        polys.append(np.c_[ev["poly_x"][a:e], ev["poly_y"][a:e]])        # streamer_index.py:269-272 / box / cutoff_index.py:96
         if kind == _hip.OVERTURNINGS:
-            x0, y0, x1, y1 = (int(v) for v in ev["box"][k])
-            polys.append(np.array([[x1, y0], [x1, y1], [x0, y1], [x0, y0]]))      # shapely box(), ccw
             orient.append("cyclonic" if ev["orientation"][k] == 0 else "anticyclonic")
-        else:
-            i1, i2 = int(ev["ind1"][k]), int(ev["ind2"][k])
-            polys.append(np.c_[ct["x"][o + i1:o + i2 + 1], ct["y"][o + i1:o + i2 + 1]])
         sums.append(ev["sums"][k])
     for b, *_ in batches:
         b.close()
