@@ -710,11 +710,11 @@ WB_KERNEL(wb_k_fill_events, WbEvFillArgs a) {
     }
 }
 
-WB_KERNEL(wb_k_sel_maxlen, int nsel, int cap_seg, const int* sel_job, const int* sel_cont, const int* c_len, int* out) {
+WB_KERNEL(wb_k_sel_lens, int nsel, int cap_seg, const int* sel_job, const int* sel_cont, const int* c_len, int* out) {
     const int base = WB_BLOCK_ID * 256;
     WB_PFOR(k, 256)
         const int s = base + (int)k;
-        if (s < nsel) wb_atomic_max(out, c_len[(size_t)sel_job[s] * cap_seg + sel_cont[s]]);
+        if (s < nsel) out[s] = c_len[(size_t)sel_job[s] * cap_seg + sel_cont[s]];
     WB_END_PFOR
 }
 
@@ -830,24 +830,38 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         st.sel_job = b->sel_job; st.sel_cont = b->sel_cont; st.c_off = b->c_off; st.c_len = b->c_len; st.cpts = b->cpts;
         st.lat_rad = b->d_latrad; st.lon_rad = b->d_lonrad; st.sphi2 = b->d_sphi2; st.cphi2 = b->d_cphi2; st.cphi = b->d_cphi;
         st.slam2 = b->d_slam2; st.clam2 = b->d_clam2;
-        st.on = (double*)talloc((size_t)nsel * 2 * cap * sizeof(double));
-        st.pre = (double*)talloc((size_t)nsel * 2 * cap * sizeof(double));
+        // exact, packed per-point storage: lengths of the selected contours -> offsets
+        int maxN = 0;
+        std::vector<long long> h_poff(nsel + 1, 0);
+        {
+            int* d_lens = (int*)talloc(nsel * sizeof(int));
+            if (!d_lens) return 1;
+            WB_LAUNCH(wb_k_sel_lens, (nsel + 255) / 256, 256, nsel, cap, b->sel_job, b->sel_cont, b->c_len, d_lens);
+            std::vector<int> lens(nsel);
+            d2h(ctx, lens.data(), d_lens, nsel * sizeof(int));
+            for (int q = 0; q < nsel; ++q) {
+                h_poff[q + 1] = h_poff[q] + lens[q];
+                maxN = lens[q] > maxN ? lens[q] : maxN;
+            }
+        }
+        const long long NPT = h_poff[nsel];
+        long long* d_poff = (long long*)talloc((nsel + 1) * sizeof(long long));
+        if (!d_poff) return 1;
+        h2d(ctx, d_poff, h_poff.data(), (nsel + 1) * sizeof(long long));
+        st.poff = d_poff;
+        st.npts_total = NPT;
+        st.on = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
+        st.pre = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
+        st.ptab = (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double));
+        st.bbx = (int*)talloc((size_t)((NPT >> 5) + nsel + 1) * 4 * sizeof(int));
+        st.dy_max = (int)floor(p.geo_dis / (6371.0 * p.dlat * (M_PI / 180.0))) + 1;
         st.npairs = (int*)talloc(nsel * sizeof(int));
         st.stage = (int*)talloc(nsel * sizeof(int));
         st.nalive = (int*)talloc(nsel * sizeof(int));
-        st.rowmax = (int*)talloc((size_t)nsel * 2 * cap * sizeof(int));
-        st.rowaux = (int*)talloc((size_t)nsel * 2 * cap * sizeof(int));
+        st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
+        st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
         st.ev_ind = ev_ind; st.ev_n = ev_n; st.band_hits = d_band; st.status = b->status;
-        if (!st.rowaux || !ev_ind) return 1;
-        // the longest selected contour bounds the tiling of the all-pairs kernel
-        int maxN = 0;
-        {
-            int* d_maxlen = (int*)talloc(sizeof(int));
-            if (!d_maxlen) return 1;
-            dmemset(ctx, d_maxlen, 0, sizeof(int));
-            WB_LAUNCH(wb_k_sel_maxlen, (nsel + 255) / 256, 256, nsel, cap, b->sel_job, b->sel_cont, b->c_len, d_maxlen);
-            d2h(ctx, &maxN, d_maxlen, sizeof(int));
-        }
+        if (!st.rowaux || !ev_ind || !st.bbx) return 1;
         for (int attempt = 0; attempt < 4; ++attempt) {
             st.cap_pairs = cap_pairs;
             st.hash_size = next_pow2(2LL * cap_pairs);
@@ -881,7 +895,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_streamer_f1, nsel, 256, st);
             b->timer.end(ctx);
-            const int chunks = ((mx < cap_pairs ? mx : cap_pairs) + WB_F2_PAIRS - 1) / WB_F2_PAIRS;
+            const int chunks = ((mx < cap_pairs ? mx : cap_pairs) + WB_F2_THREADS - 1) / WB_F2_THREADS;
             b->timer.begin(ctx, "streamer_f2");
             if (chunks > 0) WB_LAUNCH(wb_k_streamer_f2, (long long)nsel * chunks, 256, st, chunks);
             b->timer.end(ctx);

@@ -225,9 +225,15 @@ struct WbStreamerArgs {
     const double* cphi;        // [nlat] cos(lat_rad)
     const double* slam2;       // [nlon] sin(lon_rad/2)
     const double* clam2;       // [nlon] cos(lon_rad/2)
-    // per selected contour
-    double* on;                // [nsel][2*cap_seg] on[k] = d(k-1, k) * 6371, on[0] = 0
-    double* pre;               // [nsel][2*cap_seg] inclusive prefix of on
+    // per selected contour, packed by point: contour s owns [poff[s], poff[s+1])
+    const long long* poff;     // [nsel+1]
+    double* on;                // on[k] = d(k-1, k) * 6371, on[0] = 0
+    double* pre;               // inclusive prefix of on
+    double* ptab;              // [5][npts_total] sin(phi/2), cos(phi/2), cos(phi), sin(lam/2), cos(lam/2) per point
+    long long npts_total;
+    int* bbx;                  // per block of WB_BLK points (+1: the segment leaving the block): xmin, xmax, ymin, ymax;
+                               // contour s owns blocks [(poff[s] >> 5) + s, ...)
+    int dy_max;                // |y_i - y_j| above this cannot be within geo_dis (R * dphi <= geo)
     unsigned long long* pairs; // [nsel][cap_pairs] (ind1 << 32 | ind2)
     int* alive;                // [nsel][cap_pairs]
     int* npairs;               // [nsel]
@@ -235,8 +241,8 @@ struct WbStreamerArgs {
     int* nalive;               // [nsel] rows left after the last applied routine
     unsigned long long* hkey;  // [nsel][hash_size]
     unsigned long long* hval;  // [nsel][hash_size]
-    int* rowmax;               // [nsel][2*cap_seg]
-    int* rowaux;               // [nsel][2*cap_seg]
+    int* rowmax;               // packed by point like `on`
+    int* rowaux;
     int* ev_ind;               // [nsel][cap_ev][2]
     int* ev_n;                 // [nsel]
     int* band_hits;            // [2] pairs inside the geo / cont guard bands (re-evaluated exactly)
@@ -250,10 +256,11 @@ WB_HD inline double wb_haversine(double la1, double lo1, double la2, double lo2)
     return 2.0 * asin(sqrt(s0 * s0 + cos(la1) * cos(la2) * s1 * s1));
 }
 
+#define WB_BLK 32
 #define WB_GEO_BAND 1e-11     // relative guard band on h = sin^2(d/2R) around its threshold
 #define WB_CONT_BAND 1e-6     // absolute guard band (km) on the along-contour distance
 
-// per selected contour: on[] and its prefix (streamer_index.py:133)
+// per selected contour: on[] and its prefix (streamer_index.py:133), per-point trigonometric table, block boxes
 WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
     if (s >= a.nsel) return;
@@ -261,16 +268,36 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
-    double* on = a.on + (size_t)s * 2 * a.cap_seg;
-    double* pre = a.pre + (size_t)s * 2 * a.cap_seg;
+    const long long po = a.poff[s];
+    double* on = a.on + po;
+    double* pre = a.pre + po;
+    double* tab = a.ptab + po;
+    int* bbx = a.bbx + 4 * ((po >> 5) + s);
+    const int nblk = (N + WB_BLK - 1) / WB_BLK;
     WB_PFOR(i, N)
+        const uint32_t p1 = pts[i];
+        const int y1 = wb_pt_y(p1), x1 = wb_pt_x(p1) % a.nlon;
         double d = 0.0;
         if (i > 0) {
-            const uint32_t p0 = pts[i - 1], p1 = pts[i];
-            d = wb_haversine(a.lat_rad[wb_pt_y(p0)], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[wb_pt_y(p1)],
-                             a.lon_rad[wb_pt_x(p1) % a.nlon]) * 6371.0;
+            const uint32_t p0 = pts[i - 1];
+            d = wb_haversine(a.lat_rad[wb_pt_y(p0)], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[y1], a.lon_rad[x1]) * 6371.0;
         }
         on[i] = d;
+        tab[0 * a.npts_total + i] = a.sphi2[y1];
+        tab[1 * a.npts_total + i] = a.cphi2[y1];
+        tab[2 * a.npts_total + i] = a.cphi[y1];
+        tab[3 * a.npts_total + i] = a.slam2[x1];
+        tab[4 * a.npts_total + i] = a.clam2[x1];
+    WB_END_PFOR
+    WB_PFOR(b, nblk)
+        int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
+        const int lo = (int)b * WB_BLK, hi = lo + WB_BLK < N - 1 ? lo + WB_BLK : N - 1;   // one point past the block
+        for (int i = lo; i <= hi; ++i) {
+            const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
+            x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1;
+            y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        }
+        bbx[4 * b + 0] = x0; bbx[4 * b + 1] = x1; bbx[4 * b + 2] = y0; bbx[4 * b + 3] = y1;
     WB_END_PFOR
     WB_SINGLE
     double run = 0.0;
@@ -284,10 +311,12 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
     WB_END_SINGLE
 }
 
-// all-pairs test; grid = nsel * tiles, each workgroup owns WB_PAIR_ROWS rows i and sweeps j > i
+// all-pairs test (streamer_index.py:130-157); grid = nsel * tiles, a workgroup owns WB_PAIR_ROWS rows i.
+// Blocks of WB_BLK candidate points j are skipped as a whole when their bounding box cannot hold a partner:
+// |x_i - x_j| <= 120 (:157), |y_i - y_j| <= dy_max (geo < geo_dis needs R*|dphi| < geo_dis), and the block's
+// largest along-contour distance must exceed cont_dis.  What survives is evaluated exactly as before.
 #define WB_PAIR_ROWS 16
-
-struct WbPairGrid { int tiles; };
+#define WB_MAX_BLOCKS 1024      // 2*cap_seg / WB_BLK for cap_seg <= 16384; longer contours fall back to all blocks
 
 WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
     const int s = WB_BLOCK_ID / tiles, tile = WB_BLOCK_ID - s * tiles;
@@ -296,50 +325,83 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
-    const double* on = a.on + (size_t)s * 2 * a.cap_seg;
-    const double* pre = a.pre + (size_t)s * 2 * a.cap_seg;
-    unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     const int i0 = tile * WB_PAIR_ROWS;
-    for (int ii = 0; ii < WB_PAIR_ROWS; ++ii) {
-        const int i = i0 + ii;
-        if (i >= N - 1) break;
-        const uint32_t pi = pts[i];
-        const int xi = wb_pt_x(pi), yi = wb_pt_y(pi), xim = xi % a.nlon;
-        const double spi = a.sphi2[yi], cpi = a.cphi2[yi], ci = a.cphi[yi];
-        const double sli = a.slam2[xim], cli = a.clam2[xim];
-        const double prei = pre[i];
-        WB_PFOR(jj, N - 1 - i)
-            const int j = i + 1 + (int)jj;
-            const uint32_t pj = pts[j];
-            const int xj = wb_pt_x(pj), yj = wb_pt_y(pj), xjm = xj % a.nlon;
-            int dx = xi - xj;
-            if (dx < 0) dx = -dx;
-            if (dx > 120) continue;                                   // streamer_index.py:157
-            // sin((phi_i - phi_j)/2), sin((lam_i - lam_j)/2) by the subtraction formulas
-            const double sa = spi * a.cphi2[yj] - cpi * a.sphi2[yj];
-            const double sb = sli * a.clam2[xjm] - cli * a.slam2[xjm];
-            const double h = sa * sa + ci * a.cphi[yj] * (sb * sb);
-            bool near_geo;
-            if (fabs(h - a.hthr) <= WB_GEO_BAND * a.hthr) {            // guard band: evaluate as sklearn does
-                wb_atomic_add(&a.band_hits[0], 1);
-                const double geo = wb_haversine(a.lat_rad[yi], a.lon_rad[xim], a.lat_rad[yj], a.lon_rad[xjm]) * 6371.0;
-                near_geo = geo < a.geo_dis;
-            } else {
-                near_geo = h < a.hthr;
-            }
-            if (!near_geo) continue;
-            double cont = pre[j] - prei;
-            if (fabs(cont - a.cont_dis) <= WB_CONT_BAND) {            // guard band: sequential row cumsum (:135)
-                wb_atomic_add(&a.band_hits[1], 1);
-                double acc = 0.0;
-                for (int m = i + 1; m <= j; ++m) acc = acc + on[m];
-                cont = acc;
-            }
-            if (!(cont > a.cont_dis)) continue;
-            const int slot = wb_atomic_add(&a.npairs[s], 1);
-            if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
+    if (i0 >= N - 1) return;
+    const long long po = a.poff[s];
+    const double* on = a.on + po;
+    const double* pre = a.pre + po;
+    const double* t_sp = a.ptab + 0 * a.npts_total + po;
+    const double* t_cp = a.ptab + 1 * a.npts_total + po;
+    const double* t_c = a.ptab + 2 * a.npts_total + po;
+    const double* t_sl = a.ptab + 3 * a.npts_total + po;
+    const double* t_cl = a.ptab + 4 * a.npts_total + po;
+    const int* bbx = a.bbx + 4 * ((po >> 5) + s);
+    const int nblk = (N + WB_BLK - 1) / WB_BLK;
+    unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    WB_SHARED(int, blist, WB_MAX_BLOCKS);
+    WB_SHARED(int, nlist, 1);
+    WB_SHARED(int, tb, 4);
+
+    const int i1 = i0 + WB_PAIR_ROWS < N - 1 ? i0 + WB_PAIR_ROWS : N - 1;   // rows i0 .. i1-1
+    WB_SINGLE
+    int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
+    for (int i = i0; i < i1; ++i) {
+        const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
+        x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1;
+        y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+    }
+    tb[0] = x0 - 120; tb[1] = x1 + 120; tb[2] = y0 - a.dy_max; tb[3] = y1 + a.dy_max;
+    nlist[0] = 0;
+    WB_END_SINGLE
+    const bool use_list = nblk <= WB_MAX_BLOCKS;
+    if (use_list) {
+        const double pre_i0 = pre[i0];
+        WB_PFOR(b, nblk)
+            const int jlo = (int)b * WB_BLK, jhi = jlo + WB_BLK - 1 < N - 1 ? jlo + WB_BLK - 1 : N - 1;
+            if (jhi <= i0) continue;                                        // only j > i
+            const int* bb = bbx + 4 * b;
+            if (bb[0] > tb[1] || bb[1] < tb[0] || bb[2] > tb[3] || bb[3] < tb[2]) continue;
+            if (pre[jhi] - pre_i0 <= a.cont_dis - WB_CONT_BAND) continue;   // cont(i,j) <= pre[jhi] - pre[i0]
+            blist[wb_atomic_add(&nlist[0], 1)] = (int)b;
         WB_END_PFOR
     }
+    const int nb = use_list ? nlist[0] : nblk;
+    WB_PFOR(idx, (int64_t)nb * WB_BLK * WB_PAIR_ROWS)
+        const int jj = (int)(idx % WB_BLK);
+        const int ii = (int)((idx / WB_BLK) % WB_PAIR_ROWS);
+        const int bsel = (int)(idx / (WB_BLK * WB_PAIR_ROWS));
+        const int i = i0 + ii;
+        const int j = (use_list ? blist[bsel] : bsel) * WB_BLK + jj;
+        if (i >= i1 || j <= i || j >= N) continue;
+        const uint32_t pi = pts[i], pj = pts[j];
+        int dx = wb_pt_x(pi) - wb_pt_x(pj);
+        if (dx < 0) dx = -dx;
+        if (dx > 120) continue;                                   // streamer_index.py:157
+        // sin((phi_i - phi_j)/2), sin((lam_i - lam_j)/2) by the subtraction formulas
+        const double sa = t_sp[i] * t_cp[j] - t_cp[i] * t_sp[j];
+        const double sb = t_sl[i] * t_cl[j] - t_cl[i] * t_sl[j];
+        const double h = sa * sa + t_c[i] * t_c[j] * (sb * sb);
+        bool near_geo;
+        if (fabs(h - a.hthr) <= WB_GEO_BAND * a.hthr) {            // guard band: evaluate as sklearn does
+            wb_atomic_add(&a.band_hits[0], 1);
+            const int yi = wb_pt_y(pi), yj = wb_pt_y(pj), xim = wb_pt_x(pi) % a.nlon, xjm = wb_pt_x(pj) % a.nlon;
+            const double geo = wb_haversine(a.lat_rad[yi], a.lon_rad[xim], a.lat_rad[yj], a.lon_rad[xjm]) * 6371.0;
+            near_geo = geo < a.geo_dis;
+        } else {
+            near_geo = h < a.hthr;
+        }
+        if (!near_geo) continue;
+        double cont = pre[j] - pre[i];
+        if (fabs(cont - a.cont_dis) <= WB_CONT_BAND) {            // guard band: sequential row cumsum (:135)
+            wb_atomic_add(&a.band_hits[1], 1);
+            double acc = 0.0;
+            for (int m = i + 1; m <= j; ++m) acc = acc + on[m];
+            cont = acc;
+        }
+        if (!(cont > a.cont_dis)) continue;
+        const int slot = wb_atomic_add(&a.npairs[s], 1);
+        if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
+    WB_END_PFOR
 }
 
 // routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264
@@ -408,8 +470,9 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     WB_END_SINGLE
 }
 
-// routine 2: check_intersections (:185-200). grid = nsel * chunks; a workgroup takes WB_F2_PAIRS pairs
-#define WB_F2_PAIRS 8
+// routine 2: check_intersections (:185-200): one lane per candidate pair; contour blocks whose bounding box
+// misses the chord's box are skipped, the rest is tested segment by segment with the exact predicate.
+#define WB_F2_THREADS 256
 WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, int chunks) {
     const int s = WB_BLOCK_ID / chunks, chunk = WB_BLOCK_ID - s * chunks;
     if (s >= a.nsel) return;
@@ -418,31 +481,32 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, int chunks) {
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
+    const int* bbx = a.bbx + 4 * ((a.poff[s] >> 5) + s);
+    const int nblk = (N + WB_BLK - 1) / WB_BLK;
     const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     int* alive = a.alive + (size_t)s * a.cap_pairs;
     const int P = a.npairs[s];
-    WB_SHARED(int, hit, 1);
-    for (int pp = 0; pp < WB_F2_PAIRS; ++pp) {
-        const int p = chunk * WB_F2_PAIRS + pp;
-        if (p >= P) break;
-        if (!alive[p]) continue;
+    const int p0 = chunk * WB_F2_THREADS;
+    if (p0 >= P) return;
+    WB_PFOR(pp, WB_F2_THREADS)
+        const int p = p0 + (int)pp;
+        if (p >= P || !alive[p]) continue;
         const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
         const int px = wb_pt_x(pts[i]), py = wb_pt_y(pts[i]), qx = wb_pt_x(pts[j]), qy = wb_pt_y(pts[j]);
-        WB_SINGLE
-        hit[0] = 0;
-        WB_END_SINGLE
-        WB_PFOR(m, N - 1)
-            const uint32_t pa = pts[m], pb = pts[m + 1];
-            if (wb_chord_hits_segment(px, py, qx, qy, wb_pt_x(pa), wb_pt_y(pa), wb_pt_x(pb), wb_pt_y(pb), m == 0,
-                                      m == N - 2))
-                hit[0] = 1;
-        WB_END_PFOR
-        if (hit[0]) {
-            WB_SINGLE
-            alive[p] = 2;   // 2 = rejected by routine 2 (turned into 0 by f3)
-            WB_END_SINGLE
+        const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+        bool hit = false;
+        for (int b = 0; b < nblk && !hit; ++b) {
+            const int* bb = bbx + 4 * b;
+            if (bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0) continue;
+            const int mlo = b * WB_BLK, mhi = mlo + WB_BLK < N - 1 ? mlo + WB_BLK : N - 1;   // segments mlo .. mhi-1
+            for (int m = mlo; m < mhi && !hit; ++m) {
+                const uint32_t pa = pts[m], pb = pts[m + 1];
+                hit = wb_chord_hits_segment(px, py, qx, qy, wb_pt_x(pa), wb_pt_y(pa), wb_pt_x(pb), wb_pt_y(pb), m == 0,
+                                            m == N - 2);
+            }
         }
-    }
+        if (hit) alive[p] = 2;   // 2 = rejected by routine 2 (turned into 0 by f3)
+    WB_END_PFOR
 }
 
 // routines 3 and 4: check_overlapping (:202-222), check_groups (:224-251), then the polygons' end points
@@ -453,11 +517,11 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
-    const double* pre = a.pre + (size_t)s * 2 * a.cap_seg;
+    const double* pre = a.pre + a.poff[s];
     const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     int* alive = a.alive + (size_t)s * a.cap_pairs;
-    int* rowmax = a.rowmax + (size_t)s * 2 * a.cap_seg;   // per ind1: largest surviving ind2
-    int* aux = a.rowaux + (size_t)s * 2 * a.cap_seg;
+    int* rowmax = a.rowmax + a.poff[s];   // per ind1: largest surviving ind2
+    int* aux = a.rowaux + a.poff[s];
     int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
     unsigned long long* best = a.hval + (size_t)s * a.hash_size;  // reused: per group best value / index
     WB_SHARED(int, cnt, 2);
