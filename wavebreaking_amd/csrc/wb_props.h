@@ -11,6 +11,7 @@
 // one per add (no FMA contraction), because `com` truncates their ratio (:105-110).
 #pragma once
 #include "wb_core.h"
+#include <stdio.h>
 
 #if !defined(WB_HOSTSIM)
 #pragma clang fp contract(off)

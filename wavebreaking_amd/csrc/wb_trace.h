@@ -97,7 +97,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     int* keep = a.keep + (size_t)job * (2 * cap + 1);
     unsigned long long* hkey = a.hkey + (size_t)job * a.hash_size;
     uint32_t* hval = a.hval + (size_t)job * a.hash_size;
-    const int hmask = a.hash_size - 1;
+    int hsize = a.hash_size;            // shrunk below to what this job needs (clearing the table is real traffic)
     uint32_t* cpts = a.cpts + 2 * jb;
     uint32_t* cown = a.cown + 2 * jb;
     int* c_off = a.c_off + jb;
@@ -164,6 +164,13 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
             segt[dest] = wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level);
         WB_END_PFOR
     }
+
+    {   // raw points <= 2n; keys per point <= 2 (point key + x key): load factor <= 0.5
+        int want = 1024;
+        while (want < 8 * n && want < a.hash_size) want <<= 1;
+        hsize = want;
+    }
+    const int hmask = hsize - 1;
 
     // ---- P0: init
     WB_PFOR(i, n)
@@ -313,7 +320,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     WB_END_PFOR
 
     // ---- P5: order-preserving first-occurrence dedupe inside each contour
-    WB_PFOR(s, a.hash_size)
+    WB_PFOR(s, hsize)
         hkey[s] = WB_HEMPTY;
         hval[s] = WB_NIL;
     WB_END_PFOR
@@ -376,7 +383,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
     int* setsize = (int*)jA;   // [Ck]
     int* dropped = (int*)jB;   // [Ck]
-    WB_PFOR(s, a.hash_size)
+    WB_PFOR(s, hsize)
         hkey[s] = WB_HEMPTY;
     WB_END_PFOR
     WB_PFOR(f, Ck)
