@@ -299,12 +299,31 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
         }
         bbx[4 * b + 0] = x0; bbx[4 * b + 1] = x1; bbx[4 * b + 2] = y0; bbx[4 * b + 3] = y1;
     WB_END_PFOR
+    // inclusive prefix, strictly sequential (same rounding as the reference's np.cumsum over `on`); staged through
+    // LDS in chunks so that the one summing lane reads at LDS instead of L2 latency
+    WB_SHARED(double, stage, 2048);
+    WB_SHARED(double, carry, 1);
     WB_SINGLE
-    double run = 0.0;
-    for (int i = 0; i < N; ++i) {
-        run = run + on[i];
-        pre[i] = run;
+    carry[0] = 0.0;
+    WB_END_SINGLE
+    for (int c0 = 0; c0 < N; c0 += 2048) {
+        const int cn = N - c0 < 2048 ? N - c0 : 2048;
+        WB_PFOR(i, cn)
+            stage[i] = on[c0 + i];
+        WB_END_PFOR
+        WB_SINGLE
+        double run = carry[0];
+        for (int i = 0; i < cn; ++i) {
+            run = run + stage[i];
+            stage[i] = run;
+        }
+        carry[0] = run;
+        WB_END_SINGLE
+        WB_PFOR(i, cn)
+            pre[c0 + i] = stage[i];
+        WB_END_PFOR
     }
+    WB_SINGLE
     a.npairs[s] = 0;
     a.stage[s] = 0;
     a.ev_n[s] = 0;
@@ -415,9 +434,11 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     int* alive = a.alive + (size_t)s * a.cap_pairs;
     unsigned long long* hkey = a.hkey + (size_t)s * a.hash_size;
     unsigned long long* hval = a.hval + (size_t)s * a.hash_size;
-    const int hmask = a.hash_size - 1;
     WB_SHARED(int, cnt, 1);
     int P = a.npairs[s];
+    int hsize = 256;                       // table sized to this contour's pair count (clearing it is real traffic)
+    while (hsize < 2 * P && hsize < a.hash_size) hsize <<= 1;
+    const int hmask = hsize - 1;
     if (P > a.cap_pairs) {
         WB_SINGLE
         wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
@@ -436,7 +457,7 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
         WB_END_SINGLE
         return;
     }
-    WB_PFOR(q, a.hash_size)
+    WB_PFOR(q, hsize)
         hkey[q] = WB_HEMPTY;
         hval[q] = WB_HEMPTY;
     WB_END_PFOR

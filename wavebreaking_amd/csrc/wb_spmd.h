@@ -21,6 +21,7 @@
 #define WB_HD
 #define WB_DEV
 #define WB_KERNEL(name, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
+#define WB_KERNEL_LB(name, threads, waves, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
 #define WB_BLOCK_ID wb_block_id
 #define WB_GRID_DIM wb_grid_dim
 #define WB_NT 1
@@ -55,6 +56,8 @@ static inline int wb_block_scan_excl(int* a, int n) {
 #define WB_HD __host__ __device__
 #define WB_DEV __device__
 #define WB_KERNEL(name, ...) __global__ void name(__VA_ARGS__)
+// waves = minimum waves per SIMD the register allocator must leave room for
+#define WB_KERNEL_LB(name, threads, waves, ...) __global__ __launch_bounds__(threads, waves) void name(__VA_ARGS__)
 #define WB_BLOCK_ID ((int)blockIdx.x)
 #define WB_GRID_DIM ((int)gridDim.x)
 #define WB_NT ((int)blockDim.x)

@@ -42,9 +42,15 @@ struct WbTraceArgs {
     int* ncont;              // [njobs]
     uint32_t* status;        // [njobs]
     int* max_nux;            // [1] batch-wide maximum of c_nux
+    long long* dbg;          // optional [njobs][16] phase time stamps (wall_clock64), NULL in production
 };
 
 #define WB_HEMPTY 0xFFFFFFFFFFFFFFFFull
+#if defined(WB_HOSTSIM)
+#define WB_STAMP(k) ((void)0)
+#else
+#define WB_STAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)job * 16 + (k)] = (long long)wall_clock64(); } while (0)
+#endif
 
 // insert key; returns slot (or -1 when the table is full); *fresh = 1 if this call created the entry
 WB_DEV inline int wb_hash_insert(unsigned long long* hkey, int hmask, unsigned long long key, int* fresh) {
@@ -73,7 +79,7 @@ WB_DEV inline int wb_hash_find(const unsigned long long* hkey, int hmask, unsign
     return -1;
 }
 
-WB_KERNEL(wb_k_trace, WbTraceArgs a) {
+WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
     const int cap = a.cap_seg;
@@ -106,6 +112,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
     int* c_nux = a.c_nux + jb;
     int* c_sumy = a.c_sumy + jb;
 
+    WB_STAMP(0);
     // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
     //          position in its own list plus the number of smaller keys in every other list
     int n = 0;
@@ -128,13 +135,14 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         WB_END_SINGLE
         return;
     }
-    for (int s = 0; s < a.nstrips; ++s) {
-        const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
-        const int cnt = a.stg_n[job * a.nstrips + s];
-        WB_PFOR(i, cnt)
+    {   // one pass over all segments of all strips (strip found from the running counts)
+        WB_PFOR(g, n)
+            int s = 0, i = (int)g;
+            while (i >= a.stg_n[job * a.nstrips + s]) { i -= a.stg_n[job * a.nstrips + s]; ++s; }
+            const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
             const uint32_t key = a.stg_k[sb + i];
             const uint32_t kk = key & 0x07FFFFFFu;
-            int dest = (int)i;
+            int dest = i;
             for (int s2 = 0; s2 < a.nstrips; ++s2) {
                 if (s2 == s) continue;
                 const uint32_t* other = a.stg_k + ((size_t)job * a.nstrips + s2) * a.cap_strip;
@@ -165,6 +173,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         WB_END_PFOR
     }
 
+    WB_STAMP(1);
     {   // raw points <= 2n; keys per point <= 2 (point key + x key): load factor <= 0.5
         int want = 1024;
         while (want < 8 * n && want < a.hash_size) want <<= 1;
@@ -178,6 +187,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         t0[i] = 0;  // "is first segment of a cut loop"
     WB_END_PFOR
 
+    WB_STAMP(2);
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
     //          the edge this one ends on (binary search by square key in the merged list)
     WB_PFOR(i, n)
@@ -208,6 +218,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         if (s != WB_NIL) pred[s] = (uint32_t)i;
     WB_END_PFOR
 
+    WB_STAMP(3);
     int rounds = 0;
     while ((1 << rounds) < n) ++rounds;
 
@@ -245,6 +256,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         WB_END_PFOR
     }
 
+    WB_STAMP(4);
     // ---- P3: list ranking: start segment and position of every segment
     WB_PFOR(i, n)
         jA[i] = pred[i];
@@ -274,6 +286,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         start = si;
         dist = di;
     }
+    WB_STAMP(5);
     // free now: succ, pred, the two j buffers and the two "other" halves.  Name what we reuse:
     uint32_t* minidx = succ;       // per start segment: smallest member index
     uint32_t* cid_of = pred;       // per start segment: contour number (raster order of first segment)
@@ -319,6 +332,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         }
     WB_END_PFOR
 
+    WB_STAMP(6);
     // ---- P5: order-preserving first-occurrence dedupe inside each contour
     WB_PFOR(s, hsize)
         hkey[s] = WB_HEMPTY;
@@ -380,6 +394,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         }
     WB_END_PFOR
 
+    WB_STAMP(7);
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
     int* setsize = (int*)jA;   // [Ck]
     int* dropped = (int*)jB;   // [Ck]
@@ -407,6 +422,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         }
     WB_END_PFOR
 
+    WB_STAMP(8);
     // ---- P7: periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1,i2)
     //          with set(i1) a subset of set(i2): equal array lengths -> drop max(i1,i2), else drop the shorter
     WB_PFOR(pair, (int64_t)Ck * Ck)
@@ -427,6 +443,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
         }
     WB_END_PFOR
 
+    WB_STAMP(9);
     // ---- P8: final table = kept and not dropped, order preserved
     int* fin = (int*)t0;  // [Ck] -> exclusive scan
     WB_PFOR(f, Ck)
@@ -458,6 +475,7 @@ WB_KERNEL(wb_k_trace, WbTraceArgs a) {
             wb_atomic_max(a.max_nux, s_nux[f]);
         }
     WB_END_PFOR
+    WB_STAMP(10);
     WB_SINGLE
     a.ncont[job] = Cf;
     WB_END_SINGLE
