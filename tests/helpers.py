@@ -15,18 +15,20 @@ HOSTSIM_LIB = os.path.join(HOSTSIM_DIR, "libwb_hostsim.so")
 CSRC = os.path.join(ROOT, "wavebreaking_amd", "csrc")
 
 
-def build_hostsim(force=False):
-    """g++ build of the kernel sources with -DWB_HOSTSIM (test infrastructure only)."""
+def build_hostsim(force=False, variant="", defines=()):
+    """g++ build of the kernel sources with -DWB_HOSTSIM (test infrastructure only).  ``variant`` / ``defines``
+    build a second copy with other compile-time limits (e.g. a tiny WB_TRACE_LDS_N to force the big-job paths)."""
+    lib = HOSTSIM_LIB if not variant else HOSTSIM_LIB.replace(".so", "_%s.so" % variant)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     srcs.append(os.path.join(ROOT, "include", "wavebreaking_hip.h"))
-    if (not force and os.path.exists(HOSTSIM_LIB)
-            and os.path.getmtime(HOSTSIM_LIB) >= max(os.path.getmtime(s) for s in srcs)):
-        return HOSTSIM_LIB
+    if (not force and os.path.exists(lib)
+            and os.path.getmtime(lib) >= max(os.path.getmtime(s) for s in srcs)):
+        return lib
     os.makedirs(HOSTSIM_DIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-g", "-DWB_HOSTSIM", "-x", "c++", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
-           os.path.join(CSRC, "wb_api.hip"), "-o", HOSTSIM_LIB]
+    cmd = ["g++", "-O2", "-g", "-DWB_HOSTSIM", *["-D" + d for d in defines], "-x", "c++", "-std=c++17",
+           "-ffp-contract=off", "-shared", "-fPIC", os.path.join(CSRC, "wb_api.hip"), "-o", lib]
     subprocess.check_call(cmd)
-    return HOSTSIM_LIB
+    return lib
 
 
 _hostsim = None

@@ -111,3 +111,13 @@ def test_bad_arguments_fail_loudly(sim):
         ctx.contours(pv, lat, lon, [1, 2, 3, 4, 5], 2.5, 2.5)          # more than 4 levels
     with pytest.raises(RuntimeError):
         ctx.contours(pv, lat, lon, [2], 2.5, 2.5, periodic_add=400)   # > 360 degrees
+
+
+def test_big_job_paths_without_lds():
+    # a build whose LDS threshold is tiny sends every job down the global-memory paths of the link / rank kernels
+    lib = _hip.Library(helpers.build_hostsim(variant="nolds", defines=("WB_TRACE_LDS_N=16",)), allow_hostsim=True)
+    ctx = _hip.Context(0, lib)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(4, 2, lat, lon, eps=0.3)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [-2, 2], intensity=pv)
+    ctx.close()

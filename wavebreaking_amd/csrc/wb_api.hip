@@ -374,7 +374,8 @@ static int run_phase1(wb_batch* b) {
     WbTraceArgs ta;
     memset(&ta, 0, sizeof(ta));
     std::vector<void*>& sc = b->phase1_scratch;
-    for (int i = 0; i < 10; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
+    for (int i = 0; i < 11; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
+    ta.nseg = balloc<int>(b, J); sc.push_back(ta.nseg);
     for (int i = 0; i < 3; ++i) { ta.mseg[i] = balloc<uint32_t>(b, per); sc.push_back(ta.mseg[i]); }
     ta.rawpt = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawpt);
     ta.rawcid = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawcid);
@@ -427,28 +428,17 @@ static int run_phase1(wb_batch* b) {
     for (int l = 0; l < p.nlevels; ++l) ta.levels[l] = b->levels[l];
     ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
     ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.max_nux = b->d_max_nux;
-    long long* d_dbg = nullptr;
-    if (getenv("WB_TRACE_STAMPS")) { d_dbg = balloc<long long>(b, (size_t)J * 16); dmemset(ctx, d_dbg, 0, (size_t)J * 16 * 8); }
-    ta.dbg = d_dbg;
-    b->timer.begin(ctx, "trace");
-    WB_LAUNCH(wb_k_trace, J, 256, ta);
+    b->timer.begin(ctx, "trace_link");
+    WB_LAUNCH(wb_k_trace_link, J, 512, ta);
+    b->timer.end(ctx);
+    b->timer.begin(ctx, "trace_rank");
+    WB_LAUNCH(wb_k_trace_rank, J, 1024, ta);
+    b->timer.end(ctx);
+    b->timer.begin(ctx, "trace_finish");
+    WB_LAUNCH(wb_k_trace_finish, J, 256, ta);
     b->timer.end(ctx);
     WB_TICK("phase1 launches");
     if (dsync(ctx)) return 1;
-    if (d_dbg) {
-        std::vector<long long> h((size_t)J * 16);
-        d2h(ctx, h.data(), d_dbg, h.size() * 8);
-        double acc[16] = {0};
-        long long tmin = -1, tmax = 0;
-        for (int j = 0; j < J; ++j) {
-            for (int k2 = 0; k2 < 10; ++k2) acc[k2] += (double)(h[(size_t)j * 16 + k2 + 1] - h[(size_t)j * 16 + k2]);
-            if (tmin < 0 || h[(size_t)j * 16] < tmin) tmin = h[(size_t)j * 16];
-            if (h[(size_t)j * 16 + 10] > tmax) tmax = h[(size_t)j * 16 + 10];
-        }
-        fprintf(stderr, "[wb] trace phases (mean ticks/job, 100 MHz clock):");
-        for (int k2 = 0; k2 < 10; ++k2) fprintf(stderr, " p%d=%.0f", k2, acc[k2] / J);
-        fprintf(stderr, "  span=%lld ticks\n", tmax - tmin);
-    }
     WB_TICK("phase1 sync");
     return 0;
 }

@@ -1,5 +1,10 @@
-// wb_trace.h -- kernel 2: segments -> ordered, rounded, de-duplicated contours (one workgroup per
-// (time step, level) job).
+// wb_trace.h -- kernels 2a-2c: segments -> ordered, rounded, de-duplicated contours (one workgroup per
+// (time step, level) job in each of the three kernels).
+//   wb_k_trace_link   : merge the strip lists, crossing points, successor / predecessor links (keys staged in LDS)
+//   wb_k_trace_rank   : closed-loop detection + list ranking by pointer jumping, entirely in LDS (16-bit links)
+//   wb_k_trace_finish : contour numbering, dedupe, periodic duplicates, table
+// They are separate launches because they want different occupancies: the LDS kernels run one or two
+// large workgroups per CU, the finish kernel is L2-latency-bound and wants as many waves as fit.
 //
 // Restates, for one job, wavebreaking/indices/contour_index.py:103-156 of the reference:
 //   * skimage's _assemble_contours (ordering rules of SURVEY.md 8a row C2) as successor linking
@@ -25,7 +30,7 @@ struct WbTraceArgs {
     const int* stg_n;        // [njobs][nstrips]
     uint32_t* mseg[3];       // [njobs][cap_seg] merged key / from / to (scratch)
     // scratch, per job
-    uint32_t* w[10];         // 10 arrays [njobs][cap_seg]
+    uint32_t* w[11];         // 11 arrays [njobs][cap_seg]
     uint32_t* rawpt;         // [njobs][2*cap_seg]
     uint32_t* rawcid;        // [njobs][2*cap_seg]
     int* keep;               // [njobs][2*cap_seg + 1]
@@ -42,15 +47,11 @@ struct WbTraceArgs {
     int* ncont;              // [njobs]
     uint32_t* status;        // [njobs]
     int* max_nux;            // [1] batch-wide maximum of c_nux
-    long long* dbg;          // optional [njobs][16] phase time stamps (wall_clock64), NULL in production
+    int* nseg;               // [njobs] merged segment count (-1: job skipped)
 };
 
 #define WB_HEMPTY 0xFFFFFFFFFFFFFFFFull
-#if defined(WB_HOSTSIM)
-#define WB_STAMP(k) ((void)0)
-#else
-#define WB_STAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)job * 16 + (k)] = (long long)wall_clock64(); } while (0)
-#endif
+
 
 // insert key; returns slot (or -1 when the table is full); *fresh = 1 if this call created the entry
 WB_DEV inline int wb_hash_insert(unsigned long long* hkey, int hmask, unsigned long long key, int* fresh) {
@@ -79,7 +80,13 @@ WB_DEV inline int wb_hash_find(const unsigned long long* hkey, int hmask, unsign
     return -1;
 }
 
-WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
+
+#ifndef WB_TRACE_LDS_N
+#define WB_TRACE_LDS_N 8192      // jobs with at most this many segments take the LDS paths
+#endif
+
+// -------------------------------------------------------------------------------------------- 2a: link
+WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
     const int cap = a.cap_seg;
@@ -90,29 +97,11 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
     uint32_t* segt = a.mseg[2] + jb;
     uint32_t* succ = a.w[0] + jb;
     uint32_t* pred = a.w[1] + jb;
-    uint32_t* jA = a.w[2] + jb;
-    uint32_t* jB = a.w[3] + jb;
-    uint32_t* mA = a.w[4] + jb;   // pass 1: window max ; pass 2: window start
-    uint32_t* mB = a.w[5] + jb;
-    uint32_t* dA = a.w[6] + jb;   // pass 2: window length
-    uint32_t* dB = a.w[7] + jb;
-    uint32_t* t0 = a.w[8] + jb;   // misc per-segment / per-contour
-    uint32_t* t1 = a.w[9] + jb;
-    uint32_t* rawpt = a.rawpt + 2 * jb;
-    uint32_t* rawcid = a.rawcid + 2 * jb;
-    int* keep = a.keep + (size_t)job * (2 * cap + 1);
-    unsigned long long* hkey = a.hkey + (size_t)job * a.hash_size;
-    uint32_t* hval = a.hval + (size_t)job * a.hash_size;
-    int hsize = a.hash_size;            // shrunk below to what this job needs (clearing the table is real traffic)
-    uint32_t* cpts = a.cpts + 2 * jb;
-    uint32_t* cown = a.cown + 2 * jb;
-    int* c_off = a.c_off + jb;
-    int* c_len = a.c_len + jb;
-    int* c_closed = a.c_closed + jb;
-    int* c_nux = a.c_nux + jb;
-    int* c_sumy = a.c_sumy + jb;
+    uint32_t* t0 = a.w[8] + jb;
+    WB_SHARED(uint32_t, ks, WB_TRACE_LDS_N);      // keys of all strips, strip after strip
+    WB_SHARED(uint32_t, mk, WB_TRACE_LDS_N);      // merged keys
+    WB_SHARED(int, sbase, WB_MAX_STRIPS + 1);
 
-    WB_STAMP(0);
     // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
     //          position in its own list plus the number of smaller keys in every other list
     int n = 0;
@@ -122,76 +111,80 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
         if (c > a.cap_strip) over = true;
         n += c;
     }
-    if (over || n > cap) {  // overflow: the scan kernel kept counting but stopped writing
+    if (over || n > cap || n == 0) {  // overflow: the scan kernel kept counting but stopped writing
         WB_SINGLE
-        wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_SEG);
+        if (n != 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_SEG);
         a.ncont[job] = 0;
+        a.nseg[job] = n == 0 ? 0 : -1;
         WB_END_SINGLE
         return;
     }
-    if (n == 0) {
-        WB_SINGLE
-        a.ncont[job] = 0;
-        WB_END_SINGLE
-        return;
-    }
-    {   // one pass over all segments of all strips (strip found from the running counts)
+    const bool lds = n <= WB_TRACE_LDS_N;
+    WB_SINGLE
+    int run = 0;
+    for (int s = 0; s < a.nstrips; ++s) { sbase[s] = run; run += a.stg_n[job * a.nstrips + s]; }
+    sbase[a.nstrips] = run;
+    WB_END_SINGLE
+    if (lds) {
         WB_PFOR(g, n)
-            int s = 0, i = (int)g;
-            while (i >= a.stg_n[job * a.nstrips + s]) { i -= a.stg_n[job * a.nstrips + s]; ++s; }
-            const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
-            const uint32_t key = a.stg_k[sb + i];
-            const uint32_t kk = key & 0x07FFFFFFu;
-            int dest = i;
-            for (int s2 = 0; s2 < a.nstrips; ++s2) {
-                if (s2 == s) continue;
+            int s = 0;
+            while ((int)g >= sbase[s + 1]) ++s;
+            ks[g] = a.stg_k[((size_t)job * a.nstrips + s) * a.cap_strip + ((int)g - sbase[s])] & 0x07FFFFFFu;
+        WB_END_PFOR
+    }
+    WB_PFOR(g, n)
+        int s = 0;
+        while ((int)g >= sbase[s + 1]) ++s;
+        const int i = (int)g - sbase[s];
+        const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
+        const uint32_t key = a.stg_k[sb + i];
+        const uint32_t kk = key & 0x07FFFFFFu;
+        int dest = i;
+        for (int s2 = 0; s2 < a.nstrips; ++s2) {
+            if (s2 == s) continue;
+            int lo = 0, hi = sbase[s2 + 1] - sbase[s2];
+            if (lds) {
+                const uint32_t* other = ks + sbase[s2];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (other[mid] < kk) lo = mid + 1; else hi = mid;
+                }
+            } else {
                 const uint32_t* other = a.stg_k + ((size_t)job * a.nstrips + s2) * a.cap_strip;
-                int lo = 0, hi = a.stg_n[job * a.nstrips + s2];
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if ((other[mid] & 0x07FFFFFFu) < kk) lo = mid + 1; else hi = mid;
                 }
-                dest += lo;
             }
-            // crossing coordinates of the segment's two end points, rounded half-to-even (contour_index.py:111)
-            double ul, ur, ll, lr;
-            if (a.dtype == 0) {
-                const float* v = (const float*)a.stg_v + (sb + i) * 4;
-                ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
-            } else {
-                const double* v = (const double*)a.stg_v + (sb + i) * 4;
-                ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
-            }
-            const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
-            const double level = a.levels[job % a.nlev];
-            // a corner that equals the level puts the crossing ON a grid vertex: skimage's coordinate joins and
-            // the edge linking used here may then differ -> flag the job
-            if (ul == level || ur == level || ll == level || lr == level) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_HIT);
-            segk[dest] = key;
-            segf[dest] = wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level);
-            segt[dest] = wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level);
-        WB_END_PFOR
-    }
-
-    WB_STAMP(1);
-    {   // raw points <= 2n; keys per point <= 2 (point key + x key): load factor <= 0.5
-        int want = 1024;
-        while (want < 8 * n && want < a.hash_size) want <<= 1;
-        hsize = want;
-    }
-    const int hmask = hsize - 1;
-
-    // ---- P0: init
-    WB_PFOR(i, n)
-        pred[i] = WB_NIL;
-        t0[i] = 0;  // "is first segment of a cut loop"
+            dest += lo;
+        }
+        // crossing coordinates of the segment's two end points, rounded half-to-even (contour_index.py:111)
+        double ul, ur, ll, lr;
+        if (a.dtype == 0) {
+            const float* v = (const float*)a.stg_v + (sb + i) * 4;
+            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
+        } else {
+            const double* v = (const double*)a.stg_v + (sb + i) * 4;
+            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
+        }
+        const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
+        const double level = a.levels[job % a.nlev];
+        // a corner that equals the level puts the crossing ON a grid vertex: skimage's coordinate joins and
+        // the edge linking used here may then differ -> flag the job
+        if (ul == level || ur == level || ll == level || lr == level) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_HIT);
+        segk[dest] = key;
+        if (lds) mk[dest] = key;
+        segf[dest] = wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level);
+        segt[dest] = wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level);
+        pred[g] = WB_NIL;
+        t0[g] = 0;  // "is first segment of a cut loop"
     WB_END_PFOR
 
-    WB_STAMP(2);
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
     //          the edge this one ends on (binary search by square key in the merged list)
+    const uint32_t* keys = lds ? mk : segk;
     WB_PFOR(i, n)
-        const uint32_t k = segk[i];
+        const uint32_t k = keys[i];
         const int sq = wb_key_sq(k), r = sq / W, c = sq - r * W;
         const int ts = wb_seg_to(wb_key_case(k), wb_key_sub(k));
         int rr = r, cc = c;
@@ -206,10 +199,10 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
             const int target = rr * W + cc;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (wb_key_sq(segk[mid]) < target) lo = mid + 1; else hi = mid;
+                if (wb_key_sq(keys[mid]) < target) lo = mid + 1; else hi = mid;
             }
-            if (lo < n && wb_key_sq(segk[lo]) == target) {
-                const int cs2 = wb_key_case(segk[lo]);
+            if (lo < n && wb_key_sq(keys[lo]) == target) {
+                const int cs2 = wb_key_case(keys[lo]);
                 if (wb_seg_from(cs2, 0) == want) s = (uint32_t)lo;
                 else if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) s = (uint32_t)lo + 1;
             }
@@ -217,81 +210,144 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
         succ[i] = s;
         if (s != WB_NIL) pred[s] = (uint32_t)i;
     WB_END_PFOR
+    WB_SINGLE
+    a.nseg[job] = n;
+    WB_END_SINGLE
+}
 
-    WB_STAMP(3);
+// -------------------------------------------------------------------------------------------- 2b: rank
+// Pointer jumping, generic over the link type (uint16_t in LDS, uint32_t in global memory).
+//   pass 1 (over pred, running max): closed loops = elements whose pointer never reaches NIL; the loop's
+//          raster-last member is where the index equals the window max -> the contour starts right after it
+//   pass 2 (Wyllie list ranking): start segment and 1-based position of every segment
+template <class IT>
+WB_DEV inline void wb_rank_lists(int n, IT nil, const uint32_t* succ_g, uint32_t* t0_g, IT* P, IT* J0, IT* J1, IT* A0, IT* A1,
+                                 IT* D0, IT* D1, uint32_t* start_g, uint32_t* dist_g) {
     int rounds = 0;
     while ((1 << rounds) < n) ++rounds;
-
-    // ---- P2: pointer jumping over pred with a running max: finds closed loops and their
-    //          raster-last member (the contour starts right after it)
     WB_PFOR(i, n)
-        jA[i] = pred[i];
-        mA[i] = (uint32_t)i;
+        J0[i] = P[i];
+        A0[i] = (IT)i;
     WB_END_PFOR
-    {
-        uint32_t *ji = jA, *jo = jB, *mi = mA, *mo = mB;
-        for (int it = 0; it < rounds; ++it) {
-            WB_PFOR(i, n)
-                const uint32_t j = ji[i];
-                if (j != WB_NIL) {
-                    const uint32_t m1 = mi[i], m2 = mi[j];
-                    mo[i] = m1 > m2 ? m1 : m2;
-                    jo[i] = ji[j];
-                } else {
-                    mo[i] = mi[i];
-                    jo[i] = WB_NIL;
-                }
-            WB_END_PFOR
-            uint32_t* t = ji; ji = jo; jo = t;
-            t = mi; mi = mo; mo = t;
-        }
-        // cut every loop after its raster-last segment
+    IT *ji = J0, *jo = J1, *ai = A0, *ao = A1;
+    for (int it = 0; it < rounds; ++it) {
         WB_PFOR(i, n)
-            if (ji[i] != WB_NIL && mi[i] == (uint32_t)i) {
-                const uint32_t s = succ[i];
-                t0[s] = 1;
-                pred[s] = WB_NIL;
-                succ[i] = WB_NIL;
+            const IT j = ji[i];
+            if (j != nil) {
+                const IT m1 = ai[i], m2 = ai[j];
+                ao[i] = m1 > m2 ? m1 : m2;
+                jo[i] = ji[j];
+            } else {
+                ao[i] = ai[i];
+                jo[i] = nil;
             }
         WB_END_PFOR
+        IT* t = ji; ji = jo; jo = t;
+        t = ai; ai = ao; ao = t;
     }
-
-    WB_STAMP(4);
-    // ---- P3: list ranking: start segment and position of every segment
-    WB_PFOR(i, n)
-        jA[i] = pred[i];
-        mA[i] = (uint32_t)i;
-        dA[i] = 1;
-    WB_END_PFOR
-    uint32_t *start = mA, *dist = dA;
-    {
-        uint32_t *ji = jA, *jo = jB, *si = mA, *so = mB, *di = dA, *dob = dB;
-        for (int it = 0; it < rounds; ++it) {
-            WB_PFOR(i, n)
-                const uint32_t j = ji[i];
-                if (j != WB_NIL) {
-                    so[i] = si[j];
-                    dob[i] = di[i] + di[j];
-                    jo[i] = ji[j];
-                } else {
-                    so[i] = si[i];
-                    dob[i] = di[i];
-                    jo[i] = WB_NIL;
-                }
-            WB_END_PFOR
-            uint32_t* t = ji; ji = jo; jo = t;
-            t = si; si = so; so = t;
-            t = di; di = dob; dob = t;
+    WB_PFOR(i, n)   // cut every loop after its raster-last segment
+        if (ji[i] != nil && ai[i] == (IT)i) {
+            const uint32_t s = succ_g[i];
+            t0_g[s] = 1;
+            P[s] = nil;
         }
-        start = si;
-        dist = di;
+    WB_END_PFOR
+    WB_PFOR(i, n)
+        J0[i] = P[i];
+        A0[i] = (IT)i;
+        D0[i] = (IT)1;
+    WB_END_PFOR
+    ji = J0; jo = J1; ai = A0; ao = A1;
+    IT *di = D0, *dob = D1;
+    for (int it = 0; it < rounds; ++it) {
+        WB_PFOR(i, n)
+            const IT j = ji[i];
+            if (j != nil) {
+                ao[i] = ai[j];
+                dob[i] = (IT)(di[i] + di[j]);
+                jo[i] = ji[j];
+            } else {
+                ao[i] = ai[i];
+                dob[i] = di[i];
+                jo[i] = nil;
+            }
+        WB_END_PFOR
+        IT* t = ji; ji = jo; jo = t;
+        t = ai; ai = ao; ao = t;
+        t = di; di = dob; dob = t;
     }
-    WB_STAMP(5);
-    // free now: succ, pred, the two j buffers and the two "other" halves.  Name what we reuse:
+    WB_PFOR(i, n)
+        start_g[i] = (uint32_t)ai[i];
+        dist_g[i] = (uint32_t)di[i];
+    WB_END_PFOR
+}
+
+WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const int n = a.nseg[job];
+    if (n <= 0) return;
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* succ = a.w[0] + jb;
+    uint32_t* pred = a.w[1] + jb;
+    uint32_t* t0 = a.w[8] + jb;
+    uint32_t* start = a.w[4] + jb;
+    uint32_t* dist = a.w[6] + jb;
+    if (n <= WB_TRACE_LDS_N) {
+        WB_SHARED(uint16_t, lds, 7 * WB_TRACE_LDS_N);     // 112 KiB: P, J0, J1, A0, A1, D0, D1 (dist <= n <= 8192 fits)
+        uint16_t* P = lds;
+        WB_PFOR(i, n)
+            const uint32_t v = pred[i];
+            P[i] = v == WB_NIL ? (uint16_t)0xFFFF : (uint16_t)v;
+        WB_END_PFOR
+        wb_rank_lists<uint16_t>(n, (uint16_t)0xFFFF, succ, t0, P, lds + 1 * WB_TRACE_LDS_N, lds + 2 * WB_TRACE_LDS_N,
+                                lds + 3 * WB_TRACE_LDS_N, lds + 4 * WB_TRACE_LDS_N, lds + 5 * WB_TRACE_LDS_N,
+                                lds + 6 * WB_TRACE_LDS_N, start, dist);
+    } else {
+        // big job: same algorithm on 32-bit links in global memory; buffers J: w[2], w[3]; A: w[5], w[7]; D: w[9], w[10]
+        wb_rank_lists<uint32_t>(n, (uint32_t)WB_NIL, succ, t0, pred, a.w[2] + jb, a.w[3] + jb, a.w[5] + jb, a.w[7] + jb,
+                                a.w[9] + jb, a.w[10] + jb, start, dist);
+    }
+}
+
+// -------------------------------------------------------------------------------------------- 2c: finish
+WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const int n = a.nseg[job];
+    if (n <= 0) return;            // ncont already written by the link kernel
+    const int cap = a.cap_seg;
+    const size_t jb = (size_t)job * cap;
+    const uint32_t* segf = a.mseg[1] + jb;
+    const uint32_t* segt = a.mseg[2] + jb;
+    uint32_t* succ = a.w[0] + jb;
+    uint32_t* pred = a.w[1] + jb;
+    uint32_t* jA = a.w[2] + jb;
+    uint32_t* jB = a.w[3] + jb;
+    uint32_t* start = a.w[4] + jb;
+    uint32_t* dist = a.w[6] + jb;
+    uint32_t* t0 = a.w[8] + jb;   // in: "is first segment of a cut loop"; later scratch
+    uint32_t* t1 = a.w[9] + jb;
+    uint32_t* rawpt = a.rawpt + 2 * jb;
+    uint32_t* rawcid = a.rawcid + 2 * jb;
+    int* keep = a.keep + (size_t)job * (2 * cap + 1);
+    unsigned long long* hkey = a.hkey + (size_t)job * a.hash_size;
+    uint32_t* hval = a.hval + (size_t)job * a.hash_size;
+    uint32_t* cpts = a.cpts + 2 * jb;
+    uint32_t* cown = a.cown + 2 * jb;
+    int* c_off = a.c_off + jb;
+    int* c_len = a.c_len + jb;
+    int* c_closed = a.c_closed + jb;
+    int* c_nux = a.c_nux + jb;
+    int* c_sumy = a.c_sumy + jb;
+    int hsize = 1024;              // raw points <= 2n; keys per point <= 2: load factor <= 0.5
+    while (hsize < 8 * n && hsize < a.hash_size) hsize <<= 1;
+    const int hmask = hsize - 1;
+    // scratch roles in this kernel
     uint32_t* minidx = succ;       // per start segment: smallest member index
     uint32_t* cid_of = pred;       // per start segment: contour number (raster order of first segment)
-    uint32_t* spare0 = (start == mA) ? mB : mA;
-    uint32_t* spare1 = (dist == dA) ? dB : dA;
+    uint32_t* spare0 = a.w[5] + jb;
+    uint32_t* spare1 = a.w[7] + jb;
     int* flag = (int*)jA;
     int* cnt = (int*)jB;           // per contour: number of segments, then raw base
 
@@ -332,7 +388,6 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
         }
     WB_END_PFOR
 
-    WB_STAMP(6);
     // ---- P5: order-preserving first-occurrence dedupe inside each contour
     WB_PFOR(s, hsize)
         hkey[s] = WB_HEMPTY;
@@ -394,7 +449,6 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
         }
     WB_END_PFOR
 
-    WB_STAMP(7);
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
     int* setsize = (int*)jA;   // [Ck]
     int* dropped = (int*)jB;   // [Ck]
@@ -422,7 +476,6 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
         }
     WB_END_PFOR
 
-    WB_STAMP(8);
     // ---- P7: periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1,i2)
     //          with set(i1) a subset of set(i2): equal array lengths -> drop max(i1,i2), else drop the shorter
     WB_PFOR(pair, (int64_t)Ck * Ck)
@@ -443,7 +496,6 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
         }
     WB_END_PFOR
 
-    WB_STAMP(9);
     // ---- P8: final table = kept and not dropped, order preserved
     int* fin = (int*)t0;  // [Ck] -> exclusive scan
     WB_PFOR(f, Ck)
@@ -475,7 +527,6 @@ WB_KERNEL_LB(wb_k_trace, 256, 8, WbTraceArgs a) {
             wb_atomic_max(a.max_nux, s_nux[f]);
         }
     WB_END_PFOR
-    WB_STAMP(10);
     WB_SINGLE
     a.ncont[job] = Cf;
     WB_END_SINGLE
