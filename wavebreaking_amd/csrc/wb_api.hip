@@ -1002,45 +1002,57 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     }
     if (dsync(ctx)) return 1;
 
-    // ---- host tables
+    // ---- host tables (sized once, filled with plain loops)
     for (int kind = 0; kind < 3; ++kind) {
         wb_batch::Ev& t = b->ev[kind];
         t = wb_batch::Ev();
         const int lo = kind == 0 ? 0 : (kind == 1 ? NS : NS + NO), hi = kind == 0 ? NS : (kind == 1 ? NS + NO : NE);
-        for (int e = lo; e < hi; ++e) {
+        const size_t m = (size_t)(hi - lo);
+        const long long pbase = h_poff[lo], pn = h_poff[hi] - h_poff[lo];
+        t.step.resize(m); t.level.resize(m); t.contour.resize(m); t.ind1.resize(m); t.ind2.resize(m);
+        t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.ncells.resize(m);
+        t.polyoff.resize(m + 1); t.px.resize((size_t)pn); t.py.resize((size_t)pn);
+        for (size_t k = 0; k < m; ++k) {
+            const int e = lo + (int)k;
             const int* d = &h_ev[(size_t)e * 8];
             const int job = d[1];
-            t.step.push_back(b->job_step.empty() ? job / p.nlevels : b->job_step[job]);
-            t.level.push_back(b->job_level.empty() ? job % p.nlevels : b->job_level[job]);
-            t.contour.push_back(b->ct_base[job] + d[2]);
+            t.step[k] = b->job_step.empty() ? job / p.nlevels : b->job_step[job];
+            t.level[k] = b->job_level.empty() ? job % p.nlevels : b->job_level[job];
+            t.contour[k] = b->ct_base[job] + d[2];
             if (kind == WB_OVERTURNINGS) {
-                t.ind1.push_back(0); t.ind2.push_back(0);
-                t.box.insert(t.box.end(), d + 3, d + 7);
-                t.orient.push_back(d[7]);
+                t.ind1[k] = 0; t.ind2[k] = 0;
+                for (int q = 0; q < 4; ++q) t.box[4 * k + q] = d[3 + q];
+                t.orient[k] = d[7];
             } else {
-                t.ind1.push_back(d[3]); t.ind2.push_back(d[4]);
-                t.box.insert(t.box.end(), 4, 0);
-                t.orient.push_back(0);
+                t.ind1[k] = d[3]; t.ind2[k] = d[4];
             }
-            t.sums.insert(t.sums.end(), &h_sums[(size_t)e * 5], &h_sums[(size_t)e * 5] + 5);
-            t.polyoff.push_back((int64_t)t.px.size());
-            for (long long q = h_poff[e]; q < h_poff[e + 1]; ++q) {
-                t.px.push_back(wb_pt_x(h_poly[(size_t)q]));
-                t.py.push_back(wb_pt_y(h_poly[(size_t)q]));
-            }
-            t.ncells.push_back(h_nc[e]);
-            if (p.want_cells) {
-                t.celloff.push_back((int64_t)t.cx.size());
-                const long long off = h_coff[e];
-                for (int c = 0; c < h_nc[e] && off >= 0; ++c) {
+            for (int q = 0; q < 5; ++q) t.sums[5 * k + q] = h_sums[(size_t)e * 5 + q];
+            t.polyoff[k] = h_poff[e] - pbase;
+            t.ncells[k] = h_nc[e];
+        }
+        t.polyoff[m] = pn;
+        {
+            const uint32_t* src = h_poly.data() + pbase;
+            int32_t* px = t.px.data();
+            int32_t* py = t.py.data();
+            for (long long q = 0; q < pn; ++q) { px[q] = (int32_t)(src[q] & 0xFFFFu); py[q] = (int32_t)(src[q] >> 16); }
+        }
+        if (p.want_cells) {
+            t.celloff.resize(m + 1);
+            size_t tot = 0;
+            for (size_t k = 0; k < m; ++k) { t.celloff[k] = (int64_t)tot; tot += h_coff[lo + k] >= 0 ? (size_t)h_nc[lo + k] : 0; }
+            t.celloff[m] = (int64_t)tot;
+            t.cx.resize(tot); t.cy.resize(tot);
+            for (size_t k = 0; k < m; ++k) {
+                const long long off = h_coff[lo + k];
+                if (off < 0) continue;
+                for (int c = 0; c < h_nc[lo + k]; ++c) {
                     const uint32_t v = h_cells[(size_t)off + c];
-                    t.cx.push_back(wb_pt_x(v));
-                    t.cy.push_back(wb_pt_y(v));
+                    t.cx[(size_t)t.celloff[k] + c] = wb_pt_x(v);
+                    t.cy[(size_t)t.celloff[k] + c] = wb_pt_y(v);
                 }
             }
         }
-        if (p.want_cells) t.celloff.push_back((int64_t)t.cx.size());
-        t.polyoff.push_back((int64_t)t.px.size());
     }
     for (void* q : tmp) bfree_one(b, q);
     b->sel_job = b->sel_cont = b->cut_job = b->cut_cont = nullptr;

@@ -42,6 +42,8 @@ template <class T> static inline T wb_atomic_or(T* p, T v) { T o = *p; *p = o | 
 template <class T> static inline T wb_atomic_cas(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline int wb_popc32(uint32_t v) { return __builtin_popcount(v); }
 static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
+// base[idx] += val (no return value); on the GPU lanes of a wave that hit the same idx are combined first
+static inline void wb_atomic_add_agg(int* base, int idx, int val) { base[idx] += val; }
 
 // in-place exclusive scan of a[0..n); returns the total
 static inline int wb_block_scan_excl(int* a, int n) {
@@ -82,6 +84,26 @@ template <class T> __device__ inline T wb_atomic_or(T* p, T v) { return atomicOr
 template <class T> __device__ inline T wb_atomic_cas(T* p, T cmp, T v) { return atomicCAS(p, cmp, v); }
 __device__ inline int wb_popc32(uint32_t v) { return __popc(v); }
 __device__ inline int wb_popc64(uint64_t v) { return __popcll(v); }
+// base[idx] += val without return value.  Many lanes of a wave usually target the same idx (all points of one
+// long contour): they are summed inside the wave first, one atomic per distinct idx (atomics on one address
+// serialise at ~12 ns each on this chip).  Must be called by converged code paths only in the sense that every
+// participating lane reaches it; inactive lanes are simply not in the ballot.
+__device__ inline void wb_atomic_add_agg(int* base, int idx, int val) {
+    unsigned long long todo = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lidx = __shfl(idx, leader, 64);
+        const unsigned long long same = __ballot(idx == lidx) & todo;
+        // sum of val (0 <= val < 65536) over the lanes in `same`, bit-sliced with ballots: well defined whatever
+        // lanes are inactive (a shuffle would read undefined registers of lanes that left the loop)
+        int sum = 0;
+#pragma unroll
+        for (int bit = 0; bit < 16; ++bit) sum += __popcll(__ballot((val >> bit) & 1) & same) << bit;
+        if (lane == leader) atomicAdd(&base[lidx], sum);
+        todo &= ~same;
+    }
+}
 
 // 64-wide inclusive wave scan (gfx950 wavefront = 64)
 __device__ inline int wb_wave_scan_incl(int v) {

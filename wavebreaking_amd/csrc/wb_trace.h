@@ -357,7 +357,8 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
         cnt[i] = 0;
     WB_END_PFOR
     WB_PFOR(i, n)
-        wb_atomic_min(&minidx[start[i]], (uint32_t)i);
+        // ascending i per thread: after the first sweep almost every compare fails without touching the atomic unit
+        if ((uint32_t)i < minidx[start[i]]) wb_atomic_min(&minidx[start[i]], (uint32_t)i);
     WB_END_PFOR
     WB_PFOR(i, n)
         flag[i] = (minidx[start[i]] == (uint32_t)i) ? 1 : 0;
@@ -367,7 +368,7 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
         if (minidx[start[i]] == (uint32_t)i) cid_of[start[i]] = (uint32_t)flag[i];
     WB_END_PFOR
     WB_PFOR(i, n)
-        wb_atomic_add(&cnt[cid_of[start[i]]], 1);
+        wb_atomic_add_agg(cnt, (int)cid_of[start[i]], 1);
     WB_END_PFOR
     int* rawbase = (int*)spare0;   // [C+1]
     WB_PFOR(c, C)
@@ -468,11 +469,11 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
             int fresh;
             const unsigned long long k1 = ((unsigned long long)f << 32) | (uint32_t)((x % a.nlon) | (y << 16));
             if (wb_hash_insert(hkey, hmask, k1, &fresh) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-            if (fresh) wb_atomic_add(&setsize[f], 1);
+            if (fresh) wb_atomic_add(&setsize[f], 1);   // (taken by nearly every point: see the aggregated form below)
             const unsigned long long k2 = (1ull << 63) | ((unsigned long long)f << 32) | (uint32_t)x;
             if (wb_hash_insert(hkey, hmask, k2, &fresh) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
             if (fresh) wb_atomic_add(&c_nux[f], 1);
-            wb_atomic_add(&c_sumy[f], y);
+            wb_atomic_add_agg(c_sumy, (int)f, y);
         }
     WB_END_PFOR
 
