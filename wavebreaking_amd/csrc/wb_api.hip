@@ -861,6 +861,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         st.pre = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
         st.ptab = (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double));
         st.bbx = (int*)talloc((size_t)((NPT >> 5) + nsel + 1) * 4 * sizeof(int));
+        st.tbx = (int*)talloc((size_t)((NPT >> 4) + nsel + 1) * 4 * sizeof(int));
         st.dy_max = (int)floor(p.geo_dis / (6371.0 * p.dlat * (M_PI / 180.0))) + 1;
         st.npairs = (int*)talloc(nsel * sizeof(int));
         st.stage = (int*)talloc(nsel * sizeof(int));
@@ -868,7 +869,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
         st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
         st.ev_ind = ev_ind; st.ev_n = ev_n; st.band_hits = d_band; st.status = b->status;
-        if (!st.rowaux || !ev_ind || !st.bbx) return 1;
+        if (!st.rowaux || !ev_ind || !st.bbx || !st.tbx) return 1;
         for (int attempt = 0; attempt < 4; ++attempt) {
             st.cap_pairs = cap_pairs;
             st.hash_size = next_pow2(2LL * cap_pairs);
@@ -902,9 +903,23 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_streamer_f1, nsel, 256, st);
             b->timer.end(ctx);
-            const int chunks = ((mx < cap_pairs ? mx : cap_pairs) + WB_F2_THREADS - 1) / WB_F2_THREADS;
+            // work list for the chord-contour test: one workgroup per 256 candidate pairs of a contour that can
+            // still reach routine 2 (more than one candidate, streamer_index.py:261-264)
+            std::vector<int> blk_sel, blk_first;
+            for (int q = 0; q < nsel; ++q) {
+                const int P = np[q] < cap_pairs ? np[q] : cap_pairs;
+                if (P <= 1) continue;
+                for (int f0 = 0; f0 < P; f0 += WB_F2_THREADS) { blk_sel.push_back(q); blk_first.push_back(f0); }
+            }
             b->timer.begin(ctx, "streamer_f2");
-            if (chunks > 0) WB_LAUNCH(wb_k_streamer_f2, (long long)nsel * chunks, 256, st, chunks);
+            if (!blk_sel.empty()) {
+                int* d_bs = (int*)talloc(blk_sel.size() * sizeof(int));
+                int* d_bf = (int*)talloc(blk_first.size() * sizeof(int));
+                if (!d_bf) return 1;
+                h2d(ctx, d_bs, blk_sel.data(), blk_sel.size() * sizeof(int));
+                h2d(ctx, d_bf, blk_first.data(), blk_first.size() * sizeof(int));
+                WB_LAUNCH(wb_k_streamer_f2, (long long)blk_sel.size(), 256, st, d_bs, d_bf);
+            }
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f34");
             WB_LAUNCH(wb_k_streamer_f34, nsel, 256, st);

@@ -233,6 +233,7 @@ struct WbStreamerArgs {
     long long npts_total;
     int* bbx;                  // per block of WB_BLK points (+1: the segment leaving the block): xmin, xmax, ymin, ymax;
                                // contour s owns blocks [(poff[s] >> 5) + s, ...)
+    int* tbx;                  // per tile of WB_PAIR_ROWS rows: xmin, xmax, ymin, ymax; contour s owns tiles [(poff[s] >> 4) + s, ...)
     int dy_max;                // |y_i - y_j| above this cannot be within geo_dis (R * dphi <= geo)
     unsigned long long* pairs; // [nsel][cap_pairs] (ind1 << 32 | ind2)
     int* alive;                // [nsel][cap_pairs]
@@ -288,6 +289,17 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
         tab[2 * a.npts_total + i] = a.cphi[y1];
         tab[3 * a.npts_total + i] = a.slam2[x1];
         tab[4 * a.npts_total + i] = a.clam2[x1];
+    WB_END_PFOR
+    int* tbx = a.tbx + 4 * ((po >> 4) + s);
+    WB_PFOR(tl, (N + 15) / 16)
+        int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
+        const int lo = (int)tl * 16, hi = lo + 16 < N ? lo + 16 : N;
+        for (int i = lo; i < hi; ++i) {
+            const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
+            x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1;
+            y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        }
+        tbx[4 * tl + 0] = x0; tbx[4 * tl + 1] = x1; tbx[4 * tl + 2] = y0; tbx[4 * tl + 3] = y1;
     WB_END_PFOR
     WB_PFOR(b, nblk)
         int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
@@ -363,13 +375,8 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
 
     const int i1 = i0 + WB_PAIR_ROWS < N - 1 ? i0 + WB_PAIR_ROWS : N - 1;   // rows i0 .. i1-1
     WB_SINGLE
-    int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
-    for (int i = i0; i < i1; ++i) {
-        const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
-        x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1;
-        y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
-    }
-    tb[0] = x0 - 120; tb[1] = x1 + 120; tb[2] = y0 - a.dy_max; tb[3] = y1 + a.dy_max;
+    const int* tb4 = a.tbx + 4 * ((po >> 4) + s) + 4 * tile;     // box of rows i0 .. i0+15 (a superset of i0 .. i1-1)
+    tb[0] = tb4[0] - 120; tb[1] = tb4[1] + 120; tb[2] = tb4[2] - a.dy_max; tb[3] = tb4[3] + a.dy_max;
     nlist[0] = 0;
     WB_END_SINGLE
     const bool use_list = nblk <= WB_MAX_BLOCKS;
@@ -385,41 +392,60 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
         WB_END_PFOR
     }
     const int nb = use_list ? nlist[0] : nblk;
-    WB_PFOR(idx, (int64_t)nb * WB_BLK * WB_PAIR_ROWS)
-        const int jj = (int)(idx % WB_BLK);
-        const int ii = (int)((idx / WB_BLK) % WB_PAIR_ROWS);
-        const int bsel = (int)(idx / (WB_BLK * WB_PAIR_ROWS));
-        const int i = i0 + ii;
+    // the tile's rows live in LDS (read as broadcasts); a lane owns ONE candidate point j, keeps its data in
+    // registers and sweeps the rows: per evaluated pair that is 0.4 global loads instead of 14
+    WB_SHARED(double, ri, WB_PAIR_ROWS * 6);
+    WB_SHARED(int, rx, WB_PAIR_ROWS);
+    WB_SHARED(int, ry, WB_PAIR_ROWS);
+    const int nrows = i1 - i0;
+    WB_PFOR(ii, nrows)
+        const int i = i0 + (int)ii;
+        ri[6 * ii + 0] = t_sp[i]; ri[6 * ii + 1] = t_cp[i]; ri[6 * ii + 2] = t_c[i];
+        ri[6 * ii + 3] = t_sl[i]; ri[6 * ii + 4] = t_cl[i]; ri[6 * ii + 5] = pre[i];
+        rx[ii] = wb_pt_x(pts[i]);
+        ry[ii] = wb_pt_y(pts[i]);
+    WB_END_PFOR
+    WB_PFOR(idx, (int64_t)nb * WB_BLK)
+        const int bsel = (int)(idx / WB_BLK), jj = (int)(idx % WB_BLK);
         const int j = (use_list ? blist[bsel] : bsel) * WB_BLK + jj;
-        if (i >= i1 || j <= i || j >= N) continue;
-        const uint32_t pi = pts[i], pj = pts[j];
-        int dx = wb_pt_x(pi) - wb_pt_x(pj);
-        if (dx < 0) dx = -dx;
-        if (dx > 120) continue;                                   // streamer_index.py:157
-        // sin((phi_i - phi_j)/2), sin((lam_i - lam_j)/2) by the subtraction formulas
-        const double sa = t_sp[i] * t_cp[j] - t_cp[i] * t_sp[j];
-        const double sb = t_sl[i] * t_cl[j] - t_cl[i] * t_sl[j];
-        const double h = sa * sa + t_c[i] * t_c[j] * (sb * sb);
-        bool near_geo;
-        if (fabs(h - a.hthr) <= WB_GEO_BAND * a.hthr) {            // guard band: evaluate as sklearn does
-            wb_atomic_add(&a.band_hits[0], 1);
-            const int yi = wb_pt_y(pi), yj = wb_pt_y(pj), xim = wb_pt_x(pi) % a.nlon, xjm = wb_pt_x(pj) % a.nlon;
-            const double geo = wb_haversine(a.lat_rad[yi], a.lon_rad[xim], a.lat_rad[yj], a.lon_rad[xjm]) * 6371.0;
-            near_geo = geo < a.geo_dis;
-        } else {
-            near_geo = h < a.hthr;
+        if (j <= i0 || j >= N) continue;
+        const int xj = wb_pt_x(pts[j]), yj = wb_pt_y(pts[j]);
+        const double spj = t_sp[j], cpj = t_cp[j], cj = t_c[j], slj = t_sl[j], clj = t_cl[j], prej = pre[j];
+        for (int ii = 0; ii < nrows; ++ii) {
+            const int i = i0 + ii;
+            if (j <= i) break;                                        // only j > i
+            int dx = rx[ii] - xj;
+            if (dx < 0) dx = -dx;
+            if (dx > 120) continue;                                   // streamer_index.py:157
+            int dy = ry[ii] - yj;
+            if (dy < 0) dy = -dy;
+            if (dy > a.dy_max) continue;                              // R * |dphi| alone already exceeds geo_dis
+            // sin((phi_i - phi_j)/2), sin((lam_i - lam_j)/2) by the subtraction formulas
+            const double sa = ri[6 * ii + 0] * cpj - ri[6 * ii + 1] * spj;
+            const double sb = ri[6 * ii + 3] * clj - ri[6 * ii + 4] * slj;
+            const double h = sa * sa + ri[6 * ii + 2] * cj * (sb * sb);
+            bool near_geo;
+            if (fabs(h - a.hthr) <= WB_GEO_BAND * a.hthr) {            // guard band: evaluate as sklearn does
+                wb_atomic_add(&a.band_hits[0], 1);
+                const uint32_t pi = pts[i], pj = pts[j];
+                const int yi = wb_pt_y(pi), yj = wb_pt_y(pj), xim = wb_pt_x(pi) % a.nlon, xjm = wb_pt_x(pj) % a.nlon;
+                const double geo = wb_haversine(a.lat_rad[yi], a.lon_rad[xim], a.lat_rad[yj], a.lon_rad[xjm]) * 6371.0;
+                near_geo = geo < a.geo_dis;
+            } else {
+                near_geo = h < a.hthr;
+            }
+            if (!near_geo) continue;
+            double cont = prej - ri[6 * ii + 5];
+            if (fabs(cont - a.cont_dis) <= WB_CONT_BAND) {            // guard band: sequential row cumsum (:135)
+                wb_atomic_add(&a.band_hits[1], 1);
+                double acc = 0.0;
+                for (int m = i + 1; m <= j; ++m) acc = acc + on[m];
+                cont = acc;
+            }
+            if (!(cont > a.cont_dis)) continue;
+            const int slot = wb_atomic_add(&a.npairs[s], 1);
+            if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
         }
-        if (!near_geo) continue;
-        double cont = pre[j] - pre[i];
-        if (fabs(cont - a.cont_dis) <= WB_CONT_BAND) {            // guard band: sequential row cumsum (:135)
-            wb_atomic_add(&a.band_hits[1], 1);
-            double acc = 0.0;
-            for (int m = i + 1; m <= j; ++m) acc = acc + on[m];
-            cont = acc;
-        }
-        if (!(cont > a.cont_dis)) continue;
-        const int slot = wb_atomic_add(&a.npairs[s], 1);
-        if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
     WB_END_PFOR
 }
 
@@ -494,9 +520,9 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
 // routine 2: check_intersections (:185-200): one lane per candidate pair; contour blocks whose bounding box
 // misses the chord's box are skipped, the rest is tested segment by segment with the exact predicate.
 #define WB_F2_THREADS 256
-WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, int chunks) {
-    const int s = WB_BLOCK_ID / chunks, chunk = WB_BLOCK_ID - s * chunks;
-    if (s >= a.nsel) return;
+WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk_first) {
+    // work list built on the host from the pair counts: workgroup w tests pairs [blk_first[w], +256) of contour blk_sel[w]
+    const int s = blk_sel[WB_BLOCK_ID];
     if (a.stage[s] != 1 || a.nalive[s] <= 1) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
@@ -507,7 +533,7 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, int chunks) {
     const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     int* alive = a.alive + (size_t)s * a.cap_pairs;
     const int P = a.npairs[s];
-    const int p0 = chunk * WB_F2_THREADS;
+    const int p0 = blk_first[WB_BLOCK_ID];
     if (p0 >= P) return;
     WB_PFOR(pp, WB_F2_THREADS)
         const int p = p0 + (int)pp;
@@ -520,10 +546,14 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, int chunks) {
             const int* bb = bbx + 4 * b;
             if (bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0) continue;
             const int mlo = b * WB_BLK, mhi = mlo + WB_BLK < N - 1 ? mlo + WB_BLK : N - 1;   // segments mlo .. mhi-1
+            uint32_t pa = pts[mlo];
             for (int m = mlo; m < mhi && !hit; ++m) {
-                const uint32_t pa = pts[m], pb = pts[m + 1];
-                hit = wb_chord_hits_segment(px, py, qx, qy, wb_pt_x(pa), wb_pt_y(pa), wb_pt_x(pb), wb_pt_y(pb), m == 0,
-                                            m == N - 2);
+                const uint32_t pb = pts[m + 1];
+                const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                pa = pb;
+                // a segment whose box misses the chord's box cannot meet the chord: skip the exact predicate
+                if ((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)) continue;
+                hit = wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2);
             }
         }
         if (hit) alive[p] = 2;   // 2 = rejected by routine 2 (turned into 0 by f3)

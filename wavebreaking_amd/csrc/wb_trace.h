@@ -469,7 +469,7 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
             int fresh;
             const unsigned long long k1 = ((unsigned long long)f << 32) | (uint32_t)((x % a.nlon) | (y << 16));
             if (wb_hash_insert(hkey, hmask, k1, &fresh) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-            if (fresh) wb_atomic_add(&setsize[f], 1);   // (taken by nearly every point: see the aggregated form below)
+            if (fresh) wb_atomic_add_agg(setsize, (int)f, 1);
             const unsigned long long k2 = (1ull << 63) | ((unsigned long long)f << 32) | (uint32_t)x;
             if (wb_hash_insert(hkey, hmask, k2, &fresh) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
             if (fresh) wb_atomic_add(&c_nux[f], 1);
