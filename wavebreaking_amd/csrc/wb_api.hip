@@ -883,9 +883,23 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "streamer_prep");
             WB_LAUNCH(wb_k_streamer_prep, nsel, 256, st);
             b->timer.end(ctx);
-            const int tiles = (maxN + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+            // work list of the all-pairs kernel: one single-wave workgroup per 8 consecutive 16-row tiles of a contour
+            const int TPB = 8;
+            std::vector<int> pb_sel, pb_tile;
+            for (int q = 0; q < nsel; ++q) {
+                const int rows = (int)(h_poff[q + 1] - h_poff[q]) - 1;
+                const int tiles_q = (rows + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+                for (int t0 = 0; t0 < tiles_q; t0 += TPB) { pb_sel.push_back(q); pb_tile.push_back(t0); }
+            }
             b->timer.begin(ctx, "streamer_pairs");
-            if (tiles > 0) WB_LAUNCH(wb_k_streamer_pairs, (long long)nsel * tiles, 256, st, tiles);
+            if (!pb_sel.empty()) {
+                int* d_ps = (int*)talloc(pb_sel.size() * sizeof(int));
+                int* d_pt = (int*)talloc(pb_tile.size() * sizeof(int));
+                if (!d_pt) return 1;
+                h2d(ctx, d_ps, pb_sel.data(), pb_sel.size() * sizeof(int));
+                h2d(ctx, d_pt, pb_tile.data(), pb_tile.size() * sizeof(int));
+                WB_LAUNCH(wb_k_streamer_pairs, (long long)pb_sel.size(), 64, st, d_ps, d_pt, TPB);
+            }
             b->timer.end(ctx);
             std::vector<int> np(nsel);
             d2h(ctx, np.data(), st.npairs, nsel * sizeof(int));

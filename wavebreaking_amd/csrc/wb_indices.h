@@ -347,17 +347,16 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
 // |x_i - x_j| <= 120 (:157), |y_i - y_j| <= dy_max (geo < geo_dis needs R*|dphi| < geo_dis), and the block's
 // largest along-contour distance must exceed cont_dis.  What survives is evaluated exactly as before.
 #define WB_PAIR_ROWS 16
-#define WB_MAX_BLOCKS 1024      // 2*cap_seg / WB_BLK for cap_seg <= 16384; longer contours fall back to all blocks
+#define WB_MAX_BLOCKS 512       // contours up to 16384 points; longer ones fall back to sweeping all blocks
 
-WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
-    const int s = WB_BLOCK_ID / tiles, tile = WB_BLOCK_ID - s * tiles;
-    if (s >= a.nsel) return;
+WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* blk_tile0, int tiles_per_block) {
+    // work list built on the host: workgroup w (ONE wave) sweeps tiles [blk_tile0[w], +tiles_per_block) of contour
+    // blk_sel[w]; single-wave workgroups make the phase barriers free and keep 32 tiles in flight per CU
+    const int s = blk_sel[WB_BLOCK_ID];
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
-    const int i0 = tile * WB_PAIR_ROWS;
-    if (i0 >= N - 1) return;
     const long long po = a.poff[s];
     const double* on = a.on + po;
     const double* pre = a.pre + po;
@@ -372,7 +371,14 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
     WB_SHARED(int, blist, WB_MAX_BLOCKS);
     WB_SHARED(int, nlist, 1);
     WB_SHARED(int, tb, 4);
+    WB_SHARED(double, ri, WB_PAIR_ROWS * 6);
+    WB_SHARED(int, rx, WB_PAIR_ROWS);
+    WB_SHARED(int, ry, WB_PAIR_ROWS);
 
+    const int tile_begin = blk_tile0[WB_BLOCK_ID];
+    for (int tile = tile_begin; tile < tile_begin + tiles_per_block; ++tile) {
+    const int i0 = tile * WB_PAIR_ROWS;
+    if (i0 >= N - 1) break;
     const int i1 = i0 + WB_PAIR_ROWS < N - 1 ? i0 + WB_PAIR_ROWS : N - 1;   // rows i0 .. i1-1
     WB_SINGLE
     const int* tb4 = a.tbx + 4 * ((po >> 4) + s) + 4 * tile;     // box of rows i0 .. i0+15 (a superset of i0 .. i1-1)
@@ -394,9 +400,6 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
     const int nb = use_list ? nlist[0] : nblk;
     // the tile's rows live in LDS (read as broadcasts); a lane owns ONE candidate point j, keeps its data in
     // registers and sweeps the rows: per evaluated pair that is 0.4 global loads instead of 14
-    WB_SHARED(double, ri, WB_PAIR_ROWS * 6);
-    WB_SHARED(int, rx, WB_PAIR_ROWS);
-    WB_SHARED(int, ry, WB_PAIR_ROWS);
     const int nrows = i1 - i0;
     WB_PFOR(ii, nrows)
         const int i = i0 + (int)ii;
@@ -447,6 +450,7 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, int tiles) {
             if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
         }
     WB_END_PFOR
+    }   // tiles
 }
 
 // routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264
