@@ -407,8 +407,21 @@ static int run_phase1(wb_batch* b) {
         // float4 / double4 row loads need 4-column granularity and a 16 / 32 byte aligned base
         const bool vec = (p.nlon % 4 == 0) && (b->W % 4 == 0) && (((uintptr_t)b->d_field) % (4 * esz) == 0);
         long long nwg = ((long long)p.nt * NS + 3) / 4;
-        if (nwg > 256 * 8) nwg = 256 * 8;                 // persistent: 8 workgroups (32 waves) per CU
-        const dim3 grid((unsigned)nwg), block(256);
+        const dim3 block(256);
+        int per_cu = 4;
+#define WB_SCAN_OCC(T, V, N) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wb_k_scan<T, V, N>, 256, 0)
+#define WB_SCAN_OCC_N(T, V) \
+        switch (p.nlevels) { case 1: WB_SCAN_OCC(T, V, 1); break; case 2: WB_SCAN_OCC(T, V, 2); break; \
+                             case 3: WB_SCAN_OCC(T, V, 3); break; default: WB_SCAN_OCC(T, V, 4); break; }
+        if (p.dtype == 0) { if (vec) { WB_SCAN_OCC_N(float, true) } else { WB_SCAN_OCC_N(float, false) } }
+        else { if (vec) { WB_SCAN_OCC_N(double, true) } else { WB_SCAN_OCC_N(double, false) } }
+#undef WB_SCAN_OCC_N
+#undef WB_SCAN_OCC
+        if (per_cu < 1) per_cu = 1;
+        int ncu = 256;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount; }
+        if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
+        const dim3 grid((unsigned)nwg);
 #define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan<T, V, N>), grid, block, 0, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
         switch (p.nlevels) { case 1: WB_SCAN_LAUNCH(T, V, 1); break; case 2: WB_SCAN_LAUNCH(T, V, 2); break; \

@@ -136,9 +136,46 @@ __device__ inline double wb_shl1(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+__device__ inline float wb_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ inline float wb_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ inline double wb_min3(double a, double b, double c) { return wb_min(wb_min(a, b), c); }
+__device__ inline double wb_max3(double a, double b, double c) { return wb_max(wb_max(a, b), c); }
+
+// Emit path of one strip row (rare), kept out of line so that the streaming loop stays small and lean.
+template <typename T>
+__device__ __forceinline__ int wb_scan_emit(uint32_t* stg_k, T* stg_v, int off, int cap_strip, int W, int r, int c0,
+                                          unsigned inmask, T lv, unsigned long long ltmask, int lane, T p0, T p1, T p2, T p3,
+                                          T p4, T n0, T n1, T n2, T n3, T n4) {
+    const T p[5] = {p0, p1, p2, p3, p4}, n[5] = {n0, n1, n2, n3, n4};
+    int cs[4], ns[4], below = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T ul = p[k], ur = p[k + 1], ll = n[k], lr = n[k + 1];
+        const bool ok = ((inmask >> k) & 1u) && ul == ul && ur == ur && ll == ll && lr == lr;
+        // v > lvl_lo in T  <=>  (double)v > level : skimage's strict compare on the float64 copy
+        cs[k] = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
+        ns[k] = wb_case_nseg(cs[k]);
+        const unsigned long long m1 = __ballot(ns[k] >= 1), m2 = __ballot(ns[k] == 2);
+        below += __popcll(m1 & ltmask) + __popcll(m2 & ltmask);
+        total += __popcll(m1) + __popcll(m2);
+    }
+    if (total == 0) return 0;
+    int mine = off + below;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (ns[k]) wb_store_square<T>(stg_k, stg_v, cap_strip, W, r, c0 + k, cs[k], ns[k], p[k], p[k + 1], n[k], n[k + 1], mine);
+        mine += ns[k];
+    }
+    return total;
+}
+
+// One row of a lane's patch: its 4 columns, the right halo, min / max over the 5 values (NaNs ignored).
+template <typename T> struct WbRow { T v[5]; T h63; T mn, mx; };
+
 template <typename T, bool VEC, int NLEV>
 __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> strip / row addresses are scalar
     const int NS = a.nstrips;
     const int W = a.W, nlon = a.nlon, nlat = a.nlat;
     const unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -158,103 +195,82 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
         // column offsets inside a row; out-of-range lanes read a clamped (valid, ignored) address
         int cm = c0 >= nlon ? c0 - nlon : c0;
         if (cm > nlon - 4) cm = nlon - 4;
-        int ch = c0 + 4;
-        ch = ch >= nlon ? ch - nlon : ch;
-        if (ch > nlon - 1) ch = nlon - 1;
+        int chs = (s + 1) * WB_STRIP;                         // first column of the next strip (wave-uniform)
+        chs = chs >= nlon ? chs - nlon : chs;
+        if (chs > nlon - 1) chs = nlon - 1;
         bool nanflag = false;
+        int cursor[NLEV];                                     // segments written so far, per level (wave-uniform)
+#pragma unroll
+        for (int l = 0; l < NLEV; ++l) cursor[l] = 0;
 
-        T p[5], n[5], pmin[4], pmax[4];
-        T nh = (T)0;                                          // lane 63: halo of the row held in n[0..3]
-        // a row load = the lane's 4 columns + (lane 63 only) the first column of the next strip.  The halo
-        // of the other lanes is the next lane's first column; it is fetched with a DPP wave shift only when
-        // the row is consumed, so the load itself stays in flight for a whole iteration (prefetch).
-        auto load_row = [&](int r, T v[4], T& h) {
-            const T* row = f + (size_t)r * nlon;
+        // A row load = the lane's 4 columns (one vector load) + the first column of the next strip, which is the
+        // halo of lane 63 only and wave-uniform, hence a SCALAR load (its own counter: the vector loads' vmcnt
+        // bookkeeping stays exact).  The halo of the other lanes is the next lane's first column, fetched with a
+        // DPP wave shift only when the row is consumed, so the loads stay in flight for four iterations (depth-4
+        // prefetch; six row buffers that rotate by name: the loop is unrolled 6x and no register is copied).
+        auto load_row = [&](int r, WbRow<T>& R) {
+            const T* row = f + (size_t)(r < nlat ? r : nlat - 1) * nlon;
             if (VEC) {
                 const typename WbVec4<T>::type q = *reinterpret_cast<const typename WbVec4<T>::type*>(row + cm);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                R.v[0] = q.x; R.v[1] = q.y; R.v[2] = q.z; R.v[3] = q.w;
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     int c = c0 + k;
                     c = c >= nlon ? c - nlon : c;
-                    v[k] = row[c > nlon - 1 ? nlon - 1 : c];
+                    R.v[k] = row[c > nlon - 1 ? nlon - 1 : c];
                 }
             }
-            if (lane == 63) h = row[ch];
+            R.h63 = row[chs];
+        };
+        auto finish_row = [&](WbRow<T>& R) {                  // halo, NaN flag, patch-row min / max
+            const T sh = wb_shl1(R.v[0]);                     // unconditional: every lane must be active for the DPP read
+            R.v[4] = (lane == 63) ? R.h63 : sh;
+            nanflag |= __builtin_isunordered(R.v[0], R.v[1]) | __builtin_isunordered(R.v[2], R.v[3]);
+            R.mn = wb_min3(R.v[0], R.v[1], wb_min3(R.v[2], R.v[3], R.v[4]));
+            R.mx = wb_max3(R.v[0], R.v[1], wb_max3(R.v[2], R.v[3], R.v[4]));
+        };
+        // classify the lane's 2 x 5 patch of rows (P, N): the patch is connected, so it holds a crossing of lvl
+        // iff min(patch) <= lvl < max(patch); squares with a NaN corner are sorted out by the emit path
+        auto step = [&](const WbRow<T>& P, WbRow<T>& N, int r) {
+            finish_row(N);
+            const T lo = wb_min(P.mn, N.mn), hi = wb_max(P.mx, N.mx);
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) {
+                if (__any((hi > lvl[l]) && !(lo > lvl[l]))) {   // rare: this strip row carries a segment of level l
+                    const size_t base = ((size_t)(t * NLEV + l) * NS + s) * a.cap_strip;
+                    cursor[l] += wb_scan_emit<T>(a.stg_k + base, (T*)a.stg_v + base * 4, cursor[l], a.cap_strip, W, r, c0, inmask,
+                                                 lvl[l], ltmask, lane, P.v[0], P.v[1], P.v[2], P.v[3], P.v[4], N.v[0], N.v[1],
+                                                 N.v[2], N.v[3], N.v[4]);
+                }
+            }
         };
 
-        {
-            T h0 = (T)0;
-            load_row(0, p, h0);
-            const T sh = wb_shl1(p[0]);                       // unconditional: every lane must be active for the DPP read
-            p[4] = (lane == 63) ? h0 : sh;
+        WbRow<T> R0, R1, R2, R3, R4, R5;
+        load_row(0, R0);
+        load_row(1, R1);
+        load_row(2, R2);
+        load_row(3, R3);
+        load_row(4, R4);
+        finish_row(R0);
+        int r = 0;
+        for (; r + 6 <= nlat - 1; r += 6) {                   // rows (r, r+1) .. (r+5, r+6); 4 row loads always in flight
+            load_row(r + 5, R5); step(R0, R1, r);
+            load_row(r + 6, R0); step(R1, R2, r + 1);
+            load_row(r + 7, R1); step(R2, R3, r + 2);
+            load_row(r + 8, R2); step(R3, R4, r + 3);
+            load_row(r + 9, R3); step(R4, R5, r + 4);
+            load_row(r + 10, R4); step(R5, R0, r + 5);
         }
-        nanflag |= (p[0] + p[1] + p[2] + p[3]) != (p[0] + p[1] + p[2] + p[3]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { pmin[k] = wb_min(p[k], p[k + 1]); pmax[k] = wb_max(p[k], p[k + 1]); }
-        if (nlat > 1) load_row(1, n, nh);
-        T q[4], qh = (T)0;                                    // row r+2, in flight
-        if (nlat > 2) load_row(2, q, qh);
+        if (r < nlat - 1) { load_row(r + 5, R5); step(R0, R1, r); ++r; }
+        if (r < nlat - 1) { step(R1, R2, r); ++r; }
+        if (r < nlat - 1) { step(R2, R3, r); ++r; }
+        if (r < nlat - 1) { step(R3, R4, r); ++r; }
+        if (r < nlat - 1) { step(R4, R5, r); ++r; }
 
-        for (int r = 0; r < nlat - 1; ++r) {
-            T x[4], xh = (T)0;                                // prefetch row r+3: two rows are always in flight
-            const bool more = r + 3 < nlat;
-            if (more) load_row(r + 3, x, xh);
-            const T nsh = wb_shl1(n[0]);                      // (a lane that sits out would hand its neighbour `old`)
-            n[4] = (lane == 63) ? nh : nsh;
-            {   // a NaN anywhere poisons the sum (an inf - inf pair would too; PV fields carry neither)
-                const T sum = n[0] + n[1] + n[2] + n[3];
-                nanflag |= sum != sum;
-            }
-            T nmin[4], nmax[4];
-            unsigned cmask = 0;
+        if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                nmin[k] = wb_min(n[k], n[k + 1]);
-                nmax[k] = wb_max(n[k], n[k + 1]);
-                const T lo = wb_min(pmin[k], nmin[k]), hi = wb_max(pmax[k], nmax[k]);
-#pragma unroll
-                for (int l = 0; l < NLEV; ++l) cmask |= ((hi > lvl[l]) && !(lo > lvl[l])) ? (1u << k) : 0u;
-            }
-            if (__any((cmask & inmask) != 0)) {  // rare: some square of this strip row carries a segment (or a NaN)
-#pragma unroll 1
-                for (int l = 0; l < NLEV; ++l) {
-                    const int job = t * NLEV + l;
-                    const size_t base = ((size_t)job * NS + s) * a.cap_strip;
-                    const T lv = wb_level_lo<T>(a.levels[l]);
-                    const int off = a.stg_n[job * NS + s];     // strip cursor lives in memory
-                    int cs[4], ns[4], below = 0, total = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const T ul = p[k], ur = p[k + 1], ll = n[k], lr = n[k + 1];
-                        const bool ok = ((inmask >> k) & 1u) && ul == ul && ur == ur && ll == ll && lr == lr;
-                        // v > lvl_lo in T  <=>  (double)v > level : skimage's strict compare on the float64 copy
-                        cs[k] = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
-                        ns[k] = wb_case_nseg(cs[k]);
-                        const unsigned long long m1 = __ballot(ns[k] >= 1), m2 = __ballot(ns[k] == 2);
-                        below += __popcll(m1 & ltmask) + __popcll(m2 & ltmask);
-                        total += __popcll(m1) + __popcll(m2);
-                    }
-                    int mine = off + below;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (ns[k])
-                            wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs[k], ns[k],
-                                               p[k], p[k + 1], n[k], n[k + 1], mine);
-                        mine += ns[k];
-                    }
-                    if (lane == 0) a.stg_n[job * NS + s] = off + total;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) p[k] = n[k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { pmin[k] = nmin[k]; pmax[k] = nmax[k]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { n[k] = q[k]; q[k] = x[k]; }
-            nh = qh;
-            qh = xh;
+            for (int l = 0; l < NLEV; ++l) a.stg_n[(t * NLEV + l) * NS + s] = cursor[l];
         }
         if (__any(nanflag && (c0 < W)) && lane == 0) {
 #pragma unroll
