@@ -94,13 +94,14 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 const int sgn = by > ay ? 1 : -1;
                 const int ylo = ay < by ? ay : by, yhi = ay < by ? by : ay;
                 for (int y = ylo; y < yhi; ++y) {
-                    long long num = (long long)(y - ay) * (bx - ax), den = by - ay;
+                    // lattice coordinates are < 2^15: 32-bit arithmetic is exact here
+                    int num = (y - ay) * (bx - ax), den = by - ay;
                     if (den < 0) { num = -num; den = -den; }
-                    const long long cdiv = num >= 0 ? (num + den - 1) / den : -((-num) / den);
-                    long long ecol = (long long)ax + cdiv - 1;          // last lattice x strictly left of the crossing
+                    const int cdiv = num >= 0 ? (num + den - 1) / den : -((-num) / den);
+                    int ecol = ax + cdiv - 1;                            // last lattice x strictly left of the crossing
                     if (ecol >= x0) {
                         if (ecol > x1) ecol = x1;
-                        wb_atomic_add(&cells[(size_t)(y - y0) * cols + (int)(ecol - x0)], sgn);
+                        wb_atomic_add(&cells[(size_t)(y - y0) * cols + (ecol - x0)], sgn);
                     }
                 }
             }
@@ -118,13 +119,27 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         WB_PFOR(k, n)
             const uint32_t va = wb_event_vertex(d, pts, (int)k), vb = wb_event_vertex(d, pts, (int)((k + 1) % n));
             const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+            const long long dx = bx - ax, dy = by - ay, L = dx * dx + dy * dy;
+            if ((double)L * a.r2 <= 1.0 && a.r2 <= 1.0) {
+                // short edge: a lattice point off its line is at least 1/sqrt(L) >= r away, and one beyond its ends at
+                // least 1 >= r: only the lattice points ON the edge count (gcd + 1 of them, end points included)
+                int g = (int)(dx < 0 ? -dx : dx), h = (int)(dy < 0 ? -dy : dy);
+                while (h) { const int t = g % h; g = h; h = t; }
+                if (g == 0) g = 1;
+                const int sx = (int)dx / g, sy = (int)dy / g;
+                for (int t = 0; t <= g; ++t) {
+                    const int x = ax + t * sx, y = ay + t * sy;
+                    if (x >= x0 && x <= x1 && y >= y0 && y <= y1) cells[(size_t)(y - y0) * cols + (x - x0)] = 1;
+                }
+                if (L == 0 && ax >= x0 && ax <= x1 && ay >= y0 && ay <= y1) cells[(size_t)(ay - y0) * cols + (ax - x0)] = 1;
+                continue;
+            }
             int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
             int ey0 = (ay < by ? ay : by) - a.pad, ey1 = (ay < by ? by : ay) + a.pad;
             if (ex0 < x0) ex0 = x0;
             if (ex1 > x1) ex1 = x1;
             if (ey0 < y0) ey0 = y0;
             if (ey1 > y1) ey1 = y1;
-            const long long dx = bx - ax, dy = by - ay, L = dx * dx + dy * dy;
             for (int y = ey0; y <= ey1; ++y)
                 for (int x = ex0; x <= ex1; ++x) {
                     const long long t = (long long)(x - ax) * dx + (long long)(y - ay) * dy;
