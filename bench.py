@@ -86,7 +86,7 @@ def main():
 
     wall = {}
 
-    def one_pass(collect=False):
+    def one_pass(collect=False, copy=False):
         w0 = time.perf_counter()
         b = ctx.contours(d_pv, lat, lon, levels, a.dlon, a.dlon, intensity=d_int, device_shape=(nt, nlat, nlon),
                          device_dtype=np.float32, want_cells=False)
@@ -94,7 +94,7 @@ def main():
         g = wd.global_max_nux(b.max_nux(), dist if world > 1 else None)     # exchange (1): one int32 all-reduce(max)
         b.indices(g)
         w2 = time.perf_counter()
-        ev = [b.events(k) for k in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
+        ev = [b.events(k, copy=copy) for k in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
         w3 = time.perf_counter()
         if world > 1:                                                          # exchange (2): one gather to rank 0
             wd.gather_event_tables([wd.pack_events(e, step_offset=t0) for e in ev], dist, dst=0)
@@ -167,7 +167,7 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     nlat, nlon = lat.size, lon.size
     idx = sorted(set(int(round(i)) for i in np.linspace(0, nt - 1, nsample)))
-    ev = one_pass()
+    ev = one_pass(copy=True)
     t_cpu = 0.0
     ok = True
     for t in idx:

@@ -49,10 +49,11 @@ STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
 STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS = 1, 2, 4, 8, 16
 
 
-def _arr(ptr, n, dtype):
+def _arr(ptr, n, dtype, copy=True):
     if n == 0 or not ptr:
         return np.zeros(0, dtype=dtype)
-    return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
+    a = np.ctypeslib.as_array(ptr, shape=(int(n),))
+    return a.astype(dtype, copy=True) if copy else a
 
 
 class Library:
@@ -278,24 +279,27 @@ class Batch:
                     sum_y=_arr(t.sum_y, n, np.int64), npts=_arr(t.npts, n, np.int32), offset=_arr(t.offset, n, np.int64),
                     x=_arr(t.x, m, np.int32), y=_arr(t.y, m, np.int32))
 
-    def events(self, kind):
+    def events(self, kind, copy=True):
+        """Event table of one index.  ``copy=False`` hands out views of the library's host tables (valid until the
+        batch is closed or ``indices`` runs again) instead of private copies."""
         t = WbEventTable()
         if self.ctx.L.lib.wb_get_events(self.h, int(kind), C.byref(t)) != 0:
             raise RuntimeError("wb_get_events failed: " + self.ctx.error())
         n = t.n
-        out = dict(step=_arr(t.step, n, np.int32), level_idx=_arr(t.level_idx, n, np.int32),
-                   contour=_arr(t.contour, n, np.int64), ind1=_arr(t.ind1, n, np.int32), ind2=_arr(t.ind2, n, np.int32),
-                   box=_arr(t.box, 4 * n, np.int32).reshape(-1, 4), orientation=_arr(t.orientation, n, np.int32),
-                   sums=_arr(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=_arr(t.ncells, n, np.int32))
-        poff = _arr(t.poly_offset, n + 1, np.int64)
+        A = lambda p, m, dt: _arr(p, m, dt, copy)
+        out = dict(step=A(t.step, n, np.int32), level_idx=A(t.level_idx, n, np.int32),
+                   contour=A(t.contour, n, np.int64), ind1=A(t.ind1, n, np.int32), ind2=A(t.ind2, n, np.int32),
+                   box=A(t.box, 4 * n, np.int32).reshape(-1, 4), orientation=A(t.orientation, n, np.int32),
+                   sums=A(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=A(t.ncells, n, np.int32))
+        poff = A(t.poly_offset, n + 1, np.int64)
         out["poly_offset"] = poff
-        out["poly_x"] = _arr(t.poly_x, poff[-1] if n else 0, np.int32)
-        out["poly_y"] = _arr(t.poly_y, poff[-1] if n else 0, np.int32)
+        out["poly_x"] = A(t.poly_x, poff[-1] if n else 0, np.int32)
+        out["poly_y"] = A(t.poly_y, poff[-1] if n else 0, np.int32)
         if self.want_cells and t.cell_offset:
-            off = _arr(t.cell_offset, n + 1, np.int64)
+            off = A(t.cell_offset, n + 1, np.int64)
             out["cell_offset"] = off
-            out["cell_x"] = _arr(t.cell_x, off[-1] if n else 0, np.int32)
-            out["cell_y"] = _arr(t.cell_y, off[-1] if n else 0, np.int32)
+            out["cell_x"] = A(t.cell_x, off[-1] if n else 0, np.int32)
+            out["cell_y"] = A(t.cell_y, off[-1] if n else 0, np.int32)
         return out
 
     def status(self):

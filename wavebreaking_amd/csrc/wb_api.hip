@@ -740,15 +740,18 @@ WB_KERNEL(wb_k_sel_lens, int nsel, int cap_seg, const int* sel_job, const int* s
 
 // event polygons: vertices of every event, back to back (x | y<<16)
 WB_KERNEL(wb_k_pack_polys, int nev, int cap_seg, const int* ev, const long long* poff, const int* c_off, const uint32_t* cpts,
-          uint32_t* out) {
+          int* out_x, int* out_y) {
     for (int e = WB_BLOCK_ID; e < nev; e += WB_GRID_DIM) {
         const int* d = ev + (size_t)e * 8;
         const size_t jb = (size_t)d[1] * cap_seg;
         const uint32_t* pts = cpts + 2 * jb + c_off[jb + d[2]];
         const int n = (int)(poff[e + 1] - poff[e]);
-        uint32_t* dst = out + poff[e];
+        int* dx = out_x + poff[e];
+        int* dy = out_y + poff[e];
         WB_PFOR(k, n)
-            dst[k] = wb_event_vertex(d, pts, (int)k);
+            const uint32_t v = wb_event_vertex(d, pts, (int)k);
+            dx[k] = wb_pt_x(v);
+            dy[k] = wb_pt_y(v);
         WB_END_PFOR
     }
 }
@@ -969,7 +972,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     std::vector<double> h_sums((size_t)NE * 5 + 5, 0.0);
     std::vector<int> h_nc(NE + 1, 0);
     std::vector<long long> h_coff(NE + 1, 0);
-    std::vector<uint32_t> h_cells, h_poly;
+    std::vector<uint32_t> h_cells;
+    std::vector<int32_t> h_polyx, h_polyy;
     std::vector<long long> h_poff(NE + 1, 0);
     if (NE > 0) {
         int* d_sbase = (int*)talloc((nsel + 1) * sizeof(int));
@@ -1027,12 +1031,17 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         }
         {
             long long* d_poff = (long long*)talloc((NE + 1) * sizeof(long long));
-            uint32_t* d_poly = (uint32_t*)talloc((size_t)(h_poff[NE] + 1) * sizeof(uint32_t));
-            if (!d_poly) return 1;
+            int* d_px = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
+            int* d_py = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
+            if (!d_py) return 1;
             h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
-            WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_poly);
-            h_poly.resize((size_t)h_poff[NE]);
-            if (!h_poly.empty()) d2h(ctx, h_poly.data(), d_poly, h_poly.size() * sizeof(uint32_t));
+            WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_px, d_py);
+            h_polyx.resize((size_t)h_poff[NE]);
+            h_polyy.resize((size_t)h_poff[NE]);
+            if (!h_polyx.empty()) {
+                d2h(ctx, h_polyx.data(), d_px, h_polyx.size() * sizeof(int));
+                d2h(ctx, h_polyy.data(), d_py, h_polyy.size() * sizeof(int));
+            }
         }
         d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
         d2h(ctx, h_nc.data(), pa.ev_ncells, (size_t)NE * sizeof(int));
@@ -1073,11 +1082,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             t.ncells[k] = h_nc[e];
         }
         t.polyoff[m] = pn;
-        {
-            const uint32_t* src = h_poly.data() + pbase;
-            int32_t* px = t.px.data();
-            int32_t* py = t.py.data();
-            for (long long q = 0; q < pn; ++q) { px[q] = (int32_t)(src[q] & 0xFFFFu); py[q] = (int32_t)(src[q] >> 16); }
+        if (pn > 0) {
+            memcpy(t.px.data(), h_polyx.data() + pbase, (size_t)pn * sizeof(int32_t));
+            memcpy(t.py.data(), h_polyy.data() + pbase, (size_t)pn * sizeof(int32_t));
         }
         if (p.want_cells) {
             t.celloff.resize(m + 1);
