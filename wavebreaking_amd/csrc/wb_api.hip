@@ -257,10 +257,12 @@ struct wb_batch {
     std::vector<int32_t> ct_step, ct_level, ct_closed, ct_nux, ct_npts, ct_x, ct_y;
     std::vector<int64_t> ct_sumy, ct_off, ct_base;   // ct_base[job] = first contour row of the job
     struct Ev {
-        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, cx, cy, px, py;
+        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, cx, cy;
         std::vector<int64_t> contour, celloff, polyoff;
+        size_t pbase = 0;              // first polygon vertex of this table in wb_batch::poly_x / poly_y
         std::vector<double> sums;
     } ev[3];
+    std::vector<int32_t> poly_x, poly_y;   // polygon vertices of all events (streamers, overturnings, cutoffs)
     WbTimer timer;
     std::string timer_names;
 };
@@ -973,7 +975,10 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     std::vector<int> h_nc(NE + 1, 0);
     std::vector<long long> h_coff(NE + 1, 0);
     std::vector<uint32_t> h_cells;
-    std::vector<int32_t> h_polyx, h_polyy;
+    std::vector<int32_t>& h_polyx = b->poly_x;
+    std::vector<int32_t>& h_polyy = b->poly_y;
+    h_polyx.clear();
+    h_polyy.clear();
     std::vector<long long> h_poff(NE + 1, 0);
     if (NE > 0) {
         int* d_sbase = (int*)talloc((nsel + 1) * sizeof(int));
@@ -1062,7 +1067,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const long long pbase = h_poff[lo], pn = h_poff[hi] - h_poff[lo];
         t.step.resize(m); t.level.resize(m); t.contour.resize(m); t.ind1.resize(m); t.ind2.resize(m);
         t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.ncells.resize(m);
-        t.polyoff.resize(m + 1); t.px.resize((size_t)pn); t.py.resize((size_t)pn);
+        t.polyoff.resize(m + 1); t.pbase = (size_t)pbase;
         for (size_t k = 0; k < m; ++k) {
             const int e = lo + (int)k;
             const int* d = &h_ev[(size_t)e * 8];
@@ -1082,10 +1087,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             t.ncells[k] = h_nc[e];
         }
         t.polyoff[m] = pn;
-        if (pn > 0) {
-            memcpy(t.px.data(), h_polyx.data() + pbase, (size_t)pn * sizeof(int32_t));
-            memcpy(t.py.data(), h_polyy.data() + pbase, (size_t)pn * sizeof(int32_t));
-        }
+
         if (p.want_cells) {
             t.celloff.resize(m + 1);
             size_t tot = 0;
@@ -1119,7 +1121,7 @@ extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
     if (t.polyoff.empty()) t.polyoff.push_back(0);
-    o->poly_offset = t.polyoff.data(); o->poly_x = t.px.data(); o->poly_y = t.py.data();
+    o->poly_offset = t.polyoff.data(); o->poly_x = b->poly_x.data() + t.pbase; o->poly_y = b->poly_y.data() + t.pbase;
     return 0;
 }
 

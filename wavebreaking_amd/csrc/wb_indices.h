@@ -602,12 +602,11 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
         WB_PFOR(p, P)
             if (alive[p]) wb_atomic_max(&rowmax[(int)(pairs[p] >> 32)], (int)(pairs[p] & 0xFFFFFFFFull));
         WB_END_PFOR
+        WB_PFOR(i, N)
+            aux[i] = rowmax[i];
+        WB_END_PFOR
+        wb_block_scan_excl_max(aux, N, -1);   // aux[i] = max ind2 over rows < i
         WB_SINGLE
-        int run = -1;                 // aux[i] = max ind2 over rows < i
-        for (int i = 0; i < N; ++i) {
-            aux[i] = run;
-            if (rowmax[i] > run) run = rowmax[i];
-        }
         cnt[0] = 0;
         WB_END_SINGLE
         WB_PFOR(p, P)

@@ -101,18 +101,25 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                     int ecol = ax + cdiv - 1;                            // last lattice x strictly left of the crossing
                     if (ecol >= x0) {
                         if (ecol > x1) ecol = x1;
-                        wb_atomic_add(&cells[(size_t)(y - y0) * cols + (ecol - x0)], sgn);
+                        wb_atomic_add(&cells[(size_t)(ecol - x0) * rows + (y - y0)], sgn);
                     }
                 }
             }
         WB_END_PFOR
-        // B: suffix sums -> winding number != 0
+        // B: suffix sums -> winding number != 0.  Cells are stored column-major (x outer, y inner): the lane = row
+        //    sweeps below are coalesced, and the 8-wide chunks let the loads of a chunk issue back to back
         WB_PFOR(rr, rows)
             int run = 0;
-            int* row = cells + (size_t)rr * cols;
-            for (int x = cols - 1; x >= 0; --x) {
-                run += row[x];
-                row[x] = run != 0 ? 1 : 0;
+            int* col = cells + rr;
+            for (int x = cols - 1; x >= 0; x -= 8) {
+                int v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (x - q >= 0) ? col[(size_t)(x - q) * rows] : 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    run += v[q];
+                    if (x - q >= 0) col[(size_t)(x - q) * rows] = run != 0 ? 1 : 0;
+                }
             }
         WB_END_PFOR
         // C: rim: lattice points closer than r to an edge (boundary points included: d = 0)
@@ -129,9 +136,9 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 const int sx = (int)dx / g, sy = (int)dy / g;
                 for (int t = 0; t <= g; ++t) {
                     const int x = ax + t * sx, y = ay + t * sy;
-                    if (x >= x0 && x <= x1 && y >= y0 && y <= y1) cells[(size_t)(y - y0) * cols + (x - x0)] = 1;
+                    if (x >= x0 && x <= x1 && y >= y0 && y <= y1) cells[(size_t)(x - x0) * rows + (y - y0)] = 1;
                 }
-                if (L == 0 && ax >= x0 && ax <= x1 && ay >= y0 && ay <= y1) cells[(size_t)(ay - y0) * cols + (ax - x0)] = 1;
+                if (L == 0 && ax >= x0 && ax <= x1 && ay >= y0 && ay <= y1) cells[(size_t)(ax - x0) * rows + (ay - y0)] = 1;
                 continue;
             }
             int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
@@ -152,23 +159,35 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                         const long long cr = dx * (long long)(y - ay) - dy * (long long)(x - ax);
                         near = ((double)cr * (double)cr) / (double)L < a.r2;
                     }
-                    if (near) cells[(size_t)(y - y0) * cols + (x - x0)] = 1;
+                    if (near) cells[(size_t)(x - x0) * rows + (y - y0)] = 1;
                 }
         WB_END_PFOR
         // D: per-row counts and sums
         WB_PFOR(rr, rows)
             const int y = y0 + (int)rr;
-            const int* row = cells + (size_t)rr * cols;
+            const int* col = cells + rr;
             long long cnt = 0, sx = 0;
             double sv = 0.0, si = 0.0;
-            for (int x = 0; x < cols; ++x) {
-                if (row[x]) {
-                    const int gx = x0 + x;
-                    ++cnt;
-                    sx += gx;
-                    const size_t idx = tbase + (size_t)y * a.nlon + (size_t)(gx % a.nlon);
-                    sv += wb_load_field(a.data, idx, a.dtype);
-                    if (a.intensity) si += wb_load_field(a.intensity, idx, a.dtype);
+            for (int x = 0; x < cols; x += 8) {
+                int fl[8];
+                double dv[8], di[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) fl[q] = (x + q < cols) ? col[(size_t)(x + q) * rows] : 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {                       // field loads of the whole chunk, in flight together
+                    const int gx = x0 + x + q;
+                    const size_t idx = tbase + (size_t)y * a.nlon + (size_t)((gx < a.W ? gx : a.W - 1) % a.nlon);
+                    dv[q] = fl[q] ? wb_load_field(a.data, idx, a.dtype) : 0.0;
+                    di[q] = (fl[q] && a.intensity) ? wb_load_field(a.intensity, idx, a.dtype) : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (fl[q]) {
+                        ++cnt;
+                        sx += x0 + x + q;
+                        sv += dv[q];
+                        si += di[q];
+                    }
                 }
             }
             rowacc[0 * a.nlat + y] = (double)cnt;
@@ -214,10 +233,10 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         if (a.want_cells && sh_off[0] >= 0) {
             WB_PFOR(rr, rows)
                 const int y = y0 + (int)rr;
-                const int* row = cells + (size_t)rr * cols;
+                const int* col = cells + rr;
                 long long o = (long long)rowacc[0 * a.nlat + y];
                 for (int x = 0; x < cols; ++x)
-                    if (row[x]) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
+                    if (col[(size_t)x * rows]) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
             WB_END_PFOR
         }
     }

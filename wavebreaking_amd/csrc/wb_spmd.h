@@ -52,6 +52,12 @@ static inline int wb_block_scan_excl(int* a, int n) {
     return run;
 }
 
+// in-place exclusive running maximum of a[0..n): a[i] <- max(init, a[0..i-1])
+static inline void wb_block_scan_excl_max(int* a, int n, int init) {
+    int run = init;
+    for (int i = 0; i < n; ++i) { int v = a[i]; a[i] = run; if (v > run) run = v; }
+}
+
 #else
 // ---------------------------------------------------------------- HIP / gfx950
 #include <hip/hip_runtime.h>
@@ -143,5 +149,38 @@ __device__ inline int wb_block_scan_excl(int* a, int n) {
         __syncthreads();
     }
     return wb_scan_carry;
+}
+
+// in-place exclusive running maximum of a[0..n): a[i] <- max(init, a[0..i-1]); all threads of the block call it
+__device__ inline void wb_block_scan_excl_max(int* a, int n, int init) {
+    __shared__ int wb_smax_wave[16];
+    __shared__ int wb_smax_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    if (tid == 0) wb_smax_carry = init;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + tid;
+        const int v = (i < n) ? a[i] : init;
+        int inc = v;                                   // inclusive max over the wave prefix
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d && o > inc) inc = o;
+        }
+        if (lane == 63) wb_smax_wave[wave] = inc;
+        int excl = __shfl_up(inc, 1, 64);              // exclusive within the wave
+        if (lane == 0) excl = init;
+        __syncthreads();
+        int woff = wb_smax_carry;
+        for (int w = 0; w < wave; ++w) woff = wb_smax_wave[w] > woff ? wb_smax_wave[w] : woff;
+        if (i < n) a[i] = excl > woff ? excl : woff;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = wb_smax_carry;
+            for (int w = 0; w < nw; ++w) tot = wb_smax_wave[w] > tot ? wb_smax_wave[w] : tot;
+            wb_smax_carry = tot;
+        }
+        __syncthreads();
+    }
 }
 #endif
