@@ -36,6 +36,9 @@ extern "C" void wb_hostsim_set_reverse(int r) { wb_hostsim_reverse = r; }
 struct wb_ctx {
     int device = 0;
     std::string err;
+    // host buffers of the big result arrays are recycled between batches: a fresh 10 MB vector costs ~1 ms of page
+    // faults and zero-fill per pass
+    std::multimap<size_t, void*> hpool;
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
@@ -57,6 +60,22 @@ static double wb_now_ms() {
 }
 static bool wb_debug() { static int v = -1; if (v < 0) v = getenv("WB_DEBUG_TIMING") ? 1 : 0; return v == 1; }
 #define WB_TICK(label) do { if (wb_debug()) { double t_ = wb_now_ms(); fprintf(stderr, "[wb] %-28s %9.3f ms\n", label, t_ - wb_t0_); wb_t0_ = t_; } } while (0)
+
+static void* hmalloc(wb_ctx* c, size_t bytes) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    auto it = c->hpool.lower_bound(bytes);
+    if (it != c->hpool.end() && it->first <= 2 * bytes + (1u << 20)) {
+        void* p = it->second;
+        c->hpool.erase(it);
+        return p;
+    }
+    return malloc(bytes);
+}
+static void hfree(wb_ctx* c, void* p, size_t bytes) {
+    if (!p) return;
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (c->hpool.size() < 16) c->hpool.insert({bytes, p}); else free(p);
+}
 
 static int wb_fail(wb_ctx* c, const std::string& m) {
     if (c) c->err = m;
@@ -262,7 +281,8 @@ struct wb_batch {
         size_t pbase = 0;              // first polygon vertex of this table in wb_batch::poly_x / poly_y
         std::vector<double> sums;
     } ev[3];
-    std::vector<int32_t> poly_x, poly_y;   // polygon vertices of all events (streamers, overturnings, cutoffs)
+    int32_t *poly_x = nullptr, *poly_y = nullptr;   // polygon vertices of all events (streamers, overturnings, cutoffs)
+    size_t poly_n = 0, poly_bytes = 0;
     WbTimer timer;
     std::string timer_names;
 };
@@ -321,6 +341,7 @@ int wb_create(int device_id, wb_ctx** out) {
 
 void wb_destroy(wb_ctx* c) {
     if (!c) return;
+    for (auto& kv : c->hpool) free(kv.second);
 #if !defined(WB_HOSTSIM)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
@@ -342,6 +363,8 @@ void wb_free_batch(wb_batch* b) {
     if (!b) return;
     double wb_t0_ = wb_now_ms();
     for (void* p : b->owned) dfree(b->ctx, p);
+    hfree(b->ctx, b->poly_x, b->poly_bytes);
+    hfree(b->ctx, b->poly_y, b->poly_bytes);
     WB_TICK("free_batch device");
     delete b;
     WB_TICK("free_batch host");
@@ -975,10 +998,10 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     std::vector<int> h_nc(NE + 1, 0);
     std::vector<long long> h_coff(NE + 1, 0);
     std::vector<uint32_t> h_cells;
-    std::vector<int32_t>& h_polyx = b->poly_x;
-    std::vector<int32_t>& h_polyy = b->poly_y;
-    h_polyx.clear();
-    h_polyy.clear();
+    hfree(ctx, b->poly_x, b->poly_bytes);
+    hfree(ctx, b->poly_y, b->poly_bytes);
+    b->poly_x = b->poly_y = nullptr;
+    b->poly_n = b->poly_bytes = 0;
     std::vector<long long> h_poff(NE + 1, 0);
     if (NE > 0) {
         int* d_sbase = (int*)talloc((nsel + 1) * sizeof(int));
@@ -1041,11 +1064,14 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             if (!d_py) return 1;
             h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
             WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_px, d_py);
-            h_polyx.resize((size_t)h_poff[NE]);
-            h_polyy.resize((size_t)h_poff[NE]);
-            if (!h_polyx.empty()) {
-                d2h(ctx, h_polyx.data(), d_px, h_polyx.size() * sizeof(int));
-                d2h(ctx, h_polyy.data(), d_py, h_polyy.size() * sizeof(int));
+            b->poly_n = (size_t)h_poff[NE];
+            b->poly_bytes = (b->poly_n + 1) * sizeof(int32_t);
+            b->poly_x = (int32_t*)hmalloc(ctx, b->poly_bytes);
+            b->poly_y = (int32_t*)hmalloc(ctx, b->poly_bytes);
+            if (!b->poly_x || !b->poly_y) return wb_fail(ctx, "out of host memory");
+            if (b->poly_n) {
+                d2h(ctx, b->poly_x, d_px, b->poly_n * sizeof(int));
+                d2h(ctx, b->poly_y, d_py, b->poly_n * sizeof(int));
             }
         }
         d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
@@ -1121,7 +1147,7 @@ extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
     if (t.polyoff.empty()) t.polyoff.push_back(0);
-    o->poly_offset = t.polyoff.data(); o->poly_x = b->poly_x.data() + t.pbase; o->poly_y = b->poly_y.data() + t.pbase;
+    o->poly_offset = t.polyoff.data(); o->poly_x = b->poly_x ? b->poly_x + t.pbase : nullptr; o->poly_y = b->poly_y ? b->poly_y + t.pbase : nullptr;
     return 0;
 }
 
