@@ -253,7 +253,7 @@ struct wb_batch {
     uint32_t *stg_k = nullptr, *status = nullptr;
     void* stg_v = nullptr;
     int* stg_n = nullptr;
-    int nstrips = 0, cap_strip = 0;
+    int nstrips = 0, nwork_strips = 0, cap_strip = 0;
     uint32_t *cpts = nullptr, *cown = nullptr;
     int *c_off = nullptr, *c_len = nullptr, *c_closed = nullptr, *c_nux = nullptr, *c_sumy = nullptr, *ncont = nullptr;
     int* d_max_nux = nullptr;
@@ -420,6 +420,7 @@ static int run_phase1(wb_batch* b) {
     WbScanArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.nt = p.nt; sa.nlat = nlat; sa.nlon = p.nlon; sa.W = b->W; sa.nlev = p.nlevels; sa.nstrips = NS; sa.cap_strip = caps;
+    sa.nwork = b->nwork_strips; sa.padd = b->padd;
     sa.field = b->d_field;
     for (int l = 0; l < p.nlevels; ++l) sa.levels[l] = b->levels[l];
     sa.stg_k = b->stg_k; sa.stg_v = b->stg_v; sa.stg_n = b->stg_n; sa.status = b->status;
@@ -430,8 +431,8 @@ static int run_phase1(wb_batch* b) {
     {
         const size_t esz = p.dtype == 0 ? 4 : 8;
         // float4 / double4 row loads need 4-column granularity and a 16 / 32 byte aligned base
-        const bool vec = (p.nlon % 4 == 0) && (b->W % 4 == 0) && (((uintptr_t)b->d_field) % (4 * esz) == 0);
-        long long nwg = ((long long)p.nt * NS + 3) / 4;
+        const bool vec = (p.nlon % 4 == 0) && (((uintptr_t)b->d_field) % (4 * esz) == 0);
+        long long nwg = ((long long)p.nt * b->nwork_strips + 3) / 4;
         const dim3 block(256);
         int per_cu = 4;
 #define WB_SCAN_OCC(T, V, N) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wb_k_scan<T, V, N>, 256, 0)
@@ -526,8 +527,8 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
             b->d_intensity = di;
         }
     }
-    b->nstrips = (W - 1 + WB_STRIP - 1) / WB_STRIP;
-    if (b->nstrips < 1) b->nstrips = 1;
+    b->nwork_strips = (p.nlon + WB_STRIP - 1) / WB_STRIP;                       // strips that are streamed
+    b->nstrips = b->nwork_strips + (padd > 1 ? (padd - 1 + WB_STRIP - 1) / WB_STRIP : 0);   // + periodic copy lists
     int cap = p.cap_seg > 0 ? p.cap_seg : next_pow2(8LL * W);
     if (cap < 1024) cap = 1024;
     int caps = b->nstrips > 2 ? cap / 4 : (b->nstrips > 1 ? cap / 2 : cap);

@@ -3,8 +3,9 @@
 // Work decomposition: the extended row of W-1 squares is cut into strips of 256 squares; ONE WAVE
 // streams one strip of one time step top to bottom, for all contour levels at once, with no LDS and
 // no barrier (persistent waves loop over (time step, strip) work items).  A lane owns 4 consecutive
-// squares per row (one float4 / double4 load, 1 KiB per wave-load, each field value loaded from HBM once; the periodic columns nlon..W-1 of
-// contour_index.py:94-100 are re-reads of columns 0..padd-1 that hit L2).  The previous row stays in
+// squares per row (one float4 / double4 load, 1 KiB per wave-load, each field value loaded from HBM once).  The
+// periodic columns nlon..W-1 of contour_index.py:94-100 are never read again: a square in the first padd-1 base
+// columns is emitted twice, at c and at c + nlon (the second copy goes to the strip's "periodic copy" list).  The previous row stays in
 // registers together with its horizontal pair-wise min/max, so a square costs two min, two max and two
 // compares per level:
 //
@@ -27,7 +28,8 @@
 
 #define WB_MAX_LEVELS 4
 #define WB_STRIP 256          // squares per strip = 64 lanes x 4 squares
-#define WB_MAX_STRIPS 16      // W <= 4096
+#define WB_MAX_STRIPS 16      // nlon <= 4096
+#define WB_MAX_LISTS 32       // base strips + their periodic copies
 
 #define WB_ST_OVERFLOW_SEG 1u   // more segments than capacity: job skipped, host retries with a larger cap
 #define WB_ST_LEVEL_HIT 2u      // some cell equals the level exactly (edge linking != skimage's coordinate joins)
@@ -36,7 +38,11 @@
 #define WB_ST_OVERFLOW_PAIRS 16u
 
 struct WbScanArgs {
-    int nt, nlat, nlon, W, nlev, nstrips, cap_strip;
+    int nt, nlat, nlon, W, nlev, cap_strip;
+    int nwork;              // strips of 256 base columns that are actually streamed: ceil(nlon / 256)
+    int nstrips;            // segment lists per job: nwork base lists + one "periodic copy" list for every base strip
+                            // that reaches into the first padd-1 columns (list nwork + s holds the copies of strip s)
+    int padd;               // W - nlon
     const void* field;      // [nt][nlat][nlon], T
     double levels[WB_MAX_LEVELS];
     uint32_t* stg_k;        // [njobs][nstrips][cap_strip] key
@@ -79,11 +85,14 @@ void wb_scan_host(const WbScanArgs& a) {
                     const double v = (double)f[(size_t)r * a.nlon + c];
                     if (v != v) st |= WB_ST_HAS_NAN;
                 }
-            for (int s = 0; s < a.nstrips; ++s) {
+            const int cmax = a.nlon < a.W - 1 ? a.nlon : a.W - 1;     // base squares: c < min(nlon, W-1)
+            for (int s = 0; s < a.nwork; ++s) {
                 const size_t base = ((size_t)job * a.nstrips + s) * a.cap_strip;
-                int run = 0;
+                const size_t cbase = ((size_t)job * a.nstrips + a.nwork + s) * a.cap_strip;
+                const bool has_copy = a.nwork + s < a.nstrips;
+                int run = 0, crun = 0;
                 for (int r = 0; r < a.nlat - 1; ++r) {
-                    for (int c = s * WB_STRIP; c < (s + 1) * WB_STRIP && c < a.W - 1; ++c) {
+                    for (int c = s * WB_STRIP; c < (s + 1) * WB_STRIP && c < cmax; ++c) {
                         const double ul = (double)f[(size_t)r * a.nlon + c % a.nlon];
                         const double ur = (double)f[(size_t)r * a.nlon + (c + 1) % a.nlon];
                         const double ll = (double)f[(size_t)(r + 1) * a.nlon + c % a.nlon];
@@ -92,9 +101,14 @@ void wb_scan_host(const WbScanArgs& a) {
                         const int ns = wb_case_nseg(cs);
                         if (ns) wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, a.W, r, c, cs, ns, (T)ul, (T)ur, (T)ll, (T)lr, run);
                         run += ns;
+                        if (has_copy && c < a.padd - 1) {                 // the same square in the periodic columns
+                            if (ns) wb_store_square<T>(a.stg_k + cbase, (T*)a.stg_v + cbase * 4, a.cap_strip, a.W, r, c + a.nlon, cs, ns, (T)ul, (T)ur, (T)ll, (T)lr, crun);
+                            crun += ns;
+                        }
                     }
                 }
                 a.stg_n[job * a.nstrips + s] = run;
+                if (has_copy) a.stg_n[job * a.nstrips + a.nwork + s] = crun;
             }
             a.status[job] = st;
         }
@@ -103,7 +117,7 @@ void wb_scan_host(const WbScanArgs& a) {
 #else
 // ------------------------------------------------------------------------------------------------
 // gfx950 kernel: blockDim.x = 256 = 4 independent persistent waves.
-//   VEC  : rows are read with one 16 / 32 byte load per lane (needs nlon % 4 == 0, W % 4 == 0, aligned base)
+//   VEC  : rows are read with one 16 / 32 byte load per lane (needs nlon % 4 == 0 and an aligned base)
 //   NLEV : number of contour levels (compile time, so the level loops vanish)
 template <typename T> struct WbVec4;
 template <> struct WbVec4<float> { typedef float4 type; };
@@ -141,13 +155,14 @@ __device__ inline float wb_max3(float a, float b, float c) { float r; asm("v_max
 __device__ inline double wb_min3(double a, double b, double c) { return wb_min(wb_min(a, b), c); }
 __device__ inline double wb_max3(double a, double b, double c) { return wb_max(wb_max(a, b), c); }
 
-// Emit path of one strip row (rare), kept out of line so that the streaming loop stays small and lean.
+// Emit path of one strip row (rare).  Returns segments written to the base list | segments written to the copy list << 16.
 template <typename T>
-__device__ __forceinline__ int wb_scan_emit(uint32_t* stg_k, T* stg_v, int off, int cap_strip, int W, int r, int c0,
-                                          unsigned inmask, T lv, unsigned long long ltmask, int lane, T p0, T p1, T p2, T p3,
-                                          T p4, T n0, T n1, T n2, T n3, T n4) {
+__device__ __forceinline__ int wb_scan_emit(uint32_t* stg_k, T* stg_v, int off, uint32_t* cpy_k, T* cpy_v, int coff, int nlon,
+                                            int cap_strip, int W, int r, int c0, unsigned inmask, unsigned eligmask, T lv,
+                                            unsigned long long ltmask, T p0, T p1, T p2, T p3, T p4, T n0, T n1, T n2, T n3,
+                                            T n4) {
     const T p[5] = {p0, p1, p2, p3, p4}, n[5] = {n0, n1, n2, n3, n4};
-    int cs[4], ns[4], below = 0, total = 0;
+    int cs[4], ns[4], below = 0, total = 0, cbelow = 0, ctotal = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const T ul = p[k], ur = p[k + 1], ll = n[k], lr = n[k + 1];
@@ -158,15 +173,24 @@ __device__ __forceinline__ int wb_scan_emit(uint32_t* stg_k, T* stg_v, int off, 
         const unsigned long long m1 = __ballot(ns[k] >= 1), m2 = __ballot(ns[k] == 2);
         below += __popcll(m1 & ltmask) + __popcll(m2 & ltmask);
         total += __popcll(m1) + __popcll(m2);
+        const bool el = (eligmask >> k) & 1u;
+        const unsigned long long c1 = __ballot(ns[k] >= 1 && el), c2 = __ballot(ns[k] == 2 && el);
+        cbelow += __popcll(c1 & ltmask) + __popcll(c2 & ltmask);
+        ctotal += __popcll(c1) + __popcll(c2);
     }
     if (total == 0) return 0;
-    int mine = off + below;
+    int mine = off + below, cmine = coff + cbelow;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (ns[k]) wb_store_square<T>(stg_k, stg_v, cap_strip, W, r, c0 + k, cs[k], ns[k], p[k], p[k + 1], n[k], n[k + 1], mine);
+        if (ns[k]) {
+            wb_store_square<T>(stg_k, stg_v, cap_strip, W, r, c0 + k, cs[k], ns[k], p[k], p[k + 1], n[k], n[k + 1], mine);
+            if ((eligmask >> k) & 1u)
+                wb_store_square<T>(cpy_k, cpy_v, cap_strip, W, r, c0 + k + nlon, cs[k], ns[k], p[k], p[k + 1], n[k], n[k + 1], cmine);
+        }
         mine += ns[k];
+        if ((eligmask >> k) & 1u) cmine += ns[k];
     }
-    return total;
+    return total | (ctotal << 16);
 }
 
 // One row of a lane's patch: its 4 columns, the right halo, min / max over the 5 values (NaNs ignored).
@@ -176,22 +200,26 @@ template <typename T, bool VEC, int NLEV>
 __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> strip / row addresses are scalar
-    const int NS = a.nstrips;
+    const int NS = a.nstrips, NSB = a.nwork;
     const int W = a.W, nlon = a.nlon, nlat = a.nlat;
     const unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int nwork = a.nt * NS;
+    const int nwork = a.nt * NSB;
+    const int cmax = nlon < W - 1 ? nlon : W - 1;             // base squares: c < min(nlon, W-1)
 
     T lvl[NLEV];
 #pragma unroll
     for (int l = 0; l < NLEV; ++l) lvl[l] = wb_level_lo<T>(a.levels[l]);
 
     for (int g = blockIdx.x * 4 + wave; g < nwork; g += gridDim.x * 4) {     // work item = (time step, strip)
-        const int t = g / NS, s = g - t * NS;
+        const int t = g / NSB, s = g - t * NSB;
         const T* f = (const T*)a.field + (size_t)t * nlat * nlon;
         const int c0 = s * WB_STRIP + 4 * lane;
-        unsigned inmask = 0;                                  // bit k: square c0+k exists
+        unsigned inmask = 0, eligmask = 0;                    // bit k: square c0+k exists / also exists at c0+k+nlon
 #pragma unroll
-        for (int k = 0; k < 4; ++k) inmask |= (c0 + k < W - 1) ? (1u << k) : 0u;
+        for (int k = 0; k < 4; ++k) {
+            inmask |= (c0 + k < cmax) ? (1u << k) : 0u;
+            eligmask |= (c0 + k < a.padd - 1) ? (1u << k) : 0u;
+        }
         // column offsets inside a row; out-of-range lanes read a clamped (valid, ignored) address
         int cm = c0 >= nlon ? c0 - nlon : c0;
         if (cm > nlon - 4) cm = nlon - 4;
@@ -199,9 +227,9 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
         chs = chs >= nlon ? chs - nlon : chs;
         if (chs > nlon - 1) chs = nlon - 1;
         bool nanflag = false;
-        int cursor[NLEV];                                     // segments written so far, per level (wave-uniform)
+        int cursor[NLEV], ccursor[NLEV];                      // segments written so far (base list / copy list), wave-uniform
 #pragma unroll
-        for (int l = 0; l < NLEV; ++l) cursor[l] = 0;
+        for (int l = 0; l < NLEV; ++l) { cursor[l] = 0; ccursor[l] = 0; }
 
         // A row load = the lane's 4 columns (one vector load) + the first column of the next strip, which is the
         // halo of lane 63 only and wave-uniform, hence a SCALAR load (its own counter: the vector loads' vmcnt
@@ -239,9 +267,13 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
             for (int l = 0; l < NLEV; ++l) {
                 if (__any((hi > lvl[l]) && !(lo > lvl[l]))) {   // rare: this strip row carries a segment of level l
                     const size_t base = ((size_t)(t * NLEV + l) * NS + s) * a.cap_strip;
-                    cursor[l] += wb_scan_emit<T>(a.stg_k + base, (T*)a.stg_v + base * 4, cursor[l], a.cap_strip, W, r, c0, inmask,
-                                                 lvl[l], ltmask, lane, P.v[0], P.v[1], P.v[2], P.v[3], P.v[4], N.v[0], N.v[1],
-                                                 N.v[2], N.v[3], N.v[4]);
+                    const size_t cbase = ((size_t)(t * NLEV + l) * NS + NSB + s) * a.cap_strip;   // touched only if eligible
+                    const int w = wb_scan_emit<T>(a.stg_k + base, (T*)a.stg_v + base * 4, cursor[l], a.stg_k + cbase,
+                                                  (T*)a.stg_v + cbase * 4, ccursor[l], nlon, a.cap_strip, W, r, c0, inmask, eligmask,
+                                                  lvl[l], ltmask, P.v[0], P.v[1], P.v[2], P.v[3], P.v[4], N.v[0], N.v[1], N.v[2],
+                                                  N.v[3], N.v[4]);
+                    cursor[l] += w & 0xFFFF;
+                    ccursor[l] += w >> 16;
                 }
             }
         };
@@ -270,9 +302,12 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
 
         if (lane == 0) {
 #pragma unroll
-            for (int l = 0; l < NLEV; ++l) a.stg_n[(t * NLEV + l) * NS + s] = cursor[l];
+            for (int l = 0; l < NLEV; ++l) {
+                a.stg_n[(t * NLEV + l) * NS + s] = cursor[l];
+                if (NSB + s < NS) a.stg_n[(t * NLEV + l) * NS + NSB + s] = ccursor[l];
+            }
         }
-        if (__any(nanflag && (c0 < W)) && lane == 0) {
+        if (__any(nanflag && (c0 < nlon)) && lane == 0) {
 #pragma unroll
             for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
         }

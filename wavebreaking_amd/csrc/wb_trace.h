@@ -100,7 +100,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     uint32_t* t0 = a.w[8] + jb;
     WB_SHARED(uint32_t, ks, WB_TRACE_LDS_N);      // keys of all strips, strip after strip
     WB_SHARED(uint32_t, mk, WB_TRACE_LDS_N);      // merged keys
-    WB_SHARED(int, sbase, WB_MAX_STRIPS + 1);
+    WB_SHARED(int, sbase, WB_MAX_LISTS + 1);
 
     // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
     //          position in its own list plus the number of smaller keys in every other list
