@@ -340,9 +340,8 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     int* c_closed = a.c_closed + jb;
     int* c_nux = a.c_nux + jb;
     int* c_sumy = a.c_sumy + jb;
-    int hsize = 1024;              // raw points <= 2n; keys per point <= 2: load factor <= 0.5
-    while (hsize < 8 * n && hsize < a.hash_size) hsize <<= 1;
-    const int hmask = hsize - 1;
+    // the open-addressing table is sized per use to twice its number of keys (clearing it is real HBM traffic)
+    int hsize = 1024, hmask = 1023;
     // scratch roles in this kernel
     uint32_t* minidx = succ;       // per start segment: smallest member index
     uint32_t* cid_of = pred;       // per start segment: contour number (raster order of first segment)
@@ -390,6 +389,9 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     WB_END_PFOR
 
     // ---- P5: order-preserving first-occurrence dedupe inside each contour
+    hsize = 1024;                  // dedupe: one key per raw point
+    while (hsize < 2 * R && hsize < a.hash_size) hsize <<= 1;
+    hmask = hsize - 1;
     WB_PFOR(s, hsize)
         hkey[s] = WB_HEMPTY;
         hval[s] = WB_NIL;
@@ -453,6 +455,9 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
     int* setsize = (int*)jA;   // [Ck]
     int* dropped = (int*)jB;   // [Ck]
+    hsize = 1024;                  // sets: at most two keys per surviving point
+    while (hsize < 4 * (keep[R] + 1) && hsize < a.hash_size) hsize <<= 1;
+    hmask = hsize - 1;
     WB_PFOR(s, hsize)
         hkey[s] = WB_HEMPTY;
     WB_END_PFOR
