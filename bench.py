@@ -144,7 +144,7 @@ def main():
                        "nt_per_gpu": nt, "grid": [nlat, nlon], "levels": levels, "eps": a.eps,
                        "parallelism": "time-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(nt),
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
                          "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
             "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
@@ -157,6 +157,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(nt):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC pass (profiles/r01_hbm_traffic_pmc.txt: FETCH_SIZE x 2,
+    the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE), scaled to this run's batch; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.txt")
+    try:
+        for line in open(path):
+            if "wb_k_scan" in line:
+                f = line.split()
+                fetch_kb, write_kb = float(f[-3]), float(f[-1])
+                return (2.0 * fetch_kb + write_kb) * 1024.0 * nt / 1460.0
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
