@@ -1024,7 +1024,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         WbPropsArgs pa;
         memset(&pa, 0, sizeof(pa));
         const double r = ((p.dlon + p.dlat) / 2.0) / 2.0;     // index_utils.py:48-50
-        pa.nev = NE; pa.nslots = NE < 2048 ? NE : 2048; /* one wave per event slot */ pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
+        pa.nev = NE; pa.nslots = NE < 4096 ? NE : 4096; /* one wave per event slot; 4 waves per SIMD in flight */ pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
         pa.nlev = p.nlevels; pa.dtype = p.dtype; pa.want_cells = p.want_cells; pa.pad = (int)ceil(r); pa.r2 = r * r;
         pa.ev = d_ev; pa.c_off = b->c_off; pa.c_len = b->c_len; pa.cpts = b->cpts; pa.data = b->d_field;
         pa.intensity = b->d_intensity; pa.wlat = b->d_wlat; pa.job_step = b->d_job_step;
