@@ -396,7 +396,10 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
         hkey[s] = WB_HEMPTY;
         hval[s] = WB_NIL;
     WB_END_PFOR
+    // A point equal to its predecessor in the same contour can never be a first occurrence: it is dropped without
+    // touching the table (about half of all raw points: neighbouring crossings that round to the same lattice point)
     WB_PFOR(p, R)
+        if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
         int fresh;
         const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
         const int s = wb_hash_insert(hkey, hmask, key, &fresh);
@@ -405,7 +408,7 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     WB_END_PFOR
     WB_PFOR(p, R + 1)
         int kp = 0;
-        if (p < R) {
+        if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
             const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
             const int s = wb_hash_find(hkey, hmask, key);
             kp = (s >= 0 && hval[s] == (uint32_t)p) ? 1 : 0;
