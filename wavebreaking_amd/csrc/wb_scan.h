@@ -1,26 +1,28 @@
 // wb_scan.h -- kernel 1: marching-squares scan of the field (THE HBM-bound kernel).
 //
-// Work decomposition: the extended row of W-1 squares is cut into strips of 256 squares; ONE WAVE
-// streams one strip of one time step top to bottom, for all contour levels at once, with no LDS and
-// no barrier (persistent waves loop over (time step, strip) work items).  A lane owns 4 consecutive
-// squares per row (one float4 / double4 load, 1 KiB per wave-load, each field value loaded from HBM once).  The
-// periodic columns nlon..W-1 of contour_index.py:94-100 are never read again: a square in the first padd-1 base
-// columns is emitted twice, at c and at c + nlon (the second copy goes to the strip's "periodic copy" list).  The previous row stays in
-// registers together with its horizontal pair-wise min/max, so a square costs two min, two max and two
-// compares per level:
+// Work decomposition: the nlon base columns are cut into strips of 256 squares; ONE WAVE streams one strip
+// of one time step top to bottom, for all contour levels at once, with no LDS and no barrier (persistent
+// waves loop over (time step, strip) work items).  A lane owns 4 consecutive squares per row: one float4 /
+// double4 load (1 KiB per wave-load), right halo from the next lane by a DPP wave shift, six row buffers
+// that rotate by name so that four row loads are always in flight.  Every field value is loaded from HBM
+// once; the periodic columns nlon..W-1 of contour_index.py:94-100 are never read: a square of the first
+// padd-1 base columns is emitted twice, at c and at c + nlon (second copy -> the strip's "periodic copy" list).
 //
-//     crossing in the square  <=>  max(corners) > lvl  and not  min(corners) > lvl
+// Classification per lane and row: the lane's 2 x 5 patch of values is connected, so it contains a crossing
+// of lvl iff  min(patch) <= lvl < max(patch), i.e.
 //
-// evaluated in the field's own precision against  lvl_lo = largest T <= level.  That is EXACT, not a
-// conservative filter: for a T-valued v, (double)v > level  <=>  v > lvl_lo, which is skimage's strict
-// `>` on the float64 copy (contour_index.py:103).  Only when some lane of the wave sees a crossing does
-// the wave take the emit path: per-square case, ballots for raster-order offsets inside the strip; the
-// segment's key and corner values are stored (the f64 crossing coordinate c0 + (lvl - v0)/(v1 - v0) and
-// its round-half-even, contour_index.py:111, are evaluated when the trace kernel merges the strips).
-// Squares with a NaN corner are skipped like skimage does.
+//     max(patch) > lvl_lo  and not  min(patch) > lvl_lo ,     lvl_lo = largest T <= level,
 //
-// Output: per (job, strip) a list of segments in raster order (key, from point, to point); the trace
-// kernel merges the <= 16 sorted strip lists of a job by rank (wb_trace.h, P0).
+// evaluated in the field's own precision.  That is EXACT, not a conservative filter: for a T-valued v,
+// (double)v > level  <=>  v > lvl_lo, which is skimage's strict `>` on the float64 copy
+// (contour_index.py:103).  Only when some lane of the wave sees a crossing does the wave take the emit path:
+// per-square case, ballots for raster-order offsets inside the strip; the segment's key and the four corner
+// values are stored (the f64 crossing coordinate c0 + (lvl - v0)/(v1 - v0) and its round-half-even,
+// contour_index.py:111, are evaluated when the trace kernel merges the strips).  Squares with a NaN corner
+// are skipped like skimage does.
+//
+// Output: per (job, list) segments in raster order (key + corner values); the trace kernel merges the
+// <= 32 sorted lists of a job by rank (wb_trace.h, link kernel).
 //
 // Algorithmic HBM traffic: nlat*nlon*sizeof(T) per time step (+ 4+4*sizeof(T) B per segment, < 1 %).
 #pragma once
