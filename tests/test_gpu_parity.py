@@ -92,3 +92,28 @@ def test_device_generator_and_batch_invariance(ctx):
         m = bigc["step"] == t
         assert np.array_equal(bigc["npts"][m], got["contours"]["npts"])
     ctx.free(d)
+
+
+def test_very_rough_field_takes_the_big_job_paths(ctx):
+    # > 8192 segments per (step, level): 32-bit list ranking in global memory, hundreds of small contours
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(3, 1, lat, lon, eps=1.2)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2.0], intensity=pv)
+    assert len(ref["contours"]) > 100
+
+
+def test_python_surface_with_time_chunking(ctx, monkeypatch):
+    import wavebreaking_amd as wb
+    from oracle import api as oapi
+    from wavebreaking_amd import engine
+    engine._contexts.clear()
+    monkeypatch.setenv("WB_MAX_STEPS_PER_BATCH", "2")
+    lat, lon = synth.grid(1.0)
+    tm = synth.times(5, start="1959-06-01T00")
+    pv = synth.pv_field(0, 5, lat, lon, eps=0.2)
+    data = wb.GridField(pv, ("time", "lat", "lon"), {"time": tm, "lat": lat, "lon": lon})
+    ref = oapi.run_all(pv, [-2, 2], lat, lon, tm)
+    s = wb.calculate_streamers(data, [-2, 2])
+    assert len(s) == len(ref["streamers"])
+    for (_, row), r in zip(s.iterrows(), ref["streamers"]):
+        assert np.datetime64(row["date"]) == r["date"] and row["level"] == r["level"] and row["event_area"] == r["event_area"]

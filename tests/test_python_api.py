@@ -177,3 +177,24 @@ def test_product_refuses_to_run_without_the_hip_library(monkeypatch, tmp_path):
         _hip.default_library()
     with pytest.raises(RuntimeError, match="refusing"):
         _hip.Library(helpers.build_hostsim())          # a host-simulation build is never accepted as the product
+
+
+def test_time_and_level_chunking_keep_the_frame_order(hostsim_engine, monkeypatch):
+    # 5 levels (> 4 per ABI pass) and 2 steps per batch: rows must still come time-major, level-minor and the
+    # contour selection must use the maximum over ALL batches
+    data, pv, lat, lon, tm = _field(nt=3, dlon=2.5, eps=0.2)
+    levels = [-2, 2, 1.5, -1.5, 2.5]
+    ref = oapi.run_all(pv, levels, lat, lon, tm)
+    one = wb.calculate_overturnings(data, levels)
+    monkeypatch.setenv("WB_MAX_STEPS_PER_BATCH", "2")
+    two = wb.calculate_overturnings(data, levels)
+    cols = ["date", "level", "com", "mean_var", "intensity", "event_area", "orientation", "geometry"]
+    _check_events(one, ref["overturnings"], cols)
+    _check_events(two, ref["overturnings"], cols)
+    c = wb.calculate_contours(data, levels, original_coordinates=False)
+    assert len(c) == len(ref["contours"])
+    for (_, row), r in zip(c.iterrows(), ref["contours"]):
+        assert row.level == r["level"] and np.datetime64(row.date) == r["date"]
+        assert np.array_equal(np.asarray(row.geometry.coords), r["geometry"])
+    s = wb.calculate_streamers(data, levels)
+    _check_events(s, ref["streamers"], cols[:6] + ["geometry"])

@@ -47,15 +47,27 @@ class Prepared:
         self.dlon, self.dlat = float(kwargs["dlon"]), float(kwargs["dlat"])
 
 
+def max_steps_per_batch():
+    """Time steps resident per ABI batch (device scratch grows with it: ~15 MB per step and level at 0.25 degree)."""
+    return max(1, int(os.environ.get("WB_MAX_STEPS_PER_BATCH", 1460)))
+
+
 def contour_batches(prep, levels, periodic_add, params, want_cells=False):
-    """[(batch, level positions)]: one ABI batch per group of <= 4 levels."""
+    """[(batch, level positions, first time step)]: one ABI batch per block of time steps and group of <= 4 levels.
+    All batches stay alive until the caller has the maximum of ``max_nux`` over them (the reference selects contours
+    with ``exp_lon == exp_lon.max()`` over the WHOLE frame, streamer_index.py:106)."""
     ctx = get_context()
     out = []
-    for lo in range(0, len(levels), MAX_LEVELS):
-        pos = list(range(lo, min(lo + MAX_LEVELS, len(levels))))
-        b = ctx.contours(prep.values, prep.lat, prep.lon, [float(levels[i]) for i in pos], prep.dlon, prep.dlat,
-                         periodic_add=periodic_add, intensity=prep.intensity, want_cells=want_cells, **params)
-        out.append((b, pos))
+    nt = prep.values.shape[0]
+    chunk = max_steps_per_batch()
+    for t0 in range(0, nt, chunk):
+        t1 = min(nt, t0 + chunk)
+        inten = None if prep.intensity is None else prep.intensity[t0:t1]
+        for lo in range(0, len(levels), MAX_LEVELS):
+            pos = list(range(lo, min(lo + MAX_LEVELS, len(levels))))
+            b = ctx.contours(prep.values[t0:t1], prep.lat, prep.lon, [float(levels[i]) for i in pos], prep.dlon, prep.dlat,
+                             periodic_add=periodic_add, intensity=inten, want_cells=want_cells, **params)
+            out.append((b, pos, t0))
     return out
 
 

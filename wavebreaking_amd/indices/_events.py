@@ -19,7 +19,7 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
         batches, levels = state["batches"], state["levels"]          # contours computed by the decorator: reuse
     else:
         if state is not None:
-            for b, _ in state["batches"]:
+            for b, *_ in state["batches"]:
                 b.close()
         levels = engine.as_levels(contour_levels)
         if state is not None and contours is kwargs.get("contours"):
@@ -30,29 +30,29 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
             b = ctx.batch_from_contours(table, prep.values, prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
                                         prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=prep.intensity,
                                         **params)
-            batches = [(b, None)]
-    g = max(b.max_nux() for b, _ in batches) if batches else 0          # contours.exp_lon.max(), streamer_index.py:106
+            batches = [(b, None, 0)]
+    g = max(b.max_nux() for b, *_ in batches) if batches else 0          # contours.exp_lon.max(), streamer_index.py:106
     if global_max is not None:
         g = max(g, int(global_max))
     which = {_hip.STREAMERS: dict(streamers=True, overturnings=False, cutoffs=False),
              _hip.OVERTURNINGS: dict(streamers=False, overturnings=True, cutoffs=False),
              _hip.CUTOFFS: dict(streamers=False, overturnings=False, cutoffs=True)}[kind]
     rows = []
-    for bi, (b, pos) in enumerate(batches):
+    batches = list(batches)
+    for bi, (b, pos, t0) in enumerate(batches):
         b.indices(g, **which)
         ev = b.events(kind)
-        ct = None
         for k in range(ev["step"].size):
             lvl = ev["level_idx"][k]
-            rows.append((int(ev["step"][k]) if pos is not None else k, pos[int(lvl)] if pos is not None else int(lvl), bi, k))
-        batches[bi] = (b, pos, ev, ct)
+            rows.append((int(ev["step"][k]) + t0 if pos is not None else k, pos[int(lvl)] if pos is not None else int(lvl), bi, k))
+        batches[bi] = (b, pos, ev, t0)
     if len(batches) > 1:
-        rows.sort(key=lambda r: (r[0], r[1]))
+        rows.sort(key=lambda r: (r[0], r[1]))          # stable: time-major, level-minor, event order inside kept
     cols = dict(date=[], level=[])
     polys, sums, orient = [], [], []
     for _, lpos, bi, k in rows:
-        b, pos, ev, ct = batches[bi]
-        cols["date"].append(prep.times[int(ev["step"][k])])
+        b, pos, ev, t0 = batches[bi]
+        cols["date"].append(prep.times[int(ev["step"][k]) + t0])
         cols["level"].append(levels[lpos])
         a, e = int(ev["poly_offset"][k]), int(ev["poly_offset"][k + 1])
         polys.append(np.c_[ev["poly_x"][a:e], ev["poly_y"][a:e]])        # streamer_index.py:269-272 / box / cutoff_index.py:96

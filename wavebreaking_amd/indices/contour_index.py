@@ -14,11 +14,11 @@ logger = logging.getLogger(__name__)
 
 
 def _contour_frame(tables, prep, levels, original_coordinates):
-    """tables: [(contour table, level positions)] -> frame in the reference's order (time, level, contour)."""
+    """tables: [(contour table, level positions, first time step)] -> frame in the reference's order (time, level, contour)."""
     rows = []
-    for ti, (ct, pos) in enumerate(tables):
+    for ti, (ct, pos, t0) in enumerate(tables):
         for k in range(ct["step"].size):
-            rows.append((int(ct["step"][k]), pos[int(ct["level_idx"][k])], ti, k))
+            rows.append((int(ct["step"][k]) + t0, pos[int(ct["level_idx"][k])], ti, k))
     rows.sort(key=lambda r: (r[0], r[1]))          # stable: contour order inside a (step, level) is kept
     cols = dict(date=[], level=[], closed=[], exp_lon=[], mean_lat=[])
     geoms = []
@@ -56,12 +56,12 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     prep = engine.Prepared(data, None, kwargs)
     levels = engine.as_levels(contour_levels)
     batches = engine.contour_batches(prep, levels, periodic_add, {})
-    tables = [(b.contour_table(), pos) for b, pos in batches]
+    tables = [(b.contour_table(), pos, t0) for b, pos, t0 in batches]
     frame = _contour_frame(tables, prep, levels, original_coordinates)
     if keep is not None:
         keep.update(batches=batches, prep=prep, levels=levels, nrows=len(frame))
     else:
-        for b, _ in batches:
+        for b, *_ in batches:
             b.close()
     return frame
 
