@@ -41,6 +41,8 @@ struct wb_ctx {
     std::multimap<size_t, void*> hpool;
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
+    hipEvent_t fork = nullptr;
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
     // (measured: 0.7 ms for the first pass's ~40 allocations, 350 ms for every later pass), so blocks are
     // kept for the life of the context and handed out again by size
@@ -330,7 +332,9 @@ int wb_create(int device_id, wb_ctx** out) {
         delete c;
         return 1;
     }
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return 1;
     }
@@ -348,6 +352,8 @@ void wb_destroy(wb_ctx* c) {
     for (auto& kv : c->live) (void)hipFree(kv.first);
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->fork) (void)hipEventDestroy(c->fork);
 #endif
     delete c;
 }
@@ -1037,6 +1043,49 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         if (!pa.ev_cell_off) return 1;
         dmemset(ctx, pa.cell_count, 0, sizeof(unsigned long long));
         unsigned long long cell_cap = p.want_cells ? (unsigned long long)NE * 4096ull : 0ull;
+        // descriptors + polygon vertices go back on the side stream while the property kernel runs on the main one
+        bool polys_done = false;
+        auto fetch_polys = [&]() -> int {
+            if (polys_done) return 0;
+            polys_done = true;
+#if !defined(WB_HOSTSIM)
+            (void)hipEventRecord(ctx->fork, ctx->stream);            // descriptors are complete here
+            (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
+            std::swap(ctx->stream, ctx->stream2);
+#endif
+            b->timer.begin(ctx, "polygons_d2h");
+            int rc = [&]() -> int {
+        d2h(ctx, h_ev.data(), d_ev, (size_t)NE * 8 * sizeof(int));
+                // polygon vertices of all events in one packed transfer
+                for (int e = 0; e < NE; ++e) {
+                    const int* d = &h_ev[(size_t)e * 8];
+                    h_poff[e + 1] = h_poff[e] + (d[0] == WB_EV_OVERTURNING ? 4 : d[4] - d[3] + 1);
+                }
+                {
+                    long long* d_poff = (long long*)talloc((NE + 1) * sizeof(long long));
+                    int* d_px = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
+                    int* d_py = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
+                    if (!d_py) return 1;
+                    h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
+                    WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_px, d_py);
+                    b->poly_n = (size_t)h_poff[NE];
+                    b->poly_bytes = (b->poly_n + 1) * sizeof(int32_t);
+                    b->poly_x = (int32_t*)hmalloc(ctx, b->poly_bytes);
+                    b->poly_y = (int32_t*)hmalloc(ctx, b->poly_bytes);
+                    if (!b->poly_x || !b->poly_y) return wb_fail(ctx, "out of host memory");
+                    if (b->poly_n) {
+                        d2h(ctx, b->poly_x, d_px, b->poly_n * sizeof(int));
+                        d2h(ctx, b->poly_y, d_py, b->poly_n * sizeof(int));
+                    }
+                }
+                return 0;
+            }();
+            b->timer.end(ctx);
+#if !defined(WB_HOSTSIM)
+            std::swap(ctx->stream, ctx->stream2);
+#endif
+            return rc;
+        };
         for (int attempt = 0; attempt < 2; ++attempt) {
             pa.cell_cap = cell_cap;
             pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
@@ -1045,6 +1094,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "props");
             WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
             b->timer.end(ctx);
+            if (fetch_polys()) return 1;
             unsigned long long used = 0;
             d2h(ctx, &used, pa.cell_count, sizeof(used));
             if (!p.want_cells || used <= cell_cap) { h_cells.resize((size_t)used); break; }
@@ -1052,29 +1102,6 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.drop_last();
         }
         b->timer.begin(ctx, "events_d2h");
-        d2h(ctx, h_ev.data(), d_ev, (size_t)NE * 8 * sizeof(int));
-        // polygon vertices of all events in one packed transfer
-        for (int e = 0; e < NE; ++e) {
-            const int* d = &h_ev[(size_t)e * 8];
-            h_poff[e + 1] = h_poff[e] + (d[0] == WB_EV_OVERTURNING ? 4 : d[4] - d[3] + 1);
-        }
-        {
-            long long* d_poff = (long long*)talloc((NE + 1) * sizeof(long long));
-            int* d_px = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
-            int* d_py = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
-            if (!d_py) return 1;
-            h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
-            WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_px, d_py);
-            b->poly_n = (size_t)h_poff[NE];
-            b->poly_bytes = (b->poly_n + 1) * sizeof(int32_t);
-            b->poly_x = (int32_t*)hmalloc(ctx, b->poly_bytes);
-            b->poly_y = (int32_t*)hmalloc(ctx, b->poly_bytes);
-            if (!b->poly_x || !b->poly_y) return wb_fail(ctx, "out of host memory");
-            if (b->poly_n) {
-                d2h(ctx, b->poly_x, d_px, b->poly_n * sizeof(int));
-                d2h(ctx, b->poly_y, d_py, b->poly_n * sizeof(int));
-            }
-        }
         d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
         d2h(ctx, h_nc.data(), pa.ev_ncells, (size_t)NE * sizeof(int));
         if (p.want_cells) {
