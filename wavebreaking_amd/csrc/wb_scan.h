@@ -165,6 +165,7 @@ __device__ __forceinline__ int wb_scan_emit(uint32_t* stg_k, T* stg_v, int off, 
                                             T n4) {
     const T p[5] = {p0, p1, p2, p3, p4}, n[5] = {n0, n1, n2, n3, n4};
     int cs[4], ns[4], below = 0, total = 0, cbelow = 0, ctotal = 0;
+    const bool any_elig = __any(eligmask != 0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const T ul = p[k], ur = p[k + 1], ll = n[k], lr = n[k + 1];
@@ -175,10 +176,12 @@ __device__ __forceinline__ int wb_scan_emit(uint32_t* stg_k, T* stg_v, int off, 
         const unsigned long long m1 = __ballot(ns[k] >= 1), m2 = __ballot(ns[k] == 2);
         below += __popcll(m1 & ltmask) + __popcll(m2 & ltmask);
         total += __popcll(m1) + __popcll(m2);
-        const bool el = (eligmask >> k) & 1u;
-        const unsigned long long c1 = __ballot(ns[k] >= 1 && el), c2 = __ballot(ns[k] == 2 && el);
-        cbelow += __popcll(c1 & ltmask) + __popcll(c2 & ltmask);
-        ctotal += __popcll(c1) + __popcll(c2);
+        if (any_elig) {                                    // wave-uniform: only the first strips have periodic copies
+            const bool el = (eligmask >> k) & 1u;
+            const unsigned long long c1 = __ballot(ns[k] >= 1 && el), c2 = __ballot(ns[k] == 2 && el);
+            cbelow += __popcll(c1 & ltmask) + __popcll(c2 & ltmask);
+            ctotal += __popcll(c1) + __popcll(c2);
+        }
     }
     if (total == 0) return 0;
     int mine = off + below, cmine = coff + cbelow;
