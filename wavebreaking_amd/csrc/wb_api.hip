@@ -453,6 +453,7 @@ static int run_phase1(wb_batch* b) {
         int ncu = 256;
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount; }
         if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
+        if (const char* e = getenv("WB_SCAN_WGS")) { const long long v = atoll(e); if (v > 0) nwg = v; }
         const dim3 grid((unsigned)nwg);
 #define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan<T, V, N>), grid, block, 0, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
