@@ -131,6 +131,24 @@ int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, i
                   const double* lat, const double* lon, const double* wave_params /* [7][5] */, double eps,
                   uint64_t seed);
 
+/* ---- pre-processing next to the hot path ------------------------------------------
+   calculate_smoothed_field (processing/spatial.py:60-128): per time step `passes` times
+   scipy.ndimage.convolve(temp, weights, mode) / np.sum(weights) (spatial.py:101), then the rows
+   arange(-b, b), b = int(kh / 2 + 0.5), are NaN (spatial.py:104-107).  field: (nt, nlat, nlon) float32 (dtype 0) or
+   float64 (1), host or device (on_device); weights: kh x kw row-major, 1..7 each; wsum = np.sum(weights) as the
+   caller's numpy evaluates it; mode: 0 reflect, 1 constant (cval 0), 2 nearest, 3 mirror, 4 wrap; out: float64
+   (nt, nlat, nlon) (numpy >= 2 promotion of float32 / int64), host or device; flags bit 0 = one launch per pass
+   even where the fused kernel applies, bit 1 = always the hardware division (parity tests). */
+int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on_device, int64_t nt, int nlat, int nlon, int passes,
+                    const double* weights, int kh, int kw, double wsum, int mode, double* out, int out_on_device,
+                    int flags);
+/* calculate_momentum_flux (processing/spatial.py:27-57): (u - u.mean(lon)) * (v - v.mean(lon)) in u's dtype, the
+   zonal mean being numpy's nanmean (pairwise row sum in the array dtype).  u, v, out: (nt, nlat, nlon). */
+int wb_momentum_flux(wb_ctx* ctx, const void* u, const void* v, int dtype, int on_device, int64_t nt, int nlat, int nlon,
+                     void* out, int out_on_device);
+/* device time (HIP events on the context's stream) of the kernels of the last wb_smooth_field / wb_momentum_flux */
+float wb_last_op_ms(wb_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

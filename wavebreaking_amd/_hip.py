@@ -94,6 +94,13 @@ class Library:
         lib.wb_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                       C.c_uint64]
+        dp = C.POINTER(C.c_double)
+        lib.wb_smooth_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, dp,
+                                        C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        lib.wb_momentum_flux.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_int]
+        lib.wb_last_op_ms.argtypes = [C.c_void_p]
+        lib.wb_last_op_ms.restype = C.c_float
 
 
 _default = None
@@ -165,6 +172,76 @@ class Context:
                                       wp.ctypes.data_as(dp), float(eps), int(seed))
         if rc != 0:
             raise RuntimeError("wb_synth_fill failed: " + self.error())
+
+    # -- pre-processing (processing/spatial.py)
+    SMOOTH_MODES = {"reflect": 0, "grid-mirror": 0, "constant": 1, "grid-constant": 1, "nearest": 2, "mirror": 3,
+                    "wrap": 4, "grid-wrap": 4}
+
+    def smooth_field(self, field, passes, weights, mode="wrap", device_shape=None, device_dtype=None, out_device=None,
+                     per_pass=False):
+        """``passes`` x (scipy.ndimage.convolve / np.sum(weights)) per time step + NaN border rows -> float64 cube.
+        ``field``: numpy (time, lat, lon) array or, with device_shape/device_dtype, a device pointer;
+        ``out_device``: device pointer of a float64 cube to fill instead of returning a numpy array."""
+        if mode not in self.SMOOTH_MODES:
+            raise RuntimeError("wb_smooth_field: unknown boundary mode %r" % (mode,))
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if w.ndim != 2:
+            raise RuntimeError("wb_smooth_field: weights must be two-dimensional")
+        wsum = float(np.sum(weights))
+        if device_shape is not None:
+            nt, nlat, nlon = device_shape
+            dt = np.dtype(device_dtype)
+            src, on_dev = C.c_void_p(int(field)), 1
+        else:
+            field = np.ascontiguousarray(field)
+            if field.dtype not in (np.float32, np.float64):
+                field = field.astype(np.float64)
+            nt, nlat, nlon = field.shape
+            dt = field.dtype
+            src, on_dev = field.ctypes.data_as(C.c_void_p), 0
+        out = None
+        if out_device is None:
+            out = np.empty((nt, nlat, nlon), dtype=np.float64)
+            dst, out_dev = out.ctypes.data_as(C.c_void_p), 0
+        else:
+            dst, out_dev = C.c_void_p(int(out_device)), 1
+        rc = self.L.lib.wb_smooth_field(self.h, src, 0 if dt == np.float32 else 1, on_dev, int(nt), int(nlat), int(nlon),
+                                        int(passes), w.ctypes.data_as(C.POINTER(C.c_double)), w.shape[0], w.shape[1], wsum,
+                                        self.SMOOTH_MODES[mode], dst, out_dev, 1 if per_pass else 0)
+        if rc != 0:
+            raise RuntimeError("wb_smooth_field failed: " + self.error())
+        return out
+
+    def momentum_flux(self, u, v, device_shape=None, device_dtype=None, out_device=None):
+        """(u - nanmean_lon u) * (v - nanmean_lon v) in u's dtype."""
+        if device_shape is not None:
+            nt, nlat, nlon = device_shape
+            dt = np.dtype(device_dtype)
+            pu, pv, on_dev = C.c_void_p(int(u)), C.c_void_p(int(v)), 1
+        else:
+            u = np.ascontiguousarray(u)
+            if u.dtype not in (np.float32, np.float64):
+                u = u.astype(np.float64)
+            v = np.ascontiguousarray(v, dtype=u.dtype)
+            if u.shape != v.shape or u.ndim != 3:
+                raise RuntimeError("wb_momentum_flux: u and v must be (time, lat, lon) cubes of one shape")
+            nt, nlat, nlon = u.shape
+            dt = u.dtype
+            pu, pv, on_dev = u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), 0
+        out = None
+        if out_device is None:
+            out = np.empty((nt, nlat, nlon), dtype=dt)
+            dst, out_dev = out.ctypes.data_as(C.c_void_p), 0
+        else:
+            dst, out_dev = C.c_void_p(int(out_device)), 1
+        rc = self.L.lib.wb_momentum_flux(self.h, pu, pv, 0 if dt == np.float32 else 1, on_dev, int(nt), int(nlat), int(nlon),
+                                         dst, out_dev)
+        if rc != 0:
+            raise RuntimeError("wb_momentum_flux failed: " + self.error())
+        return out
+
+    def last_op_ms(self):
+        return float(self.L.lib.wb_last_op_ms(self.h))
 
     # -- the hot path
     def _params(self, field, lat, lon, levels, dlon, dlat, periodic_add, intensity, geo_dis, cont_dis, range_group,

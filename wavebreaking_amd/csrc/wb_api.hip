@@ -39,6 +39,7 @@ struct wb_ctx {
     // host buffers of the big result arrays are recycled between batches: a fresh 10 MB vector costs ~1 ms of page
     // faults and zero-fill per pass
     std::multimap<size_t, void*> hpool;
+    float last_op_ms = 0.f;
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
@@ -1344,3 +1345,183 @@ extern "C" int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0
     dfree(ctx, d_lon);
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------------ pre-processing
+#include "wb_spatial.h"
+#include <float.h>
+
+#if !defined(WB_HOSTSIM)
+struct WbOpTimer {
+    wb_ctx* c; hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit WbOpTimer(wb_ctx* ctx) : c(ctx) {
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, c->stream);
+    }
+    void stop() {
+        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        c->last_op_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+};
+template <typename T, bool CAST, bool UNIT4, bool FAST>
+static void wb_launch_smooth_plus2(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
+    const long long waves = a.nt * a.nstrips;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    switch (P) {
+#define WB_SP_CASE(N) \
+    case N: hipLaunchKernelGGL((wb_k_smooth_plus<T, N, CAST, UNIT4, FAST>), grid, block, 0, ctx->stream, a); break;
+        WB_SP_CASE(1) WB_SP_CASE(2) WB_SP_CASE(3) WB_SP_CASE(4) WB_SP_CASE(5) WB_SP_CASE(6) WB_SP_CASE(7) WB_SP_CASE(8)
+#undef WB_SP_CASE
+    }
+}
+template <typename T, bool CAST>
+static void wb_launch_smooth_plus(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
+    // the default weights (outer taps 1, integer sum) get the specialised instance, anything else the general one
+    if (a.unit4 && a.fastdiv) wb_launch_smooth_plus2<T, CAST, true, true>(ctx, P, a);
+    else wb_launch_smooth_plus2<T, CAST, false, false>(ctx, P, a);
+}
+#else
+struct WbOpTimer { explicit WbOpTimer(wb_ctx*) {} void stop() {} };
+#endif
+#define WB_SP_MAXFUSE 8
+
+extern "C" float wb_last_op_ms(wb_ctx* ctx) { return ctx ? ctx->last_op_ms : 0.f; }
+
+extern "C" int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on_device, int64_t nt, int nlat, int nlon,
+                               int passes, const double* weights, int kh, int kw, double wsum, int mode, double* out,
+                               int out_on_device, int flags) {
+    if (!ctx) return 1;
+    if (!field || !out || !weights || nt < 0 || nlat < 1 || nlon < 1 || passes < 1 || kh < 1 || kw < 1 || kh > 7 || kw > 7 ||
+        mode < 0 || mode > 4 || (dtype != 0 && dtype != 1)) {
+        ctx->err = "wb_smooth_field: bad argument (passes >= 1, weights 1..7 x 1..7, mode 0..4, dtype 0/1)";
+        return 1;
+    }
+    const int b = (int)(kh / 2.0 + 0.5);                       // spatial.py:105
+    if (b > nlat) { ctx->err = "wb_smooth_field: border rows exceed the latitude axis"; return 1; }
+    if (nt == 0) return 0;
+    const size_t ncell = (size_t)nt * nlat * nlon, esz = dtype == 0 ? 4 : 8;
+    WbSmoothArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nt = nt; a.nlat = nlat; a.nlon = nlon; a.mode = mode; a.wsum = wsum;
+    // scipy _correlate_or_convolve(convolution=True): flipped kernel, origin -origin (-1 for even sizes)
+    const int ch = kh / 2 - ((kh & 1) ? 0 : 1), cw = kw / 2 - ((kw & 1) ? 0 : 1);
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) {
+            const double w = weights[(kh - 1 - i) * kw + (kw - 1 - j)];
+            if (!(fabs(w) > DBL_EPSILON)) continue;             // ni_filters.c: only taps with |w| > eps take part
+            a.tr[a.ntap] = i - ch; a.tc[a.ntap] = j - cw; a.tw[a.ntap] = w; ++a.ntap;
+        }
+    {   // wb_sm_div's short sequence needs wsum = k * 2^j with an odd integer |k| < 2^26 and a moderate exponent
+        int ex = 0;
+        const double m = frexp(wsum, &ex);
+        const double k26 = ldexp(m, 26);
+        a.fastdiv = (wsum == wsum && wsum != 0.0 && fabs(wsum) < 1e300 && k26 == floor(k26) && ex > -60 && ex < 60) ? 1 : 0;
+        a.rsum = 1.0 / wsum;
+        if (flags & 2) a.fastdiv = 0;
+    }
+    bool plus = false;
+#if !defined(WB_HOSTSIM)
+    if (kh == 3 && kw == 3 && mode == WB_SM_WRAP && !(flags & 1)) {
+        auto F = [&](int i, int j) { return weights[(2 - i) * 3 + (2 - j)]; };
+        auto zero = [&](double w) { return !(fabs(w) > DBL_EPSILON); };
+        if (zero(F(0, 0)) && zero(F(0, 2)) && zero(F(2, 0)) && zero(F(2, 2))) {
+            plus = true;
+            const double pw[5] = {F(0, 1), F(1, 0), F(1, 1), F(1, 2), F(2, 1)};
+            for (int k = 0; k < 5; ++k) { a.pw[k] = pw[k]; a.puse[k] = zero(pw[k]) ? 0 : 1; }
+            a.unit4 = (pw[0] == 1.0 && pw[1] == 1.0 && pw[3] == 1.0 && pw[4] == 1.0) ? 1 : 0;
+        }
+    }
+#endif
+    (void)flags;
+    // device buffers: input copy (host input), output (host output), one float64 scratch cube when several launches chain
+    const int nlaunch = plus ? (passes + WB_SP_MAXFUSE - 1) / WB_SP_MAXFUSE : passes;
+    const void* d_in = field;
+    void* d_in_own = nullptr;
+    if (!on_device) {
+        d_in_own = dmalloc(ctx, ncell * esz);
+        if (!d_in_own) return 1;
+        h2d(ctx, d_in_own, field, ncell * esz);
+        d_in = d_in_own;
+    }
+    double* d_out = out_on_device ? out : (double*)dmalloc(ctx, ncell * 8);
+    double* d_tmp = nlaunch > 1 ? (double*)dmalloc(ctx, ncell * 8) : nullptr;
+    if (!d_out || (nlaunch > 1 && !d_tmp)) { ctx->err = "wb_smooth_field: out of device memory"; return 1; }
+    WbOpTimer timer(ctx);
+    const void* src = d_in;
+    int done = 0;
+    for (int l = 0; l < nlaunch; ++l) {
+        const int P = plus ? ((passes - done) < WB_SP_MAXFUSE ? (passes - done) : WB_SP_MAXFUSE) : 1;
+        double* dst = ((nlaunch - 1 - l) & 1) ? d_tmp : d_out;          // the last launch lands in d_out
+        a.in = src; a.out = dst;
+        a.in_f32 = (l == 0 && dtype == 0) ? 1 : 0;
+        a.cast_f32 = a.in_f32;
+        a.nan_rows = (l == nlaunch - 1) ? b : 0;
+        if (plus) {
+#if !defined(WB_HOSTSIM)
+            a.halo = P + (P & 1);
+            a.strip_w = 128 - 2 * a.halo;
+            a.nstrips = (nlon + a.strip_w - 1) / a.strip_w;
+            a.vec = ((nlon & 1) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) ? 1 : 0;
+            if (a.in_f32) wb_launch_smooth_plus<float, true>(ctx, P, a);
+            else wb_launch_smooth_plus<double, false>(ctx, P, a);
+#endif
+        } else {
+            const long long nchunk = ((long long)ncell + WB_SM_CHUNK - 1) / WB_SM_CHUNK;
+            WB_LAUNCH(wb_k_smooth_pass, nchunk < 8192 ? nchunk : 8192, 256, a);
+        }
+        src = dst;
+        done += P;
+    }
+    timer.stop();
+    int rc = 0;
+    if (!out_on_device) { rc = d2h(ctx, out, d_out, ncell * 8); dfree(ctx, d_out); }
+    else rc = dsync(ctx);
+    if (d_tmp) dfree(ctx, d_tmp);
+    if (d_in_own) dfree(ctx, d_in_own);
+    return rc;
+}
+
+extern "C" int wb_momentum_flux(wb_ctx* ctx, const void* u, const void* v, int dtype, int on_device, int64_t nt, int nlat,
+                                int nlon, void* out, int out_on_device) {
+    if (!ctx) return 1;
+    if (!u || !v || !out || nt < 0 || nlat < 1 || nlon < 1 || (dtype != 0 && dtype != 1)) {
+        ctx->err = "wb_momentum_flux: bad argument";
+        return 1;
+    }
+    if (nt == 0) return 0;
+    WbMfluxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nrows = (long long)nt * nlat; a.nlon = nlon;
+    if (wb_mf_plan(a, nlon)) { ctx->err = "wb_momentum_flux: longitude axis too long for the summation plan"; return 1; }
+    const size_t bytes = (size_t)nt * nlat * nlon * (dtype == 0 ? 4 : 8);
+    void *du = nullptr, *dv = nullptr;
+    if (!on_device) {
+        du = dmalloc(ctx, bytes); dv = dmalloc(ctx, bytes);
+        if (!du || !dv) { ctx->err = "wb_momentum_flux: out of device memory"; return 1; }
+        h2d(ctx, du, u, bytes); h2d(ctx, dv, v, bytes);
+    }
+    void* dout = out_on_device ? out : dmalloc(ctx, bytes);
+    if (!dout) { ctx->err = "wb_momentum_flux: out of device memory"; return 1; }
+    a.u = on_device ? u : du; a.v = on_device ? v : dv; a.out = dout;
+    WbOpTimer timer(ctx);
+    const long long grid = a.nrows < 16384 ? a.nrows : 16384;     // single-wave workgroups, each looping over rows
+    if (dtype == 0) WB_LAUNCH(wb_k_mflux<float>, grid, 64, a);
+    else WB_LAUNCH(wb_k_mflux<double>, grid, 64, a);
+    timer.stop();
+    int rc = 0;
+    if (!out_on_device) { rc = d2h(ctx, out, dout, bytes); dfree(ctx, dout); }
+    else rc = dsync(ctx);
+    if (du) dfree(ctx, du);
+    if (dv) dfree(ctx, dv);
+    return rc;
+}
+
+#if defined(WB_HOSTSIM)
+extern "C" void wb_hostsim_div(const double* a, int64_t n, double S, double* fast, double* plain) {
+    const double y = 1.0 / S;
+    for (int64_t i = 0; i < n; ++i) { fast[i] = wb_sm_div(a[i], S, y, true); plain[i] = a[i] / S; }
+}
+#endif
