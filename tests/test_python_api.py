@@ -198,3 +198,55 @@ def test_time_and_level_chunking_keep_the_frame_order(hostsim_engine, monkeypatc
         assert np.array_equal(np.asarray(row.geometry.coords), r["geometry"])
     s = wb.calculate_streamers(data, levels)
     _check_events(s, ref["streamers"], cols[:6] + ["geometry"])
+
+
+# ------------------------------------------------------------------ processing/spatial.py (tests/test_wavebreaking.py:107-112)
+def _spatial_checks():
+    from oracle import spatial as ospatial
+    data, pv, lat, lon, tm = _field(nt=2)
+    data.attrs["units"] = "PVU"
+    sm = wb.calculate_smoothed_field(data, 10)
+    assert type(sm) is type(data)
+    assert sm.name == "smooth_PV" and sm.attrs == {"units": "PVU", "smooth_passes": 10} and sm.dims == ("time", "lat", "lon")
+    np.testing.assert_array_equal(sm.values, ospatial.smooth_field(pv, 10))
+    assert np.isnan(sm.values[:, [0, 1, -2, -1]]).all()
+    # keyword form, other kernel and boundary mode, permuted dimensions in -> (time, lat, lon) out
+    w = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]])
+    perm = wb.GridField(np.transpose(pv, (2, 0, 1)), ("lon", "time", "lat"), {k: data.coords[k] for k in ("lon", "time", "lat")},
+                        name="PV")
+    sm2 = wb.calculate_smoothed_field(data=perm, passes=2, weights=w, mode="nearest")
+    assert sm2.dims == ("time", "lat", "lon")
+    np.testing.assert_array_equal(sm2.values, ospatial.smooth_field(pv, 2, w, "nearest"))
+    np.testing.assert_array_equal(wb.calculate_smoothed_field(data, 0).values[:, 2:-2], pv[:, 2:-2])
+    with pytest.raises(TypeError, match="data has to be a"):
+        wb.calculate_smoothed_field(pv, 2)
+    with pytest.raises(TypeError):
+        wb.calculate_smoothed_field(data, 2.5)
+    # the smoothed field (NaN border rows) feeds the indices
+    c = wb.calculate_contours(sm, 2)
+    ref = oapi.run_all(ospatial.smooth_field(pv, 10), [2], lat, lon, tm)
+    assert len(c) == len(ref["contours"]) > 0
+
+    rng = np.random.default_rng(21)
+    u_np = (rng.standard_normal(pv.shape) * 12 + 5).astype(np.float32)
+    v_np = (rng.standard_normal(pv.shape) * 7).astype(np.float32)
+    u = wb.GridField(u_np, data.dims, data.coords, name="U")
+    v = wb.GridField(v_np, data.dims, data.coords, name="V")
+    mf = wb.calculate_momentum_flux(u, v)
+    assert type(mf) is type(u) and mf.name == "mflux" and mf.dims == u.dims and mf.values.dtype == np.float32
+    np.testing.assert_array_equal(mf.values, ospatial.momentum_flux(u_np, v_np))
+    with pytest.raises(TypeError, match="v has to be a"):
+        wb.calculate_momentum_flux(u, v_np)
+    # used as the intensity field of an index (README workflow)
+    s = wb.calculate_streamers(data, 2, intensity=mf)
+    assert "intensity" in s.columns
+
+
+def test_spatial_functions_hostsim(hostsim_engine):
+    _spatial_checks()
+
+
+@pytest.mark.gpu
+def test_spatial_functions_gpu():
+    engine._contexts.clear()
+    _spatial_checks()

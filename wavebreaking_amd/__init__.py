@@ -1,7 +1,8 @@
 """wavebreaking_amd -- MI355X-native implementation of the WaveBreaking hot path.
 
 Same call surface as the reference package for this path (wavebreaking/__init__.py:31-34):
-calculate_contours, calculate_streamers, calculate_overturnings, calculate_cutoffs -- xarray.DataArray
+calculate_contours, calculate_streamers, calculate_overturnings, calculate_cutoffs, plus the two pre-processing
+functions calculate_smoothed_field and calculate_momentum_flux (wavebreaking/__init__.py:25-26) -- xarray.DataArray
 (or wavebreaking_amd.GridField) in, GeoDataFrame (or pandas.DataFrame when geopandas is absent) out.
 """
 __version__ = "0.1.0"
@@ -11,3 +12,4 @@ from wavebreaking_amd.indices.contour_index import calculate_contours  # noqa: F
 from wavebreaking_amd.indices.cutoff_index import calculate_cutoffs  # noqa: F401
 from wavebreaking_amd.indices.overturning_index import calculate_overturnings  # noqa: F401
 from wavebreaking_amd.indices.streamer_index import calculate_streamers  # noqa: F401
+from wavebreaking_amd.processing.spatial import calculate_momentum_flux, calculate_smoothed_field  # noqa: F401
