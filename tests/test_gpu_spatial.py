@@ -77,3 +77,38 @@ def test_momentum_flux_quarter_degree(ctx, dtype):
     rows = [(0, 10), (1, 360)]
     for t, j in rows:                                                    # and the oracle on a few rows
         np.testing.assert_array_equal(spatial.momentum_flux(u[t:t + 1, j:j + 1], v[t:t + 1, j:j + 1])[0, 0], want[t, j])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_inputs_outside_the_short_division_range(ctx, dtype):
+    """Infinities and magnitudes outside 2^-100 .. 2^100 make a strip fall back to the IEEE division; results stay exact."""
+    rng = np.random.default_rng(13)
+    pv = rng.standard_normal((3, 40, 300)).astype(dtype)
+    pv[0, 7, 11] = np.inf
+    pv[0, 30, 200] = -np.inf
+    if dtype == np.float64:
+        pv[1, 5, 5] = 3e-200
+        pv[1, 20, 150:160] *= 1e-310          # subnormal
+        pv[2, 9, 250] = 1e250
+    else:
+        pv[1, 5, 5] = 1e-44                    # float32 subnormal: inside the double range, stays on the short path
+        pv[2, 9, 250] = 3e38
+    with np.errstate(all="ignore"):
+        want = spatial.smooth_field(pv, 6, FIVE)
+    got = ctx.smooth_field(pv, 6, FIVE)
+    np.testing.assert_array_equal(got, want)
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.uint64), want[ok].view(np.uint64))
+
+
+def test_momentum_flux_row_lengths(ctx):
+    rng = np.random.default_rng(14)
+    for nlon in (1, 2, 8, 1536, 1537, 3600, 4096):
+        u = rng.standard_normal((1, 3, nlon)).astype(np.float32)
+        v = rng.standard_normal((1, 3, nlon))
+        with np.errstate(all="ignore"):
+            for a, b in ((u, v.astype(np.float32)), (u.astype(np.float64), v)):
+                want = (a - np.nanmean(a, axis=2)[..., None]) * (b - np.nanmean(b, axis=2)[..., None])
+                np.testing.assert_array_equal(ctx.momentum_flux(a, b), want)
+    with pytest.raises(RuntimeError):
+        ctx.momentum_flux(np.zeros((1, 1, 5000), np.float32), np.zeros((1, 1, 5000), np.float32))

@@ -1380,7 +1380,7 @@ static void wb_launch_smooth_plus2(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
 template <typename T, bool CAST>
 static void wb_launch_smooth_plus(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
     // the default weights (outer taps 1, integer sum) get the specialised instance, anything else the general one
-    if (a.unit4 && a.fastdiv) wb_launch_smooth_plus2<T, CAST, true, true>(ctx, P, a);
+    if (a.unit4 && a.fastdiv == 2) wb_launch_smooth_plus2<T, CAST, true, true>(ctx, P, a);
     else wb_launch_smooth_plus2<T, CAST, false, false>(ctx, P, a);
 }
 #else
@@ -1432,6 +1432,9 @@ extern "C" int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on
             const double pw[5] = {F(0, 1), F(1, 0), F(1, 1), F(1, 2), F(2, 1)};
             for (int k = 0; k < 5; ++k) { a.pw[k] = pw[k]; a.puse[k] = zero(pw[k]) ? 0 : 1; }
             a.unit4 = (pw[0] == 1.0 && pw[1] == 1.0 && pw[3] == 1.0 && pw[4] == 1.0) ? 1 : 0;
+            // the fused kernel's unchecked short division (wb_sp_strip) also bounds |S| and the centre weight
+            const double ac = fabs(pw[2]), as = fabs(wsum);
+            if (a.fastdiv && as >= 0x1p-20 && as <= 0x1p20 && (zero(pw[2]) || (ac >= 0x1p-20 && ac <= 0x1p20))) a.fastdiv = 2;
         }
     }
 #endif
@@ -1495,7 +1498,7 @@ extern "C" int wb_momentum_flux(wb_ctx* ctx, const void* u, const void* v, int d
     WbMfluxArgs a;
     memset(&a, 0, sizeof(a));
     a.nrows = (long long)nt * nlat; a.nlon = nlon;
-    if (wb_mf_plan(a, nlon)) { ctx->err = "wb_momentum_flux: longitude axis too long for the summation plan"; return 1; }
+    if (nlon > 4096 || wb_mf_plan(a, nlon)) { ctx->err = "wb_momentum_flux: longitude axis too long for the summation plan"; return 1; }
     const size_t bytes = (size_t)nt * nlat * nlon * (dtype == 0 ? 4 : 8);
     void *du = nullptr, *dv = nullptr;
     if (!on_device) {

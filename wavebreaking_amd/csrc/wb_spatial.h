@@ -183,27 +183,41 @@ WB_KERNEL(wb_k_mflux, WbMfluxArgs a) {
     WB_SHARED(T, part, 2 * WB_MF_MAXLEAF * 8);
     WB_SHARED(T, leafsum, 2 * WB_MF_MAXLEAF);
     WB_SHARED(int, nanc, 2);
-    const int L = a.nleaf;
+    const int L = a.nleaf, nlon = a.nlon;
     for (long long row = WB_BLOCK_ID; row < a.nrows; row += WB_GRID_DIM) {
-        const T* ur = (const T*)a.u + row * a.nlon;
-        const T* vr = (const T*)a.v + row * a.nlon;
+        const T* ur = (const T*)a.u + row * nlon;
+        const T* vr = (const T*)a.v + row * nlon;
         WB_PFOR(f, 2)
             nanc[f] = 0;
         WB_END_PFOR
-        // 8 strided partial sums per leaf (r[k] = a[k]; r[k] += a[i + k], i = 8, 16, ..), NaN counted and taken as 0
-        WB_PFOR(task, 2 * L * 8)
-            const int k = (int)(task & 7), leaf = (int)((task >> 3) % L), f = (int)((task >> 3) / L);
-            const T* x = (f ? vr : ur) + a.leaf_off[leaf];
-            const int n = a.leaf_len[leaf];
-            T r = (T)0;
-            int nn = 0;
-            if (n >= 8) {
-                const int body = n - (n % 8);
-                { const T e = x[k]; const bool isn = e != e; nn += isn; r = isn ? (T)0 : e; }
-                for (int i = 8 + k; i < body; i += 8) { const T e = x[i]; const bool isn = e != e; nn += isn; r = r + (isn ? (T)0 : e); }
+        // 8 strided partial sums per leaf (r[k] = a[k]; r[k] += a[i + k], i = 8, 16, ..), NaN counted and taken as 0.
+        // A task owns chain k of one leaf for BOTH fields; its <= 16 + 16 elements are fetched by independent loads
+        // first (one memory latency per task), then added in order.
+        WB_PFOR(task, L * 8)
+            const int k = (int)(task & 7), leaf = (int)(task >> 3);
+            const int n = a.leaf_len[leaf], body = n - (n % 8), cnt = n >= 8 ? body / 8 : 0;
+            const T* xu = ur + a.leaf_off[leaf] + k;
+            const T* xv = vr + a.leaf_off[leaf] + k;
+            T eu[16], ev[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                eu[i] = i < cnt ? xu[8 * i] : (T)0;
+                ev[i] = i < cnt ? xv[8 * i] : (T)0;
             }
-            part[task] = r;
-            if (nn) wb_atomic_add(&nanc[f], nn);
+            int nu = 0, nv = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (eu[i] != eu[i]) { eu[i] = (T)0; ++nu; }
+                if (ev[i] != ev[i]) { ev[i] = (T)0; ++nv; }
+            }
+            T ru = eu[0], rv = ev[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i)
+                if (i < cnt) { ru = ru + eu[i]; rv = rv + ev[i]; }
+            part[task] = ru;
+            part[L * 8 + task] = rv;
+            if (nu) wb_atomic_add(&nanc[0], nu);
+            if (nv) wb_atomic_add(&nanc[1], nv);
         WB_END_PFOR
         WB_PFOR(task, 2 * L)
             const int leaf = (int)(task % L), f = (int)(task / L);
@@ -231,10 +245,10 @@ WB_KERNEL(wb_k_mflux, WbMfluxArgs a) {
             WB_END_PFOR
         }
         // np.nanmean: true_divide(total, count) evaluated in double, stored in the array dtype
-        const T um = (T)((double)leafsum[0] / (double)(a.nlon - nanc[0]));
-        const T vm = (T)((double)leafsum[L] / (double)(a.nlon - nanc[1]));
-        T* o = (T*)a.out + row * a.nlon;
-        WB_PFOR(c, a.nlon)
+        const T um = (T)((double)leafsum[0] / (double)(nlon - nanc[0]));
+        const T vm = (T)((double)leafsum[L] / (double)(nlon - nanc[1]));
+        T* o = (T*)a.out + row * nlon;
+        WB_PFOR(c, nlon)
             o[c] = (ur[c] - um) * (vr[c] - vm);
         WB_END_PFOR
     }
@@ -261,13 +275,17 @@ template <typename T> struct WbVec2;
 template <> struct WbVec2<float> { typedef float2 type; };
 template <> struct WbVec2<double> { typedef double2 type; };
 
-// T = element type of the input cube, P = passes fused in this launch, CAST = stage 1 rounds its accumulator to float
-// UNIT4 = the four outer taps have weight 1 (no multiply), FAST = wb_sm_div's short sequence applies
+// One strip of one time step.  UNIT4 = the four outer taps have weight 1 (no multiply).  FAST = divisions by wb_sm_div's
+// short sequence WITHOUT its per-call range test: the host admits it only for 2^-20 <= |S|, |centre weight| <= 2^20, and the
+// strip watches its inputs instead -- if every input is NaN, zero or of magnitude 2^-100 .. 2^100 then every intermediate
+// of up to 8 passes is NaN, +0 or of magnitude 2^-850 .. 2^430 (a non-zero sum of such terms is at least one ulp of the
+// smallest, a pass shrinks by at most 2^-93 and grows by at most 2^41), where the sequence is exact.  Returns true if an
+// input fell outside; the caller then redoes the strip with the IEEE division.
 template <typename T, int P, bool CAST, bool UNIT4, bool FAST>
-__global__ __launch_bounds__(256) void wb_k_smooth_plus(WbSmoothArgs a) {
+__device__ __forceinline__ bool wb_sp_strip(const WbSmoothArgs& a) {
     const int lane = threadIdx.x & 63;
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // work item = (time step, strip)
-    if (g >= a.nt * a.nstrips) return;                                          // whole waves leave together
+    if (g >= a.nt * a.nstrips) return false;                                    // whole waves leave together
     const long long t = g / a.nstrips;
     const int s = (int)(g - t * a.nstrips);
     const int nlat = a.nlat, nlon = a.nlon, H = a.halo;
@@ -283,6 +301,7 @@ __global__ __launch_bounds__(256) void wb_k_smooth_plus(WbSmoothArgs a) {
     const double wU = a.pw[0], wL = a.pw[1], wC = a.pw[2], wR = a.pw[3], wD = a.pw[4];
     const bool uU = a.puse[0], uL = a.puse[1], uC = a.puse[2], uR = a.puse[3], uD = a.puse[4];
     const double S = a.wsum, Y = a.rsum, qnan = __builtin_nan("");
+    bool bad = false;
 
     double win[P][3][2];                                                        // stage s-1 output: rows (newest-2 .. newest)
 #pragma unroll
@@ -301,11 +320,20 @@ __global__ __launch_bounds__(256) void wb_k_smooth_plus(WbSmoothArgs a) {
             dst[0] = row[c0]; dst[1] = row[c1];
         }
     };
+    auto div = [&](double v) {
+        if (!FAST) return v / S;
+        const double q = v * Y;
+        return __builtin_fma(__builtin_fma(-S, q, v), Y, q);
+    };
     const int nticks = nlat + 2 * P;
     auto tick = [&](int tau, auto ph) {
         constexpr int N = decltype(ph)::value, M = (N + 2) % 3, O = (N + 1) % 3;   // newest / middle / oldest slot
         double x0 = (double)ld[N][0], x1 = (double)ld[N][1];
         if (tau + 3 < nticks) load(tau + 3, ld[N]);
+        if (FAST) {
+            const double a0 = __builtin_fabs(x0), a1 = __builtin_fabs(x1);     // comparisons are false for NaN
+            bad |= (a0 > 0x1p100) | (a1 > 0x1p100) | ((a0 < 0x1p-100) & (a0 > 0.0)) | ((a1 < 0x1p-100) & (a1 > 0.0));
+        }
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             win[q][N][0] = x0; win[q][N][1] = x1;
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(256) void wb_k_smooth_plus(WbSmoothArgs a) {
                 if (uD) { t0 += wD * x0; t1 += wD * x1; }
             }
             if (CAST && q == 0) { t0 = (double)(float)t0; t1 = (double)(float)t1; }
-            x0 = wb_sm_div(t0, S, Y, FAST); x1 = wb_sm_div(t1, S, Y, FAST);
+            x0 = div(t0); x1 = div(t1);
         }
         const int r = tau - 2 * P;                                              // row the last stage just finished
         if (r >= 0) {
@@ -351,5 +379,16 @@ __global__ __launch_bounds__(256) void wb_k_smooth_plus(WbSmoothArgs a) {
     }
     if (tau < nticks) { tick(tau, WbInt<0>()); ++tau; }
     if (tau < nticks) { tick(tau, WbInt<1>()); ++tau; }
+    return bad;
+}
+
+// T = element type of the input cube, P = passes fused in this launch, CAST = stage 1 rounds its accumulator to float
+template <typename T, int P, bool CAST, bool UNIT4, bool FAST>
+__global__ __launch_bounds__(256) void wb_k_smooth_plus(WbSmoothArgs a) {
+    if (FAST) {
+        if (__any(wb_sp_strip<T, P, CAST, UNIT4, true>(a))) (void)wb_sp_strip<T, P, CAST, UNIT4, false>(a);
+    } else {
+        (void)wb_sp_strip<T, P, CAST, UNIT4, false>(a);
+    }
 }
 #endif
