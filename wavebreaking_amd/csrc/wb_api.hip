@@ -1368,8 +1368,10 @@ struct WbOpTimer {
 };
 template <typename T, bool CAST, bool UNIT4, bool FAST>
 static void wb_launch_smooth_plus2(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
+    // four strips per workgroup (measured: 1, 2, 8, 13, 16 waves per workgroup are all slower)
     const long long waves = a.nt * a.nstrips;
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    const int wpb = 4;
+    const dim3 grid((unsigned)((waves + wpb - 1) / wpb)), block(64 * wpb);
     switch (P) {
 #define WB_SP_CASE(N) \
     case N: hipLaunchKernelGGL((wb_k_smooth_plus<T, N, CAST, UNIT4, FAST>), grid, block, 0, ctx->stream, a); break;

@@ -284,7 +284,7 @@ template <> struct WbVec2<double> { typedef double2 type; };
 template <typename T, int P, bool CAST, bool UNIT4, bool FAST>
 __device__ __forceinline__ bool wb_sp_strip(const WbSmoothArgs& a) {
     const int lane = threadIdx.x & 63;
-    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // work item = (time step, strip)
+    const long long g = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // work item = (time step, strip)
     if (g >= a.nt * a.nstrips) return false;                                    // whole waves leave together
     const long long t = g / a.nstrips;
     const int s = (int)(g - t * a.nstrips);
