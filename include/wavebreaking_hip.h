@@ -146,7 +146,18 @@ int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on_device, in
    zonal mean being numpy's nanmean (pairwise row sum in the array dtype).  u, v, out: (nt, nlat, nlon). */
 int wb_momentum_flux(wb_ctx* ctx, const void* u, const void* v, int dtype, int on_device, int64_t nt, int nlat, int nlon,
                      void* out, int out_on_device);
-/* device time (HIP events on the context's stream) of the kernels of the last wb_smooth_field / wb_momentum_flux */
+/* to_xarray (processing/events.py:37-110): out[step, j, i] = value (1 without `value`) for every grid point contained in
+   event.geometry.buffer(radius), radius = (dlon + dlat) / 4 (events.py:69-79); later events overwrite earlier ones where
+   they overlap (events.py:93-99).  lat / lon ascending and regular.  Event k: time index step[k], rings
+   ring_offset[k] .. ring_offset[k+1] (parts of a MultiPolygon and holes alike: even-odd), ring q: vertices
+   vert_offset[q] .. vert_offset[q+1] of vx (degrees east) / vy (degrees north).  out: (nt, nlat, nlon) of out_dtype
+   0 int8 / 1 float32 / 2 float64, zero-filled here first; host or device. */
+int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const double* lat, const double* lon, double radius,
+                   int64_t nev, const int32_t* step, const double* value, const int64_t* ring_offset,
+                   const int64_t* vert_offset, const double* vx, const double* vy, int out_dtype, void* out,
+                   int out_on_device);
+/* device time (HIP events on the context's stream) of the kernels of the last wb_smooth_field / wb_momentum_flux /
+   wb_flag_events */
 float wb_last_op_ms(wb_ctx* ctx);
 
 #ifdef __cplusplus

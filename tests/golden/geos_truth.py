@@ -61,3 +61,23 @@ CELLS = [
     ([(0, 0), (9, 1), (9, 3), (0, 3)], 0.125,
      [(0, 0), (1, 0)] + [(x, 1) for x in range(10)] + [(x, 2) for x in range(10)] + [(x, 3) for x in range(10)]),
 ]
+
+# to_xarray (events.py:69-79): polygon.buffer(r).contains(Point(lon_i, lat_j)) on the grid lon = 0..7, lat = 0..5
+# (unit spacing, r = 1/2).  (rings, expected flagged (lon, lat) points, why)
+FLAGS = [
+    ([[(1, 1), (4, 1), (4, 3), (1, 3)]],
+     [(x, y) for y in (1, 2, 3) for x in (1, 2, 3, 4)],
+     "rectangle: its lattice points; every other grid point is >= 1 away"),
+    ([[(0, 0), (4, 0), (0, 4)]],
+     [(x, y) for y in range(5) for x in range(5) if x + y <= 4],
+     "triangle: points on or under the hypotenuse; the nearest others are 1/sqrt(2) > 1/2 from it"),
+    ([[(0, 0), (2, 1), (0, 1)]],
+     [(0, 0), (1, 0), (0, 1), (1, 1), (2, 1)],
+     "thin triangle: (1,0) is 1/sqrt(5) < 1/2 from the edge (0,0)-(2,1)"),
+    ([[(1, 1), (2, 1), (2, 2), (1, 2)], [(5, 3), (7, 3), (7, 5), (5, 5)]],
+     [(1, 1), (2, 1), (1, 2), (2, 2)] + [(x, y) for y in (3, 4, 5) for x in (5, 6, 7)],
+     "MultiPolygon of two parts (a polygon split at the last meridian): union of the parts"),
+    ([[(0, 0), (6, 0), (6, 5), (0, 5)], [(2, 1), (5, 1), (5, 4), (2, 4)]],
+     [(x, y) for y in range(6) for x in range(7) if not (2 < x < 5 and 1 < y < 4)],
+     "polygon with a hole: the two points strictly inside the hole, (3,2),(4,2),(3,3),(4,3), are 1 from its rim -> out"),
+]

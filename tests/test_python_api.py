@@ -250,3 +250,52 @@ def test_spatial_functions_hostsim(hostsim_engine):
 def test_spatial_functions_gpu():
     engine._contexts.clear()
     _spatial_checks()
+
+
+# ------------------------------------------------------------------ processing/events.py:to_xarray (tests/test_wavebreaking.py:179-186)
+def _to_xarray_checks():
+    from oracle import flags as oflags
+    from wavebreaking_amd.processing.events import _rings
+    data, pv, lat, lon, tm = _field(nt=3)
+    streamers = wb.calculate_streamers(data, 2)
+    flag = wb.to_xarray(data, streamers)
+    assert type(flag) is type(data) and flag.dims == data.dims and flag.name == "flag"
+    assert flag.values.dtype == np.int8 and flag.attrs["long_name"] == "flag wave breaking"
+    steps = [int(np.nonzero(tm == np.datetime64(d))[0][0]) for d in streamers["date"]]
+    rings = [_rings(g) for g in streamers["geometry"]]
+    want = oflags.flag_events(3, lat, lon, 0.5, steps, rings)
+    np.testing.assert_array_equal(flag.values, want)
+    assert 0 < want.sum() < want.size
+    # every cell of calculate_properties' buffered index polygon that is not next to the seam is flagged as well
+    ref = oapi.run_all(pv, [2], lat, lon, tm)
+    for row in ref["streamers"]:
+        t = int(np.nonzero(tm == row["date"])[0][0])
+        xs, ys = (np.asarray(c) for c in row["_cells"])
+        keep = (xs % lon.size > 1) & (xs % lon.size < lon.size - 2)
+        assert flag.values[t, ys[keep], xs[keep] % lon.size].all()
+    # a value column, overlapping events: the later row wins (events.py:93-99); descending latitude and permuted dims
+    ev = pd.concat([streamers, wb.calculate_overturnings(data, 2)]).reset_index(drop=True)
+    ev["event_id"] = np.arange(1, len(ev) + 1, dtype=float)
+    data_d = data.sortby("lat", ascending=False)
+    got = wb.to_xarray(data_d, ev, flag="event_id", name="which")
+    assert got.values.dtype == data.values.dtype and got.name == "which"
+    steps = [int(np.nonzero(tm == np.datetime64(d))[0][0]) for d in ev["date"]]
+    wantv = oflags.flag_events(3, lat, lon, 0.5, steps, [_rings(g) for g in ev["geometry"]], ev["event_id"].values,
+                               dtype=data.values.dtype)
+    np.testing.assert_array_equal(got.values, wantv[:, ::-1, :])
+    with pytest.raises(KeyError, match="nope is not a column"):
+        wb.to_xarray(data, ev, flag="nope")
+    with pytest.raises(ValueError, match="empty"):
+        wb.to_xarray(data, ev.iloc[:0])
+    with pytest.raises(TypeError, match="events has to be a"):
+        wb.to_xarray(data, "events")
+
+
+def test_to_xarray_hostsim(hostsim_engine):
+    _to_xarray_checks()
+
+
+@pytest.mark.gpu
+def test_to_xarray_gpu():
+    engine._contexts.clear()
+    _to_xarray_checks()

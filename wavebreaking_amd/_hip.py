@@ -99,6 +99,8 @@ class Library:
                                         C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_int]
         lib.wb_momentum_flux.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int,
                                          C.c_void_p, C.c_int]
+        lib.wb_flag_events.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int64, C.POINTER(C.c_int32),
+                                       dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp, dp, C.c_int, C.c_void_p, C.c_int]
         lib.wb_last_op_ms.argtypes = [C.c_void_p]
         lib.wb_last_op_ms.restype = C.c_float
 
@@ -238,6 +240,45 @@ class Context:
                                          dst, out_dev)
         if rc != 0:
             raise RuntimeError("wb_momentum_flux failed: " + self.error())
+        return out
+
+    def flag_events(self, nt, lat, lon, radius, steps, rings_per_event, values=None, dtype=np.int8, out_device=None):
+        """to_xarray's rule: cube (nt, nlat, nlon) with ``values[k]`` (1) at every grid point contained in event k's
+        geometry buffered by ``radius``; ``rings_per_event[k]`` = list of (n, 2) lon/lat rings; lat / lon ascending."""
+        lat = np.ascontiguousarray(lat, dtype=np.float64)
+        lon = np.ascontiguousarray(lon, dtype=np.float64)
+        nev = len(rings_per_event)
+        ring_off = np.zeros(nev + 1, dtype=np.int64)
+        vert_off = [0]
+        xs, ys = [], []
+        for k, rings in enumerate(rings_per_event):
+            for ring in rings:
+                ring = np.asarray(ring, dtype=np.float64).reshape(-1, 2)
+                xs.append(ring[:, 0])
+                ys.append(ring[:, 1])
+                vert_off.append(vert_off[-1] + len(ring))
+            ring_off[k + 1] = len(vert_off) - 1
+        vert_off = np.asarray(vert_off, dtype=np.int64)
+        vx = np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(0))
+        vy = np.ascontiguousarray(np.concatenate(ys) if ys else np.zeros(0))
+        st = np.ascontiguousarray(steps, dtype=np.int32)
+        val = None if values is None else np.ascontiguousarray(values, dtype=np.float64)
+        dt = np.dtype(dtype)
+        code = {np.dtype(np.int8): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}[dt]
+        out = None
+        if out_device is None:
+            out = np.empty((int(nt), lat.size, lon.size), dtype=dt)
+            dst, on_dev = out.ctypes.data_as(C.c_void_p), 0
+        else:
+            dst, on_dev = C.c_void_p(int(out_device)), 1
+        dp = C.POINTER(C.c_double)
+        rc = self.L.lib.wb_flag_events(self.h, int(nt), lat.size, lon.size, lat.ctypes.data_as(dp), lon.ctypes.data_as(dp),
+                                       float(radius), nev, st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       val.ctypes.data_as(dp) if val is not None else None,
+                                       ring_off.ctypes.data_as(C.POINTER(C.c_int64)), vert_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       vx.ctypes.data_as(dp), vy.ctypes.data_as(dp), code, dst, on_dev)
+        if rc != 0:
+            raise RuntimeError("wb_flag_events failed: " + self.error())
         return out
 
     def last_op_ms(self):

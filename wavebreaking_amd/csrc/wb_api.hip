@@ -1524,6 +1524,94 @@ extern "C" int wb_momentum_flux(wb_ctx* ctx, const void* u, const void* v, int d
     return rc;
 }
 
+#include "wb_flags.h"
+#include <algorithm>
+#include <numeric>
+
+extern "C" int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const double* lat, const double* lon, double radius,
+                              int64_t nev, const int32_t* step, const double* value, const int64_t* ring_offset,
+                              const int64_t* vert_offset, const double* vx, const double* vy, int out_dtype, void* out,
+                              int out_on_device) {
+    if (!ctx) return 1;
+    if (!out || !lat || !lon || nt < 0 || nlat < 2 || nlon < 2 || nev < 0 || out_dtype < 0 || out_dtype > 2 || !(radius >= 0.0) ||
+        (nev > 0 && (!step || !ring_offset || !vert_offset || !vx || !vy))) {
+        ctx->err = "wb_flag_events: bad argument";
+        return 1;
+    }
+    const double dlat = lat[1] - lat[0], dlon = lon[1] - lon[0];
+    if (!(dlat > 0.0) || !(dlon > 0.0)) { ctx->err = "wb_flag_events: lat / lon must be ascending"; return 1; }
+    for (int64_t k = 0; k < nev; ++k)
+        if (step[k] < 0 || step[k] >= nt) { ctx->err = "wb_flag_events: event time index out of range"; return 1; }
+    const size_t esz = out_dtype == 0 ? 1 : (out_dtype == 1 ? 4 : 8);
+    const size_t bytes = (size_t)nt * nlat * nlon * esz;
+    void* d_out = out_on_device ? out : dmalloc(ctx, bytes ? bytes : 1);
+    if (!d_out) { ctx->err = "wb_flag_events: out of device memory"; return 1; }
+    dmemset(ctx, d_out, 0, bytes);
+    int rc = 0;
+    if (nev > 0 && nt > 0) {
+        // events by time step, frame order inside a step
+        std::vector<int64_t> order((size_t)nev);
+        std::iota(order.begin(), order.end(), (int64_t)0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return step[x] < step[y]; });
+        std::vector<int> act_step;
+        std::vector<long long> act_ev0, ev_ring0((size_t)nev + 1), ring_v0;
+        std::vector<double> svx, svy, sval;
+        ring_v0.push_back(0);
+        for (int64_t q = 0; q < nev; ++q) {
+            const int64_t k = order[(size_t)q];
+            if (q == 0 || step[k] != step[order[(size_t)q - 1]]) { act_step.push_back(step[k]); act_ev0.push_back(q); }
+            ev_ring0[(size_t)q] = (long long)ring_v0.size() - 1;
+            for (int64_t rg = ring_offset[k]; rg < ring_offset[k + 1]; ++rg) {
+                for (int64_t v = vert_offset[rg]; v < vert_offset[rg + 1]; ++v) { svx.push_back(vx[v]); svy.push_back(vy[v]); }
+                ring_v0.push_back((long long)svx.size());
+            }
+            if (value) sval.push_back(value[k]);
+        }
+        act_ev0.push_back(nev);
+        ev_ring0[(size_t)nev] = (long long)ring_v0.size() - 1;
+        WbFlagArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nt = nt; a.nlat = nlat; a.nlon = nlon; a.dlat = dlat; a.dlon = dlon; a.r = radius; a.nact = (int)act_step.size();
+        a.out_dtype = out_dtype; a.out = d_out;
+        const int grid = a.nact < 1024 ? a.nact : 1024;
+        auto up = [&](const void* h, size_t n) -> void* {
+            void* d = dmalloc(ctx, n ? n : 8);
+            if (d && n) h2d(ctx, d, h, n);
+            return d;
+        };
+        double* d_lat = (double*)up(lat, nlat * sizeof(double));
+        double* d_lon = (double*)up(lon, nlon * sizeof(double));
+        int* d_as = (int*)up(act_step.data(), act_step.size() * sizeof(int));
+        long long* d_ae = (long long*)up(act_ev0.data(), act_ev0.size() * sizeof(long long));
+        long long* d_er = (long long*)up(ev_ring0.data(), ev_ring0.size() * sizeof(long long));
+        long long* d_rv = (long long*)up(ring_v0.data(), ring_v0.size() * sizeof(long long));
+        double* d_vx = (double*)up(svx.data(), svx.size() * sizeof(double));
+        double* d_vy = (double*)up(svy.data(), svy.size() * sizeof(double));
+        double* d_val = value ? (double*)up(sval.data(), sval.size() * sizeof(double)) : nullptr;
+        int* d_tog = (int*)dmalloc(ctx, (size_t)grid * nlat * (nlon + 1) * sizeof(int));
+        if (!d_lat || !d_lon || !d_as || !d_ae || !d_er || !d_rv || !d_vx || !d_vy || !d_tog || (value && !d_val)) {
+            ctx->err = "wb_flag_events: out of device memory";
+            rc = 1;
+        } else {
+            a.lat = d_lat; a.lon = d_lon; a.act_step = d_as; a.act_ev0 = d_ae; a.ev_ring0 = d_er; a.ring_v0 = d_rv;
+            a.vx = d_vx; a.vy = d_vy; a.value = d_val; a.tog = d_tog;
+            WbOpTimer timer(ctx);
+            WB_LAUNCH(wb_k_flag_events, grid, 256, a);
+            timer.stop();
+        }
+        for (void* d : {(void*)d_lat, (void*)d_lon, (void*)d_as, (void*)d_ae, (void*)d_er, (void*)d_rv, (void*)d_vx, (void*)d_vy,
+                        (void*)d_val, (void*)d_tog})
+            if (d) dfree(ctx, d);
+    }
+    if (!out_on_device) {
+        if (!rc) rc = d2h(ctx, out, d_out, bytes);
+        dfree(ctx, d_out);
+    } else if (!rc) {
+        rc = dsync(ctx);
+    }
+    return rc;
+}
+
 #if defined(WB_HOSTSIM)
 extern "C" void wb_hostsim_div(const double* a, int64_t n, double S, double* fast, double* plain) {
     const double y = 1.0 / S;
