@@ -881,7 +881,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         ev_ind = (int*)talloc((size_t)nsel * cap_ev * 2 * sizeof(int));
         WbStreamerArgs st;
         memset(&st, 0, sizeof(st));
-        st.nsel = nsel; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.cap_ev = cap_ev;
+        st.nsel = nsel; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.W = b->W; st.cap_ev = cap_ev;
         st.geo_dis = p.geo_dis; st.cont_dis = p.cont_dis;
         { const double sv = sin(p.geo_dis / (2.0 * 6371.0)); st.hthr = sv * sv; }
         st.sel_job = b->sel_job; st.sel_cont = b->sel_cont; st.c_off = b->c_off; st.c_len = b->c_len; st.cpts = b->cpts;

@@ -209,7 +209,7 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // streamer index
 struct WbStreamerArgs {
-    int nsel, cap_seg, nlon, nlat, cap_pairs, cap_ev, hash_size;  // hash_size: pow2 >= 2*cap_pairs
+    int nsel, cap_seg, nlon, nlat, W, cap_pairs, cap_ev, hash_size;  // hash_size: pow2 >= 2*cap_pairs
     double geo_dis, cont_dis;
     double hthr;               // sin^2(geo_dis / (2*6371))
     const int* sel_job;
@@ -487,19 +487,14 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
         WB_END_SINGLE
         return;
     }
+    // Two pairs coincide after x mod nlon only if one is the copy of the other one period further east: both end points
+    // of the western pair lie in x < W - nlon, both of the eastern one in x >= nlon (a mixed pair would need its copy in
+    // the opposite index order).  Only western pairs are entered into the table and only eastern pairs look themselves
+    // up -- a quarter of the pairs each on a full-span contour; everything else survives without touching it.
+    const int padd = a.W - a.nlon;
     WB_PFOR(q, hsize)
         hkey[q] = WB_HEMPTY;
         hval[q] = WB_HEMPTY;
-    WB_END_PFOR
-    WB_PFOR(p, P)
-        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
-        const uint32_t pi = pts[i], pj = pts[j];
-        const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
-                                       ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
-                                       ((unsigned long long)wb_pt_y(pj) << 48);
-        int fresh;
-        const int slot = wb_hash_insert(hkey, hmask, key, &fresh);
-        if (slot >= 0) wb_atomic_min(&hval[slot], pairs[p]);
     WB_END_PFOR
     WB_SINGLE
     cnt[0] = 0;
@@ -507,16 +502,33 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     WB_PFOR(p, P)
         const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
         const uint32_t pi = pts[i], pj = pts[j];
-        const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
-                                       ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
-                                       ((unsigned long long)wb_pt_y(pj) << 48);
-        const int slot = wb_hash_find(hkey, hmask, key);
-        // of the pairs that coincide after x mod nlon the first (in frame order = (ind1, ind2) order) stays
-        if (slot >= 0 && hval[slot] != pairs[p]) alive[p] = 0;
-        else wb_atomic_add(&cnt[0], 1);
+        if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
+            const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
+                                           ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
+                                           ((unsigned long long)wb_pt_y(pj) << 48);
+            int fresh;
+            const int slot = wb_hash_insert(hkey, hmask, key, &fresh);
+            if (slot >= 0) wb_atomic_min(&hval[slot], (unsigned long long)p);
+        }
+    WB_END_PFOR
+    WB_PFOR(p, P)
+        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
+        const uint32_t pi = pts[i], pj = pts[j];
+        if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
+            const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
+                                           ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
+                                           ((unsigned long long)wb_pt_y(pj) << 48);
+            const int slot = wb_hash_find(hkey, hmask, key);
+            if (slot >= 0) {
+                // of the two the first in frame order = (ind1, ind2) order stays
+                const int pw = (int)hval[slot];
+                alive[pairs[pw] < pairs[p] ? p : pw] = 0;
+                wb_atomic_add(&cnt[0], 1);
+            }
+        }
     WB_END_PFOR
     WB_SINGLE
-    a.nalive[s] = cnt[0];
+    a.nalive[s] = P - cnt[0];
     a.stage[s] = 1;
     WB_END_SINGLE
 }
