@@ -98,3 +98,76 @@ def test_shard_covers_everything():
             blocks = [wd.shard(nt, r, world) for r in range(world)]
             assert blocks[0][0] == 0 and sum(c for _, c in blocks) == nt
             assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+
+
+WORKER_FRAMES = r'''
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import wavebreaking_amd as wb
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip, engine
+from wavebreaking_amd import distributed as wd
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+engine._contexts[0] = _hip.Context(0, helpers.hostsim_library())
+NT = 5
+lat, lon = synth.grid(2.5)
+pv = synth.pv_field(0, NT, lat, lon, eps=0.2)
+pv[wd.shard(NT, 1, 2)[0]:, 20:30, :] = 0.0          # the second shard has no southern full-span contour
+data = wb.GridField(pv, ("time", "lat", "lon"), {"time": synth.times(NT), "lat": lat, "lon": lon}, name="PV")
+out = {}
+for name in ("calculate_contours", "calculate_streamers", "calculate_overturnings", "calculate_cutoffs"):
+    kw = dict(intensity=data) if name != "calculate_contours" else dict(original_coordinates=False)
+    out[name] = wd.calculate_sharded(getattr(wb, name), data, [-2, 2], dist=dist, **kw)
+if dist.get_rank() == 0:
+    pickle.dump(out, open(sys.argv[2], "wb"))
+else:
+    assert all(v is None for v in out.values())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_calls_return_the_single_process_frames(tmp_path, monkeypatch):
+    import pickle
+
+    import wavebreaking_amd as wb
+    from wavebreaking_amd import engine
+    helpers.build_hostsim()
+    script = tmp_path / "worker_frames.py"
+    script.write_text(WORKER_FRAMES)
+    out = tmp_path / "frames.pkl"
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = pickle.load(open(out, "rb"))
+
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    monkeypatch.setitem(engine._contexts, 0, ctx)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    NT = 5
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(0, NT, lat, lon, eps=0.2)
+    pv[wd.shard(NT, 1, 2)[0]:, 20:30, :] = 0.0
+    data = wb.GridField(pv, ("time", "lat", "lon"), {"time": synth.times(NT), "lat": lat, "lon": lon}, name="PV")
+    for name, frame in got.items():
+        kw = dict(intensity=data) if name != "calculate_contours" else dict(original_coordinates=False)
+        want = getattr(wb, name)(data, [-2, 2], **kw)
+        assert frame.columns.to_list() == want.columns.to_list() and len(frame) == len(want) > 0, name
+        for col in want.columns:
+            if col == "geometry":
+                for a, b in zip(frame[col], want[col]):
+                    ra = [np.asarray(g.exterior.coords) for g in a.geoms] if hasattr(a, "geoms") else [np.asarray(a.coords)]
+                    rb = [np.asarray(g.exterior.coords) for g in b.geoms] if hasattr(b, "geoms") else [np.asarray(b.coords)]
+                    assert len(ra) == len(rb) and all(np.array_equal(x, y) for x, y in zip(ra, rb))
+            else:
+                assert frame[col].to_list() == want[col].to_list(), (name, col)
+    ctx.close()

@@ -88,3 +88,74 @@ def gather_event_tables(tables, dist=None, dst=0):
             res[k].append(block[o:o + c])
             o += c
     return [np.concatenate(v, axis=0) if v else np.zeros((0, width)) for v in res]
+
+
+# ------------------------------------------------------------------------------------------------ whole calls
+def _time_block(data, time_name, first, count):
+    """``data`` restricted to time steps [first, first + count)."""
+    if hasattr(data, "isel"):                                   # xarray.DataArray
+        return data.isel({time_name: slice(first, first + count)})
+    from wavebreaking_amd import gridfield as _gf
+    ax = data.dims.index(time_name)
+    sl = [slice(None)] * len(data.dims)
+    sl[ax] = slice(first, first + count)
+    coords = dict(data.coords)
+    c = data.coords[time_name]
+    coords[time_name] = _gf.Coord(c.values[first:first + count], c.attrs, c.encoding)
+    return _gf.GridField(data.values[tuple(sl)], data.dims, coords, data.attrs, data.name)
+
+
+def gather_frames(frame, dist, dst=0):
+    """exchange (2) for whole frames (rows AND geometries): every rank's frame travels as one byte buffer in a single
+    gather (sizes first); ``dst`` gets the list of frames in rank (= time) order, the others None."""
+    import pickle
+    import torch
+    world, rank, dev = dist.get_world_size(), dist.get_rank(), _device(dist)
+    blob = np.frombuffer(pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL), dtype=np.uint8)
+    size = torch.tensor([blob.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(t.item()) for t in sizes]
+    buf = torch.zeros(max(sizes), dtype=torch.uint8, device=dev)
+    buf[: blob.size] = torch.from_numpy(blob.copy()).to(dev)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return [pickle.loads(out[r][: sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+
+
+def calculate_sharded(func, data, contour_levels, *args, dist=None, dst=0, **kwargs):
+    """Run ``func`` (calculate_contours / calculate_streamers / calculate_overturnings / calculate_cutoffs) time-sharded
+    over the ranks of ``dist``: every rank passes the SAME full ``data`` (and ``intensity``), works on its contiguous
+    block of time steps, the contour selection uses the maximum over all ranks (one all-reduce of an int32), and the
+    frames are gathered to rank ``dst`` in time order -- which returns what the single-process call returns; the other
+    ranks return None."""
+    import pandas as pd
+    from wavebreaking_amd import engine
+    from wavebreaking_amd.utils import data_utils as du
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return func(data, contour_levels, *args, **kwargs)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    tn = kwargs.get("time_name") or du.get_time_name(data)
+    first, count = shard(len(data[tn]), rank, world)
+    engine.set_global_max_hook(lambda g: global_max_nux(g, dist))
+    try:
+        if count == 0:
+            frame = pd.DataFrame()
+            if func.__name__ != "calculate_contours":
+                engine.global_max(0)                                 # keep the collective matched
+        else:
+            kw = dict(kwargs)
+            if kw.get("intensity") is not None:
+                kw["intensity"] = _time_block(kw["intensity"], tn, first, count)
+            frame = func(_time_block(data, tn, first, count), contour_levels, *args, **kw)
+    finally:
+        engine.set_global_max_hook(None)
+    frames = gather_frames(frame, dist, dst)
+    if frames is None:
+        return None
+    frames = [f for f in frames if len(f)]
+    if not frames:
+        return frame
+    return pd.concat(frames).reset_index(drop=True)

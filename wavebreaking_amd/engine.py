@@ -9,6 +9,18 @@ from wavebreaking_amd.utils import data_utils as du
 
 _contexts = {}
 MAX_LEVELS = 4
+_global_max_hook = None
+
+
+def set_global_max_hook(hook):
+    """``hook(local_max) -> global_max``: how the maximum distinct-longitude count is completed across the ranks of a
+    time-sharded run (wavebreaking_amd.distributed installs an all-reduce(max) here); None = single process."""
+    global _global_max_hook
+    _global_max_hook = hook
+
+
+def global_max(local_max):
+    return int(local_max) if _global_max_hook is None else int(_global_max_hook(int(local_max)))
 
 
 def get_context(device=None):

@@ -34,6 +34,7 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     g = max(b.max_nux() for b, *_ in batches) if batches else 0          # contours.exp_lon.max(), streamer_index.py:106
     if global_max is not None:
         g = max(g, int(global_max))
+    g = engine.global_max(g)                                               # time-sharded runs: all-reduce(max) across ranks
     which = {_hip.STREAMERS: dict(streamers=True, overturnings=False, cutoffs=False),
              _hip.OVERTURNINGS: dict(streamers=False, overturnings=True, cutoffs=False),
              _hip.CUTOFFS: dict(streamers=False, overturnings=False, cutoffs=True)}[kind]
