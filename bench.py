@@ -104,7 +104,7 @@ def main():
                 stage_ms.setdefault(name, []).append(ms)
             counts.update(polygon_vertices=int(sum(e["poly_x"].size for e in ev)),
                           streamers=int(ev[0]["step"].size), overturnings=int(ev[1]["step"].size),
-                          cutoffs=int(ev[2]["step"].size), band_hits=b.band_hits(),
+                          cutoffs=int(ev[2]["step"].size), band_hits=b.band_hits(), pair_stats=b.pair_stats(),
                           status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0)
         b.close()
         w5 = time.perf_counter()
@@ -148,6 +148,9 @@ def main():
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
                          "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
             "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
+            # the all-pairs streamer test, reported separately (base-point pairs per second of its kernel)
+            "pair_evaluations_per_s": counts["pair_stats"][0] / (float(np.mean(stage_ms["streamer_pairs"])) * 1e-3)
+            if stage_ms.get("streamer_pairs") else None,
             "host_wall_ms": {k: float(np.mean(v)) for k, v in wall.items()},
             "counts": counts,
         }
@@ -193,9 +196,37 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
         t_cpu += time.perf_counter() - tic
         for k, name in enumerate(("streamers", "overturnings", "cutoffs")):
             ok &= int((ev[k]["step"] == t).sum()) == len(ref[name])
-    return {"value": len(idx) / t_cpu, "unit": "timesteps/s", "cores": 1, "kind": "port",
-            "sample": "steps %s of the same device-generated batch, oracle.api.run_all (numpy, 1 thread), %.1f s"
-                      % (idx, t_cpu), "event_counts_match_gpu": bool(ok)}
+    out = {"value": len(idx) / t_cpu, "unit": "timesteps/s", "cores": 1, "kind": "port",
+           "sample": "steps %s of the same device-generated batch, oracle.api.run_all (numpy, 1 thread), %.1f s"
+                     % (idx, t_cpu), "event_counts_match_gpu": bool(ok)}
+    # the same restatement on all host cores (one time step per worker process, steps are independent); never the headline
+    try:
+        import multiprocessing as mp
+        ncores = len(os.sched_getaffinity(0))
+        nw = max(1, min(ncores, 32))
+        steps = [int(round(i)) for i in np.linspace(0, nt - 1, nw)]
+        jobs = []
+        for t in steps:
+            pv = ctx.to_host(d_pv, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4)
+            it = ctx.to_host(d_int, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4) if d_int else None
+            jobs.append((pv, it, levels, lat, lon))
+        with mp.get_context("spawn").Pool(nw) as pool:
+            pool.map(_cpu_step, jobs[:nw])                      # imports / warm-up in every worker
+            tic = time.perf_counter()
+            pool.map(_cpu_step, jobs)
+            t_all = time.perf_counter() - tic
+        out["all_cores"] = {"value": len(jobs) / t_all, "unit": "timesteps/s", "cores": nw, "host_cores": ncores,
+                            "sample": "%d steps, one per worker process, %.1f s" % (len(jobs), t_all)}
+    except Exception as e:                                       # a reported extra, never fatal
+        out["all_cores"] = {"error": repr(e)}
+    return out
+
+
+def _cpu_step(job):
+    pv, it, levels, lat, lon = job
+    from oracle import api as oapi
+    from oracle import synth
+    return len(oapi.run_all(pv, levels, lat, lon, synth.times(1), intensity=it)["streamers"])
 
 
 if __name__ == "__main__":

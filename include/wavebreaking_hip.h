@@ -117,6 +117,9 @@ int wb_get_contours(wb_batch* b, wb_contour_table* out);
 int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */
 int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont);            /* threshold guard-band re-evaluations */
+/* streamer all-pairs test of the last wb_indices: base-point pairs covered (sum of N(N-1)/2 over the selected contours,
+   streamer_index.py:130-157) and candidate pairs found */
+int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs);
 /* per-stage device times of the last wb_contours / wb_indices calls, measured with HIP events on the
    context's stream: names is a NUL-separated list */
 int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);

@@ -271,6 +271,7 @@ struct wb_batch {
     int nsel = 0, ncut = 0;
     int *sel_job = nullptr, *sel_cont = nullptr, *cut_job = nullptr, *cut_cont = nullptr;
     long long band[2] = {0, 0};
+    long long pair_stats[2] = {0, 0};       // base-point pairs covered by the all-pairs test / candidate pairs found
     // batches built from a user-supplied contour frame: one job per contour row
     std::vector<int> job_step, job_level;
     int* d_job_step = nullptr;
@@ -608,6 +609,13 @@ extern "C" int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont) {
     return 0;
 }
 
+extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs) {
+    if (!b) return 1;
+    *point_pairs = b->pair_stats[0];
+    *candidate_pairs = b->pair_stats[1];
+    return 0;
+}
+
 extern "C" int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n) {
     if (!b) return 1;
     b->timer.collect();
@@ -896,9 +904,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             WB_LAUNCH(wb_k_sel_lens, (nsel + 255) / 256, 256, nsel, cap, b->sel_job, b->sel_cont, b->c_len, d_lens);
             std::vector<int> lens(nsel);
             d2h(ctx, lens.data(), d_lens, nsel * sizeof(int));
+            b->pair_stats[0] = 0;
             for (int q = 0; q < nsel; ++q) {
                 h_poff[q + 1] = h_poff[q] + lens[q];
                 maxN = lens[q] > maxN ? lens[q] : maxN;
+                b->pair_stats[0] += (long long)lens[q] * (lens[q] - 1) / 2;      // base-point pairs the all-pairs test covers
             }
         }
         const long long NPT = h_poff[nsel];
@@ -954,7 +964,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             std::vector<int> np(nsel);
             d2h(ctx, np.data(), st.npairs, nsel * sizeof(int));
             int mx = 0;
-            for (int v : np) mx = v > mx ? v : mx;
+            b->pair_stats[1] = 0;
+            for (int v : np) { mx = v > mx ? v : mx; b->pair_stats[1] += v; }    // candidate pairs that pass both distance tests
             if (mx > cap_pairs && attempt < 3) {
                 bfree_one(b, st.pairs); bfree_one(b, st.alive); bfree_one(b, st.hkey); bfree_one(b, st.hval);
                 for (void* q : {(void*)st.pairs, (void*)st.alive, (void*)st.hkey, (void*)st.hval})
