@@ -81,6 +81,69 @@ WB_DEV inline int wb_hash_find(const unsigned long long* hkey, int hmask, unsign
 }
 
 
+// ---- compact tables.  When (contour, x, y) fits 32 bits the dedupe table holds ONE 64-bit word per entry,
+// key << 32 | position: an insert is a CAS into an empty slot or an atomicMin on a slot that already carries the key
+// (equal high halves, so the minimum is the smaller position); a probe touches one 8-byte word instead of a key and a
+// value array.  The set table of the periodic-duplicate rule shrinks to 32-bit keys the same way.
+#define WB_HEMPTY32 0xFFFFFFFFu
+#ifndef WB_TRACE_PACK
+#define WB_TRACE_PACK 1           // 0: always the two-array 64-bit-key tables (tests)
+#endif
+WB_DEV inline bool wb_hash_put_min(unsigned long long* tab, int hmask, uint32_t key, uint32_t pos) {
+    const unsigned long long mine = ((unsigned long long)key << 32) | pos;
+    uint32_t s = (uint32_t)wb_mix64(key) & (uint32_t)hmask;
+    for (int probe = 0; probe <= hmask; ++probe) {
+        unsigned long long cur = tab[s];
+        if (cur == WB_HEMPTY) {
+            cur = wb_atomic_cas(&tab[s], (unsigned long long)WB_HEMPTY, mine);
+            if (cur == WB_HEMPTY) return true;
+        }
+        if ((uint32_t)(cur >> 32) == key) { wb_atomic_min(&tab[s], mine); return true; }
+        s = (s + 1) & (uint32_t)hmask;
+    }
+    return false;
+}
+WB_DEV inline uint32_t wb_hash_get_min(const unsigned long long* tab, int hmask, uint32_t key) {
+    uint32_t s = (uint32_t)wb_mix64(key) & (uint32_t)hmask;
+    for (int probe = 0; probe <= hmask; ++probe) {
+        const unsigned long long cur = tab[s];
+        if (cur == WB_HEMPTY) return WB_NIL;
+        if ((uint32_t)(cur >> 32) == key) return (uint32_t)cur;
+        s = (s + 1) & (uint32_t)hmask;
+    }
+    return WB_NIL;
+}
+// 32-bit key set: returns 1 if this call created the entry, 0 if it was there, -1 if the table is full
+WB_DEV inline int wb_set32_insert(uint32_t* tab, int hmask, uint32_t key) {
+    uint32_t s = (uint32_t)wb_mix64(key) & (uint32_t)hmask;
+    for (int probe = 0; probe <= hmask; ++probe) {
+        uint32_t cur = tab[s];
+        if (cur == key) return 0;
+        if (cur == WB_HEMPTY32) {
+            cur = wb_atomic_cas(&tab[s], (uint32_t)WB_HEMPTY32, key);
+            if (cur == WB_HEMPTY32) return 1;
+            if (cur == key) return 0;
+        }
+        s = (s + 1) & (uint32_t)hmask;
+    }
+    return -1;
+}
+WB_DEV inline bool wb_set32_has(const uint32_t* tab, int hmask, uint32_t key) {
+    uint32_t s = (uint32_t)wb_mix64(key) & (uint32_t)hmask;
+    for (int probe = 0; probe <= hmask; ++probe) {
+        const uint32_t cur = tab[s];
+        if (cur == key) return true;
+        if (cur == WB_HEMPTY32) return false;
+        s = (s + 1) & (uint32_t)hmask;
+    }
+    return false;
+}
+WB_DEV inline int wb_bits_for(int n) {   // bits that hold every value in [0, n)
+    int b = 0;
+    while ((1 << b) < n) ++b;
+    return b;
+}
+
 #ifndef WB_TRACE_LDS_N
 #define WB_TRACE_LDS_N 8192      // jobs with at most this many segments take the LDS paths
 #endif
@@ -389,32 +452,61 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     WB_END_PFOR
 
     // ---- P5: order-preserving first-occurrence dedupe inside each contour
-    hsize = 1024;                  // dedupe: one key per raw point
-    while (hsize < 2 * R && hsize < a.hash_size) hsize <<= 1;
-    hmask = hsize - 1;
-    WB_PFOR(s, hsize)
-        hkey[s] = WB_HEMPTY;
-        hval[s] = WB_NIL;
-    WB_END_PFOR
     // A point equal to its predecessor in the same contour can never be a first occurrence: it is dropped without
-    // touching the table (about half of all raw points: neighbouring crossings that round to the same lattice point)
+    // touching the table (about half of all raw points: neighbouring crossings that round to the same lattice point).
+    // The table is sized to twice the keys that do go in (clearing and probing it is real HBM traffic).
+    WB_SHARED(int, nkeys, 1);
+    WB_SINGLE
+    nkeys[0] = 0;
+    WB_END_SINGLE
     WB_PFOR(p, R)
-        if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
-        int fresh;
-        const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
-        const int s = wb_hash_insert(hkey, hmask, key, &fresh);
-        if (s >= 0) wb_atomic_min(&hval[s], (uint32_t)p);
-        else wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+        wb_atomic_add_agg(nkeys, 0, (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) ? 0 : 1);
     WB_END_PFOR
-    WB_PFOR(p, R + 1)
-        int kp = 0;
-        if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
+    hsize = 1024;
+    while (hsize < 2 * nkeys[0] && hsize < a.hash_size) hsize <<= 1;
+    hmask = hsize - 1;
+    const int bx = wb_bits_for(a.W), by = wb_bits_for(a.nlat);
+    const bool pk5 = WB_TRACE_PACK && bx + by + wb_bits_for(C) <= 32;       // (contour, x, y) in 32 bits: one-word entries
+    if (pk5) {
+        WB_PFOR(s, hsize)
+            hkey[s] = WB_HEMPTY;
+        WB_END_PFOR
+        WB_PFOR(p, R)
+            if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
+            const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+            if (!wb_hash_put_min(hkey, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+        WB_END_PFOR
+        WB_PFOR(p, R + 1)
+            int kp = 0;
+            if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
+                const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+                kp = wb_hash_get_min(hkey, hmask, key) == (uint32_t)p ? 1 : 0;
+            }
+            keep[p] = kp;
+        WB_END_PFOR
+    } else {
+        WB_PFOR(s, hsize)
+            hkey[s] = WB_HEMPTY;
+            hval[s] = WB_NIL;
+        WB_END_PFOR
+        WB_PFOR(p, R)
+            if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
+            int fresh;
             const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
-            const int s = wb_hash_find(hkey, hmask, key);
-            kp = (s >= 0 && hval[s] == (uint32_t)p) ? 1 : 0;
-        }
-        keep[p] = kp;
-    WB_END_PFOR
+            const int s = wb_hash_insert(hkey, hmask, key, &fresh);
+            if (s >= 0) wb_atomic_min(&hval[s], (uint32_t)p);
+            else wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+        WB_END_PFOR
+        WB_PFOR(p, R + 1)
+            int kp = 0;
+            if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
+                const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
+                const int s = wb_hash_find(hkey, hmask, key);
+                kp = (s >= 0 && hval[s] == (uint32_t)p) ? 1 : 0;
+            }
+            keep[p] = kp;
+        WB_END_PFOR
+    }
     // keep[] becomes the exclusive scan = new position; remember the flags in t1 (bit per raw point
     // would do, but raw points can be 2*cap: use the rawcid high bit instead)
     WB_PFOR(p, R)
@@ -461,9 +553,18 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     hsize = 1024;                  // sets: at most two keys per surviving point
     while (hsize < 4 * (keep[R] + 1) && hsize < a.hash_size) hsize <<= 1;
     hmask = hsize - 1;
-    WB_PFOR(s, hsize)
-        hkey[s] = WB_HEMPTY;
-    WB_END_PFOR
+    const int bf = wb_bits_for(Ck);
+    const bool pk6 = WB_TRACE_PACK && bf + bx + by <= 30;                    // 32-bit set keys, bit 31 tags the x-only keys
+    uint32_t* set32 = hval;
+    if (pk6) {
+        WB_PFOR(s, hsize)
+            set32[s] = WB_HEMPTY32;
+        WB_END_PFOR
+    } else {
+        WB_PFOR(s, hsize)
+            hkey[s] = WB_HEMPTY;
+        WB_END_PFOR
+    }
     WB_PFOR(f, Ck)
         setsize[f] = 0;
         dropped[f] = 0;
@@ -474,13 +575,19 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
         if (f != WB_NIL) {
             const uint32_t pt = cpts[q];
             const int x = wb_pt_x(pt), y = wb_pt_y(pt);
-            int fresh;
-            const unsigned long long k1 = ((unsigned long long)f << 32) | (uint32_t)((x % a.nlon) | (y << 16));
-            if (wb_hash_insert(hkey, hmask, k1, &fresh) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-            if (fresh) wb_atomic_add_agg(setsize, (int)f, 1);
-            const unsigned long long k2 = (1ull << 63) | ((unsigned long long)f << 32) | (uint32_t)x;
-            if (wb_hash_insert(hkey, hmask, k2, &fresh) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-            if (fresh) wb_atomic_add(&c_nux[f], 1);
+            int fresh1, fresh2;
+            if (pk6) {
+                fresh1 = wb_set32_insert(set32, hmask, (f << (bx + by)) | ((uint32_t)y << bx) | (uint32_t)(x % a.nlon));
+                fresh2 = wb_set32_insert(set32, hmask, 0x80000000u | (f << bx) | (uint32_t)x);
+                if (fresh1 < 0 || fresh2 < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+            } else {
+                const unsigned long long k1 = ((unsigned long long)f << 32) | (uint32_t)((x % a.nlon) | (y << 16));
+                if (wb_hash_insert(hkey, hmask, k1, &fresh1) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+                const unsigned long long k2 = (1ull << 63) | ((unsigned long long)f << 32) | (uint32_t)x;
+                if (wb_hash_insert(hkey, hmask, k2, &fresh2) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+            }
+            if (fresh1 > 0) wb_atomic_add_agg(setsize, (int)f, 1);
+            if (fresh2 > 0) wb_atomic_add(&c_nux[f], 1);
             wb_atomic_add_agg(c_sumy, (int)f, y);
         }
     WB_END_PFOR
@@ -494,9 +601,14 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
         bool sub = true;
         for (int q = 0; q < l1 && sub; ++q) {
             const uint32_t pt = cpts[o1 + q];
-            const unsigned long long k1 =
-                ((unsigned long long)i2 << 32) | (uint32_t)((wb_pt_x(pt) % a.nlon) | (wb_pt_y(pt) << 16));
-            if (wb_hash_find(hkey, hmask, k1) < 0) sub = false;
+            if (pk6) {
+                sub = wb_set32_has(set32, hmask, ((uint32_t)i2 << (bx + by)) | ((uint32_t)wb_pt_y(pt) << bx) |
+                                                     (uint32_t)(wb_pt_x(pt) % a.nlon));
+            } else {
+                const unsigned long long k1 =
+                    ((unsigned long long)i2 << 32) | (uint32_t)((wb_pt_x(pt) % a.nlon) | (wb_pt_y(pt) << 16));
+                if (wb_hash_find(hkey, hmask, k1) < 0) sub = false;
+            }
         }
         if (sub) {
             const int l2 = c_len[i2];
