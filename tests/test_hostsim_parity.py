@@ -115,7 +115,7 @@ def test_bad_arguments_fail_loudly(sim):
 
 def test_big_job_paths_without_lds():
     # a build whose LDS threshold is tiny sends every job down the global-memory paths of the link / rank kernels
-    lib = _hip.Library(helpers.build_hostsim(variant="nolds", defines=("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0")), allow_hostsim=True)
+    lib = _hip.Library(helpers.build_hostsim(variant="nolds", defines=("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0", "WB_PROPS_LROWS=4", "WB_PROPS_PART=4")), allow_hostsim=True)
     ctx = _hip.Context(0, lib)
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(4, 2, lat, lon, eps=0.3)

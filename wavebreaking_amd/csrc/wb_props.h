@@ -18,6 +18,12 @@
 #endif
 
 enum { WB_EV_STREAMER = 0, WB_EV_OVERTURNING = 1, WB_EV_CUTOFF = 2 };
+#ifndef WB_PROPS_LROWS
+#define WB_PROPS_LROWS 160
+#endif
+#ifndef WB_PROPS_PART
+#define WB_PROPS_PART 192
+#endif
 
 struct WbPropsArgs {
     int nev, nslots, nlat, nlon, W, cap_seg, nlev, dtype, want_cells, pad;
@@ -54,11 +60,29 @@ WB_DEV inline uint32_t wb_event_vertex(const int* d, const uint32_t* pts, int k)
     return (uint32_t)x | ((uint32_t)y << 16);
 }
 
+// lattice point (x, y) closer than r to the segment a-b (exact integer projection, one division)
+WB_DEV inline bool wb_near_segment(int x, int y, int ax, int ay, int bx, int by, double r2) {
+    const long long dx = bx - ax, dy = by - ay, L = dx * dx + dy * dy;
+    const long long t = (long long)(x - ax) * dx + (long long)(y - ay) * dy;
+    if (L == 0 || t <= 0) return (double)((long long)(x - ax) * (x - ax) + (long long)(y - ay) * (y - ay)) < r2;
+    if (t >= L) return (double)((long long)(x - bx) * (x - bx) + (long long)(y - by) * (y - by)) < r2;
+    const long long cr = dx * (long long)(y - ay) - dy * (long long)(x - ax);
+    return ((double)cr * (double)cr) / (double)L < r2;
+}
+
+#define WB_PROPS_LONG 16
 WB_KERNEL(wb_k_props, WbPropsArgs a) {
+    WB_SHARED(int, longe, WB_PROPS_LONG);
+    WB_SHARED(int, nlong, 1);
     WB_SHARED(int, bb, 4);
     WB_SHARED(long long, sh_off, 1);
+    // per-row partial sums of the current event: in LDS when the event spans at most WB_PROPS_LROWS rows (the final
+    // accumulation over rows is sequential by contract; from global memory every row costs a dependent round trip)
+    WB_SHARED(double, lacc, 4 * WB_PROPS_LROWS);
+    WB_SHARED(double, lpart, 2 * WB_PROPS_PART);       // (data, intensity) partial sums of the box path's column chunks
     const int slot = WB_BLOCK_ID;
     int* cells = a.cells + (size_t)slot * a.W * a.nlat;
+    double* cells_d = (double*)cells;                     // box path, very wide boxes: chunk partials in the (then unused) cell scratch
     double* rowacc = a.rowacc + (size_t)slot * 4 * a.nlat;
     for (int e = WB_BLOCK_ID; e < a.nev; e += WB_GRID_DIM) {
         const int* d = a.ev + (size_t)e * 8;
@@ -70,6 +94,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 
         WB_SINGLE
         bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
+        nlong[0] = 0;
         WB_END_SINGLE
         WB_PFOR(k, n)
             const uint32_t v = wb_event_vertex(d, pts, (int)k);
@@ -78,11 +103,18 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             wb_atomic_max(&bb[2], wb_pt_x(v));
             wb_atomic_max(&bb[3], wb_pt_y(v));
         WB_END_PFOR
-        const int x0 = bb[0] - a.pad < 0 ? 0 : bb[0] - a.pad;
-        const int y0 = bb[1] - a.pad < 0 ? 0 : bb[1] - a.pad;
-        const int x1 = bb[2] + a.pad > a.W - 1 ? a.W - 1 : bb[2] + a.pad;
-        const int y1 = bb[3] + a.pad > a.nlat - 1 ? a.nlat - 1 : bb[3] + a.pad;
+        // An overturning event is an axis-parallel box (overturning_index.py:211): with r <= 1 its cells are exactly the
+        // lattice points of the closed box (every other lattice point is at least 1 away), so nothing is rasterised
+        const bool full = kind == WB_EV_OVERTURNING && a.r2 <= 1.0;
+        const int epad = full ? 0 : a.pad;
+        const int x0 = bb[0] - epad < 0 ? 0 : bb[0] - epad;
+        const int y0 = bb[1] - epad < 0 ? 0 : bb[1] - epad;
+        const int x1 = bb[2] + epad > a.W - 1 ? a.W - 1 : bb[2] + epad;
+        const int y1 = bb[3] + epad > a.nlat - 1 ? a.nlat - 1 : bb[3] + epad;
         const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
+        const bool lrow = rows <= WB_PROPS_LROWS;
+#define WB_ACC(q, y) (lrow ? lacc[(q) * WB_PROPS_LROWS + ((y) - y0)] : rowacc[(q) * a.nlat + (y)])
+        if (!full) {
         WB_PFOR(idx, (int64_t)rows * cols)
             cells[idx] = 0;
         WB_END_PFOR
@@ -141,6 +173,10 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 if (L == 0 && ax >= x0 && ax <= x1 && ay >= y0 && ay <= y1) cells[(size_t)(ax - x0) * rows + (ay - y0)] = 1;
                 continue;
             }
+            // long edge (a streamer's closing chord): its box can hold hundreds of lattice points -- queued and tested
+            // by the whole workgroup below; only if the queue is full does this lane walk the box itself
+            const int slot_e = wb_atomic_add(&nlong[0], 1);
+            if (slot_e < WB_PROPS_LONG) { longe[slot_e] = (int)k; continue; }
             int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
             int ey0 = (ay < by ? ay : by) - a.pad, ey1 = (ay < by ? by : ay) + a.pad;
             if (ex0 < x0) ex0 = x0;
@@ -148,20 +184,73 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             if (ey0 < y0) ey0 = y0;
             if (ey1 > y1) ey1 = y1;
             for (int y = ey0; y <= ey1; ++y)
-                for (int x = ex0; x <= ex1; ++x) {
-                    const long long t = (long long)(x - ax) * dx + (long long)(y - ay) * dy;
-                    bool near;
-                    if (L == 0 || t <= 0) {
-                        near = (double)((long long)(x - ax) * (x - ax) + (long long)(y - ay) * (y - ay)) < a.r2;
-                    } else if (t >= L) {
-                        near = (double)((long long)(x - bx) * (x - bx) + (long long)(y - by) * (y - by)) < a.r2;
-                    } else {
-                        const long long cr = dx * (long long)(y - ay) - dy * (long long)(x - ax);
-                        near = ((double)cr * (double)cr) / (double)L < a.r2;
-                    }
-                    if (near) cells[(size_t)(x - x0) * rows + (y - y0)] = 1;
-                }
+                for (int x = ex0; x <= ex1; ++x)
+                    if (wb_near_segment(x, y, ax, ay, bx, by, a.r2)) cells[(size_t)(x - x0) * rows + (y - y0)] = 1;
         WB_END_PFOR
+        {
+            const int nq = nlong[0] < WB_PROPS_LONG ? nlong[0] : WB_PROPS_LONG;
+            for (int qe = 0; qe < nq; ++qe) {
+                const int k = longe[qe];
+                const uint32_t va = wb_event_vertex(d, pts, k), vb = wb_event_vertex(d, pts, (k + 1) % n);
+                const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+                int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
+                int ey0 = (ay < by ? ay : by) - a.pad, ey1 = (ay < by ? by : ay) + a.pad;
+                if (ex0 < x0) ex0 = x0;
+                if (ex1 > x1) ex1 = x1;
+                if (ey0 < y0) ey0 = y0;
+                if (ey1 > y1) ey1 = y1;
+                const int ew = ex1 - ex0 + 1, eh = ey1 - ey0 + 1;
+                if (ew <= 0 || eh <= 0) continue;                        // block-uniform
+                WB_PFOR(c, (int64_t)ew * eh)
+                    const int x = ex0 + (int)(c / eh), y = ey0 + (int)(c % eh);
+                    if (wb_near_segment(x, y, ax, ay, bx, by, a.r2)) cells[(size_t)(x - x0) * rows + (y - y0)] = 1;
+                WB_END_PFOR
+            }
+        }
+        }   // !full
+        if (full) {
+            // D for boxes: every cell counts, so the integer sums are closed forms and the field sums are taken in tasks
+            // of 8 consecutive columns of one row with adjacent lanes on adjacent chunks (lane-per-row reads touch 64
+            // different DRAM rows per instruction and run at the chip's random-sector rate); a row's chunk partials are
+            // then added in ascending x by the lane that owns the row.
+            const int nch = (cols + 7) >> 3;
+            int rblk = WB_PROPS_PART / nch;
+            if (rblk < 1) rblk = 1;
+            for (int rb = 0; rb < rows; rb += rblk) {
+                const int nr = rows - rb < rblk ? rows - rb : rblk;
+                WB_PFOR(t, (int64_t)nr * nch)
+                    const int rr = rb + (int)(t / nch), ch = (int)(t % nch);
+                    const int y = y0 + rr;
+                    double sv = 0.0, si = 0.0;
+                    double dv[8], di[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int gx = x0 + ch * 8 + q;
+                        const bool in = ch * 8 + q < cols;
+                        const size_t idx = tbase + (size_t)y * a.nlon + (size_t)((gx < a.W ? gx : a.W - 1) % a.nlon);
+                        dv[q] = in ? wb_load_field(a.data, idx, a.dtype) : 0.0;
+                        di[q] = (in && a.intensity) ? wb_load_field(a.intensity, idx, a.dtype) : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (ch * 8 + q < cols) { sv += dv[q]; si += di[q]; }
+                    if (nch <= WB_PROPS_PART) { lpart[2 * t] = sv; lpart[2 * t + 1] = si; }
+                    else { cells_d[2 * ((size_t)rr * nch + ch)] = sv; cells_d[2 * ((size_t)rr * nch + ch) + 1] = si; }
+                WB_END_PFOR
+                WB_PFOR(r2, nr)
+                    const int rr = rb + (int)r2, y = y0 + rr;
+                    double sv = 0.0, si = 0.0;
+                    for (int ch = 0; ch < nch; ++ch) {
+                        if (nch <= WB_PROPS_PART) { sv += lpart[2 * (r2 * nch + ch)]; si += lpart[2 * (r2 * nch + ch) + 1]; }
+                        else { sv += cells_d[2 * ((size_t)rr * nch + ch)]; si += cells_d[2 * ((size_t)rr * nch + ch) + 1]; }
+                    }
+                    WB_ACC(0, y) = (double)cols;
+                    WB_ACC(1, y) = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
+                    WB_ACC(2, y) = sv;
+                    WB_ACC(3, y) = si;
+                WB_END_PFOR
+            }
+        } else {
         // D: per-row counts and sums
         WB_PFOR(rr, rows)
             const int y = y0 + (int)rr;
@@ -172,7 +261,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 int fl[8];
                 double dv[8], di[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) fl[q] = (x + q < cols) ? col[(size_t)(x + q) * rows] : 0;
+                for (int q = 0; q < 8; ++q) fl[q] = (x + q < cols) ? (full ? 1 : col[(size_t)(x + q) * rows]) : 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {                       // field loads of the whole chunk, in flight together
                     const int gx = x0 + x + q;
@@ -190,23 +279,24 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                     }
                 }
             }
-            rowacc[0 * a.nlat + y] = (double)cnt;
-            rowacc[1 * a.nlat + y] = (double)sx;
-            rowacc[2 * a.nlat + y] = sv;
-            rowacc[3 * a.nlat + y] = si;
+            WB_ACC(0, y) = (double)cnt;
+            WB_ACC(1, y) = (double)sx;
+            WB_ACC(2, y) = sv;
+            WB_ACC(3, y) = si;
         WB_END_PFOR
+        }   // full / generic D
         WB_SINGLE
         double areas = 0.0, mv = 0.0, it = 0.0, xc = 0.0, yc = 0.0;
         long long nc = 0;
         for (int y = y0; y <= y1; ++y) {
-            const double cnt = rowacc[0 * a.nlat + y];
+            const double cnt = WB_ACC(0, y);
             if (cnt == 0.0) continue;
             const double w = a.wlat[y];
             areas = areas + w * cnt;
-            xc = xc + w * rowacc[1 * a.nlat + y];
+            xc = xc + w * WB_ACC(1, y);
             yc = yc + w * ((double)y * cnt);
-            mv = mv + w * rowacc[2 * a.nlat + y];
-            it = it + w * rowacc[3 * a.nlat + y];
+            mv = mv + w * WB_ACC(2, y);
+            it = it + w * WB_ACC(3, y);
             nc += (long long)cnt;
         }
         a.ev_sums[(size_t)e * 5 + 0] = areas;
@@ -222,8 +312,8 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             // per-row start offsets (rows ascending, x ascending inside a row)
             long long run = off;
             for (int y = y0; y <= y1; ++y) {
-                const double cnt = rowacc[0 * a.nlat + y];
-                rowacc[0 * a.nlat + y] = (double)run;
+                const double cnt = WB_ACC(0, y);
+                WB_ACC(0, y) = (double)run;
                 run += (long long)cnt;
             }
             a.ev_cell_off[e] = off;
@@ -234,10 +324,11 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             WB_PFOR(rr, rows)
                 const int y = y0 + (int)rr;
                 const int* col = cells + rr;
-                long long o = (long long)rowacc[0 * a.nlat + y];
+                long long o = (long long)WB_ACC(0, y);
                 for (int x = 0; x < cols; ++x)
-                    if (col[(size_t)x * rows]) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
+                    if (full || col[(size_t)x * rows]) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
             WB_END_PFOR
         }
+#undef WB_ACC
     }
 }
