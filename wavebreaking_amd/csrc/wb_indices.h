@@ -536,6 +536,8 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
 // routine 2: check_intersections (:185-200): one lane per candidate pair; contour blocks whose bounding box
 // misses the chord's box are skipped, the rest is tested segment by segment with the exact predicate.
 #define WB_F2_THREADS 256
+#define WB_F2_SUP 8
+#define WB_F2_SUPMAX 64
 WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk_first) {
     // work list built on the host from the pair counts: workgroup w tests pairs [blk_first[w], +256) of contour blk_sel[w]
     const int s = blk_sel[WB_BLOCK_ID];
@@ -551,6 +553,21 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk
     const int P = a.npairs[s];
     const int p0 = blk_first[WB_BLOCK_ID];
     if (p0 >= P) return;
+    // second level of boxes: one per WB_F2_SUP consecutive blocks (a chord's box meets a handful of them)
+    WB_SHARED(int, sbb, 4 * WB_F2_SUPMAX);
+    const int nsup = (nblk + WB_F2_SUP - 1) / WB_F2_SUP;
+    const bool two = nsup <= WB_F2_SUPMAX;
+    if (two) {
+        WB_PFOR(sb, nsup)
+            int v0 = 0x7FFFFFFF, v1 = -1, v2 = 0x7FFFFFFF, v3 = -1;
+            for (int b = (int)sb * WB_F2_SUP; b < ((int)sb + 1) * WB_F2_SUP && b < nblk; ++b) {
+                const int* bb = bbx + 4 * b;
+                v0 = bb[0] < v0 ? bb[0] : v0; v1 = bb[1] > v1 ? bb[1] : v1;
+                v2 = bb[2] < v2 ? bb[2] : v2; v3 = bb[3] > v3 ? bb[3] : v3;
+            }
+            sbb[4 * sb] = v0; sbb[4 * sb + 1] = v1; sbb[4 * sb + 2] = v2; sbb[4 * sb + 3] = v3;
+        WB_END_PFOR
+    }
     WB_PFOR(pp, WB_F2_THREADS)
         const int p = p0 + (int)pp;
         if (p >= P || !alive[p]) continue;
@@ -559,6 +576,10 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk
         const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
         bool hit = false;
         for (int b = 0; b < nblk && !hit; ++b) {
+            if (two && (b % WB_F2_SUP) == 0) {
+                const int* sq = sbb + 4 * (b / WB_F2_SUP);
+                if (sq[0] > cx1 || sq[1] < cx0 || sq[2] > cy1 || sq[3] < cy0) { b += WB_F2_SUP - 1; continue; }
+            }
             const int* bb = bbx + 4 * b;
             if (bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0) continue;
             const int mlo = b * WB_BLK, mhi = mlo + WB_BLK < N - 1 ? mlo + WB_BLK : N - 1;   // segments mlo .. mhi-1
