@@ -923,6 +923,30 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         st.bbx = (int*)talloc((size_t)((NPT >> 5) + nsel + 1) * 4 * sizeof(int));
         st.tbx = (int*)talloc((size_t)((NPT >> 4) + nsel + 1) * 4 * sizeof(int));
         st.dy_max = (int)floor(p.geo_dis / (6371.0 * p.dlat * (M_PI / 180.0))) + 1;
+        {   // per latitude row: the largest |dx| (index units) at which a partner within dy_max rows can still be closer
+            // than geo_dis -- haversine >= cos(phi_i) cos(phi_j) sin^2(dlambda / 2) -- capped by the reference's 120
+            std::vector<int> dxl(p.nlat, 120);
+            const double dlr = p.dlon * (M_PI / 180.0);
+            if (120.0 * p.dlon <= 180.0) {                               // sin^2 is monotonic over the whole window
+                for (int y = 0; y < p.nlat; ++y) {
+                    double cm = 1.0;                                     // the partner row that allows most: smallest cosine
+                    for (int y2 = y - st.dy_max < 0 ? 0 : y - st.dy_max; y2 <= y + st.dy_max && y2 < p.nlat; ++y2) {
+                        const double c2 = cos(b->lat[y2] * (M_PI / 180.0));
+                        cm = c2 < cm ? c2 : cm;
+                    }
+                    const double den = cos(b->lat[y] * (M_PI / 180.0)) * cm;
+                    if (!(den > 0.0)) continue;
+                    const double ratio = st.hthr * (1.0 + 1e-9) / den;
+                    if (ratio >= 1.0) continue;
+                    const double lim = floor(2.0 * asin(sqrt(ratio)) / dlr) + 2.0;
+                    if (lim < 120.0) dxl[y] = (int)lim;
+                }
+            }
+            int* d_dxl = (int*)talloc(p.nlat * sizeof(int));
+            if (!d_dxl) return 1;
+            h2d(ctx, d_dxl, dxl.data(), p.nlat * sizeof(int));
+            st.dxlim = d_dxl;
+        }
         st.npairs = (int*)talloc(nsel * sizeof(int));
         st.stage = (int*)talloc(nsel * sizeof(int));
         st.nalive = (int*)talloc(nsel * sizeof(int));

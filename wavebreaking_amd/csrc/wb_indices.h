@@ -235,6 +235,7 @@ struct WbStreamerArgs {
                                // contour s owns blocks [(poff[s] >> 5) + s, ...)
     int* tbx;                  // per tile of WB_PAIR_ROWS rows: xmin, xmax, ymin, ymax; contour s owns tiles [(poff[s] >> 4) + s, ...)
     int dy_max;                // |y_i - y_j| above this cannot be within geo_dis (R * dphi <= geo)
+    const int* dxlim;          // [nlat] |x_i - x_j| above this cannot be within geo_dis for a base point in row y (<= 120)
     unsigned long long* pairs; // [nsel][cap_pairs] (ind1 << 32 | ind2)
     int* alive;                // [nsel][cap_pairs]
     int* npairs;               // [nsel]
@@ -374,6 +375,7 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* 
     WB_SHARED(double, ri, WB_PAIR_ROWS * 6);
     WB_SHARED(int, rx, WB_PAIR_ROWS);
     WB_SHARED(int, ry, WB_PAIR_ROWS);
+    WB_SHARED(int, rl, WB_PAIR_ROWS);
 
     const int tile_begin = blk_tile0[WB_BLOCK_ID];
     for (int tile = tile_begin; tile < tile_begin + tiles_per_block; ++tile) {
@@ -382,7 +384,10 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* 
     const int i1 = i0 + WB_PAIR_ROWS < N - 1 ? i0 + WB_PAIR_ROWS : N - 1;   // rows i0 .. i1-1
     WB_SINGLE
     const int* tb4 = a.tbx + 4 * ((po >> 4) + s) + 4 * tile;     // box of rows i0 .. i0+15 (a superset of i0 .. i1-1)
-    tb[0] = tb4[0] - 120; tb[1] = tb4[1] + 120; tb[2] = tb4[2] - a.dy_max; tb[3] = tb4[3] + a.dy_max;
+    // dxlim grows with |latitude|: over the tile's rows it is largest at one of the two ends of their y range
+    const int ya = tb4[2] < 0 ? 0 : (tb4[2] > a.nlat - 1 ? a.nlat - 1 : tb4[2]), yb = tb4[3] < 0 ? 0 : (tb4[3] > a.nlat - 1 ? a.nlat - 1 : tb4[3]);
+    const int ml = a.dxlim[ya] > a.dxlim[yb] ? a.dxlim[ya] : a.dxlim[yb];
+    tb[0] = tb4[0] - ml; tb[1] = tb4[1] + ml; tb[2] = tb4[2] - a.dy_max; tb[3] = tb4[3] + a.dy_max;
     nlist[0] = 0;
     WB_END_SINGLE
     const bool use_list = nblk <= WB_MAX_BLOCKS;
@@ -407,6 +412,7 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* 
         ri[6 * ii + 3] = t_sl[i]; ri[6 * ii + 4] = t_cl[i]; ri[6 * ii + 5] = pre[i];
         rx[ii] = wb_pt_x(pts[i]);
         ry[ii] = wb_pt_y(pts[i]);
+        rl[ii] = a.dxlim[wb_pt_y(pts[i])];
     WB_END_PFOR
     WB_PFOR(idx, (int64_t)nb * WB_BLK)
         const int bsel = (int)(idx / WB_BLK), jj = (int)(idx % WB_BLK);
@@ -419,7 +425,7 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* 
             if (j <= i) break;                                        // only j > i
             int dx = rx[ii] - xj;
             if (dx < 0) dx = -dx;
-            if (dx > 120) continue;                                   // streamer_index.py:157
+            if (dx > rl[ii]) continue;                                // streamer_index.py:157 (<= 120) and the row's geo_dis reach
             int dy = ry[ii] - yj;
             if (dy < 0) dy = -dy;
             if (dy > a.dy_max) continue;                              // R * |dphi| alone already exceeds geo_dis
