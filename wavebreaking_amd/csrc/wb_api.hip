@@ -64,20 +64,37 @@ static double wb_now_ms() {
 static bool wb_debug() { static int v = -1; if (v < 0) v = getenv("WB_DEBUG_TIMING") ? 1 : 0; return v == 1; }
 #define WB_TICK(label) do { if (wb_debug()) { double t_ = wb_now_ms(); fprintf(stderr, "[wb] %-28s %9.3f ms\n", label, t_ - wb_t0_); wb_t0_ = t_; } } while (0)
 
-static void* hmalloc(wb_ctx* c, size_t bytes) {
-    bytes = (bytes + 4095) & ~(size_t)4095;
-    auto it = c->hpool.lower_bound(bytes);
-    if (it != c->hpool.end() && it->first <= 2 * bytes + (1u << 20)) {
+// Host buffers of the big result arrays (polygon vertices).  Product build: PINNED memory, so the device-to-host copy
+// lands in them directly (through the staging buffer it costs a second pass over the data on the host, ~0.3 ms per
+// array and batch); pinning is expensive, so blocks are rounded up to a power of two and recycled by the context.
+static void* hmalloc(wb_ctx* c, size_t bytes, size_t* got) {
+    size_t want = (size_t)1 << 20;
+    while (want < bytes) want <<= 1;
+    *got = want;
+    auto it = c->hpool.find(want);
+    if (it != c->hpool.end()) {
         void* p = it->second;
         c->hpool.erase(it);
         return p;
     }
-    return malloc(bytes);
+#if defined(WB_HOSTSIM)
+    return malloc(want);
+#else
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+#endif
+}
+static void hrelease(void* p) {
+#if defined(WB_HOSTSIM)
+    free(p);
+#else
+    (void)hipHostFree(p);
+#endif
 }
 static void hfree(wb_ctx* c, void* p, size_t bytes) {
     if (!p) return;
-    bytes = (bytes + 4095) & ~(size_t)4095;
-    if (c->hpool.size() < 16) c->hpool.insert({bytes, p}); else free(p);
+    if (c->hpool.size() < 8) c->hpool.insert({bytes, p}); else hrelease(p);
 }
 
 static int wb_fail(wb_ctx* c, const std::string& m) {
@@ -91,6 +108,7 @@ static void dfree(wb_ctx*, void* p) { free(p); }
 static int dmemset(wb_ctx*, void* p, int v, size_t bytes) { memset(p, v, bytes); return 0; }
 static int h2d(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
 static int d2h(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
+static int d2h_pinned(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
 static int dsync(wb_ctx*) { return 0; }
 #else
 static void* dmalloc(wb_ctx* c, size_t bytes) {
@@ -170,6 +188,10 @@ static int d2h(wb_ctx* c, void* d, const void* s, size_t b) {
         }
         return 0;
     }
+    return hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
+}
+// destination is pinned host memory: no staging
+static int d2h_pinned(wb_ctx* c, void* d, const void* s, size_t b) {
     return hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
 }
 static int dsync(wb_ctx* c) {
@@ -347,7 +369,7 @@ int wb_create(int device_id, wb_ctx** out) {
 
 void wb_destroy(wb_ctx* c) {
     if (!c) return;
-    for (auto& kv : c->hpool) free(kv.second);
+    for (auto& kv : c->hpool) hrelease(kv.second);
 #if !defined(WB_HOSTSIM)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
@@ -817,10 +839,16 @@ static void make_tables(wb_batch* b) {
         slam2[x] = sin(0.5 * lonrad[x]);
         clam2[x] = cos(0.5 * lonrad[x]);
     }
-    b->d_lat = upload(b, b->lat);
-    b->d_latrad = upload(b, latrad); b->d_lonrad = upload(b, lonrad);
-    b->d_sphi2 = upload(b, sphi2); b->d_cphi2 = upload(b, cphi2); b->d_cphi = upload(b, cphi);
-    b->d_slam2 = upload(b, slam2); b->d_clam2 = upload(b, clam2); b->d_wlat = upload(b, wlat);
+    // one transfer for all nine tables (every separate small copy costs ~25 us of launch and synchronisation)
+    std::vector<double> all;
+    all.reserve((size_t)6 * p.nlat + (size_t)3 * p.nlon);
+    auto put = [&](const std::vector<double>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); return o; };
+    const size_t o_lat = put(b->lat), o_latrad = put(latrad), o_sphi2 = put(sphi2), o_cphi2 = put(cphi2), o_cphi = put(cphi),
+                 o_wlat = put(wlat), o_lonrad = put(lonrad), o_slam2 = put(slam2), o_clam2 = put(clam2);
+    double* base = upload(b, all);
+    b->d_lat = base + o_lat; b->d_latrad = base + o_latrad; b->d_sphi2 = base + o_sphi2; b->d_cphi2 = base + o_cphi2;
+    b->d_cphi = base + o_cphi; b->d_wlat = base + o_wlat; b->d_lonrad = base + o_lonrad; b->d_slam2 = base + o_slam2;
+    b->d_clam2 = base + o_clam2;
 }
 
 extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
@@ -928,13 +956,13 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             std::vector<int> dxl(p.nlat, 120);
             const double dlr = p.dlon * (M_PI / 180.0);
             if (120.0 * p.dlon <= 180.0) {                               // sin^2 is monotonic over the whole window
+                std::vector<double> cl(p.nlat);
+                for (int y = 0; y < p.nlat; ++y) cl[y] = cos(b->lat[y] * (M_PI / 180.0));
                 for (int y = 0; y < p.nlat; ++y) {
-                    double cm = 1.0;                                     // the partner row that allows most: smallest cosine
-                    for (int y2 = y - st.dy_max < 0 ? 0 : y - st.dy_max; y2 <= y + st.dy_max && y2 < p.nlat; ++y2) {
-                        const double c2 = cos(b->lat[y2] * (M_PI / 180.0));
-                        cm = c2 < cm ? c2 : cm;
-                    }
-                    const double den = cos(b->lat[y] * (M_PI / 180.0)) * cm;
+                    // the partner row that allows most has the smallest cosine: one of the two ends of the window
+                    const int ya = y - st.dy_max < 0 ? 0 : y - st.dy_max, yb = y + st.dy_max > p.nlat - 1 ? p.nlat - 1 : y + st.dy_max;
+                    const double cm = cl[ya] < cl[yb] ? cl[ya] : cl[yb];
+                    const double den = cl[y] * cm;
                     if (!(den > 0.0)) continue;
                     const double ratio = st.hthr * (1.0 + 1e-9) / den;
                     if (ratio >= 1.0) continue;
@@ -1106,13 +1134,13 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                     h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
                     WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_px, d_py);
                     b->poly_n = (size_t)h_poff[NE];
-                    b->poly_bytes = (b->poly_n + 1) * sizeof(int32_t);
-                    b->poly_x = (int32_t*)hmalloc(ctx, b->poly_bytes);
-                    b->poly_y = (int32_t*)hmalloc(ctx, b->poly_bytes);
+                    size_t want = (b->poly_n + 1) * sizeof(int32_t);
+                    b->poly_x = (int32_t*)hmalloc(ctx, want, &b->poly_bytes);
+                    b->poly_y = (int32_t*)hmalloc(ctx, want, &b->poly_bytes);
                     if (!b->poly_x || !b->poly_y) return wb_fail(ctx, "out of host memory");
                     if (b->poly_n) {
-                        d2h(ctx, b->poly_x, d_px, b->poly_n * sizeof(int));
-                        d2h(ctx, b->poly_y, d_py, b->poly_n * sizeof(int));
+                        if (d2h_pinned(ctx, b->poly_x, d_px, b->poly_n * sizeof(int)) ||
+                            d2h_pinned(ctx, b->poly_y, d_py, b->poly_n * sizeof(int))) return 1;
                     }
                 }
                 return 0;
