@@ -43,7 +43,7 @@ struct wb_ctx {
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
-    hipEvent_t fork = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
     // (measured: 0.7 ms for the first pass's ~40 allocations, 350 ms for every later pass), so blocks are
     // kept for the life of the context and handed out again by size
@@ -358,7 +358,8 @@ int wb_create(int device_id, wb_ctx** out) {
     }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return 1;
     }
@@ -378,6 +379,7 @@ void wb_destroy(wb_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
 #endif
     delete c;
 }
@@ -902,9 +904,20 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         oa.rg_over_dlon = p.range_group / p.dlon; oa.minexp_over_dlon = p.ot_min_exp / p.dlon;
         oa.sel_job = b->sel_job; oa.sel_cont = b->sel_cont; oa.c_off = b->c_off; oa.c_len = b->c_len; oa.cpts = b->cpts;
         oa.lat = b->d_lat; oa.ot_n = ot_n; oa.ot_box = ot_box; oa.ot_orient = ot_orient; oa.status = b->status;
+        // independent of the streamer chain: runs on the side stream, under the chain's kernels and the host's
+        // work-list building between them; joined before its counts are read
+#if !defined(WB_HOSTSIM)
+        (void)hipEventRecord(ctx->fork, ctx->stream);
+        (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
+        std::swap(ctx->stream, ctx->stream2);
+#endif
         b->timer.begin(ctx, "overturn");
         WB_LAUNCH(wb_k_overturn, nsel, 256, oa);
         b->timer.end(ctx);
+#if !defined(WB_HOSTSIM)
+        (void)hipEventRecord(ctx->join, ctx->stream);
+        std::swap(ctx->stream, ctx->stream2);
+#endif
     }
 
     // ---- streamers
@@ -1062,6 +1075,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     // ---- event list (streamers, overturnings, cutoffs), then cells + sums
     std::vector<int> h_evn(nsel, 0), h_otn(nsel, 0), sbase(nsel + 1, 0), obase(nsel + 1, 0);
     if (ev_n) d2h(ctx, h_evn.data(), ev_n, nsel * sizeof(int));
+#if !defined(WB_HOSTSIM)
+    if (ot_n) (void)hipStreamWaitEvent(ctx->stream, ctx->join, 0);
+#endif
     if (ot_n) d2h(ctx, h_otn.data(), ot_n, nsel * sizeof(int));
     for (int s = 0; s < nsel; ++s) { sbase[s + 1] = sbase[s] + h_evn[s]; obase[s + 1] = obase[s] + h_otn[s]; }
     const int NS = sbase[nsel], NO = obase[nsel], NCU = ncut, NE = NS + NO + NCU;
