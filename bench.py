@@ -32,14 +32,16 @@ HBM_MEASURED = 6.29e12     # float4 copy
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nt", type=int, default=int(os.environ.get("WB_BENCH_NT", 1460)), help="time steps per GPU per pass")
     ap.add_argument("--dlon", type=float, default=0.25)
     ap.add_argument("--eps", type=float, default=0.0, help="cell noise amplitude (0 = smoothed PV, 0.3 = rough)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 4)),
                     help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-intensity", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("WB_BENCH_STREAMS", 2)),
+                    help="batches in flight per GPU (contexts = HIP streams + host threads); 1 = strictly one after the other")
     return ap.parse_args()
 
 
@@ -62,7 +64,9 @@ def main():
     from wavebreaking_amd import _hip
     from wavebreaking_amd import distributed as wd
 
-    ctx = _hip.Context(local)
+    from wavebreaking_amd.pipeline import BatchPipeline
+    pipe = BatchPipeline(local, depth=a.streams)        # a.streams batches in flight, one context (stream + thread) each
+    ctx = pipe.contexts[0]
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
     levels = [-2.0, 2.0]
@@ -83,43 +87,72 @@ def main():
 
     stage_ms = {}
     counts = {}
-
     wall = {}
 
-    def one_pass(collect=False, copy=False):
+    # one step = one pass of the hot path over the resident batch; the two ABI phases run on a worker thread of the
+    # pass's context, the two exchanges of a multi-GPU run on this thread in pass order (wavebreaking_amd/pipeline.py)
+    def phase1(c, k):
         w0 = time.perf_counter()
-        b = ctx.contours(d_pv, lat, lon, levels, a.dlon, a.dlon, intensity=d_int, device_shape=(nt, nlat, nlon),
-                         device_dtype=np.float32, want_cells=False)
+        b = c.contours(d_pv, lat, lon, levels, a.dlon, a.dlon, intensity=d_int, device_shape=(nt, nlat, nlon),
+                       device_dtype=np.float32, want_cells=False)
+        b._wall1 = 1e3 * (time.perf_counter() - w0)
+        return b
+
+    def reduce_max(m):
+        return wd.global_max_nux(m, dist if world > 1 else None)                # exchange (1): one int32 all-reduce(max)
+
+    def phase2(c, k, b, g, copy=False):
         w1 = time.perf_counter()
-        g = wd.global_max_nux(b.max_nux(), dist if world > 1 else None)     # exchange (1): one int32 all-reduce(max)
         b.indices(g)
         w2 = time.perf_counter()
-        ev = [b.events(k, copy=copy) for k in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
+        ev = [b.events(i, copy=copy) for i in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
         w3 = time.perf_counter()
-        if world > 1:                                                          # exchange (2): one gather to rank 0
-            wd.gather_event_tables([wd.pack_events(e, step_offset=t0) for e in ev], dist, dst=0)
-        w4 = time.perf_counter()
-        if collect:
-            for name, ms in b.timings():
-                stage_ms.setdefault(name, []).append(ms)
-            counts.update(polygon_vertices=int(sum(e["poly_x"].size for e in ev)),
-                          streamers=int(ev[0]["step"].size), overturnings=int(ev[1]["step"].size),
-                          cutoffs=int(ev[2]["step"].size), band_hits=b.band_hits(), pair_stats=b.pair_stats(),
-                          status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0)
+        res = dict(timings=b.timings(),
+                   counts=dict(polygon_vertices=int(sum(e["poly_x"].size for e in ev)), streamers=int(ev[0]["step"].size),
+                               overturnings=int(ev[1]["step"].size), cutoffs=int(ev[2]["step"].size),
+                               band_hits=b.band_hits(), pair_stats=b.pair_stats(),
+                               status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
+                   packed=[wd.pack_events(e, step_offset=t0) for e in ev] if world > 1 else None,
+                   events=ev if copy else None)
         b.close()
-        w5 = time.perf_counter()
-        if collect:
-            for k, v in (("contours_call", w1 - w0), ("indices_call", w2 - w1), ("tables_call", w3 - w2),
-                         ("gather", w4 - w3), ("free", w5 - w4)):
-                wall.setdefault(k, []).append(1e3 * v)
-        return ev
+        res["wall"] = dict(contours_call=b._wall1, indices_call=1e3 * (w2 - w1), tables_call=1e3 * (w3 - w2),
+                           free=1e3 * (time.perf_counter() - w3))
+        return res
 
-    for _ in range(a.warmup):
-        one_pass()
+    def collect_pass(keep):
+        def collect(k, res):
+            w = time.perf_counter()
+            if world > 1:                                                      # exchange (2): one gather to rank 0
+                wd.gather_event_tables(res["packed"], dist, dst=0)
+            if keep:
+                for name, ms in res["timings"]:
+                    stage_ms.setdefault(name, []).append(ms)
+                counts.update(res["counts"])
+                for kk, v in res["wall"].items():
+                    wall.setdefault(kk, []).append(v)
+                wall.setdefault("gather", []).append(1e3 * (time.perf_counter() - w))
+            return res
+        return collect
+
+    def solo_pass(c, copy=False):
+        """a single pass alone on the device"""
+        b = phase1(c, 0)
+        return phase2(c, 0, b, reduce_max(b.max_nux()), copy=copy)
+
+    def one_pass(copy=False):
+        return solo_pass(ctx, copy)
+
+    # setup, like the field allocation: the first pass of a context allocates its device scratch; the last of these
+    # passes also gives the scan kernel's duration with nothing else on the device
+    for c in pipe.contexts[1:]:
+        solo_pass(c)
+    solo = solo_pass(ctx)
+    solo = solo_pass(ctx)
+    solo_scan_ms = dict(solo["timings"]).get("scan", float("nan"))
+    pipe.run(a.warmup, phase1, reduce_max, phase2, collect_pass(False))
     barrier()
     tic = time.perf_counter()
-    for _ in range(a.steps):
-        one_pass(collect=True)
+    pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True))
     barrier()
     dt = time.perf_counter() - tic
     if world > 1:
@@ -142,10 +175,14 @@ def main():
                                    "streamers+overturnings+cutoffs, intensity field %s (BASELINE.json configs[2])"
                                    % (nt, "off" if a.no_intensity else "on"),
                        "nt_per_gpu": nt, "grid": [nlat, nlon], "levels": levels, "eps": a.eps,
-                       "parallelism": "time-sharded x%d" % world},
+                       "parallelism": "time-sharded x%d, %d batches in flight per GPU" % (world, pipe.depth)},
             "roofline": {"bound": "hbm", "kernel": "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(nt),
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
+                         # the same kernel with nothing else on the device (one pass before the warm-up); in the timed
+                         # region it shares HBM with the other batch's kernels
+                         "launch_ms_alone": solo_scan_ms, "achieved_alone": nt * bytes_per_ts / (solo_scan_ms * 1e-3) / 1e9,
+                         "frac_alone": nt * bytes_per_ts / (solo_scan_ms * 1e-3) / HBM_PEAK,
                          "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
             "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
             # the all-pairs streamer test, reported separately (base-point pairs per second of its kernel)
@@ -157,6 +194,7 @@ def main():
         if world == 1 and a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass)
         print(json.dumps(out), flush=True)
+    pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -185,7 +223,7 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     nlat, nlon = lat.size, lon.size
     idx = sorted(set(int(round(i)) for i in np.linspace(0, nt - 1, nsample)))
-    ev = one_pass(copy=True)
+    ev = one_pass(copy=True)["events"]
     t_cpu = 0.0
     ok = True
     for t in idx:
