@@ -208,8 +208,8 @@ def pmc_traffic(nt):
         for line in open(path):
             if "wb_k_scan" in line:
                 f = line.split()
-                fetch_kb, write_kb = float(f[-3]), float(f[-1])
-                return (2.0 * fetch_kb + write_kb) * 1024.0 * nt / 1460.0
+                calls, fetch_kb, write_kb = max(1.0, float(f[-4])), float(f[-3]), float(f[-1])   # counters are summed over the launches
+                return (2.0 * fetch_kb + write_kb) / calls * 1024.0 * nt / 1460.0
     except Exception:
         pass
     return None
