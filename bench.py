@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 4)),
                     help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-intensity", action="store_true")
+    ap.add_argument("--scan-split", type=int, default=0, help="1: two-kernel scan (capture + build)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WB_BENCH_STREAMS", 2)),
                     help="batches in flight per GPU (contexts = HIP streams + host threads); 1 = strictly one after the other")
     return ap.parse_args()
@@ -67,6 +68,8 @@ def main():
     from wavebreaking_amd.pipeline import BatchPipeline
     pipe = BatchPipeline(local, depth=a.streams)        # a.streams batches in flight, one context (stream + thread) each
     ctx = pipe.contexts[0]
+    for c in pipe.contexts:
+        c.set_option("scan_split", a.scan_split)
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
     levels = [-2.0, 2.0]
@@ -176,7 +179,7 @@ def main():
                                    % (nt, "off" if a.no_intensity else "on"),
                        "nt_per_gpu": nt, "grid": [nlat, nlon], "levels": levels, "eps": a.eps,
                        "parallelism": "time-sharded x%d, %d batches in flight per GPU" % (world, pipe.depth)},
-            "roofline": {"bound": "hbm", "kernel": "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "wb_k_scan_capture<float>" if a.scan_split else "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(nt),
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
                          # the same kernel with nothing else on the device (one pass before the warm-up); in the timed
@@ -205,11 +208,13 @@ def pmc_traffic(nt):
     the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE), scaled to this run's batch; None if absent."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.txt")
     try:
-        for line in open(path):
-            if "wb_k_scan" in line:
-                f = line.split()
-                calls, fetch_kb, write_kb = max(1.0, float(f[-4])), float(f[-3]), float(f[-1])   # counters are summed over the launches
-                return (2.0 * fetch_kb + write_kb) / calls * 1024.0 * nt / 1460.0
+        lines = open(path).read().splitlines()
+        for name in ("wb_k_scan<", "wb_k_scan_capture"):
+            for line in lines:
+                if name in line:
+                    f = line.split()
+                    calls, fetch_kb, write_kb = max(1.0, float(f[-4])), float(f[-3]), float(f[-1])   # sums over the launches
+                    return (2.0 * fetch_kb + write_kb) / calls * 1024.0 * nt / 1460.0
     except Exception:
         pass
     return None

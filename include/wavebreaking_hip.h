@@ -99,6 +99,8 @@ int wb_create(int device_id, wb_ctx** ctx);
 void wb_destroy(wb_ctx* ctx);
 const char* wb_last_error(wb_ctx* ctx);
 const char* wb_backend(void);                       /* "hip" for the product library */
+/* tuning switches of a context; "scan_split" = 1: the field scan as two kernels (streaming capture + list build) */
+int wb_set_option(wb_ctx* ctx, const char* name, int value);
 
 /* phase 1: contours of every (time step, level) of the batch (contour_index.py:87-156) */
 int wb_contours(wb_ctx* ctx, const wb_params* p, wb_batch** batch);

@@ -11,14 +11,19 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def ctx(request):
     lib = _hip.Library()
     assert lib.backend == "hip"
     c = _hip.Context(0, lib)
+    c.set_option("scan_split", getattr(request, "param", 0))     # 1: the two-kernel scan (capture + build)
     yield c
     c.close()
 
 
+two_scans = pytest.mark.parametrize("ctx", [0, 1], indirect=True, ids=["scan", "scan_split"])
+
+
+@two_scans
 def test_full_parity_1deg(ctx):
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(10, 6, lat, lon, eps=0.3)
@@ -33,6 +38,7 @@ def test_demo_shaped_config0(ctx):
     helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2], intensity=pv)
 
 
+@two_scans
 def test_nan_rows_f64_three_levels(ctx):
     lat, lon = synth.grid(2.5)
     pv = synth.pv_field(3, 3, lat, lon, eps=0.2).astype(np.float64)
@@ -42,6 +48,7 @@ def test_nan_rows_f64_three_levels(ctx):
     assert (got["status"] & _hip.STATUS_HAS_NAN).all()
 
 
+@two_scans
 @pytest.mark.parametrize("padd", [0, 57, 360])
 def test_periodic_add_variants(ctx, padd):
     lat, lon = synth.grid(1.0)
@@ -49,6 +56,7 @@ def test_periodic_add_variants(ctx, padd):
     helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2], periodic_add=padd)
 
 
+@two_scans
 def test_quarter_degree_parity(ctx):
     # BASELINE.json configs[2] grid (1440 x 721), both levels, all three indices; 2 steps keep the oracle in seconds
     lat, lon = synth.grid(0.25)
@@ -57,6 +65,7 @@ def test_quarter_degree_parity(ctx):
     assert max(len(c["geometry"]) for c in ref["contours"]) > 2000
 
 
+@two_scans
 def test_capacity_retry_paths(ctx):
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(2, 2, lat, lon, eps=0.3)

@@ -102,6 +102,7 @@ class Library:
                                          C.c_void_p, C.c_int]
         lib.wb_flag_events.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int64, C.POINTER(C.c_int32),
                                        dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp, dp, C.c_int, C.c_void_p, C.c_int]
+        lib.wb_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         lib.wb_last_op_ms.argtypes = [C.c_void_p]
         lib.wb_last_op_ms.restype = C.c_float
 
@@ -140,6 +141,10 @@ class Context:
 
     def error(self):
         return self.L.lib.wb_last_error(self.h).decode()
+
+    def set_option(self, name, value):
+        if self.L.lib.wb_set_option(self.h, name.encode(), int(value)) != 0:
+            raise RuntimeError("wb_set_option failed: " + self.error())
 
     # -- device memory helpers (bench / tests)
     def alloc(self, nbytes):

@@ -40,6 +40,9 @@ struct wb_ctx {
     // faults and zero-fill per pass
     std::multimap<size_t, void*> hpool;
     float last_op_ms = 0.f;
+    // 1: scan as two kernels (capture + build, wb_scan.h).  Faster alone on the device (1.32 + 0.23 ms against 1.70 ms), not
+    // faster with two batches in flight (the default way to run), hence off unless asked for (wb_set_option / WB_SCAN_SPLIT)
+    int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) != 0) ? 1 : 0;
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
@@ -480,6 +483,37 @@ static int run_phase1(wb_batch* b) {
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount; }
         if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
         if (const char* e = getenv("WB_SCAN_WGS")) { const long long v = atoll(e); if (v > 0) nwg = v; }
+        if (ctx->scan_split && nlat < 65536 && b->W <= 65536) {
+            // two kernels (wb_scan.h): the streaming kernel captures the patches that hold a crossing, the build
+            // kernel turns them into the per-level segment lists
+            const long long items = (long long)p.nt * b->nwork_strips;
+            sa.cap_rec = caps;
+            sa.cap_k = balloc<uint32_t>(b, (size_t)items * caps);
+            sa.cap_v = balloc<unsigned char>(b, (size_t)items * caps * 10 * esz);
+            sa.cap_n = balloc<int>(b, (size_t)items);
+            if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
+            b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
+            long long mwg = (items + 3) / 4;
+            if (mwg > (long long)ncu * 8) mwg = (long long)ncu * 8;
+            const dim3 mgrid((unsigned)mwg), bgrid((unsigned)items);
+#define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan_capture<T, V, N>), mgrid, block, 0, ctx->stream, sa)
+#define WB_SCAN_N(T, V) \
+            switch (p.nlevels) { case 1: WB_SCAN_LAUNCH(T, V, 1); break; case 2: WB_SCAN_LAUNCH(T, V, 2); break; \
+                                 case 3: WB_SCAN_LAUNCH(T, V, 3); break; default: WB_SCAN_LAUNCH(T, V, 4); break; }
+            if (p.dtype == 0) { if (vec) { WB_SCAN_N(float, true) } else { WB_SCAN_N(float, false) } }
+            else { if (vec) { WB_SCAN_N(double, true) } else { WB_SCAN_N(double, false) } }
+#undef WB_SCAN_LAUNCH
+#undef WB_SCAN_N
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "scan_build");
+#define WB_BUILD_LAUNCH(T, N) hipLaunchKernelGGL((wb_k_scan_build<T, N>), bgrid, block, 0, ctx->stream, sa)
+#define WB_BUILD_N(T) \
+            switch (p.nlevels) { case 1: WB_BUILD_LAUNCH(T, 1); break; case 2: WB_BUILD_LAUNCH(T, 2); break; \
+                                 case 3: WB_BUILD_LAUNCH(T, 3); break; default: WB_BUILD_LAUNCH(T, 4); break; }
+            if (p.dtype == 0) { WB_BUILD_N(float) } else { WB_BUILD_N(double) }
+#undef WB_BUILD_N
+#undef WB_BUILD_LAUNCH
+        } else {
         const dim3 grid((unsigned)nwg);
 #define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan<T, V, N>), grid, block, 0, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
@@ -489,6 +523,7 @@ static int run_phase1(wb_batch* b) {
         else { if (vec) { WB_SCAN_N(double, true) } else { WB_SCAN_N(double, false) } }
 #undef WB_SCAN_N
 #undef WB_SCAN_LAUNCH
+        }
     }
 #endif
     b->timer.end(ctx);
@@ -1470,6 +1505,13 @@ struct WbOpTimer { explicit WbOpTimer(wb_ctx*) {} void stop() {} };
 #define WB_SP_MAXFUSE 8
 
 extern "C" float wb_last_op_ms(wb_ctx* ctx) { return ctx ? ctx->last_op_ms : 0.f; }
+
+extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return 1;
+    if (!strcmp(name, "scan_split")) { ctx->scan_split = value ? 1 : 0; return 0; }
+    ctx->err = std::string("wb_set_option: unknown option ") + name;
+    return 1;
+}
 
 extern "C" int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on_device, int64_t nt, int nlat, int nlon,
                                int passes, const double* weights, int kh, int kw, double wsum, int mode, double* out,
