@@ -110,6 +110,9 @@ int wb_contours(wb_ctx* ctx, const wb_params* p, wb_batch** batch);
 int wb_batch_from_contours(wb_ctx* ctx, const wb_params* p, int64_t n, const int32_t* step, const int32_t* level_idx,
                            const int32_t* closed, const int64_t* offset, const int32_t* npts, const int32_t* x,
                            const int32_t* y, wb_batch** batch);
+/* index parameters of an existing batch (its contours do not depend on them); NaN keeps the current value */
+int wb_set_index_params(wb_batch* b, double geo_dis, double cont_dis, double range_group, double ot_min_exp,
+                        double co_min_exp);
 int wb_batch_max_nux(wb_batch* b);                  /* local max of len(set(x)); all-reduce(max) it across ranks */
 /* phase 2: indices.  global_max_nux plays contours.exp_lon.max() (streamer_index.py:106);
    which = bit mask 1 streamers | 2 overturnings | 4 cutoffs */

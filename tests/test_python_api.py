@@ -299,3 +299,18 @@ def test_to_xarray_hostsim(hostsim_engine):
 def test_to_xarray_gpu():
     engine._contexts.clear()
     _to_xarray_checks()
+
+
+def test_index_parameters_reach_a_reused_contour_batch(hostsim_engine):
+    """The decorator's contour batch is reused by the index; non-default parameters must still take effect."""
+    data, pv, lat, lon, tm = _field(nt=2)
+    for kw in (dict(geo_dis=400, cont_dis=1000), dict(geo_dis=1200, cont_dis=2500)):
+        got = wb.calculate_streamers(data, 2, **kw)
+        ref = oapi.run_all(pv[:2], [2], lat, lon, tm, **kw)
+        assert len(got) == len(ref["streamers"])
+    got = wb.calculate_overturnings(data, 2, range_group=2, min_exp=10)
+    ref = oapi.run_all(pv[:2], [2], lat, lon, tm, range_group=2, min_exp=10)
+    assert len(got) == len(ref["overturnings"])
+    got = wb.calculate_cutoffs(data, 2, min_exp=2)
+    ref = oapi.run_all(pv[:2], [2], lat, lon, tm, min_exp=2)
+    assert len(got) == len(ref["cutoffs"])

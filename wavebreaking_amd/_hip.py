@@ -79,6 +79,7 @@ class Library:
         lib.wb_batch_from_contours.argtypes = [C.c_void_p, C.POINTER(WbParams), C.c_int64, i32p, i32p, i32p, i64p, i32p,
                                                i32p, i32p, C.POINTER(C.c_void_p)]
         lib.wb_batch_max_nux.argtypes = [C.c_void_p]
+        lib.wb_set_index_params.argtypes = [C.c_void_p] + [C.c_double] * 5
         lib.wb_indices.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
         lib.wb_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbEventTable)]
@@ -386,6 +387,11 @@ class Batch:
 
     def max_nux(self):
         return int(self.ctx.L.lib.wb_batch_max_nux(self.h))
+
+    def set_index_params(self, geo_dis=None, cont_dis=None, range_group=None, ot_min_exp=None, co_min_exp=None):
+        """Parameters of the indices for a batch whose contours exist already (None keeps the current value)."""
+        v = [float('nan') if x is None else float(x) for x in (geo_dis, cont_dis, range_group, ot_min_exp, co_min_exp)]
+        self.ctx.L.lib.wb_set_index_params(self.h, *v)
 
     def indices(self, global_max_nux=None, streamers=True, overturnings=True, cutoffs=True):
         g = self.max_nux() if global_max_nux is None else int(global_max_nux)

@@ -668,6 +668,17 @@ extern "C" int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont) {
     return 0;
 }
 
+extern "C" int wb_set_index_params(wb_batch* b, double geo_dis, double cont_dis, double range_group, double ot_min_exp,
+                                   double co_min_exp) {
+    if (!b) return 1;
+    if (geo_dis == geo_dis) b->p.geo_dis = geo_dis;            // NaN = keep
+    if (cont_dis == cont_dis) b->p.cont_dis = cont_dis;
+    if (range_group == range_group) b->p.range_group = range_group;
+    if (ot_min_exp == ot_min_exp) b->p.ot_min_exp = ot_min_exp;
+    if (co_min_exp == co_min_exp) b->p.co_min_exp = co_min_exp;
+    return 0;
+}
+
 extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs) {
     if (!b) return 1;
     *point_pairs = b->pair_stats[0];

@@ -15,14 +15,17 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     prep = engine.Prepared(data, intensity, dim_kwargs)
     state = kwargs.get("_wb_state")
     ctx = engine.get_context()
-    if state is not None and contours is kwargs.get("contours") and len(contours) == state["nrows"] and intensity is None:
+    own = state is not None and contours is state.get("frame")     # the frame the decorator computed a moment ago
+    if own and len(contours) == state["nrows"] and intensity is None:
         batches, levels = state["batches"], state["levels"]          # contours computed by the decorator: reuse
+        for b, *_ in batches:
+            b.set_index_params(**params)
     else:
         if state is not None:
             for b, *_ in state["batches"]:
                 b.close()
         levels = engine.as_levels(contour_levels)
-        if state is not None and contours is kwargs.get("contours"):
+        if own:
             # same contours, but the index needs the intensity field on the device too
             batches = engine.contour_batches(prep, levels, periodic_add, params)
         else:

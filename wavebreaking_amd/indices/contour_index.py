@@ -59,7 +59,7 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     tables = [(b.contour_table(), pos, t0) for b, pos, t0 in batches]
     frame = _contour_frame(tables, prep, levels, original_coordinates)
     if keep is not None:
-        keep.update(batches=batches, prep=prep, levels=levels, nrows=len(frame))
+        keep.update(batches=batches, prep=prep, levels=levels, nrows=len(frame), frame=frame)
     else:
         for b, *_ in batches:
             b.close()
