@@ -144,6 +144,13 @@ WB_DEV inline int wb_bits_for(int n) {   // bits that hold every value in [0, n)
     return b;
 }
 
+#ifndef WB_TRACE_BIGLEN
+#define WB_TRACE_BIGLEN 128       // contours at least this long count their distinct x in an LDS bitmap
+#endif
+#define WB_TRACE_NBIG 16
+#define WB_TRACE_XWORDS 128        // bitmap words per long contour: W <= 4096
+#define WB_TRACE_NCAND 128
+
 #ifndef WB_TRACE_LDS_N
 #define WB_TRACE_LDS_N 8192      // jobs with at most this many segments take the LDS paths
 #endif
@@ -565,9 +572,29 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
             hkey[s] = WB_HEMPTY;
         WB_END_PFOR
     }
+    // the distinct-x count of a LONG contour (most points of a job belong to one or two of them) is taken from a bitmap
+    // over x in LDS instead of one table insert per point
+    WB_SHARED(uint32_t, xbits, WB_TRACE_NBIG * WB_TRACE_XWORDS);
+    WB_SHARED(int, bigf, WB_TRACE_NBIG);
+    WB_SHARED(int, nbig, 1);
+    int* bigof = (int*)t0;         // [Ck] slot of a long contour, -1 otherwise (t0 is free until P8)
+    const int xw = (a.W + 31) >> 5;
+    WB_SINGLE
+    nbig[0] = 0;
+    WB_END_SINGLE
     WB_PFOR(f, Ck)
         setsize[f] = 0;
         dropped[f] = 0;
+        int slot = -1;
+        if (c_len[f] >= WB_TRACE_BIGLEN && xw <= WB_TRACE_XWORDS) {
+            slot = wb_atomic_add(&nbig[0], 1);
+            if (slot < WB_TRACE_NBIG) bigf[slot] = (int)f; else slot = -1;
+        }
+        bigof[f] = slot;
+    WB_END_PFOR
+    const int nb = nbig[0] < WB_TRACE_NBIG ? nbig[0] : WB_TRACE_NBIG;
+    WB_PFOR(w, nb * xw)
+        xbits[(w / xw) * WB_TRACE_XWORDS + (w % xw)] = 0u;
     WB_END_PFOR
     const int npts = (Ck > 0) ? keep[R] : 0;
     WB_PFOR(q, npts)
@@ -575,31 +602,51 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
         if (f != WB_NIL) {
             const uint32_t pt = cpts[q];
             const int x = wb_pt_x(pt), y = wb_pt_y(pt);
-            int fresh1, fresh2;
+            const int slot = bigof[f];
+            int fresh1, fresh2 = 0;
+            if (slot >= 0) wb_atomic_or(&xbits[slot * WB_TRACE_XWORDS + (x >> 5)], 1u << (x & 31));
             if (pk6) {
                 fresh1 = wb_set32_insert(set32, hmask, (f << (bx + by)) | ((uint32_t)y << bx) | (uint32_t)(x % a.nlon));
-                fresh2 = wb_set32_insert(set32, hmask, 0x80000000u | (f << bx) | (uint32_t)x);
+                if (slot < 0) fresh2 = wb_set32_insert(set32, hmask, 0x80000000u | (f << bx) | (uint32_t)x);
                 if (fresh1 < 0 || fresh2 < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
             } else {
                 const unsigned long long k1 = ((unsigned long long)f << 32) | (uint32_t)((x % a.nlon) | (y << 16));
                 if (wb_hash_insert(hkey, hmask, k1, &fresh1) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-                const unsigned long long k2 = (1ull << 63) | ((unsigned long long)f << 32) | (uint32_t)x;
-                if (wb_hash_insert(hkey, hmask, k2, &fresh2) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+                if (slot < 0) {
+                    const unsigned long long k2 = (1ull << 63) | ((unsigned long long)f << 32) | (uint32_t)x;
+                    if (wb_hash_insert(hkey, hmask, k2, &fresh2) < 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+                }
             }
             if (fresh1 > 0) wb_atomic_add_agg(setsize, (int)f, 1);
             if (fresh2 > 0) wb_atomic_add(&c_nux[f], 1);
             wb_atomic_add_agg(c_sumy, (int)f, y);
         }
     WB_END_PFOR
+    WB_PFOR(w, nb * xw)
+        const uint32_t v = xbits[(w / xw) * WB_TRACE_XWORDS + (w % xw)];
+        if (v) wb_atomic_add(&c_nux[bigf[w / xw]], wb_popc32(v));
+    WB_END_PFOR
 
     // ---- P7: periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1,i2)
     //          with set(i1) a subset of set(i2): equal array lengths -> drop max(i1,i2), else drop the shorter
+    //          Almost every pair fails on the first point of i1; the few that pass it (a contour and its copy one period
+    //          further east) are queued and their points are checked by the whole workgroup instead of one lane.
+    WB_SHARED(int, cand, 2 * WB_TRACE_NCAND);
+    WB_SHARED(int, ncand, 2);      // [0] queued pairs, [1] failure flag of the pair being checked
+    WB_SINGLE
+    ncand[0] = 0;
+    WB_END_SINGLE
     WB_PFOR(pair, (int64_t)Ck * Ck)
         const int i1 = (int)(pair / Ck), i2 = (int)(pair - (int64_t)i1 * Ck);
         if (i1 == i2 || setsize[i1] > setsize[i2]) continue;
         const int o1 = c_off[i1], l1 = c_len[i1];
         bool sub = true;
+        int checked = 0;
         for (int q = 0; q < l1 && sub; ++q) {
+            if (q == 1) {                                      // first point is in: hand the rest to the workgroup
+                const int slot = wb_atomic_add(&ncand[0], 1);
+                if (slot < WB_TRACE_NCAND) { cand[2 * slot] = i1; cand[2 * slot + 1] = i2; checked = -1; break; }
+            }
             const uint32_t pt = cpts[o1 + q];
             if (pk6) {
                 sub = wb_set32_has(set32, hmask, ((uint32_t)i2 << (bx + by)) | ((uint32_t)wb_pt_y(pt) << bx) |
@@ -610,12 +657,44 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
                 if (wb_hash_find(hkey, hmask, k1) < 0) sub = false;
             }
         }
-        if (sub) {
+        if (sub && checked == 0) {
             const int l2 = c_len[i2];
             const int d = (l1 == l2) ? (i1 > i2 ? i1 : i2) : (l1 < l2 ? i1 : i2);
             dropped[d] = 1;
         }
     WB_END_PFOR
+    {
+        const int nc = ncand[0] < WB_TRACE_NCAND ? ncand[0] : WB_TRACE_NCAND;
+        for (int c = 0; c < nc; ++c) {
+            const int i1 = cand[2 * c], i2 = cand[2 * c + 1];
+            const int o1 = c_off[i1], l1 = c_len[i1];
+            WB_SINGLE
+            ncand[1] = 0;
+            WB_END_SINGLE
+            WB_PFOR(q, l1)
+                const uint32_t pt = cpts[o1 + q];
+                bool in;
+                if (pk6) {
+                    in = wb_set32_has(set32, hmask, ((uint32_t)i2 << (bx + by)) | ((uint32_t)wb_pt_y(pt) << bx) |
+                                                        (uint32_t)(wb_pt_x(pt) % a.nlon));
+                } else {
+                    const unsigned long long k1 =
+                        ((unsigned long long)i2 << 32) | (uint32_t)((wb_pt_x(pt) % a.nlon) | (wb_pt_y(pt) << 16));
+                    in = wb_hash_find(hkey, hmask, k1) >= 0;
+                }
+                if (!in) ncand[1] = 1;
+            WB_END_PFOR
+            if (ncand[1] == 0) {
+                WB_SINGLE
+                const int l2 = c_len[i2];
+                const int d = (l1 == l2) ? (i1 > i2 ? i1 : i2) : (l1 < l2 ? i1 : i2);
+                dropped[d] = 1;
+                WB_END_SINGLE
+            } else {
+                WB_SYNC();                                     // keep the barrier count of the two branches equal
+            }
+        }
+    }
 
     // ---- P8: final table = kept and not dropped, order preserved
     int* fin = (int*)t0;  // [Ck] -> exclusive scan
