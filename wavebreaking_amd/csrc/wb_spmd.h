@@ -123,23 +123,32 @@ __device__ inline int wb_wave_scan_incl(int v) {
 }
 
 // in-place exclusive scan of a[0..n) (global or LDS), all threads of the block call it;
-// returns the total to every thread.  Chunks of blockDim.x elements, running carry.
+// returns the total to every thread.  A thread owns 8 consecutive elements of a chunk of 8 * blockDim.x (local prefix,
+// wave scan of the thread sums, running carry): a per-job array of a few thousand entries is two or three chunks, each
+// one memory round trip and three barriers.
 __device__ inline int wb_block_scan_excl(int* a, int n) {
     __shared__ int wb_scan_wave[16];
     __shared__ int wb_scan_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
     if (tid == 0) wb_scan_carry = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int i = base + tid;
-        const int v = (i < n) ? a[i] : 0;
-        const int inc = wb_wave_scan_incl(v);
+    for (int base = 0; base < n; base += 8 * blockDim.x) {
+        const int i0 = base + 8 * tid;
+        int v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < n) ? a[i0 + k] : 0; sum += v[k]; }
+        const int inc = wb_wave_scan_incl(sum);
         if (lane == 63) wb_scan_wave[wave] = inc;
         __syncthreads();
         int woff = 0;
         for (int w = 0; w < wave; ++w) woff += wb_scan_wave[w];
         const int carry = wb_scan_carry;
-        if (i < n) a[i] = carry + woff + inc - v;
+        int run = carry + woff + inc - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < n) a[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
         if (tid == 0) {
             int tot = 0;
