@@ -542,7 +542,7 @@ static int run_phase1(wb_batch* b) {
     WB_LAUNCH(wb_k_trace_rank, J, 1024, ta);
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_finish");
-    WB_LAUNCH(wb_k_trace_finish, J, 256, ta);
+    WB_LAUNCH(wb_k_trace_finish, J, 1024, ta);
     b->timer.end(ctx);
     WB_TICK("phase1 launches");
     if (dsync(ctx)) return 1;

@@ -381,7 +381,14 @@ WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------- 2c: finish
-WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
+// Workgroups of 1024 threads, two per CU: the same number of waves as eight workgroups of 256, but room for a 64 KiB
+// table in LDS per workgroup -- the dedupe table and the set table of a typical job (a few thousand keys) live there
+// instead of in L2 / HBM, where every probe costs a 64-byte sector.
+#ifndef WB_TRACE_LTAB
+#define WB_TRACE_LTAB 8192        // 64-bit entries of the LDS table (= 16384 32-bit set entries)
+#endif
+WB_KERNEL_LB(wb_k_trace_finish, 1024, 8, WbTraceArgs a) {
+    WB_SHARED(unsigned long long, ltab, WB_TRACE_LTAB);
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
     const int n = a.nseg[job];
@@ -474,7 +481,24 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     hmask = hsize - 1;
     const int bx = wb_bits_for(a.W), by = wb_bits_for(a.nlat);
     const bool pk5 = WB_TRACE_PACK && bx + by + wb_bits_for(C) <= 32;       // (contour, x, y) in 32 bits: one-word entries
-    if (pk5) {
+    if (pk5 && hsize <= WB_TRACE_LTAB && 2 * nkeys[0] <= hsize) {           // ... and few enough for the LDS table
+        WB_PFOR(s, hsize)
+            ltab[s] = WB_HEMPTY;
+        WB_END_PFOR
+        WB_PFOR(p, R)
+            if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
+            const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+            if (!wb_hash_put_min(ltab, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
+        WB_END_PFOR
+        WB_PFOR(p, R + 1)
+            int kp = 0;
+            if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
+                const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+                kp = wb_hash_get_min(ltab, hmask, key) == (uint32_t)p ? 1 : 0;
+            }
+            keep[p] = kp;
+        WB_END_PFOR
+    } else if (pk5) {
         WB_PFOR(s, hsize)
             hkey[s] = WB_HEMPTY;
         WB_END_PFOR
@@ -557,12 +581,17 @@ WB_KERNEL_LB(wb_k_trace_finish, 256, 8, WbTraceArgs a) {
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
     int* setsize = (int*)jA;   // [Ck]
     int* dropped = (int*)jB;   // [Ck]
-    hsize = 1024;                  // sets: at most two keys per surviving point
+    hsize = 1024;                  // sets: at most two keys per surviving point (x keys of long contours go to bitmaps)
     while (hsize < 4 * (keep[R] + 1) && hsize < a.hash_size) hsize <<= 1;
-    hmask = hsize - 1;
     const int bf = wb_bits_for(Ck);
     const bool pk6 = WB_TRACE_PACK && bf + bx + by <= 30;                    // 32-bit set keys, bit 31 tags the x-only keys
-    uint32_t* set32 = hval;
+    // LDS table (as 32-bit entries) when three slots per surviving point fit
+    int lsize = 1024;
+    while (lsize < 3 * (keep[R] + 1) && lsize < 2 * WB_TRACE_LTAB) lsize <<= 1;
+    const bool l6 = pk6 && 3 * (keep[R] + 1) <= lsize;
+    if (l6) hsize = lsize;
+    hmask = hsize - 1;
+    uint32_t* set32 = l6 ? (uint32_t*)ltab : hval;
     if (pk6) {
         WB_PFOR(s, hsize)
             set32[s] = WB_HEMPTY32;
