@@ -113,9 +113,19 @@ def test_bad_arguments_fail_loudly(sim):
         ctx.contours(pv, lat, lon, [2], 2.5, 2.5, periodic_add=400)   # > 360 degrees
 
 
+def test_packed_tables_in_global_memory():
+    # packed (one-word) table entries, but LDS tables too small for any job: the global-memory variants of the packed paths
+    lib = _hip.Library(helpers.build_hostsim(variant="noltab", defines=("WB_F1_LTAB=2", "WB_TRACE_LTAB=2")), allow_hostsim=True)
+    ctx = _hip.Context(0, lib)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(4, 2, lat, lon, eps=0.3)
+    helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [-2, 2], intensity=pv)
+    ctx.close()
+
+
 def test_big_job_paths_without_lds():
     # a build whose LDS threshold is tiny sends every job down the global-memory paths of the link / rank kernels
-    lib = _hip.Library(helpers.build_hostsim(variant="nolds", defines=("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0", "WB_PROPS_LROWS=4", "WB_PROPS_PART=4")), allow_hostsim=True)
+    lib = _hip.Library(helpers.build_hostsim(variant="nolds", defines=("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0", "WB_PROPS_LROWS=4", "WB_PROPS_PART=4", "WB_F1_LTAB=2", "WB_TRACE_LTAB=2")), allow_hostsim=True)
     ctx = _hip.Context(0, lib)
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(4, 2, lat, lon, eps=0.3)

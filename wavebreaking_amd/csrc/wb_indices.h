@@ -459,6 +459,11 @@ WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* 
     }   // tiles
 }
 
+#ifndef WB_F1_LTAB
+#define WB_F1_LTAB 4096            // entries of routine 1's LDS table (32 KiB)
+#endif
+WB_HD inline int wb_bits_for_i(int n) { int b = 0; while ((1 << b) < n) ++b; return b; }
+
 // routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264
 WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
@@ -483,8 +488,16 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
         WB_END_SINGLE
         return;
     }
+    const int padd = a.W - a.nlon;
+    WB_SHARED(int, nwest, 1);
+    WB_SINGLE
+    nwest[0] = 0;
+    cnt[0] = 0;
+    WB_END_SINGLE
     WB_PFOR(p, P)
         alive[p] = 1;
+        const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+        if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) wb_atomic_add(&nwest[0], 1);
     WB_END_PFOR
     if (P <= 1) {
         WB_SINGLE
@@ -493,18 +506,71 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
         WB_END_SINGLE
         return;
     }
+    // Usual case: the western pairs (a quarter of all on a full-span contour) fit a table in LDS whose 64-bit entries
+    // hold the key (x1 mod nlon, y1, x2 mod nlon, y2) above the pair index -- no table in global memory to clear and probe.
+    {
+        WB_SHARED(unsigned long long, ltab, WB_F1_LTAB);
+        const int bxx = wb_bits_for_i(a.nlon), byy = wb_bits_for_i(a.nlat), pb = wb_bits_for_i(P);
+        int lsize = WB_F1_LTAB < 256 ? WB_F1_LTAB : 256;
+        while (lsize < 2 * nwest[0] && lsize < WB_F1_LTAB) lsize <<= 1;
+        if (2 * (bxx + byy) + pb <= 63 && 2 * nwest[0] <= lsize) {
+            const int lmask = lsize - 1;
+            const unsigned long long pmask = (1ull << pb) - 1ull;
+            WB_PFOR(q, lsize)
+                ltab[q] = WB_HEMPTY;
+            WB_END_PFOR
+            WB_PFOR(p, P)
+                const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+                if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
+                    const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
+                                                     (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
+                    const unsigned long long mine = (key << pb) | (unsigned long long)p;
+                    uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
+                    for (int probe = 0; probe <= lmask; ++probe) {
+                        unsigned long long cur = ltab[sl];
+                        if (cur == WB_HEMPTY) {
+                            cur = wb_atomic_cas(&ltab[sl], (unsigned long long)WB_HEMPTY, mine);
+                            if (cur == WB_HEMPTY) break;
+                        }
+                        if ((cur >> pb) == key) { wb_atomic_min(&ltab[sl], mine); break; }
+                        sl = (sl + 1) & (uint32_t)lmask;
+                    }
+                }
+            WB_END_PFOR
+            WB_PFOR(p, P)
+                const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+                if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
+                    const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
+                                                     (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
+                    uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
+                    for (int probe = 0; probe <= lmask; ++probe) {
+                        const unsigned long long cur = ltab[sl];
+                        if (cur == WB_HEMPTY) break;
+                        if ((cur >> pb) == key) {
+                            const int pw = (int)(cur & pmask);
+                            alive[pairs[pw] < pairs[p] ? p : pw] = 0;       // the first in (ind1, ind2) order stays
+                            wb_atomic_add(&cnt[0], 1);
+                            break;
+                        }
+                        sl = (sl + 1) & (uint32_t)lmask;
+                    }
+                }
+            WB_END_PFOR
+            WB_SINGLE
+            a.nalive[s] = P - cnt[0];
+            a.stage[s] = 1;
+            WB_END_SINGLE
+            return;
+        }
+    }
     // Two pairs coincide after x mod nlon only if one is the copy of the other one period further east: both end points
     // of the western pair lie in x < W - nlon, both of the eastern one in x >= nlon (a mixed pair would need its copy in
     // the opposite index order).  Only western pairs are entered into the table and only eastern pairs look themselves
     // up -- a quarter of the pairs each on a full-span contour; everything else survives without touching it.
-    const int padd = a.W - a.nlon;
     WB_PFOR(q, hsize)
         hkey[q] = WB_HEMPTY;
         hval[q] = WB_HEMPTY;
     WB_END_PFOR
-    WB_SINGLE
-    cnt[0] = 0;
-    WB_END_SINGLE
     WB_PFOR(p, P)
         const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
         const uint32_t pi = pts[i], pj = pts[j];

@@ -586,7 +586,7 @@ WB_KERNEL_LB(wb_k_trace_finish, 1024, 8, WbTraceArgs a) {
     const int bf = wb_bits_for(Ck);
     const bool pk6 = WB_TRACE_PACK && bf + bx + by <= 30;                    // 32-bit set keys, bit 31 tags the x-only keys
     // LDS table (as 32-bit entries) when three slots per surviving point fit
-    int lsize = 1024;
+    int lsize = 2 * WB_TRACE_LTAB < 1024 ? 2 * WB_TRACE_LTAB : 1024;
     while (lsize < 3 * (keep[R] + 1) && lsize < 2 * WB_TRACE_LTAB) lsize <<= 1;
     const bool l6 = pk6 && 3 * (keep[R] + 1) <= lsize;
     if (l6) hsize = lsize;
