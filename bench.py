@@ -5,6 +5,10 @@ One "step" = one pass of the whole hot path (contours of every (time step, level
 overturning and cutoff indices + event/contour tables back in host memory) over ONE resident batch of
 `--nt` synthetic time steps per GPU (default 1460 = one year 6-hourly, BASELINE.json configs[2]).
 Inputs are generated on the device and are resident in HBM when the timed region starts.
+`--streams` passes (default 2) are in flight per GPU at any time, each on its own context = HIP stream +
+host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.
+(`--streams 3` gives a few % more timesteps/s but the scan kernel, which the roofline is quoted on, then
+shares HBM with two other batches; `--streams 1` runs the passes strictly one after the other.)
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
