@@ -100,6 +100,16 @@ static void hfree(wb_ctx* c, void* p, size_t bytes) {
     if (c->hpool.size() < 8) c->hpool.insert({bytes, p}); else hrelease(p);
 }
 
+// every entry point that touches the device selects the context's device first: the current device is per host thread
+// (worker threads of a pipeline, ranks driving GPUs other than 0)
+static inline void wb_use(wb_ctx* c) {
+#if !defined(WB_HOSTSIM)
+    if (c) (void)hipSetDevice(c->device);
+#else
+    (void)c;
+#endif
+}
+
 static int wb_fail(wb_ctx* c, const std::string& m) {
     if (c) c->err = m;
     return 1;
@@ -389,13 +399,14 @@ void wb_destroy(wb_ctx* c) {
 
 const char* wb_last_error(wb_ctx* c) { return c ? c->err.c_str() : "no context"; }
 
-void* wb_dev_alloc(wb_ctx* c, uint64_t bytes) { return dmalloc(c, (size_t)bytes); }
-void wb_dev_free(wb_ctx* c, void* p) { dfree(c, p); }
-int wb_memcpy_h2d(wb_ctx* c, void* d, const void* s, uint64_t b) { return h2d(c, d, s, (size_t)b); }
-int wb_memcpy_d2h(wb_ctx* c, void* d, const void* s, uint64_t b) { return d2h(c, d, s, (size_t)b); }
+void* wb_dev_alloc(wb_ctx* c, uint64_t bytes) { wb_use(c); return dmalloc(c, (size_t)bytes); }
+void wb_dev_free(wb_ctx* c, void* p) { wb_use(c); dfree(c, p); }
+int wb_memcpy_h2d(wb_ctx* c, void* d, const void* s, uint64_t b) { wb_use(c); return h2d(c, d, s, (size_t)b); }
+int wb_memcpy_d2h(wb_ctx* c, void* d, const void* s, uint64_t b) { wb_use(c); return d2h(c, d, s, (size_t)b); }
 
 void wb_free_batch(wb_batch* b) {
     if (!b) return;
+    wb_use(b->ctx);
     double wb_t0_ = wb_now_ms();
     for (void* p : b->owned) dfree(b->ctx, p);
     hfree(b->ctx, b->poly_x, b->poly_bytes);
@@ -1455,6 +1466,7 @@ WB_KERNEL(wb_k_synth, WbSynthArgs a) {
 extern "C" int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, int nlat, int nlon,
                              const double* lat, const double* lon, const double* wave_params, double eps, uint64_t seed) {
     if (!ctx || !dev_field) return 1;
+    wb_use(ctx);
     double* d_lat = (double*)dmalloc(ctx, nlat * sizeof(double));
     double* d_lon = (double*)dmalloc(ctx, nlon * sizeof(double));
     if (!d_lon) return 1;
@@ -1528,6 +1540,7 @@ extern "C" int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on
                                int passes, const double* weights, int kh, int kw, double wsum, int mode, double* out,
                                int out_on_device, int flags) {
     if (!ctx) return 1;
+    wb_use(ctx);
     if (!field || !out || !weights || nt < 0 || nlat < 1 || nlon < 1 || passes < 1 || kh < 1 || kw < 1 || kh > 7 || kw > 7 ||
         mode < 0 || mode > 4 || (dtype != 0 && dtype != 1)) {
         ctx->err = "wb_smooth_field: bad argument (passes >= 1, weights 1..7 x 1..7, mode 0..4, dtype 0/1)";
@@ -1624,6 +1637,7 @@ extern "C" int wb_smooth_field(wb_ctx* ctx, const void* field, int dtype, int on
 extern "C" int wb_momentum_flux(wb_ctx* ctx, const void* u, const void* v, int dtype, int on_device, int64_t nt, int nlat,
                                 int nlon, void* out, int out_on_device) {
     if (!ctx) return 1;
+    wb_use(ctx);
     if (!u || !v || !out || nt < 0 || nlat < 1 || nlon < 1 || (dtype != 0 && dtype != 1)) {
         ctx->err = "wb_momentum_flux: bad argument";
         return 1;
@@ -1665,6 +1679,7 @@ extern "C" int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const
                               const int64_t* vert_offset, const double* vx, const double* vy, int out_dtype, void* out,
                               int out_on_device) {
     if (!ctx) return 1;
+    wb_use(ctx);
     if (!out || !lat || !lon || nt < 0 || nlat < 2 || nlon < 2 || nev < 0 || out_dtype < 0 || out_dtype > 2 || !(radius >= 0.0) ||
         (nev > 0 && (!step || !ring_offset || !vert_offset || !vx || !vy))) {
         ctx->err = "wb_flag_events: bad argument";
