@@ -350,7 +350,8 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
 #define WB_PAIR_ROWS 16
 #define WB_MAX_BLOCKS 512       // contours up to 16384 points; longer ones fall back to sweeping all blocks
 
-WB_KERNEL(wb_k_streamer_pairs, WbStreamerArgs a, const int* blk_sel, const int* blk_tile0, int tiles_per_block) {
+// six waves per SIMD (80 VGPRs): the kernel waits on memory 60 % of its wave cycles; 5 waves (96) are no faster, 7-8 spill
+WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a, const int* blk_sel, const int* blk_tile0, int tiles_per_block) {
     // work list built on the host: workgroup w (ONE wave) sweeps tiles [blk_tile0[w], +tiles_per_block) of contour
     // blk_sel[w]; single-wave workgroups make the phase barriers free and keep 32 tiles in flight per CU
     const int s = blk_sel[WB_BLOCK_ID];
