@@ -493,7 +493,6 @@ static int run_phase1(wb_batch* b) {
         int ncu = 256;
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount; }
         if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
-        if (const char* e = getenv("WB_SCAN_WGS")) { const long long v = atoll(e); if (v > 0) nwg = v; }
         if (ctx->scan_split && nlat < 65536 && b->W <= 65536) {
             // two kernels (wb_scan.h): the streaming kernel captures the patches that hold a crossing, the build
             // kernel turns them into the per-level segment lists
