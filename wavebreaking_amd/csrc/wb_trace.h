@@ -3,8 +3,8 @@
 //   wb_k_trace_link   : merge the strip lists, crossing points, successor / predecessor links (keys staged in LDS)
 //   wb_k_trace_rank   : closed-loop detection + list ranking by pointer jumping, entirely in LDS (16-bit links)
 //   wb_k_trace_finish : contour numbering, dedupe, periodic duplicates, table
-// They are separate launches because they want different occupancies: the LDS kernels run one or two
-// large workgroups per CU, the finish kernel is L2-latency-bound and wants as many waves as fit.
+// They are separate launches because they want different shapes: link 512 threads + 64 KiB of keys in LDS, rank 1024
+// threads + 112 KiB of 16-bit links, finish 1024 threads + a 64 KiB LDS table (two workgroups per CU).
 //
 // Restates, for one job, wavebreaking/indices/contour_index.py:103-156 of the reference:
 //   * skimage's _assemble_contours (ordering rules of SURVEY.md 8a row C2) as successor linking
