@@ -59,11 +59,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local = local % max(1, torch.cuda.device_count())          # dry runs with more ranks than GPUs share devices
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL over xGMI; WB_BENCH_BACKEND=gloo only serves dry runs of the N > 1 logic on fewer GPUs than ranks
+        dist.init_process_group(os.environ.get("WB_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from oracle import synth
     from wavebreaking_amd import _hip
@@ -163,7 +165,7 @@ def main():
     barrier()
     dt = time.perf_counter() - tic
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
