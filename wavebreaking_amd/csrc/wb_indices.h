@@ -690,24 +690,32 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
     int stage = a.stage[s];
     int nal = a.nalive[s];
 
-    if (stage == 1 && nal > 1) {   // finish routine 2's bookkeeping
-        WB_SINGLE
-        cnt[0] = 0;
-        WB_END_SINGLE
+    bool rows_ready = false;
+    if (stage == 1 && nal > 1) {   // finish routine 2's bookkeeping; the same pass already collects routine 3's row maxima
+        WB_PFOR(i, N)
+            rowmax[i] = -1;
+            if (i == 0) cnt[0] = 0;
+        WB_END_PFOR
         WB_PFOR(p, P)
             if (alive[p] == 2) alive[p] = 0;
-            if (alive[p]) wb_atomic_add(&cnt[0], 1);
+            if (alive[p]) {
+                wb_atomic_add(&cnt[0], 1);
+                wb_atomic_max(&rowmax[(int)(pairs[p] >> 32)], (int)(pairs[p] & 0xFFFFFFFFull));
+            }
         WB_END_PFOR
         nal = cnt[0];
         stage = 2;
+        rows_ready = true;
     }
     if (stage == 2 && nal > 1) {   // routine 3: a pair inside another pair's [ind1, ind2] range goes
-        WB_PFOR(i, N)
-            rowmax[i] = -1;
-        WB_END_PFOR
-        WB_PFOR(p, P)
-            if (alive[p]) wb_atomic_max(&rowmax[(int)(pairs[p] >> 32)], (int)(pairs[p] & 0xFFFFFFFFull));
-        WB_END_PFOR
+        if (!rows_ready) {
+            WB_PFOR(i, N)
+                rowmax[i] = -1;
+            WB_END_PFOR
+            WB_PFOR(p, P)
+                if (alive[p]) wb_atomic_max(&rowmax[(int)(pairs[p] >> 32)], (int)(pairs[p] & 0xFFFFFFFFull));
+            WB_END_PFOR
+        }
         WB_PFOR(i, N)
             aux[i] = rowmax[i];
         WB_END_PFOR

@@ -160,17 +160,20 @@ __device__ inline int wb_block_scan_excl(int* a, int n) {
     return wb_scan_carry;
 }
 
-// in-place exclusive running maximum of a[0..n): a[i] <- max(init, a[0..i-1]); all threads of the block call it
+// in-place exclusive running maximum of a[0..n): a[i] <- max(init, a[0..i-1]); all threads of the block call it.
+// Eight consecutive elements per thread and chunk, like wb_block_scan_excl.
 __device__ inline void wb_block_scan_excl_max(int* a, int n, int init) {
     __shared__ int wb_smax_wave[16];
     __shared__ int wb_smax_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
     if (tid == 0) wb_smax_carry = init;
     __syncthreads();
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int i = base + tid;
-        const int v = (i < n) ? a[i] : init;
-        int inc = v;                                   // inclusive max over the wave prefix
+    for (int base = 0; base < n; base += 8 * blockDim.x) {
+        const int i0 = base + 8 * tid;
+        int v[8], mx = init;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < n) ? a[i0 + k] : init; mx = v[k] > mx ? v[k] : mx; }
+        int inc = mx;                                  // inclusive max over the wave prefix of the thread maxima
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(inc, d, 64);
@@ -180,9 +183,14 @@ __device__ inline void wb_block_scan_excl_max(int* a, int n, int init) {
         int excl = __shfl_up(inc, 1, 64);              // exclusive within the wave
         if (lane == 0) excl = init;
         __syncthreads();
-        int woff = wb_smax_carry;
-        for (int w = 0; w < wave; ++w) woff = wb_smax_wave[w] > woff ? wb_smax_wave[w] : woff;
-        if (i < n) a[i] = excl > woff ? excl : woff;
+        int run = wb_smax_carry;
+        for (int w = 0; w < wave; ++w) run = wb_smax_wave[w] > run ? wb_smax_wave[w] : run;
+        run = excl > run ? excl : run;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < n) a[i0 + k] = run;
+            run = v[k] > run ? v[k] : run;
+        }
         __syncthreads();
         if (tid == 0) {
             int tot = wb_smax_carry;
