@@ -67,8 +67,8 @@ def main():
         # "nccl" is RCCL over xGMI; WB_BENCH_BACKEND=gloo only serves dry runs of the N > 1 logic on fewer GPUs than ranks
         dist.init_process_group(os.environ.get("WB_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
-    from oracle import synth
     from wavebreaking_amd import _hip
+    from wavebreaking_amd import synthetic as synth        # workload definition (the oracle is imported by the cpu_baseline leg only)
     from wavebreaking_amd import distributed as wd
 
     from wavebreaking_amd.pipeline import BatchPipeline

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
-    from oracle import synth          # input generator parameters only
+    from wavebreaking_amd import synthetic as synth
     from wavebreaking_amd import _hip
     ctx = _hip.Context(0)
     lat, lon = synth.grid(0.25)

@@ -1,5 +1,5 @@
 """Wider GPU parity sweep than the test suite (minutes, not seconds): three grid resolutions, smooth to very rough fields,
-both scan variants, every table of the path against the oracle (tests/helpers.full_parity).  python tools/parity_sweep.py"""
+both scan variants, every table of the path against the oracle (tests/helpers.full_parity).  python tests/gpu_parity_sweep.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

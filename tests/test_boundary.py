@@ -34,3 +34,18 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "oracle/" in src and f.endswith(".py") and "import" in src.split("oracle/")[0][-40:]:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_product_workload_definition_matches_the_oracle_generator():
+    """wavebreaking_amd.synthetic (what bench.py feeds the device generator) and oracle.synth (what the tests' numpy fields
+    are made of) describe the same record."""
+    import numpy as np
+    from oracle import synth as osynth
+    from wavebreaking_amd import synthetic as psynth
+    assert psynth.SEED == osynth.SEED
+    for seed in (psynth.SEED, 20241, 7):
+        np.testing.assert_array_equal(psynth.wave_params(seed), osynth.wave_params(seed))
+    for d in (0.25, 1.0, 2.5):
+        for a, b in zip(psynth.grid(d), osynth.grid(d)):
+            np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(psynth.times(5), osynth.times(5))
