@@ -49,3 +49,21 @@ def test_product_workload_definition_matches_the_oracle_generator():
         for a, b in zip(psynth.grid(d), osynth.grid(d)):
             np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(psynth.times(5), osynth.times(5))
+
+
+def test_bench_imports_the_oracle_in_its_cpu_baseline_leg_only():
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel, allowed in (("bench.py", {"cpu_baseline", "_cpu_step"}), (os.path.join("benchmarks", "bench_spatial.py"), set())):
+        tree = ast.parse(open(os.path.join(root, rel)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            for node in (fn.body if isinstance(fn, ast.Module) else ast.walk(fn)):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    where = "<module>" if isinstance(fn, ast.Module) else fn.name
+                    assert where in allowed, "%s imports the oracle in %s" % (rel, where)
