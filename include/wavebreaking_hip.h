@@ -122,6 +122,11 @@ int wb_get_contours(wb_batch* b, wb_contour_table* out);
 int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */
 int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont);            /* threshold guard-band re-evaluations */
+/* calculate_properties truncates x_com / areas and y_com / areas (index_utils.py:105-110); events whose quotient lies
+   within the rounding slack of an integer have their three sums re-evaluated cell by cell in the reference's order
+   (pandas' compensated group sum over rows in (y, x) order, index_utils.py:91-102).  Counts of the last wb_indices:
+   rasterised events (streamers, cutoffs) / overturning boxes that took that path. */
+int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes);
 /* streamer all-pairs test of the last wb_indices: base-point pairs covered (sum of N(N-1)/2 over the selected contours,
    streamer_index.py:130-157) and candidate pairs found */
 int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs);

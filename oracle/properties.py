@@ -19,30 +19,42 @@ def event_cells(polygon, dlon, dlat, width, nlat):
     return geom.polygon_cells(polygon, ((dlon + dlat) / 2) / 2, width, nlat)
 
 
-def event_sums(xs, ys, t, data, intensity, weight_lat, nlon):
-    """index_utils.py:63-102 for one event.
+def group_sum(values):
+    """pandas ``groupby(...).sum()`` of one group of float64 values (index_utils.py:94-102).
 
-    ``areas``, ``x_com``, ``y_com`` use the canonical row order shared with the HIP path
-    (per-row exact integer counts, rows ascending, one rounding per multiply and per add)
-    because ``com`` truncates their ratio (:105-110) and is compared bit-exactly;
-    ``mean_var`` / ``intensity`` are compared to 1e-6 relative and may be summed in any order."""
-    areas = 0.0
-    x_com = 0.0
-    y_com = 0.0
-    mean_var = 0.0
-    inten = 0.0
-    for y in np.unique(ys):
-        m = ys == y
-        w = float(weight_lat[y])
-        n = int(np.count_nonzero(m))
-        sx = int(xs[m].sum())
-        areas = areas + w * float(n)
-        x_com = x_com + w * float(sx)
-        y_com = y_com + w * float(int(y) * n)
-        mean_var += w * float(np.sum(data[t, y, xs[m] % nlon].astype(np.float64)))
-        if intensity is not None:
-            inten += w * float(np.sum(intensity[t, y, xs[m] % nlon].astype(np.float64)))
-    return areas, mean_var, inten, x_com, y_com
+    Third-party arithmetic, not under /root/reference: pandas ``_libs/groupby.pyx:group_sum`` adds the rows of a group
+    one after the other in frame order with Kahan compensation (``y = v - c; t = s + y; c = (t - s) - y; s = t``, the
+    compensation reset to 0 when it becomes NaN).  Pinned bit-for-bit against pandas 2.3.3 by
+    tests/golden/props_pandas.npz."""
+    s = 0.0
+    c = 0.0
+    for v in values:
+        y = v - c
+        t = s + y
+        c = (t - s) - y
+        if c != c:
+            c = 0.0
+        s = t
+    return s
+
+
+def event_sums(xs, ys, t, data, intensity, weight_lat, nlon):
+    """index_utils.py:63-102 for one event, in the reference's arithmetic: one frame row per cell in the join's row
+    order -- the grid points are numbered y-major, x-minor (np.meshgrid(...).flatten(), :37-41), ``xs, ys`` arrive in
+    that order --, per-row products ``areas = weight_lat[y]`` (:63), ``areas * data`` (:66-75), ``x * areas``,
+    ``y * areas`` (:91-92) rounded once each, and the five columns summed by pandas' groupby sum (:94-102)."""
+    xs = np.asarray(xs, dtype=np.int64)
+    ys = np.asarray(ys, dtype=np.int64)
+    areas = np.asarray(weight_lat, dtype=np.float64)[ys]
+    val = np.asarray(data[t, ys, xs % nlon], dtype=np.float64)
+    cols = [areas, areas * val]
+    if intensity is not None:
+        cols.append(areas * np.asarray(intensity[t, ys, xs % nlon], dtype=np.float64))
+    else:
+        cols.append(np.zeros(len(xs)))                                               # :88-89 (intensity = 0)
+    cols.append(xs.astype(np.float64) * areas)
+    cols.append(ys.astype(np.float64) * areas)
+    return tuple(group_sum(c.tolist()) for c in cols)
 
 
 def calculate_properties(events, data, intensity, lat, lon, periodic_add):

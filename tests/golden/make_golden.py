@@ -8,9 +8,10 @@ Run in the build container (the two interpreters hold different libraries):
     /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py skimage   # scikit-image 0.18.3
     python3 tests/golden/make_golden.py sklearn                             # scikit-learn 1.7.2
     python3 tests/golden/make_golden.py pandas                              # pandas 2.3.3
+    python3 tests/golden/make_golden.py props                               # pandas 2.3.3 (groupby sums of calculate_properties)
 
 Outputs: tests/golden/contours_cases.npz, contours_random.npz, haversine.npz,
-pandas_rules.npz (all < 200 KB).
+pandas_rules.npz, props_pandas.npz (all < 200 KB).
 """
 import os
 import sys
@@ -195,6 +196,89 @@ def make_pandas():
     print("pandas goldens written")
 
 
+def make_props():
+    """The arithmetic of calculate_properties (index_utils.py:58-111) on per-cell frames: one row per (event, cell) in
+    the join's row order (grid points numbered y-major, x-minor, :37-41), the per-row products and
+    ``groupby("id").agg(sum)`` evaluated by pandas itself.  Boxes with min_lon + max_lon even make x_com / areas an
+    integer mathematically, which is where the summation order decides the truncated centre-of-mass index (:105-110)."""
+    import pandas as pd
+
+    rng = np.random.RandomState(4242)
+    store = {"pandas_version": np.array(pd.__version__), "numpy_version": np.array(np.__version__)}
+    ev_id, ev_x, ev_y, ev_val, ev_int = [], [], [], [], []
+    boxes, grid_of = [], []
+    grids = {}
+    for gi, d in enumerate((1.0, 0.25)):
+        lat = -90.0 + d * np.arange(int(round(180 / d)) + 1)
+        area_cell = np.round(6371 * 2 * np.pi / (360 / ((d + d) / 2))) ** 2        # index_utils.py:58-61
+        grids[gi] = np.cos(np.radians(lat)) * area_cell                              # :62
+        store["weight_lat_%d" % gi] = grids[gi]
+    eid = 0
+
+    def add(gi, xs, ys, with_data):
+        nonlocal eid
+        n = len(xs)
+        ev_id.append(np.full(n, eid)); ev_x.append(xs); ev_y.append(ys)
+        ev_val.append((rng.standard_normal(n) * 3).astype(np.float32) if with_data else np.zeros(n, np.float32))
+        ev_int.append((rng.standard_normal(n) * 40).astype(np.float32) if with_data else np.zeros(n, np.float32))
+        grid_of.append(gi)
+        eid += 1
+
+    # (a) boxes, cells in (y, x) order as np.meshgrid(...).flatten() numbers them
+    for k in range(40):
+        gi = k % 2
+        nlat = len(grids[gi])
+        cols = int(rng.randint(5, 28 if gi == 0 else 110))
+        x0 = int(rng.randint(0, 300 if gi == 0 else 1700))
+        x1 = x0 + cols - 1
+        if k % 4 != 3 and (x0 + x1) % 2 == 1:                                       # three of four: min_lon + max_lon even
+            x1 += 1
+        rows = int(rng.randint(3, 22 if gi == 0 else 60))
+        y0 = int(rng.randint(nlat // 2 + 5, nlat - rows - 8)) if k % 3 else int(rng.randint(8, nlat // 2 - rows - 5))
+        y1 = y0 + rows - 1
+        gx, gy = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1))
+        boxes.append((eid, x0, y0, x1, y1))
+        add(gi, gx.flatten(), gy.flatten(), with_data=(k < 12))
+    # (b) ragged cell sets (streamer / cutoff like): random row spans
+    for k in range(10):
+        gi = k % 2
+        nlat = len(grids[gi])
+        rows = int(rng.randint(4, 30))
+        y0 = int(rng.randint(10, nlat - rows - 10))
+        xs, ys = [], []
+        c = int(rng.randint(20, 200))
+        for r in range(rows):
+            a = c + int(rng.randint(-4, 5)); b = a + int(rng.randint(1, 40))
+            xs.append(np.arange(a, b + 1)); ys.append(np.full(b - a + 1, y0 + r))
+            if rng.rand() < 0.3:                                                     # a second span in the row
+                a2 = b + int(rng.randint(2, 9)); b2 = a2 + int(rng.randint(0, 12))
+                xs.append(np.arange(a2, b2 + 1)); ys.append(np.full(b2 - a2 + 1, y0 + r))
+        add(gi, np.concatenate(xs), np.concatenate(ys), with_data=True)
+    ids = np.concatenate(ev_id); X = np.concatenate(ev_x); Y = np.concatenate(ev_y)
+    V = np.concatenate(ev_val); I = np.concatenate(ev_int)
+    gof = np.asarray(grid_of)
+    sums = np.zeros((eid, 5))
+    for gi in grids:
+        m = gof[ids] == gi
+        merged = pd.DataFrame({"id": ids[m], "x": X[m], "y": Y[m]})
+        merged["areas"] = grids[gi][merged.y]                                        # :63
+        merged["mean_var"] = merged.areas * V[m].astype(np.float64)                  # :66-75 (float32 field * float64)
+        merged["intensity"] = merged.areas * I[m].astype(np.float64)                 # :77-87
+        merged["x_com"] = merged.x * merged.areas                                    # :91
+        merged["y_com"] = merged.y * merged.areas                                    # :92
+        agg = merged.groupby("id").agg({"areas": "sum", "mean_var": "sum", "intensity": "sum", "x_com": "sum",
+                                        "y_com": "sum"})                             # :94-102
+        sums[agg.index.values] = agg[["areas", "mean_var", "intensity", "x_com", "y_com"]].values
+    com_ix = (sums[:, 3] / sums[:, 0]).astype("int")                                 # :105-110
+    com_iy = (sums[:, 4] / sums[:, 0]).astype("int")
+    store.update(ids=ids.astype(np.int32), x=X.astype(np.int16), y=Y.astype(np.int16), val=V, inten=I, grid_of=gof,
+                 boxes=np.asarray(boxes), sums=sums, com_ix=com_ix, com_iy=com_iy)
+    np.savez_compressed(os.path.join(HERE, "props_pandas.npz"), **store)
+    r = sums[:, 3] / sums[:, 0]
+    print("props goldens written: %d events, %d cells, %d with x_com/areas within 1e-9 of an integer"
+          % (eid, len(ids), int(np.sum(np.abs(r - np.round(r)) < 1e-9))))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else ""
-    {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas}[which]()
+    {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas, "props": make_props}[which]()

@@ -49,6 +49,7 @@ def run_abi(ctx, data, lat, lon, levels, intensity=None, periodic_add=120.0, wan
     b.indices()
     out = dict(contours=b.contour_table(), streamers=b.events(_hip.STREAMERS), overturnings=b.events(_hip.OVERTURNINGS),
                cutoffs=b.events(_hip.CUTOFFS), status=b.status(), band=b.band_hits(), max_nux=b.max_nux(),
+               com_rechecks=b.com_rechecks(),
                timings=b.timings())
     b.close()
     return out
@@ -95,9 +96,22 @@ def compare_events(got, contours, ref_rows, kind, levels, rtol=1e-6):
             assert np.array_equal(got["cell_x"][a:b], xs) and np.array_equal(got["cell_y"][a:b], ys), (kind, k)
         ref = np.asarray(r["_sums"])
         s = got["sums"][k]
-        # areas / x_com / y_com share the summation order with the oracle: exact; data sums: rtol
-        assert s[0] == ref[0] and s[3] == ref[3] and s[4] == ref[4], (kind, k, s, ref)
+        # com = (lon[int(x_com / areas) % nlon], lat[int(y_com / areas)]) (index_utils.py:105-110): the truncated indices
+        # are bit-exact against the reference's arithmetic (per-cell products, pandas' compensated group sum) ...
+        assert int(s[3] / s[0]) == int(ref[3] / ref[0]) and int(s[4] / s[0]) == int(ref[4] / ref[0]), (kind, k, s, ref)
+        # ... because every event whose quotient lies within the rounding slack of an integer is re-evaluated in the
+        # reference's order: there the three sums themselves are equal to the last bit
+        rows = int(ys.max() - ys.min()) + 1
+        for q in (ref[3] / ref[0], ref[4] / ref[0]):
+            if abs(q - np.rint(q)) <= (abs(q) + 1.0) * (2.0 * rows + 16.0) * 2.0 ** -53:
+                assert s[0] == ref[0] and s[3] == ref[3] and s[4] == ref[4], (kind, k, s, ref)
+                NEAR_INTEGER_EVENTS[kind] = NEAR_INTEGER_EVENTS.get(kind, 0) + 1
+        assert np.allclose(s[[0, 3, 4]], ref[[0, 3, 4]], rtol=1e-12, atol=0.0), (kind, k, s, ref)
+        # data sums: 1e-6 relative (north_star)
         assert np.allclose(s[1:3], ref[1:3], rtol=rtol, atol=1e-9 * abs(ref[0])), (kind, k, s, ref)
+
+
+NEAR_INTEGER_EVENTS = {}     # events seen by compare_events whose com quotient sat within the slack of an integer
 
 
 def full_parity(ctx, data, lat, lon, times, levels, intensity=None, periodic_add=120.0, **kw):
@@ -109,3 +123,79 @@ def full_parity(ctx, data, lat, lon, times, levels, intensity=None, periodic_add
     for kind in ("streamers", "overturnings", "cutoffs"):
         compare_events(got[kind], got["contours"], ref[kind], kind, levels)
     return got, ref
+
+
+def symmetric_cutoff_case(ctx, dlon=1.0, nsteps=2):
+    """Cutoffs whose polygons are mirror-symmetric in x (x_com / areas is an integer or a half-integer mathematically), cut
+    from a contour frame handed in (decorator_contour_calculation, contour_index.py:197-249): the events whose
+    centre-of-mass sums the rasterising kernel has to re-evaluate in the reference's order.  Returns (ABI tables,
+    oracle rows, rechecks)."""
+    from oracle import indices as oind
+    from oracle import properties as oprop
+    from oracle import synth
+    lat, lon = synth.grid(dlon)
+    nlon = lon.size
+    rng = np.random.RandomState(5)
+    data = (rng.standard_normal((nsteps, lat.size, nlon)) * 2).astype(np.float32)
+    W = nlon + int(120 / dlon)
+    rows = []
+    for t in range(nsteps):
+        # one contour across the whole extended grid (so that the closed ones are shorter than the maximum), then closed
+        # shapes: rectangles, diamonds, octagons; centre column integer or half-integer
+        xs = np.arange(W)
+        rows.append(dict(step=t, closed=False, xy=np.c_[xs, np.full(W, lat.size // 2) + (xs % 2)]))
+        for k in range(14):
+            sc = max(1, int(round(1.0 / dlon)))
+            cx2 = 2 * int(rng.randint(30 * sc, nlon - 30 * sc)) + (k % 2)   # twice the centre column
+            cy = int(rng.randint(30 * sc, lat.size - 30 * sc))
+            hw2 = 2 * int(rng.randint(3 * sc, 12 * sc)) + (k % 2)           # twice the half width (same parity as cx2)
+            hh = int(rng.randint(2 * sc, 9 * sc))
+            x0, x1 = (cx2 - hw2) // 2, (cx2 + hw2) // 2
+            if k % 3 == 0:
+                ring = [(x0, cy - hh), (x1, cy - hh), (x1, cy + hh), (x0, cy + hh)]
+            elif k % 3 == 1:
+                m = min(hh, (x1 - x0) // 2)
+                ring = [(x0 + m, cy - hh), (x1 - m, cy - hh), (x1, cy - hh + m), (x1, cy + hh - m), (x1 - m, cy + hh),
+                        (x0 + m, cy + hh), (x0, cy + hh - m), (x0, cy - hh + m)]
+            else:
+                h = (x1 - x0) // 2
+                ring = [(x0, cy), (x0 + h, cy - h), (x1 - h, cy - h), (x1, cy), (x1 - h, cy + h), (x0 + h, cy + h)]
+            ring = [p for i, p in enumerate(ring) if p != ring[i - 1]]
+            dense = []                                                     # every lattice point along the ring, like a traced contour
+            for i, (ax, ay) in enumerate(ring):
+                bx, by = ring[(i + 1) % len(ring)]
+                g = int(np.gcd(abs(bx - ax), abs(by - ay)))
+                dense += [(ax + (bx - ax) // g * q, ay + (by - ay) // g * q) for q in range(g)]
+            ring = dense
+            rows.append(dict(step=t, closed=True, xy=np.asarray(ring)))
+    npts = np.array([len(r["xy"]) for r in rows], dtype=np.int32)
+    table = dict(step=np.array([r["step"] for r in rows], dtype=np.int32), level_idx=np.zeros(len(rows), np.int32),
+                 closed=np.array([r["closed"] for r in rows], dtype=np.int32), npts=npts,
+                 offset=(np.cumsum(npts) - npts).astype(np.int64),
+                 x=np.concatenate([r["xy"][:, 0] for r in rows]).astype(np.int32),
+                 y=np.concatenate([r["xy"][:, 1] for r in rows]).astype(np.int32))
+    b = ctx.batch_from_contours(table, data, lat, lon, [2.0], dlon, dlon, intensity=data, want_cells=True)
+    b.indices(streamers=False, overturnings=False)
+    got = b.events(_hip.CUTOFFS)
+    rechecks = b.com_rechecks()
+    assert not b.status().any()
+    b.close()
+    tm = synth.times(nsteps)
+    crow = [dict(date=tm[r["step"]], level=2.0, closed=r["closed"], exp_lon=len(set(r["xy"][:, 0].tolist())) * dlon,
+                 geometry=r["xy"], _t=r["step"]) for r in rows]
+    ev = oind.calculate_cutoffs(crow, 5)
+    ref = oprop.calculate_properties(ev, data, data, lat, lon, 120)
+    assert got["step"].size == len(ref) and len(ref) >= 10 * nsteps, (got["step"].size, len(ref))
+    nnear = 0
+    for k, r in enumerate(ref):
+        xs, ys = r["_cells"]
+        a, e = got["cell_offset"][k], got["cell_offset"][k + 1]
+        assert np.array_equal(got["cell_x"][a:e], xs) and np.array_equal(got["cell_y"][a:e], ys), k
+        s, q = got["sums"][k], np.asarray(r["_sums"])
+        assert int(s[3] / s[0]) == int(q[3] / q[0]) and int(s[4] / s[0]) == int(q[4] / q[0]), (k, s, q)
+        qx = q[3] / q[0]
+        if abs(qx - np.rint(qx)) < 1e-9:
+            nnear += 1
+            assert s[0] == q[0] and s[3] == q[3] and s[4] == q[4], (k, s, q)
+        assert np.allclose(s, q, rtol=1e-6)
+    return got, ref, rechecks, nnear

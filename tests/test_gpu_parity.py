@@ -126,3 +126,20 @@ def test_python_surface_with_time_chunking(ctx, monkeypatch):
     assert len(s) == len(ref["streamers"])
     for (_, row), r in zip(s.iterrows(), ref["streamers"]):
         assert np.datetime64(row["date"]) == r["date"] and row["level"] == r["level"] and row["event_area"] == r["event_area"]
+
+
+def test_com_follows_the_reference_arithmetic(ctx):
+    """>= 20 events whose x_com / areas is an integer mathematically (boxes with min_lon + max_lon even): the truncated
+    centre-of-mass index and the three sums equal the reference's per-cell, pandas-summed values bit for bit."""
+    helpers.NEAR_INTEGER_EVENTS.clear()
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(0, 12, lat, lon, eps=0.3)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(12), [-2, 2], intensity=pv)
+    assert helpers.NEAR_INTEGER_EVENTS.get("overturnings", 0) >= 20
+    assert got["com_rechecks"][1] >= 20
+
+
+@pytest.mark.parametrize("dlon,nsteps", [(1.0, 2), (0.25, 1)])
+def test_com_of_symmetric_rasterised_events(ctx, dlon, nsteps):
+    got, ref, rechecks, near = helpers.symmetric_cutoff_case(ctx, dlon, nsteps)
+    assert near >= 5 * nsteps and rechecks[0] >= near and rechecks[1] == 0

@@ -131,3 +131,22 @@ def test_big_job_paths_without_lds():
     pv = synth.pv_field(4, 2, lat, lon, eps=0.3)
     helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [-2, 2], intensity=pv)
     ctx.close()
+
+
+def test_com_follows_the_reference_arithmetic(sim):
+    """calculate_properties truncates x_com / areas (index_utils.py:105-110): overturning boxes with min_lon + max_lon even
+    put that quotient ON an integer, so the sums must be pandas' compensated per-cell sums to the last bit."""
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(0)
+    helpers.NEAR_INTEGER_EVENTS.clear()
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(0, 12, lat, lon, eps=0.3)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(12), [-2, 2], intensity=pv)
+    assert helpers.NEAR_INTEGER_EVENTS.get("overturnings", 0) >= 20       # compare_events asserted bit equality of the sums there
+    assert got["com_rechecks"][1] >= 20
+
+
+def test_com_of_symmetric_rasterised_events(sim):
+    lib, ctx = sim
+    got, ref, rechecks, near = helpers.symmetric_cutoff_case(ctx)
+    assert near >= 10 and rechecks[0] >= near and rechecks[1] == 0

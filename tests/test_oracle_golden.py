@@ -143,3 +143,51 @@ def test_seam_split_areas():
     # not touching the seam: untouched
     rings = properties.transform_polygon(np.array([[3, 2], [5, 2], [5, 4]]), lat, lon)
     assert len(rings) == 1 and np.array_equal(rings[0][:, 0], lon[[3, 5, 5]])
+
+
+class _CellValues:
+    """stands in for data[t, ys, xs % nlon]: hands back the fixture's per-cell float32 values"""
+
+    def __init__(self, v):
+        self.v = v
+
+    def __getitem__(self, key):
+        return self.v
+
+
+def test_property_sums_vs_pandas(golden_dir):
+    """calculate_properties' per-cell products and groupby sums (index_utils.py:58-111): the oracle's restatement of
+    pandas' compensated group sum against pandas 2.3.3 itself, bit for bit, on frames whose x_com / areas is an integer
+    mathematically (symmetric boxes) -- the case where the summation order decides the truncated index."""
+    g = np.load(golden_dir + "/props_pandas.npz")
+    ids, X, Y = g["ids"], g["x"].astype(np.int64), g["y"].astype(np.int64)
+    nev = len(g["sums"])
+    near = 0
+    for e in range(nev):
+        m = ids == e
+        w = g["weight_lat_%d" % int(g["grid_of"][e])]
+        s = properties.event_sums(X[m], Y[m], 0, _CellValues(g["val"][m]), _CellValues(g["inten"][m]), w, 1 << 20)
+        assert tuple(s) == tuple(g["sums"][e]), (e, s, g["sums"][e])
+        assert int(s[3] / s[0]) == g["com_ix"][e] and int(s[4] / s[0]) == g["com_iy"][e]
+        r = s[3] / s[0]
+        near += abs(r - round(r)) < 1e-9
+    assert near >= 20
+    # the boxes of the fixture are what they claim to be: cells in (y, x) order, as np.meshgrid(...).flatten() numbers them
+    for e, x0, y0, x1, y1 in g["boxes"]:
+        gx, gy = np.meshgrid(np.arange(x0, x1 + 1), np.arange(y0, y1 + 1))
+        assert np.array_equal(X[ids == e], gx.flatten()) and np.array_equal(Y[ids == e], gy.flatten())
+
+
+def test_group_sum_is_not_a_plain_sum(golden_dir):
+    """guards the fixture's power: a naive left-to-right sum of the same rows misses pandas' value on some events"""
+    g = np.load(golden_dir + "/props_pandas.npz")
+    ids, X, Y = g["ids"], g["x"].astype(np.int64), g["y"].astype(np.int64)
+    differ = 0
+    for e in range(len(g["sums"])):
+        m = ids == e
+        w = g["weight_lat_%d" % int(g["grid_of"][e])]
+        acc = 0.0
+        for v in (X[m].astype(np.float64) * w[Y[m]]).tolist():
+            acc += v
+        differ += acc != g["sums"][e][3]
+    assert differ >= 5

@@ -6,9 +6,17 @@
 // rasterised by scanline crossing counts (signed, suffix-summed per row), the rim by exact
 // point-segment distance tests around every edge; sums follow :58-102.
 //
-// Sum order contract shared with the oracle (oracle/properties.py:event_sums): areas, x_com, y_com are
-// accumulated over rows in ascending y from exact per-row integer counts, one rounding per multiply and
-// one per add (no FMA contraction), because `com` truncates their ratio (:105-110).
+// com = (lon[int(x_com / areas) % nlon], lat[int(y_com / areas)]) TRUNCATES the ratio of two sums (:105-110), so the
+// sums must be the reference's to the last bit whenever the ratio sits next to an integer -- and it sits exactly ON one
+// for every overturning box with min_lon + max_lon even.  The reference's sums: one frame row per cell in the join's row
+// order (grid points numbered y-major, x-minor, :37-41), areas = weight_lat[y] (:63), x_com = x * areas, y_com = y * areas
+// (:91-92, one rounding each), summed by pandas' groupby sum (:94-102) = sequential Kahan-compensated addition
+// (pandas _libs/groupby.pyx group_sum; pinned by tests/golden/props_pandas.npz).  That chain is sequential by nature, so:
+//   * fast path: per-row integer counts, areas += w * cnt etc. over rows -- within (2 rows + 8) ulp of the reference's value;
+//   * when x_com / areas or y_com / areas lies within that bound (times a safety factor) of an integer, the event's three
+//     sums are re-evaluated cell by cell exactly as above (WB_KAHAN) and counted (wb_get_com_rechecks): one lane walking
+//     the event's raster here, one lane per box in wb_k_box_com (boxes need no raster).
+// mean_var / intensity sums are compared to 1e-6 relative and keep the row-wise order.
 #pragma once
 #include "wb_core.h"
 #include <stdio.h>
@@ -40,6 +48,7 @@ struct WbPropsArgs {
     double* rowacc;             // [nslots][4][nlat]
     double* ev_sums;            // [nev][5]: areas, mean_var, intensity, x_com, y_com  (sums, :94-102)
     int* ev_ncells;             // [nev]
+    int* com_rechecks;          // [2] events / boxes whose areas, x_com, y_com were re-evaluated in the reference's order
     unsigned long long* cell_count;  // [1] bump allocator of the cell pool
     unsigned long long cell_cap;
     uint32_t* cell_pool;        // (x | y<<16)
@@ -69,6 +78,26 @@ WB_DEV inline bool wb_near_segment(int x, int y, int ax, int ay, int bx, int by,
     const long long cr = dx * (long long)(y - ay) - dy * (long long)(x - ax);
     return ((double)cr * (double)cr) / (double)L < r2;
 }
+
+// one step of pandas' group_sum: s += v with Kahan compensation c (groupby.pyx: y = v - c; t = s + y; c = t - s - y)
+#define WB_KAHAN(s, c, v)                          \
+    do {                                           \
+        const double wb_y_ = (v) - (c);            \
+        const double wb_t_ = (s) + wb_y_;          \
+        (c) = (wb_t_ - (s)) - wb_y_;               \
+        if ((c) != (c)) (c) = 0.0;                 \
+        (s) = wb_t_;                               \
+    } while (0)
+
+// Is the truncation of num / den safe against an error of `ulps` units of 2^-53 (relative) in the quotient?
+WB_HD inline bool wb_trunc_unsafe(double num, double den, double ulps) {
+    const double q = num / den;
+    const double tol = (fabs(q) + 1.0) * ulps * 1.1102230246251565e-16;
+    return fabs(q - rint(q)) <= tol;
+}
+// relative error bound (in units of 2^-53) between the row-wise sums over `rows` rows and the reference's compensated
+// cell-wise sums, for the QUOTIENT of two such sums; x4 safety
+WB_HD inline double wb_com_ulps(int rows) { return 4.0 * (2.0 * (double)rows + 16.0); }
 
 #define WB_PROPS_LONG 16
 WB_KERNEL(wb_k_props, WbPropsArgs a) {
@@ -299,11 +328,34 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             it = it + w * WB_ACC(3, y);
             nc += (long long)cnt;
         }
-        a.ev_sums[(size_t)e * 5 + 0] = areas;
+        // boxes: areas / x_com / y_com come from wb_k_box_com (which runs beside this kernel and owns those three slots)
+        if (!full) {
+            const double ulps = wb_com_ulps(rows);
+            if (nc > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps))) {
+                // the reference's order: cells (y, x) ascending, one product per cell, compensated sums
+                double sa = 0.0, ca = 0.0, sx = 0.0, cx = 0.0, sy = 0.0, cy = 0.0;
+                for (int y = y0; y <= y1; ++y) {
+                    if (WB_ACC(0, y) == 0.0) continue;
+                    const double w = a.wlat[y];
+                    const double yw = (double)y * w;
+                    const int* col = cells + (y - y0);
+                    for (int x = 0; x < cols; ++x) {
+                        if (!col[(size_t)x * rows]) continue;
+                        const double xw = (double)(x0 + x) * w;
+                        WB_KAHAN(sa, ca, w);
+                        WB_KAHAN(sx, cx, xw);
+                        WB_KAHAN(sy, cy, yw);
+                    }
+                }
+                areas = sa; xc = sx; yc = sy;
+                wb_atomic_add(&a.com_rechecks[0], 1);
+            }
+            a.ev_sums[(size_t)e * 5 + 0] = areas;
+            a.ev_sums[(size_t)e * 5 + 3] = xc;
+            a.ev_sums[(size_t)e * 5 + 4] = yc;
+        }
         a.ev_sums[(size_t)e * 5 + 1] = mv;
         a.ev_sums[(size_t)e * 5 + 2] = it;
-        a.ev_sums[(size_t)e * 5 + 3] = xc;
-        a.ev_sums[(size_t)e * 5 + 4] = yc;
         a.ev_ncells[e] = (int)nc;
         long long off = -1;
         if (a.want_cells) {
@@ -331,4 +383,61 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         }
 #undef WB_ACC
     }
+}
+
+// areas / x_com / y_com of the overturning boxes (the events wb_k_props does not rasterise): every cell of the closed box
+// counts, so the row-wise sums are closed forms and the reference-order re-evaluation needs no raster either -- one lane
+// per box, WB_BOXCOM_PER_WG boxes per single-wave workgroup (a box in the guard band walks its rows x cols cells
+// sequentially: few lanes per wave keep a wave's duration near its longest box).  Launched on the side stream next to
+// wb_k_props; the two kernels write disjoint slots of ev_sums.
+#define WB_BOXCOM_PER_WG 8
+struct WbBoxComArgs {
+    int nev, first, nlat, W;      // events [first, first + nev) are the overturning boxes
+    const int* ev;                // [..][8]
+    const double* wlat;
+    double* ev_sums;              // [..][5]: slots 0, 3, 4 written here
+    int* com_rechecks;            // [2]
+};
+WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
+    WB_PFOR(k, WB_BOXCOM_PER_WG)
+        const int q = WB_BLOCK_ID * WB_BOXCOM_PER_WG + (int)k;
+        if (q < a.nev) {
+            const int e = a.first + q;
+            const int* d = a.ev + (size_t)e * 8;
+            int x0 = d[3], y0 = d[4], x1 = d[5], y1 = d[6];
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 > a.W - 1) x1 = a.W - 1;
+            if (y1 > a.nlat - 1) y1 = a.nlat - 1;
+            const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
+            const double cnt = (double)cols;
+            const double sxr = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
+            double areas = 0.0, xc = 0.0, yc = 0.0;
+            for (int y = y0; y <= y1; ++y) {
+                const double w = a.wlat[y];
+                areas = areas + w * cnt;
+                xc = xc + w * sxr;
+                yc = yc + w * ((double)y * cnt);
+            }
+            const double ulps = wb_com_ulps(rows);
+            if (cols > 0 && rows > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps))) {
+                double sa = 0.0, ca = 0.0, sx = 0.0, cx = 0.0, sy = 0.0, cy = 0.0;
+                for (int y = y0; y <= y1; ++y) {
+                    const double w = a.wlat[y];
+                    const double yw = (double)y * w;
+                    for (int x = x0; x <= x1; ++x) {
+                        const double xw = (double)x * w;
+                        WB_KAHAN(sa, ca, w);
+                        WB_KAHAN(sx, cx, xw);
+                        WB_KAHAN(sy, cy, yw);
+                    }
+                }
+                areas = sa; xc = sx; yc = sy;
+                wb_atomic_add(&a.com_rechecks[1], 1);
+            }
+            a.ev_sums[(size_t)e * 5 + 0] = areas;
+            a.ev_sums[(size_t)e * 5 + 3] = xc;
+            a.ev_sums[(size_t)e * 5 + 4] = yc;
+        }
+    WB_END_PFOR
 }
