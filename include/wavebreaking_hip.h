@@ -90,10 +90,12 @@ typedef struct wb_event_table {
 } wb_event_table;
 
 #define WB_STATUS_OVERFLOW_SEG 1u
-#define WB_STATUS_LEVEL_HIT 2u     /* a cell equals a level exactly: edge linking != skimage's coordinate joins */
+#define WB_STATUS_LEVEL_HIT 2u     /* a cell on a contour equals the level: crossings on grid vertices, joined as skimage joins them */
 #define WB_STATUS_HAS_NAN 4u
 #define WB_STATUS_HASH_FULL 8u
 #define WB_STATUS_OVERFLOW_PAIRS 16u
+#define WB_STATUS_LEVEL_ORDER 32u  /* ... and two contour ends compete for one vertex: skimage's sequential assembly is order dependent
+                                      there (it may raise KeyError); this job's contours are NOT the reference's */
 
 int wb_create(int device_id, wb_ctx** ctx);
 void wb_destroy(wb_ctx* ctx);

@@ -15,13 +15,24 @@ Algorithm:
 * crossing coordinate on an edge ``from + (lvl - v_from)/(v_to - v_from)`` in
   float64, always evaluated left->right on horizontal and top->bottom on vertical
   edges, so both squares sharing an edge get bit-identical coordinates;
-* scikit-image joins segments through a coordinate dictionary; away from the
-  degenerate ``value == level`` case that is the same as linking through integer
-  edge ids, which is what is done here (and on the GPU);
-* ordering rules: contours sorted by their raster-first segment; an open contour
-  starts at its predecessor-less segment; a closed contour starts (and ends) at
-  the ``to`` point of its raster-last segment.
+* scikit-image joins segments through a coordinate dictionary, sequentially in raster
+  order (``_assemble_contours``).  While no cell equals the level every crossing
+  coordinate belongs to exactly one grid edge and that is the same as linking through
+  integer edge ids (``assemble``; ordering rules: contours sorted by their raster-first
+  segment; an open contour starts at its predecessor-less segment; a closed contour
+  starts and ends at the ``to`` point of its raster-last segment);
+* a cell EQUAL to the level (it counts as "not above") puts every crossing of its
+  incident edges ON the grid vertex: up to four arrivals and four departures then share
+  one dictionary key, zero-length segments are skipped, a later contour end overwrites an
+  earlier one under the same key, and in rare constellations the third-party code raises
+  KeyError.  ``join_by_coordinates`` restates that sequential walk literally and is what
+  ``find_contours`` uses whenever a cell equals the level (pinned by
+  tests/golden/contours_levelhit.npz, KeyError cases included); ``vertex_links`` is the
+  order-independent formulation the HIP kernel uses (a four-square state machine per
+  vertex), valid whenever no contour end gets overwritten.
 """
+from collections import deque
+
 import numpy as np
 
 TOP, RIGHT, BOTTOM, LEFT = 0, 1, 2, 3
@@ -163,12 +174,152 @@ def assemble(seg):
     return chains
 
 
+def join_by_coordinates(p_from, p_to):
+    """skimage ``_assemble_contours`` (site-packages/skimage/measure/_find_contours.py, 0.18.3): the segments are taken
+    in raster order and joined through two dictionaries keyed by the EXACT float coordinates of the pieces' first and
+    last points; a segment whose two ends coincide is skipped; when two pieces are joined the one created first
+    survives.  Raises KeyError exactly where the third-party routine does (a piece end whose dictionary entry was
+    overwritten by another piece ending on the same grid vertex).  Returns the pieces in creation order."""
+    pieces, first_at, last_at = {}, {}, {}
+    created = 0
+    for f, t in zip(map(tuple, np.asarray(p_from).reshape(-1, 2).tolist()),
+                    map(tuple, np.asarray(p_to).reshape(-1, 2).tolist())):
+        if f == t:
+            continue
+        after, n_after = first_at.pop(t, (None, None))       # the piece that starts where this segment ends
+        before, n_before = last_at.pop(f, (None, None))       # the piece that ends where this segment starts
+        if before is not None and after is not None:
+            if before is after:
+                before.append(t)                               # the piece closes
+            elif n_after > n_before:
+                before.extend(after)
+                last_at.pop(after[-1])
+                pieces.pop(n_after, None)
+                first_at[before[0]] = (before, n_before)
+                last_at[before[-1]] = (before, n_before)
+            else:
+                after.extendleft(reversed(before))
+                first_at.pop(before[0])
+                pieces.pop(n_before, None)
+                first_at[after[0]] = (after, n_after)
+                last_at[after[-1]] = (after, n_after)
+        elif before is None and after is None:
+            d = deque((f, t))
+            pieces[created] = d
+            first_at[f] = (d, created)
+            last_at[t] = (d, created)
+            created += 1
+        elif before is None:
+            after.appendleft(f)
+            first_at[f] = (after, n_after)
+        else:
+            before.append(t)
+            last_at[t] = (before, n_before)
+    return [np.array(c) for _, c in sorted(pieces.items())]
+
+
+_CORNER_OF = {TOP: ((0, 0), (0, 1)), BOTTOM: ((1, 0), (1, 1)), LEFT: ((0, 0), (1, 0)), RIGHT: ((0, 1), (1, 1))}
+
+
+def _end_vertex(a, level, r, c, side):
+    """grid vertex (row, col) the crossing on `side` of square (r, c) sits on (one end of the edge equals the level), or None"""
+    for dr, dc in _CORNER_OF[int(side)]:
+        if a[r + dr, c + dc] == level:
+            return (r + dr, c + dc)
+    return None
+
+
+def vertex_links(image, level, seg):
+    """succ / pred / dead (zero-length) per segment with the crossings that sit ON a grid vertex resolved by a small
+    state machine per vertex: the segment ends on the vertex are visited in raster order (at most the two segments of
+    each of the four squares around it); an arrival takes the pending departure or becomes the pending arrival, a
+    departure takes the pending arrival or becomes the pending departure.  Equal to ``join_by_coordinates`` unless a
+    pending end gets overwritten (``overwritten`` > 0: the sequential walk may then join differently or raise)."""
+    a = np.asarray(image).astype(np.float64)
+    succ, pred = link_segments(seg)
+    n = succ.size
+    fv = [_end_vertex(a, level, seg["r"][i], seg["c"][i], seg["side_from"][i]) for i in range(n)]
+    tv = [_end_vertex(a, level, seg["r"][i], seg["c"][i], seg["side_to"][i]) for i in range(n)]
+    dead = np.array([fv[i] is not None and fv[i] == tv[i] for i in range(n)], dtype=bool)
+    events = {}
+    for i in range(n):
+        if tv[i] is not None:
+            succ[i] = -1
+        if fv[i] is not None:
+            pred[i] = -1
+        if dead[i]:
+            continue
+        if tv[i] is not None:
+            events.setdefault(tv[i], []).append((i, 0))
+        if fv[i] is not None:
+            events.setdefault(fv[i], []).append((i, 1))
+    overwritten = 0
+    for ev in events.values():
+        ev.sort()
+        arrival = departure = None
+        for i, leaving in ev:
+            if not leaving:
+                if departure is not None:
+                    succ[i], pred[departure], departure = departure, i, None
+                else:
+                    overwritten += arrival is not None
+                    arrival = i
+            else:
+                if arrival is not None:
+                    succ[arrival], pred[i], arrival = i, arrival, None
+                else:
+                    overwritten += departure is not None
+                    departure = i
+    return succ, pred, dead, overwritten
+
+
+def assemble_links(succ, pred, dead):
+    """chains of segment indices in scikit-image order from successor links (dead segments left out)"""
+    n = succ.size
+    visited = dead.copy()
+    succ_l = succ.tolist()
+    chains = []
+    for s in np.nonzero((pred < 0) & ~dead)[0].tolist():
+        chain, i = [], s
+        while i >= 0 and not visited[i]:
+            visited[i] = True
+            chain.append(i)
+            i = succ_l[i]
+        chains.append(chain)
+    for s in range(n):
+        if visited[s]:
+            continue
+        loop, i = [], s
+        while not visited[i]:
+            visited[i] = True
+            loop.append(i)
+            i = succ_l[i]
+        k = loop.index(max(loop))
+        chains.append(loop[k + 1:] + loop[:k + 1])
+    chains.sort(key=min)
+    return chains
+
+
 def find_contours(image, level):
     """Restatement of skimage.measure.find_contours(image, level): list of (n,2) float64 (row, col)."""
     seg = contour_segments(image, level)
+    if seg["level_hits"]:
+        return join_by_coordinates(seg["p_from"], seg["p_to"])
     out = []
     for chain, _closed in assemble(seg):
         idx = np.asarray(chain)
         pts = np.concatenate([seg["p_from"][idx[:1]], seg["p_to"][idx]], axis=0)
         out.append(pts)
     return out
+
+
+def find_contours_vertex_machine(image, level):
+    """the same contours from ``vertex_links`` (what the HIP link kernel computes); also returns the number of
+    overwritten pending ends (0: guaranteed equal to ``find_contours``)"""
+    seg = contour_segments(image, level)
+    succ, pred, dead, overwritten = vertex_links(image, level, seg)
+    out = []
+    for chain in assemble_links(succ, pred, dead):
+        idx = np.asarray(chain)
+        out.append(np.concatenate([seg["p_from"][idx[:1]], seg["p_to"][idx]], axis=0))
+    return out, overwritten

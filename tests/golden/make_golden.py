@@ -6,12 +6,13 @@ is how they were made.  Nothing from /root/reference is imported or copied.
 Run in the build container (the two interpreters hold different libraries):
 
     /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py skimage   # scikit-image 0.18.3
+    /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py levelhit  # scikit-image 0.18.3, cells equal to the level
     python3 tests/golden/make_golden.py sklearn                             # scikit-learn 1.7.2
     python3 tests/golden/make_golden.py pandas                              # pandas 2.3.3
     python3 tests/golden/make_golden.py props                               # pandas 2.3.3 (groupby sums of calculate_properties)
 
 Outputs: tests/golden/contours_cases.npz, contours_random.npz, haversine.npz,
-pandas_rules.npz, props_pandas.npz (all < 200 KB).
+pandas_rules.npz, props_pandas.npz, contours_levelhit.npz (all < 200 KB).
 """
 import os
 import sys
@@ -111,6 +112,105 @@ def make_skimage():
     store["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "contours_random.npz"), **store)
     print("skimage goldens written:", names)
+
+
+def levelhit_fields():
+    """Fields with cells EQUAL to the level next to the contour (contour_index.py:103 on packed / rounded PV): the
+    crossing then sits on a grid vertex and skimage joins through a coordinate shared by up to eight segment ends."""
+    rng = np.random.RandomState(2024)
+    out = {}
+    lat = np.linspace(-60, 60, 25)[:, None]
+    lon = np.linspace(0, 360, 40, endpoint=False)[None, :]
+    base = (lat / 10.0 + 1.4 * np.sin(np.radians(3 * lon)) + 0.9 * np.cos(np.radians(5 * lon + 40))).astype(np.float32).astype(np.float64)
+
+    def near_contour(a, level):
+        hi = a > level
+        m = np.zeros_like(hi)
+        m[:-1] |= hi[:-1] != hi[1:]
+        m[1:] |= hi[:-1] != hi[1:]
+        m[:, :-1] |= hi[:, :-1] != hi[:, 1:]
+        m[:, 1:] |= hi[:, :-1] != hi[:, 1:]
+        return np.argwhere(m)
+
+    # hand-made: interior hit, hit on every image edge, a saddle through a hit, two adjacent hits, a hit next to a NaN
+    a = base.copy(); j, i = near_contour(a, 2.0)[7]; a[j, i] = 2.0; out["interior"] = (a, 2.0)
+    a = base.copy()
+    for j, i in near_contour(a, 2.0):
+        if i == 0 or i == a.shape[1] - 1:
+            a[j, i] = 2.0
+    out["on_left_right_edge"] = (a, 2.0)
+    a = base.T.copy()
+    for j, i in near_contour(a, 2.0):
+        if j == 0 or j == a.shape[0] - 1:
+            a[j, i] = 2.0
+    out["on_top_bottom_edge"] = (a, 2.0)
+    out["saddle"] = (np.array([[3.0, 1.0, 3.0, 1.0], [1.0, 2.0, 1.0, 3.0], [3.0, 1.0, 3.0, 1.0], [1.0, 3.0, 2.0, 3.0]]), 2.0)
+    out["plus"] = (np.array([[1.0, 3.0, 1.0], [3.0, 2.0, 3.0], [1.0, 3.0, 1.0]]), 2.0)
+    out["cross_low"] = (np.array([[3.0, 1.0, 3.0], [1.0, 2.0, 1.0], [3.0, 1.0, 3.0]]), 2.0)
+    out["ring_of_hits"] = (np.array([[1, 1, 1, 1, 1], [1, 2, 2, 2, 1], [1, 2, 3, 2, 1], [1, 2, 2, 2, 1], [1, 1, 1, 1, 1]], dtype=float), 2.0)
+    a = base.copy(); c = near_contour(a, 2.0); j, i = c[11]; a[j, i] = 2.0; a[min(j + 1, a.shape[0] - 1), i] = 2.0; out["adjacent_pair"] = (a, 2.0)
+    a = base.copy(); j, i = near_contour(a, 2.0)[19]; a[j, i] = 2.0; a[max(j - 1, 0), max(i - 1, 0)] = np.nan; out["next_to_nan"] = (a, 2.0)
+    # periodic pad exactly as contour_index.py:94-100 builds it: the hit column appears twice (x and x + nlon)
+    a = base.copy(); c = near_contour(a, 2.0); c = c[c[:, 1] < 10]; j, i = c[3]; a[j, i] = 2.0
+    out["periodic_seam"] = (np.concatenate([a, a[:, :13]], axis=1), 2.0)
+    a = base.copy(); a[near_contour(a, 2.0)[5][0], 0] = 2.0; a[near_contour(a, 2.0)[9][0], a.shape[1] - 1] = 2.0
+    out["periodic_seam_edge"] = (np.concatenate([a, a[:, :13]], axis=1), 2.0)
+    # random: smooth fields with 1..6 hits (some adjacent), a few with NaN cells; keeps every case where skimage raises
+    k = 0
+    nerr = 0
+    from skimage.measure import find_contours
+    while k < 40:
+        shape = (int(rng.randint(6, 22)), int(rng.randint(6, 28)))
+        a = _smooth(rng, shape, int(rng.randint(0, 4)))
+        a = (a / a.std()).astype(np.float32).astype(np.float64)
+        c = near_contour(a, 0.0)
+        for _ in range(int(rng.randint(1, 7))):
+            if len(c) == 0:
+                break
+            j, i = c[rng.randint(len(c))]
+            a[j, i] = 0.0
+            if rng.rand() < 0.3:
+                a[min(max(j + rng.randint(-1, 2), 0), shape[0] - 1), min(max(i + rng.randint(-1, 2), 0), shape[1] - 1)] = 0.0
+        if rng.rand() < 0.2:
+            a[rng.randint(shape[0]), rng.randint(shape[1])] = np.nan
+        try:
+            find_contours(a, 0.0)
+            raises = False
+        except KeyError:
+            raises = True
+        if raises:
+            nerr += 1
+        elif k >= 34 and nerr < 4:
+            continue                                   # the last slots are reserved for KeyError cases
+        out["random%02d" % k] = (a, 0.0)
+        k += 1
+    return out
+
+
+def make_levelhit():
+    from skimage.measure import find_contours
+    import skimage
+
+    store = {"skimage_version": np.array(skimage.__version__)}
+    names, nraise = [], 0
+    for name, (a, level) in levelhit_fields().items():
+        names.append(name)
+        assert np.array_equal(a.astype(np.float32).astype(np.float64), a, equal_nan=True)
+        store[name + "__field"] = a.astype(np.float32)          # every value is float32-representable
+        store[name + "__level"] = np.array(level)
+        try:
+            cont = find_contours(a, level)
+            cat, off = _pack([np.asarray(c) for c in cont])
+            store[name + "__raises"] = np.array(0)
+        except KeyError:
+            cat, off = np.zeros((0, 2)), np.zeros(1, dtype=np.int64)
+            store[name + "__raises"] = np.array(1)
+            nraise += 1
+        store[name + "__pts"] = cat
+        store[name + "__off"] = off
+    store["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "contours_levelhit.npz"), **store)
+    print("level-hit goldens written: %d fields, %d of them make skimage raise KeyError" % (len(names), nraise))
 
 
 def make_sklearn():
@@ -281,4 +381,5 @@ def make_props():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else ""
-    {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas, "props": make_props}[which]()
+    {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas, "props": make_props,
+     "levelhit": make_levelhit}[which]()

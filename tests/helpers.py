@@ -199,3 +199,70 @@ def symmetric_cutoff_case(ctx, dlon=1.0, nsteps=2):
             assert s[0] == q[0] and s[3] == q[3] and s[4] == q[4], (k, s, q)
         assert np.allclose(s, q, rtol=1e-6)
     return got, ref, rechecks, nnear
+
+
+def level_hit_goldens_case(ctx, golden_dir):
+    """Every field of tests/golden/contours_levelhit.npz (cells equal to the level; scikit-image's own outputs) through the
+    ABI as a one-step batch without periodic columns: the contour table equals contour_index.py:103-156 applied to
+    skimage's contours, or the job carries STATUS_LEVEL_ORDER where two contour ends compete for a vertex (which
+    includes every field on which skimage raises KeyError).  Returns (fields equal, fields flagged)."""
+    from oracle import marching
+    g = np.load(os.path.join(golden_dir, "contours_levelhit.npz"))
+    nequal = nflag = 0
+    for name in g["names"]:
+        a, lv = g[name + "__field"].astype(np.float64), float(g[name + "__level"])
+        nlat, nlon = a.shape
+        lat, lon = np.arange(nlat, dtype=np.float64), np.arange(nlon, dtype=np.float64)
+        b = ctx.contours(a[None], lat, lon, [lv], 1.0, 1.0, periodic_add=0.0)
+        got, st = b.contour_table(), int(b.status()[0])
+        b.close()
+        overwritten = marching.find_contours_vertex_machine(a, lv)[1]
+        assert bool(st & _hip.STATUS_LEVEL_ORDER) == (overwritten > 0), (name, st, overwritten)
+        if int(g[name + "__raises"]) or overwritten:
+            assert st & _hip.STATUS_LEVEL_ORDER, name
+            nflag += 1
+            continue
+        off, pts = g[name + "__off"], g[name + "__pts"]
+        raw = [pts[off[i]:off[i + 1]] for i in range(len(off) - 1)]            # scikit-image's contours themselves
+        items, closed = [], []
+        for item in raw:                                                      # contour_index.py:108-117
+            xy, cl = ocont.round_dedupe(item)
+            if len(xy) >= 4:
+                items.append(xy)
+                closed.append(cl)
+        drop = ocont.check_duplicates(items, nlon)                            # :119-147
+        keep = [i for i in range(len(items)) if i not in drop]
+        assert got["step"].size == len(keep), (name, got["step"].size, len(keep))
+        for k, i in enumerate(keep):
+            o, n = int(got["offset"][k]), int(got["npts"][k])
+            assert np.array_equal(np.c_[got["x"][o:o + n], got["y"][o:o + n]], items[i]), (name, k)
+            assert bool(got["closed"][k]) == bool(closed[i]), (name, k)
+        nequal += 1
+    return nequal, nflag
+
+
+def level_hit_field(seed, dlon=1.0, eps=0.3, nhits=4, level=2.0, seam=True):
+    """synthetic PV with cells set EQUAL to the level next to the contour (some adjacent pairs, one in the first columns
+    so that it appears twice in the periodically extended field)"""
+    from oracle import synth
+    lat, lon = synth.grid(dlon)
+    rng = np.random.RandomState(1000 + seed)
+    pv = synth.pv_field(seed, 1, lat, lon, eps=eps)
+    a = pv[0]
+    hi = a > level
+    m = np.zeros_like(hi)
+    m[:-1] |= hi[:-1] != hi[1:]
+    m[1:] |= hi[:-1] != hi[1:]
+    m[:, :-1] |= hi[:, :-1] != hi[:, 1:]
+    m[:, 1:] |= hi[:, :-1] != hi[:, 1:]
+    c = np.argwhere(m)
+    for _ in range(nhits):
+        j, i = c[rng.randint(len(c))]
+        a[j, i] = level
+        if rng.rand() < 0.3:
+            a[j, (i + 1) % lon.size] = level
+    if seam:
+        cc = c[c[:, 1] < 3]
+        if len(cc):
+            a[cc[0][0], cc[0][1]] = level
+    return pv, lat, lon

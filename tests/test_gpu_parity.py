@@ -143,3 +143,15 @@ def test_com_follows_the_reference_arithmetic(ctx):
 def test_com_of_symmetric_rasterised_events(ctx, dlon, nsteps):
     got, ref, rechecks, near = helpers.symmetric_cutoff_case(ctx, dlon, nsteps)
     assert near >= 5 * nsteps and rechecks[0] >= near and rechecks[1] == 0
+
+
+def test_cells_equal_to_the_level_golden_fields(ctx, golden_dir):
+    nequal, nflag = helpers.level_hit_goldens_case(ctx, golden_dir)
+    assert nequal >= 35 and nflag >= 4
+
+
+@pytest.mark.parametrize("seed,dlon", [(0, 1.0), (1, 1.0), (2, 1.0), (3, 1.0), (4, 0.25)])
+def test_cells_equal_to_the_level_full_path(ctx, seed, dlon):
+    pv, lat, lon = helpers.level_hit_field(seed, dlon=dlon, nhits=4 if dlon == 1.0 else 12)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2.0], intensity=pv)
+    assert got["status"][0] & _hip.STATUS_LEVEL_HIT and not (got["status"][0] & _hip.STATUS_LEVEL_ORDER)

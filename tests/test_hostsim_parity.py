@@ -150,3 +150,21 @@ def test_com_of_symmetric_rasterised_events(sim):
     lib, ctx = sim
     got, ref, rechecks, near = helpers.symmetric_cutoff_case(ctx)
     assert near >= 10 and rechecks[0] >= near and rechecks[1] == 0
+
+
+def test_cells_equal_to_the_level_golden_fields(sim, golden_dir):
+    lib, ctx = sim
+    nequal, nflag = helpers.level_hit_goldens_case(ctx, golden_dir)
+    assert nequal >= 35 and nflag >= 4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_cells_equal_to_the_level_full_path(sim, seed):
+    """contours AND events of a field with level hits equal the oracle's, whose find_contours follows skimage's
+    coordinate joins there (pinned by contours_levelhit.npz)"""
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(seed & 1)
+    pv, lat, lon = helpers.level_hit_field(seed)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2.0], intensity=pv)
+    assert got["status"][0] & _hip.STATUS_LEVEL_HIT and not (got["status"][0] & _hip.STATUS_LEVEL_ORDER)
+    lib.lib.wb_hostsim_set_reverse(0)

@@ -191,3 +191,42 @@ def test_group_sum_is_not_a_plain_sum(golden_dir):
             acc += v
         differ += acc != g["sums"][e][3]
     assert differ >= 5
+
+
+def test_cells_equal_to_the_level_vs_skimage(golden_dir):
+    """find_contours with cells EQUAL to the level (contour_index.py:103 on packed or rounded PV): crossings on grid
+    vertices, zero-length segments, dictionary keys shared by several contour ends -- bit-exact against scikit-image
+    0.18.3, including the fields on which the third-party routine raises KeyError."""
+    g = np.load(golden_dir + "/contours_levelhit.npz")
+    nraise = nmachine = 0
+    for name in g["names"]:
+        a, lv = g[name + "__field"].astype(np.float64), float(g[name + "__level"])
+        assert np.count_nonzero(a == lv) > 0, name
+        if int(g[name + "__raises"]):
+            with pytest.raises(KeyError):
+                marching.find_contours(a, lv)
+            nraise += 1
+            assert marching.find_contours_vertex_machine(a, lv)[1] > 0, name     # ... and the kernel's formulation knows
+            continue
+        cont = marching.find_contours(a, lv)
+        off, pts = g[name + "__off"], g[name + "__pts"]
+        assert len(cont) == len(off) - 1, name
+        for i, c in enumerate(cont):
+            assert np.array_equal(c, pts[off[i]:off[i + 1]]), (name, i)
+        # the order-independent formulation the HIP link kernel uses: equal whenever no pending end was overwritten
+        mach, overwritten = marching.find_contours_vertex_machine(a, lv)
+        if overwritten == 0:
+            nmachine += 1
+            assert len(mach) == len(cont) and all(np.array_equal(x, y) for x, y in zip(mach, cont)), name
+    assert nraise >= 3 and nmachine >= 40
+
+
+def test_edge_linking_and_coordinate_join_agree_without_level_hits(golden_dir):
+    g = np.load(golden_dir + "/contours_random.npz")
+    for name in g["names"]:
+        a, lv = g[name + "__field"], float(g[name + "__level"])
+        seg = marching.contour_segments(a, lv)
+        assert seg["level_hits"] == 0
+        joined = marching.join_by_coordinates(seg["p_from"], seg["p_to"])
+        linked = marching.find_contours(a, lv)
+        assert len(joined) == len(linked) and all(np.array_equal(x, y) for x, y in zip(joined, linked)), name

@@ -314,3 +314,62 @@ def test_index_parameters_reach_a_reused_contour_batch(hostsim_engine):
     got = wb.calculate_cutoffs(data, 2, min_exp=2)
     ref = oapi.run_all(pv[:2], [2], lat, lon, tm, min_exp=2)
     assert len(got) == len(ref["cutoffs"])
+
+
+def test_status_words_reach_the_caller(hostsim_engine, golden_dir, monkeypatch):
+    """A frame that may differ from the reference's is never handed out silently: cells equal to the level are
+    followed exactly (skimage's coordinate joins) unless two contour ends compete for a vertex -> ValueError; truncated
+    tables -> RuntimeError; guard-band hits -> warning."""
+    # (a) level hits that the vertex rule resolves: same frame as the oracle, no error
+    pv, lat, lon = helpers.level_hit_field(2)
+    tm = synth.times(1, start="1959-06-01T00")
+    coords = {"time": tm, "lat": wb.gridfield.Coord(lat, {"units": "degrees_north"}), "lon": wb.gridfield.Coord(lon, {"units": "degrees_east"})}
+    data = wb.GridField(pv, ("time", "lat", "lon"), coords, name="PV")
+    ref = oapi.run_all(pv, [2], lat, lon, tm)
+    c = wb.calculate_contours(data, 2, original_coordinates=False)
+    assert len(c) == len(ref["contours"])
+    for (_, row), r in zip(c.iterrows(), ref["contours"]):
+        assert np.array_equal(np.asarray(row.geometry.coords), r["geometry"]) and row.closed == r["closed"]
+    # (b) two contour ends on one vertex (a golden field on which skimage raises KeyError): explicit error
+    g = np.load(golden_dir + "/contours_levelhit.npz")
+    name = [n for n in g["names"] if int(g[n + "__raises"])][0]
+    a = g[name + "__field"].astype(np.float64)
+    f = wb.GridField(a[None], ("time", "lat", "lon"), {"time": tm, "lat": np.arange(a.shape[0], dtype=float),
+                                                         "lon": np.arange(a.shape[1], dtype=float)})
+    with pytest.raises(ValueError, match="order-dependent"):
+        wb.calculate_contours(f, float(g[name + "__level"]), periodic_add=0, original_coordinates=False)
+    with pytest.raises(ValueError, match="order-dependent"):
+        wb.calculate_cutoffs(f, float(g[name + "__level"]), periodic_add=0)
+    # (c) truncated event lists are an error, not a shorter frame
+    class _B:
+        nlev = 1
+
+        def __init__(self, st, band=(0, 0)):
+            self._st, self._band = st, band
+
+        def status(self):
+            return np.asarray(self._st, dtype=np.uint32)
+
+        def band_hits(self):
+            return self._band
+
+    for bit in (_hip.STATUS_OVERFLOW_SEG, _hip.STATUS_HASH_FULL, _hip.STATUS_OVERFLOW_PAIRS):
+        with pytest.raises(RuntimeError):
+            engine.check_batch(_B([0, bit]), "indices", tm, [2], [0], 0)
+    engine.check_batch(_B([_hip.STATUS_LEVEL_HIT | _hip.STATUS_HAS_NAN]), "indices", tm, [2], [0], 0)
+
+
+def test_guard_band_hits_are_reported(caplog):
+    class _B:
+        nlev = 1
+
+        def status(self):
+            return np.zeros(1, dtype=np.uint32)
+
+        def band_hits(self):
+            return (2, 1)
+
+    import logging
+    with caplog.at_level(logging.WARNING):
+        engine.check_batch(_B(), "indices")
+    assert "guard band" in caplog.text

@@ -46,7 +46,7 @@ class WbEventTable(C.Structure):
 
 
 STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
-STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS = 1, 2, 4, 8, 16
+STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS, STATUS_LEVEL_ORDER = 1, 2, 4, 8, 16, 32
 
 
 def _arr(ptr, n, dtype, copy=True):

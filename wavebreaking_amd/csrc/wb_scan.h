@@ -34,7 +34,7 @@
 #define WB_MAX_LISTS 32       // base strips + their periodic copies
 
 #define WB_ST_OVERFLOW_SEG 1u   // more segments than capacity: job skipped, host retries with a larger cap
-#define WB_ST_LEVEL_HIT 2u      // some cell equals the level exactly (edge linking != skimage's coordinate joins)
+#define WB_ST_LEVEL_HIT 2u      // some cell on a contour equals the level exactly (joined by the vertex rule, wb_trace.h)
 #define WB_ST_HAS_NAN 4u
 #define WB_ST_HASH_FULL 8u
 #define WB_ST_OVERFLOW_PAIRS 16u

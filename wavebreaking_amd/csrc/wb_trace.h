@@ -52,6 +52,63 @@ struct WbTraceArgs {
 
 #define WB_HEMPTY 0xFFFFFFFFFFFFFFFFull
 
+// ---- cells EQUAL to the level (contour_index.py:103 on packed / rounded PV).  Such a cell counts as "not above", every
+// crossing of its incident edges sits ON the grid vertex (fraction exactly 0 or 1), and skimage's _assemble_contours joins
+// through that one coordinate: a segment with both ends on the vertex is skipped, the other segment ends on the vertex --
+// at most two per square, four squares -- are matched in raster order: an arrival takes the pending departure or becomes
+// the pending arrival, a departure takes the pending arrival or becomes the pending departure (oracle/marching.py:
+// vertex_links, pinned by tests/golden/contours_levelhit.npz).  A pending end that gets overwritten leaves its piece open
+// there; skimage's sequential walk may then even join differently or raise KeyError, so such a job is flagged
+// WB_ST_LEVEL_ORDER and not returned as a result.
+#define WB_PT_VERTEX 0x8000u       // in a packed crossing point (x | y << 16): the crossing sits exactly on that grid vertex
+#define WB_PT_MASK 0xFFFF7FFFu
+#define WB_ST_LEVEL_ORDER 32u
+
+// does the crossing on `side` of a square sit on a grid vertex (one end of that edge equals the level)?
+WB_HD inline bool wb_side_on_vertex(int side, double ul, double ur, double ll, double lr, double level) {
+    if (side == WB_TOP) return ul == level || ur == level;
+    if (side == WB_BOTTOM) return ll == level || lr == level;
+    if (side == WB_LEFT) return ul == level || ll == level;
+    return ur == level || lr == level;
+}
+// is `side` of a square incident to its corner q (0 ul, 1 ur, 2 ll, 3 lr)?
+WB_HD inline bool wb_side_at_corner(int side, int q) {
+    if (q == 0) return side == WB_TOP || side == WB_LEFT;
+    if (q == 1) return side == WB_TOP || side == WB_RIGHT;
+    if (q == 2) return side == WB_BOTTOM || side == WB_LEFT;
+    return side == WB_BOTTOM || side == WB_RIGHT;
+}
+// The state machine of one hit vertex (pr, pc) from the point of view of segment `me`, an arrival there: index of the
+// departure it is joined to, or WB_NIL.  *overwritten is set when some pending end at this vertex gets overwritten.
+WB_DEV inline uint32_t wb_vertex_match(const uint32_t* keys, int n, int W, int nlat, int pr, int pc, uint32_t me, bool* overwritten) {
+    uint32_t arrival = WB_NIL, departure = WB_NIL, mine = WB_NIL;
+    for (int q = 3; q >= 0; --q) {             // squares in raster order: the vertex is their corner lr, ll, ur, ul
+        const int r = pr - (q >> 1), c = pc - (q & 1);
+        if (r < 0 || c < 0 || r >= nlat - 1 || c >= W - 1) continue;
+        const int target = r * W + c;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (wb_key_sq(keys[mid]) < target) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= n || wb_key_sq(keys[lo]) != target) continue;
+        const int cs = wb_key_case(keys[lo]);
+        for (int sub = 0; sub < wb_case_nseg(cs); ++sub) {
+            const bool arr = wb_side_at_corner(wb_seg_to(cs, sub), q), dep = wb_side_at_corner(wb_seg_from(cs, sub), q);
+            if (arr == dep) continue;          // neither end on this vertex, or both: a zero-length segment, skipped
+            const uint32_t idx = (uint32_t)(lo + sub);
+            if (arr) {
+                if (departure != WB_NIL) { if (idx == me) mine = departure; departure = WB_NIL; }
+                else { if (arrival != WB_NIL) { *overwritten = true; } arrival = idx; }
+            } else {
+                if (arrival != WB_NIL) { if (arrival == me) mine = idx; arrival = WB_NIL; }
+                else { if (departure != WB_NIL) { *overwritten = true; } departure = idx; }
+            }
+        }
+    }
+    return mine;
+}
+
 
 // insert key; returns slot (or -1 when the table is full); *fresh = 1 if this call created the entry
 WB_DEV inline int wb_hash_insert(unsigned long long* hkey, int hmask, unsigned long long key, int* fresh) {
@@ -239,13 +296,14 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         }
         const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
         const double level = a.levels[job % a.nlev];
-        // a corner that equals the level puts the crossing ON a grid vertex: skimage's coordinate joins and
-        // the edge linking used here may then differ -> flag the job
+        // a corner that equals the level puts the crossing ON a grid vertex: joined by the vertex rule below; the
+        // job is flagged for the caller's information
         if (ul == level || ur == level || ll == level || lr == level) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_HIT);
         segk[dest] = key;
         if (lds) mk[dest] = key;
-        segf[dest] = wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level);
-        segt[dest] = wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level);
+        const int sfrom = wb_seg_from(cs, sub), sto = wb_seg_to(cs, sub);
+        segf[dest] = wb_crossing_point(sfrom, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sfrom, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
+        segt[dest] = wb_crossing_point(sto, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sto, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
         pred[g] = WB_NIL;
         t0[g] = 0;  // "is first segment of a cut loop"
     WB_END_PFOR
@@ -264,7 +322,15 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         else cc = c - 1;
         const int want = ts ^ 2;  // opposite side
         uint32_t s = WB_NIL;
-        if (rr >= 0 && rr < a.nlat - 1 && cc >= 0 && cc < W - 1) {
+        const uint32_t pt = segt[i];
+        if (pt & WB_PT_VERTEX) {
+            // the crossing sits on a grid vertex (a cell equal to the level): joined by skimage's coordinate rule
+            if (!((segf[i] & WB_PT_VERTEX) && segf[i] == pt)) {              // not a zero-length segment
+                bool overwritten = false;
+                s = wb_vertex_match(keys, n, W, a.nlat, wb_pt_y(pt & WB_PT_MASK), wb_pt_x(pt & WB_PT_MASK), (uint32_t)i, &overwritten);
+                if (overwritten) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_ORDER);
+            }
+        } else if (rr >= 0 && rr < a.nlat - 1 && cc >= 0 && cc < W - 1) {
             int lo = 0, hi = n;
             const int target = rr * W + cc;
             while (lo < hi) {
@@ -378,6 +444,16 @@ WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
         wb_rank_lists<uint32_t>(n, (uint32_t)WB_NIL, succ, t0, pred, a.w[2] + jb, a.w[3] + jb, a.w[5] + jb, a.w[7] + jb,
                                 a.w[9] + jb, a.w[10] + jb, start, dist);
     }
+    // contour_index.py:109 calls a contour closed when its first and last float coordinates are equal: besides the
+    // loops cut above that is an OPEN chain that leaves and reaches the same grid vertex (cells equal to the level)
+    const uint32_t* segf = a.mseg[1] + jb;
+    const uint32_t* segt = a.mseg[2] + jb;
+    WB_PFOR(i, n)
+        if (succ[i] == WB_NIL && (segt[i] & WB_PT_VERTEX)) {
+            const uint32_t s = start[i];
+            if (segf[s] == segt[i]) t0[s] = 1;
+        }
+    WB_END_PFOR
 }
 
 // -------------------------------------------------------------------------------------------- 2c: finish
@@ -456,10 +532,10 @@ WB_KERNEL_LB(wb_k_trace_finish, 1024, 8, WbTraceArgs a) {
         const uint32_t c = cid_of[start[i]];
         const int pos = (int)dist[i] - 1;
         const int p = rawbase[c] + pos + 1;
-        rawpt[p] = segt[i];
+        rawpt[p] = segt[i] & WB_PT_MASK;
         rawcid[p] = c;
         if (pos == 0) {
-            rawpt[rawbase[c]] = segf[i];
+            rawpt[rawbase[c]] = segf[i] & WB_PT_MASK;
             rawcid[rawbase[c]] = c;
             closed_raw[c] = (int)t0[i];
         }

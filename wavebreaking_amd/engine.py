@@ -1,5 +1,6 @@
 """Glue between the reference-shaped Python functions and the C ABI: one cached context per device,
 array extraction, level chunking (the ABI takes up to 4 levels per pass), frame <-> table conversion."""
+import logging
 import os
 
 import numpy as np
@@ -21,6 +22,48 @@ def set_global_max_hook(hook):
 
 def global_max(local_max):
     return int(local_max) if _global_max_hook is None else int(_global_max_hook(int(local_max)))
+
+
+logger = logging.getLogger(__name__)
+
+_FATAL = (
+    (_hip.STATUS_OVERFLOW_SEG, "more contour segments than the segment capacity allows (after the automatic retries)"),
+    (_hip.STATUS_HASH_FULL, "a hash table of the contour assembly ran full"),
+    (_hip.STATUS_OVERFLOW_PAIRS, "more candidate base-point pairs, streamers or overturning groups per contour than the "
+                                 "kernels hold; the event list would be truncated"),
+)
+LEVEL_ORDER_TEXT = ("cells equal to the contour level put two contour ends on one grid vertex: scikit-image's "
+                    "find_contours (contour_index.py:103) joins them in an order-dependent way there and may itself raise "
+                    "KeyError; that case is not reproduced.  Perturb the level by one ulp or unpack the field to float32 / float64.")
+
+
+def check_batch(batch, what, times=None, levels=None, pos=None, t0=0):
+    """Raise / warn on the per-(time step, level) status words and the guard-band counters of an ABI batch: a frame
+    that may differ from the reference's is never handed out silently."""
+    st = np.asarray(batch.status())
+    nlev = max(1, int(batch.nlev))
+
+    def where(jobs):
+        out = []
+        for j in jobs[:5]:
+            step, li = int(j) // nlev + int(t0), int(j) % nlev
+            date = times[step] if times is not None and pos is not None and step < len(times) else step
+            lvl = levels[pos[li]] if levels is not None and pos is not None and li < len(pos) else li
+            out.append("(%s, level %s)" % (date, lvl) if pos is not None else "(contour row %d)" % int(j))
+        return ", ".join(out) + (" ... %d in all" % len(jobs) if len(jobs) > 5 else "")
+
+    for bit, text in _FATAL:
+        jobs = np.nonzero(st & bit)[0]
+        if jobs.size:
+            raise RuntimeError("wavebreaking_amd %s: %s at %s" % (what, text, where(jobs)))
+    jobs = np.nonzero(st & _hip.STATUS_LEVEL_ORDER)[0]
+    if jobs.size:
+        raise ValueError("wavebreaking_amd %s: %s  Affected: %s" % (what, LEVEL_ORDER_TEXT, where(jobs)))
+    geo, cont = batch.band_hits()
+    if geo or cont:
+        logger.warning("wavebreaking_amd %s: %d great-circle and %d along-contour distance comparisons fell within the guard band "
+                       "of their threshold (streamer_index.py:138) and were re-evaluated in the reference's operation order; "
+                       "they may still depend on the last bit of the math library" % (what, geo, cont))
 
 
 def get_context(device=None):
@@ -79,6 +122,13 @@ def contour_batches(prep, levels, periodic_add, params, want_cells=False):
             pos = list(range(lo, min(lo + MAX_LEVELS, len(levels))))
             b = ctx.contours(prep.values[t0:t1], prep.lat, prep.lon, [float(levels[i]) for i in pos], prep.dlon, prep.dlat,
                              periodic_add=periodic_add, intensity=inten, want_cells=want_cells, **params)
+            try:
+                check_batch(b, "contours", prep.times, levels, pos, t0)
+            except Exception:
+                b.close()
+                for ob, *_ in out:
+                    ob.close()
+                raise
             out.append((b, pos, t0))
     return out
 

@@ -45,6 +45,12 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     batches = list(batches)
     for bi, (b, pos, t0) in enumerate(batches):
         b.indices(g, **which)
+        try:
+            engine.check_batch(b, "indices", prep.times, levels, pos, t0)
+        except Exception:
+            for ob, *_ in batches:
+                ob.close()
+            raise
         ev = b.events(kind)
         for k in range(ev["step"].size):
             lvl = ev["level_idx"][k]
