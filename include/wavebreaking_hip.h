@@ -127,8 +127,9 @@ int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont);            /* th
 /* calculate_properties truncates x_com / areas and y_com / areas (index_utils.py:105-110); events whose quotient lies
    within the rounding slack of an integer have their three sums re-evaluated cell by cell in the reference's order
    (pandas' compensated group sum over rows in (y, x) order, index_utils.py:91-102).  Counts of the last wb_indices:
-   rasterised events (streamers, cutoffs) / overturning boxes that took that path. */
-int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes);
+   rasterised events (streamers, cutoffs) / overturning boxes that took that path / boxes among them whose row-parallel
+   evaluation could not be verified and which were walked by one lane instead. */
+int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes, int64_t* boxes_one_lane);
 /* streamer all-pairs test of the last wb_indices: base-point pairs covered (sum of N(N-1)/2 over the selected contours,
    streamer_index.py:130-157) and candidate pairs found */
 int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs);

@@ -168,3 +168,15 @@ def test_cells_equal_to_the_level_full_path(sim, seed):
     got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2.0], intensity=pv)
     assert got["status"][0] & _hip.STATUS_LEVEL_HIT and not (got["status"][0] & _hip.STATUS_LEVEL_ORDER)
     lib.lib.wb_hostsim_set_reverse(0)
+
+
+def test_box_com_one_lane_walk():
+    # a build whose row-parallel box evaluation never applies (2 rows at most): every box in the guard band is walked
+    # cell by cell by one lane -- same sums
+    lib = _hip.Library(helpers.build_hostsim(variant="boxlane", defines=("WB_BOXCOM_ROWS=2",)), allow_hostsim=True)
+    ctx = _hip.Context(0, lib)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(0, 6, lat, lon, eps=0.3)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(6), [-2, 2], intensity=pv)
+    assert got["com_rechecks"][1] >= 8 and got["com_rechecks"][2] == got["com_rechecks"][1]
+    ctx.close()

@@ -86,7 +86,7 @@ class Library:
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        lib.wb_get_com_rechecks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.wb_get_com_rechecks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
         lib.wb_free_batch.argtypes = [C.c_void_p]
         lib.wb_dev_alloc.argtypes = [C.c_void_p, C.c_uint64]
@@ -445,11 +445,11 @@ class Batch:
         return int(g.value), int(c.value)
 
     def com_rechecks(self):
-        """(rasterised events, boxes) whose areas / x_com / y_com were re-evaluated cell by cell in the reference's
-        order because x_com / areas or y_com / areas sat next to an integer (last indices() call)."""
-        a, c = C.c_int64(), C.c_int64()
-        self.ctx.L.lib.wb_get_com_rechecks(self.h, C.byref(a), C.byref(c))
-        return int(a.value), int(c.value)
+        """(rasterised events, boxes, boxes walked by one lane) whose areas / x_com / y_com were re-evaluated cell by cell
+        in the reference's order because x_com / areas or y_com / areas sat next to an integer (last indices() call)."""
+        a, c, o = C.c_int64(), C.c_int64(), C.c_int64()
+        self.ctx.L.lib.wb_get_com_rechecks(self.h, C.byref(a), C.byref(c), C.byref(o))
+        return int(a.value), int(c.value), int(o.value)
 
     def pair_stats(self):
         """(base-point pairs covered by the all-pairs test, candidate pairs found) of the last indices() call."""

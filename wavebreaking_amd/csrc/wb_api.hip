@@ -307,7 +307,7 @@ struct wb_batch {
     int *sel_job = nullptr, *sel_cont = nullptr, *cut_job = nullptr, *cut_cont = nullptr;
     long long band[2] = {0, 0};
     long long pair_stats[2] = {0, 0};       // base-point pairs covered by the all-pairs test / candidate pairs found
-    long long com_rechecks[2] = {0, 0};     // events / boxes whose centre-of-mass sums were re-evaluated in the reference's order
+    long long com_rechecks[3] = {0, 0, 0};     // events / boxes whose centre-of-mass sums were re-evaluated in the reference's order
     // batches built from a user-supplied contour frame: one job per contour row
     std::vector<int> job_step, job_level;
     int* d_job_step = nullptr;
@@ -690,10 +690,11 @@ extern "C" int wb_set_index_params(wb_batch* b, double geo_dis, double cont_dis,
     return 0;
 }
 
-extern "C" int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes) {
+extern "C" int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes, int64_t* boxes_one_lane) {
     if (!b) return 1;
     *events = b->com_rechecks[0];
     *boxes = b->com_rechecks[1];
+    *boxes_one_lane = b->com_rechecks[2];
     return 0;
 }
 
@@ -1184,11 +1185,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         pa.ev_sums = (double*)talloc((size_t)NE * 5 * sizeof(double));
         pa.ev_ncells = (int*)talloc((size_t)NE * sizeof(int));
         pa.cell_count = (unsigned long long*)talloc(sizeof(unsigned long long));
-        pa.com_rechecks = (int*)talloc(2 * sizeof(int));
+        pa.com_rechecks = (int*)talloc(3 * sizeof(int));
         pa.ev_cell_off = (long long*)talloc((size_t)NE * sizeof(long long));
         if (!pa.ev_cell_off) return 1;
         dmemset(ctx, pa.cell_count, 0, sizeof(unsigned long long));
-        dmemset(ctx, pa.com_rechecks, 0, 2 * sizeof(int));
+        dmemset(ctx, pa.com_rechecks, 0, 3 * sizeof(int));
         if (NO > 0 && pa.r2 <= 1.0) {
             // areas / x_com / y_com of the boxes (wb_k_props leaves those three slots of a box to this kernel)
             WbBoxComArgs ba;
@@ -1196,7 +1197,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             ba.nev = NO; ba.first = NS; ba.nlat = p.nlat; ba.W = b->W; ba.ev = d_ev; ba.wlat = b->d_wlat;
             ba.ev_sums = pa.ev_sums; ba.com_rechecks = pa.com_rechecks;
             b->timer.begin(ctx, "box_com");
-            WB_LAUNCH(wb_k_box_com, (NO + WB_BOXCOM_PER_WG - 1) / WB_BOXCOM_PER_WG, 64, ba);
+            WB_LAUNCH(wb_k_box_com, NO, 64, ba);
             b->timer.end(ctx);
         }
         unsigned long long cell_cap = p.want_cells ? (unsigned long long)NE * 4096ull : 0ull;
@@ -1262,10 +1263,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
         d2h(ctx, h_nc.data(), pa.ev_ncells, (size_t)NE * sizeof(int));
         {
-            int rc2[2] = {0, 0};
+            int rc2[3] = {0, 0, 0};
             d2h(ctx, rc2, pa.com_rechecks, sizeof(rc2));
             b->com_rechecks[0] = rc2[0];
             b->com_rechecks[1] = rc2[1];
+            b->com_rechecks[2] = rc2[2];
         }
         if (p.want_cells) {
             d2h(ctx, h_coff.data(), pa.ev_cell_off, (size_t)NE * sizeof(long long));

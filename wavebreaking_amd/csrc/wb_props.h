@@ -48,7 +48,7 @@ struct WbPropsArgs {
     double* rowacc;             // [nslots][4][nlat]
     double* ev_sums;            // [nev][5]: areas, mean_var, intensity, x_com, y_com  (sums, :94-102)
     int* ev_ncells;             // [nev]
-    int* com_rechecks;          // [2] events / boxes whose areas, x_com, y_com were re-evaluated in the reference's order
+    int* com_rechecks;          // [3] events / boxes whose areas, x_com, y_com were re-evaluated in the reference's order (wb_k_box_com)
     unsigned long long* cell_count;  // [1] bump allocator of the cell pool
     unsigned long long cell_cap;
     uint32_t* cell_pool;        // (x | y<<16)
@@ -386,58 +386,223 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 }
 
 // areas / x_com / y_com of the overturning boxes (the events wb_k_props does not rasterise): every cell of the closed box
-// counts, so the row-wise sums are closed forms and the reference-order re-evaluation needs no raster either -- one lane
-// per box, WB_BOXCOM_PER_WG boxes per single-wave workgroup (a box in the guard band walks its rows x cols cells
-// sequentially: few lanes per wave keep a wave's duration near its longest box).  Launched on the side stream next to
-// wb_k_props; the two kernels write disjoint slots of ev_sums.
-#define WB_BOXCOM_PER_WG 8
+// counts, so the row-wise sums are closed forms.  A box with min_lon + max_lon even has x_com / areas = an integer
+// mathematically -- half of all boxes need the reference-order re-evaluation, a chain of rows x cols dependent compensated
+// additions (up to 10^5 cells).  One workgroup per box makes that chain row-parallel and still bit-exact:
+//   * a step of pandas' compensated sum (y = v - c; t = s + y; c = t - s - y) is EXACT -- s - c grows by exactly v -- unless
+//     v - c needs rounding, which happens where the terms step up into a higher binade (c still carries the finer bits of
+//     the previous terms); between such steps the state is a function of the exact running total E alone: s = RN(E), c = s - E;
+//   * pass 1 (lane per row): the row's terms fl(x * w) cut into segments at every binade step-up; first term and exact
+//     128-bit fixed-point total of the rest of each segment;
+//   * pass 2 (one lane per chain, O(1) per segment): state from E, the REAL step for the segment's first term, E := s - c
+//     exactly, E += rest; this predicts the state at the start of every row;
+//   * pass 3 (lane per row): the real recurrence over the whole row from the predicted state; its end state must equal the
+//     state predicted for the next row bit for bit.  All rows verified => the chained states are exactly those of the
+//     sequential walk (induction from the first row, whose start state 0, 0 is certain).  Any mismatch (a rounding tie, an
+//     inexact step elsewhere), more than WB_BOXCOM_SEGS segments in a row or more than WB_BOXCOM_ROWS rows => one lane walks
+//     all cells instead (counted in com_rechecks[2]); correctness never rests on the prediction.
+#ifndef WB_BOXCOM_ROWS
+#define WB_BOXCOM_ROWS 256
+#endif
+#define WB_BOXCOM_SEGS 4
+typedef unsigned __int128 wb_u128;
 struct WbBoxComArgs {
     int nev, first, nlat, W;      // events [first, first + nev) are the overturning boxes
     const int* ev;                // [..][8]
     const double* wlat;
     double* ev_sums;              // [..][5]: slots 0, 3, 4 written here
-    int* com_rechecks;            // [2]
+    int* com_rechecks;            // [3]: rasterised events / boxes re-evaluated / boxes that needed the one-lane walk
 };
+// v = m * 2^e, m < 2^53 (v >= 0, finite)
+WB_HD inline void wb_dbl_split(double v, unsigned long long* m, int* e) {
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    const int ef = (int)((b >> 52) & 0x7FF);
+    const unsigned long long fr = b & 0xFFFFFFFFFFFFFull;
+    if (ef == 0) { *m = fr; *e = -1074; } else { *m = fr | (1ull << 52); *e = ef - 1075; }
+}
+WB_HD inline wb_u128 wb_fix128(double v, int ue) {
+    unsigned long long m; int e;
+    wb_dbl_split(v, &m, &e);
+    if (!m) return (wb_u128)0;
+    if (e >= ue) return (wb_u128)m << (e - ue);
+    // a small multiple of 2^ue (a compensation term): its 53-bit mantissa ends in zeros
+    return ue - e > 63 ? (wb_u128)0 : (wb_u128)(m >> (ue - e));
+}
+// state (s, c) of the compensated sum whose exact running total is E * 2^ue, every step having been exact: s = RN(E),
+// c = s - E.  false: c does not fit a double (such a state cannot have been reached by exact steps)
+WB_HD inline bool wb_state_from_exact(wb_u128 E, int ue, double* s, double* c) {
+    if (E == 0) { *s = 0.0; *c = 0.0; return true; }
+    const unsigned long long hi = (unsigned long long)(E >> 64), lo = (unsigned long long)E;
+    const int msb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
+    if (msb <= 52) { *s = ldexp((double)lo, ue); *c = 0.0; return true; }
+    const int sh = msb - 52;
+    if (sh > 53) return false;
+    unsigned long long q = (unsigned long long)(E >> sh);
+    const wb_u128 rem = E - ((wb_u128)q << sh), half = (wb_u128)1 << (sh - 1);
+    const bool up = rem > half || (rem == half && (q & 1ull));
+    if (up) q += 1;
+    *s = ldexp((double)q, sh + ue);
+    if (up) *c = ldexp((double)(unsigned long long)(((wb_u128)q << sh) - E), ue);
+    else *c = rem ? -ldexp((double)(unsigned long long)rem, ue) : 0.0;
+    return true;
+}
+
+WB_DEV inline int wb_dbl_exp(double v) { unsigned long long m; int e; wb_dbl_split(v, &m, &e); return m ? e : -100000; }
+
 WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
-    WB_PFOR(k, WB_BOXCOM_PER_WG)
-        const int q = WB_BLOCK_ID * WB_BOXCOM_PER_WG + (int)k;
-        if (q < a.nev) {
-            const int e = a.first + q;
-            const int* d = a.ev + (size_t)e * 8;
-            int x0 = d[3], y0 = d[4], x1 = d[5], y1 = d[6];
-            if (x0 < 0) x0 = 0;
-            if (y0 < 0) y0 = 0;
-            if (x1 > a.W - 1) x1 = a.W - 1;
-            if (y1 > a.nlat - 1) y1 = a.nlat - 1;
-            const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
-            const double cnt = (double)cols;
-            const double sxr = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
-            double areas = 0.0, xc = 0.0, yc = 0.0;
-            for (int y = y0; y <= y1; ++y) {
-                const double w = a.wlat[y];
-                areas = areas + w * cnt;
-                xc = xc + w * sxr;
-                yc = yc + w * ((double)y * cnt);
-            }
-            const double ulps = wb_com_ulps(rows);
-            if (cols > 0 && rows > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps))) {
-                double sa = 0.0, ca = 0.0, sx = 0.0, cx = 0.0, sy = 0.0, cy = 0.0;
-                for (int y = y0; y <= y1; ++y) {
-                    const double w = a.wlat[y];
-                    const double yw = (double)y * w;
-                    for (int x = x0; x <= x1; ++x) {
-                        const double xw = (double)x * w;
-                        WB_KAHAN(sa, ca, w);
-                        WB_KAHAN(sx, cx, xw);
-                        WB_KAHAN(sy, cy, yw);
-                    }
+    WB_SHARED(double, segv, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);                // x chain: first term of a row's segment
+    WB_SHARED(unsigned long long, seglo, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);   // ... exact total of the segment's other terms
+    WB_SHARED(unsigned long long, seghi, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);
+    WB_SHARED(int, nseg, WB_BOXCOM_ROWS);
+    WB_SHARED(double, st, 6 * (WB_BOXCOM_ROWS + 1));             // per chain: predicted state s, c at the start of every row (+ after the last)
+    WB_SHARED(int, ctl, 4);                                      // [0] in band, [1] unit exponent, [2] not verified
+    const int q = WB_BLOCK_ID;
+    if (q >= a.nev) return;
+    const int e = a.first + q;
+    const int* d = a.ev + (size_t)e * 8;
+    int x0 = d[3], y0 = d[4], x1 = d[5], y1 = d[6];
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > a.W - 1) x1 = a.W - 1;
+    if (y1 > a.nlat - 1) y1 = a.nlat - 1;
+    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
+    WB_SINGLE
+    const double cnt = (double)cols;
+    const double sxr = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
+    double areas = 0.0, xc = 0.0, yc = 0.0;
+    int emin = 4096, emax = -4096;
+    for (int y = y0; y <= y1; ++y) {
+        const double w = a.wlat[y];
+        areas = areas + w * cnt;
+        xc = xc + w * sxr;
+        yc = yc + w * ((double)y * cnt);
+        unsigned long long m; int ex;
+        wb_dbl_split(w, &m, &ex);
+        if (m) { emin = ex < emin ? ex : emin; emax = ex > emax ? ex : emax; }
+    }
+    const double ulps = wb_com_ulps(rows);
+    const bool band = cols > 0 && rows > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps));
+    ctl[0] = band ? 1 : 0;
+    ctl[1] = emin;
+    // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
+    ctl[2] = (rows > WB_BOXCOM_ROWS || emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
+    if (!band) {
+        a.ev_sums[(size_t)e * 5 + 0] = areas;
+        a.ev_sums[(size_t)e * 5 + 3] = xc;
+        a.ev_sums[(size_t)e * 5 + 4] = yc;
+    } else {
+        wb_atomic_add(&a.com_rechecks[1], 1);
+    }
+    WB_END_SINGLE
+    if (!ctl[0]) return;
+    const int ue = ctl[1];
+    if (!ctl[2]) {
+        // pass 1: segments of the x chain, row by row
+        WB_PFOR(r, rows)
+            const double w = a.wlat[y0 + (int)r];
+            int ns = 0, eprev = 0;
+            wb_u128 rest = 0;
+            bool over = false;
+            for (int x = x0; x <= x1; ++x) {
+                const double p = (double)x * w;
+                const int ep = wb_dbl_exp(p);
+                if (x == x0 || ep > eprev) {                     // row start or a step up into a higher binade: new segment
+                    if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
+                    if (ns == WB_BOXCOM_SEGS) { over = true; break; }
+                    segv[ns * WB_BOXCOM_ROWS + r] = p;
+                    rest = 0;
+                    ++ns;
+                } else {
+                    rest += wb_fix128(p, ue);
                 }
-                areas = sa; xc = sx; yc = sy;
-                wb_atomic_add(&a.com_rechecks[1], 1);
+                eprev = ep;
             }
-            a.ev_sums[(size_t)e * 5 + 0] = areas;
-            a.ev_sums[(size_t)e * 5 + 3] = xc;
-            a.ev_sums[(size_t)e * 5 + 4] = yc;
+            if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
+            nseg[r] = ns;
+            if (over) ctl[2] = 1;
+        WB_END_PFOR
+    }
+    if (!ctl[2]) {
+        // pass 2: predicted state at every row start; chains 0 areas (terms w), 1 x_com (x * w), 2 y_com (y * w)
+        WB_PFOR(ch, 3)
+            wb_u128 E = 0;
+            bool ok = true;
+            for (int r = 0; r < rows && ok; ++r) {
+                const int y = y0 + r;
+                const double w = a.wlat[y];
+                const int ns = ch == 1 ? nseg[r] : 1;
+                for (int k = 0; k < ns && ok; ++k) {
+                    double sv, cv;
+                    ok = wb_state_from_exact(E, ue, &sv, &cv);
+                    if (k == 0) { st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + r] = sv; st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + r] = cv; }
+                    double v;
+                    wb_u128 rest;
+                    if (ch == 1) {
+                        v = segv[k * WB_BOXCOM_ROWS + r];
+                        rest = ((wb_u128)seghi[k * WB_BOXCOM_ROWS + r] << 64) | seglo[k * WB_BOXCOM_ROWS + r];
+                    } else {
+                        v = ch == 0 ? w : (double)y * w;
+                        unsigned long long m; int ex;
+                        wb_dbl_split(v, &m, &ex);
+                        rest = m ? (((wb_u128)m * (unsigned)(cols - 1)) << (ex - ue)) : (wb_u128)0;
+                    }
+                    WB_KAHAN(sv, cv, v);                          // the real step for the segment's first term
+                    E = wb_fix128(sv, ue);                         // s - c exactly
+                    if (cv > 0.0) { const wb_u128 f = wb_fix128(cv, ue); if (f > E) ok = false; else E -= f; }
+                    else if (cv < 0.0) E += wb_fix128(-cv, ue);
+                    E += rest;
+                }
+            }
+            double sv = 0.0, cv = 0.0;
+            ok = ok && wb_state_from_exact(E, ue, &sv, &cv);
+            st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + rows] = sv;
+            st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + rows] = cv;
+            if (!ok) ctl[2] = 1;
+        WB_END_PFOR
+    }
+    if (!ctl[2]) {
+        // pass 3: the real recurrence over every row from its predicted state; the end must be the next row's start
+        WB_PFOR(r, rows)
+            const int y = y0 + (int)r;
+            const double w = a.wlat[y], yw = (double)y * w;
+            double sa = st[0 * (WB_BOXCOM_ROWS + 1) + r], ca = st[1 * (WB_BOXCOM_ROWS + 1) + r];
+            double sx = st[2 * (WB_BOXCOM_ROWS + 1) + r], cx = st[3 * (WB_BOXCOM_ROWS + 1) + r];
+            double sy = st[4 * (WB_BOXCOM_ROWS + 1) + r], cy = st[5 * (WB_BOXCOM_ROWS + 1) + r];
+            for (int x = x0; x <= x1; ++x) {
+                const double xw = (double)x * w;
+                WB_KAHAN(sa, ca, w);
+                WB_KAHAN(sx, cx, xw);
+                WB_KAHAN(sy, cy, yw);
+            }
+            if (!(sa == st[0 * (WB_BOXCOM_ROWS + 1) + r + 1] && ca == st[1 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
+                  sx == st[2 * (WB_BOXCOM_ROWS + 1) + r + 1] && cx == st[3 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
+                  sy == st[4 * (WB_BOXCOM_ROWS + 1) + r + 1] && cy == st[5 * (WB_BOXCOM_ROWS + 1) + r + 1])) ctl[2] = 1;
+        WB_END_PFOR
+    }
+    WB_SINGLE
+    double sa, sx, sy;
+    if (ctl[2]) {                                                // not verified: one lane walks every cell in the reference's order
+        double ca = 0.0, cx = 0.0, cy = 0.0;
+        sa = 0.0; sx = 0.0; sy = 0.0;
+        for (int y = y0; y <= y1; ++y) {
+            const double w = a.wlat[y];
+            const double yw = (double)y * w;
+            for (int x = x0; x <= x1; ++x) {
+                const double xw = (double)x * w;
+                WB_KAHAN(sa, ca, w);
+                WB_KAHAN(sx, cx, xw);
+                WB_KAHAN(sy, cy, yw);
+            }
         }
-    WB_END_PFOR
+        wb_atomic_add(&a.com_rechecks[2], 1);
+    } else {
+        sa = st[0 * (WB_BOXCOM_ROWS + 1) + rows];
+        sx = st[2 * (WB_BOXCOM_ROWS + 1) + rows];
+        sy = st[4 * (WB_BOXCOM_ROWS + 1) + rows];
+    }
+    a.ev_sums[(size_t)e * 5 + 0] = sa;
+    a.ev_sums[(size_t)e * 5 + 3] = sx;
+    a.ev_sums[(size_t)e * 5 + 4] = sy;
+    WB_END_SINGLE
 }
