@@ -133,6 +133,9 @@ int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes, int64_t* b
 /* streamer all-pairs test of the last wb_indices: base-point pairs covered (sum of N(N-1)/2 over the selected contours,
    streamer_index.py:130-157) and candidate pairs found */
 int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs);
+/* ... and the pairs whose great-circle term was actually evaluated (the others were excluded as whole blocks or by the
+   |dx| / |dy| reach tests) */
+int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated);
 /* per-stage device times of the last wb_contours / wb_indices calls, measured with HIP events on the
    context's stream: names is a NUL-separated list */
 int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);

@@ -86,6 +86,7 @@ class Library:
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.wb_get_evaluated_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.wb_get_com_rechecks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
         lib.wb_free_batch.argtypes = [C.c_void_p]
@@ -456,6 +457,12 @@ class Batch:
         a, c = C.c_int64(), C.c_int64()
         self.ctx.L.lib.wb_get_pair_stats(self.h, C.byref(a), C.byref(c))
         return int(a.value), int(c.value)
+
+    def evaluated_pairs(self):
+        """pairs whose great-circle term the all-pairs kernel actually evaluated (last indices() call)"""
+        a = C.c_int64()
+        self.ctx.L.lib.wb_get_evaluated_pairs(self.h, C.byref(a))
+        return int(a.value)
 
     def timings(self):
         names = C.c_char_p()

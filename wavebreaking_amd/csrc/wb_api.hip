@@ -5,6 +5,7 @@
 #include "../../include/wavebreaking_hip.h"
 
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -58,6 +59,19 @@ struct wb_ctx {
     void* pin = nullptr;
     size_t pin_bytes = 0;
 #endif
+    // per-grid device tables (trigonometric tables, area weights, the all-pairs reach per latitude row): built once per
+    // (lat, lon, resolution, geo_dis) and shared by every batch of the context
+    struct Tables {
+        std::vector<double> lat, lon;
+        double dlon = 0, dlat = 0, geo_dis = 0;
+        double* base = nullptr;
+        size_t o_lat = 0, o_latrad = 0, o_sphi2 = 0, o_cphi2 = 0, o_cphi = 0, o_wlat = 0, o_lonrad = 0, o_slam2 = 0, o_clam2 = 0;
+        int* dxlim = nullptr;
+        int dy_max = 0;
+        double hthr = 0;
+    };
+    std::vector<Tables*> tables;
+    WbCtl* h_ctl = nullptr;                   // pinned: where the control block of a batch lands (two snapshots)
 };
 
 #include <chrono>
@@ -215,6 +229,62 @@ static int dsync(wb_ctx* c) {
 }
 #endif
 
+// asynchronous device-to-host copy into PINNED memory on the context's current stream (no synchronisation)
+static int d2h_async(wb_ctx* c, void* dst_pinned, const void* src, size_t bytes) {
+    if (!bytes) return 0;
+#if defined(WB_HOSTSIM)
+    (void)c;
+    memcpy(dst_pinned, src, bytes);
+    return 0;
+#else
+    return hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess;
+#endif
+}
+static WbCtl* host_ctl(wb_ctx* c) {
+    if (c->h_ctl) return c->h_ctl;
+#if defined(WB_HOSTSIM)
+    c->h_ctl = (WbCtl*)calloc(2, sizeof(WbCtl));
+#else
+    void* q = nullptr;
+    if (hipHostMalloc(&q, 2 * sizeof(WbCtl), hipHostMallocDefault) != hipSuccess) return nullptr;
+    c->h_ctl = (WbCtl*)q;
+#endif
+    return c->h_ctl;
+}
+// side stream: the launches between side_begin and side_end run next to whatever follows on the main stream
+static void side_begin(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    (void)hipEventRecord(ctx->fork, ctx->stream);
+    (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
+    std::swap(ctx->stream, ctx->stream2);
+#else
+    (void)ctx;
+#endif
+}
+static void side_end(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    (void)hipEventRecord(ctx->join, ctx->stream);
+    std::swap(ctx->stream, ctx->stream2);
+#else
+    (void)ctx;
+#endif
+}
+static void side_join(wb_ctx* ctx) {          // the main stream waits for the side stream's last side_end
+#if !defined(WB_HOSTSIM)
+    (void)hipStreamWaitEvent(ctx->stream, ctx->join, 0);
+#else
+    (void)ctx;
+#endif
+}
+static int side_sync(wb_ctx* ctx) {           // the HOST waits for the side stream
+#if !defined(WB_HOSTSIM)
+    return hipStreamSynchronize(ctx->stream2) != hipSuccess;
+#else
+    (void)ctx;
+    return 0;
+#endif
+}
+
 // stage timer: HIP events on the context's stream (host simulation: zeros)
 struct WbTimer {
     std::vector<std::string> names;
@@ -267,6 +337,16 @@ struct WbTimer {
         }
 #endif
     }
+    void truncate(size_t n) {               // forget the stages after the first n (a repeated phase)
+        collect();
+        if (n >= names.size()) return;
+        names.resize(n);
+        ms.resize(n);
+#if !defined(WB_HOSTSIM)
+        ev0.resize(n);
+        ev1.resize(n);
+#endif
+    }
     void clear() {
         collect();
         names.clear();
@@ -294,7 +374,6 @@ struct wb_batch {
     int nstrips = 0, nwork_strips = 0, cap_strip = 0;
     uint32_t *cpts = nullptr, *cown = nullptr;
     int *c_off = nullptr, *c_len = nullptr, *c_closed = nullptr, *c_nux = nullptr, *c_sumy = nullptr, *ncont = nullptr;
-    int* d_max_nux = nullptr;
     std::vector<void*> phase1_scratch;
     int max_nux = 0;
     std::vector<int> h_ncont;
@@ -306,7 +385,10 @@ struct wb_batch {
     int nsel = 0, ncut = 0;
     int *sel_job = nullptr, *sel_cont = nullptr, *cut_job = nullptr, *cut_cont = nullptr;
     long long band[2] = {0, 0};
-    long long pair_stats[2] = {0, 0};       // base-point pairs covered by the all-pairs test / candidate pairs found
+    long long pair_stats[3] = {0, 0, 0};    // base-point pairs covered by the all-pairs test / candidates found / pairs evaluated
+    WbCtl* d_ctl = nullptr;                 // device control block of the batch
+    WbCtl h_ctl;                            // its phase-1 values (host copy)
+    std::vector<std::pair<void*, size_t>> hres;   // pinned host blocks of the result copies
     long long com_rechecks[3] = {0, 0, 0};     // events / boxes whose centre-of-mass sums were re-evaluated in the reference's order
     // batches built from a user-supplied contour frame: one job per contour row
     std::vector<int> job_step, job_level;
@@ -324,6 +406,7 @@ struct wb_batch {
     int32_t *poly_x = nullptr, *poly_y = nullptr;   // polygon vertices of all events (streamers, overturnings, cutoffs)
     size_t poly_n = 0, poly_bytes = 0;
     WbTimer timer;
+    size_t timer_phase1 = 0;                // stages recorded by wb_contours
     std::string timer_names;
 };
 
@@ -385,6 +468,14 @@ int wb_create(int device_id, wb_ctx** out) {
 void wb_destroy(wb_ctx* c) {
     if (!c) return;
     for (auto& kv : c->hpool) hrelease(kv.second);
+    for (wb_ctx::Tables* t : c->tables) delete t;
+    if (c->h_ctl) {
+#if defined(WB_HOSTSIM)
+        free(c->h_ctl);
+#else
+        (void)hipHostFree(c->h_ctl);
+#endif
+    }
 #if !defined(WB_HOSTSIM)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
@@ -420,6 +511,31 @@ void wb_free_batch(wb_batch* b) {
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------ phase 1
+// bounds for phase 2 + the ONE read-back of phase 1: control block and contour counts per job
+static int phase1_summary(wb_batch* b) {
+    wb_ctx* ctx = b->ctx;
+    WbCtl* hc = host_ctl(ctx);
+    if (!hc) return wb_fail(ctx, "out of pinned host memory");
+    WbSummaryArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.njobs = b->njobs; sa.cap_seg = b->cap_seg; sa.ncont = b->ncont; sa.c_len = b->c_len; sa.c_nux = b->c_nux;
+    sa.c_closed = b->c_closed; sa.ctl = b->d_ctl;
+    b->timer.begin(ctx, "summary");
+    WB_LAUNCH(wb_k_phase1_summary, b->njobs < 4096 ? b->njobs : 4096, 64, sa);
+    b->timer.end(ctx);
+    size_t got = 0;
+    int* h_nc = (int*)hmalloc(ctx, (size_t)(b->njobs + 1) * sizeof(int), &got);
+    if (!h_nc) return wb_fail(ctx, "out of pinned host memory");
+    d2h_async(ctx, &hc[0], b->d_ctl, sizeof(WbCtl));
+    d2h_async(ctx, h_nc, b->ncont, (size_t)b->njobs * sizeof(int));
+    const int rc = dsync(ctx);
+    b->h_ctl = hc[0];
+    b->max_nux = b->h_ctl.max_nux;
+    b->h_ncont.assign(h_nc, h_nc + b->njobs);
+    hfree(ctx, h_nc, got);
+    return rc;
+}
+
 static int run_phase1(wb_batch* b) {
     wb_ctx* ctx = b->ctx;
     const wb_params& p = b->p;
@@ -441,8 +557,8 @@ static int run_phase1(wb_batch* b) {
     b->c_nux = balloc<int>(b, per);
     b->c_sumy = balloc<int>(b, per);
     b->ncont = balloc<int>(b, J);
-    b->d_max_nux = balloc<int>(b, 1);
-    if (!b->d_max_nux) return 1;
+    b->d_ctl = balloc<WbCtl>(b, 1);
+    if (!b->d_ctl) return 1;
     WbTraceArgs ta;
     memset(&ta, 0, sizeof(ta));
     std::vector<void*>& sc = b->phase1_scratch;
@@ -460,7 +576,7 @@ static int run_phase1(wb_batch* b) {
     dmemset(ctx, b->status, 0, (size_t)J * sizeof(uint32_t));
     WB_TICK("phase1 memset launch call");
     if (wb_debug()) { dsync(ctx); WB_TICK("phase1 memset status sync"); }
-    dmemset(ctx, b->d_max_nux, 0, sizeof(int));
+    dmemset(ctx, b->d_ctl, 0, sizeof(WbCtl));
     dmemset(ctx, b->stg_n, 0, (size_t)J * NS * sizeof(int));
     if (wb_debug()) { dsync(ctx); WB_TICK("phase1 memsets+sync"); }
 
@@ -545,7 +661,7 @@ static int run_phase1(wb_batch* b) {
     ta.stg_k = b->stg_k; ta.stg_v = b->stg_v; ta.stg_n = b->stg_n; ta.dtype = p.dtype; ta.nlev = p.nlevels;
     for (int l = 0; l < p.nlevels; ++l) ta.levels[l] = b->levels[l];
     ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
-    ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.max_nux = b->d_max_nux;
+    ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.ctl = b->d_ctl;
     b->timer.begin(ctx, "trace_link");
     WB_LAUNCH(wb_k_trace_link, J, 512, ta);
     b->timer.end(ctx);
@@ -555,9 +671,9 @@ static int run_phase1(wb_batch* b) {
     b->timer.begin(ctx, "trace_finish");
     WB_LAUNCH(wb_k_trace_finish, J, 1024, ta);
     b->timer.end(ctx);
-    WB_TICK("phase1 launches");
-    if (dsync(ctx)) return 1;
-    WB_TICK("phase1 sync");
+    if (phase1_summary(b)) return 1;
+    b->timer_phase1 = b->timer.names.size();
+    WB_TICK("phase1 launches + sync");
     return 0;
 }
 
@@ -616,18 +732,7 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
         b->cap_strip = caps;
         b->timer.clear();
         if (run_phase1(b)) { std::string e = ctx->err; wb_free_batch(b); return wb_fail(ctx, e); }
-        std::vector<int> nseg((size_t)b->njobs * b->nstrips);
-        d2h(ctx, nseg.data(), b->stg_n, nseg.size() * sizeof(int));
-        int mx = 0, mxs = 0;
-        for (int j = 0; j < b->njobs; ++j) {
-            int tot = 0;
-            for (int q = 0; q < b->nstrips; ++q) {
-                const int v = nseg[(size_t)j * b->nstrips + q];
-                tot += v;
-                mxs = v > mxs ? v : mxs;
-            }
-            mx = tot > mx ? tot : mx;
-        }
+        const int mx = b->h_ctl.max_seg_job, mxs = b->h_ctl.max_seg_strip;     // non-zero only when a capacity was exceeded
         if (mx <= cap && mxs <= caps) break;
         // overflow: free everything phase 1 allocated (the field copies stay) and retry with room to spare
         std::vector<void*> keep;
@@ -641,11 +746,7 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
         if (caps > cap) caps = cap;
         if (attempt == 5) { wb_free_batch(b); return wb_fail(ctx, "segment capacity overflow"); }
     }
-    b->h_ncont.resize(b->njobs);
-    b->h_status.resize(b->njobs);
-    d2h(ctx, b->h_ncont.data(), b->ncont, b->njobs * sizeof(int));
-    d2h(ctx, b->h_status.data(), b->status, b->njobs * sizeof(uint32_t));
-    d2h(ctx, &b->max_nux, b->d_max_nux, sizeof(int));
+    b->h_status.assign(b->njobs, 0);
     // phase-1 scratch is dead now
     double wb_t0_ = wb_now_ms();
     for (void* q : b->phase1_scratch) bfree_one(b, q);
@@ -702,6 +803,11 @@ extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* can
     if (!b) return 1;
     *point_pairs = b->pair_stats[0];
     *candidate_pairs = b->pair_stats[1];
+    return 0;
+}
+extern "C" int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated) {
+    if (!b) return 1;
+    *evaluated = b->pair_stats[2];
     return 0;
 }
 
@@ -821,57 +927,91 @@ extern "C" int wb_get_contours(wb_batch* b, wb_contour_table* o) {
 
 // ------------------------------------------------------------------------------------------------ phase 2
 struct WbEvFillArgs {
-    int nsel, ncut, cap_ev;
+    int cap_ev, cap_ne, cap_seg;
+    long long cap_poly;
+    WbCtl* ctl;
     const int* sel_job; const int* sel_cont; const int* cut_job; const int* cut_cont;
-    const int* ev_n; const int* ev_ind; const int* sbase;   // streamers
-    const int* ot_n; const int* ot_box; const int* ot_orient; const int* obase;   // overturnings
-    const int* c_len; int cap_seg;
-    int* ev;   // [NE][8]
-    int off_s, off_o, off_c;
+    const int* ev_n; const int* ev_ind; int* sbase;   // streamers (ev_n == NULL: not requested)
+    const int* ot_n; const int* ot_box; const int* ot_orient; int* obase;   // overturnings
+    const int* c_len;
+    int* ev;           // [cap_ne][8]
+    int* plen;         // [cap_ne + 1] polygon length of an event -> exclusive scan
+    long long* poff;   // [cap_ne + 1]
 };
+// event offsets: streamers, then overturnings, then cutoffs, each in (selected contour, event) order = frame order
+WB_KERNEL(wb_k_event_offsets, WbEvFillArgs a) {
+    const int nsel = a.ctl->nsel;
+    WB_PFOR(s, nsel)
+        a.sbase[s] = a.ev_n ? a.ev_n[s] : 0;
+        a.obase[s] = a.ot_n ? a.ot_n[s] : 0;
+    WB_END_PFOR
+    const int NS = wb_block_scan_excl(a.sbase, nsel);
+    const int NO = wb_block_scan_excl(a.obase, nsel);
+    WB_SINGLE
+    const long long NE = (long long)NS + NO + a.ctl->ncut;
+    a.ctl->NS = NS;
+    a.ctl->NO = NO;
+    if (NE > a.cap_ne) { a.ctl->overflow |= 1; a.ctl->NE = 0; a.ctl->ne_demand = (int)(NE > 0x7FFFFFFF ? 0x7FFFFFFF : NE); }
+    else a.ctl->NE = (int)NE;
+    WB_END_SINGLE
+}
 WB_KERNEL(wb_k_fill_events, WbEvFillArgs a) {
     const int s = WB_BLOCK_ID;
-    if (s < a.nsel) {
+    const int nsel = a.ctl->nsel;
+    if (a.ctl->NE == 0) return;
+    const int NS = a.ctl->NS, NO = a.ctl->NO;
+    if (s < nsel) {
         if (a.ev_n) {
             WB_PFOR(e, a.ev_n[s])
-                int* d = a.ev + (size_t)(a.off_s + a.sbase[s] + e) * 8;
+                const int row = a.sbase[s] + (int)e;
+                int* d = a.ev + (size_t)row * 8;
                 d[0] = WB_EV_STREAMER; d[1] = a.sel_job[s]; d[2] = a.sel_cont[s];
                 d[3] = a.ev_ind[((size_t)s * a.cap_ev + e) * 2]; d[4] = a.ev_ind[((size_t)s * a.cap_ev + e) * 2 + 1];
                 d[5] = 0; d[6] = 0; d[7] = 0;
+                a.plen[row] = d[4] - d[3] + 1;
             WB_END_PFOR
         }
         if (a.ot_n) {
             WB_PFOR(e, a.ot_n[s])
-                int* d = a.ev + (size_t)(a.off_o + a.obase[s] + e) * 8;
+                const int row = NS + a.obase[s] + (int)e;
+                int* d = a.ev + (size_t)row * 8;
                 const int* bx = a.ot_box + ((size_t)s * WB_OT_CAP + e) * 4;
-                d[0] = WB_EV_OVERTURNING; d[1] = a.sel_job[s]; d[2] = a.sel_cont[s];
+                d[0] = WB_EV_OVERTURNING | (a.ot_orient[(size_t)s * WB_OT_CAP + e] << 8); d[1] = a.sel_job[s]; d[2] = a.sel_cont[s];
                 d[3] = bx[0]; d[4] = bx[1]; d[5] = bx[2]; d[6] = bx[3];
-                d[7] = a.ot_orient[(size_t)s * WB_OT_CAP + e];
+                d[7] = s * WB_OT_CAP + (int)e;                   // slot of the box in ot_sums
+                a.plen[row] = 4;
             WB_END_PFOR
         }
     } else {
-        const int c = s - a.nsel;
-        if (c < a.ncut) {
+        const int c = s - nsel;
+        if (c < a.ctl->ncut) {
             WB_SINGLE
-            int* d = a.ev + (size_t)(a.off_c + c) * 8;
+            const int row = NS + NO + c;
+            int* d = a.ev + (size_t)row * 8;
             d[0] = WB_EV_CUTOFF; d[1] = a.cut_job[c]; d[2] = a.cut_cont[c];
             d[3] = 0; d[4] = a.c_len[(size_t)a.cut_job[c] * a.cap_seg + a.cut_cont[c]] - 1; d[5] = 0; d[6] = 0; d[7] = 0;
+            a.plen[row] = d[4] + 1;
             WB_END_SINGLE
         }
     }
 }
-
-WB_KERNEL(wb_k_sel_lens, int nsel, int cap_seg, const int* sel_job, const int* sel_cont, const int* c_len, int* out) {
-    const int base = WB_BLOCK_ID * 256;
-    WB_PFOR(k, 256)
-        const int s = base + (int)k;
-        if (s < nsel) out[s] = c_len[(size_t)sel_job[s] * cap_seg + sel_cont[s]];
+WB_KERNEL(wb_k_poly_offsets, WbEvFillArgs a) {
+    const int NE = a.ctl->NE;
+    const int total = wb_block_scan_excl(a.plen, NE);
+    WB_PFOR(e, NE + 1)
+        a.poff[e] = e < NE ? (long long)a.plen[e] : (long long)total;
     WB_END_PFOR
+    WB_SINGLE
+    a.ctl->poly_total = total;
+    if ((long long)total > a.cap_poly) a.ctl->overflow |= 2;
+    WB_END_SINGLE
 }
 
-// event polygons: vertices of every event, back to back (x | y<<16)
-WB_KERNEL(wb_k_pack_polys, int nev, int cap_seg, const int* ev, const long long* poff, const int* c_off, const uint32_t* cpts,
+// event polygons: vertices of every event, back to back
+WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const long long* poff, const int* c_off, const uint32_t* cpts,
           int* out_x, int* out_y) {
+    if (ctl->overflow & 2) return;
+    const int nev = ctl->NE;
     for (int e = WB_BLOCK_ID; e < nev; e += WB_GRID_DIM) {
         const int* d = ev + (size_t)e * 8;
         const size_t jb = (size_t)d[1] * cap_seg;
@@ -887,9 +1027,13 @@ WB_KERNEL(wb_k_pack_polys, int nev, int cap_seg, const int* ev, const long long*
     }
 }
 
-static void make_tables(wb_batch* b) {
-    if (b->d_lat) return;
+static wb_ctx::Tables* make_tables(wb_batch* b) {
+    wb_ctx* ctx = b->ctx;
     const wb_params& p = b->p;
+    for (wb_ctx::Tables* t : ctx->tables)
+        if (t->dlon == p.dlon && t->dlat == p.dlat && t->geo_dis == p.geo_dis && t->lat == b->lat && t->lon == b->lon) return t;
+    wb_ctx::Tables* t = new wb_ctx::Tables();
+    t->lat = b->lat; t->lon = b->lon; t->dlon = p.dlon; t->dlat = p.dlat; t->geo_dis = p.geo_dis;
     std::vector<double> latrad(p.nlat), sphi2(p.nlat), cphi2(p.nlat), cphi(p.nlat), wlat(p.nlat);
     std::vector<double> lonrad(p.nlon), slam2(p.nlon), clam2(p.nlon);
     // index_utils.py:58-62
@@ -906,18 +1050,44 @@ static void make_tables(wb_batch* b) {
         slam2[x] = sin(0.5 * lonrad[x]);
         clam2[x] = cos(0.5 * lonrad[x]);
     }
-    // one transfer for all nine tables (every separate small copy costs ~25 us of launch and synchronisation)
     std::vector<double> all;
     all.reserve((size_t)6 * p.nlat + (size_t)3 * p.nlon);
     auto put = [&](const std::vector<double>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); return o; };
-    const size_t o_lat = put(b->lat), o_latrad = put(latrad), o_sphi2 = put(sphi2), o_cphi2 = put(cphi2), o_cphi = put(cphi),
-                 o_wlat = put(wlat), o_lonrad = put(lonrad), o_slam2 = put(slam2), o_clam2 = put(clam2);
-    double* base = upload(b, all);
-    b->d_lat = base + o_lat; b->d_latrad = base + o_latrad; b->d_sphi2 = base + o_sphi2; b->d_cphi2 = base + o_cphi2;
-    b->d_cphi = base + o_cphi; b->d_wlat = base + o_wlat; b->d_lonrad = base + o_lonrad; b->d_slam2 = base + o_slam2;
-    b->d_clam2 = base + o_clam2;
+    t->o_lat = put(b->lat); t->o_latrad = put(latrad); t->o_sphi2 = put(sphi2); t->o_cphi2 = put(cphi2); t->o_cphi = put(cphi);
+    t->o_wlat = put(wlat); t->o_lonrad = put(lonrad); t->o_slam2 = put(slam2); t->o_clam2 = put(clam2);
+    t->base = (double*)dmalloc(ctx, all.size() * sizeof(double));
+    // streamer thresholds
+    { const double sv = sin(p.geo_dis / (2.0 * 6371.0)); t->hthr = sv * sv; }
+    t->dy_max = (int)floor(p.geo_dis / (6371.0 * p.dlat * (M_PI / 180.0))) + 1;
+    // per latitude row: the largest |dx| (index units) at which a partner within dy_max rows can still be closer than
+    // geo_dis -- haversine >= cos(phi_i) cos(phi_j) sin^2(dlambda / 2) -- capped by the reference's 120 (streamer_index.py:157)
+    std::vector<int> dxl(p.nlat, 120);
+    const double dlr = p.dlon * (M_PI / 180.0);
+    if (120.0 * p.dlon <= 180.0) {                               // sin^2 is monotonic over the whole window
+        for (int y = 0; y < p.nlat; ++y) {
+            // the partner row that allows most has the smallest cosine: one of the two ends of the window
+            const int ya = y - t->dy_max < 0 ? 0 : y - t->dy_max, yb = y + t->dy_max > p.nlat - 1 ? p.nlat - 1 : y + t->dy_max;
+            const double cm = cphi[ya] < cphi[yb] ? cphi[ya] : cphi[yb];
+            const double den = cphi[y] * cm;
+            if (!(den > 0.0)) continue;
+            const double ratio = t->hthr * (1.0 + 1e-9) / den;
+            if (ratio >= 1.0) continue;
+            const double lim = floor(2.0 * asin(sqrt(ratio)) / dlr) + 2.0;
+            if (lim < 120.0) dxl[y] = (int)lim;
+        }
+    }
+    t->dxlim = (int*)dmalloc(ctx, p.nlat * sizeof(int));
+    if (!t->base || !t->dxlim) { delete t; return nullptr; }
+    h2d(ctx, t->base, all.data(), all.size() * sizeof(double));
+    h2d(ctx, t->dxlim, dxl.data(), p.nlat * sizeof(int));
+    ctx->tables.push_back(t);
+    return t;
 }
 
+// Phase 2 without the host in the middle: work lists, offsets and counts live on the device (WbCtl), launch sizes and
+// allocations come from the phase-1 bounds, capacities that turn out too small are reported through the control block
+// and the whole phase is repeated with room to spare (rare).  The host waits twice: for the first control-block snapshot
+// (event and vertex counts -> sizes of the result copies) while the property kernel is still running, and for the end.
 extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     if (!b) return 1;
     wb_ctx* ctx = b->ctx;
@@ -926,356 +1096,275 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
 #if !defined(WB_HOSTSIM)
     if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
 #endif
-    make_tables(b);
-    std::vector<void*> tmp;   // device scratch of this call
-    auto talloc = [&](size_t bytes) { void* q = dmalloc(ctx, bytes); if (q) { b->owned.push_back(q); tmp.push_back(q); } return q; };
-
-    // ---- selection
-    WbSelectArgs sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.njobs = J; sa.cap_seg = cap; sa.gmax = gmax; sa.dlon = p.dlon; sa.co_min_exp = p.co_min_exp;
-    sa.ncont = b->ncont; sa.c_nux = b->c_nux; sa.c_closed = b->c_closed;
-    int* d_nsel = (int*)talloc(J * sizeof(int));
-    int* d_ncut = (int*)talloc(J * sizeof(int));
-    int* d_tot = (int*)talloc(2 * sizeof(int));
-    if (!d_tot) return 1;
-    sa.nsel = d_nsel; sa.ncut = d_ncut;
-    b->timer.begin(ctx, "select");
-    WB_LAUNCH(wb_k_select_count, J, 64, sa);
-    WB_LAUNCH(wb_k_scan_jobs, 1, 256, J, d_nsel, d_ncut, d_tot);
-    int tot[2] = {0, 0};
-    d2h(ctx, tot, d_tot, sizeof(tot));
-    b->nsel = tot[0];
-    b->ncut = (which & 4) ? tot[1] : 0;
-    const int nsel = b->nsel, ncut = b->ncut;
-    b->sel_job = (int*)talloc((nsel + 1) * sizeof(int)); b->sel_cont = (int*)talloc((nsel + 1) * sizeof(int));
-    b->cut_job = (int*)talloc((tot[1] + 1) * sizeof(int)); b->cut_cont = (int*)talloc((tot[1] + 1) * sizeof(int));
-    if (!b->cut_cont) return 1;
-    sa.selbase = d_nsel; sa.cutbase = d_ncut;
-    sa.sel_job = b->sel_job; sa.sel_cont = b->sel_cont; sa.cut_job = b->cut_job; sa.cut_cont = b->cut_cont;
-    WB_LAUNCH(wb_k_select_fill, J, 64, sa);
-    b->timer.end(ctx);
-
-    // ---- overturnings
-    int *ot_n = nullptr, *ot_box = nullptr, *ot_orient = nullptr;
-    if ((which & 2) && nsel > 0) {
-        ot_n = (int*)talloc(nsel * sizeof(int));
-        ot_box = (int*)talloc((size_t)nsel * WB_OT_CAP * 4 * sizeof(int));
-        ot_orient = (int*)talloc((size_t)nsel * WB_OT_CAP * sizeof(int));
-        if (!ot_orient) return 1;
-        WbOverturnArgs oa;
-        memset(&oa, 0, sizeof(oa));
-        oa.nsel = nsel; oa.cap_seg = cap; oa.nlon = p.nlon; oa.W = b->W;
-        oa.rg_over_dlon = p.range_group / p.dlon; oa.minexp_over_dlon = p.ot_min_exp / p.dlon;
-        oa.sel_job = b->sel_job; oa.sel_cont = b->sel_cont; oa.c_off = b->c_off; oa.c_len = b->c_len; oa.cpts = b->cpts;
-        oa.lat = b->d_lat; oa.ot_n = ot_n; oa.ot_box = ot_box; oa.ot_orient = ot_orient; oa.status = b->status;
-        // independent of the streamer chain: runs on the side stream, under the chain's kernels and the host's
-        // work-list building between them; joined before its counts are read
-#if !defined(WB_HOSTSIM)
-        (void)hipEventRecord(ctx->fork, ctx->stream);
-        (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
-        std::swap(ctx->stream, ctx->stream2);
-#endif
-        b->timer.begin(ctx, "overturn");
-        WB_LAUNCH(wb_k_overturn, nsel, 256, oa);
-        b->timer.end(ctx);
-#if !defined(WB_HOSTSIM)
-        (void)hipEventRecord(ctx->join, ctx->stream);
-        std::swap(ctx->stream, ctx->stream2);
-#endif
-    }
-
-    // ---- streamers
-    int *ev_n = nullptr, *ev_ind = nullptr;
+    wb_ctx::Tables* T = make_tables(b);
+    WbCtl* hc = host_ctl(ctx);
+    if (!T || !hc) return wb_fail(ctx, "out of memory (tables)");
+    const WbCtl& h1 = b->h_ctl;                 // phase-1 summary
+    // bounds: the selected contours are those with nux == gmax; with gmax equal to this batch's maximum they are counted
+    // exactly by the phase-1 summary, with a larger one (another rank holds the full-span contour) there are none
+    const bool at_max = gmax == h1.max_nux, above = gmax > h1.max_nux;
+    const int nsel_b = at_max ? h1.nsel_max : (above ? 0 : h1.ncont_total);
+    const long long npt_b = at_max ? h1.npt_sel_max : (above ? 0 : h1.npts_total);
+    const int items_b = at_max ? h1.pair_items_max : (above ? 0 : (int)(h1.npts_total / (WB_PAIR_ROWS * WB_PAIR_TPB)) + h1.ncont_total);
+    const int ncut_b = (which & 4) ? h1.nclosed : 0;
+    const long long npt_cut_b = (which & 4) ? h1.npt_closed : 0;
+    const bool do_st = (which & 1) && nsel_b > 0, do_ot = (which & 2) && nsel_b > 0;
     const int cap_ev = 256;
-    if ((which & 1) && nsel > 0) {
-        int cap_pairs = p.cap_pairs > 0 ? p.cap_pairs : 65536;
-        int* d_band = (int*)talloc(2 * sizeof(int));
-        ev_n = (int*)talloc(nsel * sizeof(int));
-        ev_ind = (int*)talloc((size_t)nsel * cap_ev * 2 * sizeof(int));
-        WbStreamerArgs st;
-        memset(&st, 0, sizeof(st));
-        st.nsel = nsel; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.W = b->W; st.cap_ev = cap_ev;
-        st.geo_dis = p.geo_dis; st.cont_dis = p.cont_dis;
-        { const double sv = sin(p.geo_dis / (2.0 * 6371.0)); st.hthr = sv * sv; }
-        st.sel_job = b->sel_job; st.sel_cont = b->sel_cont; st.c_off = b->c_off; st.c_len = b->c_len; st.cpts = b->cpts;
-        st.lat_rad = b->d_latrad; st.lon_rad = b->d_lonrad; st.sphi2 = b->d_sphi2; st.cphi2 = b->d_cphi2; st.cphi = b->d_cphi;
-        st.slam2 = b->d_slam2; st.clam2 = b->d_clam2;
-        // exact, packed per-point storage: lengths of the selected contours -> offsets
-        int maxN = 0;
-        std::vector<long long> h_poff(nsel + 1, 0);
-        {
-            int* d_lens = (int*)talloc(nsel * sizeof(int));
-            if (!d_lens) return 1;
-            WB_LAUNCH(wb_k_sel_lens, (nsel + 255) / 256, 256, nsel, cap, b->sel_job, b->sel_cont, b->c_len, d_lens);
-            std::vector<int> lens(nsel);
-            d2h(ctx, lens.data(), d_lens, nsel * sizeof(int));
-            b->pair_stats[0] = 0;
-            for (int q = 0; q < nsel; ++q) {
-                h_poff[q + 1] = h_poff[q] + lens[q];
-                maxN = lens[q] > maxN ? lens[q] : maxN;
-                b->pair_stats[0] += (long long)lens[q] * (lens[q] - 1) / 2;      // base-point pairs the all-pairs test covers
-            }
-        }
-        const long long NPT = h_poff[nsel];
-        long long* d_poff = (long long*)talloc((nsel + 1) * sizeof(long long));
-        if (!d_poff) return 1;
-        h2d(ctx, d_poff, h_poff.data(), (nsel + 1) * sizeof(long long));
-        st.poff = d_poff;
-        st.npts_total = NPT;
-        st.on = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
-        st.pre = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
-        st.ptab = (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double));
-        st.bbx = (int*)talloc((size_t)((NPT >> 5) + nsel + 1) * 4 * sizeof(int));
-        st.tbx = (int*)talloc((size_t)((NPT >> 4) + nsel + 1) * 4 * sizeof(int));
-        st.dy_max = (int)floor(p.geo_dis / (6371.0 * p.dlat * (M_PI / 180.0))) + 1;
-        {   // per latitude row: the largest |dx| (index units) at which a partner within dy_max rows can still be closer
-            // than geo_dis -- haversine >= cos(phi_i) cos(phi_j) sin^2(dlambda / 2) -- capped by the reference's 120
-            std::vector<int> dxl(p.nlat, 120);
-            const double dlr = p.dlon * (M_PI / 180.0);
-            if (120.0 * p.dlon <= 180.0) {                               // sin^2 is monotonic over the whole window
-                std::vector<double> cl(p.nlat);
-                for (int y = 0; y < p.nlat; ++y) cl[y] = cos(b->lat[y] * (M_PI / 180.0));
-                for (int y = 0; y < p.nlat; ++y) {
-                    // the partner row that allows most has the smallest cosine: one of the two ends of the window
-                    const int ya = y - st.dy_max < 0 ? 0 : y - st.dy_max, yb = y + st.dy_max > p.nlat - 1 ? p.nlat - 1 : y + st.dy_max;
-                    const double cm = cl[ya] < cl[yb] ? cl[ya] : cl[yb];
-                    const double den = cl[y] * cm;
-                    if (!(den > 0.0)) continue;
-                    const double ratio = st.hthr * (1.0 + 1e-9) / den;
-                    if (ratio >= 1.0) continue;
-                    const double lim = floor(2.0 * asin(sqrt(ratio)) / dlr) + 2.0;
-                    if (lim < 120.0) dxl[y] = (int)lim;
-                }
-            }
-            int* d_dxl = (int*)talloc(p.nlat * sizeof(int));
-            if (!d_dxl) return 1;
-            h2d(ctx, d_dxl, dxl.data(), p.nlat * sizeof(int));
-            st.dxlim = d_dxl;
-        }
-        st.npairs = (int*)talloc(nsel * sizeof(int));
-        st.stage = (int*)talloc(nsel * sizeof(int));
-        st.nalive = (int*)talloc(nsel * sizeof(int));
-        st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
-        st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
-        st.ev_ind = ev_ind; st.ev_n = ev_n; st.band_hits = d_band; st.status = b->status;
-        if (!st.rowaux || !ev_ind || !st.bbx || !st.tbx) return 1;
-        for (int attempt = 0; attempt < 4; ++attempt) {
-            st.cap_pairs = cap_pairs;
-            st.hash_size = next_pow2(2LL * cap_pairs);
-            if (st.hash_size < next_pow2(4LL * cap)) st.hash_size = next_pow2(4LL * cap);
-            st.pairs = (unsigned long long*)talloc((size_t)nsel * cap_pairs * 8);
-            st.alive = (int*)talloc((size_t)nsel * cap_pairs * sizeof(int));
-            st.hkey = (unsigned long long*)talloc((size_t)nsel * st.hash_size * 8);
-            st.hval = (unsigned long long*)talloc((size_t)nsel * st.hash_size * 8);
-            if (!st.hval) return 1;
-            dmemset(ctx, d_band, 0, 2 * sizeof(int));
-            b->timer.begin(ctx, "streamer_prep");
-            WB_LAUNCH(wb_k_streamer_prep, nsel, 256, st);
-            b->timer.end(ctx);
-            // work list of the all-pairs kernel: one single-wave workgroup per 8 consecutive 16-row tiles of a contour
-            const int TPB = 8;
-            std::vector<int> pb_sel, pb_tile;
-            for (int q = 0; q < nsel; ++q) {
-                const int rows = (int)(h_poff[q + 1] - h_poff[q]) - 1;
-                const int tiles_q = (rows + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
-                for (int t0 = 0; t0 < tiles_q; t0 += TPB) { pb_sel.push_back(q); pb_tile.push_back(t0); }
-            }
-            b->timer.begin(ctx, "streamer_pairs");
-            if (!pb_sel.empty()) {
-                int* d_ps = (int*)talloc(pb_sel.size() * sizeof(int));
-                int* d_pt = (int*)talloc(pb_tile.size() * sizeof(int));
-                if (!d_pt) return 1;
-                h2d(ctx, d_ps, pb_sel.data(), pb_sel.size() * sizeof(int));
-                h2d(ctx, d_pt, pb_tile.data(), pb_tile.size() * sizeof(int));
-                WB_LAUNCH(wb_k_streamer_pairs, (long long)pb_sel.size(), 64, st, d_ps, d_pt, TPB);
-            }
-            b->timer.end(ctx);
-            std::vector<int> np(nsel);
-            d2h(ctx, np.data(), st.npairs, nsel * sizeof(int));
-            int mx = 0;
-            b->pair_stats[1] = 0;
-            for (int v : np) { mx = v > mx ? v : mx; b->pair_stats[1] += v; }    // candidate pairs that pass both distance tests
-            if (mx > cap_pairs && attempt < 3) {
-                bfree_one(b, st.pairs); bfree_one(b, st.alive); bfree_one(b, st.hkey); bfree_one(b, st.hval);
-                for (void* q : {(void*)st.pairs, (void*)st.alive, (void*)st.hkey, (void*)st.hval})
-                    for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == q) { tmp.erase(tmp.begin() + i); break; }
-                cap_pairs = next_pow2((long long)mx + mx / 8);
-                b->timer.drop_last();
-                b->timer.drop_last();
-                continue;
-            }
-            b->timer.begin(ctx, "streamer_f1");
-            WB_LAUNCH(wb_k_streamer_f1, nsel, 256, st);
-            b->timer.end(ctx);
-            // work list for the chord-contour test: one workgroup per 256 candidate pairs of a contour that can
-            // still reach routine 2 (more than one candidate, streamer_index.py:261-264)
-            std::vector<int> blk_sel, blk_first;
-            for (int q = 0; q < nsel; ++q) {
-                const int P = np[q] < cap_pairs ? np[q] : cap_pairs;
-                if (P <= 1) continue;
-                for (int f0 = 0; f0 < P; f0 += WB_F2_THREADS) { blk_sel.push_back(q); blk_first.push_back(f0); }
-            }
-            b->timer.begin(ctx, "streamer_f2");
-            if (!blk_sel.empty()) {
-                int* d_bs = (int*)talloc(blk_sel.size() * sizeof(int));
-                int* d_bf = (int*)talloc(blk_first.size() * sizeof(int));
-                if (!d_bf) return 1;
-                h2d(ctx, d_bs, blk_sel.data(), blk_sel.size() * sizeof(int));
-                h2d(ctx, d_bf, blk_first.data(), blk_first.size() * sizeof(int));
-                WB_LAUNCH(wb_k_streamer_f2, (long long)blk_sel.size(), 256, st, d_bs, d_bf);
-            }
-            b->timer.end(ctx);
-            b->timer.begin(ctx, "streamer_f34");
-            WB_LAUNCH(wb_k_streamer_f34, nsel, 256, st);
-            b->timer.end(ctx);
-            int band[2];
-            d2h(ctx, band, d_band, sizeof(band));
-            b->band[0] = band[0];
-            b->band[1] = band[1];
-            break;
-        }
-    }
+    int cap_pairs = p.cap_pairs > 0 ? p.cap_pairs : 65536;
+    int cap_ne = 16 * (b->job_step.empty() ? J : 64) + 4096 + ncut_b;
+    long long cap_poly = 2 * npt_b + npt_cut_b + 4LL * cap_ne + 1024;
+    unsigned long long cell_cap = p.want_cells ? (unsigned long long)cap_ne * 1024ull : 0ull;
+    const double r = ((p.dlon + p.dlat) / 2.0) / 2.0;     // index_utils.py:48-50
 
-    // ---- event list (streamers, overturnings, cutoffs), then cells + sums
-    std::vector<int> h_evn(nsel, 0), h_otn(nsel, 0), sbase(nsel + 1, 0), obase(nsel + 1, 0);
-    if (ev_n) d2h(ctx, h_evn.data(), ev_n, nsel * sizeof(int));
-#if !defined(WB_HOSTSIM)
-    if (ot_n) (void)hipStreamWaitEvent(ctx->stream, ctx->join, 0);
-#endif
-    if (ot_n) d2h(ctx, h_otn.data(), ot_n, nsel * sizeof(int));
-    for (int s = 0; s < nsel; ++s) { sbase[s + 1] = sbase[s] + h_evn[s]; obase[s + 1] = obase[s] + h_otn[s]; }
-    const int NS = sbase[nsel], NO = obase[nsel], NCU = ncut, NE = NS + NO + NCU;
-    std::vector<int> h_ev((size_t)NE * 8 + 8, 0);
-    std::vector<double> h_sums((size_t)NE * 5 + 5, 0.0);
-    std::vector<int> h_nc(NE + 1, 0);
-    std::vector<long long> h_coff(NE + 1, 0);
-    std::vector<uint32_t> h_cells;
+    // result buffers of the previous call
     hfree(ctx, b->poly_x, b->poly_bytes);
     hfree(ctx, b->poly_y, b->poly_bytes);
     b->poly_x = b->poly_y = nullptr;
     b->poly_n = b->poly_bytes = 0;
-    std::vector<long long> h_poff(NE + 1, 0);
-    if (NE > 0) {
-        int* d_sbase = (int*)talloc((nsel + 1) * sizeof(int));
-        int* d_obase = (int*)talloc((nsel + 1) * sizeof(int));
-        int* d_ev = (int*)talloc((size_t)NE * 8 * sizeof(int));
-        if (!d_ev) return 1;
-        h2d(ctx, d_sbase, sbase.data(), (nsel + 1) * sizeof(int));
-        h2d(ctx, d_obase, obase.data(), (nsel + 1) * sizeof(int));
-        WbEvFillArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.nsel = nsel; fa.ncut = NCU; fa.cap_ev = cap_ev;
-        fa.sel_job = b->sel_job; fa.sel_cont = b->sel_cont; fa.cut_job = b->cut_job; fa.cut_cont = b->cut_cont;
-        fa.ev_n = ev_n; fa.ev_ind = ev_ind; fa.sbase = d_sbase; fa.ot_n = ot_n; fa.ot_box = ot_box; fa.ot_orient = ot_orient;
-        fa.obase = d_obase; fa.c_len = b->c_len; fa.cap_seg = cap; fa.ev = d_ev; fa.off_s = 0; fa.off_o = NS; fa.off_c = NS + NO;
-        b->timer.begin(ctx, "fill_events");
-        WB_LAUNCH(wb_k_fill_events, nsel + NCU, 64, fa);
+    for (auto& hb : b->hres) hfree(ctx, hb.first, hb.second);
+    b->hres.clear();
+
+    WbCtl fin;
+    memset(&fin, 0, sizeof(fin));
+    int* h_ev = nullptr; double* h_sums = nullptr; int* h_nc = nullptr; long long* h_poff = nullptr; long long* h_coff = nullptr;
+    uint32_t* h_cells = nullptr;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        std::vector<void*> tmp;   // device scratch of this attempt
+        auto talloc = [&](size_t bytes) { void* q = dmalloc(ctx, bytes); if (q) { b->owned.push_back(q); tmp.push_back(q); } return q; };
+        auto release = [&]() { for (void* q : tmp) bfree_one(b, q); tmp.clear(); };
+        b->timer.truncate(b->timer_phase1);
+        WbCtl* ctl = b->d_ctl;
+        // the phase-2 part of the control block starts from zero (phase-1 values stay)
+        dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, sizeof(WbCtl) - offsetof(WbCtl, nsel));
+
+        // ---- selection
+        WbSelectArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.njobs = J; sa.cap_seg = cap; sa.gmax = gmax; sa.want_cut = (which & 4) ? 1 : 0; sa.dlon = p.dlon; sa.co_min_exp = p.co_min_exp;
+        sa.ncont = b->ncont; sa.c_nux = b->c_nux; sa.c_closed = b->c_closed;
+        int* d_nsel = (int*)talloc(J * sizeof(int));
+        int* d_ncut = (int*)talloc(J * sizeof(int));
+        b->sel_job = (int*)talloc((nsel_b + 1) * sizeof(int)); b->sel_cont = (int*)talloc((nsel_b + 1) * sizeof(int));
+        b->cut_job = (int*)talloc((ncut_b + 1) * sizeof(int)); b->cut_cont = (int*)talloc((ncut_b + 1) * sizeof(int));
+        if (!b->cut_cont || !d_ncut) { release(); return 1; }
+        sa.nsel = d_nsel; sa.ncut = d_ncut;
+        b->timer.begin(ctx, "select");
+        WB_LAUNCH(wb_k_select_count, J, 64, sa);
+        WB_LAUNCH(wb_k_scan_jobs, 1, 256, J, d_nsel, d_ncut, &ctl->nsel);      // totals -> ctl->nsel, ctl->ncut
+        sa.selbase = d_nsel; sa.cutbase = d_ncut;
+        sa.sel_job = b->sel_job; sa.sel_cont = b->sel_cont; sa.cut_job = b->cut_job; sa.cut_cont = b->cut_cont;
+        WB_LAUNCH(wb_k_select_fill, J, 64, sa);
         b->timer.end(ctx);
 
+        // ---- overturnings + the centre-of-mass sums of their boxes: side stream, next to the streamer chain
+        int *ot_n = nullptr, *ot_box = nullptr, *ot_orient = nullptr;
+        double* ot_sums = nullptr;
+        if (do_ot) {
+            ot_n = (int*)talloc(nsel_b * sizeof(int));
+            ot_box = (int*)talloc((size_t)nsel_b * WB_OT_CAP * 4 * sizeof(int));
+            ot_orient = (int*)talloc((size_t)nsel_b * WB_OT_CAP * sizeof(int));
+            ot_sums = (double*)talloc((size_t)nsel_b * WB_OT_CAP * 3 * sizeof(double));
+            if (!ot_sums) { release(); return 1; }
+            WbOverturnArgs oa;
+            memset(&oa, 0, sizeof(oa));
+            oa.ctl = ctl; oa.cap_seg = cap; oa.nlon = p.nlon; oa.W = b->W;
+            oa.rg_over_dlon = p.range_group / p.dlon; oa.minexp_over_dlon = p.ot_min_exp / p.dlon;
+            oa.sel_job = b->sel_job; oa.sel_cont = b->sel_cont; oa.c_off = b->c_off; oa.c_len = b->c_len; oa.cpts = b->cpts;
+            oa.lat = T->base + T->o_lat; oa.ot_n = ot_n; oa.ot_box = ot_box; oa.ot_orient = ot_orient; oa.status = b->status;
+            side_begin(ctx);
+            b->timer.begin(ctx, "overturn");
+            WB_LAUNCH(wb_k_overturn, nsel_b, 256, oa);
+            b->timer.end(ctx);
+            if (r * r <= 1.0) {
+                WbBoxComArgs ba;
+                memset(&ba, 0, sizeof(ba));
+                ba.nlat = p.nlat; ba.W = b->W; ba.ctl = ctl; ba.ot_n = ot_n; ba.ot_box = ot_box; ba.wlat = T->base + T->o_wlat;
+                ba.ot_sums = ot_sums;
+                b->timer.begin(ctx, "box_com");
+                WB_LAUNCH(wb_k_box_com, (long long)nsel_b * WB_BOXCOM_SPLIT, 64, ba);
+                b->timer.end(ctx);
+            }
+            side_end(ctx);
+        }
+
+        // ---- streamers
+        int *ev_n = nullptr, *ev_ind = nullptr;
+        if (do_st) {
+            WbStreamerArgs st;
+            memset(&st, 0, sizeof(st));
+            ev_n = (int*)talloc(nsel_b * sizeof(int));
+            ev_ind = (int*)talloc((size_t)nsel_b * cap_ev * 2 * sizeof(int));
+            st.ctl = ctl; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.W = b->W; st.cap_ev = cap_ev;
+            st.geo_dis = p.geo_dis; st.cont_dis = p.cont_dis; st.hthr = T->hthr; st.dy_max = T->dy_max; st.dxlim = T->dxlim;
+            st.sel_job = b->sel_job; st.sel_cont = b->sel_cont; st.c_off = b->c_off; st.c_len = b->c_len; st.cpts = b->cpts;
+            st.lat_rad = T->base + T->o_latrad; st.lon_rad = T->base + T->o_lonrad; st.sphi2 = T->base + T->o_sphi2;
+            st.cphi2 = T->base + T->o_cphi2; st.cphi = T->base + T->o_cphi; st.slam2 = T->base + T->o_slam2; st.clam2 = T->base + T->o_clam2;
+            const long long NPT = npt_b;
+            st.npts_total = NPT + 1;
+            st.poff = (long long*)talloc((nsel_b + 1) * sizeof(long long));
+            st.item_off = (int*)talloc((nsel_b + 1) * sizeof(int));
+            st.item_sel = (int*)talloc((size_t)(items_b + 1) * sizeof(int));
+            st.item_tile = (int*)talloc((size_t)(items_b + 1) * sizeof(int));
+            st.f2_off = (int*)talloc((nsel_b + 1) * sizeof(int));
+            int* d_lens = (int*)talloc((nsel_b + 1) * sizeof(int));
+            st.on = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
+            st.pre = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
+            st.ptab = (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double));
+            st.bbx = (int*)talloc((size_t)((NPT >> 5) + nsel_b + 1) * 4 * sizeof(int));
+            st.tbx = (int*)talloc((size_t)((NPT >> 4) + nsel_b + 1) * 4 * sizeof(int));
+            st.npairs = (int*)talloc(nsel_b * sizeof(int));
+            st.stage = (int*)talloc(nsel_b * sizeof(int));
+            st.nalive = (int*)talloc(nsel_b * sizeof(int));
+            st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
+            st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
+            st.ev_ind = ev_ind; st.ev_n = ev_n; st.status = b->status;
+            st.cap_pairs = cap_pairs;
+            st.hash_size = next_pow2(2LL * cap_pairs);
+            if (st.hash_size < next_pow2(4LL * cap)) st.hash_size = next_pow2(4LL * cap);
+            st.pairs = (unsigned long long*)talloc((size_t)nsel_b * cap_pairs * 8);
+            st.alive = (int*)talloc((size_t)nsel_b * cap_pairs * sizeof(int));
+            st.hkey = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
+            st.hval = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
+            if (!st.hval || !st.rowaux || !ev_ind || !st.bbx || !st.tbx || !d_lens || !st.item_tile) { release(); return 1; }
+            b->timer.begin(ctx, "streamer_lists");
+            WB_LAUNCH(wb_k_sel_scan, 1, 1024, st, d_lens);
+            WB_LAUNCH(wb_k_pair_items, nsel_b, 64, st);
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "streamer_prep");
+            WB_LAUNCH(wb_k_streamer_prep, nsel_b, 256, st);
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "streamer_pairs");
+            if (items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "streamer_f1");
+            WB_LAUNCH(wb_k_streamer_f1, nsel_b, 256, st);
+            WB_LAUNCH(wb_k_f2_items, 1, 1024, st);
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "streamer_f2");
+            {
+                long long g2 = (long long)nsel_b * ((cap_pairs + WB_F2_THREADS - 1) / WB_F2_THREADS);
+                if (g2 > 16384) g2 = 16384;                         // persistent: the workgroups stride over the device-built list
+                WB_LAUNCH(wb_k_streamer_f2, g2, 256, st);
+            }
+            b->timer.end(ctx);
+            b->timer.begin(ctx, "streamer_f34");
+            WB_LAUNCH(wb_k_streamer_f34, nsel_b, 256, st);
+            b->timer.end(ctx);
+        }
+        if (do_ot) side_join(ctx);
+
+        // ---- event list (streamers, overturnings, cutoffs): offsets, descriptors, polygon offsets
+        WbEvFillArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.cap_ev = cap_ev; fa.cap_ne = cap_ne; fa.cap_seg = cap; fa.cap_poly = cap_poly; fa.ctl = ctl;
+        fa.sel_job = b->sel_job; fa.sel_cont = b->sel_cont; fa.cut_job = b->cut_job; fa.cut_cont = b->cut_cont;
+        fa.ev_n = ev_n; fa.ev_ind = ev_ind; fa.ot_n = ot_n; fa.ot_box = ot_box; fa.ot_orient = ot_orient; fa.c_len = b->c_len;
+        fa.sbase = (int*)talloc((nsel_b + 1) * sizeof(int));
+        fa.obase = (int*)talloc((nsel_b + 1) * sizeof(int));
+        fa.ev = (int*)talloc((size_t)(cap_ne + 1) * 8 * sizeof(int));
+        fa.plen = (int*)talloc((size_t)(cap_ne + 1) * sizeof(int));
+        fa.poff = (long long*)talloc((size_t)(cap_ne + 1) * sizeof(long long));
+        int* d_px = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
+        int* d_py = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
         WbPropsArgs pa;
         memset(&pa, 0, sizeof(pa));
-        const double r = ((p.dlon + p.dlat) / 2.0) / 2.0;     // index_utils.py:48-50
-        pa.nev = NE; pa.nslots = NE < 4096 ? NE : 4096; /* one wave per event slot; 4 waves per SIMD in flight */ pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
+        pa.ctl = ctl; pa.nslots = 4096; /* one wave per event slot; 4 waves per SIMD in flight */
+        pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
         pa.nlev = p.nlevels; pa.dtype = p.dtype; pa.want_cells = p.want_cells; pa.pad = (int)ceil(r); pa.r2 = r * r;
-        pa.ev = d_ev; pa.c_off = b->c_off; pa.c_len = b->c_len; pa.cpts = b->cpts; pa.data = b->d_field;
-        pa.intensity = b->d_intensity; pa.wlat = b->d_wlat; pa.job_step = b->d_job_step;
+        pa.ev = fa.ev; pa.ot_sums = ot_sums; pa.c_off = b->c_off; pa.c_len = b->c_len; pa.cpts = b->cpts; pa.data = b->d_field;
+        pa.intensity = b->d_intensity; pa.wlat = T->base + T->o_wlat; pa.job_step = b->d_job_step;
+        if (cap_ne < pa.nslots) pa.nslots = cap_ne > 0 ? cap_ne : 1;
         pa.cells = (int*)talloc((size_t)pa.nslots * b->W * p.nlat * sizeof(int));
         pa.rowacc = (double*)talloc((size_t)pa.nslots * 4 * p.nlat * sizeof(double));
-        pa.ev_sums = (double*)talloc((size_t)NE * 5 * sizeof(double));
-        pa.ev_ncells = (int*)talloc((size_t)NE * sizeof(int));
-        pa.cell_count = (unsigned long long*)talloc(sizeof(unsigned long long));
-        pa.com_rechecks = (int*)talloc(3 * sizeof(int));
-        pa.ev_cell_off = (long long*)talloc((size_t)NE * sizeof(long long));
-        if (!pa.ev_cell_off) return 1;
-        dmemset(ctx, pa.cell_count, 0, sizeof(unsigned long long));
-        dmemset(ctx, pa.com_rechecks, 0, 3 * sizeof(int));
-        if (NO > 0 && pa.r2 <= 1.0) {
-            // areas / x_com / y_com of the boxes (wb_k_props leaves those three slots of a box to this kernel)
-            WbBoxComArgs ba;
-            memset(&ba, 0, sizeof(ba));
-            ba.nev = NO; ba.first = NS; ba.nlat = p.nlat; ba.W = b->W; ba.ev = d_ev; ba.wlat = b->d_wlat;
-            ba.ev_sums = pa.ev_sums; ba.com_rechecks = pa.com_rechecks;
-            b->timer.begin(ctx, "box_com");
-            WB_LAUNCH(wb_k_box_com, NO, 64, ba);
-            b->timer.end(ctx);
-        }
-        unsigned long long cell_cap = p.want_cells ? (unsigned long long)NE * 4096ull : 0ull;
-        // descriptors + polygon vertices go back on the side stream while the property kernel runs on the main one
-        bool polys_done = false;
-        auto fetch_polys = [&]() -> int {
-            if (polys_done) return 0;
-            polys_done = true;
-#if !defined(WB_HOSTSIM)
-            (void)hipEventRecord(ctx->fork, ctx->stream);            // descriptors are complete here
-            (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
-            std::swap(ctx->stream, ctx->stream2);
-#endif
-            b->timer.begin(ctx, "polygons_d2h");
-            int rc = [&]() -> int {
-        d2h(ctx, h_ev.data(), d_ev, (size_t)NE * 8 * sizeof(int));
-                // polygon vertices of all events in one packed transfer
-                for (int e = 0; e < NE; ++e) {
-                    const int* d = &h_ev[(size_t)e * 8];
-                    h_poff[e + 1] = h_poff[e] + (d[0] == WB_EV_OVERTURNING ? 4 : d[4] - d[3] + 1);
-                }
-                {
-                    long long* d_poff = (long long*)talloc((NE + 1) * sizeof(long long));
-                    int* d_px = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
-                    int* d_py = (int*)talloc((size_t)(h_poff[NE] + 1) * sizeof(int));
-                    if (!d_py) return 1;
-                    h2d(ctx, d_poff, h_poff.data(), (NE + 1) * sizeof(long long));
-                    WB_LAUNCH(wb_k_pack_polys, NE < 2048 ? NE : 2048, 256, NE, cap, d_ev, d_poff, b->c_off, b->cpts, d_px, d_py);
-                    b->poly_n = (size_t)h_poff[NE];
-                    size_t want = (b->poly_n + 1) * sizeof(int32_t);
-                    b->poly_x = (int32_t*)hmalloc(ctx, want, &b->poly_bytes);
-                    b->poly_y = (int32_t*)hmalloc(ctx, want, &b->poly_bytes);
-                    if (!b->poly_x || !b->poly_y) return wb_fail(ctx, "out of host memory");
-                    if (b->poly_n) {
-                        if (d2h_pinned(ctx, b->poly_x, d_px, b->poly_n * sizeof(int)) ||
-                            d2h_pinned(ctx, b->poly_y, d_py, b->poly_n * sizeof(int))) return 1;
-                    }
-                }
-                return 0;
-            }();
-            b->timer.end(ctx);
-#if !defined(WB_HOSTSIM)
-            std::swap(ctx->stream, ctx->stream2);
-#endif
-            return rc;
-        };
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            pa.cell_cap = cell_cap;
-            pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
-            if (cell_cap && !pa.cell_pool) return 1;
-            dmemset(ctx, pa.cell_count, 0, sizeof(unsigned long long));
-            b->timer.begin(ctx, "props");
-            WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
-            b->timer.end(ctx);
-            if (fetch_polys()) return 1;
-            unsigned long long used = 0;
-            d2h(ctx, &used, pa.cell_count, sizeof(used));
-            if (!p.want_cells || used <= cell_cap) { h_cells.resize((size_t)used); break; }
-            cell_cap = used;   // second pass with the exact size
-            b->timer.drop_last();
-        }
-        b->timer.begin(ctx, "events_d2h");
-        d2h(ctx, h_sums.data(), pa.ev_sums, (size_t)NE * 5 * sizeof(double));
-        d2h(ctx, h_nc.data(), pa.ev_ncells, (size_t)NE * sizeof(int));
-        {
-            int rc2[3] = {0, 0, 0};
-            d2h(ctx, rc2, pa.com_rechecks, sizeof(rc2));
-            b->com_rechecks[0] = rc2[0];
-            b->com_rechecks[1] = rc2[1];
-            b->com_rechecks[2] = rc2[2];
-        }
-        if (p.want_cells) {
-            d2h(ctx, h_coff.data(), pa.ev_cell_off, (size_t)NE * sizeof(long long));
-            if (!h_cells.empty()) d2h(ctx, h_cells.data(), pa.cell_pool, h_cells.size() * sizeof(uint32_t));
-        }
+        pa.ev_sums = (double*)talloc((size_t)(cap_ne + 1) * 5 * sizeof(double));
+        pa.ev_ncells = (int*)talloc((size_t)(cap_ne + 1) * sizeof(int));
+        pa.ev_cell_off = (long long*)talloc((size_t)(cap_ne + 1) * sizeof(long long));
+        pa.cell_cap = cell_cap;
+        pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
+        if (!d_py || !fa.poff || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
+        b->timer.begin(ctx, "fill_events");
+        WB_LAUNCH(wb_k_event_offsets, 1, 1024, fa);
+        if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa);
+        WB_LAUNCH(wb_k_poly_offsets, 1, 1024, fa);
         b->timer.end(ctx);
+        // descriptors are complete: vertices + the first control-block snapshot on the side stream, properties on the main one
+        side_begin(ctx);
+        b->timer.begin(ctx, "polygons");
+        WB_LAUNCH(wb_k_pack_polys, 2048, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, d_px, d_py);
+        b->timer.end(ctx);
+        d2h_async(ctx, &hc[0], ctl, sizeof(WbCtl));
+        side_end(ctx);
+        b->timer.begin(ctx, "props");
+        WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
+        b->timer.end(ctx);
+        d2h_async(ctx, &hc[1], ctl, sizeof(WbCtl));              // second snapshot: property kernel's counters
+        if (side_sync(ctx)) { release(); return wb_fail(ctx, "HIP error on the side stream"); }
+        const WbCtl s1 = hc[0];
+        bool again = false;
+        if (do_st && s1.max_pairs > cap_pairs) { cap_pairs = next_pow2((long long)s1.max_pairs + s1.max_pairs / 8); again = true; }
+        if (s1.overflow & 1) { cap_ne = next_pow2((long long)s1.ne_demand + s1.ne_demand / 4); again = true; }
+        if (s1.overflow & 2) { cap_poly = s1.poly_total + s1.poly_total / 8 + 1024; again = true; }
+        if (again) {
+            if (dsync(ctx)) { release(); return 1; }
+            release();
+            if (attempt == 5) return wb_fail(ctx, "capacity overflow in the index phase");
+            if (p.want_cells) cell_cap = (unsigned long long)cap_ne * 1024ull;
+            continue;
+        }
+        const int NE = s1.NE;
+        const long long NV = s1.poly_total;
+        // result copies: vertices and descriptors on the side stream (the property kernel is still running), sums after it
+        size_t got = 0;
+        auto hbuf = [&](size_t bytes) -> void* { void* q = hmalloc(ctx, bytes ? bytes : 8, &got); if (q) b->hres.push_back({q, got}); return q; };
+        h_ev = (int*)hbuf((size_t)(NE + 1) * 8 * sizeof(int));
+        h_poff = (long long*)hbuf((size_t)(NE + 1) * sizeof(long long));
+        h_sums = (double*)hbuf((size_t)(NE + 1) * 5 * sizeof(double));
+        h_nc = (int*)hbuf((size_t)(NE + 1) * sizeof(int));
+        h_coff = p.want_cells ? (long long*)hbuf((size_t)(NE + 1) * sizeof(long long)) : nullptr;
+        b->poly_n = (size_t)NV;
+        b->poly_x = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
+        b->poly_y = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
+        if (!h_ev || !h_poff || !h_sums || !h_nc || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
+#if !defined(WB_HOSTSIM)
+        std::swap(ctx->stream, ctx->stream2);
+#endif
+        b->timer.begin(ctx, "polygons_d2h");
+        d2h_async(ctx, h_ev, fa.ev, (size_t)NE * 8 * sizeof(int));
+        d2h_async(ctx, h_poff, fa.poff, (size_t)(NE + 1) * sizeof(long long));
+        d2h_async(ctx, b->poly_x, d_px, (size_t)NV * sizeof(int));
+        d2h_async(ctx, b->poly_y, d_py, (size_t)NV * sizeof(int));
+        b->timer.end(ctx);
+#if !defined(WB_HOSTSIM)
+        std::swap(ctx->stream, ctx->stream2);
+#endif
+        b->timer.begin(ctx, "events_d2h");
+        d2h_async(ctx, h_sums, pa.ev_sums, (size_t)NE * 5 * sizeof(double));
+        d2h_async(ctx, h_nc, pa.ev_ncells, (size_t)NE * sizeof(int));
+        if (p.want_cells) d2h_async(ctx, h_coff, pa.ev_cell_off, (size_t)NE * sizeof(long long));
+        b->timer.end(ctx);
+        if (dsync(ctx) || side_sync(ctx)) { release(); return 1; }
+        fin = hc[1];
+        if (p.want_cells) {
+            if (fin.cell_count > cell_cap) {                    // cell pool too small: the phase again with the exact size
+                cell_cap = fin.cell_count + 1024;
+                release();
+                if (attempt == 5) return wb_fail(ctx, "cell pool overflow");
+                continue;
+            }
+            h_cells = (uint32_t*)hbuf((size_t)(fin.cell_count + 1) * sizeof(uint32_t));
+            if (!h_cells) { release(); return wb_fail(ctx, "out of host memory"); }
+            d2h_async(ctx, h_cells, pa.cell_pool, (size_t)fin.cell_count * sizeof(uint32_t));
+            if (dsync(ctx)) { release(); return 1; }
+        }
+        release();
+        break;
     }
-    if (dsync(ctx)) return 1;
+    b->sel_job = b->sel_cont = b->cut_job = b->cut_cont = nullptr;
+    b->nsel = fin.nsel; b->ncut = fin.ncut;
+    b->band[0] = fin.band[0]; b->band[1] = fin.band[1];
+    b->pair_stats[0] = fin.point_pairs; b->pair_stats[1] = fin.cand_pairs; b->pair_stats[2] = fin.evaluated_pairs;
+    for (int q = 0; q < 3; ++q) b->com_rechecks[q] = fin.com_rechecks[q];
+    const int NS = fin.NS, NO = fin.NO, NE = fin.NE;
 
     // ---- host tables (sized once, filled with plain loops)
     for (int kind = 0; kind < 3; ++kind) {
@@ -1283,7 +1372,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         t = wb_batch::Ev();
         const int lo = kind == 0 ? 0 : (kind == 1 ? NS : NS + NO), hi = kind == 0 ? NS : (kind == 1 ? NS + NO : NE);
         const size_t m = (size_t)(hi - lo);
-        const long long pbase = h_poff[lo], pn = h_poff[hi] - h_poff[lo];
+        const long long pbase = NE ? h_poff[lo] : 0, pn = NE ? h_poff[hi] - h_poff[lo] : 0;
         t.step.resize(m); t.level.resize(m); t.contour.resize(m); t.ind1.resize(m); t.ind2.resize(m);
         t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.ncells.resize(m);
         t.polyoff.resize(m + 1); t.pbase = (size_t)pbase;
@@ -1297,7 +1386,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             if (kind == WB_OVERTURNINGS) {
                 t.ind1[k] = 0; t.ind2[k] = 0;
                 for (int q = 0; q < 4; ++q) t.box[4 * k + q] = d[3 + q];
-                t.orient[k] = d[7];
+                t.orient[k] = d[0] >> 8;
             } else {
                 t.ind1[k] = d[3]; t.ind2[k] = d[4];
             }
@@ -1324,8 +1413,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             }
         }
     }
-    for (void* q : tmp) bfree_one(b, q);
-    b->sel_job = b->sel_cont = b->cut_job = b->cut_cont = nullptr;
+    // the small pinned result blocks go back to the context's pool
+    for (auto& hb : b->hres) hfree(ctx, hb.first, hb.second);
+    b->hres.clear();
     b->timer.collect();
     return 0;
 }
@@ -1431,13 +1521,21 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
     b->c_nux = upload(b, h_nux); b->c_sumy = upload(b, h_sy); b->ncont = upload(b, h_nc);
     b->d_job_step = upload(b, b->job_step);
     b->status = balloc<uint32_t>(b, J > 0 ? J : 1);
-    if (!b->status) { wb_free_batch(b); return 1; }
+    b->d_ctl = balloc<WbCtl>(b, 1);
+    if (!b->status || !b->d_ctl) { wb_free_batch(b); return 1; }
     dmemset(ctx, b->status, 0, (size_t)(J > 0 ? J : 1) * sizeof(uint32_t));
-    b->h_ncont = h_nc;
+    {
+        WbCtl c0;
+        memset(&c0, 0, sizeof(c0));
+        c0.max_nux = b->max_nux;
+        h2d(ctx, b->d_ctl, &c0, sizeof(c0));
+    }
     b->h_status.assign(J, 0);
     b->ct_base.assign(J + 1, 0);
     for (int j = 0; j < J; ++j) b->ct_base[j + 1] = j + 1;
-    if (dsync(ctx)) { wb_free_batch(b); return 1; }
+    if (J > 0 ? phase1_summary(b) : dsync(ctx)) { wb_free_batch(b); return 1; }
+    b->h_ncont = h_nc;
+    b->max_nux = b->h_ctl.max_nux;
     *out = b;
     return 0;
 }

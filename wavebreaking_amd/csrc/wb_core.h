@@ -67,6 +67,40 @@ WB_HD inline int wb_key_sq(uint32_t k) { return (int)((k & 0x07FFFFFFu) >> 1); }
 WB_HD inline int wb_key_sub(uint32_t k) { return (int)(k & 1u); }
 WB_HD inline int wb_key_case(uint32_t k) { return (int)(k >> 27) & 15; }
 
+// ------------------------------------------------------------------ control block
+// Counters of a batch that live on the device and are read back by the host ONCE per ABI phase (a small pinned copy):
+// launch sizes and allocations come from the phase-1 bounds, loop limits inside the kernels from the device copy, so no
+// kernel of a phase waits for the host.
+struct WbCtl {
+    // phase 1 (wb_contours)
+    int max_nux;                 // largest distinct-longitude count of a contour (exp_lon.max() / dlon of this batch)
+    int max_seg_job;             // largest segment count of a (step, level) job / of a strip list: capacity checks
+    int max_seg_strip;
+    int ncont_total;             // contours of the batch
+    long long npts_total;        // their points
+    int nsel_max;                // contours with nux == max_nux (= the selected ones unless another rank holds a larger maximum)
+    int nclosed;                 // closed contours (cutoff candidates whatever the selection maximum)
+    long long npt_sel_max;       // points of the former / of the latter
+    long long npt_closed;
+    int pair_items_max;          // work items of the all-pairs kernel for the contours with nux == max_nux
+    int pad0;
+    // phase 2 (wb_indices)
+    int nsel, ncut;              // selected contours / cutoff contours
+    long long npt_sel;
+    int n_pair_items, n_f2_items;
+    int max_pairs;               // largest candidate count of a contour (capacity check)
+    int NS, NO, NE;              // streamer / overturning events, all events
+    int overflow;                // bit 0: more events than cap_ne, bit 1: more polygon vertices than cap_poly
+    long long cand_pairs;        // candidate pairs that passed both distance tests
+    long long point_pairs;       // sum of N (N - 1) / 2 over the selected contours
+    long long evaluated_pairs;   // pairs whose great-circle term was actually evaluated
+    long long poly_total;        // polygon vertices of all events
+    int band[2];                 // guard-band re-evaluations (geo, cont)
+    int com_rechecks[3];
+    int ne_demand;               // events found when they exceeded cap_ne
+    unsigned long long cell_count;
+};
+
 // ------------------------------------------------------------------ integer predicates
 WB_HD inline int64_t wb_orient(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t cx, int64_t cy) {
     return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);

@@ -13,6 +13,7 @@
 // selection
 struct WbSelectArgs {
     int njobs, cap_seg, gmax;      // gmax: global max of the distinct-x count (exp_lon.max() / dlon)
+    int want_cut;                  // cutoffs requested
     double dlon, co_min_exp;
     const int* ncont;              // [njobs]
     const int* c_nux;              // [njobs][cap_seg]
@@ -41,7 +42,7 @@ WB_KERNEL(wb_k_select_count, WbSelectArgs a) {
     int s = 0, c = 0;
     for (int k = 0; k < a.ncont[job]; ++k) {
         if (a.c_nux[jb + k] == a.gmax) ++s;
-        if (wb_is_cutoff(a.c_nux[jb + k], a.c_closed[jb + k], a.gmax, a.dlon, a.co_min_exp)) ++c;
+        if (a.want_cut && wb_is_cutoff(a.c_nux[jb + k], a.c_closed[jb + k], a.gmax, a.dlon, a.co_min_exp)) ++c;
     }
     a.nsel[job] = s;
     a.ncut[job] = c;
@@ -66,7 +67,7 @@ WB_KERNEL(wb_k_select_fill, WbSelectArgs a) {
     int s = a.selbase[job], c = a.cutbase[job];
     for (int k = 0; k < a.ncont[job]; ++k) {
         if (a.c_nux[jb + k] == a.gmax) { a.sel_job[s] = job; a.sel_cont[s] = k; ++s; }
-        if (wb_is_cutoff(a.c_nux[jb + k], a.c_closed[jb + k], a.gmax, a.dlon, a.co_min_exp)) {
+        if (a.want_cut && wb_is_cutoff(a.c_nux[jb + k], a.c_closed[jb + k], a.gmax, a.dlon, a.co_min_exp)) {
             a.cut_job[c] = job; a.cut_cont[c] = k; ++c;
         }
     }
@@ -79,7 +80,8 @@ WB_KERNEL(wb_k_select_fill, WbSelectArgs a) {
 #define WB_MAXW 4100
 
 struct WbOverturnArgs {
-    int nsel, cap_seg, nlon, W;
+    int cap_seg, nlon, W;
+    const WbCtl* ctl;          // ctl->nsel selected contours
     double rg_over_dlon;       // range_group / dlon
     double minexp_over_dlon;   // min_exp / dlon
     const int* sel_job;
@@ -107,7 +109,7 @@ WB_HD inline bool wb_arc_subset(int a0, int b0, int a1, int b1, int nlon) {
 
 WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
     const int s = WB_BLOCK_ID;
-    if (s >= a.nsel) return;
+    if (s >= a.ctl->nsel) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -209,7 +211,8 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // streamer index
 struct WbStreamerArgs {
-    int nsel, cap_seg, nlon, nlat, W, cap_pairs, cap_ev, hash_size;  // hash_size: pow2 >= 2*cap_pairs
+    int cap_seg, nlon, nlat, W, cap_pairs, cap_ev, hash_size;  // hash_size: pow2 >= 2*cap_pairs
+    WbCtl* ctl;                // ctl->nsel selected contours; counters of the pass
     double geo_dis, cont_dis;
     double hthr;               // sin^2(geo_dis / (2*6371))
     const int* sel_job;
@@ -226,11 +229,15 @@ struct WbStreamerArgs {
     const double* slam2;       // [nlon] sin(lon_rad/2)
     const double* clam2;       // [nlon] cos(lon_rad/2)
     // per selected contour, packed by point: contour s owns [poff[s], poff[s+1])
-    const long long* poff;     // [nsel+1]
+    long long* poff;           // [nsel+1] first point of a selected contour in the packed arrays (device scan)
+    int* item_off;             // [nsel+1] first work item of a contour in the all-pairs kernel's list
+    int* item_sel;             // [items] contour / first 16-row tile of a work item
+    int* item_tile;
+    int* f2_off;               // [nsel+1] first 256-pair block of a contour in routine 2's work list
     double* on;                // on[k] = d(k-1, k) * 6371, on[0] = 0
     double* pre;               // inclusive prefix of on
     double* ptab;              // [5][npts_total] sin(phi/2), cos(phi/2), cos(phi), sin(lam/2), cos(lam/2) per point
-    long long npts_total;
+    long long npts_total;      // capacity of the packed per-point arrays (plane stride of ptab)
     int* bbx;                  // per block of WB_BLK points (+1: the segment leaving the block): xmin, xmax, ymin, ymax;
                                // contour s owns blocks [(poff[s] >> 5) + s, ...)
     int* tbx;                  // per tile of WB_PAIR_ROWS rows: xmin, xmax, ymin, ymax; contour s owns tiles [(poff[s] >> 4) + s, ...)
@@ -247,7 +254,6 @@ struct WbStreamerArgs {
     int* rowaux;
     int* ev_ind;               // [nsel][cap_ev][2]
     int* ev_n;                 // [nsel]
-    int* band_hits;            // [2] pairs inside the geo / cont guard bands (re-evaluated exactly)
     uint32_t* status;          // [njobs]
 };
 
@@ -265,7 +271,7 @@ WB_HD inline double wb_haversine(double la1, double lo1, double la2, double lo2)
 // per selected contour: on[] and its prefix (streamer_index.py:133), per-point trigonometric table, block boxes
 WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
-    if (s >= a.nsel) return;
+    if (s >= a.ctl->nsel) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -347,13 +353,17 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
 // Blocks of WB_BLK candidate points j are skipped as a whole when their bounding box cannot hold a partner:
 // |x_i - x_j| <= 120 (:157), |y_i - y_j| <= dy_max (geo < geo_dis needs R*|dphi| < geo_dis), and the block's
 // largest along-contour distance must exceed cont_dis.  What survives is evaluated exactly as before.
-#define WB_PAIR_ROWS 16
 #define WB_MAX_BLOCKS 512       // contours up to 16384 points; longer ones fall back to sweeping all blocks
 
 // six waves per SIMD (80 VGPRs): the kernel waits on memory 60 % of its wave cycles; 5 waves (96) are no faster, 7-8 spill
-WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a, const int* blk_sel, const int* blk_tile0, int tiles_per_block) {
-    // work list built on the host: workgroup w (ONE wave) sweeps tiles [blk_tile0[w], +tiles_per_block) of contour
-    // blk_sel[w]; single-wave workgroups make the phase barriers free and keep 32 tiles in flight per CU
+WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
+    // work list built on the device (wb_k_pair_items): workgroup w (ONE wave) sweeps WB_PAIR_TPB tiles from item_tile[w] of
+    // contour item_sel[w]; single-wave workgroups make the phase barriers free and keep 32 tiles in flight per CU
+    if (WB_BLOCK_ID >= a.ctl->n_pair_items) return;
+    const int tiles_per_block = WB_PAIR_TPB;
+    const int* blk_sel = a.item_sel;
+    const int* blk_tile0 = a.item_tile;
+    long long evaluated = 0;                    // pairs whose great-circle term is evaluated by this lane
     const int s = blk_sel[WB_BLOCK_ID];
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
@@ -434,9 +444,10 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a, const int* blk_sel, c
             const double sa = ri[6 * ii + 0] * cpj - ri[6 * ii + 1] * spj;
             const double sb = ri[6 * ii + 3] * clj - ri[6 * ii + 4] * slj;
             const double h = sa * sa + ri[6 * ii + 2] * cj * (sb * sb);
+            ++evaluated;
             bool near_geo;
             if (fabs(h - a.hthr) <= WB_GEO_BAND * a.hthr) {            // guard band: evaluate as sklearn does
-                wb_atomic_add(&a.band_hits[0], 1);
+                wb_atomic_add(&a.ctl->band[0], 1);
                 const uint32_t pi = pts[i], pj = pts[j];
                 const int yi = wb_pt_y(pi), yj = wb_pt_y(pj), xim = wb_pt_x(pi) % a.nlon, xjm = wb_pt_x(pj) % a.nlon;
                 const double geo = wb_haversine(a.lat_rad[yi], a.lon_rad[xim], a.lat_rad[yj], a.lon_rad[xjm]) * 6371.0;
@@ -447,7 +458,7 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a, const int* blk_sel, c
             if (!near_geo) continue;
             double cont = prej - ri[6 * ii + 5];
             if (fabs(cont - a.cont_dis) <= WB_CONT_BAND) {            // guard band: sequential row cumsum (:135)
-                wb_atomic_add(&a.band_hits[1], 1);
+                wb_atomic_add(&a.ctl->band[1], 1);
                 double acc = 0.0;
                 for (int m = i + 1; m <= j; ++m) acc = acc + on[m];
                 cont = acc;
@@ -458,6 +469,7 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a, const int* blk_sel, c
         }
     WB_END_PFOR
     }   // tiles
+    if (evaluated) wb_atomic_add((unsigned long long*)&a.ctl->evaluated_pairs, (unsigned long long)evaluated);
 }
 
 #ifndef WB_F1_LTAB
@@ -468,7 +480,7 @@ WB_HD inline int wb_bits_for_i(int n) { int b = 0; while ((1 << b) < n) ++b; ret
 // routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264
 WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
-    if (s >= a.nsel) return;
+    if (s >= a.ctl->nsel) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -478,6 +490,10 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     unsigned long long* hval = a.hval + (size_t)s * a.hash_size;
     WB_SHARED(int, cnt, 1);
     int P = a.npairs[s];
+    WB_SINGLE
+    wb_atomic_max(&a.ctl->max_pairs, P);
+    wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
+    WB_END_SINGLE
     int hsize = 256;                       // table sized to this contour's pair count (clearing it is real traffic)
     while (hsize < 2 * P && hsize < a.hash_size) hsize <<= 1;
     const int hmask = hsize - 1;
@@ -611,10 +627,20 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
 #define WB_F2_THREADS 256
 #define WB_F2_SUP 8
 #define WB_F2_SUPMAX 64
-WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk_first) {
-    // work list built on the host from the pair counts: workgroup w tests pairs [blk_first[w], +256) of contour blk_sel[w]
-    const int s = blk_sel[WB_BLOCK_ID];
-    if (a.stage[s] != 1 || a.nalive[s] <= 1) return;
+WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a) {
+    // work list on the device: block w of the list = pairs [256 (w - f2_off[s]), +256) of the contour s with
+    // f2_off[s] <= w < f2_off[s+1] (wb_k_f2_items; only contours that can still reach routine 2, streamer_index.py:261-264);
+    // persistent workgroups stride over the list
+    WB_SHARED(int, sbb, 4 * WB_F2_SUPMAX);
+    const int nitems = a.ctl->n_f2_items, nsel = a.ctl->nsel;
+    for (int w = WB_BLOCK_ID; w < nitems; w += WB_GRID_DIM) {
+    int lo = 0, hi = nsel;                                // largest s with f2_off[s] <= w
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.f2_off[mid] <= w) lo = mid; else hi = mid;
+    }
+    const int s = lo;
+    if (a.stage[s] != 1 || a.nalive[s] <= 1) continue;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -624,10 +650,9 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk
     const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     int* alive = a.alive + (size_t)s * a.cap_pairs;
     const int P = a.npairs[s];
-    const int p0 = blk_first[WB_BLOCK_ID];
-    if (p0 >= P) return;
+    const int p0 = (w - a.f2_off[s]) * WB_F2_THREADS;
+    if (p0 >= P) continue;
     // second level of boxes: one per WB_F2_SUP consecutive blocks (a chord's box meets a handful of them)
-    WB_SHARED(int, sbb, 4 * WB_F2_SUPMAX);
     const int nsup = (nblk + WB_F2_SUP - 1) / WB_F2_SUP;
     const bool two = nsup <= WB_F2_SUPMAX;
     if (two) {
@@ -668,12 +693,13 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a, const int* blk_sel, const int* blk
         }
         if (hit) alive[p] = 2;   // 2 = rejected by routine 2 (turned into 0 by f3)
     WB_END_PFOR
+    }   // work list
 }
 
 // routines 3 and 4: check_overlapping (:202-222), check_groups (:224-251), then the polygons' end points
 WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
-    if (s >= a.nsel) return;
+    if (s >= a.ctl->nsel) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -834,4 +860,56 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
         a.nalive[s] = nal;
         WB_END_SINGLE
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// work lists and offsets, built on the device (single workgroups: a few thousand entries each)
+
+// lengths of the selected contours -> packed point offsets, work items of the all-pairs kernel
+WB_KERNEL(wb_k_sel_scan, WbStreamerArgs a, int* tmp) {
+    const int nsel = a.ctl->nsel;
+    WB_SHARED(unsigned long long, pp, 1);
+    WB_SINGLE
+    pp[0] = 0ull;
+    WB_END_SINGLE
+    WB_PFOR(s, nsel)
+        const int len = a.c_len[(size_t)a.sel_job[s] * a.cap_seg + a.sel_cont[s]];
+        tmp[s] = len;
+        wb_atomic_add(&pp[0], (unsigned long long)((long long)len * (len - 1) / 2));   // base-point pairs the all-pairs test covers
+        const int tiles = (len - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+        a.item_off[s] = (tiles + WB_PAIR_TPB - 1) / WB_PAIR_TPB;
+    WB_END_PFOR
+    const int npt = wb_block_scan_excl(tmp, nsel);
+    const int nit = wb_block_scan_excl(a.item_off, nsel);
+    WB_PFOR(s, nsel + 1)
+        a.poff[s] = s < nsel ? (long long)tmp[s] : (long long)npt;
+        if (s == nsel) a.item_off[s] = nit;
+    WB_END_PFOR
+    WB_SINGLE
+    a.ctl->npt_sel = npt;
+    a.ctl->n_pair_items = nit;
+    a.ctl->point_pairs = (long long)pp[0];
+    WB_END_SINGLE
+}
+WB_KERNEL(wb_k_pair_items, WbStreamerArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.ctl->nsel) return;
+    const int first = a.item_off[s], n = a.item_off[s + 1] - first;
+    WB_PFOR(k, n)
+        a.item_sel[first + k] = s;
+        a.item_tile[first + k] = (int)k * WB_PAIR_TPB;
+    WB_END_PFOR
+}
+// routine 2's work list: 256-pair blocks of the contours that still hold more than one candidate (streamer_index.py:261-264)
+WB_KERNEL(wb_k_f2_items, WbStreamerArgs a) {
+    const int nsel = a.ctl->nsel;
+    WB_PFOR(s, nsel)
+        const int P = a.npairs[s] < a.cap_pairs ? a.npairs[s] : a.cap_pairs;
+        a.f2_off[s] = P > 1 ? (P + WB_F2_THREADS - 1) / WB_F2_THREADS : 0;
+    WB_END_PFOR
+    const int n = wb_block_scan_excl(a.f2_off, nsel);
+    WB_SINGLE
+    a.f2_off[nsel] = n;
+    a.ctl->n_f2_items = n;
+    WB_END_SINGLE
 }

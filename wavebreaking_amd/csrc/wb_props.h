@@ -34,9 +34,11 @@ enum { WB_EV_STREAMER = 0, WB_EV_OVERTURNING = 1, WB_EV_CUTOFF = 2 };
 #endif
 
 struct WbPropsArgs {
-    int nev, nslots, nlat, nlon, W, cap_seg, nlev, dtype, want_cells, pad;
+    int nslots, nlat, nlon, W, cap_seg, nlev, dtype, want_cells, pad;
+    WbCtl* ctl;                 // ctl->NE events; com_rechecks, cell_count
     double r2;                  // buffer radius squared, ((dlon+dlat)/4)^2 in index units
-    const int* ev;              // [nev][8]: kind, job, contour, a0..a3, orientation
+    const int* ev;              // [NE][8]: kind | orientation << 8, job, contour, a0..a3, overturnings: slot of the box in ot_sums
+    const double* ot_sums;      // [slots][3] areas, x_com, y_com of the overturning boxes (wb_k_box_com)
     const int* c_off;
     const int* c_len;
     const uint32_t* cpts;
@@ -48,8 +50,6 @@ struct WbPropsArgs {
     double* rowacc;             // [nslots][4][nlat]
     double* ev_sums;            // [nev][5]: areas, mean_var, intensity, x_com, y_com  (sums, :94-102)
     int* ev_ncells;             // [nev]
-    int* com_rechecks;          // [3] events / boxes whose areas, x_com, y_com were re-evaluated in the reference's order (wb_k_box_com)
-    unsigned long long* cell_count;  // [1] bump allocator of the cell pool
     unsigned long long cell_cap;
     uint32_t* cell_pool;        // (x | y<<16)
     long long* ev_cell_off;     // [nev]
@@ -60,7 +60,7 @@ WB_HD inline double wb_load_field(const void* p, size_t idx, int dtype) {
 }
 
 WB_DEV inline uint32_t wb_event_vertex(const int* d, const uint32_t* pts, int k) {
-    const int kind = d[0];
+    const int kind = d[0] & 0xFF;
     if (kind == WB_EV_STREAMER) return pts[d[3] + k];
     if (kind == WB_EV_CUTOFF) return pts[k];
     // shapely.geometry.box(minx, miny, maxx, maxy): (maxx,miny),(maxx,maxy),(minx,maxy),(minx,miny)
@@ -113,9 +113,10 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
     int* cells = a.cells + (size_t)slot * a.W * a.nlat;
     double* cells_d = (double*)cells;                     // box path, very wide boxes: chunk partials in the (then unused) cell scratch
     double* rowacc = a.rowacc + (size_t)slot * 4 * a.nlat;
-    for (int e = WB_BLOCK_ID; e < a.nev; e += WB_GRID_DIM) {
+    const int nev = a.ctl->NE;
+    for (int e = WB_BLOCK_ID; e < nev; e += WB_GRID_DIM) {
         const int* d = a.ev + (size_t)e * 8;
-        const int kind = d[0], job = d[1], cont = d[2];
+        const int kind = d[0] & 0xFF, job = d[1], cont = d[2];
         const size_t jb = (size_t)job * a.cap_seg;
         const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + cont];
         const int n = (kind == WB_EV_STREAMER) ? (d[4] - d[3] + 1) : (kind == WB_EV_CUTOFF ? a.c_len[jb + cont] : 4);
@@ -328,8 +329,12 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             it = it + w * WB_ACC(3, y);
             nc += (long long)cnt;
         }
-        // boxes: areas / x_com / y_com come from wb_k_box_com (which runs beside this kernel and owns those three slots)
-        if (!full) {
+        // boxes: areas / x_com / y_com come from wb_k_box_com (which ran beside the streamer kernels)
+        if (full) {
+            a.ev_sums[(size_t)e * 5 + 0] = a.ot_sums[(size_t)d[7] * 3 + 0];
+            a.ev_sums[(size_t)e * 5 + 3] = a.ot_sums[(size_t)d[7] * 3 + 1];
+            a.ev_sums[(size_t)e * 5 + 4] = a.ot_sums[(size_t)d[7] * 3 + 2];
+        } else {
             const double ulps = wb_com_ulps(rows);
             if (nc > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps))) {
                 // the reference's order: cells (y, x) ascending, one product per cell, compensated sums
@@ -348,7 +353,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                     }
                 }
                 areas = sa; xc = sx; yc = sy;
-                wb_atomic_add(&a.com_rechecks[0], 1);
+                wb_atomic_add(&a.ctl->com_rechecks[0], 1);
             }
             a.ev_sums[(size_t)e * 5 + 0] = areas;
             a.ev_sums[(size_t)e * 5 + 3] = xc;
@@ -359,7 +364,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         a.ev_ncells[e] = (int)nc;
         long long off = -1;
         if (a.want_cells) {
-            off = (long long)wb_atomic_add(a.cell_count, (unsigned long long)nc);
+            off = (long long)wb_atomic_add(&a.ctl->cell_count, (unsigned long long)nc);
             if ((unsigned long long)off + (unsigned long long)nc > a.cell_cap) off = -1;
             // per-row start offsets (rows ascending, x ascending inside a row)
             long long run = off;
@@ -402,16 +407,18 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 //     inexact step elsewhere), more than WB_BOXCOM_SEGS segments in a row or more than WB_BOXCOM_ROWS rows => one lane walks
 //     all cells instead (counted in com_rechecks[2]); correctness never rests on the prediction.
 #ifndef WB_BOXCOM_ROWS
-#define WB_BOXCOM_ROWS 256
+#define WB_BOXCOM_ROWS 128           // taller boxes (more than 32 degrees of latitude on the 0.25 degree grid) take the one-lane walk
 #endif
+#define WB_BOXCOM_SPLIT 2            // workgroups per selected contour (its boxes are dealt out round-robin)
 #define WB_BOXCOM_SEGS 4
 typedef unsigned __int128 wb_u128;
 struct WbBoxComArgs {
-    int nev, first, nlat, W;      // events [first, first + nev) are the overturning boxes
-    const int* ev;                // [..][8]
+    int nlat, W;
+    WbCtl* ctl;                   // ctl->nsel selected contours; com_rechecks[1] boxes re-evaluated, [2] ... by the one-lane walk
+    const int* ot_n;              // [nsel] boxes of a selected contour
+    const int* ot_box;            // [nsel][WB_OT_CAP][4]
     const double* wlat;
-    double* ev_sums;              // [..][5]: slots 0, 3, 4 written here
-    int* com_rechecks;            // [3]: rasterised events / boxes re-evaluated / boxes that needed the one-lane walk
+    double* ot_sums;              // [nsel][WB_OT_CAP][3] areas, x_com, y_com
 };
 // v = m * 2^e, m < 2^53 (v >= 0, finite)
 WB_HD inline void wb_dbl_split(double v, unsigned long long* m, int* e) {
@@ -457,11 +464,14 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     WB_SHARED(int, nseg, WB_BOXCOM_ROWS);
     WB_SHARED(double, st, 6 * (WB_BOXCOM_ROWS + 1));             // per chain: predicted state s, c at the start of every row (+ after the last)
     WB_SHARED(int, ctl, 4);                                      // [0] in band, [1] unit exponent, [2] not verified
-    const int q = WB_BLOCK_ID;
-    if (q >= a.nev) return;
-    const int e = a.first + q;
-    const int* d = a.ev + (size_t)e * 8;
-    int x0 = d[3], y0 = d[4], x1 = d[5], y1 = d[6];
+    const int sel = WB_BLOCK_ID / WB_BOXCOM_SPLIT;
+    if (sel >= a.ctl->nsel) return;
+    const int nbox = a.ot_n[sel];
+    for (int g = WB_BLOCK_ID % WB_BOXCOM_SPLIT; g < nbox; g += WB_BOXCOM_SPLIT) {
+    WB_SYNC();                                                   // the previous box's control words have been read by everyone
+    const int* d = a.ot_box + ((size_t)sel * WB_OT_CAP + g) * 4;
+    double* out = a.ot_sums + ((size_t)sel * WB_OT_CAP + g) * 3;
+    int x0 = d[0], y0 = d[1], x1 = d[2], y1 = d[3];
     if (x0 < 0) x0 = 0;
     if (y0 < 0) y0 = 0;
     if (x1 > a.W - 1) x1 = a.W - 1;
@@ -488,14 +498,14 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
     ctl[2] = (rows > WB_BOXCOM_ROWS || emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
     if (!band) {
-        a.ev_sums[(size_t)e * 5 + 0] = areas;
-        a.ev_sums[(size_t)e * 5 + 3] = xc;
-        a.ev_sums[(size_t)e * 5 + 4] = yc;
+        out[0] = areas;
+        out[1] = xc;
+        out[2] = yc;
     } else {
-        wb_atomic_add(&a.com_rechecks[1], 1);
+        wb_atomic_add(&a.ctl->com_rechecks[1], 1);
     }
     WB_END_SINGLE
-    if (!ctl[0]) return;
+    if (!ctl[0]) continue;
     const int ue = ctl[1];
     if (!ctl[2]) {
         // pass 1: segments of the x chain, row by row
@@ -595,14 +605,15 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                 WB_KAHAN(sy, cy, yw);
             }
         }
-        wb_atomic_add(&a.com_rechecks[2], 1);
+        wb_atomic_add(&a.ctl->com_rechecks[2], 1);
     } else {
         sa = st[0 * (WB_BOXCOM_ROWS + 1) + rows];
         sx = st[2 * (WB_BOXCOM_ROWS + 1) + rows];
         sy = st[4 * (WB_BOXCOM_ROWS + 1) + rows];
     }
-    a.ev_sums[(size_t)e * 5 + 0] = sa;
-    a.ev_sums[(size_t)e * 5 + 3] = sx;
-    a.ev_sums[(size_t)e * 5 + 4] = sy;
+    out[0] = sa;
+    out[1] = sx;
+    out[2] = sy;
     WB_END_SINGLE
+    }   // boxes of this contour
 }

@@ -46,8 +46,8 @@ struct WbTraceArgs {
     int* c_sumy;
     int* ncont;              // [njobs]
     uint32_t* status;        // [njobs]
-    int* max_nux;            // [1] batch-wide maximum of c_nux
     int* nseg;               // [njobs] merged segment count (-1: job skipped)
+    WbCtl* ctl;              // batch counters (capacity checks, maxima)
 };
 
 #define WB_HEMPTY 0xFFFFFFFFFFFFFFFFull
@@ -231,13 +231,20 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
 
     // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
     //          position in its own list plus the number of smaller keys in every other list
-    int n = 0;
+    int n = 0, nmax = 0;
     bool over = false;
     for (int s = 0; s < a.nstrips; ++s) {
         const int c = a.stg_n[job * a.nstrips + s];
         if (c > a.cap_strip) over = true;
+        nmax = c > nmax ? c : nmax;
         n += c;
     }
+    WB_SINGLE
+    if (n > a.cap_seg || over) {          // the host grows the capacities and re-runs the phase
+        wb_atomic_max(&a.ctl->max_seg_job, n);
+        wb_atomic_max(&a.ctl->max_seg_strip, nmax);
+    }
+    WB_END_SINGLE
     if (over || n > cap || n == 0) {  // overflow: the scan kernel kept counting but stopped writing
         WB_SINGLE
         if (n != 0) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_SEG);
@@ -829,10 +836,62 @@ WB_KERNEL_LB(wb_k_trace_finish, 1024, 8, WbTraceArgs a) {
             c_closed[g] = s_cl[f];
             c_nux[g] = s_nux[f];
             c_sumy[g] = s_sy[f];
-            wb_atomic_max(a.max_nux, s_nux[f]);
+            wb_atomic_max(&a.ctl->max_nux, s_nux[f]);
         }
     WB_END_PFOR
     WB_SINGLE
     a.ncont[job] = Cf;
     WB_END_SINGLE
+}
+
+// -------------------------------------------------------------------------------------------- phase-1 summary
+// Bounds for phase 2, taken after the batch maximum of nux is final: how many contours reach it and how long they are
+// (they are the selected ones unless another rank / batch holds a larger maximum, in which case nothing is selected),
+// the closed contours (cutoff candidates), the work items of the all-pairs kernel.
+#define WB_PAIR_ROWS 16
+#define WB_PAIR_TPB 8             // 16-row tiles per work item of the all-pairs kernel
+struct WbSummaryArgs {
+    int njobs, cap_seg;
+    const int* ncont; const int* c_len; const int* c_nux; const int* c_closed;
+    WbCtl* ctl;
+};
+WB_KERNEL(wb_k_phase1_summary, WbSummaryArgs a) {
+    WB_SHARED(long long, acc, 8);
+    for (int job = WB_BLOCK_ID; job < a.njobs; job += WB_GRID_DIM) {
+        const size_t jb = (size_t)job * a.cap_seg;
+        const int C = a.ncont[job], mx = a.ctl->max_nux;
+        WB_SINGLE
+        for (int k = 0; k < 8; ++k) acc[k] = 0;
+        WB_END_SINGLE
+        WB_PFOR(k, C)
+            const int len = a.c_len[jb + k];
+            wb_atomic_add((unsigned long long*)&acc[0], 1ull);
+            wb_atomic_add((unsigned long long*)&acc[1], (unsigned long long)len);
+            if (a.c_nux[jb + k] == mx) {
+                wb_atomic_add((unsigned long long*)&acc[2], 1ull);
+                wb_atomic_add((unsigned long long*)&acc[3], (unsigned long long)len);
+                const int tiles = (len - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+                wb_atomic_add((unsigned long long*)&acc[4], (unsigned long long)((tiles + WB_PAIR_TPB - 1) / WB_PAIR_TPB));
+            }
+            if (a.c_closed[jb + k]) {
+                wb_atomic_add((unsigned long long*)&acc[5], 1ull);
+                wb_atomic_add((unsigned long long*)&acc[6], (unsigned long long)len);
+            }
+        WB_END_PFOR
+        WB_SINGLE
+        if (acc[0]) {
+            wb_atomic_add(&a.ctl->ncont_total, (int)acc[0]);
+            wb_atomic_add((unsigned long long*)&a.ctl->npts_total, (unsigned long long)acc[1]);
+            if (acc[2]) {
+                wb_atomic_add(&a.ctl->nsel_max, (int)acc[2]);
+                wb_atomic_add((unsigned long long*)&a.ctl->npt_sel_max, (unsigned long long)acc[3]);
+                wb_atomic_add(&a.ctl->pair_items_max, (int)acc[4]);
+            }
+            if (acc[5]) {
+                wb_atomic_add(&a.ctl->nclosed, (int)acc[5]);
+                wb_atomic_add((unsigned long long*)&a.ctl->npt_closed, (unsigned long long)acc[6]);
+            }
+        }
+        WB_END_SINGLE
+    }
 }
