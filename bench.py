@@ -119,7 +119,8 @@ def main():
         res = dict(timings=b.timings(),
                    counts=dict(polygon_vertices=int(sum(e["poly_x"].size for e in ev)), streamers=int(ev[0]["step"].size),
                                overturnings=int(ev[1]["step"].size), cutoffs=int(ev[2]["step"].size),
-                               band_hits=b.band_hits(), pair_stats=b.pair_stats(),
+                               band_hits=b.band_hits(), pair_stats=b.pair_stats(), evaluated_pairs=b.evaluated_pairs(),
+                               com_rechecks=b.com_rechecks(),
                                status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
                    packed=[wd.pack_events(e, step_offset=t0) for e in ev] if world > 1 else None,
                    events=ev if copy else None)
@@ -194,8 +195,11 @@ def main():
                          "frac_alone": nt * bytes_per_ts / (solo_scan_ms * 1e-3) / HBM_PEAK,
                          "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
             "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
-            # the all-pairs streamer test, reported separately (base-point pairs per second of its kernel)
+            # the all-pairs streamer test, reported separately: base-point pairs COVERED per second of its kernel
+            # (N (N - 1) / 2 per contour; most are excluded as whole blocks) and pairs whose great-circle term is EVALUATED
             "pair_evaluations_per_s": counts["pair_stats"][0] / (float(np.mean(stage_ms["streamer_pairs"])) * 1e-3)
+            if stage_ms.get("streamer_pairs") else None,
+            "pairs_evaluated_per_s": counts["evaluated_pairs"] / (float(np.mean(stage_ms["streamer_pairs"])) * 1e-3)
             if stage_ms.get("streamer_pairs") else None,
             "host_wall_ms": {k: float(np.mean(v)) for k, v in wall.items()},
             "counts": counts,

@@ -56,6 +56,17 @@ def test_periodic_add_variants(ctx, padd):
     helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2], periodic_add=padd)
 
 
+def test_eager_and_lazy_routine_2_agree(ctx):
+    # the exhaustive formulation (chord test for every candidate pair, then routines 3 + 4) against the oracle as well
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(20, 4, lat, lon, eps=0.3)
+    ctx.set_option("eager_f2", 1)
+    try:
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(4), [-2, 2], intensity=pv)
+    finally:
+        ctx.set_option("eager_f2", 0)
+
+
 @two_scans
 def test_quarter_degree_parity(ctx):
     # BASELINE.json configs[2] grid (1440 x 721), both levels, all three indices; 2 steps keep the oracle in seconds

@@ -20,16 +20,19 @@ def sim():
     ctx.close()
 
 
+@pytest.mark.parametrize("eager", [0, 1], ids=["lazy_f2", "eager_f2"])
 @pytest.mark.parametrize("reverse", [0, 1])
-def test_full_parity_1deg_two_levels(sim, reverse):
+def test_full_parity_1deg_two_levels(sim, reverse, eager):
     lib, ctx = sim
     lib.lib.wb_hostsim_set_reverse(reverse)
+    ctx.set_option("eager_f2", eager)       # 1: chord test for every candidate pair instead of the lazy sweep
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(10, 3, lat, lon, eps=0.3)
     inten = synth.pv_field(10, 3, lat, lon, eps=0.0, seed=20241)
     got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(3), [-2, 2], intensity=inten)
     assert len(ref["streamers"]) > 5 and len(ref["overturnings"]) > 5 and len(ref["cutoffs"]) > 5
     assert got["band"] == (0, 0) and not got["status"].any()
+    ctx.set_option("eager_f2", 0)
 
 
 def test_demo_shaped_config0(sim):

@@ -1,22 +1,30 @@
 #!/bin/bash
-# One GPU session: parity tests, the bench line, rocprofv3 kernel stats and the two PMC passes (scratch under gpurun_out/).
+# One GPU session: parity tests, the bench line (default and one batch at a time), rocprofv3 kernel stats and the two PMC
+# passes; scratch under gpurun_out/$1 (summaries are copied to profiles/ by hand).
 set -u
 cd "$(dirname "$0")/.."
 R=$PWD
+O=gpurun_out/${1:-round}
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3) > gpurun_out/gpu_tests.txt
-timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
-timeout 300 python benchmarks/bench_spatial.py > gpurun_out/bench_spatial.json 2> gpurun_out/bench_spatial.err
+mkdir -p $O
+if [ "${2:-tests}" = "tests" ]; then (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > $O/gpu_tests.txt; fi
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python bench.py --streams 1 --cpu-sample 0 > $O/bench_s1.json 2> $O/bench_s1.err
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $R/gpurun_out/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $R/gpurun_out/pmc_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_spatial -- python3 $R/benchmarks/bench_spatial.py --reps 3 > $R/gpurun_out/prof_spatial.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_stats -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --streams 1 > $R/$O/prof_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_stats2 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 > $R/$O/prof_stats2.log 2>&1
+if [ "${3:-pmc}" = "pmc" ]; then
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --streams 1 > $R/$O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --streams 1 > $R/$O/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d $R/$O/pmc_sq -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --streams 1 > $R/$O/pmc_sq.log 2>&1
+fi
 cd $R
-python tools/profile_summary.py stats gpurun_out/prof_stats > gpurun_out/kernel_stats.csv 2>&1
-python tools/profile_summary.py pmc gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/hbm_traffic_pmc.txt 2>&1
-python tools/profile_summary.py stats gpurun_out/prof_spatial > gpurun_out/kernel_stats_spatial.csv 2>&1
+python tools/profile_summary.py stats $O/prof_stats > $O/kernel_stats_one_batch.csv 2>&1
+python tools/profile_summary.py stats $O/prof_stats2 > $O/kernel_stats.csv 2>&1
+if [ "${3:-pmc}" = "pmc" ]; then
+python tools/profile_summary.py pmc $O/pmc_fetch $O/pmc_write > $O/hbm_traffic_pmc.txt 2>&1
+python tools/profile_summary.py sq $O/pmc_sq > $O/sq_counters.txt 2>&1
+fi
 # keep only the summaries (the raw traces are large)
-rm -rf gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/prof_spatial
-cat gpurun_out/gpu_tests.txt; tail -c 3000 gpurun_out/bench.json
+rm -rf $O/prof_stats $O/prof_stats2 $O/pmc_fetch $O/pmc_write $O/pmc_sq
+cat $O/gpu_tests.txt 2>/dev/null; tail -c 600 $O/bench.json; echo; head -30 $O/kernel_stats_one_batch.csv

@@ -47,8 +47,24 @@ def pmc(dfetch, dwrite):
         print("%-64s%8d %16.0f %22.3f %16.0f" % (k[:60], calls, fv, 2.0 * fv * 1024 / 1e9, wv))
 
 
+def sq(d):
+    """per kernel: SQ counters summed over its dispatches; parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves waiting on memory
+    or a barrier), issue = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES"""
+    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+             "SQ_INSTS_VMEM", "SQ_INSTS_LDS"]
+    tabs = {n: counters(d, n) for n in names}
+    print("%-56s%6s %14s %8s %8s %12s %12s %12s %12s" % ("kernel", "calls", "wave_cycles", "parked", "issue", "valu", "salu", "vmem", "lds"))
+    for k, (calls, wc) in tabs["SQ_WAVE_CYCLES"].items():
+        g = lambda n: tabs[n].get(k, (0, 0.0))[1]
+        print("%-56s%6d %14.0f %8.3f %8.3f %12.0f %12.0f %12.0f %12.0f" % (
+            k[:54], calls, wc, g("SQ_WAIT_ANY") / max(wc, 1), g("SQ_ACTIVE_INST_ANY") / max(wc, 1), g("SQ_INSTS_VALU"),
+            g("SQ_INSTS_SALU"), g("SQ_INSTS_VMEM"), g("SQ_INSTS_LDS")))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3])

@@ -44,6 +44,7 @@ struct wb_ctx {
     // 1: scan as two kernels (capture + build, wb_scan.h).  Faster alone on the device (1.32 + 0.23 ms against 1.70 ms), not
     // faster with two batches in flight (the default way to run), hence off unless asked for (wb_set_option / WB_SCAN_SPLIT)
     int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) != 0) ? 1 : 0;
+    int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
@@ -521,7 +522,7 @@ static int phase1_summary(wb_batch* b) {
     sa.njobs = b->njobs; sa.cap_seg = b->cap_seg; sa.ncont = b->ncont; sa.c_len = b->c_len; sa.c_nux = b->c_nux;
     sa.c_closed = b->c_closed; sa.ctl = b->d_ctl;
     b->timer.begin(ctx, "summary");
-    WB_LAUNCH(wb_k_phase1_summary, b->njobs < 4096 ? b->njobs : 4096, 64, sa);
+    WB_LAUNCH(wb_k_phase1_summary, (b->njobs + 63) / 64 < 256 ? (b->njobs + 63) / 64 : 256, 64, sa);
     b->timer.end(ctx);
     size_t got = 0;
     int* h_nc = (int*)hmalloc(ctx, (size_t)(b->njobs + 1) * sizeof(int), &got);
@@ -1217,6 +1218,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.nalive = (int*)talloc(nsel_b * sizeof(int));
             st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
             st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
+            st.rowmx = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
             st.ev_ind = ev_ind; st.ev_n = ev_n; st.status = b->status;
             st.cap_pairs = cap_pairs;
             st.hash_size = next_pow2(2LL * cap_pairs);
@@ -1225,7 +1227,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.alive = (int*)talloc((size_t)nsel_b * cap_pairs * sizeof(int));
             st.hkey = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
             st.hval = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
-            if (!st.hval || !st.rowaux || !ev_ind || !st.bbx || !st.tbx || !d_lens || !st.item_tile) { release(); return 1; }
+            if (!st.hval || !st.rowaux || !st.rowmx || !ev_ind || !st.bbx || !st.tbx || !d_lens || !st.item_tile) { release(); return 1; }
             b->timer.begin(ctx, "streamer_lists");
             WB_LAUNCH(wb_k_sel_scan, 1, 1024, st, d_lens);
             WB_LAUNCH(wb_k_pair_items, nsel_b, 64, st);
@@ -1238,18 +1240,24 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_streamer_f1, nsel_b, 256, st);
-            WB_LAUNCH(wb_k_f2_items, 1, 1024, st);
             b->timer.end(ctx);
-            b->timer.begin(ctx, "streamer_f2");
-            {
+            if (ctx->eager_f2) {
+                // routine 2 for every candidate pair, then routines 3 + 4 on the survivors (option "eager_f2": the exhaustive
+                // formulation, kept as a cross-check of the lazy one)
+                b->timer.begin(ctx, "streamer_f2");
+                WB_LAUNCH(wb_k_f2_items, 1, 1024, st);
                 long long g2 = (long long)nsel_b * ((cap_pairs + WB_F2_THREADS - 1) / WB_F2_THREADS);
                 if (g2 > 16384) g2 = 16384;                         // persistent: the workgroups stride over the device-built list
                 WB_LAUNCH(wb_k_streamer_f2, g2, 256, st);
+                b->timer.end(ctx);
+                b->timer.begin(ctx, "streamer_f34");
+                WB_LAUNCH(wb_k_streamer_f34, nsel_b, 256, st);
+                b->timer.end(ctx);
+            } else {
+                b->timer.begin(ctx, "streamer_f234");
+                WB_LAUNCH(wb_k_streamer_f234, nsel_b, 256, st);
+                b->timer.end(ctx);
             }
-            b->timer.end(ctx);
-            b->timer.begin(ctx, "streamer_f34");
-            WB_LAUNCH(wb_k_streamer_f34, nsel_b, 256, st);
-            b->timer.end(ctx);
         }
         if (do_ot) side_join(ctx);
 
@@ -1657,6 +1665,7 @@ extern "C" float wb_last_op_ms(wb_ctx* ctx) { return ctx ? ctx->last_op_ms : 0.f
 extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "scan_split")) { ctx->scan_split = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "eager_f2")) { ctx->eager_f2 = value ? 1 : 0; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;
 }

@@ -252,6 +252,7 @@ struct WbStreamerArgs {
     unsigned long long* hval;  // [nsel][hash_size]
     int* rowmax;               // packed by point like `on`
     int* rowaux;
+    int* rowmx;
     int* ev_ind;               // [nsel][cap_ev][2]
     int* ev_n;                 // [nsel]
     uint32_t* status;          // [njobs]
@@ -711,7 +712,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
     int* aux = a.rowaux + a.poff[s];
     int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
     unsigned long long* best = a.hval + (size_t)s * a.hash_size;  // reused: per group best value / index
-    WB_SHARED(int, cnt, 2);
+    WB_SHARED(int, cnt, 4);
     const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
     int stage = a.stage[s];
     int nal = a.nalive[s];
@@ -787,8 +788,9 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
             lab[m] = (int)m;
         WB_END_PFOR
         for (int iter = 0; iter < M; ++iter) {
+            const int cf = 1 + (iter & 1);       // alternating slots: a slot is rewritten two barriers after its last read
             WB_SINGLE
-            cnt[1] = 0;
+            cnt[cf] = 0;
             WB_END_SINGLE
             WB_PFOR(pair, (int64_t)M * M)
                 const int m1 = (int)(pair / M), m2 = (int)(pair - (int64_t)m1 * M);
@@ -800,7 +802,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
                         const int l1 = lab[m1], l2 = lab[m2];
                         if (l1 != l2) {
                             wb_atomic_min(&lab[l1 > l2 ? l1 : l2], l1 < l2 ? l1 : l2);
-                            cnt[1] = 1;
+                            cnt[cf] = 1;
                         }
                     }
                 }
@@ -810,7 +812,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
                 while (lab[l] != l) l = lab[l];
                 lab[m] = l;
             WB_END_PFOR
-            if (!cnt[1]) break;
+            if (!cnt[cf]) break;
         }
         // per group: max of on[ind1 : ind2+1].sum()  (= pre[ind2] - pre[ind1-1]); ties -> lowest member
         WB_PFOR(m, M)
@@ -858,6 +860,217 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
         if (M > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
         a.stage[s] = stage;
         a.nalive[s] = nal;
+        WB_END_SINGLE
+    }
+}
+
+// routines 2, 3 and 4 in one kernel, routine 2 evaluated LAZILY.
+//   check_overlapping (:202-222) keeps, of the pairs that passed check_intersections (:185-200), the maximal [ind1, ind2]
+//   intervals: sweeping the rows ind1 in ascending order with M = the largest ind2 kept so far, a row contributes its
+//   largest ind2 > M whose chord passes routine 2 -- and nothing else of that row, and no pair with ind2 <= M, matters,
+//   whatever routine 2 would say about them.  So the chord test (the expensive part: chord against every contour segment)
+//   runs only for the candidates the sweep actually asks about, in descending ind2 per row until one passes: a few dozen
+//   tests per contour instead of thousands, each done by the whole workgroup over the contour held in LDS.
+//   The reference's loop control (`while len(df_bp.index) > 1`, :261-264) is kept: routine 2 only runs when more than one
+//   pair survived routine 1 (wb_k_streamer_f1's bookkeeping); routines 3 and 4 are the identity on fewer than two pairs,
+//   so composing them unconditionally gives the same rows.
+//   check_groups (:224-251): label propagation over the intersecting chords, the longest member of a group stays.
+#ifndef WB_F234_LPTS
+#define WB_F234_LPTS 8192          // contour points held in LDS for the chord tests (longer contours read global memory)
+#endif
+WB_KERNEL(wb_k_streamer_f234, WbStreamerArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.ctl->nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* gpts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    const double* pre = a.pre + a.poff[s];
+    const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    const int* alive = a.alive + (size_t)s * a.cap_pairs;
+    int* rowcnt = a.rowmax + a.poff[s];   // [N] alive candidates of a row
+    int* rowoff = a.rowaux + a.poff[s];   // [N] first entry of the row in jlist
+    int* rmax = a.rowmx + a.poff[s];      // [N] largest ind2 among the row's alive candidates
+    int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
+    unsigned long long* best = a.hval + (size_t)s * a.hash_size;  // routine 4: per group best value / index
+    const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
+    int* jlist = (int*)(a.hkey + (size_t)s * a.hash_size);          // [P] ind2 of the alive candidates, grouped by row
+    int* mi = jlist + P;                                             // [M] ind1 of survivor m
+    int* mj = mi + (P < N ? P : N) + 1;                              // [M] ind2
+    int* lab = mj + (P < N ? P : N) + 1;                             // [M] group label
+    WB_SHARED(uint32_t, lpts, WB_F234_LPTS);
+    WB_SHARED(int, sh, 10);              // [0] M, [1] next row, [2] survivors, [3] row found, [4] candidate, [5..6] hit flag, [7..8] change flag
+                                         // (flags alternate between two slots: a slot is rewritten two barriers after its last read)
+    const int stage = a.stage[s];
+    const int nal = a.nalive[s];
+    const bool in_lds = N <= WB_F234_LPTS;
+    const uint32_t* pts = in_lds ? lpts : gpts;
+    if (in_lds) {
+        WB_PFOR(i, N)
+            lpts[i] = gpts[i];
+        WB_END_PFOR
+    }
+    WB_SINGLE
+    sh[0] = -1; sh[1] = 0; sh[2] = 0;
+    WB_END_SINGLE
+    if (stage == 1 && nal > 1) {
+        // candidates by row (counting sort on ind1)
+        WB_PFOR(i, N)
+            rowcnt[i] = 0;
+            rmax[i] = -1;
+        WB_END_PFOR
+        WB_PFOR(p, P)
+            if (alive[p]) wb_atomic_add(&rowcnt[(int)(pairs[p] >> 32)], 1);
+        WB_END_PFOR
+        WB_PFOR(i, N)
+            rowoff[i] = rowcnt[i];
+        WB_END_PFOR
+        wb_block_scan_excl(rowoff, N);
+        WB_PFOR(i, N)
+            rowcnt[i] = 0;
+        WB_END_PFOR
+        WB_PFOR(p, P)
+            if (alive[p]) {
+                const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
+                jlist[rowoff[i] + wb_atomic_add(&rowcnt[i], 1)] = j;
+                wb_atomic_max(&rmax[i], j);
+            }
+        WB_END_PFOR
+        // the sweep
+        for (;;) {
+            WB_SINGLE
+            sh[3] = 0x7FFFFFFF;
+            WB_END_SINGLE
+            {
+                const int M = sh[0], cur = sh[1];
+                WB_PFOR(t, WB_NT)
+                    for (int i = cur + (int)t; i < N; i += WB_NT)
+                        if (rmax[i] > M) { wb_atomic_min(&sh[3], i); break; }
+                WB_END_PFOR
+            }
+            const int row = sh[3];
+            if (row == 0x7FFFFFFF) break;
+            int bound = 0x7FFFFFFF;
+            for (int ntest = 0;; ++ntest) {
+                const int hf = 5 + (ntest & 1);
+                // the row's largest candidate in (M, bound)
+                WB_SINGLE
+                int jn = -1;
+                const int M = sh[0];
+                for (int q = rowoff[row]; q < rowoff[row] + rowcnt[row]; ++q) {
+                    const int j = jlist[q];
+                    if (j > M && j < bound && j > jn) jn = j;
+                }
+                sh[4] = jn;
+                sh[hf] = 0;
+                WB_END_SINGLE
+                const int jn = sh[4];
+                if (jn < 0) break;
+                // routine 2 for this one chord: does the open chord meet the contour's interior? (all lanes, all segments)
+                const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]), qx = wb_pt_x(pts[jn]), qy = wb_pt_y(pts[jn]);
+                const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                WB_PFOR(m, N - 1)
+                    const uint32_t pa = pts[m], pb = pts[m + 1];
+                    const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                    // a segment whose box misses the chord's box cannot meet the chord
+                    if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
+                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) sh[hf] = 1;
+                WB_END_PFOR
+                if (!sh[hf]) {                             // passes routine 2: the row's survivor
+                    WB_SINGLE
+                    mi[sh[2]] = row;
+                    mj[sh[2]] = jn;
+                    sh[2] += 1;
+                    sh[0] = jn;
+                    WB_END_SINGLE
+                    break;
+                }
+                bound = jn;
+            }
+            WB_SINGLE
+            sh[1] = row + 1;
+            WB_END_SINGLE
+        }
+    } else {
+        // routine 2 never ran (`while len(df_bp.index) > 1`): at most one pair is left
+        WB_PFOR(p, P)
+            if (alive[p] == 1) {
+                mi[0] = (int)(pairs[p] >> 32);
+                mj[0] = (int)(pairs[p] & 0xFFFFFFFFull);
+                sh[2] = 1;
+            }
+        WB_END_PFOR
+    }
+    const int M = sh[2];
+
+    if (M > 1) {   // routine 4: group chords that intersect; keep the longest of each group
+        int* aux = rowoff;                                 // [M <= N] scratch for the group scan
+        WB_PFOR(m, M)
+            lab[m] = (int)m;
+        WB_END_PFOR
+        for (int iter = 0; iter < M; ++iter) {
+            const int cf = 7 + (iter & 1);
+            WB_SINGLE
+            sh[cf] = 0;
+            WB_END_SINGLE
+            WB_PFOR(pair, (int64_t)M * M)
+                const int m1 = (int)(pair / M), m2 = (int)(pair - (int64_t)m1 * M);
+                if (m1 < m2 && lab[m1] != lab[m2]) {
+                    const uint32_t a1 = pts[mi[m1]], b1 = pts[mj[m1]], a2 = pts[mi[m2]], b2 = pts[mj[m2]];
+                    if (wb_segments_intersect(wb_pt_x(a1), wb_pt_y(a1), wb_pt_x(b1), wb_pt_y(b1), wb_pt_x(a2), wb_pt_y(a2),
+                                              wb_pt_x(b2), wb_pt_y(b2))) {
+                        // hook the larger root under the smaller one (labels are roots after the shortcut pass)
+                        const int l1 = lab[m1], l2 = lab[m2];
+                        if (l1 != l2) {
+                            wb_atomic_min(&lab[l1 > l2 ? l1 : l2], l1 < l2 ? l1 : l2);
+                            sh[cf] = 1;
+                        }
+                    }
+                }
+            WB_END_PFOR
+            WB_PFOR(m, M)   // shortcut labels to their root
+                int l = lab[m];
+                while (lab[l] != l) l = lab[l];
+                lab[m] = l;
+            WB_END_PFOR
+            if (!sh[cf]) break;
+        }
+        // per group: max of on[ind1 : ind2+1].sum()  (= pre[ind2] - pre[ind1-1]); ties -> lowest member
+        WB_PFOR(m, M)
+            best[m] = 0ull;
+            best[M + m] = WB_HEMPTY;
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
+            unsigned long long bits;
+            memcpy(&bits, &v, 8);
+            wb_atomic_max(&best[lab[m]], bits);
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
+            unsigned long long bits;
+            memcpy(&bits, &v, 8);
+            if (bits == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
+        WB_END_PFOR
+        const int Gn = wb_block_scan_excl(aux, M);
+        WB_PFOR(m, M)
+            if (lab[m] == (int)m && aux[m] < a.cap_ev) {
+                const int w = (int)best[M + m];
+                ev[2 * aux[m] + 0] = mi[w];
+                ev[2 * aux[m] + 1] = mj[w];
+            }
+        WB_END_PFOR
+        WB_SINGLE
+        a.ev_n[s] = Gn < a.cap_ev ? Gn : a.cap_ev;
+        if (Gn > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+        WB_END_SINGLE
+    } else {
+        WB_SINGLE
+        if (M == 1) { ev[0] = mi[0]; ev[1] = mj[0]; }
+        a.ev_n[s] = M;
         WB_END_SINGLE
     }
 }

@@ -856,42 +856,42 @@ struct WbSummaryArgs {
     WbCtl* ctl;
 };
 WB_KERNEL(wb_k_phase1_summary, WbSummaryArgs a) {
-    WB_SHARED(long long, acc, 8);
-    for (int job = WB_BLOCK_ID; job < a.njobs; job += WB_GRID_DIM) {
-        const size_t jb = (size_t)job * a.cap_seg;
-        const int C = a.ncont[job], mx = a.ctl->max_nux;
-        WB_SINGLE
-        for (int k = 0; k < 8; ++k) acc[k] = 0;
-        WB_END_SINGLE
-        WB_PFOR(k, C)
-            const int len = a.c_len[jb + k];
-            wb_atomic_add((unsigned long long*)&acc[0], 1ull);
-            wb_atomic_add((unsigned long long*)&acc[1], (unsigned long long)len);
-            if (a.c_nux[jb + k] == mx) {
-                wb_atomic_add((unsigned long long*)&acc[2], 1ull);
-                wb_atomic_add((unsigned long long*)&acc[3], (unsigned long long)len);
-                const int tiles = (len - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
-                wb_atomic_add((unsigned long long*)&acc[4], (unsigned long long)((tiles + WB_PAIR_TPB - 1) / WB_PAIR_TPB));
-            }
-            if (a.c_closed[jb + k]) {
-                wb_atomic_add((unsigned long long*)&acc[5], 1ull);
-                wb_atomic_add((unsigned long long*)&acc[6], (unsigned long long)len);
-            }
-        WB_END_PFOR
-        WB_SINGLE
-        if (acc[0]) {
-            wb_atomic_add(&a.ctl->ncont_total, (int)acc[0]);
-            wb_atomic_add((unsigned long long*)&a.ctl->npts_total, (unsigned long long)acc[1]);
-            if (acc[2]) {
-                wb_atomic_add(&a.ctl->nsel_max, (int)acc[2]);
-                wb_atomic_add((unsigned long long*)&a.ctl->npt_sel_max, (unsigned long long)acc[3]);
-                wb_atomic_add(&a.ctl->pair_items_max, (int)acc[4]);
-            }
-            if (acc[5]) {
-                wb_atomic_add(&a.ctl->nclosed, (int)acc[5]);
-                wb_atomic_add((unsigned long long*)&a.ctl->npt_closed, (unsigned long long)acc[6]);
+    // a lane per job, sums in registers, one LDS atomic per lane and counter, one global atomic per workgroup and counter
+    WB_SHARED(unsigned long long, acc, 8);
+    WB_SINGLE
+    for (int k = 0; k < 8; ++k) acc[k] = 0ull;
+    WB_END_SINGLE
+    const int mx = a.ctl->max_nux;
+    WB_PFOR(t, WB_NT)
+        unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int job = WB_BLOCK_ID * WB_NT + (int)t; job < a.njobs; job += WB_GRID_DIM * WB_NT) {
+            const size_t jb = (size_t)job * a.cap_seg;
+            const int C = a.ncont[job];
+            for (int k = 0; k < C; ++k) {
+                const int len = a.c_len[jb + k];
+                v[0] += 1; v[1] += (unsigned long long)len;
+                if (a.c_nux[jb + k] == mx) {
+                    const int tiles = (len - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+                    v[2] += 1; v[3] += (unsigned long long)len; v[4] += (unsigned long long)((tiles + WB_PAIR_TPB - 1) / WB_PAIR_TPB);
+                }
+                if (a.c_closed[jb + k]) { v[5] += 1; v[6] += (unsigned long long)len; }
             }
         }
-        WB_END_SINGLE
+        for (int k = 0; k < 7; ++k) if (v[k]) wb_atomic_add(&acc[k], v[k]);
+    WB_END_PFOR
+    WB_SINGLE
+    if (acc[0]) {
+        wb_atomic_add(&a.ctl->ncont_total, (int)acc[0]);
+        wb_atomic_add((unsigned long long*)&a.ctl->npts_total, acc[1]);
+        if (acc[2]) {
+            wb_atomic_add(&a.ctl->nsel_max, (int)acc[2]);
+            wb_atomic_add((unsigned long long*)&a.ctl->npt_sel_max, acc[3]);
+            wb_atomic_add(&a.ctl->pair_items_max, (int)acc[4]);
+        }
+        if (acc[5]) {
+            wb_atomic_add(&a.ctl->nclosed, (int)acc[5]);
+            wb_atomic_add((unsigned long long*)&a.ctl->npt_closed, acc[6]);
+        }
     }
+    WB_END_SINGLE
 }
