@@ -1255,7 +1255,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
-                WB_LAUNCH(wb_k_streamer_f234, nsel_b, 256, st);
+                WB_LAUNCH(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, st);
                 b->timer.end(ctx);
             }
         }
@@ -1369,6 +1369,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     }
     b->sel_job = b->sel_cont = b->cut_job = b->cut_cont = nullptr;
     b->nsel = fin.nsel; b->ncut = fin.ncut;
+    if (getenv("WB_DEBUG_STAMPS")) {
+        fprintf(stderr, "[wb] stamps (ms of workgroup time, 100 MHz clock):");
+        for (int q = 0; q < 24; ++q) if (fin.dbg[q]) fprintf(stderr, " %d:%.2f", q, (double)fin.dbg[q] * 1e-5);
+        fprintf(stderr, "\n");
+    }
     b->band[0] = fin.band[0]; b->band[1] = fin.band[1];
     b->pair_stats[0] = fin.point_pairs; b->pair_stats[1] = fin.cand_pairs; b->pair_stats[2] = fin.evaluated_pairs;
     for (int q = 0; q < 3; ++q) b->com_rechecks[q] = fin.com_rechecks[q];

@@ -876,9 +876,12 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 //   so composing them unconditionally gives the same rows.
 //   check_groups (:224-251): label propagation over the intersecting chords, the longest member of a group stays.
 #ifndef WB_F234_LPTS
-#define WB_F234_LPTS 8192          // contour points held in LDS for the chord tests (longer contours read global memory)
+#define WB_F234_LPTS 4096          // contour points (and per-row maxima) held in LDS; longer contours work in global memory
 #endif
-WB_KERNEL(wb_k_streamer_f234, WbStreamerArgs a) {
+#define WB_F234_THREADS 512
+#define WB_F234_CAND 1024          // candidates of one row collected after its first chord failed
+#define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
+WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
     if (s >= a.ctl->nsel) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
@@ -888,109 +891,190 @@ WB_KERNEL(wb_k_streamer_f234, WbStreamerArgs a) {
     const double* pre = a.pre + a.poff[s];
     const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     const int* alive = a.alive + (size_t)s * a.cap_pairs;
-    int* rowcnt = a.rowmax + a.poff[s];   // [N] alive candidates of a row
-    int* rowoff = a.rowaux + a.poff[s];   // [N] first entry of the row in jlist
-    int* rmax = a.rowmx + a.poff[s];      // [N] largest ind2 among the row's alive candidates
     int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
     unsigned long long* best = a.hval + (size_t)s * a.hash_size;  // routine 4: per group best value / index
     const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
-    int* jlist = (int*)(a.hkey + (size_t)s * a.hash_size);          // [P] ind2 of the alive candidates, grouped by row
-    int* mi = jlist + P;                                             // [M] ind1 of survivor m
+    int* mi = (int*)(a.hkey + (size_t)s * a.hash_size);             // [M] ind1 of survivor m (M <= min(P, N))
     int* mj = mi + (P < N ? P : N) + 1;                              // [M] ind2
     int* lab = mj + (P < N ? P : N) + 1;                             // [M] group label
+    int* aux = lab + (P < N ? P : N) + 1;                            // [M] scratch of the group scan
     WB_SHARED(uint32_t, lpts, WB_F234_LPTS);
-    WB_SHARED(int, sh, 10);              // [0] M, [1] next row, [2] survivors, [3] row found, [4] candidate, [5..6] hit flag, [7..8] change flag
-                                         // (flags alternate between two slots: a slot is rewritten two barriers after its last read)
+    WB_SHARED(int, lrmax, WB_F234_LPTS);         // per row: largest ind2 among its alive candidates
+    WB_SHARED(uint32_t, nebits, WB_F234_LPTS / 32);   // rows that still hold a candidate above M
+    WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
+    WB_SHARED(int, csort, WB_F234_CAND);
+    WB_SHARED(int, hitf, WB_F234_BATCH);
+    WB_SHARED(int, sh, 10);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate
+                                         // (words alternate between two slots: a slot is rewritten two barriers after its last read)
     const int stage = a.stage[s];
     const int nal = a.nalive[s];
     const bool in_lds = N <= WB_F234_LPTS;
     const uint32_t* pts = in_lds ? lpts : gpts;
-    if (in_lds) {
-        WB_PFOR(i, N)
-            lpts[i] = gpts[i];
-        WB_END_PFOR
-    }
+    int* rmax = in_lds ? lrmax : a.rowmx + a.poff[s];
+    const int nw = (N + 31) >> 5;
+    WB_STAMP_BEGIN
+    WB_PFOR(i, N)
+        if (in_lds) lpts[i] = gpts[i];
+        rmax[i] = -1;
+        if (in_lds && (i & 31) == 0) nebits[i >> 5] = 0u;
+    WB_END_PFOR
     WB_SINGLE
-    sh[0] = -1; sh[1] = 0; sh[2] = 0;
+    sh[2] = 0;
+    sh[3] = 0x7FFFFFFF; sh[4] = 0x7FFFFFFF;     // search results of even / odd iterations
+    sh[5] = 0; sh[6] = 0;                       // hit flags of even / odd chord tests
     WB_END_SINGLE
+    WB_STAMP(a.ctl, 0);
     if (stage == 1 && nal > 1) {
-        // candidates by row (counting sort on ind1)
-        WB_PFOR(i, N)
-            rowcnt[i] = 0;
-            rmax[i] = -1;
-        WB_END_PFOR
-        WB_PFOR(p, P)
-            if (alive[p]) wb_atomic_add(&rowcnt[(int)(pairs[p] >> 32)], 1);
-        WB_END_PFOR
-        WB_PFOR(i, N)
-            rowoff[i] = rowcnt[i];
-        WB_END_PFOR
-        wb_block_scan_excl(rowoff, N);
-        WB_PFOR(i, N)
-            rowcnt[i] = 0;
-        WB_END_PFOR
+        // per row: the largest ind2 among the alive candidates; rows that hold one
         WB_PFOR(p, P)
             if (alive[p]) {
                 const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
-                jlist[rowoff[i] + wb_atomic_add(&rowcnt[i], 1)] = j;
                 wb_atomic_max(&rmax[i], j);
+                if (in_lds) wb_atomic_or(&nebits[i >> 5], 1u << (i & 31));
             }
         WB_END_PFOR
-        // the sweep
-        for (;;) {
-            WB_SINGLE
-            sh[3] = 0x7FFFFFFF;
-            WB_END_SINGLE
-            {
-                const int M = sh[0], cur = sh[1];
+        WB_STAMP(a.ctl, 1);
+        // The sweep.  M (largest ind2 kept so far), the next row and the survivor count are the same in every lane and
+        // live in registers; the two words a step communicates through (row found, chord hit) alternate between two
+        // slots, and the slot of the NEXT step is reset after this step's first barrier -- two barriers per step.
+        int M = -1, cur = 0, nsurv = 0, ntest = 0;
+        for (int step = 0;; ++step) {
+            const int fs = 3 + (step & 1);
+            if (in_lds) {
+                // a lane per bitmap word: rows whose largest candidate is not above M can never matter again (M only
+                // grows) and leave the bitmap; the lowest remaining row at or after `cur` is the next one to handle
+                WB_PFOR(w, nw)
+                    uint32_t bits = nebits[w];
+                    uint32_t keep = bits;
+                    while (bits) {
+                        const int bit = wb_ctz32(bits);
+                        bits &= bits - 1u;
+                        const int i = ((int)w << 5) + bit;
+                        if (i < cur || rmax[i] <= M) keep &= ~(1u << bit);
+                        else { wb_atomic_min(&sh[fs], i); break; }
+                    }
+                    nebits[w] = keep;
+                WB_END_PFOR
+            } else {
                 WB_PFOR(t, WB_NT)
                     for (int i = cur + (int)t; i < N; i += WB_NT)
-                        if (rmax[i] > M) { wb_atomic_min(&sh[3], i); break; }
+                        if (rmax[i] > M) { wb_atomic_min(&sh[fs], i); break; }
                 WB_END_PFOR
             }
-            const int row = sh[3];
+            const int row = sh[fs];
+            WB_STAMP(a.ctl, 4);
             if (row == 0x7FFFFFFF) break;
+            int jn = rmax[row];                 // the row's largest candidate first
             int bound = 0x7FFFFFFF;
-            for (int ntest = 0;; ++ntest) {
-                const int hf = 5 + (ntest & 1);
-                // the row's largest candidate in (M, bound)
-                WB_SINGLE
-                int jn = -1;
-                const int M = sh[0];
-                for (int q = rowoff[row]; q < rowoff[row] + rowcnt[row]; ++q) {
-                    const int j = jlist[q];
-                    if (j > M && j < bound && j > jn) jn = j;
-                }
-                sh[4] = jn;
-                sh[hf] = 0;
-                WB_END_SINGLE
-                const int jn = sh[4];
-                if (jn < 0) break;
+            for (;;) {
                 // routine 2 for this one chord: does the open chord meet the contour's interior? (all lanes, all segments)
+                const int hf = 5 + (ntest & 1);
+                ++ntest;
                 const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]), qx = wb_pt_x(pts[jn]), qy = wb_pt_y(pts[jn]);
                 const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
                 WB_PFOR(m, N - 1)
+                    if (m == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; }   // the next step's / test's slots
                     const uint32_t pa = pts[m], pb = pts[m + 1];
                     const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
                     // a segment whose box misses the chord's box cannot meet the chord
                     if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
                         if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) sh[hf] = 1;
                 WB_END_PFOR
+                WB_STAMP(a.ctl, 6);
                 if (!sh[hf]) {                             // passes routine 2: the row's survivor
-                    WB_SINGLE
-                    mi[sh[2]] = row;
-                    mj[sh[2]] = jn;
-                    sh[2] += 1;
-                    sh[0] = jn;
-                    WB_END_SINGLE
+                    if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
+                    ++nsurv;
+                    M = jn;
                     break;
                 }
+                // The chord meets the contour.  The row's other candidates in (M, jn) are collected once, sorted in descending
+                // order and tested WB_F234_BATCH at a time (every lane takes a few contour segments against all chords of the
+                // batch); the first one in that order that passes is the row's survivor.
                 bound = jn;
+                bool done = false;
+                while (!done) {
+                    WB_SINGLE
+                    sh[9] = 0;
+                    WB_END_SINGLE
+                    WB_PFOR(p, P)
+                        if (alive[p] && (int)(pairs[p] >> 32) == row) {
+                            const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                            if (j > M && j < bound) {
+                                const int slot = wb_atomic_add(&sh[9], 1);
+                                if (slot < WB_F234_CAND) cand[slot] = j;
+                            }
+                        }
+                    WB_END_PFOR
+                    WB_STAMP(a.ctl, 5);
+                    const int found = sh[9];
+                    if (found == 0) { done = true; break; }
+                    int K = found < WB_F234_CAND ? found : WB_F234_CAND;
+                    if (found > WB_F234_CAND) {
+                        // more candidates than the list holds: keep only those above the list's K-th largest is not possible
+                        // without the full set -- take the single largest instead (one chord per round)
+                        WB_SINGLE
+                        sh[9] = -1;
+                        WB_END_SINGLE
+                        WB_PFOR(p, P)
+                            if (alive[p] && (int)(pairs[p] >> 32) == row) {
+                                const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                                if (j > M && j < bound) wb_atomic_max(&sh[9], j);
+                            }
+                        WB_END_PFOR
+                        K = 1;
+                        WB_SINGLE
+                        csort[0] = sh[9];
+                        WB_END_SINGLE
+                    } else {
+                        WB_PFOR(t, K)                             // rank sort, descending (the ind2 of a row are distinct)
+                            const int v = cand[t];
+                            int rk = 0;
+                            for (int u = 0; u < K; ++u) rk += cand[u] > v ? 1 : 0;
+                            csort[rk] = v;
+                        WB_END_PFOR
+                    }
+                    for (int b0 = 0; b0 < K && !done; b0 += WB_F234_BATCH) {
+                        const int nb = K - b0 < WB_F234_BATCH ? K - b0 : WB_F234_BATCH;
+                        WB_PFOR(c, nb)
+                            hitf[c] = 0;
+                        WB_END_PFOR
+                        const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]);
+                        WB_PFOR(m, N - 1)
+                            const uint32_t pa = pts[m], pb = pts[m + 1];
+                            const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                            for (int c = 0; c < nb; ++c) {
+                                const uint32_t pq = pts[csort[b0 + c]];
+                                const int qx = wb_pt_x(pq), qy = wb_pt_y(pq);
+                                const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                                if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
+                                    if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) hitf[c] = 1;
+                            }
+                        WB_END_PFOR
+                        WB_STAMP(a.ctl, 6);
+                        for (int c = 0; c < nb; ++c) {
+                            if (!hitf[c]) {                        // the largest candidate that passes routine 2
+                                jn = csort[b0 + c];
+                                if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
+                                ++nsurv;
+                                M = jn;
+                                done = true;
+                                break;
+                            }
+                        }
+                        WB_SYNC();                                 // hitf is read by every lane before the next batch clears it
+                    }
+                    if (!done) {
+                        if (found > WB_F234_CAND) bound = csort[0];   // one chord was tested: the next round looks below it
+                        else done = true;                              // every candidate of the row failed
+                    }
+                }
+                break;
             }
-            WB_SINGLE
-            sh[1] = row + 1;
-            WB_END_SINGLE
+            cur = row + 1;
         }
+        WB_SINGLE
+        sh[2] = nsurv;
+        WB_END_SINGLE
     } else {
         // routine 2 never ran (`while len(df_bp.index) > 1`): at most one pair is left
         WB_PFOR(p, P)
@@ -1002,9 +1086,9 @@ WB_KERNEL(wb_k_streamer_f234, WbStreamerArgs a) {
         WB_END_PFOR
     }
     const int M = sh[2];
+    WB_STAMP(a.ctl, 7);
 
     if (M > 1) {   // routine 4: group chords that intersect; keep the longest of each group
-        int* aux = rowoff;                                 // [M <= N] scratch for the group scan
         WB_PFOR(m, M)
             lab[m] = (int)m;
         WB_END_PFOR
@@ -1073,6 +1157,8 @@ WB_KERNEL(wb_k_streamer_f234, WbStreamerArgs a) {
         a.ev_n[s] = M;
         WB_END_SINGLE
     }
+    WB_STAMP(a.ctl, 8);
+    WB_STAMP_FLUSH(a.ctl);
 }
 
 // ------------------------------------------------------------------------------------------------

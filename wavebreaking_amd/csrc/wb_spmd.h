@@ -41,6 +41,7 @@ template <class T> static inline T wb_atomic_max(T* p, T v) { T o = *p; if (v > 
 template <class T> static inline T wb_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T wb_atomic_cas(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline int wb_popc32(uint32_t v) { return __builtin_popcount(v); }
+static inline int wb_ctz32(uint32_t v) { return __builtin_ctz(v); }
 static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
 // base[idx] += val (no return value); on the GPU lanes of a wave that hit the same idx are combined first
 static inline void wb_atomic_add_agg(int* base, int idx, int val) { base[idx] += val; }
@@ -89,6 +90,7 @@ template <class T> __device__ inline T wb_atomic_max(T* p, T v) { return atomicM
 template <class T> __device__ inline T wb_atomic_or(T* p, T v) { return atomicOr(p, v); }
 template <class T> __device__ inline T wb_atomic_cas(T* p, T cmp, T v) { return atomicCAS(p, cmp, v); }
 __device__ inline int wb_popc32(uint32_t v) { return __popc(v); }
+__device__ inline int wb_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
 __device__ inline int wb_popc64(uint64_t v) { return __popcll(v); }
 // base[idx] += val without return value.  Many lanes of a wave usually target the same idx (all points of one
 // long contour): they are summed inside the wave first, one atomic per distinct idx (atomics on one address
