@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 4)),
                     help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-intensity", action="store_true")
-    ap.add_argument("--scan-split", type=int, default=0, help="1: two-kernel scan (capture + build)")
+    ap.add_argument("--scan-split", type=int, default=int(os.environ.get("WB_BENCH_SCAN_SPLIT", 1)),
+                    help="1: streaming scan (patch capture) + list build kernel; 0: single classify-and-emit kernel")
+    ap.add_argument("--scan-variant", type=int, default=int(os.environ.get("WB_BENCH_SCAN_VARIANT", 1)),
+                    help="streaming scan: ring depth x waves per SIMD (0: 8x6, 1: 10x5, 2: 13x4, 3: 6x8)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WB_BENCH_STREAMS", 2)),
                     help="batches in flight per GPU (contexts = HIP streams + host threads); 1 = strictly one after the other")
     return ap.parse_args()
@@ -76,6 +79,7 @@ def main():
     ctx = pipe.contexts[0]
     for c in pipe.contexts:
         c.set_option("scan_split", a.scan_split)
+        c.set_option("scan_variant", a.scan_variant)
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
     levels = [-2.0, 2.0]
@@ -186,7 +190,7 @@ def main():
                                    % (nt, "off" if a.no_intensity else "on"),
                        "nt_per_gpu": nt, "grid": [nlat, nlon], "levels": levels, "eps": a.eps,
                        "parallelism": "time-sharded x%d, %d batches in flight per GPU" % (world, pipe.depth)},
-            "roofline": {"bound": "hbm", "kernel": "wb_k_scan_capture<float>" if a.scan_split else "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "wb_k_scan_stream<float>" if a.scan_split else "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(nt),
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
                          # the same kernel with nothing else on the device (one pass before the warm-up); in the timed

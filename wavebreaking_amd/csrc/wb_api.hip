@@ -18,6 +18,7 @@
 #include "wb_indices.h"
 #include "wb_props.h"
 #include "wb_scan.h"
+#include "wb_stream.h"
 #include "wb_trace.h"
 
 #if defined(WB_HOSTSIM)
@@ -41,9 +42,11 @@ struct wb_ctx {
     // faults and zero-fill per pass
     std::multimap<size_t, void*> hpool;
     float last_op_ms = 0.f;
-    // 1: scan as two kernels (capture + build, wb_scan.h).  Faster alone on the device (1.32 + 0.23 ms against 1.70 ms), not
-    // faster with two batches in flight (the default way to run), hence off unless asked for (wb_set_option / WB_SCAN_SPLIT)
-    int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) != 0) ? 1 : 0;
+    // 1 (default): scan as two kernels -- the streaming patch capture (wb_stream.h: 1.20 ms = 5.1 TB/s for 1460 steps of
+    // 1440 x 721 f32) + the list build (0.24 ms); 0: the single classify-and-emit kernel wb_k_scan (1.5-1.7 ms)
+    int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) == 0) ? 0 : 1;
+    int scan_debug = 0;
+    int scan_variant = 1;                     // streaming scan: ring depth x waves per SIMD (0: 8 x 6, 1: 10 x 5, 2: 13 x 4, 3: 6 x 8)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
@@ -615,22 +618,49 @@ static int run_phase1(wb_batch* b) {
             // two kernels (wb_scan.h): the streaming kernel captures the patches that hold a crossing, the build
             // kernel turns them into the per-level segment lists
             const long long items = (long long)p.nt * b->nwork_strips;
+            // one workgroup per (time step, row band) item (a wave per strip), persistent; ring depth / waves per SIMD by option
+            const int variant = ctx->scan_variant;
+            const int wps = !(p.dtype == 0 && vec) ? 4 : (variant == 1 ? 5 : (variant == 2 ? 4 : (variant == 3 ? 8 : 6)));
+            int wg_per_cu = (wps * 4) / b->nwork_strips;
+            if (wg_per_cu < 1) wg_per_cu = 1;
+            const long long slots = (long long)ncu * wg_per_cu;
+            // bands: about six work items per resident workgroup, so that the last round of the persistent grid is nearly full
+            int nbands = (int)((6 * slots + p.nt - 1) / p.nt);
+            if (nbands < 1) nbands = 1;
+            if (nbands > 8) nbands = 8;
+            if (nbands > nlat - 1) nbands = nlat - 1;
+            sa.band_rows = (nlat - 1 + nbands - 1) / nbands;
+            sa.nbands = (nlat - 1 + sa.band_rows - 1) / sa.band_rows;
             sa.cap_rec = caps;
-            sa.cap_k = balloc<uint32_t>(b, (size_t)items * caps);
-            sa.cap_v = balloc<unsigned char>(b, (size_t)items * caps * 10 * esz);
-            sa.cap_n = balloc<int>(b, (size_t)items);
+            sa.debug = ctx->scan_debug;
+            const long long lists = items * sa.nbands;
+            sa.cap_k = balloc<uint32_t>(b, (size_t)lists * caps);
+            sa.cap_v = balloc<unsigned char>(b, (size_t)lists * caps * 10 * esz);
+            sa.cap_n = balloc<int>(b, (size_t)lists);
             if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
             b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
-            long long mwg = (items + 3) / 4;
-            if (mwg > (long long)ncu * 8) mwg = (long long)ncu * 8;
-            const dim3 mgrid((unsigned)mwg), bgrid((unsigned)items);
-#define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan_capture<T, V, N>), mgrid, block, 0, ctx->stream, sa)
+            const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz);   // a patch buffer per wave
+            long long mwg = slots;
+            if (mwg > (long long)p.nt * sa.nbands) mwg = (long long)p.nt * sa.nbands;
+            const dim3 mgrid((unsigned)mwg), sblock(64 * b->nwork_strips), bgrid((unsigned)items);
+#define WB_STREAM_F32(N) \
+            switch (variant) { \
+                case 1: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 10, 5>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 2: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 13, 4>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 3: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 6, 8>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                default: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6>), mgrid, sblock, slds, ctx->stream, sa); break; \
+            }
+#define WB_STREAM_ANY(T, V, N) hipLaunchKernelGGL((wb_k_scan_stream<T, V, N, 6, 4>), mgrid, sblock, slds, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
-            switch (p.nlevels) { case 1: WB_SCAN_LAUNCH(T, V, 1); break; case 2: WB_SCAN_LAUNCH(T, V, 2); break; \
-                                 case 3: WB_SCAN_LAUNCH(T, V, 3); break; default: WB_SCAN_LAUNCH(T, V, 4); break; }
-            if (p.dtype == 0) { if (vec) { WB_SCAN_N(float, true) } else { WB_SCAN_N(float, false) } }
+            switch (p.nlevels) { case 1: WB_STREAM_ANY(T, V, 1); break; case 2: WB_STREAM_ANY(T, V, 2); break; \
+                                 case 3: WB_STREAM_ANY(T, V, 3); break; default: WB_STREAM_ANY(T, V, 4); break; }
+            if (p.dtype == 0 && vec) {
+                switch (p.nlevels) { case 1: WB_STREAM_F32(1); break; case 2: WB_STREAM_F32(2); break;
+                                     case 3: WB_STREAM_F32(3); break; default: WB_STREAM_F32(4); break; }
+            } else if (p.dtype == 0) { WB_SCAN_N(float, false) }
             else { if (vec) { WB_SCAN_N(double, true) } else { WB_SCAN_N(double, false) } }
-#undef WB_SCAN_LAUNCH
+#undef WB_STREAM_F32
+#undef WB_STREAM_ANY
 #undef WB_SCAN_N
             b->timer.end(ctx);
             b->timer.begin(ctx, "scan_build");
@@ -1671,6 +1701,8 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "scan_split")) { ctx->scan_split = value ? 1 : 0; return 0; }
     if (!strcmp(name, "eager_f2")) { ctx->eager_f2 = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
+    if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;
 }

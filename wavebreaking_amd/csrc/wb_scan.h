@@ -52,10 +52,13 @@ struct WbScanArgs {
     int* stg_n;             // [njobs][nstrips] segments found (may exceed cap_strip: overflow)
     uint32_t* status;       // [njobs]
     // two-kernel scan: patches (2 x 5 values of one lane and row) that hold a crossing of some level, per (time step, strip)
-    uint32_t* cap_k;        // [nt][nwork][cap_rec]      r << 16 | c0
-    void* cap_v;            // [nt][nwork][cap_rec][10]  upper row v0..v4, lower row v0..v4 (T)
+    uint32_t* cap_k;        // [lists][cap_rec]      r << 16 | c0
+    void* cap_v;            // [lists][10][cap_rec]  upper row v0..v4, lower row v0..v4 (T): value k of patch i at [k * cap_rec + i]
     int* cap_n;             // [nt][nwork] patches found (may exceed cap_rec: overflow)
     int cap_rec;
+    int debug;              // development: bit 0 = the streaming scan stores no patches (streaming ceiling of the traversal)
+    int nbands, band_rows;  // streaming scan: a time step is cut into nbands bands of band_rows rows of squares; the lists above
+                            // are then per (time step, band, strip): index (t * nbands + band) * nwork + strip
 };
 
 // a segment is stored as its key + the four corner values of its square; the crossing coordinates
@@ -325,184 +328,145 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The scan as two kernels.  wb_k_scan carries its emit path in registers (116 VGPRs -> 4 waves per SIMD with 4 row loads
-// each in flight); a read-only probe with the same traversal but more loads in flight streams at 6.1 TB/s.
-//   wb_k_scan_capture : the same sweep and the same patch test with 8 row buffers (6 loads in flight, 121 VGPRs; 10 buffers
-//       need 145 and run slower); a lane whose
-//       2 x 5 patch holds a crossing of ANY level appends the patch (10 values + position) to the list of its
-//       (time step, strip) -- ballot compaction, raster order.  This is the kernel that streams the field.
-//   wb_k_scan_build   : one workgroup per (time step, strip) turns the patches into the segment lists of every level
-//       (square cases, block scan for the raster-ordered positions, key + four corner values per segment, periodic
-//       copies) -- the staging format the trace kernels read.  It touches the captured patches only (a few % of the field).
-template <typename T, bool VEC, int NLEV>
-__global__ __launch_bounds__(256) void wb_k_scan_capture(WbScanArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NSB = a.nwork;
-    const int W = a.W, nlon = a.nlon, nlat = a.nlat;
-    const unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int nwork = a.nt * NSB;
-    const int cmax = nlon < W - 1 ? nlon : W - 1;
-    T lvl[NLEV];
+// The scan as two kernels: wb_k_scan_stream (wb_stream.h) streams the field and captures the 2 x 5 patches that hold a
+// crossing; wb_k_scan_build below, one workgroup per (time step, strip), turns the patches into the segment lists of every
+// level (square cases, block scan for the raster-ordered positions, key + four corner values per segment, periodic
+// copies) -- the staging format the trace kernels read.  It touches the captured patches only (a few % of the field).
+// Patch layout: value k (0..4 upper row, 5..9 lower row) of patch i of a list at cap_v[list][k * cap_rec + i].
+#define WB_BUILD_CHUNK 2048
+// in-place exclusive scan of 64-bit values in LDS (two 32-bit counters per word, no carry between them as long as each
+// stays below 2^32); every thread of the block calls it; returns the total
+__device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* a, int n) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    if (tid == 0) carry_s = 0ull;
+    __syncthreads();
+    for (int base = 0; base < n; base += 8 * blockDim.x) {
+        const int i0 = base + 8 * tid;
+        unsigned long long v[8], sum = 0ull;
 #pragma unroll
-    for (int l = 0; l < NLEV; ++l) lvl[l] = wb_level_lo<T>(a.levels[l]);
-
-    for (int g = blockIdx.x * 4 + wave; g < nwork; g += gridDim.x * 4) {
-        const int t = g / NSB, s = g - t * NSB;
-        const T* f = (const T*)a.field + (size_t)t * nlat * nlon;
-        const int c0 = s * WB_STRIP + 4 * lane;
-        const bool live = c0 < cmax;                          // the lane owns at least one square
-        int cm = c0 >= nlon ? c0 - nlon : c0;
-        if (cm > nlon - 4) cm = nlon - 4;
-        int chs = (s + 1) * WB_STRIP;
-        chs = chs >= nlon ? chs - nlon : chs;
-        if (chs > nlon - 1) chs = nlon - 1;
-        bool nanflag = false;
-        int count = 0;                                        // wave-uniform
-        uint32_t* ck = a.cap_k + (size_t)g * a.cap_rec;
-        T* cv = (T*)a.cap_v + (size_t)g * a.cap_rec * 10;
-
-        auto load_row = [&](int r, WbRow<T>& R) {
-            const T* row = f + (size_t)(r < nlat ? r : nlat - 1) * nlon;
-            if (VEC) {
-                const typename WbVec4<T>::type q = *reinterpret_cast<const typename WbVec4<T>::type*>(row + cm);
-                R.v[0] = q.x; R.v[1] = q.y; R.v[2] = q.z; R.v[3] = q.w;
-            } else {
+        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < n) ? a[i0 + k] : 0ull; sum += v[k]; }
+        unsigned long long inc = sum;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int c = c0 + k;
-                    c = c >= nlon ? c - nlon : c;
-                    R.v[k] = row[c > nlon - 1 ? nlon - 1 : c];
-                }
-            }
-            R.h63 = row[chs];
-        };
-        auto finish_row = [&](WbRow<T>& R) {
-            const T sh = wb_shl1(R.v[0]);
-            R.v[4] = (lane == 63) ? R.h63 : sh;
-            nanflag |= __builtin_isunordered(R.v[0], R.v[1]) | __builtin_isunordered(R.v[2], R.v[3]);
-            R.mn = wb_min3(R.v[0], R.v[1], wb_min3(R.v[2], R.v[3], R.v[4]));
-            R.mx = wb_max3(R.v[0], R.v[1], wb_max3(R.v[2], R.v[3], R.v[4]));
-        };
-        auto step = [&](const WbRow<T>& P, WbRow<T>& N, int r) {
-            finish_row(N);
-            const T lo = wb_min(P.mn, N.mn), hi = wb_max(P.mx, N.mx);
-            bool hit = false;
-#pragma unroll
-            for (int l = 0; l < NLEV; ++l) hit |= (hi > lvl[l]) && !(lo > lvl[l]);
-            hit = hit && live;
-            const unsigned long long m = __ballot(hit);
-            if (m) {                                          // rare: append this row's patches in lane order
-                const int pos = count + __popcll(m & ltmask);
-                if (hit && pos < a.cap_rec) {
-                    ck[pos] = ((uint32_t)r << 16) | (uint32_t)c0;
-                    T* d = cv + (size_t)pos * 10;
-                    d[0] = P.v[0]; d[1] = P.v[1]; d[2] = P.v[2]; d[3] = P.v[3]; d[4] = P.v[4];
-                    d[5] = N.v[0]; d[6] = N.v[1]; d[7] = N.v[2]; d[8] = N.v[3]; d[9] = N.v[4];
-                }
-                count += __popcll(m);
-            }
-        };
-        WbRow<T> R0, R1, R2, R3, R4, R5, R6, R7;
-        load_row(0, R0); load_row(1, R1); load_row(2, R2); load_row(3, R3); load_row(4, R4); load_row(5, R5); load_row(6, R6);
-        finish_row(R0);
-        int r = 0;
-        for (; r + 8 <= nlat - 1; r += 8) {                 // 6 row loads always in flight
-            load_row(r + 7, R7); step(R0, R1, r);
-            load_row(r + 8, R0); step(R1, R2, r + 1);
-            load_row(r + 9, R1); step(R2, R3, r + 2);
-            load_row(r + 10, R2); step(R3, R4, r + 3);
-            load_row(r + 11, R3); step(R4, R5, r + 4);
-            load_row(r + 12, R4); step(R5, R6, r + 5);
-            load_row(r + 13, R5); step(R6, R7, r + 6);
-            load_row(r + 14, R6); step(R7, R0, r + 7);
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
         }
-        if (r < nlat - 1) { load_row(r + 7, R7); step(R0, R1, r); ++r; }
-        if (r < nlat - 1) { step(R1, R2, r); ++r; }
-        if (r < nlat - 1) { step(R2, R3, r); ++r; }
-        if (r < nlat - 1) { step(R3, R4, r); ++r; }
-        if (r < nlat - 1) { step(R4, R5, r); ++r; }
-        if (r < nlat - 1) { step(R5, R6, r); ++r; }
-        if (r < nlat - 1) { step(R6, R7, r); ++r; }
-        if (lane == 0) a.cap_n[g] = count;
-        if (__any(nanflag && (c0 < nlon)) && lane == 0) {
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long woff = 0ull;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const unsigned long long carry = carry_s;
+        unsigned long long run = carry + woff + inc - sum;
 #pragma unroll
-            for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < n) a[i0 + k] = run;
+            run += v[k];
         }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0ull;
+            for (int w = 0; w < nw; ++w) tot += wsum[w];
+            carry_s = carry + tot;
+        }
+        __syncthreads();
     }
+    return carry_s;
 }
 
-#define WB_BUILD_CHUNK 2048
 template <typename T, int NLEV>
 __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
-    __shared__ int cb[WB_BUILD_CHUNK];                        // per patch: segments for the base list -> exclusive scan
-    __shared__ int cc[WB_BUILD_CHUNK];                        // per patch: segments for the periodic-copy list
+    __shared__ unsigned long long cb[WB_BUILD_CHUNK];         // per patch: segments for the base list | periodic-copy list << 32 -> scan
+    __shared__ int boff[17];                                   // first patch of a band in the concatenation of the bands' lists
     const int g = blockIdx.x;
     const int NS = a.nstrips, NSB = a.nwork;
     const int t = g / NSB, s = g - t * NSB;
     const int W = a.W, nlon = a.nlon;
     const int cmax = nlon < W - 1 ? nlon : W - 1;
-    int nrec = a.cap_n[g];
-    const bool over = nrec > a.cap_rec;
-    if (over) nrec = a.cap_rec;
-    const uint32_t* ck = a.cap_k + (size_t)g * a.cap_rec;
-    const T* cv = (const T*)a.cap_v + (size_t)g * a.cap_rec * 10;
+    const int nbands = a.nbands > 0 ? a.nbands : 1;
+    const size_t cs = (size_t)a.cap_rec;
     const bool has_copy = NSB + s < NS;
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int band = 0; band < nbands; ++band) {
+            boff[band] = run;
+            const int n = a.cap_n[((size_t)t * nbands + band) * NSB + s];
+            run += n < a.cap_rec ? n : a.cap_rec;
+        }
+        boff[nbands] = run;
+    }
+    __syncthreads();
+    const int total = boff[nbands];
+    int excess = 0;
+    for (int band = 0; band < nbands; ++band) {
+        const int n = a.cap_n[((size_t)t * nbands + band) * NSB + s];
+        if (n > a.cap_rec) excess += n - a.cap_rec;
+    }
+    // patch i of the concatenation: its list and its index there
+    auto locate = [&](int i, size_t& gl, int& li) {
+        int band = 0;
+        while (band + 1 < nbands && i >= boff[band + 1]) ++band;
+        gl = ((size_t)t * nbands + band) * NSB + s;
+        li = i - boff[band];
+    };
     for (int l = 0; l < NLEV; ++l) {
         const T lv = wb_level_lo<T>(a.levels[l]);
         const size_t base = ((size_t)(t * NLEV + l) * NS + s) * a.cap_strip;
         const size_t cbase = ((size_t)(t * NLEV + l) * NS + NSB + s) * a.cap_strip;
-        int cur = 0, ccur = 0;
-        for (int q0 = 0; q0 < nrec; q0 += WB_BUILD_CHUNK) {
-            const int nq = nrec - q0 < WB_BUILD_CHUNK ? nrec - q0 : WB_BUILD_CHUNK;
+        unsigned long long cur = 0ull;                         // segments written so far: base list | copy list << 32
+        for (int q0 = 0; q0 < total; q0 += WB_BUILD_CHUNK) {
+            const int nq = total - q0 < WB_BUILD_CHUNK ? total - q0 : WB_BUILD_CHUNK;
             for (int i = threadIdx.x; i < nq; i += blockDim.x) {
-                const uint32_t key = ck[q0 + i];
+                size_t gl; int li;
+                locate(q0 + i, gl, li);
+                const uint32_t key = a.cap_k[gl * cs + li];
                 const int c0 = (int)(key & 0xFFFFu);
-                const T* d = cv + (size_t)(q0 + i) * 10;
-                int nb = 0, nc = 0;
+                const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
+                unsigned nb = 0, nc = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const T ul = d[k], ur = d[k + 1], ll = d[5 + k], lr = d[6 + k];
+                    const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
                     const bool ok = (c0 + k < cmax) && ul == ul && ur == ur && ll == ll && lr == lr;
-                    const int cs = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
-                    const int ns = wb_case_nseg(cs);
+                    const int cs2 = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
+                    const int ns = wb_case_nseg(cs2);
                     nb += ns;
                     if (c0 + k < a.padd - 1) nc += ns;
                 }
-                cb[i] = nb;
-                cc[i] = nc;
+                cb[i] = (unsigned long long)nb | ((unsigned long long)nc << 32);
             }
             __syncthreads();
-            const int tb = wb_block_scan_excl(cb, nq);
-            const int tc = has_copy ? wb_block_scan_excl(cc, nq) : 0;
+            const unsigned long long tot = wb_block_scan_excl_u64(cb, nq);
             for (int i = threadIdx.x; i < nq; i += blockDim.x) {
-                const uint32_t key = ck[q0 + i];
+                size_t gl; int li;
+                locate(q0 + i, gl, li);
+                const uint32_t key = a.cap_k[gl * cs + li];
                 const int r = (int)(key >> 16), c0 = (int)(key & 0xFFFFu);
-                const T* d = cv + (size_t)(q0 + i) * 10;
-                int mine = cur + cb[i], cmine = ccur + cc[i];
+                const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
+                const unsigned long long at = cur + cb[i];
+                int mine = (int)(at & 0xFFFFFFFFull), cmine = (int)(at >> 32);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const T ul = d[k], ur = d[k + 1], ll = d[5 + k], lr = d[6 + k];
+                    const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
                     const bool ok = (c0 + k < cmax) && ul == ul && ur == ur && ll == ll && lr == lr;
-                    const int cs = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
-                    const int ns = wb_case_nseg(cs);
+                    const int cs2 = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
+                    const int ns = wb_case_nseg(cs2);
                     if (ns) {
-                        wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs, ns, ul, ur, ll, lr, mine);
+                        wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs2, ns, ul, ur, ll, lr, mine);
                         if (has_copy && c0 + k < a.padd - 1)
-                            wb_store_square<T>(a.stg_k + cbase, (T*)a.stg_v + cbase * 4, a.cap_strip, W, r, c0 + k + nlon, cs, ns, ul, ur, ll, lr, cmine);
+                            wb_store_square<T>(a.stg_k + cbase, (T*)a.stg_v + cbase * 4, a.cap_strip, W, r, c0 + k + nlon, cs2, ns, ul, ur, ll, lr, cmine);
                     }
                     mine += ns;
                     if (c0 + k < a.padd - 1) cmine += ns;
                 }
             }
             __syncthreads();
-            cur += tb;
-            ccur += tc;
+            cur += tot;
         }
         if (threadIdx.x == 0) {
             // an overflowed patch list makes the segment count overflow too: the host grows the capacities and re-runs
-            a.stg_n[(t * NLEV + l) * NS + s] = over ? a.cap_strip + 1 + (a.cap_n[g] - a.cap_rec) : cur;
-            if (has_copy) a.stg_n[(t * NLEV + l) * NS + NSB + s] = ccur;
+            a.stg_n[(t * NLEV + l) * NS + s] = excess ? a.cap_strip + 1 + excess : (int)(cur & 0xFFFFFFFFull);
+            if (has_copy) a.stg_n[(t * NLEV + l) * NS + NSB + s] = (int)(cur >> 32);
         }
     }
 }

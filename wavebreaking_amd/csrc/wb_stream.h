@@ -1,0 +1,156 @@
+// wb_stream.h -- the field scan as a pure streaming kernel (THE HBM-bound kernel of the path).
+//
+// wb_k_scan (wb_scan.h) classifies AND emits segments in one kernel: its emit path costs 116 VGPRs, which leaves 4 waves
+// per SIMD with 4 row loads each in flight -- 16 KiB per SIMD, and the HBM pipe of this chip wants several times that
+// (loaded latency is ~4 us: bandwidth grew in proportion to the bytes in flight in every variant measured).  This kernel
+// does the least a pass over the field must do:
+//   * a WORKGROUP works on a band of rows of one time step, a wave on one 256-column strip of it, streaming top to bottom
+//     (bands: a few times more work items than resident workgroups, so the last round of the persistent grid is nearly
+//     full; a band re-reads one row of its neighbour): the workgroup reads every row as one contiguous 4 * nlon byte run, and the one value a strip needs from its right neighbour (the halo of
+//     lane 63, a scalar load) was just fetched by the neighbouring wave of the same workgroup -- an L2 hit, not a second
+//     trip to HBM (the strips of a time step used to be spread over workgroups on different XCDs: 1.19x over-fetch);
+//   * a row buffer is the lane's 16 bytes and nothing else; halo, minimum and maximum are formed when a row is consumed,
+//     so an 8-deep ring (7 loads in flight) fits in 64 VGPRs -> 8 waves per SIMD;
+//   * a lane whose 2 x 5 patch holds a crossing of ANY level (min(patch) <= level < max(patch), evaluated in the field's own
+//     precision against the largest T <= level: exactly skimage's strict `>` on the float64 copy, contour_index.py:103)
+//     appends the patch to the list of its (time step, band, strip) by ballot compaction, raster order -- through a small
+//     per-wave LDS buffer that is flushed to HBM 32+ patches at a time with full-width stores (the patches of one row are
+//     a handful of 44-byte items: stored directly they cost a dozen nearly empty store instructions per row, and those,
+//     not the loads, set the kernel's duration: 1.6 ms against 1.1 ms with the stores switched off).
+// wb_k_scan_build (wb_scan.h) turns the patches into the per-level segment lists the trace kernels read.
+//
+// Algorithmic HBM traffic: nlat * nlon * sizeof(T) per time step read once (+ 44 B per captured patch, ~6 %).
+#pragma once
+#include "wb_scan.h"
+
+#if !defined(WB_HOSTSIM)
+#define WB_STREAM_FLUSH 32         // patches in the wave's LDS buffer that trigger a flush
+#define WB_STREAM_LBUF 160         // its capacity: a row adds at most 64
+// D = ring depth (D - 1 row loads in flight per wave); WPS = waves per SIMD the register allocation must leave room for
+template <typename T, bool VEC, int NLEV, int D, int WPS>
+__global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // strip = wave of the workgroup
+    const int NSB = a.nwork;
+    const int nlon = a.nlon, nlat = a.nlat;
+    const unsigned long long ltmask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int cmax = nlon < a.W - 1 ? nlon : a.W - 1;
+    T lvl[NLEV];
+#pragma unroll
+    for (int l = 0; l < NLEV; ++l) lvl[l] = wb_level_lo<T>(a.levels[l]);
+    const int c0 = s * WB_STRIP + 4 * lane;
+    const bool live = c0 < cmax;                              // the lane owns at least one square
+    int cm = c0 >= nlon ? c0 - nlon : c0;
+    if (cm > nlon - 4) cm = nlon - 4;
+    int chs = (s + 1) * WB_STRIP;                             // first column of the next strip: halo of lane 63 (wave-uniform)
+    chs = chs >= nlon ? chs - nlon : chs;
+    if (chs > nlon - 1) chs = nlon - 1;
+    typedef typename WbVec4<T>::type V4;
+    // the halo of lane 63 is wave-uniform: read through the constant address space it becomes a scalar load (its own
+    // counter; the field is not written by this kernel)
+    typedef const __attribute__((address_space(4))) T* CT;
+    // this wave's patch buffer in LDS: keys, then the ten values as ten arrays (plain 4 / 8 byte LDS stores, no tuples)
+    extern __shared__ __attribute__((aligned(16))) uint32_t wb_stream_lds[];
+    constexpr int LW = WB_STREAM_LBUF * (1 + 10 * (int)(sizeof(T) / 4));      // dwords per wave
+    uint32_t* lkey = wb_stream_lds + (size_t)s * LW;
+    T* lval = reinterpret_cast<T*>(lkey + WB_STREAM_LBUF);
+
+    const int nitems = a.nt * a.nbands;
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) { // persistent: a workgroup strides over (time step, row band) items
+        const int t = it / a.nbands, band = it - t * a.nbands;
+        const int rb0 = band * a.band_rows;                   // squares of rows rb0 .. rb1 - 1: field rows rb0 .. rb1
+        const int rb1 = rb0 + a.band_rows < nlat - 1 ? rb0 + a.band_rows : nlat - 1;
+        const int g = it * NSB + s;                           // patch list of this (time step, band, strip)
+        const T* f = (const T*)a.field + (size_t)t * nlat * nlon;
+        bool nanflag = false;
+        int count = 0;                                        // patches appended so far (wave-uniform)
+        int fill = 0;                                         // patches waiting in the wave's LDS buffer (wave-uniform)
+        uint32_t* ck = a.cap_k + (size_t)g * a.cap_rec;       // the list in HBM: keys, and value k of patch i at cv[k * cap_rec + i]
+        T* cv = (T*)a.cap_v + (size_t)g * a.cap_rec * 10;
+        auto flush = [&]() {
+            // patches [count, count + fill) of the list <- the LDS buffer: eleven full-width stores per 64 patches
+            int w = a.cap_rec - count;
+            w = w < 0 ? 0 : (w < fill ? w : fill);
+            if (a.debug & 1) w = 0;
+            for (int j = lane; j < w; j += 64) {
+                ck[count + j] = lkey[j];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_rec + count + j] = lval[k * WB_STREAM_LBUF + j];
+            }
+            count += fill;
+            fill = 0;
+        };
+        V4 q[D];                                              // the ring: raw row data only (register-resident: every index
+        T h[D];                                               // below is a compile-time constant after unrolling)
+        auto load = [&](int r, V4& qq, T& hh) {
+            const T* row = f + (size_t)(r < rb1 ? r : rb1) * nlon;      // reads past the band repeat its last row (cache hits)
+            if (VEC) qq = *reinterpret_cast<const V4*>(row + cm);
+            else {
+                int cc = c0; cc = cc >= nlon ? cc - nlon : cc; qq.x = row[cc > nlon - 1 ? nlon - 1 : cc];
+                cc = c0 + 1; cc = cc >= nlon ? cc - nlon : cc; qq.y = row[cc > nlon - 1 ? nlon - 1 : cc];
+                cc = c0 + 2; cc = cc >= nlon ? cc - nlon : cc; qq.z = row[cc > nlon - 1 ? nlon - 1 : cc];
+                cc = c0 + 3; cc = cc >= nlon ? cc - nlon : cc; qq.w = row[cc > nlon - 1 ? nlon - 1 : cc];
+            }
+            hh = ((CT)row)[chs];
+        };
+        T p4, pmn, pmx;                                       // previous row, completed: its halo, minimum and maximum
+        auto finish = [&](const V4& qq, T hh, T& v4, T& mn, T& mx) {
+            const T sh = wb_shl1(qq.x);                       // unconditional: every lane must be active for the DPP read
+            v4 = (lane == 63) ? hh : sh;
+            nanflag |= __builtin_isunordered(qq.x, qq.y) | __builtin_isunordered(qq.z, qq.w);
+            mn = wb_min3(qq.x, qq.y, wb_min3(qq.z, qq.w, v4));
+            mx = wb_max3(qq.x, qq.y, wb_max3(qq.z, qq.w, v4));
+        };
+        auto step = [&](int r, const V4& P, const V4& N, T hN) {   // rows (r, r + 1) = (P, N)
+            T n4, nmn, nmx;
+            finish(N, hN, n4, nmn, nmx);
+            const T lo = wb_min(pmn, nmn), hi = wb_max(pmx, nmx);
+            bool hit = false;
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) hit |= (hi > lvl[l]) && !(lo > lvl[l]);
+            hit = hit && live;
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                if (hit) {
+                    const int pos = fill + __popcll(m & ltmask);
+                    lkey[pos] = ((uint32_t)r << 16) | (uint32_t)c0;
+                    T* d = lval + pos;                        // value k of the buffered patch pos at lval[k * WB_STREAM_LBUF + pos]
+                    d[0] = P.x; d[WB_STREAM_LBUF] = P.y; d[2 * WB_STREAM_LBUF] = P.z; d[3 * WB_STREAM_LBUF] = P.w; d[4 * WB_STREAM_LBUF] = p4;
+                    d[5 * WB_STREAM_LBUF] = N.x; d[6 * WB_STREAM_LBUF] = N.y; d[7 * WB_STREAM_LBUF] = N.z; d[8 * WB_STREAM_LBUF] = N.w;
+                    d[9 * WB_STREAM_LBUF] = n4;
+                }
+                fill += __popcll(m);
+                if (fill > WB_STREAM_LBUF - 64) flush();      // no room for another full row (rare: the regular flush is below)
+            }
+            p4 = n4; pmn = nmn; pmx = nmx;
+        };
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k) load(rb0 + k, q[k], h[k]);
+        finish(q[0], h[0], p4, pmn, pmx);
+        int r = rb0;
+        for (; r + D <= rb1; r += D) {                        // D - 1 row loads always in flight
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                load(r + k + D - 1, q[(k + D - 1) % D], h[(k + D - 1) % D]);
+                __builtin_amdgcn_sched_barrier(0);            // a step's work stays between its load and the next one
+                step(r + k, q[k], q[(k + 1) % D], h[(k + 1) % D]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (fill >= WB_STREAM_FLUSH) flush();             // once per D rows
+        }
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k) {
+            if (r + k < rb1) {
+                if (k == 0) load(r + D - 1, q[D - 1], h[D - 1]);
+                step(r + k, q[k], q[k + 1], h[k + 1]);
+            }
+        }
+        flush();
+        if (lane == 0) a.cap_n[g] = count;
+        if (__any(nanflag && (c0 < nlon)) && lane == 0) {
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
+        }
+    }
+}
+#endif
