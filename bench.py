@@ -125,6 +125,7 @@ def main():
                                overturnings=int(ev[1]["step"].size), cutoffs=int(ev[2]["step"].size),
                                band_hits=b.band_hits(), pair_stats=b.pair_stats(), evaluated_pairs=b.evaluated_pairs(),
                                com_rechecks=b.com_rechecks(),
+                               polygons_not_simple=int(sum(int(np.count_nonzero(e["flags"] & 1)) for e in ev)),
                                status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
                    packed=[wd.pack_events(e, step_offset=t0) for e in ev] if world > 1 else None,
                    events=ev if copy else None)

@@ -87,7 +87,10 @@ typedef struct wb_event_table {
     const int64_t* poly_offset; /* [n+1] polygon vertices in index coordinates (streamers, cutoffs; overturnings: */
     const int32_t* poly_x;      /*  the 4 box corners in shapely.geometry.box order), so that the event table   */
     const int32_t* poly_y;      /*  is self-contained and the contour table need not be fetched                 */
+    const int32_t* flags;       /* bit 0 (WB_EVENT_NOT_SIMPLE): the event's polygon crosses itself -- its cells follow the non-zero
+                                   winding rule; the reference relies on GEOS' make_valid there (index_utils.py:164), unpinned */
 } wb_event_table;
+#define WB_EVENT_NOT_SIMPLE 1
 
 #define WB_STATUS_OVERFLOW_SEG 1u
 #define WB_STATUS_LEVEL_HIT 2u     /* a cell on a contour equals the level: crossings on grid vertices, joined as skimage joins them */

@@ -86,7 +86,7 @@ def segments_intersect(p1, q1, p2, q2):
     return False
 
 
-def polygon_cells(poly, r, width, height):
+def polygon_cells(poly, r, width, height, return_winding=False):
     """Lattice points ``(x in [0,width), y in [0,height))`` contained in
     ``Polygon(poly).buffer(r)`` (index_utils.py:37-51, sjoin predicate 'contains').
 
@@ -134,4 +134,14 @@ def polygon_cells(poly, r, width, height):
         near |= d2 < r2
     inside = (wind != 0) | near
     ys, xs = np.nonzero(inside)
+    if return_winding:
+        return xs + x0, ys + y0, wind
     return xs + x0, ys + y0
+
+
+def polygon_not_simple(poly, width, height):
+    """the flag the kernels attach to an event whose polygon crosses itself: some lattice point has a winding number
+    other than 0 and ONE constant +-1 (a simple polygon winds once around all of its interior, in one direction)"""
+    wind = polygon_cells(poly, 0.125, width, height, return_winding=True)[2]
+    pos, neg, big = bool((wind > 0).any()), bool((wind < 0).any()), bool((np.abs(wind) > 1).any())
+    return big or (pos and neg)

@@ -78,6 +78,7 @@ def calculate_properties(events, data, intensity, lat, lon, periodic_add):
         if "orientation" in ev:
             row["orientation"] = ev["orientation"]
         row["_sums"] = (areas, mv, it, xc, yc)
+        row["_not_simple"] = "orientation" not in ev and geom.polygon_not_simple(ev["polygon"], width, nlat)
         row["_cells"] = (xs, ys)
         row["_t"] = ev["_t"]
         out.append(row)
@@ -85,74 +86,144 @@ def calculate_properties(events, data, intensity, lat, lon, periodic_add):
 
 
 # --------------------------------------------------------------------------- transform_polygons
+# The seam split (index_utils.py:148-173) is GEOS work in the reference (linemerge / unary_union / polygonize /
+# make_valid: **parity unpinned**, no GEOS here).  The restatement below is deliberately NOT the product's algorithm
+# (wavebreaking_amd/utils/index_utils.py pairs the line points by sorting them): it works in exact rational arithmetic,
+# decides which stretch of the cutting line lies inside the polygon by an explicit point-in-polygon test of its midpoint,
+# and `clipped_area_exact` gives a third, ring-free statement of the same region (Green's theorem with the abscissa
+# clamped at the line).
+from fractions import Fraction
 
-def _clip_halfplane(ring, L, keep_le):
-    """Pieces of the closed ring (n,2 float) on one side of the vertical line x = L
-    (closed half-plane).  Proper multi-piece split: boundary chains on the kept side are
-    re-connected along the line by pairing the line points sorted by y."""
-    v = np.asarray(ring, dtype=np.float64)
+
+def _inside_exact(px, py, v):
+    """strictly inside the closed integer ring v (even-odd), exact; points on the boundary count as outside"""
+    n = len(v)
+    inside = False
+    for k in range(n):
+        ax, ay = v[k]
+        bx, by = v[(k + 1) % n]
+        # on the boundary?
+        cr = (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+        if cr == 0 and min(ax, bx) <= px <= max(ax, bx) and min(ay, by) <= py <= max(ay, by):
+            return False
+        if (ay > py) != (by > py):
+            xc = ax + Fraction((py - ay) * (bx - ax), (by - ay))
+            if xc > px:
+                inside = not inside
+    return inside
+
+
+def split_rings_exact(ring, L, keep_le):
+    """Pieces of the closed integer ring on one side of the vertical line x = L (closed half-plane) as lists of exact
+    (Fraction) points.  Boundary chains on the kept side are linked across the line from a chain's exit point to the
+    neighbouring line point (above or below) whose connecting stretch of the line has its midpoint strictly inside the
+    polygon."""
+    v = [(int(x), int(y)) for x, y in np.asarray(ring)]
+    if len(v) > 1 and v[0] == v[-1]:
+        v = v[:-1]
     n = len(v)
 
-    def inside(p):
+    def keep(p):
         return p[0] <= L if keep_le else p[0] >= L
 
-    ins = [inside(p) for p in v]
-    if all(ins):
-        return [v]
-    if not any(ins):
-        return []
-    # rotate so that we start on an outside vertex
-    s = ins.index(False)
-    order = [(s + k) % n for k in range(n)]
-    chains = []
-    cur = None
+    nodes = []                                   # boundary nodes in order: vertices + strict crossings of the line
     for k in range(n):
-        a, b = v[order[k]], v[order[(k + 1) % n]]
-        ia, ib = ins[order[k]], ins[order[(k + 1) % n]]
-        if not ia and ib:                      # entering
-            t = (L - a[0]) / (b[0] - a[0])
-            cur = [np.array([L, a[1] + t * (b[1] - a[1])]), b.copy()]
-        elif ia and ib:
-            cur.append(b.copy())
-        elif ia and not ib:                    # leaving
-            t = (L - a[0]) / (b[0] - a[0])
-            cur.append(np.array([L, a[1] + t * (b[1] - a[1])]))
+        a, b = v[k], v[(k + 1) % n]
+        nodes.append((Fraction(a[0]), Fraction(a[1])))
+        if (a[0] < L < b[0]) or (b[0] < L < a[0]):
+            t = Fraction(L - a[0], b[0] - a[0])
+            nodes.append((Fraction(L), a[1] + t * (b[1] - a[1])))
+    kp = [keep(p) for p in nodes]
+    if all(kp):
+        return [nodes]
+    if not any(kp):
+        return []
+    m = len(nodes)
+    s = kp.index(False)
+    chains, cur = [], None
+    for q in range(1, m + 1):
+        i = (s + q) % m
+        if kp[i]:
+            if cur is None:
+                cur = []
+            cur.append(nodes[i])
+        elif cur is not None:
             chains.append(cur)
             cur = None
-    # pair the line points by y
-    pts = []
-    for ci, ch in enumerate(chains):
-        pts.append((ch[0][1], 0, ci))          # entry
-        pts.append((ch[-1][1], 1, ci))         # exit
-    pts.sort(key=lambda p: (p[0], p[1]))
-    partner = {}
-    for k in range(0, len(pts) - 1, 2):
-        partner[(pts[k][1], pts[k][2])] = (pts[k + 1][1], pts[k + 1][2])
-        partner[(pts[k + 1][1], pts[k + 1][2])] = (pts[k][1], pts[k][2])
+    if cur is not None:
+        chains.append(cur)
+    chains = [c for c in chains if len(c) >= 2]                      # a lone point touching the line from outside
+    # every chain starts and ends ON the line
+    assert all(c[0][0] == L and c[-1][0] == L for c in chains)
+    ys = sorted({c[0][1] for c in chains} | {c[-1][1] for c in chains})
+    entry_at = {}
+    for ci, c in enumerate(chains):
+        entry_at.setdefault(c[0][1], []).append(ci)
+
+    def partner(y0):
+        """the line point joined to (L, y0) through the polygon's interior along the line"""
+        k = ys.index(y0)
+        for kk in (k + 1, k - 1):
+            if 0 <= kk < len(ys):
+                mid = (Fraction(L), (y0 + ys[kk]) / 2)
+                if _inside_exact(mid[0], mid[1], v):
+                    return ys[kk]
+        return y0                                                    # the chain closes on itself (exit = entry point)
+
     used = [False] * len(chains)
     pieces = []
     for c0 in range(len(chains)):
         if used[c0]:
             continue
-        piece = []
-        c = c0
-        guard = 0
-        while not used[c] and guard <= len(chains):
+        piece, c = [], c0
+        while not used[c]:
             used[c] = True
             piece.extend(chains[c])
-            kind, nxt = partner.get((1, c), (0, c))
-            c = nxt
-            guard += 1
-        piece = np.asarray(piece)
-        if len(piece) >= 3 and abs(ring_area(piece)) > 0:
+            yn = partner(chains[c][-1][1])
+            cand = [ci for ci in entry_at.get(yn, []) if not used[ci]] or entry_at.get(yn, [c0])
+            c = cand[0]
+        if len(piece) >= 3 and ring_area_exact(piece) != 0:
             pieces.append(piece)
     return pieces
+
+
+def ring_area_exact(r):
+    n = len(r)
+    return sum(r[k][0] * r[(k + 1) % n][1] - r[(k + 1) % n][0] * r[k][1] for k in range(n)) / 2
+
+
+def clipped_area_exact(ring, L, keep_le):
+    """|area| of (closed integer polygon) intersected with the half-plane x <= L (or x >= L), by Green's theorem with the
+    abscissa clamped at the line: area = | closed integral of min(x, L) dy | -- exact, no rings involved"""
+    v = [(int(x), int(y)) for x, y in np.asarray(ring)]
+    n = len(v)
+    total = Fraction(0)
+    for k in range(n):
+        (ax, ay), (bx, by) = v[k], v[(k + 1) % n]
+        pts = [(Fraction(ax), Fraction(ay))]
+        if (ax < L < bx) or (bx < L < ax):
+            t = Fraction(L - ax, bx - ax)
+            pts.append((Fraction(L), ay + t * (by - ay)))
+        pts.append((Fraction(bx), Fraction(by)))
+        for (x0, y0), (x1, y1) in zip(pts[:-1], pts[1:]):
+            c0 = min(x0, L) if keep_le else max(x0, L) - L
+            c1 = min(x1, L) if keep_le else max(x1, L) - L
+            total += (c0 + c1) / 2 * (y1 - y0)                      # the clamped abscissa is linear on each piece
+    return abs(total)
 
 
 def ring_area(r):
     r = np.asarray(r, dtype=np.float64)
     x, y = r[:, 0], r[:, 1]
     return 0.5 * float(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y))
+
+
+def split_index_polygon(polygon, nlon):
+    """index_utils.py:148-166: the parts of the index polygon left of x = nlon - 1 and right of x = nlon (the strip
+    between the last meridian and its periodic copy removed), as float rings in index coordinates"""
+    coords = np.asarray(polygon).astype("int")
+    pieces = split_rings_exact(coords, nlon - 1, True) + split_rings_exact(coords, nlon, False)
+    return [np.array([[float(x), float(y)] for x, y in p]) for p in pieces]
 
 
 def transform_polygon(polygon, lat, lon):
@@ -169,6 +240,32 @@ def transform_polygon(polygon, lat, lon):
 
     if not (coords[:, 0] >= nlon).any():                                    # :136
         return [to_lonlat(coords)]
-    # :148-173: drop the strip nlon-1 < x < nlon, keep what is left on either side
-    pieces = _clip_halfplane(coords, nlon - 1, True) + _clip_halfplane(coords, nlon, False)
-    return [to_lonlat(p) for p in pieces]
+    return [to_lonlat(p) for p in split_index_polygon(coords, nlon)]
+
+
+def canonical_ring(r, ndigits=9):
+    """a ring as a rotation- and direction-independent tuple (for comparing ring SETS): consecutive repeats dropped, then
+    the lexicographically smallest rotation of the ring or its reversal"""
+    pts = [tuple(round(float(c), ndigits) for c in p) for p in np.asarray(r)]
+    if len(pts) > 1 and pts[0] == pts[-1]:
+        pts = pts[:-1]
+    pts = [p for i, p in enumerate(pts) if p != pts[i - 1]] or pts[:1]
+    # vertices in the middle of a straight stretch carry no shape (a polygon touching the cutting line from the far side
+    # leaves such a node on the line; whether the reference's GEOS output keeps it is unpinned)
+    changed = True
+    while changed and len(pts) > 3:
+        changed = False
+        for i in range(len(pts)):
+            a, b, c = pts[i - 1], pts[i], pts[(i + 1) % len(pts)]
+            if abs((b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])) < 1e-9 and \
+                    (b[0] - a[0]) * (c[0] - b[0]) + (b[1] - a[1]) * (c[1] - b[1]) >= 0:
+                del pts[i]
+                changed = True
+                break
+    best = None
+    for seq in (pts, pts[::-1]):
+        for k in range(len(seq)):
+            rot = tuple(seq[k:] + seq[:k])
+            if best is None or rot < best:
+                best = rot
+    return best

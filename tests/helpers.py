@@ -94,6 +94,7 @@ def compare_events(got, contours, ref_rows, kind, levels, rtol=1e-6):
         if "cell_offset" in got:
             a, b = got["cell_offset"][k], got["cell_offset"][k + 1]
             assert np.array_equal(got["cell_x"][a:b], xs) and np.array_equal(got["cell_y"][a:b], ys), (kind, k)
+        assert bool(got["flags"][k] & _hip.EVENT_NOT_SIMPLE) == bool(r["_not_simple"]), (kind, k)
         ref = np.asarray(r["_sums"])
         s = got["sums"][k]
         # com = (lon[int(x_com / areas) % nlon], lat[int(y_com / areas)]) (index_utils.py:105-110): the truncated indices
@@ -266,3 +267,43 @@ def level_hit_field(seed, dlon=1.0, eps=0.3, nhits=4, level=2.0, seam=True):
         if len(cc):
             a[cc[0][0], cc[0][1]] = level
     return pv, lat, lon
+
+
+def not_simple_polygon_case(ctx):
+    """A cutoff whose polygon crosses itself (a bow tie handed in as a closed contour) next to a simple one: the event
+    table flags the first, the oracle's winding numbers agree, cells follow the non-zero winding rule."""
+    from oracle import geom
+    from oracle import synth
+    lat, lon = synth.grid(1.0)
+    W = lon.size + 120
+    data = np.zeros((1, lat.size, lon.size), dtype=np.float32)
+
+    def dense(ring):
+        out = []
+        for i, (ax, ay) in enumerate(ring):
+            bx, by = ring[(i + 1) % len(ring)]
+            g = int(np.gcd(abs(bx - ax), abs(by - ay)))
+            out += [(ax + (bx - ax) // g * q, ay + (by - ay) // g * q) for q in range(g)]
+        return np.asarray(out)
+
+    xs = np.arange(W)
+    rows = [np.c_[xs, np.full(W, 90) + (xs % 2)],
+            dense([(100, 40), (112, 52), (112, 40), (100, 52)]),          # bow tie: the two diagonals cross at (106, 46)
+            dense([(200, 40), (212, 40), (212, 52), (200, 52)])]          # square
+    # the bow tie visits (106, 46) twice: a traced contour never repeats a point, a frame handed in may
+    npts = np.array([len(r) for r in rows], dtype=np.int32)
+    table = dict(step=np.zeros(3, np.int32), level_idx=np.zeros(3, np.int32), closed=np.array([0, 1, 1], np.int32), npts=npts,
+                 offset=(np.cumsum(npts) - npts).astype(np.int64), x=np.concatenate([r[:, 0] for r in rows]).astype(np.int32),
+                 y=np.concatenate([r[:, 1] for r in rows]).astype(np.int32))
+    b = ctx.batch_from_contours(table, data, lat, lon, [2.0], 1.0, 1.0, want_cells=True)
+    b.indices(streamers=False, overturnings=False)
+    got = b.events(_hip.CUTOFFS)
+    b.close()
+    assert got["step"].size == 2
+    assert [int(f) & _hip.EVENT_NOT_SIMPLE for f in got["flags"]] == [1, 0]
+    assert geom.polygon_not_simple(rows[1], W, lat.size) and not geom.polygon_not_simple(rows[2], W, lat.size)
+    for k, r in enumerate(rows[1:]):
+        cx, cy = geom.polygon_cells(r, 0.5, W, lat.size)
+        a, e = got["cell_offset"][k], got["cell_offset"][k + 1]
+        assert np.array_equal(got["cell_x"][a:e], cx) and np.array_equal(got["cell_y"][a:e], cy)
+    return got

@@ -166,3 +166,7 @@ def test_cells_equal_to_the_level_full_path(ctx, seed, dlon):
     pv, lat, lon = helpers.level_hit_field(seed, dlon=dlon, nhits=4 if dlon == 1.0 else 12)
     got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2.0], intensity=pv)
     assert got["status"][0] & _hip.STATUS_LEVEL_HIT and not (got["status"][0] & _hip.STATUS_LEVEL_ORDER)
+
+
+def test_polygon_that_crosses_itself_is_flagged(ctx):
+    helpers.not_simple_polygon_case(ctx)

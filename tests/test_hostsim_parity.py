@@ -183,3 +183,8 @@ def test_box_com_one_lane_walk():
     got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(6), [-2, 2], intensity=pv)
     assert got["com_rechecks"][1] >= 8 and got["com_rechecks"][2] == got["com_rechecks"][1]
     ctx.close()
+
+
+def test_polygon_that_crosses_itself_is_flagged(sim):
+    lib, ctx = sim
+    helpers.not_simple_polygon_case(ctx)

@@ -230,3 +230,55 @@ def test_edge_linking_and_coordinate_join_agree_without_level_hits(golden_dir):
         joined = marching.join_by_coordinates(seg["p_from"], seg["p_to"])
         linked = marching.find_contours(a, lv)
         assert len(joined) == len(linked) and all(np.array_equal(x, y) for x, y in zip(joined, linked)), name
+
+
+def test_lattice_rasterisation_interior_vs_matplotlib():
+    """geom.polygon_cells (the oracle's restatement of buffer(r) + contains, index_utils.py:37-51) on random simple
+    lattice polygons: its interior term against matplotlib.path.Path.contains_points (a third-party point-in-polygon,
+    importable here), its boundary / rim term against exact point-segment distances."""
+    mpath = pytest.importorskip("matplotlib.path")
+    rng = np.random.RandomState(8)
+    checked = 0
+    for trial in range(150):
+        n = int(rng.randint(3, 12))
+        cx, cy = rng.uniform(12, 28), rng.uniform(12, 28)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = rng.uniform(2.0, 11.0, n)
+        pts = np.c_[np.rint(cx + rad * np.cos(ang)), np.rint(cy + rad * np.sin(ang))].astype(int)
+        if len(set(map(tuple, pts))) != len(pts):
+            continue
+        ok = True
+        for i in range(n):                                   # simple?
+            for j in range(i + 1, n):
+                if j == i + 1 or (i == 0 and j == n - 1):
+                    continue
+                ok &= not geom.segments_intersect(pts[i], pts[(i + 1) % n], pts[j], pts[(j + 1) % n])
+        for i in range(n):
+            a, b, c = pts[i - 1], pts[i], pts[(i + 1) % n]
+            if geom.orient(a[0], a[1], b[0], b[1], c[0], c[1]) == 0 and np.dot(b - a, c - b) < 0:
+                ok = False
+        if not ok:
+            continue
+        gx, gy = np.meshgrid(np.arange(0, 41), np.arange(0, 41))
+        P = np.c_[gx.ravel(), gy.ravel()]
+        # exact distance of every lattice point to the boundary
+        on_boundary = np.zeros(len(P), dtype=bool)
+        d2min = np.full(len(P), np.inf)
+        for k in range(n):
+            a, b = pts[k].astype(float), pts[(k + 1) % n].astype(float)
+            ab = b - a
+            t = np.clip(((P - a) @ ab) / (ab @ ab), 0.0, 1.0)
+            d2 = np.sum((P - (a + t[:, None] * ab)) ** 2, axis=1)
+            d2min = np.minimum(d2min, d2)
+        on_boundary = d2min < 1e-18
+        inside_mpl = mpath.Path(np.r_[pts, pts[:1]], closed=True).contains_points(P) & ~on_boundary
+        for r in (0.125, 0.5):
+            want = inside_mpl | (d2min < r * r - 1e-12)
+            xs, ys = geom.polygon_cells(pts, r, 41, 41)
+            got = np.zeros((41, 41), dtype=bool)
+            got[ys, xs] = True
+            # a lattice point off a lattice segment is never at distance exactly r for r = 1/8, 1/2 (SURVEY 8a P1)
+            assert not np.any(np.abs(np.sqrt(d2min[~on_boundary]) - r) < 1e-9)
+            assert np.array_equal(got.ravel(), want), trial
+        checked += 1
+    assert checked >= 60

@@ -42,10 +42,12 @@ class WbEventTable(C.Structure):
         ("ncells", C.POINTER(C.c_int32)), ("cell_offset", C.POINTER(C.c_int64)),
         ("cell_x", C.POINTER(C.c_int32)), ("cell_y", C.POINTER(C.c_int32)),
         ("poly_offset", C.POINTER(C.c_int64)), ("poly_x", C.POINTER(C.c_int32)), ("poly_y", C.POINTER(C.c_int32)),
+        ("flags", C.POINTER(C.c_int32)),
     ]
 
 
 STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
+EVENT_NOT_SIMPLE = 1
 STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS, STATUS_LEVEL_ORDER = 1, 2, 4, 8, 16, 32
 
 
@@ -422,7 +424,8 @@ class Batch:
         out = dict(step=A(t.step, n, np.int32), level_idx=A(t.level_idx, n, np.int32),
                    contour=A(t.contour, n, np.int64), ind1=A(t.ind1, n, np.int32), ind2=A(t.ind2, n, np.int32),
                    box=A(t.box, 4 * n, np.int32).reshape(-1, 4), orientation=A(t.orientation, n, np.int32),
-                   sums=A(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=A(t.ncells, n, np.int32))
+                   sums=A(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=A(t.ncells, n, np.int32),
+                   flags=A(t.flags, n, np.int32))
         poff = A(t.poly_offset, n + 1, np.int64)
         out["poly_offset"] = poff
         out["poly_x"] = A(t.poly_x, poff[-1] if n else 0, np.int32)

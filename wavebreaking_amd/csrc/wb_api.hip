@@ -402,7 +402,7 @@ struct wb_batch {
     std::vector<int32_t> ct_step, ct_level, ct_closed, ct_nux, ct_npts, ct_x, ct_y;
     std::vector<int64_t> ct_sumy, ct_off, ct_base;   // ct_base[job] = first contour row of the job
     struct Ev {
-        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, cx, cy;
+        std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, flags, cx, cy;
         std::vector<int64_t> contour, celloff, polyoff;
         size_t pbase = 0;              // first polygon vertex of this table in wb_batch::poly_x / poly_y
         std::vector<double> sums;
@@ -1157,7 +1157,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
 
     WbCtl fin;
     memset(&fin, 0, sizeof(fin));
-    int* h_ev = nullptr; double* h_sums = nullptr; int* h_nc = nullptr; long long* h_poff = nullptr; long long* h_coff = nullptr;
+    int* h_ev = nullptr; double* h_sums = nullptr; int* h_nc = nullptr; int* h_fl = nullptr; long long* h_poff = nullptr; long long* h_coff = nullptr;
     uint32_t* h_cells = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {
         std::vector<void*> tmp;   // device scratch of this attempt
@@ -1316,10 +1316,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         pa.rowacc = (double*)talloc((size_t)pa.nslots * 4 * p.nlat * sizeof(double));
         pa.ev_sums = (double*)talloc((size_t)(cap_ne + 1) * 5 * sizeof(double));
         pa.ev_ncells = (int*)talloc((size_t)(cap_ne + 1) * sizeof(int));
+        pa.ev_flags = (int*)talloc((size_t)(cap_ne + 1) * sizeof(int));
         pa.ev_cell_off = (long long*)talloc((size_t)(cap_ne + 1) * sizeof(long long));
         pa.cell_cap = cell_cap;
         pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
-        if (!d_py || !fa.poff || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
+        if (!d_py || !fa.poff || !pa.ev_flags || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
         b->timer.begin(ctx, "fill_events");
         WB_LAUNCH(wb_k_event_offsets, 1, 1024, fa);
         if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa);
@@ -1358,11 +1359,12 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         h_poff = (long long*)hbuf((size_t)(NE + 1) * sizeof(long long));
         h_sums = (double*)hbuf((size_t)(NE + 1) * 5 * sizeof(double));
         h_nc = (int*)hbuf((size_t)(NE + 1) * sizeof(int));
+        h_fl = (int*)hbuf((size_t)(NE + 1) * sizeof(int));
         h_coff = p.want_cells ? (long long*)hbuf((size_t)(NE + 1) * sizeof(long long)) : nullptr;
         b->poly_n = (size_t)NV;
         b->poly_x = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
         b->poly_y = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
-        if (!h_ev || !h_poff || !h_sums || !h_nc || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
+        if (!h_ev || !h_poff || !h_sums || !h_nc || !h_fl || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
 #if !defined(WB_HOSTSIM)
         std::swap(ctx->stream, ctx->stream2);
 #endif
@@ -1378,6 +1380,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.begin(ctx, "events_d2h");
         d2h_async(ctx, h_sums, pa.ev_sums, (size_t)NE * 5 * sizeof(double));
         d2h_async(ctx, h_nc, pa.ev_ncells, (size_t)NE * sizeof(int));
+        d2h_async(ctx, h_fl, pa.ev_flags, (size_t)NE * sizeof(int));
         if (p.want_cells) d2h_async(ctx, h_coff, pa.ev_cell_off, (size_t)NE * sizeof(long long));
         b->timer.end(ctx);
         if (dsync(ctx) || side_sync(ctx)) { release(); return 1; }
@@ -1417,7 +1420,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const size_t m = (size_t)(hi - lo);
         const long long pbase = NE ? h_poff[lo] : 0, pn = NE ? h_poff[hi] - h_poff[lo] : 0;
         t.step.resize(m); t.level.resize(m); t.contour.resize(m); t.ind1.resize(m); t.ind2.resize(m);
-        t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.ncells.resize(m);
+        t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.ncells.resize(m); t.flags.resize(m);
         t.polyoff.resize(m + 1); t.pbase = (size_t)pbase;
         for (size_t k = 0; k < m; ++k) {
             const int e = lo + (int)k;
@@ -1436,6 +1439,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             for (int q = 0; q < 5; ++q) t.sums[5 * k + q] = h_sums[(size_t)e * 5 + q];
             t.polyoff[k] = h_poff[e] - pbase;
             t.ncells[k] = h_nc[e];
+            t.flags[k] = h_fl[e];
         }
         t.polyoff[m] = pn;
 
@@ -1469,7 +1473,7 @@ extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
     o->n = (int64_t)t.step.size();
     o->step = t.step.data(); o->level_idx = t.level.data(); o->contour = t.contour.data();
     o->ind1 = t.ind1.data(); o->ind2 = t.ind2.data(); o->box = t.box.data(); o->orientation = t.orient.data();
-    o->sums = t.sums.data(); o->ncells = t.ncells.data();
+    o->sums = t.sums.data(); o->ncells = t.ncells.data(); o->flags = t.flags.data();
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
     if (t.polyoff.empty()) t.polyoff.push_back(0);

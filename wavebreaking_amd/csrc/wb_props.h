@@ -50,6 +50,7 @@ struct WbPropsArgs {
     double* rowacc;             // [nslots][4][nlat]
     double* ev_sums;            // [nev][5]: areas, mean_var, intensity, x_com, y_com  (sums, :94-102)
     int* ev_ncells;             // [nev]
+    int* ev_flags;              // [nev] bit 0: the polygon crosses itself (winding numbers other than 0 and one constant +-1)
     unsigned long long cell_cap;
     uint32_t* cell_pool;        // (x | y<<16)
     long long* ev_cell_off;     // [nev]
@@ -104,6 +105,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
     WB_SHARED(int, longe, WB_PROPS_LONG);
     WB_SHARED(int, nlong, 1);
     WB_SHARED(int, bb, 4);
+    WB_SHARED(int, wseen, 1);           // winding numbers met: bit 0 positive, bit 1 negative, bit 2 beyond +-1
     WB_SHARED(long long, sh_off, 1);
     // per-row partial sums of the current event: in LDS when the event spans at most WB_PROPS_LROWS rows (the final
     // accumulation over rows is sequential by contract; from global memory every row costs a dependent round trip)
@@ -125,6 +127,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         WB_SINGLE
         bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
         nlong[0] = 0;
+        wseen[0] = 0;
         WB_END_SINGLE
         WB_PFOR(k, n)
             const uint32_t v = wb_event_vertex(d, pts, (int)k);
@@ -171,7 +174,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         // B: suffix sums -> winding number != 0.  Cells are stored column-major (x outer, y inner): the lane = row
         //    sweeps below are coalesced, and the 8-wide chunks let the loads of a chunk issue back to back
         WB_PFOR(rr, rows)
-            int run = 0;
+            int run = 0, seen = 0;
             int* col = cells + rr;
             for (int x = cols - 1; x >= 0; x -= 8) {
                 int v[8];
@@ -180,9 +183,11 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     run += v[q];
+                    seen |= (run > 0 ? 1 : 0) | (run < 0 ? 2 : 0) | ((run > 1 || run < -1) ? 4 : 0);
                     if (x - q >= 0) col[(size_t)(x - q) * rows] = run != 0 ? 1 : 0;
                 }
             }
+            if (seen & ~wseen[0]) wb_atomic_or(&wseen[0], seen);
         WB_END_PFOR
         // C: rim: lattice points closer than r to an edge (boundary points included: d = 0)
         WB_PFOR(k, n)
@@ -361,6 +366,9 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         }
         a.ev_sums[(size_t)e * 5 + 1] = mv;
         a.ev_sums[(size_t)e * 5 + 2] = it;
+        // a simple polygon has ONE non-zero winding number, +1 or -1 (events whose polygon is not simple are
+        // flagged; the reference hands such polygons to GEOS' make_valid, index_utils.py:164, which is unpinned here)
+        a.ev_flags[e] = (!full && ((wseen[0] & 4) || (wseen[0] & 3) == 3)) ? 1 : 0;
         a.ev_ncells[e] = (int)nc;
         long long off = -1;
         if (a.want_cells) {

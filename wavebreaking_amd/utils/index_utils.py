@@ -72,6 +72,12 @@ def _clip_halfplane(ring, L, keep_le):
     return pieces
 
 
+def split_index_polygon(polygon, nlon):
+    """index_utils.py:148-166: the index polygon without the strip nlon - 1 < x < nlon, as float rings in index coordinates"""
+    coords = np.asarray(polygon).astype("int")
+    return _clip_halfplane(coords, nlon - 1, True) + _clip_halfplane(coords, nlon, False)
+
+
 def transform_polygon_rings(polygon, lon, lat, nlon):
     """One event: index polygon -> list of (lon, lat) rings (index_utils.py:129-173).
 
@@ -87,8 +93,7 @@ def transform_polygon_rings(polygon, lon, lat, nlon):
 
     if not (coords[:, 0] >= nlon).any():                                   # :136
         return [to_lonlat(coords)]
-    pieces = _clip_halfplane(coords, nlon - 1, True) + _clip_halfplane(coords, nlon, False)
-    return [to_lonlat(p) for p in pieces]
+    return [to_lonlat(p) for p in split_index_polygon(coords, nlon)]
 
 
 def transform_polygons(polygons, lon, lat, nlon):
