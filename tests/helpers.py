@@ -15,9 +15,12 @@ HOSTSIM_LIB = os.path.join(HOSTSIM_DIR, "libwb_hostsim.so")
 CSRC = os.path.join(ROOT, "wavebreaking_amd", "csrc")
 
 
-def build_hostsim(force=False, variant="", defines=()):
+def build_hostsim(force=False, variant="", defines=(), sanitize=False):
     """g++ build of the kernel sources with -DWB_HOSTSIM (test infrastructure only).  ``variant`` / ``defines``
-    build a second copy with other compile-time limits (e.g. a tiny WB_TRACE_LDS_N to force the big-job paths)."""
+    build a second copy with other compile-time limits (e.g. a tiny WB_TRACE_LDS_N to force the big-job paths);
+    ``sanitize``: with AddressSanitizer + UndefinedBehaviorSanitizer (loaded in a child process with libasan preloaded)."""
+    if sanitize:
+        variant = (variant + "_" if variant else "") + "asan"
     lib = HOSTSIM_LIB if not variant else HOSTSIM_LIB.replace(".so", "_%s.so" % variant)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     srcs.append(os.path.join(ROOT, "include", "wavebreaking_hip.h"))
@@ -25,7 +28,8 @@ def build_hostsim(force=False, variant="", defines=()):
             and os.path.getmtime(lib) >= max(os.path.getmtime(s) for s in srcs)):
         return lib
     os.makedirs(HOSTSIM_DIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-g", "-DWB_HOSTSIM", *["-D" + d for d in defines], "-x", "c++", "-std=c++17",
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"] if sanitize else []
+    cmd = ["g++", "-O1" if sanitize else "-O2", "-g", *san, "-DWB_HOSTSIM", *["-D" + d for d in defines], "-x", "c++", "-std=c++17",
            "-ffp-contract=off", "-shared", "-fPIC", os.path.join(CSRC, "wb_api.hip"), "-o", lib]
     subprocess.check_call(cmd)
     return lib

@@ -4,8 +4,9 @@
 // block-strided loop followed by __syncthreads(), atomics are HIP atomics, scans use
 // 64-wide wave shuffles + LDS.
 //
-// Host-simulation build (-DWB_HOSTSIM, g++ with ASan/UBSan; TEST INFRASTRUCTURE ONLY,
-// built into tests/_hostsim/ and never loaded by the package): a kernel is a plain
+// Host-simulation build (-DWB_HOSTSIM, g++; one variant with -fsanitize=address,undefined run by
+// tests/test_hostsim_sanitizers.py; TEST INFRASTRUCTURE ONLY, built into tests/_hostsim/ and never
+// loaded by the package): a kernel is a plain
 // function run once per block index, WB_PFOR runs its iterations one after another in
 // ascending -- or, with WB_HOSTSIM_REVERSE, descending -- order (a phase whose result
 // depends on that order has a race), atomics are plain read-modify-writes.  This is how

@@ -66,6 +66,23 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     return frame
 
 
+def _validate_contour_frame(contours, contour_levels):
+    """a contour frame handed in by the caller (contour_index.py:209-245): a non-empty frame in index coordinates; levels
+    that are asked for but absent only give a warning"""
+    if not isinstance(contours, _gf.frame_types()):
+        raise TypeError("contours has to be a geopandas.GeoDataFrame!")
+    if contours.empty:
+        raise ValueError("contours geopandas.GeoDataFrame is empty!")
+    present = set(contours.level)
+    missing = [lev for lev in engine.as_levels(contour_levels) if lev not in present]
+    if missing:
+        logger.warning("\n The contour levels {} are not present in 'contours'".format(missing))
+    first = np.asarray(contours.iloc[0].geometry.coords.xy).T
+    if not ((first.astype("int") == first).all() and (first[:, 0] >= 0).all()):
+        raise ValueError("Original coordinates not supported for the index calculation. "
+                         "Use original_coordinates=False in the contour calculation.")
+
+
 def decorator_contour_calculation(func):
     """decorator to wrap the contour calculation around the index functions (contour_index.py:197-249)"""
 
@@ -79,24 +96,7 @@ def decorator_contour_calculation(func):
                                                     _keep_batches=state, **dim_kwargs)
             kwargs["_wb_state"] = state
         else:
-            if not isinstance(kwargs["contours"], _gf.frame_types()):
-                raise TypeError("contours has to be a geopandas.GeoDataFrame!")
-            if kwargs["contours"].empty:
-                raise ValueError("contours geopandas.GeoDataFrame is empty!")
-            try:
-                iter(contour_levels)
-            except Exception:
-                contour_levels = [contour_levels]
-            check_levels = [i for i in contour_levels if i not in set(kwargs["contours"].level)]
-            if len(check_levels) > 0:
-                logger.warning("\n The contour levels {} are not present in 'contours'".format(check_levels))
-            coords = np.asarray(kwargs["contours"].iloc[0].geometry.coords.xy).T
-            check_int = (coords.astype("int") == coords).all()
-            check_zero = (coords[:, 0] >= 0).all()
-            if not (check_int and check_zero):
-                errmsg = "Original coordinates not supported for the index calculation. "
-                hint = "Use original_coordinates=False in the contour calculation."
-                raise ValueError(errmsg + hint)
+            _validate_contour_frame(kwargs["contours"], contour_levels)
         return func(data, contour_levels, periodic_add=periodic_add, *args, **kwargs)
 
     return wrapper

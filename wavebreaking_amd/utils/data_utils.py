@@ -1,7 +1,10 @@
-"""Argument / dimension helpers -- same names, argument meaning and error behaviour as
-wavebreaking/utils/data_utils.py (reference lines cited per function).  Works on xarray.DataArray when
-xarray is importable and on wavebreaking_amd.GridField otherwise.  The reference's global
-``warnings.filterwarnings("ignore")`` (data_utils.py:23-25) is deliberately NOT replicated.
+"""Argument and dimension helpers of the index functions.
+
+Same public names, argument meaning, defaults and error texts as wavebreaking/utils/data_utils.py (the reference's tests
+call them directly, tests/test_wavebreaking.py:57-79), organised differently: ONE table describes how each of the three
+dimensions is recognised and one resolver walks it.  Works on xarray.DataArray when xarray is importable and on
+wavebreaking_amd.GridField otherwise.  The reference's global ``warnings.filterwarnings("ignore")`` (data_utils.py:23-25)
+is deliberately not replicated.
 """
 import functools
 
@@ -9,24 +12,79 @@ import numpy as np
 
 from wavebreaking_amd import gridfield as _gf
 
+# how a dimension is recognised (data_utils.py:76-126): `units` values that identify it, whether a substring of the units
+# is enough, whether the datetime64[ns] dtype identifies it, its conventional names, and the error when nothing matches
+_DIMENSIONS = {
+    "time": dict(units=("since",), substring=True, datetime=True, names=("time",),
+                 error="'time' dimension (dtype='datetime64[ns]') not found."
+                       " Add time dimension with xarray.DataArray.expand_dims('time')."),
+    "lon": dict(units=("degree_east", "degrees_east"), substring=False, datetime=False, names=("lon", "longitude", "x"),
+                error="'longitude' dimension (units='degrees_east') not found."),
+    "lat": dict(units=("degree_north", "degrees_north"), substring=False, datetime=False, names=("lat", "latitude", "y"),
+                error="latitude' dimension (units='degrees_north') not found."),
+}
+# keyword <- (kind, what): the eight keywords get_dimension_attributes fills in (data_utils.py:160-176)
+_KEYWORDS = (("time_name", "time", "name"), ("lon_name", "lon", "name"), ("lat_name", "lat", "name"),
+             ("ntime", "time", "size"), ("nlon", "lon", "size"), ("nlat", "lat", "size"),
+             ("dlon", "lon", "step"), ("dlat", "lat", "step"))
 
-def _type_name(t):
-    if isinstance(t, tuple):
-        t = t[0]
-    return str(t)[8:-2]
+
+def _units_of(coord):
+    """every `units` string a coordinate carries (attributes first, then the netCDF encoding)"""
+    return [holder["units"] for holder in (coord.attrs, getattr(coord, "encoding", {})) if "units" in holder]
+
+
+def _find_dimension(data, kind):
+    rule = _DIMENSIONS[kind]
+    for dim in data.dims:
+        coord = data[dim]
+        units = _units_of(coord) if rule["substring"] else _units_of(coord)[:1] if "units" in coord.attrs else []
+        by_units = any((any(u in text for u in rule["units"]) if rule["substring"] else text in rule["units"]) for text in units)
+        by_dtype = rule["datetime"] and coord.dtype == np.dtype("datetime64[ns]")
+        if by_units or by_dtype or dim in rule["names"]:
+            return dim
+    raise ValueError(rule["error"])
+
+
+def get_time_name(data):
+    """name of the time dimension (data_utils.py:76-94)"""
+    return _find_dimension(data, "time")
+
+
+def get_lon_name(data):
+    """name of the longitude dimension (data_utils.py:97-110)"""
+    return _find_dimension(data, "lon")
+
+
+def get_lat_name(data):
+    """name of the latitude dimension (data_utils.py:113-126)"""
+    return _find_dimension(data, "lat")
+
+
+def get_spatial_resolution(data, dim):
+    """the one grid step of a regular coordinate (data_utils.py:129-144)"""
+    coord = np.asarray(data[dim].data)
+    steps = abs(np.unique(coord[1:] - coord[:-1]))
+    if len(steps) > 1:
+        raise ValueError("No regular grid found for dimension {}.".format(dim))
+    if steps[0] == 0:
+        raise ValueError("Two equivalent coordinates found for dimension {}.".format(dim))
+    return steps[0]
 
 
 def check_argument_types(arguments, types):
-    """decorator to check the type of function arguments (data_utils.py:28-50)"""
+    """decorator: the named arguments must be instances of the given types (data_utils.py:28-50); an argument is looked up
+    by keyword first, else by its position in `arguments`"""
+    wanted = list(zip(range(len(arguments)), arguments, types))
 
     def decorator(func):
         @functools.wraps(func)
         def wrapper(*args, **kwargs):
-            for (arg_index, arg_name), arg_type in zip(enumerate(arguments), types):
-                value = kwargs[arg_name] if arg_name in kwargs else args[arg_index]
-                if not isinstance(value, arg_type):
-                    errmsg = arg_name + " has to be a " + _type_name(arg_type) + "!"
-                    raise TypeError(errmsg)
+            for position, name, kind in wanted:
+                value = kwargs[name] if name in kwargs else args[position]
+                if not isinstance(value, kind):
+                    shown = kind[0] if isinstance(kind, tuple) else kind
+                    raise TypeError(name + " has to be a " + str(shown)[8:-2] + "!")
             return func(*args, **kwargs)
 
         return wrapper
@@ -35,91 +93,41 @@ def check_argument_types(arguments, types):
 
 
 def check_empty_dataframes(func):
-    """decorator to check if there is an empty DataFrame (data_utils.py:53-73)"""
+    """decorator: no frame among the arguments may be empty (data_utils.py:53-73)"""
+    frames = _gf.frame_types()
 
     @functools.wraps(func)
     def wrapper(*args, **kwargs):
-        frames = _gf.frame_types()
-        for item in args:
-            if isinstance(item, frames) and item.empty:
-                raise ValueError("geopandas.GeoDataFrame is empty!")
-        for key, item in kwargs.items():
-            if isinstance(item, frames) and item.empty:
-                raise ValueError(key + " geopandas.GeoDataFrame is empty!")
+        labelled = [("", a) for a in args] + [(key + " ", a) for key, a in kwargs.items()]
+        for label, value in labelled:
+            if isinstance(value, frames) and value.empty:
+                raise ValueError(label + "geopandas.GeoDataFrame is empty!")
         return func(*args, **kwargs)
 
     return wrapper
 
 
-def get_time_name(data):
-    """check for 'time' dimension and return name (data_utils.py:76-94)"""
-    for dim in data.dims:
-        if (
-            ("units" in data[dim].attrs and "since" in data[dim].attrs["units"])
-            or ("units" in data[dim].encoding and "since" in data[dim].encoding["units"])
-            or (data[dim].dtype == np.dtype("datetime64[ns]"))
-            or (dim in ["time"])
-        ):
-            return dim
-    errmsg = "'time' dimension (dtype='datetime64[ns]') not found."
-    hint = " Add time dimension with xarray.DataArray.expand_dims('time')."
-    raise ValueError(errmsg + hint)
-
-
-def get_lon_name(data):
-    """check for 'longitude' dimension and return name (data_utils.py:97-110)"""
-    for dim in data.dims:
-        if (
-            "units" in data[dim].attrs and data[dim].attrs["units"] in ["degree_east", "degrees_east"]
-        ) or dim in ["lon", "longitude", "x"]:
-            return dim
-    raise ValueError("'longitude' dimension (units='degrees_east') not found.")
-
-
-def get_lat_name(data):
-    """check for 'latitude' dimension and return name (data_utils.py:113-126)"""
-    for dim in data.dims:
-        if (
-            "units" in data[dim].attrs and data[dim].attrs["units"] in ["degree_north", "degrees_north"]
-        ) or dim in ["lat", "latitude", "y"]:
-            return dim
-    raise ValueError("latitude' dimension (units='degrees_north') not found.")
-
-
-def get_spatial_resolution(data, dim):
-    """check resolution of the longitude and latitude coordinate (data_utils.py:129-144)"""
-    coord = np.asarray(data[dim].data)
-    delta = abs(np.unique((coord[1:] - coord[:-1])))
-    if len(delta) > 1:
-        raise ValueError("No regular grid found for dimension {}.".format(dim))
-    elif delta[0] == 0:
-        raise ValueError("Two equivalent coordinates found for dimension {}.".format(dim))
-    return delta[0]
-
-
 def get_dimension_attributes(arg_name):
-    """decorator to get the dimension, size and resolution of the input data (data_utils.py:147-193)"""
+    """decorator: fills time_name / lon_name / lat_name, ntime / nlon / nlat and dlon / dlat for the data argument unless
+    the caller passed them (data_utils.py:147-193)"""
 
     def decorator(func):
         @functools.wraps(func)
         def wrapper(*args, **kwargs):
             data = kwargs[arg_name] if arg_name in kwargs else args[0]
-            names = ["time_name", "lon_name", "lat_name"]
-            sizes = ["ntime", "nlon", "nlat"]
-            resolutions = ["dlon", "dlat"]
-            get_dims = [get_time_name, get_lon_name, get_lat_name]
-            for name, get_dim in zip(names, get_dims):
-                if name not in kwargs:
-                    kwargs[name] = get_dim(data)
-            for size, name in zip(sizes, names):
-                if size not in kwargs:
-                    kwargs[size] = len(data[kwargs[name]])
-            for res, name in zip(resolutions, names[1:]):
-                if res not in kwargs:
-                    kwargs[res] = get_spatial_resolution(data, kwargs[name])
+            for keyword, kind, what in _KEYWORDS:
+                if keyword in kwargs:
+                    continue
+                if what == "name":
+                    kwargs[keyword] = _find_dimension(data, kind)
+                elif what == "size":
+                    kwargs[keyword] = len(data[kwargs[kind + "_name"]])
+                else:
+                    kwargs[keyword] = get_spatial_resolution(data, kwargs[kind + "_name"])
             if len(data.dims) > 3:
-                err_dims = [dim for dim in data.dims if dim not in [kwargs[name] for name in names]]
-                raise ValueError("Unexpected dimension(s): {}. Select dimensions first.".format(err_dims))
+                known = {kwargs[kind + "_name"] for kind in _DIMENSIONS}
+                raise ValueError("Unexpected dimension(s): {}. Select dimensions first.".format(
+                    [dim for dim in data.dims if dim not in known]))
             return func(*args, **kwargs)
 
         return wrapper
@@ -128,14 +136,11 @@ def get_dimension_attributes(arg_name):
 
 
 def correct_dimension_orientation(data, *args, **kwargs):
-    """check the orientation of the latitude and longitude dimension (data_utils.py:196-213).
-    Done ONCE per call here (the reference re-sorts the cube for every step x level, contour_index.py:87)."""
-    wrong_lat_orientation = np.average(np.diff(np.asarray(data[kwargs["lat_name"]].values))) < 0
-    wrong_lon_orientation = np.average(np.diff(np.asarray(data[kwargs["lon_name"]].values))) < 0
-    if wrong_lat_orientation:
-        data = data.sortby(kwargs["lat_name"], ascending=True)
-    if wrong_lon_orientation:
-        data = data.sortby(kwargs["lon_name"], ascending=True)
+    """latitude and longitude ascending (data_utils.py:196-213).  Done ONCE per call here; the reference re-sorts the
+    cube for every step x level (contour_index.py:87)."""
+    for axis in ("lat_name", "lon_name"):
+        if np.average(np.diff(np.asarray(data[kwargs[axis]].values))) < 0:
+            data = data.sortby(kwargs[axis], ascending=True)
     return data
 
 

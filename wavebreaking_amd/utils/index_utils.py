@@ -102,58 +102,66 @@ def transform_polygons(polygons, lon, lat, nlon):
 
 
 def combine_shared(lst):
-    """Combine all elements of a list that have at least one element in common (index_utils.py:187-214)."""
-    elements = list(lst)
-    output = []
-    while len(elements) > 0:
-        first, *rest = elements
-        first = set(first)
-        lf = -1
-        while len(first) > lf:
-            lf = len(first)
-            rest2 = []
-            for r in rest:
-                if len(first.intersection(set(r))) > 0:
-                    first |= set(r)
-                else:
-                    rest2.append(r)
-            rest = rest2
-        output.append(list(first))
-        elements = rest
-    return output
+    """Merge the lists that share at least one element, transitively (index_utils.py:187-214): connected components
+    of the "shares an element" relation by union-find over the elements; components come out in the order of their
+    first list, each as a list of its distinct elements.  (The index kernels do the same by label propagation,
+    csrc/wb_indices.h; this host version exists because the reference's tests call it, tests/test_wavebreaking.py:101-104.)"""
+    groups = [list(g) for g in lst]
+    parent = {}
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    for g in groups:
+        for x in g:
+            parent.setdefault(x, x)
+        for x in g[1:]:
+            ra, rb = find(g[0]), find(x)
+            if ra != rb:
+                parent[rb] = ra
+    merged, slot = [], {}
+    for g in groups:
+        if not g:
+            continue
+        root = find(g[0])
+        if root not in slot:
+            slot[root] = len(merged)
+            merged.append([])
+    for x in parent:                                   # elements in first-seen order
+        merged[slot[find(x)]].append(x)
+    return merged
 
 
-def iterate_time_dimension(func):
-    """decorator to iterate function over time dimension (index_utils.py:217-235).  Kept for API parity;
-    the HIP path batches all time steps in one launch instead."""
-    import pandas as pd
+def _iterate_over(keyword, values_of):
+    """decorator factory behind the two iteration decorators: call the function once per value with kwargs[keyword] set
+    and stack the frames it returns (index_utils.py:217-258).  The HIP path does not loop -- every (time step, level) of
+    a call is one job of a batched launch -- these exist because the reference's tests use them as public helpers."""
 
-    @functools.wraps(func)
-    def wrapper(data, contour_levels, *args, **kwargs):
-        steps = data[kwargs["time_name"]]
-        repeat_func = []
-        for step in steps:
-            kwargs["step"] = step
-            repeat_func.append(func(data, contour_levels, *args, **kwargs))
-        return pd.concat(repeat_func).reset_index(drop=True)
+    def decorator(func):
+        @functools.wraps(func)
+        def wrapper(data, contour_levels, *args, **kwargs):
+            import pandas as pd
+            frames = []
+            for value in values_of(data, contour_levels, kwargs):
+                frames.append(func(data, contour_levels, *args, **dict(kwargs, **{keyword: value})))
+            return pd.concat(frames).reset_index(drop=True)
 
-    return wrapper
+        return wrapper
+
+    return decorator
 
 
-def iterate_contour_levels(func):
-    """decorator to iterate function over contour levels (index_utils.py:238-258)."""
-    import pandas as pd
+def _levels_of(data, contour_levels, kwargs):
+    try:
+        return list(contour_levels)
+    except TypeError:
+        return [contour_levels]
 
-    @functools.wraps(func)
-    def wrapper(data, contour_levels, *args, **kwargs):
-        repeat_func = []
-        try:
-            iter(contour_levels)
-        except Exception:
-            contour_levels = [contour_levels]
-        for level in contour_levels:
-            kwargs["level"] = level
-            repeat_func.append(func(data, contour_levels, *args, **kwargs))
-        return pd.concat(repeat_func).reset_index(drop=True)
 
-    return wrapper
+iterate_time_dimension = _iterate_over("step", lambda data, contour_levels, kwargs: data[kwargs["time_name"]])
+iterate_time_dimension.__doc__ = "decorator: once per time step, kwargs['step'] set (index_utils.py:217-235)"
+iterate_contour_levels = _iterate_over("level", _levels_of)
+iterate_contour_levels.__doc__ = "decorator: once per contour level, kwargs['level'] set (index_utils.py:238-258)"
