@@ -15,8 +15,9 @@ shares HBM with two other batches; `--streams 1` runs the passes strictly one af
 
 N > 1: time steps are sharded across ranks (weak scaling: every rank owns --nt steps of the synthetic
 40-year record, rank r starting at r*nt), one all-reduce(max) of the distinct-longitude count
-(contours.exp_lon.max() over the whole frame, streamer_index.py:106) and one gather of the event tables
-to rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+(contours.exp_lon.max() over the whole frame, streamer_index.py:106) and one gather of the event rows and
+polygon vertices to rank 0 over RCCL, device to device (wavebreaking_amd.distributed.gather_device_tables).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -80,6 +81,7 @@ def main():
     for c in pipe.contexts:
         c.set_option("scan_split", a.scan_split)
         c.set_option("scan_variant", a.scan_variant)
+        c.set_option("keep_device", 1 if world > 1 else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
     levels = [-2.0, 2.0]
@@ -116,6 +118,7 @@ def main():
 
     def phase2(c, k, b, g, copy=False):
         w1 = time.perf_counter()
+        b.set_step_offset(t0)
         b.indices(g)
         w2 = time.perf_counter()
         ev = [b.events(i, copy=copy) for i in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
@@ -127,9 +130,10 @@ def main():
                                com_rechecks=b.com_rechecks(),
                                polygons_not_simple=int(sum(int(np.count_nonzero(e["flags"] & 1)) for e in ev)),
                                status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
-                   packed=[wd.pack_events(e, step_offset=t0) for e in ev] if world > 1 else None,
+                   batch=b if world > 1 else None,
                    events=ev if copy else None)
-        b.close()
+        if world == 1:
+            b.close()
         res["wall"] = dict(contours_call=b._wall1, indices_call=1e3 * (w2 - w1), tables_call=1e3 * (w3 - w2),
                            free=1e3 * (time.perf_counter() - w3))
         return res
@@ -137,8 +141,14 @@ def main():
     def collect_pass(keep):
         def collect(k, res):
             w = time.perf_counter()
-            if world > 1:                                                      # exchange (2): one gather to rank 0
-                wd.gather_event_tables(res["packed"], dist, dst=0)
+            if world > 1:
+                # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there)
+                cat = wd.gather_device_tables(res["batch"], dist, dst=0)
+                res["batch"].close()
+                res["batch"] = None
+                if keep and cat is not None:
+                    counts["gathered_events"] = int(sum(e["step"].size for e in cat))
+                    counts["gathered_polygon_vertices"] = int(sum(e["poly_x"].size for e in cat))
             if keep:
                 for name, ms in res["timings"]:
                     stage_ms.setdefault(name, []).append(ms)

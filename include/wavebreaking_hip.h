@@ -142,6 +142,15 @@ int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated);
 /* per-stage device times of the last wb_contours / wb_indices calls, measured with HIP events on the
    context's stream: names is a NUL-separated list */
 int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);
+/* Time-sharded runs (one process per GPU): with the context option "keep_device" = 1, wb_indices also leaves its result ON
+   THE DEVICE -- one row of WB_ROW_WIDTH doubles per event (step + the offset set by wb_set_step_offset, level, contour
+   inside its (step, level), ind1, ind2, box[4], orientation, the five sums, cell count, kind, flags, polygon length, 0;
+   streamers, then overturnings, then cutoffs: n[3]) and the polygon vertices -- so that the gather to rank 0 over RCCL
+   moves device buffers (no host staging).  Pointers are device pointers, valid until the next wb_indices / wb_free_batch. */
+#define WB_ROW_WIDTH 20
+int wb_set_step_offset(wb_batch* b, int64_t first_step);
+int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[3], const int32_t** poly_x, const int32_t** poly_y,
+                         int64_t* nverts);
 void wb_free_batch(wb_batch* b);
 
 /* device memory + synthetic ERA5-shaped PV for the benchmark */

@@ -171,3 +171,70 @@ def test_sharded_calls_return_the_single_process_frames(tmp_path, monkeypatch):
             else:
                 assert frame[col].to_list() == want[col].to_list(), (name, col)
     ctx.close()
+
+
+WORKER3 = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+from wavebreaking_amd import distributed as wd
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+NT = 2                                  # three ranks, two time steps: the last rank owns NO step
+lat, lon = synth.grid(2.5)
+first, count = wd.shard(NT, rank, world)
+b = None
+local_max = 0
+if count:
+    pv = synth.pv_field(first, count, lat, lon, eps=0.2)
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    ctx.set_option("keep_device", 1)
+    b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 2.5, 2.5, intensity=pv)
+    local_max = b.max_nux()
+g = wd.global_max_nux(local_max, dist)
+if b is not None:
+    b.set_step_offset(first)
+    b.indices(g)
+out = wd.gather_device_tables(b, dist, dst=0)
+if rank == 0:
+    np.savez(sys.argv[2], g=g, **{"%s_%d" % (k, i): v for i, ev in enumerate(out) for k, v in ev.items()})
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_three_ranks_one_without_steps_gather_complete_catalogue(tmp_path):
+    """exchange (2) as bench.py runs it for N > 1 (wavebreaking_amd.distributed.gather_device_tables): packed rows AND polygon
+    vertices reach rank 0; a rank whose shard is empty takes part in both collectives"""
+    helpers.build_hostsim()
+    script = tmp_path / "worker3.py"
+    script.write_text(WORKER3)
+    out = tmp_path / "rank0.npz"
+    port = _free_port()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(0, 2, lat, lon, eps=0.2)
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 2.5, 2.5, intensity=pv)
+    assert int(got["g"]) == b.max_nux()
+    b.indices()
+    total = 0
+    for i in (0, 1, 2):
+        ev = b.events(i)
+        for k in ("step", "level_idx", "ind1", "ind2", "box", "orientation", "ncells", "flags", "poly_offset", "poly_x", "poly_y"):
+            assert np.array_equal(got["%s_%d" % (k, i)], ev[k]), (i, k)
+        assert np.array_equal(got["sums_%d" % i], ev["sums"])
+        total += ev["step"].size
+    assert total > 10
+    b.close()

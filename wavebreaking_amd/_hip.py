@@ -48,6 +48,7 @@ class WbEventTable(C.Structure):
 
 STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
 EVENT_NOT_SIMPLE = 1
+ROW_WIDTH = 20
 STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS, STATUS_LEVEL_ORDER = 1, 2, 4, 8, 16, 32
 
 
@@ -88,6 +89,9 @@ class Library:
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.wb_set_step_offset.argtypes = [C.c_void_p, C.c_int64]
+        lib.wb_get_device_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         lib.wb_get_evaluated_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.wb_get_com_rechecks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
@@ -460,6 +464,20 @@ class Batch:
         a, c = C.c_int64(), C.c_int64()
         self.ctx.L.lib.wb_get_pair_stats(self.h, C.byref(a), C.byref(c))
         return int(a.value), int(c.value)
+
+    def set_step_offset(self, first_step):
+        """first time step of this batch in the whole record (added to the step column of the device rows)"""
+        self.ctx.L.lib.wb_set_step_offset(self.h, int(first_step))
+
+    def device_tables(self):
+        """(rows pointer, (n streamers, n overturnings, n cutoffs), poly_x pointer, poly_y pointer, vertices): the result
+        of the last indices() as DEVICE buffers (context option "keep_device")"""
+        rows, px, py = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = (C.c_int64 * 3)()
+        nv = C.c_int64()
+        if self.ctx.L.lib.wb_get_device_tables(self.h, C.byref(rows), n, C.byref(px), C.byref(py), C.byref(nv)) != 0:
+            raise RuntimeError("wb_get_device_tables: set the context option keep_device before indices()")
+        return rows.value or 0, (int(n[0]), int(n[1]), int(n[2])), px.value or 0, py.value or 0, int(nv.value)
 
     def evaluated_pairs(self):
         """pairs whose great-circle term the all-pairs kernel actually evaluated (last indices() call)"""

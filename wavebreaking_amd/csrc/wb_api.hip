@@ -47,6 +47,7 @@ struct wb_ctx {
     int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) == 0) ? 0 : 1;
     int scan_debug = 0;
     int scan_variant = 1;                     // streaming scan: ring depth x waves per SIMD (0: 8 x 6, 1: 10 x 5, 2: 13 x 4, 3: 6 x 8)
+    int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
@@ -393,6 +394,11 @@ struct wb_batch {
     WbCtl* d_ctl = nullptr;                 // device control block of the batch
     WbCtl h_ctl;                            // its phase-1 values (host copy)
     std::vector<std::pair<void*, size_t>> hres;   // pinned host blocks of the result copies
+    // device-resident result of the last wb_indices (kept when the context option "keep_device" is set): packed rows and
+    // polygon vertices for the device-to-device gather of a time-sharded run
+    double* dev_rows = nullptr;
+    int *dev_px = nullptr, *dev_py = nullptr, *d_job_level = nullptr;
+    long long dev_n[3] = {0, 0, 0}, dev_nv = 0, step_offset = 0;
     long long com_rechecks[3] = {0, 0, 0};     // events / boxes whose centre-of-mass sums were re-evaluated in the reference's order
     // batches built from a user-supplied contour frame: one job per contour row
     std::vector<int> job_step, job_level;
@@ -836,6 +842,20 @@ extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* can
     *candidate_pairs = b->pair_stats[1];
     return 0;
 }
+extern "C" int wb_set_step_offset(wb_batch* b, int64_t first_step) {
+    if (!b) return 1;
+    b->step_offset = first_step;
+    return 0;
+}
+extern "C" int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[3], const int32_t** poly_x, const int32_t** poly_y,
+                                    int64_t* nverts) {
+    if (!b || !b->dev_rows) return 1;
+    *rows = b->dev_rows;
+    n[0] = b->dev_n[0]; n[1] = b->dev_n[1]; n[2] = b->dev_n[2];
+    *poly_x = b->dev_px; *poly_y = b->dev_py;
+    *nverts = b->dev_nv;
+    return 0;
+}
 extern "C" int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated) {
     if (!b) return 1;
     *evaluated = b->pair_stats[2];
@@ -1036,6 +1056,39 @@ WB_KERNEL(wb_k_poly_offsets, WbEvFillArgs a) {
     a.ctl->poly_total = total;
     if ((long long)total > a.cap_poly) a.ctl->overflow |= 2;
     WB_END_SINGLE
+}
+
+// one row of 20 doubles per event, on the device, for the rank-0 gather of a time-sharded run (no host staging):
+// step (+ the shard's first step), level, contour inside its (step, level) job, ind1, ind2, box[4], orientation, the five
+// sums, cell count, kind, flags, polygon length
+#define WB_ROW_WIDTH 20
+WB_KERNEL(wb_k_pack_rows, const WbCtl* ctl, const int* ev, const double* sums, const int* ncells, const int* flags,
+          const long long* poff, const int* job_step, const int* job_level, int nlev, long long step_offset, double* rows) {
+    const int nev = ctl->NE;
+    for (int e0 = WB_BLOCK_ID * 256; e0 < nev; e0 += WB_GRID_DIM * 256) {
+        WB_PFOR(k, 256)
+            const int e = e0 + (int)k;
+            if (e < nev) {
+                const int* d = ev + (size_t)e * 8;
+                double* r = rows + (size_t)e * WB_ROW_WIDTH;
+                const int kind = d[0] & 0xFF, job = d[1];
+                r[0] = (double)((job_step ? job_step[job] : job / nlev) + step_offset);
+                r[1] = (double)(job_level ? job_level[job] : job % nlev);
+                r[2] = (double)d[2];
+                const bool box = kind == WB_EV_OVERTURNING;
+                r[3] = box ? 0.0 : (double)d[3];
+                r[4] = box ? 0.0 : (double)d[4];
+                for (int q = 0; q < 4; ++q) r[5 + q] = box ? (double)d[3 + q] : 0.0;
+                r[9] = (double)(d[0] >> 8);
+                for (int q = 0; q < 5; ++q) r[10 + q] = sums[(size_t)e * 5 + q];
+                r[15] = (double)ncells[e];
+                r[16] = (double)kind;
+                r[17] = (double)flags[e];
+                r[18] = (double)(poff[e + 1] - poff[e]);
+                r[19] = 0.0;
+            }
+        WB_END_PFOR
+    }
 }
 
 // event polygons: vertices of every event, back to back
@@ -1383,6 +1436,19 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         d2h_async(ctx, h_fl, pa.ev_flags, (size_t)NE * sizeof(int));
         if (p.want_cells) d2h_async(ctx, h_coff, pa.ev_cell_off, (size_t)NE * sizeof(long long));
         b->timer.end(ctx);
+        if (ctx->keep_device) {
+            // device copies for the gather: rows packed here, vertex arrays taken out of this attempt's scratch
+            if (b->dev_rows) { bfree_one(b, b->dev_rows); bfree_one(b, b->dev_px); bfree_one(b, b->dev_py); }
+            b->dev_rows = balloc<double>(b, (size_t)(NE + 1) * WB_ROW_WIDTH);
+            if (!b->dev_rows) { release(); return 1; }
+            if (!b->job_level.empty() && !b->d_job_level) b->d_job_level = upload(b, b->job_level);
+            WB_LAUNCH(wb_k_pack_rows, NE < 256 * 1024 ? (NE + 255) / 256 + 1 : 1024, 256, ctl, fa.ev, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
+                      fa.poff, b->d_job_step, b->d_job_level, p.nlevels, b->step_offset, b->dev_rows);
+            b->dev_px = d_px; b->dev_py = d_py;
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == (void*)d_px) { tmp.erase(tmp.begin() + i); break; }
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == (void*)d_py) { tmp.erase(tmp.begin() + i); break; }
+            b->dev_nv = NV;
+        }
         if (dsync(ctx) || side_sync(ctx)) { release(); return 1; }
         fin = hc[1];
         if (p.want_cells) {
@@ -1411,6 +1477,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     b->pair_stats[0] = fin.point_pairs; b->pair_stats[1] = fin.cand_pairs; b->pair_stats[2] = fin.evaluated_pairs;
     for (int q = 0; q < 3; ++q) b->com_rechecks[q] = fin.com_rechecks[q];
     const int NS = fin.NS, NO = fin.NO, NE = fin.NE;
+    b->dev_n[0] = NS; b->dev_n[1] = NO; b->dev_n[2] = NE - NS - NO;
 
     // ---- host tables (sized once, filled with plain loops)
     for (int kind = 0; kind < 3; ++kind) {
@@ -1705,6 +1772,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "scan_split")) { ctx->scan_split = value ? 1 : 0; return 0; }
     if (!strcmp(name, "eager_f2")) { ctx->eager_f2 = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "keep_device")) { ctx->keep_device = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;

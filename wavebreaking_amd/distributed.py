@@ -90,6 +90,91 @@ def gather_event_tables(tables, dist=None, dst=0):
     return [np.concatenate(v, axis=0) if v else np.zeros((0, width)) for v in res]
 
 
+# ------------------------------------------------------------------------------------------------ device-resident gather
+class _DeviceBuffer:
+    """a device allocation of the C ABI as a CUDA-array-interface object (zero-copy torch.as_tensor)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _wrap(ptr, shape, np_dtype, on_gpu):
+    """torch tensor over a buffer of the library: device memory of the HIP build (no copy), host memory of the
+    host-simulation build used by the CPU tests"""
+    import ctypes
+    import torch
+    n = int(np.prod(shape))
+    if n == 0 or not ptr:
+        return torch.zeros(tuple(shape), dtype=torch.from_numpy(np.zeros(0, np_dtype)).dtype, device="cuda" if on_gpu else "cpu")
+    if on_gpu:
+        return torch.as_tensor(_DeviceBuffer(ptr, shape, np.dtype(np_dtype).str), device="cuda")
+    buf = (ctypes.c_char * (n * np.dtype(np_dtype).itemsize)).from_address(int(ptr))
+    return torch.from_numpy(np.frombuffer(buf, dtype=np_dtype).reshape(shape).copy())
+
+
+ROW_FIELDS = dict(step=0, level_idx=1, contour=2, ind1=3, ind2=4, orientation=9, ncells=15, kind=16, flags=17, npoly=18)
+
+
+def rows_to_events(rows, poly_x, poly_y):
+    """packed device rows (n, 20) + the vertices of the same events -> the three event dictionaries of Batch.events()"""
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, 20)
+    npoly = rows[:, 18].astype(np.int64)
+    start = np.cumsum(npoly) - npoly
+    out = []
+    for kind in (0, 1, 2):
+        m = rows[:, 16] == kind
+        r = rows[m]
+        vidx = np.concatenate([np.arange(s0, s0 + k) for s0, k in zip(start[m], npoly[m])]) if m.any() else np.zeros(0, np.int64)
+        i32 = lambda c: r[:, c].astype(np.int32)
+        out.append(dict(step=i32(0), level_idx=i32(1), contour=r[:, 2].astype(np.int64), ind1=i32(3), ind2=i32(4),
+                        box=r[:, 5:9].astype(np.int32), orientation=i32(9), sums=r[:, 10:15].copy(), ncells=i32(15), flags=i32(17),
+                        poly_offset=np.concatenate([[0], np.cumsum(npoly[m])]).astype(np.int64),
+                        poly_x=np.asarray(poly_x)[vidx].astype(np.int32), poly_y=np.asarray(poly_y)[vidx].astype(np.int32)))
+    return out
+
+
+def gather_device_tables(batch, dist=None, dst=0):
+    """exchange (2) without host staging: the packed event rows and polygon vertices that ``Batch.indices`` left on the
+    device (context option "keep_device") travel device-to-device in one gather each (sizes first); ``dst`` copies the
+    concatenation to the host ONCE and returns [streamers, overturnings, cutoffs] in rank (= time) order -- the complete
+    catalogue including geometry; the other ranks return None.  ``batch`` may be None on a rank without time steps."""
+    import torch
+    single = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    if batch is None:
+        ptr, n3, px, py, nv, on_gpu = 0, (0, 0, 0), 0, 0, 0, (not single and dist.get_backend() == "nccl")
+    else:
+        ptr, n3, px, py, nv = batch.device_tables()
+        on_gpu = batch.ctx.L.backend == "hip"
+    ne = sum(n3)
+    rows = _wrap(ptr, (ne, 20), np.float64, on_gpu)
+    vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+    if single:
+        return rows_to_events(rows.cpu().numpy(), vx.cpu().numpy(), vy.cpu().numpy())
+    world, rank, dev = dist.get_world_size(), dist.get_rank(), rows.device
+    counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts)
+    allc = torch.stack(allc).cpu().numpy()
+    me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
+    rbuf = torch.zeros((max(me, 1), 20), dtype=torch.float64, device=dev)
+    vbuf = torch.zeros((2, max(mv, 1)), dtype=torch.int32, device=dev)
+    if ne:
+        rbuf[:ne] = rows
+    if nv:
+        vbuf[0, :nv] = vx
+        vbuf[1, :nv] = vy
+    rout = [torch.zeros_like(rbuf) for _ in range(world)] if rank == dst else None
+    vout = [torch.zeros_like(vbuf) for _ in range(world)] if rank == dst else None
+    dist.gather(rbuf, rout, dst=dst)
+    dist.gather(vbuf, vout, dst=dst)
+    if rank != dst:
+        return None
+    rcat = torch.cat([rout[r][: int(allc[r, 0])] for r in range(world)]).cpu().numpy()      # the one copy to the host
+    vcat = torch.cat([vout[r][:, : int(allc[r, 1])] for r in range(world)], dim=1).cpu().numpy()
+    # rows are (streamers, overturnings, cutoffs) per rank: rows_to_events selects by kind, rank order = time order
+    return rows_to_events(rcat, vcat[0], vcat[1])
+
+
 # ------------------------------------------------------------------------------------------------ whole calls
 def _time_block(data, time_name, first, count):
     """``data`` restricted to time steps [first, first + count)."""
