@@ -144,7 +144,7 @@ def main():
             if world > 1:
                 # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there)
                 cat = wd.gather_device_tables(res["batch"], dist, dst=0)
-                res["batch"].close()
+                pipe.close_batch(k, res["batch"])          # a context is single-threaded: its own worker frees the batch
                 res["batch"] = None
                 if keep and cat is not None:
                     counts["gathered_events"] = int(sum(e["step"].size for e in cat))
@@ -162,7 +162,11 @@ def main():
     def solo_pass(c, copy=False):
         """a single pass alone on the device"""
         b = phase1(c, 0)
-        return phase2(c, 0, b, reduce_max(b.max_nux()), copy=copy)
+        res = phase2(c, 0, b, reduce_max(b.max_nux()), copy=copy)
+        if res.get("batch") is not None:                       # N > 1: phase2 leaves the batch open for the gather
+            res["batch"].close()
+            res["batch"] = None
+        return res
 
     def one_pass(copy=False):
         return solo_pass(ctx, copy)

@@ -384,7 +384,8 @@ class Batch:
 
     def close(self):
         if self.h:
-            self.ctx.L.lib.wb_free_batch(self.h)
+            if self.ctx.h:                      # a batch that outlived its context was released with it
+                self.ctx.L.lib.wb_free_batch(self.h)
             self.h = None
 
     def __del__(self):

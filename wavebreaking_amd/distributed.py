@@ -150,6 +150,8 @@ def gather_device_tables(batch, dist=None, dst=0):
     vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
     if single:
         return rows_to_events(rows.cpu().numpy(), vx.cpu().numpy(), vy.cpu().numpy())
+    if dist.get_backend() != "nccl":                        # dry runs of the N > 1 logic over gloo: CPU tensors
+        rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
     world, rank, dev = dist.get_world_size(), dist.get_rank(), rows.device
     counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(counts) for _ in range(world)]

@@ -31,6 +31,10 @@ class BatchPipeline:
         for c in self.contexts:
             c.close()
 
+    def close_batch(self, k, batch):
+        """free batch k on the worker thread of its context (a context, including its allocator, belongs to one thread)"""
+        return self._workers[k % self.depth].submit(batch.close)
+
     def run(self, n, contours, reduce_max, indices, collect):
         """``n`` batches.  Worker of context ``k % depth``:  ``b = contours(ctx, k)`` then, once the caller's thread has
         turned the batch's local maximum into ``g = reduce_max(b.max_nux())``, ``r = indices(ctx, k, b, g)`` (which also
