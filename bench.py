@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 4)),
                     help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-intensity", action="store_true")
+    ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("WB_BENCH_E2E_STEPS", 365)),
+                    help="time steps of the end-to-end (drop-in API, host-resident cube, upload included) measurement; 0 = skip")
     ap.add_argument("--scan-split", type=int, default=int(os.environ.get("WB_BENCH_SCAN_SPLIT", 1)),
                     help="1: streaming scan (patch capture) + list build kernel; 0: single classify-and-emit kernel")
     ap.add_argument("--scan-variant", type=int, default=int(os.environ.get("WB_BENCH_SCAN_VARIANT", 1)),
@@ -223,6 +225,8 @@ def main():
             "host_wall_ms": {k: float(np.mean(v)) for k, v in wall.items()},
             "counts": counts,
         }
+        if world == 1 and a.e2e_steps > 0:
+            out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass)
         print(json.dumps(out), flush=True)
@@ -247,6 +251,40 @@ def pmc_traffic(nt):
     except Exception:
         pass
     return None
+
+
+def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
+    """What a drop-in user pays (reported alongside, never `value`): a HOST-resident float32 cube handed to the
+    reference-shaped functions, README style -- wb.calculate_streamers / overturnings / cutoffs called one after the other,
+    each tracing its own contours -- from the numpy array to the finished frames with geometry: upload over PCIe
+    (double-buffered, pinned staging), kernels, tables, lon / lat polygons and frame construction included."""
+    import wavebreaking_amd as wb
+    from wavebreaking_amd import synthetic as synth
+    nlat, nlon = lat.size, lon.size
+    pv = ctx.to_host(d_pv, (nt, nlat, nlon), np.float32)
+    inten = ctx.to_host(d_int, (nt, nlat, nlon), np.float32) if d_int else None
+    tm = synth.times(nt)
+    coords = {"time": tm, "lat": wb.gridfield.Coord(lat, {"units": "degrees_north"}), "lon": wb.gridfield.Coord(lon, {"units": "degrees_east"})}
+    data = wb.GridField(pv, ("time", "lat", "lon"), coords, name="PV")
+    idata = wb.GridField(inten, data.dims, coords, name="intensity") if inten is not None else None
+    tic = time.perf_counter()
+    p = ctx.to_device(pv)                                     # the upload alone, for reference
+    t_up = time.perf_counter() - tic
+    ctx.free(p)
+    calls = (("calculate_streamers", wb.calculate_streamers), ("calculate_overturnings", wb.calculate_overturnings),
+             ("calculate_cutoffs", wb.calculate_cutoffs))
+    secs, rows = {}, {}
+    for rep in range(2):                                      # the second round is reported (contexts and tables warm)
+        for name, f in calls:
+            tic = time.perf_counter()
+            frame = f(data=data, contour_levels=levels, intensity=idata)
+            secs[name] = time.perf_counter() - tic
+            rows[name] = int(len(frame))
+    total = sum(secs.values())
+    return {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
+            "upload_GBps": pv.nbytes / t_up / 1e9,
+            "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, H2D included"
+                    % (nt, pv.nbytes / 1e9)}
 
 
 def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):

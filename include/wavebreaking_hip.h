@@ -123,6 +123,20 @@ int wb_batch_max_nux(wb_batch* b);                  /* local max of len(set(x));
    which = bit mask 1 streamers | 2 overturnings | 4 cutoffs */
 int wb_indices(wb_batch* b, int global_max_nux, int which);
 
+/* transform_polygons (index_utils.py:129-184) for a whole event table: the polygons in the data's own coordinates,
+   (lon[x % nlon], lat[y]); an event that reaches the periodic columns is cut at the last meridian into several rings
+   (:148-173).  Event k owns rings ring_offset[k] .. ring_offset[k+1] (none: empty polygon, one: Polygon, several:
+   MultiPolygon), ring q the vertices vert_offset[q] .. vert_offset[q+1] (not repeated at the end).  Same layout as the
+   input of wb_flag_events. */
+typedef struct wb_geometry {
+    int64_t n;
+    const int64_t* ring_offset;
+    int64_t nrings;
+    const int64_t* vert_offset;
+    const double* x;            /* degrees east */
+    const double* y;            /* degrees north */
+} wb_geometry;
+int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* out);
 int wb_get_contours(wb_batch* b, wb_contour_table* out);
 int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */

@@ -46,6 +46,11 @@ class WbEventTable(C.Structure):
     ]
 
 
+class WbGeometry(C.Structure):
+    _fields_ = [("n", C.c_int64), ("ring_offset", C.POINTER(C.c_int64)), ("nrings", C.c_int64),
+                ("vert_offset", C.POINTER(C.c_int64)), ("x", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double))]
+
+
 STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
 EVENT_NOT_SIMPLE = 1
 ROW_WIDTH = 20
@@ -86,6 +91,7 @@ class Library:
         lib.wb_indices.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
         lib.wb_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbEventTable)]
+        lib.wb_get_event_geometry.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbGeometry)]
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -441,6 +447,15 @@ class Batch:
             out["cell_x"] = A(t.cell_x, off[-1] if n else 0, np.int32)
             out["cell_y"] = A(t.cell_y, off[-1] if n else 0, np.int32)
         return out
+
+    def event_geometry(self, kind):
+        """transform_polygons for the whole table: (ring_offset per event, vert_offset per ring, lon, lat) arrays"""
+        g = WbGeometry()
+        if self.ctx.L.lib.wb_get_event_geometry(self.h, int(kind), C.byref(g)) != 0:
+            raise RuntimeError("wb_get_event_geometry failed: " + self.ctx.error())
+        voff = _arr(g.vert_offset, g.nrings + 1, np.int64)
+        nv = int(voff[-1]) if voff.size else 0
+        return _arr(g.ring_offset, g.n + 1, np.int64), voff, _arr(g.x, nv, np.float64), _arr(g.y, nv, np.float64)
 
     def status(self):
         p = C.POINTER(C.c_uint32)()

@@ -12,9 +12,11 @@
 
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "wb_core.h"
+#include "wb_geometry.h"
 #include "wb_indices.h"
 #include "wb_props.h"
 #include "wb_scan.h"
@@ -63,6 +65,8 @@ struct wb_ctx {
     // evicts and restores the process's queues (measured: ~20 ms stall on the next dispatch).
     void* pin = nullptr;
     size_t pin_bytes = 0;
+    void* h2d_pin[2] = {nullptr, nullptr};    // double-buffered staging of large uploads
+    hipEvent_t h2d_ev[2] = {nullptr, nullptr};
 #endif
     // per-grid device tables (trigonometric tables, area weights, the all-pairs reach per latitude row): built once per
     // (lat, lon, resolution, geo_dis) and shared by every batch of the context
@@ -198,15 +202,44 @@ static void* wb_pin(wb_ctx* c, size_t bytes) {
     c->pin_bytes = want;
     return c->pin;
 }
+// Host -> device copy of a large pageable buffer: chunks go through TWO pinned staging buffers, the host memcpy of chunk
+// k + 1 (split over a few threads: one core copies ~10 GB/s, PCIe Gen5 takes ~55) overlapping the DMA of chunk k.
+#define WB_H2D_CHUNK ((size_t)64 << 20)
+#define WB_H2D_THREADS 4
+static void wb_par_memcpy(char* dst, const char* src, size_t n) {
+    if (n < ((size_t)8 << 20)) { memcpy(dst, src, n); return; }
+    std::thread th[WB_H2D_THREADS - 1];
+    const size_t part = (n / WB_H2D_THREADS + 4095) & ~(size_t)4095;
+    for (int t = 1; t < WB_H2D_THREADS; ++t) {
+        const size_t o = (size_t)t * part;
+        if (o >= n) break;
+        const size_t m = n - o < part ? n - o : part;
+        th[t - 1] = std::thread([=]() { memcpy(dst + o, src + o, m); });
+    }
+    memcpy(dst, src, part < n ? part : n);
+    for (int t = 1; t < WB_H2D_THREADS; ++t) if (th[t - 1].joinable()) th[t - 1].join();
+}
 static int h2d(wb_ctx* c, void* d, const void* s, size_t b) {
-    if (b > WB_PIN_THRESHOLD && wb_pin(c, b < ((size_t)256 << 20) ? b : ((size_t)256 << 20))) {
-        for (size_t o = 0; o < b; o += c->pin_bytes) {
-            const size_t n = b - o < c->pin_bytes ? b - o : c->pin_bytes;
-            memcpy(c->pin, (const char*)s + o, n);
-            if (hipMemcpyAsync((char*)d + o, c->pin, n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+    if (b > WB_PIN_THRESHOLD) {
+        if (!c->h2d_pin[0]) {
+            for (int k = 0; k < 2; ++k) {
+                if (hipHostMalloc(&c->h2d_pin[k], WB_H2D_CHUNK, hipHostMallocDefault) != hipSuccess) { c->h2d_pin[k] = nullptr; break; }
+                (void)hipEventCreateWithFlags(&c->h2d_ev[k], hipEventDisableTiming);
+            }
         }
-        return 0;
+        if (c->h2d_pin[0] && c->h2d_pin[1]) {
+            int k = 0;
+            bool used[2] = {false, false};
+            for (size_t o = 0; o < b; o += WB_H2D_CHUNK, k ^= 1) {
+                const size_t n = b - o < WB_H2D_CHUNK ? b - o : WB_H2D_CHUNK;
+                if (used[k] && hipEventSynchronize(c->h2d_ev[k]) != hipSuccess) return 1;      // the buffer's previous DMA is done
+                wb_par_memcpy((char*)c->h2d_pin[k], (const char*)s + o, n);
+                if (hipMemcpyAsync((char*)d + o, c->h2d_pin[k], n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
+                (void)hipEventRecord(c->h2d_ev[k], c->stream);
+                used[k] = true;
+            }
+            return hipStreamSynchronize(c->stream) != hipSuccess;
+        }
     }
     return hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
 }
@@ -413,6 +446,7 @@ struct wb_batch {
         size_t pbase = 0;              // first polygon vertex of this table in wb_batch::poly_x / poly_y
         std::vector<double> sums;
     } ev[3];
+    WbRingSink geo[3];                              // event geometry in lon / lat (wb_get_event_geometry), built on demand
     int32_t *poly_x = nullptr, *poly_y = nullptr;   // polygon vertices of all events (streamers, overturnings, cutoffs)
     size_t poly_n = 0, poly_bytes = 0;
     WbTimer timer;
@@ -491,6 +525,7 @@ void wb_destroy(wb_ctx* c) {
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     for (auto& kv : c->live) (void)hipFree(kv.first);
     if (c->pin) (void)hipHostFree(c->pin);
+    for (int k = 0; k < 2; ++k) { if (c->h2d_pin[k]) (void)hipHostFree(c->h2d_pin[k]); if (c->h2d_ev[k]) (void)hipEventDestroy(c->h2d_ev[k]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -840,6 +875,26 @@ extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* can
     if (!b) return 1;
     *point_pairs = b->pair_stats[0];
     *candidate_pairs = b->pair_stats[1];
+    return 0;
+}
+extern "C" int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* o) {
+    if (!b || !o || kind < 0 || kind > 2) return 1;
+    wb_batch::Ev& t = b->ev[kind];
+    WbRingSink& g = b->geo[kind];
+    g = WbRingSink();
+    const int64_t n = (int64_t)t.step.size();
+    g.ring_offset.push_back(0);
+    g.vert_offset.push_back(0);
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t a = t.polyoff[(size_t)k], e = t.polyoff[(size_t)k + 1];
+        wb_event_rings(b->poly_x + t.pbase + a, b->poly_y + t.pbase + a, e - a, b->lon.data(), b->lat.data(), b->p.nlon, g);
+    }
+    o->n = n;
+    o->ring_offset = g.ring_offset.data();
+    o->nrings = (int64_t)g.vert_offset.size() - 1;
+    o->vert_offset = g.vert_offset.data();
+    o->x = g.x.data();
+    o->y = g.y.data();
     return 0;
 }
 extern "C" int wb_set_step_offset(wb_batch* b, int64_t first_step) {

@@ -16,8 +16,8 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     state = kwargs.get("_wb_state")
     ctx = engine.get_context()
     own = state is not None and contours is state.get("frame")     # the frame the decorator computed a moment ago
-    if own and len(contours) == state["nrows"] and intensity is None:
-        batches, levels = state["batches"], state["levels"]          # contours computed by the decorator: reuse
+    if own and len(contours) == state["nrows"]:
+        batches, levels = state["batches"], state["levels"]          # contours (and fields) the decorator put on the device: reuse
         for b, *_ in batches:
             b.set_index_params(**params)
     else:
@@ -26,7 +26,6 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
                 b.close()
         levels = engine.as_levels(contour_levels)
         if own:
-            # same contours, but the index needs the intensity field on the device too
             batches = engine.contour_batches(prep, levels, periodic_add, params)
         else:
             table, levels = engine.frame_to_table(contours, prep.times, levels)
@@ -41,7 +40,9 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     which = {_hip.STREAMERS: dict(streamers=True, overturnings=False, cutoffs=False),
              _hip.OVERTURNINGS: dict(streamers=False, overturnings=True, cutoffs=False),
              _hip.CUTOFFS: dict(streamers=False, overturnings=False, cutoffs=True)}[kind]
-    rows = []
+    # per batch: events + their geometry in lon / lat (transform_polygons for the whole table in the library); no per-event
+    # Python work except wrapping a ring array into a geometry object
+    parts = []
     batches = list(batches)
     for bi, (b, pos, t0) in enumerate(batches):
         b.indices(g, **which)
@@ -52,29 +53,44 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
                 ob.close()
             raise
         ev = b.events(kind)
-        for k in range(ev["step"].size):
-            lvl = ev["level_idx"][k]
-            rows.append((int(ev["step"][k]) + t0 if pos is not None else k, pos[int(lvl)] if pos is not None else int(lvl), bi, k))
-        batches[bi] = (b, pos, ev, t0)
-    if len(batches) > 1:
-        rows.sort(key=lambda r: (r[0], r[1]))          # stable: time-major, level-minor, event order inside kept
-    cols = dict(date=[], level=[])
-    polys, sums, orient = [], [], []
-    for _, lpos, bi, k in rows:
-        b, pos, ev, t0 = batches[bi]
-        cols["date"].append(prep.times[int(ev["step"][k]) + t0])
-        cols["level"].append(levels[lpos])
-        a, e = int(ev["poly_offset"][k]), int(ev["poly_offset"][k + 1])
-        polys.append(np.c_[ev["poly_x"][a:e], ev["poly_y"][a:e]])        # streamer_index.py:269-272 / box / cutoff_index.py:96
-        if kind == _hip.OVERTURNINGS:
-            orient.append("cyclonic" if ev["orientation"][k] == 0 else "anticyclonic")
-        sums.append(ev["sums"][k])
+        n = ev["step"].size
+        if n == 0:
+            continue
+        ring_off, vert_off, gx, gy = b.event_geometry(kind)
+        if pos is not None:
+            step = ev["step"].astype(np.int64) + t0
+            lpos = np.asarray(pos, dtype=np.int64)[ev["level_idx"]]
+        else:                                   # a frame handed in: one job per contour row, rows keep the frame's order
+            step = ev["step"].astype(np.int64)
+            lpos = ev["level_idx"].astype(np.int64)
+        parts.append(dict(step=step, lpos=lpos, order_key=(step if pos is not None else np.arange(n)), sums=ev["sums"],
+                          orientation=ev["orientation"], ring_off=ring_off, vert_off=vert_off, gx=gx, gy=gy, n=n))
     for b, *_ in batches:
         b.close()
-    if len(rows) == 0:
+    if not parts:
         return _gf.empty_frame()                                          # streamer_index.py:278-279
-    com, mean_var, inten, area = iu.properties_from_sums(np.asarray(sums), prep.lon, prep.lat, prep.nlon)
+    step = np.concatenate([p["step"] for p in parts])
+    lpos = np.concatenate([p["lpos"] for p in parts])
+    sums = np.concatenate([p["sums"] for p in parts])
+    orient_code = np.concatenate([p["orientation"] for p in parts])
+    # geometry objects, batch after batch (the three cases of index_utils.py:167-173 in make_polygon)
+    geoms = []
+    for p in parts:
+        xy = np.c_[p["gx"], p["gy"]]
+        ro, vo = p["ring_off"], p["vert_off"]
+        for k in range(p["n"]):
+            geoms.append(_gf.make_polygon([xy[vo[q]:vo[q + 1]] for q in range(ro[k], ro[k + 1])]))
+    if len(parts) > 1 and batches[0][1] is not None:
+        # several batches (time blocks, level groups): time-major, level-minor, event order inside a (step, level) kept
+        order = np.lexsort((np.arange(step.size), lpos, step))
+        step, lpos, sums, orient_code = step[order], lpos[order], sums[order], orient_code[order]
+        geoms = [geoms[i] for i in order]
+    level_values = np.empty(len(levels), dtype=object)
+    level_values[:] = list(levels)
+    cols = dict(date=np.asarray(prep.times)[step], level=list(level_values[lpos]))
+    com, mean_var, inten, area = iu.properties_from_sums(sums, prep.lon, prep.lat, prep.nlon)
     cols.update(com=com, mean_var=mean_var, intensity=inten, event_area=area)   # index_utils.py:113-120
     if kind == _hip.OVERTURNINGS:
-        cols["orientation"] = orient
-    return _gf.make_frame(cols, iu.transform_polygons(polys, prep.lon, prep.lat, prep.nlon))
+        names = np.array(["cyclonic", "anticyclonic"], dtype=object)
+        cols["orientation"] = list(names[orient_code])
+    return _gf.make_frame(cols, geoms)

@@ -14,32 +14,56 @@ logger = logging.getLogger(__name__)
 
 
 def _contour_frame(tables, prep, levels, original_coordinates):
-    """tables: [(contour table, level positions, first time step)] -> frame in the reference's order (time, level, contour)."""
-    rows = []
-    for ti, (ct, pos, t0) in enumerate(tables):
-        for k in range(ct["step"].size):
-            rows.append((int(ct["step"][k]) + t0, pos[int(ct["level_idx"][k])], ti, k))
-    rows.sort(key=lambda r: (r[0], r[1]))          # stable: contour order inside a (step, level) is kept
-    cols = dict(date=[], level=[], closed=[], exp_lon=[], mean_lat=[])
+    """tables: [(contour table, level positions, first time step)] -> frame in the reference's order (time, level, contour).
+    Array work over all contours at once; the only per-contour Python steps are a slice, a mean and the geometry object."""
+    tables = [t for t in tables if t[0]["step"].size]
+    if not tables:
+        return _gf.make_frame(dict(date=[], level=[], closed=[], exp_lon=[], mean_lat=[]), [])
+    step = np.concatenate([ct["step"].astype(np.int64) + t0 for ct, pos, t0 in tables])
+    lpos = np.concatenate([np.asarray(pos, dtype=np.int64)[ct["level_idx"]] for ct, pos, t0 in tables])
+    closed = np.concatenate([ct["closed"] for ct, pos, t0 in tables])
+    nux = np.concatenate([ct["nux"] for ct, pos, t0 in tables]).astype(np.int64)
+    sum_y = np.concatenate([ct["sum_y"] for ct, pos, t0 in tables])
+    npts = np.concatenate([ct["npts"] for ct, pos, t0 in tables]).astype(np.int64)
+    x = np.concatenate([ct["x"] for ct, pos, t0 in tables]).astype(np.int64)
+    y = np.concatenate([ct["y"] for ct, pos, t0 in tables]).astype(np.int64)
+    off = np.cumsum(npts) - npts
+    nc = step.size
+    if len(tables) > 1:                                # stable: contour order inside a (step, level) is kept
+        order = np.lexsort((np.arange(nc), lpos, step))
+    else:
+        order = np.arange(nc)
+    level_values = np.empty(len(levels), dtype=object)
+    level_values[:] = list(levels)
+    cols = dict(date=np.asarray(prep.times)[step[order]], level=list(level_values[lpos[order]]), closed=list(closed[order].astype(bool)))
     geoms = []
-    for step, lpos, ti, k in rows:
-        ct = tables[ti][0]
-        o, n = int(ct["offset"][k]), int(ct["npts"][k])
-        x, y = ct["x"][o:o + n], ct["y"][o:o + n]
-        cols["date"].append(prep.times[step])
-        cols["level"].append(levels[lpos])
-        cols["closed"].append(bool(ct["closed"][k]))
-        if original_coordinates:                                             # contour_index.py:177-194
-            co = np.c_[prep.lon[x % prep.nlon], prep.lat[y]]
-            _, first = np.unique(co, axis=0, return_index=True)
-            co = co[np.sort(first)]
-            cols["exp_lon"].append(len(set(co[:, 0].tolist())) * prep.dlon)
-            cols["mean_lat"].append(np.round(co[:, 1].mean(), 2))
-            geoms.append(_gf.make_linestring(co))
-        else:
-            cols["exp_lon"].append(int(ct["nux"][k]) * prep.dlon)            # :154
-            cols["mean_lat"].append(np.round(int(ct["sum_y"][k]) / n, 2))    # :155
-            geoms.append(_gf.make_linestring(np.c_[x, y]))
+    if original_coordinates:                                                 # contour_index.py:177-194
+        cid = np.repeat(np.arange(nc), npts)
+        xm = x % prep.nlon
+        # first occurrence of every (lon, lat) pair inside its contour, contour order kept
+        key = (cid * prep.nlon + xm) * prep.nlat + y
+        _, first = np.unique(key, return_index=True)
+        keep = np.zeros(key.size, dtype=bool)
+        keep[first] = True
+        kept_n = np.bincount(cid[keep], minlength=nc)
+        kept_off = np.cumsum(kept_n) - kept_n
+        lonv, latv = prep.lon[xm[keep]], prep.lat[y[keep]]
+        distinct_lon = np.bincount(np.unique(cid * prep.nlon + xm) // prep.nlon, minlength=nc)
+        exp_lon, mean_lat = [], []
+        co = np.c_[lonv, latv]
+        for k in order:
+            seg = co[kept_off[k]:kept_off[k] + kept_n[k]]
+            exp_lon.append(distinct_lon[k] * prep.dlon)
+            mean_lat.append(np.round(seg[:, 1].mean(), 2))
+            geoms.append(_gf.make_linestring(seg))
+    else:
+        exp_lon = list(nux[order] * prep.dlon)                               # :154
+        mean_lat = [np.round(int(sum_y[k]) / int(npts[k]), 2) for k in order]   # :155
+        xy = np.c_[x, y]
+        for k in order:
+            geoms.append(_gf.make_linestring(xy[off[k]:off[k] + npts[k]]))
+    cols["exp_lon"] = exp_lon
+    cols["mean_lat"] = mean_lat
     return _gf.make_frame(cols, geoms)
 
 
@@ -53,16 +77,19 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     rows are ordered time-major, then by level, then in scikit-image's contour order.
     """
     keep = kwargs.pop("_keep_batches", None)
-    prep = engine.Prepared(data, None, kwargs)
+    prep = engine.Prepared(data, kwargs.pop("_intensity", None), kwargs)   # the index decorators upload the intensity with the field
     levels = engine.as_levels(contour_levels)
+    if keep is None:
+        # nothing follows: every batch is released as soon as its table is on the host
+        tables = []
+        for b, pos, t0 in engine.iter_contour_batches(prep, levels, periodic_add, {}):
+            tables.append((b.contour_table(), pos, t0))
+            b.close()
+        return _contour_frame(tables, prep, levels, original_coordinates)
     batches = engine.contour_batches(prep, levels, periodic_add, {})
     tables = [(b.contour_table(), pos, t0) for b, pos, t0 in batches]
     frame = _contour_frame(tables, prep, levels, original_coordinates)
-    if keep is not None:
-        keep.update(batches=batches, prep=prep, levels=levels, nrows=len(frame), frame=frame)
-    else:
-        for b, *_ in batches:
-            b.close()
+    keep.update(batches=batches, prep=prep, levels=levels, nrows=len(frame), frame=frame)
     return frame
 
 
@@ -93,7 +120,7 @@ def decorator_contour_calculation(func):
                           if k in kwargs}
             state = {}
             kwargs["contours"] = calculate_contours(data, contour_levels, periodic_add, original_coordinates=False,
-                                                    _keep_batches=state, **dim_kwargs)
+                                                    _keep_batches=state, _intensity=kwargs.get("intensity"), **dim_kwargs)
             kwargs["_wb_state"] = state
         else:
             _validate_contour_frame(kwargs["contours"], contour_levels)
