@@ -201,8 +201,30 @@ int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const double* la
                    int64_t nev, const int32_t* step, const double* value, const int64_t* ring_offset,
                    const int64_t* vert_offset, const double* vx, const double* vy, int out_dtype, void* out,
                    int out_on_device);
+/* track_events (processing/events.py:113-241).  n events in the caller's row order; dates either as int64 nanoseconds
+   (date_ns; hours between two rows = difference / 1e9 / 3600 as pandas computes it, events.py:163) or as float64 numbers
+   (date_val; |difference| is compared, events.py:165) -- exactly one of the two pointers is given.  Pairs with
+   0 < dt <= time_range are linked when
+     method 1 "by_distance": haversine(com_i, com_j) * 6371 < distance, com = [n][2] degrees read as the reference reads
+                             them (events.py:189-198);
+     method 0 "by_overlap":  area(A n B) / (area A + area B - area(A n B)) > overlap (events.py:209-214) for the polygons
+                             given as LATTICE rings: event k owns rings ring_offset[k] .. ring_offset[k+1], ring q the
+                             vertices vert_offset[q] .. vert_offset[q+1] of vx / vy (grid indices, |v| < 32768; closed or
+                             not; parts of a MultiPolygon and holes alike: even-odd).  buffer = 0 only.
+   label[n] <- events.py:224-238 (components named after their smallest row, renumbered 0, 1, 2, ...).  area[n] (may be
+   NULL; method 0) <- even-odd area of every event in index units.  stats[4] (may be NULL) <- pairs in range, pairs whose
+   bounding boxes overlap (method 0), pairs linked, 0. */
+int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, int method, double time_range,
+                    double overlap, double distance, const double* com, const int64_t* ring_offset,
+                    const int64_t* vert_offset, const int32_t* vx, const int32_t* vy, int32_t* label, double* area,
+                    uint64_t* stats);
+/* the overlap areas behind method 0 for an explicit list of pairs: inter[q] <- area(event pair_i[q] n event pair_j[q]),
+   area[n] (may be NULL) <- area of every event; index units.  Exactly 0 when the interiors do not meet. */
+int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx,
+                      const int32_t* vy, int64_t npairs, const int64_t* pair_i, const int64_t* pair_j, double* inter,
+                      double* area);
 /* device time (HIP events on the context's stream) of the kernels of the last wb_smooth_field / wb_momentum_flux /
-   wb_flag_events */
+   wb_flag_events / wb_track_events / wb_track_overlaps */
 float wb_last_op_ms(wb_ctx* ctx);
 
 #ifdef __cplusplus

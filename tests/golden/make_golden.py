@@ -10,9 +10,10 @@ Run in the build container (the two interpreters hold different libraries):
     python3 tests/golden/make_golden.py sklearn                             # scikit-learn 1.7.2
     python3 tests/golden/make_golden.py pandas                              # pandas 2.3.3
     python3 tests/golden/make_golden.py props                               # pandas 2.3.3 (groupby sums of calculate_properties)
+    python3 tests/golden/make_golden.py track                               # pandas 2.3.3 + scikit-learn 1.7.2 (track_events)
 
 Outputs: tests/golden/contours_cases.npz, contours_random.npz, haversine.npz,
-pandas_rules.npz, props_pandas.npz, contours_levelhit.npz (all < 200 KB).
+pandas_rules.npz, props_pandas.npz, contours_levelhit.npz, track_pinned.npz (all < 200 KB).
 """
 import os
 import sys
@@ -379,7 +380,65 @@ def make_props():
           % (eid, len(ids), int(np.sum(np.abs(r - np.round(r)) < 1e-9))))
 
 
+def make_track():
+    """What track_events (events.py:113-241) gets from pandas and scikit-learn: the hours between rows and the time-range
+    test (:151-167), the haversine distance between two centres of mass with the threshold test (:189-200), and the final
+    sort_values(by=["label", "date"]) (:241).  Several cases: shuffled rows, repeated dates, an irregular time axis, a
+    range that spans more than one step, distances within a few ulps of the threshold."""
+    import pandas as pd
+    import sklearn
+    from sklearn.metrics import DistanceMetric
+
+    dist = DistanceMetric.get_metric("haversine")
+    rng = np.random.RandomState(4242)
+    out = {}
+    cases = [dict(n=40, steps=6, step_h=6, time_range=None, distance=1000.0, shuffle=False),
+             dict(n=60, steps=8, step_h=6, time_range=12, distance=2500.0, shuffle=True),
+             dict(n=50, steps=7, step_h=1.5, time_range=2.0, distance=800.0, shuffle=True),
+             dict(n=30, steps=5, step_h=24, time_range=24, distance=4000.0, shuffle=False)]
+    for c, case in enumerate(cases):
+        n = case["n"]
+        step = rng.randint(0, case["steps"], n)
+        if not case["shuffle"]:
+            step = np.sort(step)
+        ns = (np.datetime64("1979-01-01T00", "ns").astype(np.int64)
+              + (step * case["step_h"] * 3600e9).astype(np.int64)
+              + (rng.randint(0, 3, n) == 0) * (c == 2) * np.int64(1800e9))           # case 2: an irregular axis
+        dates = ns.astype("datetime64[ns]")
+        lon = np.round(rng.uniform(-180, 179.75, n) * 4) / 4 + rng.uniform(-0.1, 0.1, n)
+        lat = np.round(rng.uniform(-80, 80, n) * 4) / 4 + rng.uniform(-0.1, 0.1, n)
+        events = pd.DataFrame({"date": dates, "com": list(zip(lon, lat))})
+        if case["time_range"] is None:
+            dif = events.date.diff()
+            time_range = dif[dif > pd.Timedelta(0)].min().total_seconds() / 3600
+        else:
+            time_range = float(case["time_range"])
+        pairs = set()
+        for i in events.index:
+            diffs = (events.date - events.date.iloc[i]).dt.total_seconds() / 3600
+            pairs.update((i, int(j)) for j in events[(diffs > 0) & (diffs <= time_range)].index)
+        pairs = np.asarray(sorted(pairs), dtype=np.int64).reshape(-1, 2)
+        com1 = np.asarray(list(events.iloc[pairs[:, 0]].com))
+        com2 = np.asarray(list(events.iloc[pairs[:, 1]].com))
+        d = np.asarray([dist.pairwise(np.radians([p1, p2]))[0, 1] for p1, p2 in zip(com1, com2)])
+        # labels of a fixed pseudo-random partition: only the SORT is pinned here
+        label = rng.randint(0, max(2, n // 4), n)
+        order = events.assign(label=label).sort_values(by=["label", "date"]).index.values
+        out.update({"c%d_dates" % c: ns, "c%d_lon" % c: lon, "c%d_lat" % c: lat, "c%d_time_range" % c: np.float64(time_range),
+                    "c%d_time_range_arg" % c: np.float64(np.nan if case["time_range"] is None else case["time_range"]),
+                    "c%d_pairs" % c: pairs, "c%d_dist" % c: d, "c%d_distance" % c: np.float64(case["distance"]),
+                    "c%d_check" % c: d * 6371 < case["distance"], "c%d_label_in" % c: label, "c%d_order" % c: order})
+    # thresholds a few ulps either side of one pair's distance
+    p1, p2 = np.array([12.25, 47.5]), np.array([19.75, 52.0])
+    d0 = dist.pairwise(np.radians([p1, p2]))[0, 1] * 6371
+    thr = np.array([np.nextafter(d0, 0), d0, np.nextafter(d0, np.inf), d0 * (1 - 1e-9), d0 * (1 + 1e-9)])
+    out.update(edge_p1=p1, edge_p2=p2, edge_d=np.float64(d0), edge_thr=thr, edge_check=d0 < thr)
+    out.update(ncases=np.int64(len(cases)), sklearn_version=np.array(sklearn.__version__), pandas_version=np.array(pd.__version__))
+    np.savez_compressed(os.path.join(HERE, "track_pinned.npz"), **out)
+    print("track goldens written")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else ""
     {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas, "props": make_props,
-     "levelhit": make_levelhit}[which]()
+     "levelhit": make_levelhit, "track": make_track}[which]()

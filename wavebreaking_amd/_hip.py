@@ -117,6 +117,10 @@ class Library:
                                          C.c_void_p, C.c_int]
         lib.wb_flag_events.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int64, C.POINTER(C.c_int32),
                                        dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp, dp, C.c_int, C.c_void_p, C.c_int]
+        i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        lib.wb_track_events.argtypes = [C.c_void_p, C.c_int64, i64p, dp, C.c_int, C.c_double, C.c_double, C.c_double, dp, i64p,
+                                        i64p, i32p, i32p, i32p, dp, C.POINTER(C.c_uint64)]
+        lib.wb_track_overlaps.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, i32p, i32p, C.c_int64, i64p, i64p, dp, dp]
         lib.wb_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         lib.wb_last_op_ms.argtypes = [C.c_void_p]
         lib.wb_last_op_ms.restype = C.c_float
@@ -301,6 +305,74 @@ class Context:
         if rc != 0:
             raise RuntimeError("wb_flag_events failed: " + self.error())
         return out
+
+    @staticmethod
+    def _lattice_rings(rings_per_event):
+        """list (per event) of lists of (n, 2) integer rings -> ring_offset, vert_offset, vx, vy"""
+        nev = len(rings_per_event)
+        ring_off = np.zeros(nev + 1, dtype=np.int64)
+        vert_off = [0]
+        parts = []
+        for k, rings in enumerate(rings_per_event):
+            for ring in rings:
+                ring = np.asarray(ring, dtype=np.int32).reshape(-1, 2)
+                parts.append(ring)
+                vert_off.append(vert_off[-1] + len(ring))
+            ring_off[k + 1] = len(vert_off) - 1
+        xy = np.concatenate(parts) if parts else np.zeros((0, 2), dtype=np.int32)
+        return (ring_off, np.asarray(vert_off, dtype=np.int64), np.ascontiguousarray(xy[:, 0], dtype=np.int32),
+                np.ascontiguousarray(xy[:, 1], dtype=np.int32))
+
+    def track_events(self, dates, method, time_range, overlap=0.0, distance=1000.0, com=None, rings_per_event=None):
+        """wb_track_events: labels of track_events (events.py:113-241) for events in the caller's row order.  ``dates``:
+        datetime64 (any unit) or numbers; ``method``: "by_overlap" (``rings_per_event[k]`` = list of (n, 2) LATTICE rings)
+        or "by_distance" (``com`` = (n, 2) degrees).  Returns (label int32[n], area float64[n] or None, stats dict)."""
+        d = np.asarray(dates)
+        n = d.shape[0]
+        i64p, i32p, dp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        ns = val = None
+        if np.issubdtype(d.dtype, np.datetime64):
+            ns = np.ascontiguousarray(d.astype("datetime64[ns]").astype(np.int64))
+        else:
+            val = np.ascontiguousarray(d, dtype=np.float64)
+        label = np.empty(n, dtype=np.int32)
+        stats = np.zeros(4, dtype=np.uint64)
+        area = None
+        if method == "by_overlap":
+            ring_off, vert_off, vx, vy = self._lattice_rings(rings_per_event)
+            assert ring_off.size == n + 1
+            area = np.empty(n, dtype=np.float64)
+            geo = (ring_off.ctypes.data_as(i64p), vert_off.ctypes.data_as(i64p), vx.ctypes.data_as(i32p), vy.ctypes.data_as(i32p))
+            cm, code = None, 0
+        elif method == "by_distance":
+            cm = np.ascontiguousarray(com, dtype=np.float64).reshape(n, 2)
+            geo, code = (None, None, None, None), 1
+        else:
+            raise ValueError("'{}' not supported as method!".format(method))
+        rc = self.L.lib.wb_track_events(self.h, n, ns.ctypes.data_as(i64p) if ns is not None else None,
+                                        val.ctypes.data_as(dp) if val is not None else None, code, float(time_range),
+                                        float(overlap), float(distance), cm.ctypes.data_as(dp) if cm is not None else None,
+                                        *geo, label.ctypes.data_as(i32p), area.ctypes.data_as(dp) if area is not None else None,
+                                        stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc != 0:
+            raise RuntimeError("wb_track_events failed: " + self.error())
+        return label, area, dict(pairs_in_range=int(stats[0]), pairs_boxes_overlap=int(stats[1]), pairs_linked=int(stats[2]))
+
+    def track_overlaps(self, rings_per_event, pairs):
+        """wb_track_overlaps: (intersection area of every pair, area of every event), index units"""
+        ring_off, vert_off, vx, vy = self._lattice_rings(rings_per_event)
+        n = ring_off.size - 1
+        pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        pi, pj = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+        inter = np.zeros(len(pairs), dtype=np.float64)
+        area = np.empty(n, dtype=np.float64)
+        i64p, i32p, dp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        rc = self.L.lib.wb_track_overlaps(self.h, n, ring_off.ctypes.data_as(i64p), vert_off.ctypes.data_as(i64p),
+                                          vx.ctypes.data_as(i32p), vy.ctypes.data_as(i32p), len(pairs), pi.ctypes.data_as(i64p),
+                                          pj.ctypes.data_as(i64p), inter.ctypes.data_as(dp), area.ctypes.data_as(dp))
+        if rc != 0:
+            raise RuntimeError("wb_track_overlaps failed: " + self.error())
+        return inter, area
 
     def last_op_ms(self):
         return float(self.L.lib.wb_last_op_ms(self.h))

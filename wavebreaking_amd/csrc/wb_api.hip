@@ -22,6 +22,7 @@
 #include "wb_scan.h"
 #include "wb_stream.h"
 #include "wb_trace.h"
+#include "wb_track.h"
 
 #if defined(WB_HOSTSIM)
 int wb_hostsim_reverse = 0;
@@ -2054,6 +2055,184 @@ extern "C" int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const
     } else if (!rc) {
         rc = dsync(ctx);
     }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ track_events
+// the geometry of wb_track_events / wb_track_overlaps on the device, events in the order `order`
+struct WbTrackGeom {
+    std::vector<long long> edge0, row0, piece0;
+    std::vector<short> ex0, ey0, ex1, ey1;
+    std::vector<int> ymin, ymax, xmin, xmax;
+    std::vector<void*> dev;
+};
+static int wb_track_geometry(wb_ctx* ctx, const char* who, int64_t n, const int64_t* order, const int64_t* ring_offset,
+                             const int64_t* vert_offset, const int32_t* vx, const int32_t* vy, WbTrackGeom& g, WbTrackArgs& a) {
+    g.edge0.assign((size_t)n + 1, 0); g.row0.assign((size_t)n + 1, 0); g.piece0.assign((size_t)n + 1, 0);
+    g.ymin.assign((size_t)n, 0); g.ymax.assign((size_t)n, 0); g.xmin.assign((size_t)n, 0); g.xmax.assign((size_t)n, 0);
+    for (int64_t q = 0; q < n; ++q) {
+        const int64_t e = order[q];
+        int y0 = INT32_MAX, y1 = INT32_MIN, x0 = INT32_MAX, x1 = INT32_MIN;
+        long long pieces = 0;
+        for (int64_t rg = ring_offset[e]; rg < ring_offset[e + 1]; ++rg) {
+            const int64_t v0 = vert_offset[rg], nv = vert_offset[rg + 1] - v0;
+            for (int64_t k = 0; k < nv; ++k) {
+                const int64_t k2 = k + 1 < nv ? k + 1 : 0;                 // the closing edge is implied (zero length if repeated)
+                const int ax = vx[v0 + k], ay = vy[v0 + k], bx = vx[v0 + k2], by = vy[v0 + k2];
+                if (ax < -32768 || ax > 32767 || ay < -32768 || ay > 32767) {
+                    ctx->err = std::string(who) + ": lattice coordinate outside the 16-bit range";
+                    return 1;
+                }
+                y0 = ay < y0 ? ay : y0; y1 = ay > y1 ? ay : y1; x0 = ax < x0 ? ax : x0; x1 = ax > x1 ? ax : x1;
+                if (ay == by) continue;                                    // horizontal edges bound no row from the side
+                g.ex0.push_back((short)ax); g.ey0.push_back((short)ay); g.ex1.push_back((short)bx); g.ey1.push_back((short)by);
+                pieces += ay < by ? by - ay : ay - by;
+            }
+        }
+        if (y0 > y1) { y0 = y1 = 0; x0 = x1 = 0; }                        // an empty geometry
+        g.ymin[(size_t)q] = y0; g.ymax[(size_t)q] = y1; g.xmin[(size_t)q] = x0; g.xmax[(size_t)q] = x1;
+        g.edge0[(size_t)q + 1] = (long long)g.ex0.size();
+        g.row0[(size_t)q + 1] = g.row0[(size_t)q] + (y1 - y0);
+        g.piece0[(size_t)q + 1] = g.piece0[(size_t)q] + pieces;
+        if (pieces > INT32_MAX) { ctx->err = std::string(who) + ": polygon too large"; return 1; }
+    }
+    auto up = [&](const void* h, size_t bytes) -> void* {
+        void* d = dmalloc(ctx, bytes ? bytes : 8);
+        if (d && bytes) h2d(ctx, d, h, bytes);
+        g.dev.push_back(d);
+        return d;
+    };
+    auto scratch = [&](size_t bytes) -> void* { void* d = dmalloc(ctx, bytes ? bytes : 8); g.dev.push_back(d); return d; };
+    const size_t rows = (size_t)g.row0[(size_t)n], pieces = (size_t)g.piece0[(size_t)n], ne = g.ex0.size();
+    a.edge0 = (const long long*)up(g.edge0.data(), g.edge0.size() * 8);
+    a.row0 = (const long long*)up(g.row0.data(), g.row0.size() * 8);
+    a.piece0 = (const long long*)up(g.piece0.data(), g.piece0.size() * 8);
+    a.ex0 = (const short*)up(g.ex0.data(), ne * 2); a.ey0 = (const short*)up(g.ey0.data(), ne * 2);
+    a.ex1 = (const short*)up(g.ex1.data(), ne * 2); a.ey1 = (const short*)up(g.ey1.data(), ne * 2);
+    a.ymin = (const int*)up(g.ymin.data(), (size_t)n * 4); a.ymax = (const int*)up(g.ymax.data(), (size_t)n * 4);
+    a.xmin = (const int*)up(g.xmin.data(), (size_t)n * 4); a.xmax = (const int*)up(g.xmax.data(), (size_t)n * 4);
+    a.row_off = (int*)scratch(rows * 4); a.row_cnt = (int*)scratch(rows * 4);
+    a.piece = (unsigned long long*)scratch(pieces * 8);
+    a.row_area = (double*)scratch(rows * 8);
+    a.area = (double*)scratch((size_t)n * 8);
+    for (void* d : g.dev)
+        if (!d) { ctx->err = std::string(who) + ": out of device memory"; return 1; }
+    return 0;
+}
+static void wb_track_release(wb_ctx* ctx, WbTrackGeom& g) {
+    for (void* d : g.dev)
+        if (d) dfree(ctx, d);
+    g.dev.clear();
+}
+
+extern "C" int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, int method,
+                               double time_range, double overlap, double distance, const double* com,
+                               const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx, const int32_t* vy,
+                               int32_t* label, double* area, uint64_t* stats) {
+    if (!ctx) return 1;
+    wb_use(ctx);
+    if (n < 1 || n > INT32_MAX || (!date_ns == !date_val) || !label || (method != 0 && method != 1) ||
+        (method == 1 && !com) || (method == 0 && (!ring_offset || !vert_offset || !vx || !vy))) {
+        ctx->err = "wb_track_events: bad argument";
+        return 1;
+    }
+    std::vector<int64_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    if (date_ns) std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return date_ns[x] < date_ns[y]; });
+    else std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return date_val[x] < date_val[y]; });
+    WbTrackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.method = method; a.date_kind = date_ns ? 0 : 1; a.time_range = time_range; a.overlap = overlap; a.distance = distance;
+    WbTrackGeom g;
+    int rc = 0;
+    if (method == 0) rc = wb_track_geometry(ctx, "wb_track_events", n, order.data(), ring_offset, vert_offset, vx, vy, g, a);
+    std::vector<long long> sns; std::vector<double> sval, scom; std::vector<int> orig((size_t)n);
+    for (int64_t q = 0; q < n; ++q) orig[(size_t)q] = (int)order[(size_t)q];
+    if (date_ns) { sns.resize((size_t)n); for (int64_t q = 0; q < n; ++q) sns[(size_t)q] = date_ns[order[(size_t)q]]; }
+    else { sval.resize((size_t)n); for (int64_t q = 0; q < n; ++q) sval[(size_t)q] = date_val[order[(size_t)q]]; }
+    if (method == 1) {
+        scom.resize((size_t)n * 2);
+        for (int64_t q = 0; q < n; ++q) { scom[(size_t)q * 2] = com[order[(size_t)q] * 2]; scom[(size_t)q * 2 + 1] = com[order[(size_t)q] * 2 + 1]; }
+    }
+    auto up = [&](const void* h, size_t bytes) -> void* {
+        void* d = dmalloc(ctx, bytes ? bytes : 8);
+        if (d && bytes) h2d(ctx, d, h, bytes);
+        g.dev.push_back(d);
+        if (!d && !rc) { ctx->err = "wb_track_events: out of device memory"; rc = 1; }
+        return d;
+    };
+    if (!rc) {
+        a.date_ns = date_ns ? (const long long*)up(sns.data(), (size_t)n * 8) : nullptr;
+        a.date_val = date_ns ? nullptr : (const double*)up(sval.data(), (size_t)n * 8);
+        a.orig = (const int*)up(orig.data(), (size_t)n * 4);
+        a.com = method == 1 ? (const double*)up(scom.data(), (size_t)n * 16) : nullptr;
+        a.parent = (int*)dmalloc(ctx, (size_t)n * 4); g.dev.push_back(a.parent);
+        a.flag = (int*)dmalloc(ctx, (size_t)n * 4); g.dev.push_back(a.flag);
+        a.label = (int*)dmalloc(ctx, (size_t)n * 4); g.dev.push_back(a.label);
+        a.stats = (unsigned long long*)dmalloc(ctx, 4 * 8); g.dev.push_back(a.stats);
+        if (!a.parent || !a.flag || !a.label || !a.stats) { ctx->err = "wb_track_events: out of device memory"; rc = 1; }
+    }
+    if (!rc) {
+        dmemset(ctx, a.stats, 0, 4 * 8);
+        WbOpTimer timer(ctx);
+        const int gl = n < 4096 ? (int)((n + 255) / 256) : 1024;         // flat kernels: a contiguous slice per workgroup
+        WB_LAUNCH(wb_k_track_init, gl, 256, a);
+        const long long ge = n < (1 << 20) ? n : (1 << 20);
+        if (method == 0) WB_LAUNCH(wb_k_track_build, ge, 256, a);
+        WB_LAUNCH(wb_k_track_pairs, ge, WB_TRACK_THREADS, a);
+        WB_LAUNCH(wb_k_track_roots, gl, 256, a);
+        WB_LAUNCH(wb_k_track_rank, 1, 1024, a);
+        WB_LAUNCH(wb_k_track_labels, gl, 256, a);
+        timer.stop();
+        rc = d2h(ctx, label, a.label, (size_t)n * 4);
+        if (!rc && stats) rc = d2h(ctx, stats, a.stats, 4 * 8);
+        if (!rc && area && method == 0) {
+            std::vector<double> sa((size_t)n);
+            rc = d2h(ctx, sa.data(), a.area, (size_t)n * 8);
+            for (int64_t q = 0; q < n; ++q) area[order[(size_t)q]] = sa[(size_t)q];
+        }
+    }
+    wb_track_release(ctx, g);
+    return rc;
+}
+
+extern "C" int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx,
+                                 const int32_t* vy, int64_t npairs, const int64_t* pair_i, const int64_t* pair_j, double* inter,
+                                 double* area) {
+    if (!ctx) return 1;
+    wb_use(ctx);
+    if (n < 1 || n > INT32_MAX || !ring_offset || !vert_offset || !vx || !vy || npairs < 0 || (npairs > 0 && (!pair_i || !pair_j || !inter))) {
+        ctx->err = "wb_track_overlaps: bad argument";
+        return 1;
+    }
+    for (int64_t q = 0; q < npairs; ++q)
+        if (pair_i[q] < 0 || pair_i[q] >= n || pair_j[q] < 0 || pair_j[q] >= n) { ctx->err = "wb_track_overlaps: pair out of range"; return 1; }
+    std::vector<int64_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    WbTrackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    WbTrackGeom g;
+    int rc = wb_track_geometry(ctx, "wb_track_overlaps", n, order.data(), ring_offset, vert_offset, vx, vy, g, a);
+    long long *d_pi = nullptr, *d_pj = nullptr;
+    double* d_out = nullptr;
+    if (!rc) {
+        d_pi = (long long*)dmalloc(ctx, (size_t)npairs * 8); g.dev.push_back(d_pi);
+        d_pj = (long long*)dmalloc(ctx, (size_t)npairs * 8); g.dev.push_back(d_pj);
+        d_out = (double*)dmalloc(ctx, (size_t)npairs * 8); g.dev.push_back(d_out);
+        if (!d_pi || !d_pj || !d_out) { ctx->err = "wb_track_overlaps: out of device memory"; rc = 1; }
+    }
+    if (!rc) {
+        if (npairs) { h2d(ctx, d_pi, pair_i, (size_t)npairs * 8); h2d(ctx, d_pj, pair_j, (size_t)npairs * 8); }
+        WbOpTimer timer(ctx);
+        WB_LAUNCH(wb_k_track_build, n < (1 << 20) ? n : (1 << 20), 256, a);
+        if (npairs) WB_LAUNCH(wb_k_track_overlap_list, npairs < (1 << 20) ? npairs : (1 << 20), WB_TRACK_THREADS, a, (long long)npairs,
+                              (const long long*)d_pi, (const long long*)d_pj, d_out);
+        timer.stop();
+        if (npairs) rc = d2h(ctx, inter, d_out, (size_t)npairs * 8);
+        if (!rc && area) rc = d2h(ctx, area, a.area, (size_t)n * 8);
+    }
+    wb_track_release(ctx, g);
     return rc;
 }
 

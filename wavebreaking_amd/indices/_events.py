@@ -93,4 +93,7 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
     if kind == _hip.OVERTURNINGS:
         names = np.array(["cyclonic", "anticyclonic"], dtype=object)
         cols["orientation"] = list(names[orient_code])
-    return _gf.make_frame(cols, geoms)
+    frame = _gf.make_frame(cols, geoms)
+    # the grid the polygon vertices lie on: track_events(method="by_overlap") works on grid indices
+    frame.attrs["wavebreaking_grid"] = dict(lon=(float(prep.lon[0]), float(prep.dlon)), lat=(float(prep.lat[0]), float(prep.dlat)))
+    return frame

@@ -1,5 +1,6 @@
-"""Event post-processing -- ``to_xarray`` with the call surface of wavebreaking/processing/events.py:37-110; the
-flagging runs in csrc/wb_flags.h (wb_flag_events).  ``track_events`` is not built."""
+"""Event post-processing with the call surface of wavebreaking/processing/events.py: ``to_xarray`` (:37-110; the flagging
+runs in csrc/wb_flags.h, wb_flag_events) and ``track_events`` (:113-241; pairs, link test, components and labels run in
+csrc/wb_track.h, wb_track_events)."""
 import numpy as np
 
 from wavebreaking_amd import engine
@@ -85,3 +86,127 @@ def to_xarray(data, events, flag="ones", name="flag", *args, **kwargs):
     if _gf._xr is not None and isinstance(data, _gf._xr.DataArray):           # pragma: no cover - xarray not in the image
         return _gf._xr.DataArray(cube, coords=[data[d] for d in data.dims], dims=data.dims, name=name, attrs=attrs)
     return _gf.GridField(cube, data.dims, dict(data.coords), attrs=attrs, name=name)
+
+
+def _pandas_frame_type():
+    import pandas as pd
+    return pd.DataFrame
+
+
+def _float_gcd(values, tol=1e-6):
+    """largest step of which every value is a whole multiple (within tol): Euclid's algorithm on floats"""
+    step = 0.0
+    for v in values:
+        a, b = max(step, abs(float(v))), min(step, abs(float(v)))
+        while b > tol * a:
+            a, b = b, a % b
+            if b > a * (1 - tol):                      # a remainder one rounding error short of the divisor
+                b = 0.0
+        step = a
+    return step
+
+
+def _axis_lattice(coords, given=None):
+    """(origin, step) of the regular grid the coordinates lie on: from the grid the frame carries, else inferred as the
+    greatest common step of the distinct values"""
+    if given is not None:
+        return float(given[0]), float(given[1])
+    u = np.unique(coords)
+    if u.size < 2:
+        return float(u[0]) if u.size else 0.0, 1.0
+    return float(u[0]), _float_gcd(np.diff(u))
+
+
+def lattice_rings(events):
+    """The event polygons as integer rings on the data's grid.  transform_polygons (index_utils.py:129-184) puts every
+    vertex on a grid point (it truncates to indices, :135), so this loses nothing for frames the index functions made;
+    the grid comes from ``events.attrs["wavebreaking_grid"]`` (set by this package's index functions) or is inferred from
+    the coordinates.  Raises ValueError for polygons that are not on a regular grid."""
+    rings = [_rings(g) for g in events["geometry"]]
+    flat = [r for rs in rings for r in rs]
+    if not flat:
+        return [[] for _ in rings]
+    allv = np.concatenate(flat)
+    grid = getattr(events, "attrs", {}).get("wavebreaking_grid")
+    out_axes = []
+    for axis, key in ((0, "lon"), (1, "lat")):
+        origin, step = _axis_lattice(allv[:, axis], None if grid is None else grid[key])
+        if not step > 0:
+            raise ValueError("track_events(method='by_overlap'): cannot find the grid step of the polygon coordinates")
+        idx = (allv[:, axis] - origin) / step
+        if np.abs(idx - np.rint(idx)).max() > 1e-6 or np.abs(idx).max() >= 32768:
+            raise ValueError("track_events(method='by_overlap') needs polygons whose vertices lie on a regular grid "
+                             "(as the index functions produce them); these do not")
+        out_axes.append(np.rint(idx).astype(np.int32))
+    xy = np.c_[out_axes[0], out_axes[1]]
+    out, pos = [], 0
+    for rs in rings:
+        mine = []
+        for r in rs:
+            mine.append(xy[pos:pos + len(r)])
+            pos += len(r)
+        out.append(mine)
+    return out
+
+
+@check_argument_types(["events"], [_pandas_frame_type()])
+@check_empty_dataframes
+def track_events(events, time_range=None, method="by_overlap", buffer=0, overlap=0, distance=1000):
+    """
+    Temporal tracking of events (events.py:113-241).
+    Events receive the same label if they spatially overlap at step t
+    and t + time_range.
+
+    Parameters
+    ----------
+        events : geopandas.GeoDataFrame (pandas.DataFrame with a geometry column when geopandas is absent)
+            date and coordinates of each identified event
+        time_range: int or float, optional
+            Time range for temporally tracking the events, in hours if the dates are np.datetime64.
+            If not specified, the smallest time difference larger than zero is used.
+        method : {"by_overlap", "by_distance"}, optional
+            * "by_overlap": same label if the polygons overlap at step t and t + time_range
+            * "by_distance": same label if the centres of mass are closer than "distance"
+        buffer : float, optional
+            buffer around the event polygons in degrees for "by_overlap"; only 0 is built here (a buffered polygon is no
+            longer a grid polygon and its area depends on GEOS' arc approximation) -- anything else raises
+            NotImplementedError
+        overlap : float, optional
+            minimum intersection-over-union for "by_overlap"
+        distance : int or float, optional
+            maximum distance in km between two events for "by_distance"
+
+    Returns
+    -------
+        events: the frame with a ``label`` column, sorted by label and date
+    """
+    events = events.reset_index(drop=True)
+    dates = np.asarray(events["date"].values)
+    is_time = np.issubdtype(dates.dtype, np.datetime64)
+    key = dates.astype("datetime64[ns]").astype(np.int64) if is_time else dates.astype(np.float64)
+    if time_range is None:                                                   # events.py:151-153
+        dif = np.diff(key)
+        dif = dif[dif > 0]
+        if dif.size == 0:
+            raise ValueError("No events detected in the time range: {}".format(np.nan))
+        time_range = float(dif.min() / 1e9 / 3600) if is_time else float(dif.min())
+    gaps = np.diff(np.unique(key))                                           # a pair in range exists iff the smallest gap fits
+    gaps = gaps / 1e9 / 3600 if is_time else gaps
+    if gaps.size == 0 or not (gaps.min() <= time_range):
+        raise ValueError("No events detected in the time range: {}".format(time_range))   # events.py:179-181
+    if method not in ("by_overlap", "by_distance"):                          # events.py:219-222
+        raise ValueError("'{}' not supported as method!".format(method) + " Supported methods are 'by_overlap' and 'by_distance'")
+    ctx = engine.get_context()
+    if method == "by_distance":
+        com = np.asarray(list(events["com"]), dtype=np.float64).reshape(len(events), 2)
+        label, _, stats = ctx.track_events(dates, method, time_range, distance=distance, com=com)
+    else:
+        if buffer != 0:
+            raise NotImplementedError("track_events(method='by_overlap'): only buffer=0 is built (exact areas of grid "
+                                      "polygons); buffered polygons need GEOS' arc approximation")
+        label, _, stats = ctx.track_events(dates, method, time_range, overlap=overlap, rings_per_event=lattice_rings(events))
+    events["label"] = label.astype(np.int64)                                 # events.py:224-238
+    order = np.lexsort((key, label))                                         # events.py:241: stable, label then date
+    out = events.iloc[order]
+    out.attrs["track_stats"] = stats
+    return out
