@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--nt", type=int, default=int(os.environ.get("WB_BENCH_NT", 1460)), help="time steps per GPU per pass")
     ap.add_argument("--dlon", type=float, default=0.25)
     ap.add_argument("--eps", type=float, default=0.0, help="cell noise amplitude (0 = smoothed PV, 0.3 = rough)")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 4)),
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 24)),
                     help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-intensity", action="store_true")
     ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("WB_BENCH_E2E_STEPS", 365)),
@@ -237,19 +237,20 @@ def main():
 
 
 def pmc_traffic(nt):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC pass (profiles/r01_hbm_traffic_pmc.txt: FETCH_SIZE x 2,
-    the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE), scaled to this run's batch; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.txt")
-    try:
-        lines = open(path).read().splitlines()
-        for name in ("wb_k_scan<", "wb_k_scan_capture"):
-            for line in lines:
-                if name in line:
-                    f = line.split()
-                    calls, fetch_kb, write_kb = max(1.0, float(f[-4])), float(f[-3]), float(f[-1])   # sums over the launches
-                    return (2.0 * fetch_kb + write_kb) / calls * 1024.0 * nt / 1460.0
-    except Exception:
-        pass
+    """HBM bytes per scan launch from the latest committed rocprofv3 PMC pass (profiles/rNN_hbm_traffic_pmc.txt: FETCH_SIZE x 2,
+    the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE; separate --pmc runs), scaled to this run's batch; None if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt")), reverse=True):
+        try:
+            lines = open(path).read().splitlines()
+            for name in ("wb_k_scan_stream<", "wb_k_scan<", "wb_k_scan_capture"):
+                for line in lines:
+                    if name in line:
+                        f = line.split()
+                        calls, fetch_kb, write_kb = max(1.0, float(f[-4])), float(f[-3]), float(f[-1])   # sums over the launches
+                        return (2.0 * fetch_kb + write_kb) / calls * 1024.0 * nt / 1460.0
+        except Exception:
+            pass
     return None
 
 
@@ -297,7 +298,8 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
     idx = sorted(set(int(round(i)) for i in np.linspace(0, nt - 1, nsample)))
     ev = one_pass(copy=True)["events"]
     t_cpu = 0.0
-    ok = True
+    counts_ok = True
+    cmp = dict(events=0, mismatches=0, max_rel_err=0.0)
     for t in idx:
         pv = ctx.to_host(d_pv, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4)
         it = ctx.to_host(d_int, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4) if d_int else None
@@ -305,10 +307,15 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
         ref = oapi.run_all(pv, levels, lat, lon, synth.times(1), intensity=it)
         t_cpu += time.perf_counter() - tic
         for k, name in enumerate(("streamers", "overturnings", "cutoffs")):
-            ok &= int((ev[k]["step"] == t).sum()) == len(ref[name])
+            counts_ok &= int((ev[k]["step"] == t).sum()) == len(ref[name])
+            _compare_step(ev[k], ref[name], t, levels, cmp)
     out = {"value": len(idx) / t_cpu, "unit": "timesteps/s", "cores": 1, "kind": "port",
-           "sample": "steps %s of the same device-generated batch, oracle.api.run_all (numpy, 1 thread), %.1f s"
-                     % (idx, t_cpu), "event_counts_match_gpu": bool(ok)}
+           "sample": "%d steps (%s ... %s) of the same device-generated batch, oracle.api.run_all (numpy, 1 thread), %.1f s"
+                     % (len(idx), idx[:3], idx[-2:], t_cpu), "event_counts_match_gpu": bool(counts_ok),
+           # the full tables of the sampled steps, GPU against oracle: level, polygon vertices, number of cells and the
+           # truncated centre-of-mass indices bit for bit; area / mean_var / intensity sums to 1e-6 relative
+           "tables_match_gpu": bool(counts_ok and cmp["mismatches"] == 0), "events_compared": cmp["events"],
+           "table_mismatches": cmp["mismatches"], "max_rel_err_sums": cmp["max_rel_err"]}
     # the same restatement on all host cores (one time step per worker process, steps are independent); never the headline
     try:
         import multiprocessing as mp
@@ -330,6 +337,27 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
     except Exception as e:                                       # a reported extra, never fatal
         out["all_cores"] = {"error": repr(e)}
     return out
+
+
+def _compare_step(table, rows, t, levels, cmp, rtol=1e-6):
+    """events of time step t in one of the GPU's event tables against the oracle's rows for that step"""
+    mine = np.nonzero(table["step"] == t)[0]
+    if mine.size != len(rows):
+        cmp["mismatches"] += abs(int(mine.size) - len(rows))
+        return
+    for k, r in zip(mine, rows):
+        cmp["events"] += 1
+        a, b = table["poly_offset"][k], table["poly_offset"][k + 1]
+        s, ref = table["sums"][k], np.asarray(r["_sums"], dtype=np.float64)
+        same = (levels[table["level_idx"][k]] == r["level"]
+                and np.array_equal(np.c_[table["poly_x"][a:b], table["poly_y"][a:b]], r["_polygon"])
+                and int(table["ncells"][k]) == len(r["_cells"][0])
+                and int(s[3] / s[0]) == int(ref[3] / ref[0]) and int(s[4] / s[0]) == int(ref[4] / ref[0]))
+        scale = np.maximum(np.abs(ref[:3]), 1e-9 * abs(ref[0]))
+        err = float(np.max(np.abs(s[:3] - ref[:3]) / scale))
+        cmp["max_rel_err"] = max(cmp["max_rel_err"], err)
+        if not same or not err <= rtol:
+            cmp["mismatches"] += 1
 
 
 def _cpu_step(job):
