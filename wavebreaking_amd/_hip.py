@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwb_hip.so")
+# WB_HIP_LIBRARY: another HIP build of the same sources (development: kernel variants side by side); never a CPU build
+LIB_PATH = os.environ.get("WB_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libwb_hip.so")
 
 
 class WbParams(C.Structure):

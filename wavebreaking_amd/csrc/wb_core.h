@@ -101,16 +101,31 @@ struct WbCtl {
     unsigned long long cell_count;
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
-// development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups
+// development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.
+// -DWB_STAMPS=1 instruments wb_k_streamer_f234 (WB_STAMP), =2 wb_k_streamer_pairs (WB_PSTAMP); WB_DEBUG_STAMPS=1 prints.
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS)
-// sums kept in registers of thread 0, one global atomic per phase and workgroup at the end (WB_STAMP_FLUSH)
-#define WB_STAMP_BEGIN long long wb_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
-#define WB_STAMP(ctl, k) do { if (threadIdx.x == 0) { const long long wb_n_ = (long long)wall_clock64(); wb_acc_[k] += wb_n_ - wb_st_; wb_st_ = wb_n_; } } while (0)
-#define WB_STAMP_FLUSH(ctl) do { if (threadIdx.x == 0) for (int wb_q_ = 0; wb_q_ < 12; ++wb_q_) if (wb_acc_[wb_q_]) atomicAdd((unsigned long long*)&(ctl)->dbg[wb_q_], (unsigned long long)wb_acc_[wb_q_]); } while (0)
+// sums kept in registers of thread 0, one global atomic per phase and workgroup at the end (..._FLUSH)
+#define WB_STAMPX_BEGIN long long wb_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
+#define WB_STAMPX(ctl, k) do { if (threadIdx.x == 0) { const long long wb_n_ = (long long)wall_clock64(); wb_acc_[k] += wb_n_ - wb_st_; wb_st_ = wb_n_; } } while (0)
+#define WB_STAMPX_FLUSH(ctl) do { if (threadIdx.x == 0) for (int wb_q_ = 0; wb_q_ < 12; ++wb_q_) if (wb_acc_[wb_q_]) atomicAdd((unsigned long long*)&(ctl)->dbg[wb_q_], (unsigned long long)wb_acc_[wb_q_]); } while (0)
+#endif
+#if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 1
+#define WB_STAMP_BEGIN WB_STAMPX_BEGIN
+#define WB_STAMP(ctl, k) WB_STAMPX(ctl, k)
+#define WB_STAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
 #else
 #define WB_STAMP_BEGIN
 #define WB_STAMP(ctl, k) ((void)0)
 #define WB_STAMP_FLUSH(ctl) ((void)0)
+#endif
+#if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 2
+#define WB_PSTAMP_BEGIN WB_STAMPX_BEGIN
+#define WB_PSTAMP(ctl, k) WB_STAMPX(ctl, k)
+#define WB_PSTAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
+#else
+#define WB_PSTAMP_BEGIN
+#define WB_PSTAMP(ctl, k) ((void)0)
+#define WB_PSTAMP_FLUSH(ctl) ((void)0)
 #endif
 
 // ------------------------------------------------------------------ integer predicates

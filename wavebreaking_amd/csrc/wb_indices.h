@@ -390,6 +390,7 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
     WB_SHARED(int, rl, WB_PAIR_ROWS);
 
     const int tile_begin = blk_tile0[WB_BLOCK_ID];
+    WB_PSTAMP_BEGIN
     for (int tile = tile_begin; tile < tile_begin + tiles_per_block; ++tile) {
     const int i0 = tile * WB_PAIR_ROWS;
     if (i0 >= N - 1) break;
@@ -402,6 +403,7 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
     tb[0] = tb4[0] - ml; tb[1] = tb4[1] + ml; tb[2] = tb4[2] - a.dy_max; tb[3] = tb4[3] + a.dy_max;
     nlist[0] = 0;
     WB_END_SINGLE
+    WB_PSTAMP(a.ctl, 0);
     const bool use_list = nblk <= WB_MAX_BLOCKS;
     if (use_list) {
         const double pre_i0 = pre[i0];
@@ -415,6 +417,7 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
         WB_END_PFOR
     }
     const int nb = use_list ? nlist[0] : nblk;
+    WB_PSTAMP(a.ctl, 1);
     // the tile's rows live in LDS (read as broadcasts); a lane owns ONE candidate point j, keeps its data in
     // registers and sweeps the rows: per evaluated pair that is 0.4 global loads instead of 14
     const int nrows = i1 - i0;
@@ -426,12 +429,17 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
         ry[ii] = wb_pt_y(pts[i]);
         rl[ii] = a.dxlim[wb_pt_y(pts[i])];
     WB_END_PFOR
+    WB_PSTAMP(a.ctl, 2);
+#if defined(WB_STAMPS) && WB_STAMPS == 2
+    if (threadIdx.x == 0) { atomicAdd((unsigned long long*)&a.ctl->dbg[12], 1ull); atomicAdd((unsigned long long*)&a.ctl->dbg[13], (unsigned long long)nb); }
+#endif
     WB_PFOR(idx, (int64_t)nb * WB_BLK)
         const int bsel = (int)(idx / WB_BLK), jj = (int)(idx % WB_BLK);
         const int j = (use_list ? blist[bsel] : bsel) * WB_BLK + jj;
         if (j <= i0 || j >= N) continue;
         const int xj = wb_pt_x(pts[j]), yj = wb_pt_y(pts[j]);
         const double spj = t_sp[j], cpj = t_cp[j], cj = t_c[j], slj = t_sl[j], clj = t_cl[j], prej = pre[j];
+        uint32_t passed = 0;                                          // bit ii: pair (i0 + ii, j) is a candidate (WB_PAIR_ROWS <= 32)
         for (int ii = 0; ii < nrows; ++ii) {
             const int i = i0 + ii;
             if (j <= i) break;                                        // only j > i
@@ -465,12 +473,31 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
                 cont = acc;
             }
             if (!(cont > a.cont_dis)) continue;
-            const int slot = wb_atomic_add(&a.npairs[s], 1);
-            if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)i << 32) | (unsigned long long)j;
+            passed |= 1u << ii;
+        }
+        // the rows that passed are appended after the sweep, one returning atomic per wave (inside the row loop every
+        // row with a pass stalled the wave for a trip to L2: 16 trips per tile where streamers are)
+        int slot = wb_append_slots(&a.npairs[s], wb_popc32(passed));
+        while (passed) {
+            const int ii = wb_ctz32(passed);
+            passed &= passed - 1u;
+            if (slot < a.cap_pairs) pairs[slot] = ((unsigned long long)(i0 + ii) << 32) | (unsigned long long)j;
+            ++slot;
         }
     WB_END_PFOR
+    WB_PSTAMP(a.ctl, 3);
     }   // tiles
-    if (evaluated) wb_atomic_add((unsigned long long*)&a.ctl->evaluated_pairs, (unsigned long long)evaluated);
+    WB_PSTAMP_FLUSH(a.ctl);
+    // one global atomic per workgroup (the lanes' counts meet in LDS first: 64 lanes adding to one global word serialise)
+    WB_SHARED(unsigned long long, evsum, 1);
+    WB_SINGLE
+    evsum[0] = 0ull;
+    WB_END_SINGLE
+    if (evaluated) wb_atomic_add(&evsum[0], (unsigned long long)evaluated);
+    WB_SYNC();
+    WB_SINGLE
+    if (evsum[0]) wb_atomic_add((unsigned long long*)&a.ctl->evaluated_pairs, evsum[0]);
+    WB_END_SINGLE
 }
 
 #ifndef WB_F1_LTAB

@@ -46,6 +46,10 @@ static inline int wb_ctz32(uint32_t v) { return __builtin_ctz(v); }
 static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
 // base[idx] += val (no return value); on the GPU lanes of a wave that hit the same idx are combined first
 static inline void wb_atomic_add_agg(int* base, int idx, int val) { base[idx] += val; }
+// slot of an append to a list whose length counter all calling lanes share (-1 for lanes with want == false)
+static inline int wb_append_slot(int* counter, bool want) { return want ? (*counter)++ : -1; }
+// first slot of n (0 <= n < 32) consecutive entries appended by the calling lane
+static inline int wb_append_slots(int* counter, int n) { const int b = *counter; *counter += n; return b; }
 
 // in-place exclusive scan of a[0..n); returns the total
 static inline int wb_block_scan_excl(int* a, int n) {
@@ -112,6 +116,40 @@ __device__ inline void wb_atomic_add_agg(int* base, int idx, int val) {
         if (lane == leader) atomicAdd(&base[lidx], sum);
         todo &= ~same;
     }
+}
+
+// slot of an append to a list whose length counter ALL calling lanes share (-1 for lanes with want == false): one atomic
+// per wave instead of one per appending lane (same-address atomics serialise).  Call from code every lane of interest
+// reaches together; lanes that left the enclosing loop are simply not in the ballot.
+__device__ inline int wb_append_slot(int* counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return -1;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+// first slot of n (0 <= n < 32) consecutive entries appended by the calling lane: the wave's lanes reserve their entries
+// with ONE returning atomic (a returning atomic is a round trip to L2: one per lane and entry, inside a loop, sets the
+// loop's pace).  Prefix and total by bit-sliced ballots: well defined whatever lanes are inactive.
+__device__ inline int wb_append_slots(int* counter, int n) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) {
+        const unsigned long long m = __ballot((n >> bit) & 1);
+        prefix += __popcll(m & lt) << bit;
+        total += __popcll(m) << bit;
+    }
+    if (total == 0) return 0;
+    const int leader = __ffsll((long long)__ballot(1)) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, leader, 64);
+    return base + prefix;
 }
 
 // 64-wide inclusive wave scan (gfx950 wavefront = 64)

@@ -849,7 +849,9 @@ WB_KERNEL_LB(wb_k_trace_finish, 1024, 8, WbTraceArgs a) {
 // (they are the selected ones unless another rank / batch holds a larger maximum, in which case nothing is selected),
 // the closed contours (cutoff candidates), the work items of the all-pairs kernel.
 #define WB_PAIR_ROWS 16
+#ifndef WB_PAIR_TPB
 #define WB_PAIR_TPB 8             // 16-row tiles per work item of the all-pairs kernel
+#endif
 struct WbSummaryArgs {
     int njobs, cap_seg;
     const int* ncont; const int* c_len; const int* c_nux; const int* c_closed;
