@@ -49,6 +49,7 @@ struct wb_ctx {
     // 1440 x 721 f32) + the list build (0.24 ms); 0: the single classify-and-emit kernel wb_k_scan (1.5-1.7 ms)
     int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) == 0) ? 0 : 1;
     int scan_debug = 0;
+    int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
     int scan_variant = 1;                     // streaming scan: ring depth x waves per SIMD (0: 8 x 6, 1: 10 x 5, 2: 13 x 4, 3: 6 x 8)
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
@@ -682,7 +683,7 @@ static int run_phase1(wb_batch* b) {
             if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
             b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
             const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz);   // a patch buffer per wave
-            long long mwg = slots;
+            long long mwg = slots * (ctx->scan_grid_mult > 0 ? ctx->scan_grid_mult : 1);
             if (mwg > (long long)p.nt * sa.nbands) mwg = (long long)p.nt * sa.nbands;
             const dim3 mgrid((unsigned)mwg), sblock(64 * b->nwork_strips), bgrid((unsigned)items);
 #define WB_STREAM_F32(N) \
@@ -1831,6 +1832,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "keep_device")) { ctx->keep_device = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
+    if (!strcmp(name, "scan_grid_mult")) { ctx->scan_grid_mult = value; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;
 }
