@@ -61,8 +61,24 @@ def sq(d):
             g("SQ_INSTS_SALU"), g("SQ_INSTS_VMEM"), g("SQ_INSTS_LDS")))
 
 
+def raw(d, pattern=""):
+    """every counter found, summed over the dispatches of each kernel whose name contains `pattern`"""
+    acc = OrderedDict()
+    for path in find(d, "*counter_collection.csv"):
+        for row in csv.DictReader(open(path)):
+            if pattern in row["Kernel_Name"]:
+                k = (row["Kernel_Name"][:60], row["Counter_Name"])
+                v = acc.setdefault(k, [set(), 0.0])
+                v[0].add(row.get("Dispatch_Id"))
+                v[1] += float(row["Counter_Value"])
+    for (k, c), (ids, v) in acc.items():
+        print("%-62s %-28s calls %3d  sum %.0f  per call %.0f" % (k, c, len(ids), v, v / max(len(ids), 1)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "raw":
+        raw(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif sys.argv[1] == "sq":
         sq(sys.argv[2])

@@ -1,3 +1,4 @@
+"""Scan kernels alone on the bench batch: duration per variant (development tool; run on the GPU box)."""
 import sys, numpy as np, time
 sys.path.insert(0, '/root/repo')
 from wavebreaking_amd import _hip, synthetic as synth
@@ -18,5 +19,8 @@ def run(split, variant, debug):
         if t["scan"] < best:
             best, bb = t["scan"], t.get("scan_build", 0.0)
     return "%.3f ms  %.2f TB/s  build %.3f ms" % (best, nt*lat.size*lon.size*4/best/1e9, bb)
-for split, variant, debug in [(0,0,0),(1,0,0),(1,1,0),(1,2,0),(1,3,0),(1,1,1)]:
+configs = [(0,0,0),(1,0,0),(1,1,0),(1,2,0),(1,3,0),(1,1,1)]
+if len(sys.argv) == 4:                                 # one configuration (e.g. under rocprofv3 --pmc): split variant debug
+    configs = [tuple(int(v) for v in sys.argv[1:4])]
+for split, variant, debug in configs:
     print(split, variant, debug, run(split, variant, debug), flush=True)
