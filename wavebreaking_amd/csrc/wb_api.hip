@@ -1059,6 +1059,7 @@ WB_KERNEL(wb_k_event_offsets, WbEvFillArgs a) {
     const long long NE = (long long)NS + NO + a.ctl->ncut;
     a.ctl->NS = NS;
     a.ctl->NO = NO;
+    a.ctl->props_cursor = 0;
     if (NE > a.cap_ne) { a.ctl->overflow |= 1; a.ctl->NE = 0; a.ctl->ne_demand = (int)(NE > 0x7FFFFFFF ? 0x7FFFFFFF : NE); }
     else a.ctl->NE = (int)NE;
     WB_END_SINGLE

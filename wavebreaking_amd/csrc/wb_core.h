@@ -99,6 +99,8 @@ struct WbCtl {
     int com_rechecks[3];
     int ne_demand;               // events found when they exceeded cap_ne
     unsigned long long cell_count;
+    int props_cursor;            // next event of the property kernel's work queue
+    int pad0_;
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.

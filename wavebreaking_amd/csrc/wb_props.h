@@ -116,7 +116,15 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
     double* cells_d = (double*)cells;                     // box path, very wide boxes: chunk partials in the (then unused) cell scratch
     double* rowacc = a.rowacc + (size_t)slot * 4 * a.nlat;
     const int nev = a.ctl->NE;
-    for (int e = WB_BLOCK_ID; e < nev; e += WB_GRID_DIM) {
+    // events are handed out one by one (streamers, the expensive ones, come first in the table): with a fixed assignment a
+    // slot that drew several long streamers finished long after the others
+    WB_SHARED(int, cur, 1);
+    for (;;) {
+        WB_SINGLE
+        cur[0] = wb_atomic_add(&a.ctl->props_cursor, 1);
+        WB_END_SINGLE
+        const int e = cur[0];
+        if (e >= nev) break;
         const int* d = a.ev + (size_t)e * 8;
         const int kind = d[0] & 0xFF, job = d[1], cont = d[2];
         const size_t jb = (size_t)job * a.cap_seg;
