@@ -166,7 +166,9 @@ def main():
     def solo_pass(c, copy=False):
         """a single pass alone on the device"""
         b = phase1(c, 0)
-        res = phase2(c, 0, b, reduce_max(b.max_nux()), copy=copy)
+        gmax = reduce_max(b.max_nux())
+        res = phase2(c, 0, b, gmax, copy=copy)
+        res["gmax"] = gmax
         if res.get("batch") is not None:                       # N > 1: phase2 leaves the batch open for the gather
             res["batch"].close()
             res["batch"] = None
@@ -182,10 +184,13 @@ def main():
     solo = solo_pass(ctx)
     solo = solo_pass(ctx)
     solo_scan_ms = dict(solo["timings"]).get("scan", float("nan"))
-    pipe.run(a.warmup, phase1, reduce_max, phase2, collect_pass(False))
+    # every pass must select against the full width of the periodically extended grid, as one call over the record would
+    full_w = lon.size + int(120.0 / a.dlon)                    # periodic_add = 120, the default of the calls above
+    full_w = full_w if solo["gmax"] == full_w else None
+    pipe.run(a.warmup, phase1, reduce_max, phase2, collect_pass(False), full_width=full_w)
     barrier()
     tic = time.perf_counter()
-    pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True))
+    pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True), full_width=full_w)
     barrier()
     dt = time.perf_counter() - tic
     if world > 1:

@@ -122,6 +122,21 @@ out = {}
 for name in ("calculate_contours", "calculate_streamers", "calculate_overturnings", "calculate_cutoffs"):
     kw = dict(intensity=data) if name != "calculate_contours" else dict(original_coordinates=False)
     out[name] = wd.calculate_sharded(getattr(wb, name), data, [-2, 2], dist=dist, **kw)
+# a contour frame handed in (the whole record, on every rank): each rank keeps the rows of its own dates
+frame = wb.calculate_contours(data, [-2, 2], original_coordinates=False)
+out["streamers_from_frame"] = wd.calculate_sharded(wb.calculate_streamers, data, [-2, 2], dist=dist, contours=frame, intensity=data)
+# a rank that fails still enters the collectives: nobody hangs, every rank raises
+def failing(d, levels, **kw):
+    if dist.get_rank() == 1:
+        raise ValueError("boom")
+    return wb.calculate_cutoffs(d, levels, **kw)
+failing.__name__ = "calculate_cutoffs"
+try:
+    wd.calculate_sharded(failing, data, [-2, 2], dist=dist)
+    raised = None
+except Exception as e:
+    raised = type(e).__name__ + ": " + str(e)
+assert raised is not None and ("boom" in raised if dist.get_rank() == 1 else "another rank" in raised), raised
 if dist.get_rank() == 0:
     pickle.dump(out, open(sys.argv[2], "wb"))
 else:
@@ -160,7 +175,11 @@ def test_sharded_calls_return_the_single_process_frames(tmp_path, monkeypatch):
     data = wb.GridField(pv, ("time", "lat", "lon"), {"time": synth.times(NT), "lat": lat, "lon": lon}, name="PV")
     for name, frame in got.items():
         kw = dict(intensity=data) if name != "calculate_contours" else dict(original_coordinates=False)
-        want = getattr(wb, name)(data, [-2, 2], **kw)
+        if name == "streamers_from_frame":
+            cf = wb.calculate_contours(data, [-2, 2], original_coordinates=False)
+            want = wb.calculate_streamers(data, [-2, 2], contours=cf, intensity=data)
+        else:
+            want = getattr(wb, name)(data, [-2, 2], **kw)
         assert frame.columns.to_list() == want.columns.to_list() and len(frame) == len(want) > 0, name
         for col in want.columns:
             if col == "geometry":

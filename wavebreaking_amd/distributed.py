@@ -7,6 +7,8 @@ Exactly two exchanges exist: (1) all-reduce(max) of one int32 -- 
 cutoff_index.py:90); (2) one gather of the event tables to rank 0 (counts first, then the payload),
 concatenated in time order.
 """
+import os
+
 import numpy as np
 
 EVENT_FIELDS = ("step", "level_idx", "contour", "ind1", "ind2", "box", "orientation", "sums", "ncells")
@@ -20,8 +22,12 @@ def shard(nt_total, rank, world):
 
 
 def _device(dist):
+    """tensor device of the collectives: with RCCL the GPU of this rank's context -- LOCAL_RANK, the rule of
+    engine.get_context -- whatever torch's current device happens to be"""
     import torch
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
 
 
 def global_max_nux(local_max, dist=None):
@@ -226,23 +232,49 @@ def calculate_sharded(func, data, contour_levels, *args, dist=None, dst=0, **kwa
     rank, world = dist.get_rank(), dist.get_world_size()
     tn = kwargs.get("time_name") or du.get_time_name(data)
     first, count = shard(len(data[tn]), rank, world)
-    engine.set_global_max_hook(lambda g: global_max_nux(g, dist))
+    reduced = []                                                    # did this rank's call reach the all-reduce?
+
+    def hook(g):
+        reduced.append(True)
+        return global_max_nux(g, dist)
+
+    engine.set_global_max_hook(hook)
+    error = None
+    frame = pd.DataFrame()
     try:
-        if count == 0:
-            frame = pd.DataFrame()
-            if func.__name__ != "calculate_contours":
-                engine.global_max(0)                                 # keep the collective matched
-        else:
+        if count > 0:
             kw = dict(kwargs)
             if kw.get("intensity") is not None:
                 kw["intensity"] = _time_block(kw["intensity"], tn, first, count)
+            if kw.get("contours") is not None and len(kw["contours"]):
+                # a contour frame handed in covers the whole record: every rank keeps the rows of its own dates
+                block_times = set(engine._time_key(t) for t in np.asarray(_time_block(data, tn, first, count)[tn].values))
+                keep = [engine._time_key(t) in block_times for t in kw["contours"]["date"]]
+                kw["contours"] = kw["contours"][np.asarray(keep, dtype=bool)].reset_index(drop=True)
             frame = func(_time_block(data, tn, first, count), contour_levels, *args, **kw)
+    except Exception as e:                                           # a failing rank still enters the collectives below:
+        error = e                                                    # the others would wait for it forever otherwise
+        frame = pd.DataFrame()
     finally:
         engine.set_global_max_hook(None)
+    if func.__name__ != "calculate_contours" and not reduced:
+        global_max_nux(0, dist)                                      # empty shard / early failure: keep the collective matched
+    failed = _any_rank_failed(error is not None, dist)
     frames = gather_frames(frame, dist, dst)
+    if error is not None:
+        raise error
+    if failed:
+        raise RuntimeError("calculate_sharded: the call failed on another rank")
     if frames is None:
         return None
     frames = [f for f in frames if len(f)]
     if not frames:
         return frame
     return pd.concat(frames).reset_index(drop=True)
+
+
+def _any_rank_failed(mine, dist):
+    import torch
+    t = torch.tensor([1 if mine else 0], dtype=torch.int32, device=_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))

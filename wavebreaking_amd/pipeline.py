@@ -3,7 +3,14 @@
 A context (``_hip.Context``) is one HIP stream driven synchronously by one host thread: between its kernels the host
 reads back counts and builds work lists, and most of its kernels are latency-bound per-(step, level) jobs with a tail.
 Two contexts on the same device, each fed by its own thread, fill those gaps with the other batch's kernels
-(measured on MI355X, 0.25 degree, 1460 steps per batch: 11.2 ms per batch alone, 8.6 ms with two in flight).
+(measured on MI355X, 0.25 degree, 1460 steps per batch: 8.2 ms per batch alone, 6.5 ms with two in flight).
+
+Selection maximum.  The reference selects contours with ``exp_lon == exp_lon.max()`` over the WHOLE frame it is given
+(streamer_index.py:106).  Here every batch is a frame of its own: batch ``k`` is selected against the maximum over
+batch ``k`` on all ranks.  A record cut into batches therefore gives the single-call catalogue exactly when every batch
+holds a contour of the largest extent -- always, when each block of time steps has a circumglobal contour (extent = the
+width of the periodically extended grid, which no contour can exceed).  ``run(..., full_width=W)`` checks that: a batch
+whose reduced maximum is smaller than ``W`` raises instead of silently selecting against a smaller maximum.
 
 ``BatchPipeline`` keeps ``depth`` contexts, each with a single worker thread (so a context is never entered by two
 threads at once), and runs a sequence of batches through the two phases of the ABI.  Whatever must happen in program
@@ -35,11 +42,11 @@ class BatchPipeline:
         """free batch k on the worker thread of its context (a context, including its allocator, belongs to one thread)"""
         return self._workers[k % self.depth].submit(batch.close)
 
-    def run(self, n, contours, reduce_max, indices, collect):
+    def run(self, n, contours, reduce_max, indices, collect, full_width=None):
         """``n`` batches.  Worker of context ``k % depth``:  ``b = contours(ctx, k)`` then, once the caller's thread has
         turned the batch's local maximum into ``g = reduce_max(b.max_nux())``, ``r = indices(ctx, k, b, g)`` (which also
         closes the batch).  Caller's thread, in batch order: ``reduce_max`` and ``collect(k, r)``.  Returns the list of
-        ``collect`` results."""
+        ``collect`` results.  ``full_width``: the extent every batch's maximum must reach (see the module docstring)."""
         d = self.depth
         c_fut, i_fut, out = {}, {}, []
         for k in range(min(d, n)):
@@ -47,6 +54,9 @@ class BatchPipeline:
         for k in range(n):
             b = c_fut.pop(k).result()
             g = reduce_max(b.max_nux())
+            if full_width is not None and g != full_width:
+                raise RuntimeError("BatchPipeline: batch %d has no contour of extent %d (largest: %d): its selection would "
+                                   "differ from a single call over the whole record" % (k, full_width, g))
             i_fut[k] = self._workers[k % d].submit(indices, self.contexts[k % d], k, b, g)
             if k + d < n:
                 c_fut[k + d] = self._workers[k % d].submit(contours, self.contexts[k % d], k + d)
