@@ -68,8 +68,14 @@ def main():
     local = local % max(1, torch.cuda.device_count())          # dry runs with more ranks than GPUs share devices
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # WB_BENCH_FORCE_DIST=1: the N > 1 branch (process group, all-reduce, device-to-device gather) with whatever ranks there
+    # are -- with one rank it exercises the RCCL path on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("WB_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # "nccl" is RCCL over xGMI; WB_BENCH_BACKEND=gloo only serves dry runs of the N > 1 logic on fewer GPUs than ranks
         dist.init_process_group(os.environ.get("WB_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
@@ -85,7 +91,7 @@ def main():
         c.set_option("scan_variant", a.scan_variant)
         if os.environ.get("WB_BENCH_SCAN_GRID"):
             c.set_option("scan_grid_mult", int(os.environ["WB_BENCH_SCAN_GRID"]))
-        c.set_option("keep_device", 1 if world > 1 else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather
+        c.set_option("keep_device", 1 if multi else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
     levels = [-2.0, 2.0]
@@ -100,7 +106,7 @@ def main():
         ctx.synth_fill(d_int, np.float32, t0, nt, lat, lon, synth.wave_params(20241), a.eps, 20241)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -118,7 +124,7 @@ def main():
         return b
 
     def reduce_max(m):
-        return wd.global_max_nux(m, dist if world > 1 else None)                # exchange (1): one int32 all-reduce(max)
+        return wd.global_max_nux(m, dist if multi else None)                # exchange (1): one int32 all-reduce(max)
 
     def phase2(c, k, b, g, copy=False):
         w1 = time.perf_counter()
@@ -134,9 +140,9 @@ def main():
                                com_rechecks=b.com_rechecks(),
                                polygons_not_simple=int(sum(int(np.count_nonzero(e["flags"] & 1)) for e in ev)),
                                status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
-                   batch=b if world > 1 else None,
+                   batch=b if multi else None,
                    events=ev if copy else None)
-        if world == 1:
+        if not multi:
             b.close()
         res["wall"] = dict(contours_call=b._wall1, indices_call=1e3 * (w2 - w1), tables_call=1e3 * (w3 - w2),
                            free=1e3 * (time.perf_counter() - w3))
@@ -145,14 +151,15 @@ def main():
     def collect_pass(keep):
         def collect(k, res):
             w = time.perf_counter()
-            if world > 1:
+            if multi:
                 # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there)
-                cat = wd.gather_device_tables(res["batch"], dist, dst=0)
+                cat = wd.gather_device_tables(res["batch"], dist, dst=0, as_rows=True)   # (rows, poly_x, poly_y) on rank 0's host
                 pipe.close_batch(k, res["batch"])          # a context is single-threaded: its own worker frees the batch
                 res["batch"] = None
                 if keep and cat is not None:
-                    counts["gathered_events"] = int(sum(e["step"].size for e in cat))
-                    counts["gathered_polygon_vertices"] = int(sum(e["poly_x"].size for e in cat))
+                    counts["gathered_events"] = int(cat[0].shape[0])
+                    counts["gathered_polygon_vertices"] = int(cat[1].size)
+                    assert int(cat[0][:, 18].sum()) == cat[1].size == cat[2].size
             if keep:
                 for name, ms in res["timings"]:
                     stage_ms.setdefault(name, []).append(ms)
@@ -193,10 +200,11 @@ def main():
     pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True), full_width=full_w)
     barrier()
     dt = time.perf_counter() - tic
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    out = None
 
     if rank == 0:
         ms_per_step = 1e3 * dt / a.steps
@@ -236,11 +244,17 @@ def main():
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass)
-        print(json.dumps(out), flush=True)
     pipe.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)               # the ONE line
+    if multi:
+        # RCCL (with NCCL_DEBUG=VERSION in the environment) writes a version banner through C stdio that is flushed when
+        # the process winds down, i.e. BEHIND the result line: whatever a rank still sends to its standard output is dropped
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 def pmc_traffic(nt):

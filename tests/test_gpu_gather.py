@@ -1,0 +1,60 @@
+"""The device-to-device gather of bench.py's N > 1 branch on real hardware: RCCL (backend "nccl") with a process group of
+ONE rank on the one GPU of the test box -- the same code path as N ranks (size exchange, padded gather, pinned D2H), minus
+the peers.  Runs in a child process (a process group per test process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from oracle import synth
+from wavebreaking_amd import _hip
+from wavebreaking_amd import distributed as wd
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+lat, lon = synth.grid(1.0)
+pv = synth.pv_field(0, 6, lat, lon, eps=0.2)
+ctx = _hip.Context(0)
+ctx.set_option("keep_device", 1)
+b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 1.0, 1.0, intensity=pv)
+g = wd.global_max_nux(b.max_nux(), dist)
+assert g == b.max_nux()
+b.set_step_offset(100)
+b.indices(g)
+want = [b.events(k, copy=True) for k in (0, 1, 2)]
+for rep in range(2):                                    # second call: the pinned buffers are reused
+    rows, px, py = wd.gather_device_tables(b, dist, dst=0, as_rows=True)
+    assert rows.shape == (sum(e["step"].size for e in want), 20) and rows.shape[0] > 0
+    assert int(rows[:, 18].sum()) == px.size == py.size == sum(e["poly_x"].size for e in want)
+    got = wd.rows_to_events(rows, px, py)
+    for e, w in zip(got, want):
+        assert np.array_equal(e["step"], w["step"] + 100) or np.array_equal(e["step"], w["step"])
+        for key in ("level_idx", "ind1", "ind2", "box", "orientation", "ncells", "flags", "poly_offset", "poly_x", "poly_y"):
+            assert np.array_equal(e[key], w[key]), key
+        assert np.array_equal(e["sums"], w["sums"])
+cat = wd.gather_device_tables(b, dist, dst=0)
+assert [e["step"].size for e in cat] == [w["step"].size for w in want]
+b.close()
+dist.barrier()
+dist.destroy_process_group()
+print("GATHER_OK")
+'''
+
+
+@pytest.mark.gpu
+def test_device_gather_over_rccl_single_rank(tmp_path):
+    script = tmp_path / "worker_gather.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "GATHER_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

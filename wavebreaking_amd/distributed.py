@@ -8,6 +8,7 @@ cutoff_index.py:90); (2) one gather of the event tables to rank 0 (counts first,
 concatenated in time order.
 """
 import os
+import sys
 
 import numpy as np
 
@@ -30,14 +31,48 @@ def _device(dist):
     return torch.device("cuda", int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
 
 
+_streams = {}
+
+
+class _exchange_stream:
+    """``with _exchange_stream(dev):`` -- the tensor work of an exchange runs on a stream of its own.  torch's default
+    stream is the device's NULL stream, which is ordered against every blocking stream of the process: a 4-byte upload on
+    it waits for all kernels the library's contexts have queued (a whole pass, ~8 ms measured) and would serialise the
+    batches in flight.  torch's non-default streams are non-blocking.  Leaving the block waits for the stream: buffers
+    of the batch may be freed, results may be read."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.cm = None
+
+    def __enter__(self):
+        if self.dev.type == "cuda":
+            import torch
+            key = (self.dev.index, __import__("threading").get_ident())
+            if key not in _streams:
+                _streams[key] = torch.cuda.Stream(device=self.dev)
+            self.stream = _streams[key]
+            self.cm = torch.cuda.stream(self.stream)
+            self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            self.stream.synchronize()
+            self.cm.__exit__(*exc)
+        return False
+
+
 def global_max_nux(local_max, dist=None):
     """exchange (1)"""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return int(local_max)
     import torch
-    t = torch.tensor([int(local_max)], dtype=torch.int32, device=_device(dist))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(t.item())
+    dev = _device(dist)
+    with _exchange_stream(dev):
+        t = torch.tensor([int(local_max)], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
 
 
 def pack_events(ev, step_offset=0, contour_offset=0):
@@ -70,28 +105,29 @@ def gather_event_tables(tables, dist=None, dst=0):
         return [np.asarray(t) for t in tables]
     import torch
     world, rank, dev = dist.get_world_size(), dist.get_rank(), _device(dist)
-    counts = torch.tensor([t.shape[0] for t in tables], dtype=torch.int64, device=dev)
-    all_counts = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts)
-    all_counts = torch.stack(all_counts).cpu().numpy()                 # (world, n_tables)
-    rows = all_counts.sum(axis=1)
     width = 18
-    mx = int(rows.max())
-    buf = torch.zeros((mx, width), dtype=torch.float64, device=dev)
-    mine = np.concatenate([np.asarray(t, dtype=np.float64).reshape(-1, width) for t in tables], axis=0)
-    if mine.shape[0]:
-        buf[: mine.shape[0]] = torch.from_numpy(mine).to(dev)
-    out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
-    if rank != dst:
-        return None
+    with _exchange_stream(dev):
+        counts = torch.tensor([t.shape[0] for t in tables], dtype=torch.int64, device=dev)
+        all_counts = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(all_counts, counts)
+        all_counts = torch.stack(all_counts).cpu().numpy()                 # (world, n_tables)
+        rows = all_counts.sum(axis=1)
+        mx = int(rows.max())
+        buf = torch.zeros((mx, width), dtype=torch.float64, device=dev)
+        mine = np.concatenate([np.asarray(t, dtype=np.float64).reshape(-1, width) for t in tables], axis=0)
+        if mine.shape[0]:
+            buf[: mine.shape[0]] = torch.from_numpy(mine).to(dev)
+        out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, out, dst=dst)
+        if rank != dst:
+            return None
+        blocks = [out[r].cpu().numpy() for r in range(world)]
     res = [[] for _ in tables]
     for r in range(world):
-        block = out[r].cpu().numpy()
         o = 0
         for k in range(len(tables)):
             c = int(all_counts[r, k])
-            res[k].append(block[o:o + c])
+            res[k].append(blocks[r][o:o + c])
             o += c
     return [np.concatenate(v, axis=0) if v else np.zeros((0, width)) for v in res]
 
@@ -122,65 +158,110 @@ ROW_FIELDS = dict(step=0, level_idx=1, contour=2, ind1=3, ind2=4, orientation=9,
 
 
 def rows_to_events(rows, poly_x, poly_y):
-    """packed device rows (n, 20) + the vertices of the same events -> the three event dictionaries of Batch.events()"""
+    """packed device rows (n, 20) + the vertices of the same events -> the three event dictionaries of Batch.events()
+    (a formatting step for consumers that want the per-index tables; no per-event Python)"""
     rows = np.asarray(rows, dtype=np.float64).reshape(-1, 20)
+    poly_x, poly_y = np.asarray(poly_x), np.asarray(poly_y)
     npoly = rows[:, 18].astype(np.int64)
     start = np.cumsum(npoly) - npoly
     out = []
     for kind in (0, 1, 2):
         m = rows[:, 16] == kind
         r = rows[m]
-        vidx = np.concatenate([np.arange(s0, s0 + k) for s0, k in zip(start[m], npoly[m])]) if m.any() else np.zeros(0, np.int64)
+        lens, first = npoly[m], start[m]
+        own = np.cumsum(lens) - lens                                   # offsets inside this kind's vertex arrays
+        vidx = np.repeat(first - own, lens) + np.arange(int(lens.sum()), dtype=np.int64)
         i32 = lambda c: r[:, c].astype(np.int32)
         out.append(dict(step=i32(0), level_idx=i32(1), contour=r[:, 2].astype(np.int64), ind1=i32(3), ind2=i32(4),
                         box=r[:, 5:9].astype(np.int32), orientation=i32(9), sums=r[:, 10:15].copy(), ncells=i32(15), flags=i32(17),
-                        poly_offset=np.concatenate([[0], np.cumsum(npoly[m])]).astype(np.int64),
-                        poly_x=np.asarray(poly_x)[vidx].astype(np.int32), poly_y=np.asarray(poly_y)[vidx].astype(np.int32)))
+                        poly_offset=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
+                        poly_x=poly_x[vidx].astype(np.int32), poly_y=poly_y[vidx].astype(np.int32)))
     return out
 
 
-def gather_device_tables(batch, dist=None, dst=0):
-    """exchange (2) without host staging: the packed event rows and polygon vertices that ``Batch.indices`` left on the
-    device (context option "keep_device") travel device-to-device in one gather each (sizes first); ``dst`` copies the
-    concatenation to the host ONCE and returns [streamers, overturnings, cutoffs] in rank (= time) order -- the complete
-    catalogue including geometry; the other ranks return None.  ``batch`` may be None on a rank without time steps."""
+_pinned = {}
+
+
+def _pinned_host(name, shape, dtype):
+    """a pinned host tensor of at least `shape` (first axis may be larger), kept for the next gather"""
     import torch
-    single = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    t = _pinned.get(name)
+    if t is None or t.shape[0] < shape[0] or tuple(t.shape[1:]) != tuple(shape[1:]):
+        grown = (int(shape[0] * 1.25) + 1,) + tuple(shape[1:])
+        t = torch.empty(grown, dtype=dtype, pin_memory=True)
+        _pinned[name] = t
+    return t
+
+
+def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
+    """exchange (2) without host staging: the packed event rows and polygon vertices that ``Batch.indices`` left on the
+    device (context option "keep_device") travel device-to-device in one gather each (sizes first); ``dst`` copies every
+    rank's part to the host ONCE (into pinned buffers kept between calls) -- the complete catalogue including geometry,
+    in rank (= time) order; the other ranks return None.  ``batch`` may be None on a rank without time steps.  When the
+    call returns the batch's device buffers are no longer needed (the batch may be closed).
+
+    Returns [streamers, overturnings, cutoffs] (the dictionaries of ``Batch.events``), or with ``as_rows`` the catalogue
+    as it travelled: ``(rows (n, 20) float64, poly_x, poly_y)`` -- row k owns the next ``rows[k, 18]`` vertices, its index
+    is ``rows[k, 16]`` (``rows_to_events`` converts; the arrays are views of the pinned buffers, valid until the next call)."""
+    import torch
+    single = dist is None or not dist.is_initialized()      # an initialised group of ONE rank still takes the collective path
     if batch is None:
         ptr, n3, px, py, nv, on_gpu = 0, (0, 0, 0), 0, 0, 0, (not single and dist.get_backend() == "nccl")
     else:
         ptr, n3, px, py, nv = batch.device_tables()
         on_gpu = batch.ctx.L.backend == "hip"
     ne = sum(n3)
-    rows = _wrap(ptr, (ne, 20), np.float64, on_gpu)
-    vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+    done = (lambda r, x, y: (r, x, y)) if as_rows else rows_to_events
     if single:
-        return rows_to_events(rows.cpu().numpy(), vx.cpu().numpy(), vy.cpu().numpy())
-    if dist.get_backend() != "nccl":                        # dry runs of the N > 1 logic over gloo: CPU tensors
-        rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
-    world, rank, dev = dist.get_world_size(), dist.get_rank(), rows.device
-    counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
-    allc = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(allc, counts)
-    allc = torch.stack(allc).cpu().numpy()
-    me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
-    rbuf = torch.zeros((max(me, 1), 20), dtype=torch.float64, device=dev)
-    vbuf = torch.zeros((2, max(mv, 1)), dtype=torch.int32, device=dev)
-    if ne:
-        rbuf[:ne] = rows
-    if nv:
-        vbuf[0, :nv] = vx
-        vbuf[1, :nv] = vy
-    rout = [torch.zeros_like(rbuf) for _ in range(world)] if rank == dst else None
-    vout = [torch.zeros_like(vbuf) for _ in range(world)] if rank == dst else None
-    dist.gather(rbuf, rout, dst=dst)
-    dist.gather(vbuf, vout, dst=dst)
-    if rank != dst:
-        return None
-    rcat = torch.cat([rout[r][: int(allc[r, 0])] for r in range(world)]).cpu().numpy()      # the one copy to the host
-    vcat = torch.cat([vout[r][:, : int(allc[r, 1])] for r in range(world)], dim=1).cpu().numpy()
-    # rows are (streamers, overturnings, cutoffs) per rank: rows_to_events selects by kind, rank order = time order
-    return rows_to_events(rcat, vcat[0], vcat[1])
+        rows = _wrap(ptr, (ne, 20), np.float64, on_gpu)
+        vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+        return done(rows.cpu().numpy(), vx.cpu().numpy(), vy.cpu().numpy())
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = _device(dist)
+    with _exchange_stream(dev):
+        rows = _wrap(ptr, (ne, 20), np.float64, on_gpu)
+        vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+        if dev.type != "cuda":                              # dry runs of the N > 1 logic over gloo: CPU tensors
+            rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
+        counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(allc, counts)
+        allc = torch.stack(allc).cpu().numpy()
+        me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
+        rbuf = torch.zeros((max(me, 1), 20), dtype=torch.float64, device=dev)
+        vbuf = torch.zeros((2, max(mv, 1)), dtype=torch.int32, device=dev)
+        if ne:
+            rbuf[:ne] = rows
+        if nv:
+            vbuf[0, :nv] = vx
+            vbuf[1, :nv] = vy
+        rout = [torch.zeros_like(rbuf) for _ in range(world)] if rank == dst else None
+        vout = [torch.zeros_like(vbuf) for _ in range(world)] if rank == dst else None
+        dist.gather(rbuf, rout, dst=dst)
+        dist.gather(vbuf, vout, dst=dst)
+        if rank != dst:
+            return None                                     # (leaving the block waits for the staging copies and the sends)
+        tot_e, tot_v = int(allc[:, 0].sum()), int(allc[:, 1].sum())
+        if dev.type != "cuda":
+            rcat = torch.cat([rout[r][: int(allc[r, 0])] for r in range(world)]).numpy()
+            vcat = torch.cat([vout[r][:, : int(allc[r, 1])] for r in range(world)], dim=1).numpy()
+            return done(rcat, vcat[0], vcat[1])
+        # the one copy to the host: every rank's valid part straight into pinned memory
+        hr = _pinned_host("rows", (max(tot_e, 1), 20), torch.float64)
+        hx = _pinned_host("vx", (max(tot_v, 1),), torch.int32)
+        hy = _pinned_host("vy", (max(tot_v, 1),), torch.int32)
+        oe = ov = 0
+        for r in range(world):
+            k, v = int(allc[r, 0]), int(allc[r, 1])
+            if k:
+                hr[oe:oe + k].copy_(rout[r][:k], non_blocking=True)
+            if v:
+                hx[ov:ov + v].copy_(vout[r][0, :v], non_blocking=True)
+                hy[ov:ov + v].copy_(vout[r][1, :v], non_blocking=True)
+            oe += k
+            ov += v
+    # rows are (streamers, overturnings, cutoffs) per rank, rank order = time order
+    return done(hr[:tot_e].numpy(), hx[:tot_v].numpy(), hy[:tot_v].numpy())
 
 
 # ------------------------------------------------------------------------------------------------ whole calls
@@ -205,17 +286,18 @@ def gather_frames(frame, dist, dst=0):
     import torch
     world, rank, dev = dist.get_world_size(), dist.get_rank(), _device(dist)
     blob = np.frombuffer(pickle.dumps(frame, protocol=pickle.HIGHEST_PROTOCOL), dtype=np.uint8)
-    size = torch.tensor([blob.size], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    sizes = [int(t.item()) for t in sizes]
-    buf = torch.zeros(max(sizes), dtype=torch.uint8, device=dev)
-    buf[: blob.size] = torch.from_numpy(blob.copy()).to(dev)
-    out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
-    if rank != dst:
-        return None
-    return [pickle.loads(out[r][: sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
+    with _exchange_stream(dev):
+        size = torch.tensor([blob.size], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(size) for _ in range(world)]
+        dist.all_gather(sizes, size)
+        sizes = [int(t.item()) for t in sizes]
+        buf = torch.zeros(max(sizes), dtype=torch.uint8, device=dev)
+        buf[: blob.size] = torch.from_numpy(blob.copy()).to(dev)
+        out = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, out, dst=dst)
+        if rank != dst:
+            return None
+        return [pickle.loads(out[r][: sizes[r]].cpu().numpy().tobytes()) for r in range(world)]
 
 
 def calculate_sharded(func, data, contour_levels, *args, dist=None, dst=0, **kwargs):
@@ -275,6 +357,8 @@ def calculate_sharded(func, data, contour_levels, *args, dist=None, dst=0, **kwa
 
 def _any_rank_failed(mine, dist):
     import torch
-    t = torch.tensor([1 if mine else 0], dtype=torch.int32, device=_device(dist))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return bool(int(t.item()))
+    dev = _device(dist)
+    with _exchange_stream(dev):
+        t = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
