@@ -31,6 +31,11 @@ helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2, -2, 1.5])
 from oracle import spatial as ospatial
 five = np.array([[0, 1, 0], [1, 2, 1], [0, 1, 0]])
 assert np.array_equal(ctx.smooth_field(pv, 3, five), ospatial.smooth_field(pv, 3, five), equal_nan=True)
+# track_events: row tables, exact overlaps, union-find (tests/test_tracking.py cases)
+from tests import test_tracking as tt
+tt._kernel_overlaps(ctx)
+tt._kernel_tracking(ctx)
+tt._kernel_thresholds(ctx)
 ctx.close()
 print("SANITIZED_OK")
 """
