@@ -203,6 +203,30 @@ def test_time_and_level_chunking_keep_the_frame_order(hostsim_engine, monkeypatc
     _check_events(s, ref["streamers"], cols[:6] + ["geometry"])
 
 
+def test_blocks_without_a_full_width_contour_wait_for_the_record_maximum(hostsim_engine, monkeypatch):
+    # the index functions finish a block of time steps as soon as the selection maximum is known (a contour spanning the
+    # whole periodically extended grid); here NO contour of level -2 does, in any block: every block has to wait for the
+    # maximum over the record, and a block that holds none of the widest contours selects nothing
+    data, pv, lat, lon, tm = _field(nt=4, dlon=2.5, eps=0.2)
+    pv = pv.copy()
+    pv[:, :, 0:6] = 0.0                                 # a meridional wall cuts the circumglobal -2 contour
+    pv[2:, :, 60:70] = 0.0                              # ... a second one shortens what is left of it in the second block
+    data = wb.GridField(pv, data.dims, data.coords, name="PV")
+    ref = oapi.run_all(pv, [-2], lat, lon, tm)
+    width = len(lon) + int(120 / 2.5)
+    spans = {}
+    for c in ref["contours"]:
+        spans.setdefault(c["date"], []).append(c["exp_lon"] / 2.5)
+    assert max(max(v) for v in spans.values()) < width
+    assert len({max(v) for v in spans.values()}) > 1     # the blocks differ in their own maxima
+    cols = ["date", "level", "com", "mean_var", "intensity", "event_area", "geometry"]
+    monkeypatch.setenv("WB_MAX_STEPS_PER_BATCH", "2")
+    for name in ("streamers", "overturnings", "cutoffs"):
+        got = getattr(wb, "calculate_" + name)(data, [-2])
+        _check_events(got, ref[name], cols[:6] + (["orientation"] if name == "overturnings" else []) + ["geometry"])
+    assert sum(len(ref[k]) for k in ("streamers", "overturnings", "cutoffs")) > 0
+
+
 # ------------------------------------------------------------------ processing/spatial.py (tests/test_wavebreaking.py:107-112)
 def _spatial_checks():
     from oracle import spatial as ospatial

@@ -109,8 +109,8 @@ def max_steps_per_batch():
 
 def iter_contour_batches(prep, levels, periodic_add, params, want_cells=False):
     """yields (batch, level positions, first time step): one ABI batch per block of time steps and group of <= 4 levels; the
-    consumer closes each batch (calculate_contours does so as soon as it has the batch's table, so device memory holds
-    one block at a time)"""
+    consumer closes each batch (calculate_contours does so as soon as it has the batch's table, the index functions as soon
+    as the block's events are on the host -- device memory holds one block at a time; WB_MAX_STEPS_PER_BATCH sets its size)"""
     ctx = get_context()
     nt = prep.values.shape[0]
     chunk = max_steps_per_batch()
@@ -127,32 +127,6 @@ def iter_contour_batches(prep, levels, periodic_add, params, want_cells=False):
                 b.close()
                 raise
             yield b, pos, t0
-
-
-def contour_batches(prep, levels, periodic_add, params, want_cells=False):
-    """[(batch, level positions, first time step)]: one ABI batch per block of time steps and group of <= 4 levels.
-    All batches stay alive until the caller has the maximum of ``max_nux`` over them (the reference selects contours
-    with ``exp_lon == exp_lon.max()`` over the WHOLE frame, streamer_index.py:106)."""
-    ctx = get_context()
-    out = []
-    nt = prep.values.shape[0]
-    chunk = max_steps_per_batch()
-    for t0 in range(0, nt, chunk):
-        t1 = min(nt, t0 + chunk)
-        inten = None if prep.intensity is None else prep.intensity[t0:t1]
-        for lo in range(0, len(levels), MAX_LEVELS):
-            pos = list(range(lo, min(lo + MAX_LEVELS, len(levels))))
-            b = ctx.contours(prep.values[t0:t1], prep.lat, prep.lon, [float(levels[i]) for i in pos], prep.dlon, prep.dlat,
-                             periodic_add=periodic_add, intensity=inten, want_cells=want_cells, **params)
-            try:
-                check_batch(b, "contours", prep.times, levels, pos, t0)
-            except Exception:
-                b.close()
-                for ob, *_ in out:
-                    ob.close()
-                raise
-            out.append((b, pos, t0))
-    return out
 
 
 def _time_key(t):

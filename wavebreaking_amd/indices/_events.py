@@ -9,64 +9,89 @@ from wavebreaking_amd.utils import index_utils as iu
 DIM_KEYS = ("time_name", "lon_name", "lat_name", "ntime", "nlon", "nlat", "dlon", "dlat")
 
 
+class LazyContours:
+    """what the decorator hands to an index function in place of the contour frame when the caller gave none: the index
+    functions trace the contours themselves, block of time steps by block, and nothing needs the frame (the reference's
+    decorator builds it, contour_index.py:197-249, only to pass it on)."""
+    empty = False
+
+    def __len__(self):
+        return 1
+
+
 def run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max=None):
     """kind: _hip.STREAMERS / OVERTURNINGS / CUTOFFS.  Returns the reference-shaped frame."""
     dim_kwargs = {k: kwargs[k] for k in DIM_KEYS}
     prep = engine.Prepared(data, intensity, dim_kwargs)
-    state = kwargs.get("_wb_state")
     ctx = engine.get_context()
-    own = state is not None and contours is state.get("frame")     # the frame the decorator computed a moment ago
-    if own and len(contours) == state["nrows"]:
-        batches, levels = state["batches"], state["levels"]          # contours (and fields) the decorator put on the device: reuse
-        for b, *_ in batches:
-            b.set_index_params(**params)
-    else:
-        if state is not None:
-            for b, *_ in state["batches"]:
-                b.close()
-        levels = engine.as_levels(contour_levels)
-        if own:
-            batches = engine.contour_batches(prep, levels, periodic_add, params)
-        else:
-            table, levels = engine.frame_to_table(contours, prep.times, levels)
-            b = ctx.batch_from_contours(table, prep.values, prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
-                                        prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=prep.intensity,
-                                        **params)
-            batches = [(b, None, 0)]
-    g = max(b.max_nux() for b, *_ in batches) if batches else 0          # contours.exp_lon.max(), streamer_index.py:106
-    if global_max is not None:
-        g = max(g, int(global_max))
-    g = engine.global_max(g)                                               # time-sharded runs: all-reduce(max) across ranks
     which = {_hip.STREAMERS: dict(streamers=True, overturnings=False, cutoffs=False),
              _hip.OVERTURNINGS: dict(streamers=False, overturnings=True, cutoffs=False),
              _hip.CUTOFFS: dict(streamers=False, overturnings=False, cutoffs=True)}[kind]
-    # per batch: events + their geometry in lon / lat (transform_polygons for the whole table in the library); no per-event
-    # Python work except wrapping a ring array into a geometry object
     parts = []
-    batches = list(batches)
-    for bi, (b, pos, t0) in enumerate(batches):
-        b.indices(g, **which)
+    pending = []                                   # batches whose contours exist and whose indices wait for the maximum
+
+    def finish(g):
+        """phase 2 for the pending batches against the selection maximum g: events + their geometry in lon / lat
+        (transform_polygons for the whole table in the library); no per-event Python except wrapping a ring array into a
+        geometry object.  Every batch is released as soon as its tables are on the host."""
+        while pending:
+            b, pos, t0 = pending.pop(0)
+            try:
+                b.indices(g, **which)
+                engine.check_batch(b, "indices", prep.times, levels, pos, t0)
+                ev = b.events(kind)
+                n = ev["step"].size
+                if n:
+                    ring_off, vert_off, gx, gy = b.event_geometry(kind)
+                    if pos is not None:
+                        step = ev["step"].astype(np.int64) + t0
+                        lpos = np.asarray(pos, dtype=np.int64)[ev["level_idx"]]
+                    else:                       # a frame handed in: one job per contour row, rows keep the frame's order
+                        step = ev["step"].astype(np.int64)
+                        lpos = ev["level_idx"].astype(np.int64)
+                    parts.append(dict(step=step, lpos=lpos, sums=ev["sums"], orientation=ev["orientation"],
+                                      ring_off=ring_off, vert_off=vert_off, gx=gx, gy=gy, n=n))
+            except Exception:
+                for ob, *_ in pending:
+                    ob.close()
+                del pending[:]
+                raise
+            finally:
+                b.close()
+
+    if isinstance(contours, LazyContours):
+        # contours traced here, one block of time steps (and group of <= 4 levels) at a time.  The reference selects the
+        # contours with exp_lon == exp_lon.max() over the WHOLE frame (streamer_index.py:106): no contour can span more
+        # than the full width of the periodically extended grid, so as soon as one does the maximum is known and every
+        # block is finished and released right after its contours exist -- device memory then holds one block at a time.
+        levels = engine.as_levels(contour_levels)
+        full_width = prep.nlon + int(periodic_add / prep.dlon)
+        g_local, nbatches = 0, 0
         try:
-            engine.check_batch(b, "indices", prep.times, levels, pos, t0)
+            for item in engine.iter_contour_batches(prep, levels, periodic_add, params):
+                nbatches += 1
+                pending.append(item)
+                g_local = max(g_local, item[0].max_nux())
+                if g_local >= full_width and (global_max is None or int(global_max) <= full_width):
+                    finish(full_width)
         except Exception:
-            for ob, *_ in batches:
+            for ob, *_ in pending:
                 ob.close()
             raise
-        ev = b.events(kind)
-        n = ev["step"].size
-        if n == 0:
-            continue
-        ring_off, vert_off, gx, gy = b.event_geometry(kind)
-        if pos is not None:
-            step = ev["step"].astype(np.int64) + t0
-            lpos = np.asarray(pos, dtype=np.int64)[ev["level_idx"]]
-        else:                                   # a frame handed in: one job per contour row, rows keep the frame's order
-            step = ev["step"].astype(np.int64)
-            lpos = ev["level_idx"].astype(np.int64)
-        parts.append(dict(step=step, lpos=lpos, order_key=(step if pos is not None else np.arange(n)), sums=ev["sums"],
-                          orientation=ev["orientation"], ring_off=ring_off, vert_off=vert_off, gx=gx, gy=gy, n=n))
-    for b, *_ in batches:
-        b.close()
+        g = engine.global_max(max(g_local, int(global_max)) if global_max is not None else g_local)   # time-sharded runs: ONE all-reduce(max) per call
+        finish(g)
+        several = nbatches > 1
+    else:
+        table, levels = engine.frame_to_table(contours, prep.times, engine.as_levels(contour_levels))
+        b = ctx.batch_from_contours(table, prep.values, prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
+                                    prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=prep.intensity, **params)
+        g = b.max_nux()                                                        # contours.exp_lon.max(), streamer_index.py:106
+        if global_max is not None:
+            g = max(g, int(global_max))
+        g = engine.global_max(g)
+        pending.append((b, None, 0))
+        finish(g)
+        several = False
     if not parts:
         return _gf.empty_frame()                                          # streamer_index.py:278-279
     step = np.concatenate([p["step"] for p in parts])
@@ -80,7 +105,7 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
         ro, vo = p["ring_off"], p["vert_off"]
         for k in range(p["n"]):
             geoms.append(_gf.make_polygon([xy[vo[q]:vo[q + 1]] for q in range(ro[k], ro[k + 1])]))
-    if len(parts) > 1 and batches[0][1] is not None:
+    if len(parts) > 1 and several:
         # several batches (time blocks, level groups): time-major, level-minor, event order inside a (step, level) kept
         order = np.lexsort((np.arange(step.size), lpos, step))
         step, lpos, sums, orient_code = step[order], lpos[order], sums[order], orient_code[order]
