@@ -89,6 +89,8 @@ def main():
     for c in pipe.contexts:
         c.set_option("scan_split", a.scan_split)
         c.set_option("scan_variant", a.scan_variant)
+        if os.environ.get("WB_BENCH_HALO_LDS"):
+            c.set_option("scan_halo_lds", int(os.environ["WB_BENCH_HALO_LDS"]))
         if os.environ.get("WB_BENCH_SCAN_GRID"):
             c.set_option("scan_grid_mult", int(os.environ["WB_BENCH_SCAN_GRID"]))
         c.set_option("keep_device", 1 if multi else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather

@@ -77,6 +77,18 @@ def test_quarter_degree_parity(ctx):
 
 
 @two_scans
+def test_consecutive_launches_on_different_fields(ctx):
+    # the streaming scan's workgroups hand each other halo columns through LDS, which keeps its contents from one launch
+    # to the next: two rough fields of the same shape one after the other (a stale halo of the first gave the second 6-8
+    # extra contours before the tags were cleared at kernel start), and the first again
+    lat, lon = synth.grid(0.25)
+    tm = synth.times(2)
+    a = synth.pv_field(500, 2, lat, lon, eps=0.3, seed=7)
+    b = synth.pv_field(900, 2, lat, lon, eps=0.3, seed=11)
+    for pv in (a, b, a):
+        helpers.full_parity(ctx, pv, lat, lon, tm, [-2, 2])
+
+
 def test_capacity_retry_paths(ctx):
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(2, 2, lat, lon, eps=0.3)

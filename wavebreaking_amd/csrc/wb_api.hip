@@ -49,6 +49,7 @@ struct wb_ctx {
     // 1440 x 721 f32) + the list build (0.24 ms); 0: the single classify-and-emit kernel wb_k_scan (1.5-1.7 ms)
     int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) == 0) ? 0 : 1;
     int scan_debug = 0;
+    int scan_halo_lds = 1;                    // streaming scan: halo columns through LDS (0: scalar loads)
     int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
     int scan_variant = 1;                     // streaming scan: ring depth x waves per SIMD (0: 8 x 6, 1: 10 x 5, 2: 13 x 4, 3: 6 x 8)
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
@@ -663,7 +664,7 @@ static int run_phase1(wb_batch* b) {
             const long long items = (long long)p.nt * b->nwork_strips;
             // one workgroup per (time step, row band) item (a wave per strip), persistent; ring depth / waves per SIMD by option
             const int variant = ctx->scan_variant;
-            const int wps = !(p.dtype == 0 && vec) ? 4 : (variant == 1 ? 5 : (variant == 2 ? 4 : (variant == 3 ? 8 : 6)));
+            const int wps = !(p.dtype == 0 && vec) ? 4 : ((variant == 1 || variant == 4 || variant == 5) ? 5 : (variant == 2 ? 4 : (variant == 3 ? 8 : 6)));
             int wg_per_cu = (wps * 4) / b->nwork_strips;
             if (wg_per_cu < 1) wg_per_cu = 1;
             const long long slots = (long long)ncu * wg_per_cu;
@@ -671,6 +672,10 @@ static int run_phase1(wb_batch* b) {
             int nbands = (int)((6 * slots + p.nt - 1) / p.nt);
             if (nbands < 1) nbands = 1;
             if (nbands > 8) nbands = 8;
+            {   // bands short enough for the LDS halo exchange of the streaming kernel (wb_k_scan_build handles up to 16)
+                const int minb = (nlat - 1 + 254) / 255;
+                if (vec && p.dtype == 0 && ctx->scan_halo_lds && nbands < minb && minb <= 16) nbands = minb;
+            }
             if (nbands > nlat - 1) nbands = nlat - 1;
             sa.band_rows = (nlat - 1 + nbands - 1) / nbands;
             sa.nbands = (nlat - 1 + sa.band_rows - 1) / sa.band_rows;
@@ -682,18 +687,24 @@ static int run_phase1(wb_batch* b) {
             sa.cap_n = balloc<int>(b, (size_t)lists);
             if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
             b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
-            const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz);   // a patch buffer per wave
+            // the strips of a workgroup hand each other the halo column through LDS when a band's rows fit (vector loads only)
+            sa.halo_rows = (vec && p.dtype == 0 && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
+            const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz)    // a patch buffer per wave
+                                + (size_t)b->nwork_strips * sa.halo_rows * (esz + 4);
             long long mwg = slots * (ctx->scan_grid_mult > 0 ? ctx->scan_grid_mult : 1);
             if (mwg > (long long)p.nt * sa.nbands) mwg = (long long)p.nt * sa.nbands;
             const dim3 mgrid((unsigned)mwg), sblock(64 * b->nwork_strips), bgrid((unsigned)items);
 #define WB_STREAM_F32(N) \
-            switch (variant) { \
-                case 1: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 10, 5>), mgrid, sblock, slds, ctx->stream, sa); break; \
-                case 2: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 13, 4>), mgrid, sblock, slds, ctx->stream, sa); break; \
-                case 3: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 6, 8>), mgrid, sblock, slds, ctx->stream, sa); break; \
-                default: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6>), mgrid, sblock, slds, ctx->stream, sa); break; \
+            if (!sa.halo_rows) hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6, false>), mgrid, sblock, slds, ctx->stream, sa); \
+            else switch (variant) { \
+                case 1: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 10, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 2: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 13, 4, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 3: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 6, 8, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 4: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 9, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 5: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                default: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
             }
-#define WB_STREAM_ANY(T, V, N) hipLaunchKernelGGL((wb_k_scan_stream<T, V, N, 6, 4>), mgrid, sblock, slds, ctx->stream, sa)
+#define WB_STREAM_ANY(T, V, N) hipLaunchKernelGGL((wb_k_scan_stream<T, V, N, 6, 4, false>), mgrid, sblock, slds, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
             switch (p.nlevels) { case 1: WB_STREAM_ANY(T, V, 1); break; case 2: WB_STREAM_ANY(T, V, 2); break; \
                                  case 3: WB_STREAM_ANY(T, V, 3); break; default: WB_STREAM_ANY(T, V, 4); break; }
@@ -1834,6 +1845,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     if (!strcmp(name, "scan_grid_mult")) { ctx->scan_grid_mult = value; return 0; }
+    if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;
 }

@@ -59,6 +59,8 @@ struct WbScanArgs {
     int debug;              // development: bit 0 = the streaming scan stores no patches (streaming ceiling of the traversal)
     int nbands, band_rows;  // streaming scan: a time step is cut into nbands bands of band_rows rows of squares; the lists above
                             // are then per (time step, band, strip): index (t * nbands + band) * nwork + strip
+    int halo_rows;          // streaming scan: > 0 = the strips of a workgroup hand each other the halo column through LDS
+                            // (band_rows + 1 slots per strip); 0 = every strip loads its halo itself (a scalar load)
 };
 
 // a segment is stored as its key + the four corner values of its square; the crossing coordinates

@@ -30,7 +30,29 @@
 #define WB_STREAM_FLUSH 32         // patches in the wave's LDS buffer that trigger a flush
 #define WB_STREAM_LBUF 160         // its capacity: a row adds at most 64
 // D = ring depth (D - 1 row loads in flight per wave); WPS = waves per SIMD the register allocation must leave room for
-template <typename T, bool VEC, int NLEV, int D, int WPS>
+// spin until the LDS word at byte address `lds_addr` equals `tag` (both wave-uniform).  One opaque instruction for the
+// compiler: a loop in the source would sit inside every unrolled step of the kernel below and cost it its register
+// allocation (the ring rows rotate by name; with back-edges in between they were copied and spilled).
+__device__ inline float wb_lds_wait_eq(uint32_t addr_tag, uint32_t tag, uint32_t addr_val) {
+    uint32_t tmp;
+    float val;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %2\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, %0, %3\n\t"
+        "s_cbranch_vccnz 2f\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "ds_read_b32 %1, %4\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(tmp), "=&v"(val) : "v"(addr_tag), "s"(tag), "v"(addr_val) : "vcc", "memory");
+    return val;
+}
+
+// HL: the strips of a workgroup exchange their halo columns through LDS (a.halo_rows slots per strip); else scalar loads
+template <typename T, bool VEC, int NLEV, int D, int WPS, bool HL>
 __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // strip = wave of the workgroup
@@ -57,6 +79,23 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     constexpr int LW = WB_STREAM_LBUF * (1 + 10 * (int)(sizeof(T) / 4));      // dwords per wave
     uint32_t* lkey = wb_stream_lds + (size_t)s * LW;
     T* lval = reinterpret_cast<T*>(lkey + WB_STREAM_LBUF);
+    // halo exchange between the strips of the workgroup (when a.halo_rows > 0): strip s publishes, for every row of the
+    // band, the first of its 256 columns -- the value lane 63 of strip s - 1 needs --, tagged with (work item, row).  The
+    // tag is written after the value and LDS operations execute in order, so a reader that sees the tag sees the value.
+    const int HR = HL ? a.halo_rows : 0;
+    typedef __attribute__((address_space(3))) volatile T* LdsT;             // explicit LDS pointers: ds_read / ds_write, never flat
+    typedef __attribute__((address_space(3))) volatile uint32_t* LdsU;
+    const LdsT hval = (LdsT)(wb_stream_lds + NSB * LW);
+    const LdsU htag = (LdsU)(hval + NSB * HR);
+    // whose first column is this strip's halo: the next strip, strip 0 when the row ends exactly at this strip's end
+    // (periodic wrap), nobody when the strip reaches past the row (lane 63 owns no square then)
+    const int hsrc = (s + 1) * WB_STRIP < nlon ? s + 1 : ((s + 1) * WB_STRIP == nlon ? 0 : -1);
+    if (HL) {
+        // LDS keeps what the previous launch left there -- tags of the very same work items included: no tag is valid
+        // until this workgroup has written it (0 is never a tag)
+        for (int i = threadIdx.x; i < NSB * HR; i += blockDim.x) htag[i] = 0u;
+        __syncthreads();
+    }
 
     const int nitems = a.nt * a.nbands;
     for (int it = blockIdx.x; it < nitems; it += gridDim.x) { // persistent: a workgroup strides over (time step, row band) items
@@ -94,7 +133,27 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
                 cc = c0 + 2; cc = cc >= nlon ? cc - nlon : cc; qq.z = row[cc > nlon - 1 ? nlon - 1 : cc];
                 cc = c0 + 3; cc = cc >= nlon ? cc - nlon : cc; qq.w = row[cc > nlon - 1 ? nlon - 1 : cc];
             }
-            hh = ((CT)row)[chs];
+            hh = T(0);
+            if (!HL) hh = ((CT)row)[chs];
+        };
+        // slots of this item, indexed by the row number itself; the tag of a row is (work item, row)
+        const uint32_t tagbase = (((uint32_t)(it + 1) & 0xFFFFu) << 16) - (uint32_t)rb0 + 1u;
+        const LdsT pubv = hval + (s * HR - rb0);
+        const LdsU pubt = htag + (s * HR - rb0);
+        const LdsT srcv = hval + ((hsrc < 0 ? 0 : hsrc) * HR - rb0);
+        const LdsU srct = htag + ((hsrc < 0 ? 0 : hsrc) * HR - rb0);
+        auto exchange = [&](int r, const V4& qq, T hh) -> T {
+            // row r has arrived: publish its first column, then take the halo from the strip to the right (which publishes
+            // BEFORE it waits itself: no cycle of waits).  A strip that runs ahead of its neighbour sleeps here.
+            if (!HL) return hh;
+            const uint32_t tag = tagbase + (uint32_t)r;
+            // every lane stores lane 0's value to the SAME word (one LDS access, no divergence: an `if (lane == 0)` here
+            // cost the kernel its register allocation), the tag after the value
+            const T x0 = __shfl(qq.x, 0, 64);
+            pubv[r] = x0;
+            pubt[r] = tag;
+            if (hsrc < 0) return hh;
+            return (T)wb_lds_wait_eq((uint32_t)(uintptr_t)(srct + r), tag, (uint32_t)(uintptr_t)(srcv + r));
         };
         T p4, pmn, pmx;                                       // previous row, completed: its halo, minimum and maximum
         auto finish = [&](const V4& qq, T hh, T& v4, T& mn, T& mx) {
@@ -106,7 +165,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         };
         auto step = [&](int r, const V4& P, const V4& N, T hN) {   // rows (r, r + 1) = (P, N)
             T n4, nmn, nmx;
-            finish(N, hN, n4, nmn, nmx);
+            finish(N, exchange(r + 1, N, hN), n4, nmn, nmx);
             const T lo = wb_min(pmn, nmn), hi = wb_max(pmx, nmx);
             bool hit = false;
 #pragma unroll
@@ -129,7 +188,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         };
 #pragma unroll
         for (int k = 0; k < D - 1; ++k) load(rb0 + k, q[k], h[k]);
-        finish(q[0], h[0], p4, pmn, pmx);
+        finish(q[0], exchange(rb0, q[0], h[0]), p4, pmn, pmx);
         int r = rb0;
         for (; r + D <= rb1; r += D) {                        // D - 1 row loads always in flight
 #pragma unroll
@@ -154,6 +213,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
 #pragma unroll
             for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
         }
+        if (HL) __syncthreads();                              // nobody overwrites a halo slot a slower strip still waits for
     }
 }
 #endif
