@@ -15,7 +15,7 @@ def ctx(request):
     lib = _hip.Library()
     assert lib.backend == "hip"
     c = _hip.Context(0, lib)
-    c.set_option("scan_split", getattr(request, "param", 0))     # 1: the two-kernel scan (capture + build)
+    c.set_option("scan_split", getattr(request, "param", 1))     # 1 (the library default): streaming scan + build; 0: the single kernel
     yield c
     c.close()
 
@@ -76,7 +76,6 @@ def test_quarter_degree_parity(ctx):
     assert max(len(c["geometry"]) for c in ref["contours"]) > 2000
 
 
-@two_scans
 def test_consecutive_launches_on_different_fields(ctx):
     # the streaming scan's workgroups hand each other halo columns through LDS, which keeps its contents from one launch
     # to the next: two rough fields of the same shape one after the other (a stale halo of the first gave the second 6-8
@@ -89,6 +88,7 @@ def test_consecutive_launches_on_different_fields(ctx):
         helpers.full_parity(ctx, pv, lat, lon, tm, [-2, 2])
 
 
+@two_scans
 def test_capacity_retry_paths(ctx):
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(2, 2, lat, lon, eps=0.3)
