@@ -6,12 +6,16 @@
 // does the least a pass over the field must do:
 //   * a WORKGROUP works on a band of rows of one time step, a wave on one 256-column strip of it, streaming top to bottom
 //     (bands: a few times more work items than resident workgroups, so the last round of the persistent grid is nearly
-//     full; a band re-reads one row of its neighbour): the workgroup reads every row as one contiguous 4 * nlon byte run,
-//     and the one value a strip needs from its right neighbour (the halo of lane 63, a scalar load) lies in the line the
-//     neighbouring wave of the same workgroup is fetching at that moment.  (The strips of a time step used to be spread over
-//     workgroups on different XCDs: 1.19x over-fetch.  The L2 does not merge the scalar and the vector miss of that line
-//     -- its request counters show one extra 64-byte request per strip and row, 6.7 % of the field's bytes -- and the
-//     variants that avoid the request were slower: DESIGN.md section 6.);
+//     full; a band re-reads one row of its neighbour): the workgroup reads every row as one contiguous 4 * nlon byte run.
+//     The one value a strip needs from its right neighbour -- the halo of lane 63 -- is handed over through LDS: every
+//     strip publishes the first of its 256 columns for every row it receives (value, then a tag of work item and row)
+//     and reads its neighbour's slot, sleeping until the tag is there; a strip publishes BEFORE it waits, so the waits
+//     cannot form a cycle, a barrier per work item keeps a fast strip from overwriting slots, and the tags are cleared
+//     at kernel start (LDS keeps the previous launch's contents -- tags of the same work items included).  The halo used
+//     to be a scalar load per strip and row: the L2 does not merge it with the neighbour's vector miss of that line
+//     (request counters: 54.1 M requests per launch for the field's 47.4 M lines, 50.5 M now), and a wait for a scalar
+//     load is a wait for all of them (its latency was exposed in two of ten rows).  Fields that are not float, or whose
+//     rows cannot be loaded as vectors, keep the scalar load (HL = false);
 //   * a row buffer is the lane's 16 bytes and nothing else; halo, minimum and maximum are formed when a row is consumed,
 //     so an 8-deep ring (7 loads in flight) fits in 64 VGPRs -> 8 waves per SIMD;
 //   * a lane whose 2 x 5 patch holds a crossing of ANY level (min(patch) <= level < max(patch), evaluated in the field's own
