@@ -49,7 +49,7 @@ def parse():
                     help="time steps of the end-to-end (drop-in API, host-resident cube, upload included) measurement; 0 = skip")
     ap.add_argument("--scan-split", type=int, default=int(os.environ.get("WB_BENCH_SCAN_SPLIT", 1)),
                     help="1: streaming scan (patch capture) + list build kernel; 0: single classify-and-emit kernel")
-    ap.add_argument("--scan-variant", type=int, default=int(os.environ.get("WB_BENCH_SCAN_VARIANT", 1)),
+    ap.add_argument("--scan-variant", type=int, default=int(os.environ.get("WB_BENCH_SCAN_VARIANT", 2)),
                     help="streaming scan: ring depth x waves per SIMD (0: 8x6, 1: 10x5, 2: 13x4, 3: 6x8)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WB_BENCH_STREAMS", 2)),
                     help="batches in flight per GPU (contexts = HIP streams + host threads); 1 = strictly one after the other")

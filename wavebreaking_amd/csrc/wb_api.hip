@@ -51,7 +51,7 @@ struct wb_ctx {
     int scan_debug = 0;
     int scan_halo_lds = 1;                    // streaming scan: halo columns through LDS (0: scalar loads)
     int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
-    int scan_variant = 1;                     // streaming scan: ring depth x waves per SIMD (0: 8 x 6, 1: 10 x 5, 2: 13 x 4, 3: 6 x 8)
+    int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
 #if !defined(WB_HOSTSIM)

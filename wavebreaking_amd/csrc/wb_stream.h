@@ -56,6 +56,7 @@ __device__ inline float wb_lds_wait_eq(uint32_t addr_tag, uint32_t tag, uint32_t
 }
 
 // HL: the strips of a workgroup exchange their halo columns through LDS (a.halo_rows slots per strip); else scalar loads
+// (deeper rings at three waves per SIMD -- 16 x 3, 18 x 3 with a 512-thread launch bound -- were slower: 1.33 ms against 1.17)
 template <typename T, bool VEC, int NLEV, int D, int WPS, bool HL>
 __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     const int lane = threadIdx.x & 63;
