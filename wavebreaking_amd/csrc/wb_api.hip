@@ -685,8 +685,12 @@ static int run_phase1(wb_batch* b) {
             sa.cap_k = balloc<uint32_t>(b, (size_t)lists * caps);
             sa.cap_v = balloc<unsigned char>(b, (size_t)lists * caps * 10 * esz);
             sa.cap_n = balloc<int>(b, (size_t)lists);
-            if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
+            unsigned char* spare = balloc<unsigned char>(b, (size_t)p.nlon * esz + 64);
+            if (!sa.cap_n || !sa.cap_v || !sa.cap_k || !spare) return 1;
+            dmemset(ctx, spare, 0, (size_t)p.nlon * esz + 64);
+            sa.spare_row = spare;
             b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
+            b->phase1_scratch.push_back(spare);
             // the strips of a workgroup hand each other the halo column through LDS when a band's rows fit (vector loads only)
             sa.halo_rows = (vec && p.dtype == 0 && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
             const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz)    // a patch buffer per wave

@@ -59,6 +59,7 @@ struct WbScanArgs {
     int debug;              // development: bit 0 = the streaming scan stores no patches (streaming ceiling of the traversal)
     int nbands, band_rows;  // streaming scan: a time step is cut into nbands bands of band_rows rows of squares; the lists above
                             // are then per (time step, band, strip): index (t * nbands + band) * nwork + strip
+    const void* spare_row;  // streaming scan: nlon values that every workgroup reads instead of rows past its band's end (always cached)
     int halo_rows;          // streaming scan: > 0 = the strips of a workgroup hand each other the halo column through LDS
                             // (band_rows + 1 slots per strip); 0 = every strip loads its halo itself (a scalar load)
 };

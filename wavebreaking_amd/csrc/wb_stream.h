@@ -12,10 +12,11 @@
 //     and reads its neighbour's slot, sleeping until the tag is there; a strip publishes BEFORE it waits, so the waits
 //     cannot form a cycle, a barrier per work item keeps a fast strip from overwriting slots, and the tags are cleared
 //     at kernel start (LDS keeps the previous launch's contents -- tags of the same work items included).  The halo used
-//     to be a scalar load per strip and row: the L2 does not merge it with the neighbour's vector miss of that line
-//     (request counters: 54.1 M requests per launch for the field's 47.4 M lines, 50.5 M now), and a wait for a scalar
-//     load is a wait for all of them (its latency was exposed in two of ten rows).  Fields that are not float, or whose
-//     rows cannot be loaded as vectors, keep the scalar load (HL = false);
+//     to be a scalar load per strip and row: the L2 does not merge it with the neighbour's vector miss of that line, and
+//     a wait for a scalar load is a wait for all of them (its latency was exposed in two of ten rows).  With the exchange,
+//     no wrap-around re-read of the row's first columns by the last strip and a spare row for the loads past a band's
+//     end, the L2's request counter shows 47.5 M requests per launch for the field's 47.4 M lines (54.1 M before).
+//     Fields that are not float, or whose rows cannot be loaded as vectors, keep the scalar load (HL = false);
 //   * a row buffer is the lane's 16 bytes and nothing else; halo, minimum and maximum are formed when a row is consumed,
 //     so an 8-deep ring (7 loads in flight) fits in 64 VGPRs -> 8 waves per SIMD;
 //   * a lane whose 2 x 5 patch holds a crossing of ANY level (min(patch) <= level < max(patch), evaluated in the field's own
@@ -72,6 +73,10 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     const bool live = c0 < cmax;                              // the lane owns at least one square
     int cm = c0 >= nlon ? c0 - nlon : c0;
     if (cm > nlon - 4) cm = nlon - 4;
+    // (with the halo exchange the lanes past the row's end own nothing and hand nothing on: they re-read the last lane's
+    // 16 bytes instead of wrapping to the row's first columns -- three more lines per row, requested while strip 0's own
+    // request for them is in flight, i.e. three more requests to the memory side: 3.2 M of 50 M per launch)
+    if (HL && c0 >= nlon) cm = nlon - 4;
     int chs = (s + 1) * WB_STRIP;                             // first column of the next strip: halo of lane 63 (wave-uniform)
     chs = chs >= nlon ? chs - nlon : chs;
     if (chs > nlon - 1) chs = nlon - 1;
@@ -92,9 +97,11 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     typedef __attribute__((address_space(3))) volatile uint32_t* LdsU;
     const LdsT hval = (LdsT)(wb_stream_lds + NSB * LW);
     const LdsU htag = (LdsU)(hval + NSB * HR);
-    // whose first column is this strip's halo: the next strip, strip 0 when the row ends exactly at this strip's end
-    // (periodic wrap), nobody when the strip reaches past the row (lane 63 owns no square then)
-    const int hsrc = (s + 1) * WB_STRIP < nlon ? s + 1 : ((s + 1) * WB_STRIP == nlon ? 0 : -1);
+    // whose first column is this strip's halo: the next strip, or strip 0 for the strip that holds the row's end (the right
+    // column of its last square is column 0: the periodic wrap)
+    const int hsrc = (s + 1) * WB_STRIP < nlon ? s + 1 : 0;
+    // the lane that takes the halo from the exchange: 63, or the last lane inside the row
+    const int hlane = (s + 1) * WB_STRIP <= nlon ? 63 : (nlon - s * WB_STRIP) / 4 - 1;
     if (HL) {
         // LDS keeps what the previous launch left there -- tags of the very same work items included: no tag is valid
         // until this workgroup has written it (0 is never a tag)
@@ -130,7 +137,10 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         V4 q[D];                                              // the ring: raw row data only (register-resident: every index
         T h[D];                                               // below is a compile-time constant after unrolling)
         auto load = [&](int r, V4& qq, T& hh) {
-            const T* row = f + (size_t)(r < rb1 ? r : rb1) * nlon;      // reads past the band repeat its last row (cache hits)
+            // the ring runs D - 1 rows ahead, past the band's last row too: those loads (never consumed) go to one spare row
+            // that every workgroup keeps hot in the CU's L1 -- repeating the band's last row, still in flight, cost a
+            // second request to the memory side for half of them (2.2 M of 50 M per launch)
+            const T* row = r <= rb1 ? f + (size_t)r * nlon : (const T*)a.spare_row;
             if (VEC) qq = *reinterpret_cast<const V4*>(row + cm);
             else {
                 int cc = c0; cc = cc >= nlon ? cc - nlon : cc; qq.x = row[cc > nlon - 1 ? nlon - 1 : cc];
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         T p4, pmn, pmx;                                       // previous row, completed: its halo, minimum and maximum
         auto finish = [&](const V4& qq, T hh, T& v4, T& mn, T& mx) {
             const T sh = wb_shl1(qq.x);                       // unconditional: every lane must be active for the DPP read
-            v4 = (lane == 63) ? hh : sh;
+            v4 = (lane == (HL ? hlane : 63)) ? hh : sh;
             nanflag |= __builtin_isunordered(qq.x, qq.y) | __builtin_isunordered(qq.z, qq.w);
             mn = wb_min3(qq.x, qq.y, wb_min3(qq.z, qq.w, v4));
             mx = wb_max3(qq.x, qq.y, wb_max3(qq.z, qq.w, v4));
