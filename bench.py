@@ -37,8 +37,8 @@ HBM_MEASURED = 6.29e12     # float4 copy
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nt", type=int, default=int(os.environ.get("WB_BENCH_NT", 1460)), help="time steps per GPU per pass")
     ap.add_argument("--dlon", type=float, default=0.25)
     ap.add_argument("--eps", type=float, default=0.0, help="cell noise amplitude (0 = smoothed PV, 0.3 = rough)")

@@ -203,6 +203,19 @@ def test_time_and_level_chunking_keep_the_frame_order(hostsim_engine, monkeypatc
     _check_events(s, ref["streamers"], cols[:6] + ["geometry"])
 
 
+def test_contour_frame_with_more_levels_than_one_pass_holds(hostsim_engine):
+    # a frame handed in (contours=) is one job per contour row: no limit of 4 levels per ABI pass applies to it
+    data, pv, lat, lon, tm = _field(nt=2, dlon=2.5, eps=0.2)
+    levels = [-2, 2, 1.5, -1.5, 2.5, 3.0]
+    frame = wb.calculate_contours(data, levels, original_coordinates=False)
+    assert len(set(frame.level)) == 6
+    ref = oapi.run_all(pv, levels, lat, lon, tm)
+    cols = ["date", "level", "com", "mean_var", "intensity", "event_area", "geometry"]
+    for name in ("streamers", "overturnings", "cutoffs"):
+        got = getattr(wb, "calculate_" + name)(data, levels, contours=frame)
+        _check_events(got, ref[name], cols[:6] + (["orientation"] if name == "overturnings" else []) + ["geometry"])
+
+
 def test_blocks_without_a_full_width_contour_wait_for_the_record_maximum(hostsim_engine, monkeypatch):
     # the index functions finish a block of time steps as soon as the selection maximum is known (a contour spanning the
     # whole periodically extended grid); here NO contour of level -2 does, in any block: every block has to wait for the
