@@ -324,10 +324,12 @@ class Context:
         return (ring_off, np.asarray(vert_off, dtype=np.int64), np.ascontiguousarray(xy[:, 0], dtype=np.int32),
                 np.ascontiguousarray(xy[:, 1], dtype=np.int32))
 
-    def track_events(self, dates, method, time_range, overlap=0.0, distance=1000.0, com=None, rings_per_event=None):
+    def track_events(self, dates, method, time_range, overlap=0.0, distance=1000.0, com=None, rings_per_event=None, rings_csr=None):
         """wb_track_events: labels of track_events (events.py:113-241) for events in the caller's row order.  ``dates``:
-        datetime64 (any unit) or numbers; ``method``: "by_overlap" (``rings_per_event[k]`` = list of (n, 2) LATTICE rings)
-        or "by_distance" (``com`` = (n, 2) degrees).  Returns (label int32[n], area float64[n] or None, stats dict)."""
+        datetime64 (any unit) or numbers; ``method``: "by_overlap" (``rings_per_event[k]`` = list of (n, 2) LATTICE rings, or
+        ``rings_csr`` = (ring_offset[n + 1], vert_offset[rings + 1], x, y) with integer x, y -- the layout of
+        ``Batch.event_geometry``) or "by_distance" (``com`` = (n, 2) degrees).  Returns (label int32[n], area float64[n] or
+        None, stats dict)."""
         d = np.asarray(dates)
         n = d.shape[0]
         i64p, i32p, dp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
@@ -340,7 +342,13 @@ class Context:
         stats = np.zeros(4, dtype=np.uint64)
         area = None
         if method == "by_overlap":
-            ring_off, vert_off, vx, vy = self._lattice_rings(rings_per_event)
+            if rings_csr is not None:
+                ring_off = np.ascontiguousarray(rings_csr[0], dtype=np.int64)
+                vert_off = np.ascontiguousarray(rings_csr[1], dtype=np.int64)
+                vx = np.ascontiguousarray(rings_csr[2], dtype=np.int32)
+                vy = np.ascontiguousarray(rings_csr[3], dtype=np.int32)
+            else:
+                ring_off, vert_off, vx, vy = self._lattice_rings(rings_per_event)
             assert ring_off.size == n + 1
             area = np.empty(n, dtype=np.float64)
             geo = (ring_off.ctypes.data_as(i64p), vert_off.ctypes.data_as(i64p), vx.ctypes.data_as(i32p), vy.ctypes.data_as(i32p))
