@@ -56,6 +56,22 @@ def test_periodic_add_variants(ctx, padd):
     helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2], periodic_add=padd)
 
 
+def test_streaming_scan_float64_and_group_maximum_of_shifted_chords(ctx):
+    # (1) the streaming scan's float64 instance on the 0.25 degree grid (six strips, scalar halo loads);
+    # (2) this field holds a streamer whose group (check_groups, streamer_index.py:224-251) has two chords shifted by one point
+    #     along the contour: their lengths on[ind1 : ind2 + 1].sum() differ in the last bits only and the reference's argmax
+    #     turns on numpy's pairwise summation of the slices -- a prefix difference picked the other chord
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(40, 1, lat, lon, eps=0.3)
+    for field in (pv, pv.astype(np.float64)):
+        for eager in (0, 1):
+            ctx.set_option("eager_f2", eager)
+            try:
+                helpers.full_parity(ctx, field, lat, lon, synth.times(1), [-2, 2, 1.5])
+            finally:
+                ctx.set_option("eager_f2", 0)
+
+
 def test_eager_and_lazy_routine_2_agree(ctx):
     # the exhaustive formulation (chord test for every candidate pair, then routines 3 + 4) against the oracle as well
     lat, lon = synth.grid(1.0)

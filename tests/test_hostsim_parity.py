@@ -106,6 +106,21 @@ def test_empty_field_gives_empty_tables(sim):
         assert got[k]["step"].size == 0
 
 
+def test_group_maximum_of_chords_shifted_along_the_contour(sim):
+    # check_groups (streamer_index.py:224-251) keeps the member with the largest on[ind1 : ind2 + 1].sum(): this 0.25 degree
+    # field holds a group with two chords shifted by one point, whose sums differ in the last bits only -- the argmax turns
+    # on numpy's pairwise summation of the slices (a prefix difference picked the other chord); lazy and eager routine 2
+    lib, ctx = sim
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(40, 1, lat, lon, eps=0.3)
+    for eager in (0, 1):
+        ctx.set_option("eager_f2", eager)
+        try:
+            helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2])
+        finally:
+            ctx.set_option("eager_f2", 0)
+
+
 def test_bad_arguments_fail_loudly(sim):
     lib, ctx = sim
     lat, lon = synth.grid(2.5)

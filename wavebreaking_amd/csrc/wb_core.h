@@ -130,6 +130,53 @@ struct WbCtl {
 #define WB_PSTAMP_FLUSH(ctl) ((void)0)
 #endif
 
+// ------------------------------------------------------------------ numpy's pairwise summation
+// ``a[0:n].sum()`` of a contiguous float64 array exactly as numpy adds it (loops_utils.h.src, DOUBLE_pairwise_sum): fewer than
+// 8 elements one after the other; up to 128 in eight interleaved accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+// plus the tail; longer arrays split at n/2 rounded down to a multiple of 8.  (check_groups compares such sums,
+// streamer_index.py:241-246: shifted chords of a lattice contour tie to the last bit.)
+WB_HD inline double wb_np_sum_leaf(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 = r0 + a[i]; r1 = r1 + a[i + 1]; r2 = r2 + a[i + 2]; r3 = r3 + a[i + 3];
+        r4 = r4 + a[i + 4]; r5 = r5 + a[i + 5]; r6 = r6 + a[i + 6]; r7 = r7 + a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+WB_HD inline double wb_np_pairwise_sum(const double* a, int n) {
+    // the recursion, unrolled onto a small stack (depth log2(n / 128) + 2: 16 frames hold n < 2^20, far beyond a contour)
+    const double* fa[16]; int fn[16]; int fs[16]; double fl[16];
+    int sp = 0;
+    fa[0] = a; fn[0] = n; fs[0] = 0; fl[0] = 0.0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        if (fs[sp] == 0) {
+            if (fn[sp] <= 128) { ret = wb_np_sum_leaf(fa[sp], fn[sp]); --sp; }
+            else {
+                int n2 = fn[sp] / 2; n2 -= n2 % 8;
+                fs[sp] = 1;
+                fa[sp + 1] = fa[sp]; fn[sp + 1] = n2; fs[sp + 1] = 0; fl[sp + 1] = 0.0;
+                ++sp;
+            }
+        } else if (fs[sp] == 1) {
+            int n2 = fn[sp] / 2; n2 -= n2 % 8;
+            fl[sp] = ret;
+            fs[sp] = 2;
+            fa[sp + 1] = fa[sp] + n2; fn[sp + 1] = fn[sp] - n2; fs[sp + 1] = 0; fl[sp + 1] = 0.0;
+            ++sp;
+        } else { ret = fl[sp] + ret; --sp; }
+    }
+    return ret;
+}
+
 // ------------------------------------------------------------------ integer predicates
 WB_HD inline int64_t wb_orient(int64_t ax, int64_t ay, int64_t bx, int64_t by, int64_t cx, int64_t cy) {
     return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);

@@ -841,22 +841,25 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
             WB_END_PFOR
             if (!cnt[cf]) break;
         }
-        // per group: max of on[ind1 : ind2+1].sum()  (= pre[ind2] - pre[ind1-1]); ties -> lowest member
+        // per group: max of on[ind1 : ind2+1].sum() -- numpy's pairwise sum of the slice, not a prefix difference: two chords
+        // shifted by one point along a lattice contour differ by on[ind1] - on[ind2 + 1], two steps of the same kind whose
+        // lengths agree to the last bit or the one before, and the reference's argmax (streamer_index.py:241-246) then
+        // turns on how the slices were added; ties -> lowest member
         WB_PFOR(m, M)
             best[m] = 0ull;
             best[M + m] = WB_HEMPTY;
         WB_END_PFOR
+        const double* onp = a.on + a.poff[s];
+        unsigned long long* gval = best + 2 * (size_t)M;          // (the table holds 4 * cap_seg >= 4 M words)
         WB_PFOR(m, M)
-            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
+            const double v = wb_np_pairwise_sum(onp + mi[m], mj[m] - mi[m] + 1);
             unsigned long long bits;
             memcpy(&bits, &v, 8);
+            gval[m] = bits;
             wb_atomic_max(&best[lab[m]], bits);
         WB_END_PFOR
         WB_PFOR(m, M)
-            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
-            unsigned long long bits;
-            memcpy(&bits, &v, 8);
-            if (bits == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
+            if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
         WB_PFOR(m, M)
             aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
@@ -1146,22 +1149,25 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
             WB_END_PFOR
             if (!sh[cf]) break;
         }
-        // per group: max of on[ind1 : ind2+1].sum()  (= pre[ind2] - pre[ind1-1]); ties -> lowest member
+        // per group: max of on[ind1 : ind2+1].sum() -- numpy's pairwise sum of the slice, not a prefix difference: two chords
+        // shifted by one point along a lattice contour differ by on[ind1] - on[ind2 + 1], two steps of the same kind whose
+        // lengths agree to the last bit or the one before, and the reference's argmax (streamer_index.py:241-246) then
+        // turns on how the slices were added; ties -> lowest member
         WB_PFOR(m, M)
             best[m] = 0ull;
             best[M + m] = WB_HEMPTY;
         WB_END_PFOR
+        const double* onp = a.on + a.poff[s];
+        unsigned long long* gval = best + 2 * (size_t)M;          // (the table holds 4 * cap_seg >= 4 M words)
         WB_PFOR(m, M)
-            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
+            const double v = wb_np_pairwise_sum(onp + mi[m], mj[m] - mi[m] + 1);
             unsigned long long bits;
             memcpy(&bits, &v, 8);
+            gval[m] = bits;
             wb_atomic_max(&best[lab[m]], bits);
         WB_END_PFOR
         WB_PFOR(m, M)
-            const double v = pre[mj[m]] - (mi[m] > 0 ? pre[mi[m] - 1] : 0.0);
-            unsigned long long bits;
-            memcpy(&bits, &v, 8);
-            if (bits == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
+            if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
         WB_PFOR(m, M)
             aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
