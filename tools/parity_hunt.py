@@ -1,0 +1,43 @@
+"""Hunt for residual parity mismatches: many random single-step fields, host-simulation library against the oracle, in worker
+processes (development tool, CPU only).   python tools/parity_hunt.py <first seed> <count> [dlon]"""
+import os, sys, time
+import multiprocessing as mp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def case(args):
+    seed, dlon = args
+    import numpy as np
+    import helpers
+    from oracle import synth
+    from wavebreaking_amd import _hip
+    rng = np.random.RandomState(seed)
+    eps = float(rng.choice([0.0, 0.1, 0.2, 0.3, 0.45]))
+    t0 = int(rng.randint(0, 5000))
+    levels = [[-2, 2], [2], [-2, 2, 1.5], [1.0, 3.0]][int(rng.randint(0, 4))]
+    lat, lon = synth.grid(dlon)
+    pv = synth.pv_field(t0, 1, lat, lon, eps=eps, seed=1000 + seed)
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    try:
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(1), levels, intensity=pv)
+        return (seed, eps, t0, levels, "ok")
+    except Exception as e:
+        return (seed, eps, t0, levels, "FAIL " + type(e).__name__ + " " + str(e)[:120])
+    finally:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    dlon = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
+    import helpers
+    helpers.build_hostsim()
+    t = time.time()
+    bad = 0
+    with mp.get_context("spawn").Pool(6) as pool:
+        for r in pool.imap_unordered(case, [(s, dlon) for s in range(first, first + count)]):
+            if r[-1] != "ok":
+                bad += 1
+                print(r, flush=True)
+    print("hunt", first, count, dlon, "failures", bad, "%.0fs" % (time.time() - t), flush=True)
