@@ -1,5 +1,6 @@
 """Hunt for residual parity mismatches: many random single-step fields, host-simulation library against the oracle, in worker
-processes (development tool, CPU only).   python tools/parity_hunt.py <first seed> <count> [dlon]"""
+processes (development tool).   python tools/parity_hunt.py <first seed> <count> [dlon]     WB_HUNT_GPU=1: the HIP library on the GPU box
+(the oracle is the slow part: WB_HUNT_WORKERS processes share the GPU)"""
 import os, sys, time
 import multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,7 @@ def case(args):
     levels = [[-2, 2], [2], [-2, 2, 1.5], [1.0, 3.0]][int(rng.randint(0, 4))]
     lat, lon = synth.grid(dlon)
     pv = synth.pv_field(t0, 1, lat, lon, eps=eps, seed=1000 + seed)
-    ctx = _hip.Context(0, helpers.hostsim_library())
+    ctx = _hip.Context(0) if os.environ.get("WB_HUNT_GPU") else _hip.Context(0, helpers.hostsim_library())
     try:
         helpers.full_parity(ctx, pv, lat, lon, synth.times(1), levels, intensity=pv)
         return (seed, eps, t0, levels, "ok")
@@ -32,10 +33,11 @@ if __name__ == "__main__":
     first, count = int(sys.argv[1]), int(sys.argv[2])
     dlon = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
     import helpers
-    helpers.build_hostsim()
+    if not os.environ.get("WB_HUNT_GPU"):
+        helpers.build_hostsim()
     t = time.time()
     bad = 0
-    with mp.get_context("spawn").Pool(6) as pool:
+    with mp.get_context("spawn").Pool(int(os.environ.get("WB_HUNT_WORKERS", 6))) as pool:
         for r in pool.imap_unordered(case, [(s, dlon) for s in range(first, first + count)]):
             if r[-1] != "ok":
                 bad += 1

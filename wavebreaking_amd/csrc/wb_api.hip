@@ -1432,7 +1432,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         int* d_py = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
         WbPropsArgs pa;
         memset(&pa, 0, sizeof(pa));
-        pa.ctl = ctl; pa.nslots = 4096; /* one wave per event slot; 4 waves per SIMD in flight */
+        // one wave per event slot, fed from the event queue; 4096 slots (4 waves per SIMD) for a year-sized batch, fewer for a
+        // few jobs: a slot owns W x nlat cells of scratch (5.5 MB at 0.25 degree)
+        pa.ctl = ctl; pa.nslots = 8 * J < 4096 ? (8 * J > 64 ? 8 * J : 64) : 4096;
         pa.nlat = p.nlat; pa.nlon = p.nlon; pa.W = b->W; pa.cap_seg = cap;
         pa.nlev = p.nlevels; pa.dtype = p.dtype; pa.want_cells = p.want_cells; pa.pad = (int)ceil(r); pa.r2 = r * r;
         pa.ev = fa.ev; pa.ot_sums = ot_sums; pa.c_off = b->c_off; pa.c_len = b->c_len; pa.cpts = b->cpts; pa.data = b->d_field;
