@@ -422,6 +422,33 @@ def test_track_events_public_gpu():
     _public_function()
 
 
+def test_tracking_of_the_index_functions_own_polygons_hostsim(monkeypatch):
+    # the polygons the path itself produces (long, thin, concave, seam-split), not synthetic stars: labels and order of
+    # wb.track_events against the exact oracle, for each index, at overlap 0 and 0.1
+    from oracle import synth
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    monkeypatch.setitem(engine._contexts, 0, ctx)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    try:
+        lat, lon = synth.grid(1.0)
+        tm = synth.times(5)
+        pv = synth.pv_field(7, 5, lat, lon, eps=0.3, seed=3)
+        data = wb.GridField(pv, ("time", "lat", "lon"), {"time": tm, "lat": gf.Coord(lat, {"units": "degrees_north"}),
+                                                           "lon": gf.Coord(lon, {"units": "degrees_east"})}, name="PV")
+        for fn in (wb.calculate_streamers, wb.calculate_cutoffs, wb.calculate_overturnings):
+            ev = fn(data, [-2, 2])
+            assert "wavebreaking_grid" in ev.attrs and len(ev) > 20
+            rings = pev.lattice_rings(ev)
+            dates = np.asarray(ev["date"].values)
+            for ov in (0.0, 0.1):
+                want, order, pairs, check = otrack.track_events(dates, rings=rings, time_range=6.0, method="by_overlap", overlap=ov)
+                got = wb.track_events(ev, time_range=6, method="by_overlap", overlap=ov)
+                assert got.index.tolist() == order.tolist() and got.label.tolist() == want[order].tolist()
+                assert 0 < check.sum() < len(check)
+    finally:
+        ctx.close()
+
+
 def test_lattice_recovery():
     assert pev._float_gcd([10, 25]) == 5.0
     assert abs(pev._float_gcd([0.1 * 3, 0.1 * 7, 0.1 * 2]) - 0.1) < 1e-12
