@@ -1,0 +1,43 @@
+"""Hunt over fields with cells EQUAL to the level: every job must either match the oracle (skimage's coordinate joins) or be
+flagged order-dependent -- and then the oracle's sequential walk must indeed differ from the vertex machine or raise
+(development tool, CPU only).   python tools/levelhit_hunt.py <first seed> <count> [dlon]"""
+import os, sys, time
+import multiprocessing as mp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def case(args):
+    seed, dlon = args
+    import numpy as np
+    import helpers
+    from oracle import synth
+    from wavebreaking_amd import _hip
+    pv, lat, lon = helpers.level_hit_field(seed, dlon=dlon, nhits=(4 + seed % 9) * int(os.environ.get("WB_HUNT_HITS", 1)))
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    try:
+        got = helpers.run_abi(ctx, pv, lat, lon, [2.0], intensity=pv)
+        st = int(got["status"][0])
+        if st & _hip.STATUS_LEVEL_ORDER:
+            return (seed, "order-dependent")
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2.0], intensity=pv)
+        return (seed, "ok" if st & _hip.STATUS_LEVEL_HIT else "ok-nohit")
+    except Exception as e:
+        return (seed, "FAIL " + type(e).__name__ + " " + str(e)[:120])
+    finally:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    dlon = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+    import helpers
+    helpers.build_hostsim()
+    t = time.time()
+    tally = {}
+    with mp.get_context("spawn").Pool(6) as pool:
+        for seed, res in pool.imap_unordered(case, [(s, dlon) for s in range(first, first + count)]):
+            tally[res.split()[0]] = tally.get(res.split()[0], 0) + 1
+            if res.startswith("FAIL"):
+                print(seed, res, flush=True)
+    print("levelhit hunt", first, count, dlon, tally, "%.0fs" % (time.time() - t), flush=True)

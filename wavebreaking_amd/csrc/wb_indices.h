@@ -848,11 +848,15 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
         WB_PFOR(m, M)
             best[m] = 0ull;
             best[M + m] = WB_HEMPTY;
+            aux[m] = 0;
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            wb_atomic_add(&aux[lab[m]], 1);                        // members per group: a group of one needs no length
         WB_END_PFOR
         const double* onp = a.on + a.poff[s];
         unsigned long long* gval = best + 2 * (size_t)M;          // (the table holds 4 * cap_seg >= 4 M words)
         WB_PFOR(m, M)
-            const double v = wb_np_pairwise_sum(onp + mi[m], mj[m] - mi[m] + 1);
+            const double v = aux[lab[m]] > 1 ? wb_np_pairwise_sum(onp + mi[m], mj[m] - mi[m] + 1) : 0.0;
             unsigned long long bits;
             memcpy(&bits, &v, 8);
             gval[m] = bits;
@@ -1156,11 +1160,15 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
         WB_PFOR(m, M)
             best[m] = 0ull;
             best[M + m] = WB_HEMPTY;
+            aux[m] = 0;
+        WB_END_PFOR
+        WB_PFOR(m, M)
+            wb_atomic_add(&aux[lab[m]], 1);                        // members per group: a group of one needs no length
         WB_END_PFOR
         const double* onp = a.on + a.poff[s];
         unsigned long long* gval = best + 2 * (size_t)M;          // (the table holds 4 * cap_seg >= 4 M words)
         WB_PFOR(m, M)
-            const double v = wb_np_pairwise_sum(onp + mi[m], mj[m] - mi[m] + 1);
+            const double v = aux[lab[m]] > 1 ? wb_np_pairwise_sum(onp + mi[m], mj[m] - mi[m] + 1) : 0.0;
             unsigned long long bits;
             memcpy(&bits, &v, 8);
             gval[m] = bits;
