@@ -83,7 +83,10 @@ def smooth_field(data, passes, weights=np.array([[0, 1, 0], [1, 2, 1], [0, 1, 0]
 
 
 def pairwise_sum(a):
-    """numpy's pairwise summation of a contiguous 1-D float array in its own dtype (loops_utils.h.src *_pairwise_sum)."""
+    """numpy's pairwise summation of a contiguous 1-D float array in its own dtype (loops_utils.h.src *_pairwise_sum).
+    This is ONE call of numpy's inner loop: a reduction over more than 8192 elements (the ufunc buffer size) is handed over in
+    blocks of 8192 whose pairwise sums are added one after the other (csrc/wb_core.h:wb_np_pairwise_sum restates that, checked
+    against numpy in tests/test_hostsim_parity.py); the rows summed here are at most 4096 long."""
     dt = a.dtype.type
     n = a.size
     if n < 8:

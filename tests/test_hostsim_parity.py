@@ -106,6 +106,23 @@ def test_empty_field_gives_empty_tables(sim):
         assert got[k]["step"].size == 0
 
 
+def test_numpy_sum_restatement(sim):
+    # wb_np_pairwise_sum (csrc/wb_core.h) against numpy's own a.sum(), bit for bit: leaves, splits, the 8192-element blocks
+    import ctypes as C
+    lib, _ = sim
+    f = lib.lib.wb_hostsim_np_sum
+    f.restype = C.c_double
+    f.argtypes = [C.POINTER(C.c_double), C.c_int64]
+    for seed in range(8):
+        rng = np.random.default_rng(seed)
+        for n in list(range(0, 24)) + [127, 128, 129, 255, 256, 257, 1000, 4095, 4097, 8191, 8192, 8193, 12000, 16385, 40000]:
+            a = np.ascontiguousarray(rng.uniform(0, 30, n) * rng.choice([1.0, 1e-3, 1e3], n))
+            assert f(a.ctypes.data_as(C.POINTER(C.c_double)), n) == float(a.sum()), (seed, n)
+            if n > 40:                                           # a slice, as check_groups takes it
+                b = a[7:n - 5]
+                assert f(b.ctypes.data_as(C.POINTER(C.c_double)), b.size) == float(b.sum()), (seed, n)
+
+
 def test_group_maximum_of_chords_shifted_along_the_contour(sim):
     # check_groups (streamer_index.py:224-251) keeps the member with the largest on[ind1 : ind2 + 1].sum(): this 0.25 degree
     # field holds a group with two chords shifted by one point, whose sums differ in the last bits only -- the argmax turns

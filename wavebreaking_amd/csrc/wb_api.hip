@@ -2258,6 +2258,7 @@ extern "C" int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_off
 }
 
 #if defined(WB_HOSTSIM)
+extern "C" double wb_hostsim_np_sum(const double* a, int64_t n) { return wb_np_pairwise_sum(a, (int)n); }
 extern "C" void wb_hostsim_div(const double* a, int64_t n, double S, double* fast, double* plain) {
     const double y = 1.0 / S;
     for (int64_t i = 0; i < n; ++i) { fast[i] = wb_sm_div(a[i], S, y, true); plain[i] = a[i] / S; }

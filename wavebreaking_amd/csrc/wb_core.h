@@ -151,30 +151,44 @@ WB_HD inline double wb_np_sum_leaf(const double* a, int n) {
     for (; i < n; ++i) res = res + a[i];
     return res;
 }
-WB_HD inline double wb_np_pairwise_sum(const double* a, int n) {
-    // the recursion, unrolled onto a small stack (depth log2(n / 128) + 2: 16 frames hold n < 2^20, far beyond a contour)
-    const double* fa[16]; int fn[16]; int fs[16]; double fl[16];
+WB_HD inline double wb_np_pairwise_block(const double* a, int n) {
+    // the recursion, unrolled onto a small stack (a block has at most 8192 elements: depth 7); a frame is (offset, length,
+    // stage) + the left half's sum
+    int fo[10], fn[10];
+    signed char fs[10];
+    double fl[10];
     int sp = 0;
-    fa[0] = a; fn[0] = n; fs[0] = 0; fl[0] = 0.0;
+    fo[0] = 0; fn[0] = n; fs[0] = 0; fl[0] = 0.0;
     double ret = 0.0;
     while (sp >= 0) {
         if (fs[sp] == 0) {
-            if (fn[sp] <= 128) { ret = wb_np_sum_leaf(fa[sp], fn[sp]); --sp; }
-            else {
+            if (fn[sp] <= 128) {
+                ret = wb_np_sum_leaf(a + fo[sp], fn[sp]);
+                --sp;
+            } else {
                 int n2 = fn[sp] / 2; n2 -= n2 % 8;
                 fs[sp] = 1;
-                fa[sp + 1] = fa[sp]; fn[sp + 1] = n2; fs[sp + 1] = 0; fl[sp + 1] = 0.0;
+                fo[sp + 1] = fo[sp]; fn[sp + 1] = n2; fs[sp + 1] = 0; fl[sp + 1] = 0.0;
                 ++sp;
             }
         } else if (fs[sp] == 1) {
             int n2 = fn[sp] / 2; n2 -= n2 % 8;
             fl[sp] = ret;
             fs[sp] = 2;
-            fa[sp + 1] = fa[sp] + n2; fn[sp + 1] = fn[sp] - n2; fs[sp + 1] = 0; fl[sp + 1] = 0.0;
+            fo[sp + 1] = fo[sp] + n2; fn[sp + 1] = fn[sp] - n2; fs[sp + 1] = 0; fl[sp + 1] = 0.0;
             ++sp;
         } else { ret = fl[sp] + ret; --sp; }
     }
     return ret;
+}
+
+// ``a[0:n].sum()``: numpy's reduction hands its inner loop at most 8192 elements at a time (the ufunc buffer size) and adds
+// the blocks' pairwise sums one after the other (checked against numpy 2.2 for lengths up to 100 000)
+WB_HD inline double wb_np_pairwise_sum(const double* a, int n) {
+    if (n <= 8192) return wb_np_pairwise_block(a, n);
+    double s = wb_np_pairwise_block(a, 8192);
+    for (int i = 8192; i < n; i += 8192) s = s + wb_np_pairwise_block(a + i, n - i < 8192 ? n - i : 8192);
+    return s;
 }
 
 // ------------------------------------------------------------------ integer predicates
