@@ -139,7 +139,7 @@ def main():
                    counts=dict(polygon_vertices=int(sum(e["poly_x"].size for e in ev)), streamers=int(ev[0]["step"].size),
                                overturnings=int(ev[1]["step"].size), cutoffs=int(ev[2]["step"].size),
                                band_hits=b.band_hits(), pair_stats=b.pair_stats(), evaluated_pairs=b.evaluated_pairs(),
-                               com_rechecks=b.com_rechecks(),
+                               com_rechecks=b.com_rechecks(), group_ties=b.group_ties(),
                                polygons_not_simple=int(sum(int(np.count_nonzero(e["flags"] & 1)) for e in ev)),
                                status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
                    batch=b if multi else None,

@@ -153,6 +153,9 @@ int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pair
 /* ... and the pairs whose great-circle term was actually evaluated (the others were excluded as whole blocks or by the
    |dx| / |dy| reach tests) */
 int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated);
+/* groups of check_groups (streamer_index.py:224-251) whose largest along-contour length was shared by several members to the
+   last bit in the last wb_indices call: there the survivor is the member that comes first in the reference's CPython set */
+int wb_get_group_ties(wb_batch* b, int64_t* ties);
 /* per-stage device times of the last wb_contours / wb_indices calls, measured with HIP events on the
    context's stream: names is a NUL-separated list */
 int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);

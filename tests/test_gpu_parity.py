@@ -72,6 +72,26 @@ def test_streaming_scan_float64_and_group_maximum_of_shifted_chords(ctx):
                 ctx.set_option("eager_f2", 0)
 
 
+def test_group_maximum_shared_by_two_members(ctx):
+    # check_groups with an exact tie of the largest length: the survivor follows the reference's CPython set order
+    # (wb_k_streamer_ties); cases found by tools/parity_hunt.py
+    lat, lon = synth.grid(1.0)
+    ties = 0
+    for seed, eps, t0, levels in ((41289, 0.0, 3601, [-2, 2]), (42352, 0.1, 2195, [1.0, 3.0])):
+        pv = synth.pv_field(t0, 6, lat, lon, eps=eps, seed=1000 + seed)
+        for eager in (0, 1):
+            ctx.set_option("eager_f2", eager)
+            try:
+                helpers.full_parity(ctx, pv, lat, lon, synth.times(6), levels, intensity=pv)
+            finally:
+                ctx.set_option("eager_f2", 0)
+        b = ctx.contours(pv, lat, lon, levels, 1.0, 1.0, intensity=pv)
+        b.indices()
+        ties += b.group_ties()
+        b.close()
+    assert ties >= 2
+
+
 def test_eager_and_lazy_routine_2_agree(ctx):
     # the exhaustive formulation (chord test for every candidate pair, then routines 3 + 4) against the oracle as well
     lat, lon = synth.grid(1.0)

@@ -123,6 +123,71 @@ def test_numpy_sum_restatement(sim):
                 assert f(b.ctypes.data_as(C.POINTER(C.c_double)), b.size) == float(b.sum()), (seed, n)
 
 
+def _reference_group_order(pairs):
+    """combine_shared (index_utils.py:187-214) for the first group of `pairs`, on ndarray rows as the reference runs it --
+    with the running interpreter's own sets"""
+    first, *rest = np.asarray(pairs)
+    first = set(first)
+    lf = -1
+    while len(first) > lf:
+        lf = len(first)
+        rest2 = []
+        for r in rest:
+            if len(first.intersection(set(r))) > 0:
+                first |= set(r)
+            else:
+                rest2.append(r)
+        rest = rest2
+    return [int(v) for v in list(first)]
+
+
+def test_cpython_set_order_restatement(sim):
+    # wb_pyset_group_order (csrc/wb_core.h) against real sets: random connected groups of 2..40 small integers, their
+    # crossing pairs in lexicographic order (self pairs included), table growth included
+    import ctypes as C
+    lib, _ = sim
+    f = lib.lib.wb_hostsim_group_order
+    f.restype = C.c_int
+    ip = C.POINTER(C.c_int)
+    rng = np.random.RandomState(0)
+    for trial in range(1500):
+        nm = rng.randint(2, 40)
+        base = rng.randint(0, 200)
+        members = np.sort(rng.choice(np.arange(base, base + rng.randint(nm, nm * 3 + 1)), nm, replace=False))
+        edges = set((int(m), int(m)) for m in members)
+        perm = rng.permutation(nm)
+        for k in range(1, nm):
+            a, b = members[perm[k]], members[perm[rng.randint(0, k)]]
+            edges.add((int(min(a, b)), int(max(a, b))))
+        for _ in range(rng.randint(0, nm)):
+            a, b = rng.choice(members, 2)
+            edges.add((int(min(a, b)), int(max(a, b))))
+        pairs = sorted(edges)
+        pp = np.ascontiguousarray([p for p, q in pairs], dtype=np.int32)
+        pq = np.ascontiguousarray([q for p, q in pairs], dtype=np.int32)
+        out = np.zeros(nm + 8, dtype=np.int32)
+        cap = 8
+        while cap < 8 * nm:
+            cap *= 2
+        n = f(pp.ctypes.data_as(ip), pq.ctypes.data_as(ip), len(pairs), cap, out.ctypes.data_as(ip))
+        assert out[:n].tolist() == _reference_group_order(pairs), (trial, pairs[:8])
+
+
+def test_group_maximum_shared_by_two_members(sim):
+    # check_groups with an EXACT tie of the largest length (two chords shifted by one point): the reference keeps the member
+    # that comes first in its CPython set -- here (15, 16) iterate as 16, 15.  Found by tools/parity_hunt.py (1 degree, 6 steps)
+    lib, ctx = sim
+    lat, lon = synth.grid(1.0)
+    for seed, eps, t0, levels in ((41289, 0.0, 3601, [-2, 2]), (42352, 0.1, 2195, [1.0, 3.0])):
+        pv = synth.pv_field(t0, 6, lat, lon, eps=eps, seed=1000 + seed)
+        for eager in (0, 1):
+            ctx.set_option("eager_f2", eager)
+            try:
+                helpers.full_parity(ctx, pv, lat, lon, synth.times(6), levels, intensity=pv)
+            finally:
+                ctx.set_option("eager_f2", 0)
+
+
 def test_group_maximum_of_chords_shifted_along_the_contour(sim):
     # check_groups (streamer_index.py:224-251) keeps the member with the largest on[ind1 : ind2 + 1].sum(): this 0.25 degree
     # field holds a group with two chords shifted by one point, whose sums differ in the last bits only -- the argmax turns

@@ -18,10 +18,11 @@ def case(args):
     t0 = int(rng.randint(0, 5000))
     levels = [[-2, 2], [2], [-2, 2, 1.5], [1.0, 3.0]][int(rng.randint(0, 4))]
     lat, lon = synth.grid(dlon)
-    pv = synth.pv_field(t0, 1, lat, lon, eps=eps, seed=1000 + seed)
+    nt = int(os.environ.get("WB_HUNT_NT", 1))
+    pv = synth.pv_field(t0, nt, lat, lon, eps=eps, seed=1000 + seed)
     ctx = _hip.Context(0) if os.environ.get("WB_HUNT_GPU") else _hip.Context(0, helpers.hostsim_library())
     try:
-        helpers.full_parity(ctx, pv, lat, lon, synth.times(1), levels, intensity=pv)
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(nt), levels, intensity=pv)
         return (seed, eps, t0, levels, "ok")
     except Exception as e:
         return (seed, eps, t0, levels, "FAIL " + type(e).__name__ + " " + str(e)[:120])

@@ -99,6 +99,7 @@ class Library:
         lib.wb_set_step_offset.argtypes = [C.c_void_p, C.c_int64]
         lib.wb_get_device_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        lib.wb_get_group_ties.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.wb_get_evaluated_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         lib.wb_get_com_rechecks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_timings.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]
@@ -548,6 +549,12 @@ class Batch:
         g, c = C.c_int64(), C.c_int64()
         self.ctx.L.lib.wb_get_band_hits(self.h, C.byref(g), C.byref(c))
         return int(g.value), int(c.value)
+
+    def group_ties(self):
+        """check_groups groups of the last indices() call whose largest length was shared by several members exactly"""
+        v = C.c_int64()
+        self.ctx.L.lib.wb_get_group_ties(self.h, C.byref(v))
+        return int(v.value)
 
     def com_rechecks(self):
         """(rasterised events, boxes, boxes walked by one lane) whose areas / x_com / y_com were re-evaluated cell by cell

@@ -436,6 +436,7 @@ struct wb_batch {
     int *dev_px = nullptr, *dev_py = nullptr, *d_job_level = nullptr;
     long long dev_n[3] = {0, 0, 0}, dev_nv = 0, step_offset = 0;
     long long com_rechecks[3] = {0, 0, 0};     // events / boxes whose centre-of-mass sums were re-evaluated in the reference's order
+    long long group_ties = 0;                  // check_groups: groups whose largest length was shared by several members
     // batches built from a user-supplied contour frame: one job per contour row
     std::vector<int> job_step, job_level;
     int* d_job_step = nullptr;
@@ -928,6 +929,11 @@ extern "C" int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[
     *nverts = b->dev_nv;
     return 0;
 }
+extern "C" int wb_get_group_ties(wb_batch* b, int64_t* ties) {
+    if (!b) return 1;
+    *ties = b->group_ties;
+    return 0;
+}
 extern "C" int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated) {
     if (!b) return 1;
     *evaluated = b->pair_stats[2];
@@ -1372,6 +1378,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.npairs = (int*)talloc(nsel_b * sizeof(int));
             st.stage = (int*)talloc(nsel_b * sizeof(int));
             st.nalive = (int*)talloc(nsel_b * sizeof(int));
+            st.tie_m = (int*)talloc(nsel_b * sizeof(int));
+            st.eager = ctx->eager_f2 ? 1 : 0;
             st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
             st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
             st.rowmx = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
@@ -1408,10 +1416,12 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
                 b->timer.begin(ctx, "streamer_f34");
                 WB_LAUNCH(wb_k_streamer_f34, nsel_b, 256, st);
+                WB_LAUNCH(wb_k_streamer_ties, (nsel_b + 63) / 64, 64, st);
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
                 WB_LAUNCH(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, st);
+                WB_LAUNCH(wb_k_streamer_ties, (nsel_b + 63) / 64, 64, st);
                 b->timer.end(ctx);
             }
         }
@@ -1551,6 +1561,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     b->band[0] = fin.band[0]; b->band[1] = fin.band[1];
     b->pair_stats[0] = fin.point_pairs; b->pair_stats[1] = fin.cand_pairs; b->pair_stats[2] = fin.evaluated_pairs;
     for (int q = 0; q < 3; ++q) b->com_rechecks[q] = fin.com_rechecks[q];
+    b->group_ties = fin.group_ties;
     const int NS = fin.NS, NO = fin.NO, NE = fin.NE;
     b->dev_n[0] = NS; b->dev_n[1] = NO; b->dev_n[2] = NE - NS - NO;
 
@@ -2258,6 +2269,11 @@ extern "C" int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_off
 }
 
 #if defined(WB_HOSTSIM)
+extern "C" int wb_hostsim_group_order(const int* pp, const int* pq, int np, int cap, int* out) {
+    std::vector<long long> ws((size_t)2 * cap);
+    std::vector<unsigned char> done((size_t)np + 1);
+    return wb_pyset_group_order(pp, pq, np, done.data(), ws.data(), cap, out);
+}
 extern "C" double wb_hostsim_np_sum(const double* a, int64_t n) { return wb_np_pairwise_sum(a, (int)n); }
 extern "C" void wb_hostsim_div(const double* a, int64_t n, double S, double* fast, double* plain) {
     const double y = 1.0 / S;

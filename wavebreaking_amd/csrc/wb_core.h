@@ -100,7 +100,7 @@ struct WbCtl {
     int ne_demand;               // events found when they exceeded cap_ne
     unsigned long long cell_count;
     int props_cursor;            // next event of the property kernel's work queue
-    int pad0_;
+    int group_ties;              // check_groups: groups whose maximum length was shared by several members (exact ties)
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.
@@ -189,6 +189,101 @@ WB_HD inline double wb_np_pairwise_sum(const double* a, int n) {
     double s = wb_np_pairwise_block(a, 8192);
     for (int i = 8192; i < n; i += 8192) s = s + wb_np_pairwise_block(a + i, n - i < 8192 ? n - i : 8192);
     return s;
+}
+
+// ------------------------------------------------------------------ CPython's set, for one tie
+// check_groups (streamer_index.py:224-251) keeps ``item[np.argmax(lengths)]`` per group, ``item`` being ``list(first)`` of
+// combine_shared (index_utils.py:187-214): when two members' lengths are EQUAL to the last bit -- chords shifted by one
+// point along a lattice contour, every few thousand time steps -- the survivor is whichever comes first in the iteration
+// order of a CPython set of small integers, i.e. in the slot order of its hash table after the very sequence of
+// ``set(row)`` / ``first |= set(row)`` operations combine_shared performs.  Restated from Objects/setobject.c (CPython 3.7
+// - 3.12: hash(int) = int, 8 initial slots, LINEAR_PROBES 9, PERTURB_SHIFT 5, growth when fill * 5 >= mask * 3 to the
+// first power of two above 4 * used, ``|=`` growing up front to above 2 * (used + other's used)); pinned against the
+// running interpreter's sets in tests/test_hostsim_parity.py.  Keys are non-negative ints; -1 marks an empty slot.
+struct WbPySet { long long* tab; long long* spare; int mask, fill, used; };
+WB_HD inline void wb_pyset_insert_clean(long long* tab, int mask, long long key) {
+    unsigned long long perturb = (unsigned long long)key;
+    unsigned long long i = (unsigned long long)key & (unsigned long long)mask;
+    for (;;) {
+        if (tab[i] < 0) { tab[i] = key; return; }
+        if (i + 9 <= (unsigned long long)mask) {
+            for (int j = 1; j <= 9; ++j) if (tab[i + j] < 0) { tab[i + j] = key; return; }
+        }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (unsigned long long)mask;
+    }
+}
+WB_HD inline void wb_pyset_resize(WbPySet& s, int minused) {
+    int newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    long long* nt = s.spare;
+    for (int i = 0; i < newsize; ++i) nt[i] = -1;
+    for (int i = 0; i <= s.mask; ++i) if (s.tab[i] >= 0) wb_pyset_insert_clean(nt, newsize - 1, s.tab[i]);
+    s.spare = s.tab; s.tab = nt; s.mask = newsize - 1; s.fill = s.used;
+}
+WB_HD inline bool wb_pyset_contains(const WbPySet& s, long long key) {
+    unsigned long long perturb = (unsigned long long)key, mask = (unsigned long long)s.mask;
+    unsigned long long i = (unsigned long long)key & mask;
+    for (;;) {
+        const int probes = (i + 9 <= mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j) {
+            if (s.tab[i + j] < 0) return false;
+            if (s.tab[i + j] == key) return true;
+        }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & mask;
+    }
+}
+WB_HD inline void wb_pyset_add(WbPySet& s, long long key) {
+    unsigned long long perturb = (unsigned long long)key, mask = (unsigned long long)s.mask;
+    unsigned long long i = (unsigned long long)key & mask;
+    for (;;) {
+        const int probes = (i + 9 <= mask) ? 9 : 0;
+        for (int j = 0; j <= probes; ++j) {
+            if (s.tab[i + j] == key) return;
+            if (s.tab[i + j] < 0) {
+                s.tab[i + j] = key;
+                ++s.fill; ++s.used;
+                if ((long long)s.fill * 5 < (long long)s.mask * 3) return;
+                wb_pyset_resize(s, s.used > 50000 ? s.used * 2 : s.used * 4);
+                return;
+            }
+        }
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & mask;
+    }
+}
+// s |= set([a, b])
+WB_HD inline void wb_pyset_merge_pair(WbPySet& s, long long a, long long b) {
+    long long ot[8];
+    for (int i = 0; i < 8; ++i) ot[i] = -1;
+    wb_pyset_insert_clean(ot, 7, a);                       // set(iterable): a, then b (two keys never fill 8 slots)
+    int oused = 1;
+    if (b != a) { wb_pyset_insert_clean(ot, 7, b); oused = 2; }
+    if ((long long)(s.fill + oused) * 5 >= (long long)s.mask * 3) wb_pyset_resize(s, (s.used + oused) * 2);
+    for (int i = 0; i < 8; ++i) if (ot[i] >= 0) wb_pyset_add(s, ot[i]);
+}
+// combine_shared for ONE group: ``pp[k] <= pq[k]``, k < np, its crossing pairs in the reference's order (lexicographic; the
+// first is the group's smallest member with itself); ws: 2 * cap slots, cap a power of two >= 8 * members.  Writes the
+// members in ``list(first)`` order to out, returns their number.
+WB_HD inline int wb_pyset_group_order(const int* pp, const int* pq, int np, unsigned char* done, long long* ws, int cap, int* out) {
+    WbPySet s;
+    s.tab = ws; s.spare = ws + cap; s.mask = 7; s.fill = 0; s.used = 0;
+    for (int i = 0; i < 8; ++i) s.tab[i] = -1;
+    wb_pyset_add(s, pp[0]);
+    wb_pyset_add(s, pq[0]);                                 // first = set(first row)
+    for (int k = 0; k < np; ++k) done[k] = k == 0;
+    int lf = -1;
+    while (s.used > lf) {
+        lf = s.used;
+        for (int k = 1; k < np; ++k) {
+            if (done[k]) continue;
+            if (wb_pyset_contains(s, pp[k]) || wb_pyset_contains(s, pq[k])) { wb_pyset_merge_pair(s, pp[k], pq[k]); done[k] = 1; }
+        }
+    }
+    int n = 0;
+    for (int i = 0; i <= s.mask; ++i) if (s.tab[i] >= 0) out[n++] = (int)s.tab[i];
+    return n;
 }
 
 // ------------------------------------------------------------------ integer predicates

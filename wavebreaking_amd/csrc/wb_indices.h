@@ -254,6 +254,8 @@ struct WbStreamerArgs {
     int* rowaux;
     int* rowmx;
     int* ev_ind;               // [nsel][cap_ev][2]
+    int* tie_m;                // [nsel] 0, or the survivor count of a contour whose check_groups met an exact tie (wb_k_streamer_ties)
+    int eager;                 // 1: the survivors were laid out by wb_k_streamer_f34, 0: by wb_k_streamer_f234
     int* ev_n;                 // [nsel]
     uint32_t* status;          // [njobs]
 };
@@ -724,10 +726,50 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a) {
     }   // work list
 }
 
+// check_groups, exact ties: which of the members of group g whose length equals the group's maximum comes first in the
+// reference's ``list(first)`` (wb_core.h: CPython's set).  Members are the survivors m with lab[m] == g, ascending = the
+// rows of the reference's frame; their crossing pairs in lexicographic order are what combine_shared saw.  ws: words of
+// scratch.  Returns -1 when the group is too large for the scratch (the lowest member stays).
+#define WB_TIE_MAX 64
+WB_HD inline int wb_group_tie_winner(const int* lab, int M, int g, const uint32_t* pts, const int* mi, const int* mj,
+                                     const unsigned long long* gval, unsigned long long bestbits, unsigned long long* ws, long long nws) {
+    int nm = 0;
+    for (int m = 0; m < M; ++m) if (lab[m] == g) ++nm;
+    if (nm > WB_TIE_MAX) return -1;
+    int cap = 8;
+    while (cap < 8 * nm) cap <<= 1;
+    const int maxp = nm * (nm + 1) / 2;                            // pairs: at most nm (nm + 1) / 2
+    // 64-bit words: two tables, members, two pair columns, the order, the done flags
+    const long long need = 2LL * cap + (nm + 2) / 2 + 2LL * ((maxp + 2) / 2) + (nm + 2) / 2 + (maxp + 8) / 8 + 4;
+    if (need > nws) return -1;
+    long long* tab = (long long*)ws;                               // 2 * cap
+    int* mem = (int*)(ws + 2 * cap);                               // nm
+    int* pp = mem + ((nm + 2) & ~1);
+    int* pq = pp + ((maxp + 2) & ~1);
+    int* out = pq + ((maxp + 2) & ~1);
+    unsigned char* done = (unsigned char*)(out + ((nm + 2) & ~1));
+    nm = 0;
+    for (int m = 0; m < M; ++m) if (lab[m] == g) mem[nm++] = m;
+    int np = 0;
+    for (int x = 0; x < nm; ++x)
+        for (int y = x; y < nm; ++y) {
+            const int m1 = mem[x], m2 = mem[y];
+            const uint32_t a1 = pts[mi[m1]], b1 = pts[mj[m1]], a2 = pts[mi[m2]], b2 = pts[mj[m2]];
+            if (x == y || wb_segments_intersect(wb_pt_x(a1), wb_pt_y(a1), wb_pt_x(b1), wb_pt_y(b1), wb_pt_x(a2), wb_pt_y(a2),
+                                                wb_pt_x(b2), wb_pt_y(b2))) { pp[np] = m1; pq[np] = m2; ++np; }
+        }
+    const int n = wb_pyset_group_order(pp, pq, np, done, tab, cap, out);
+    for (int k = 0; k < n; ++k) if (gval[out[k]] == bestbits) return out[k];
+    return -1;
+}
+
 // routines 3 and 4: check_overlapping (:202-222), check_groups (:224-251), then the polygons' end points
 WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
     if (s >= a.ctl->nsel) return;
+    WB_SINGLE
+    a.tie_m[s] = 0;
+    WB_END_SINGLE
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -865,6 +907,12 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
+        // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
+        // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
+        // registers); here the lowest such member stands in and the contour is marked
+        WB_PFOR(m, M)
+            if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
+        WB_END_PFOR
         WB_PFOR(m, M)
             aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
         WB_END_PFOR
@@ -918,6 +966,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
     if (s >= a.ctl->nsel) return;
+    if (WB_TID == 0) a.tie_m[s] = 0;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* gpts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -1177,6 +1226,12 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
+        // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
+        // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
+        // registers); here the lowest such member stands in and the contour is marked
+        WB_PFOR(m, M)
+            if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
+        WB_END_PFOR
         WB_PFOR(m, M)
             aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
         WB_END_PFOR
@@ -1206,6 +1261,41 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
 // work lists and offsets, built on the device (single workgroups: a few thousand entries each)
 
 // lengths of the selected contours -> packed point offsets, work items of the all-pairs kernel
+// check_groups, exact ties (after wb_k_streamer_f234 / f34): for the contours marked there, the survivor of every group whose
+// largest length is shared by several members becomes the member that comes first in the reference's CPython set
+// (wb_group_tie_winner), and the event's end points are rewritten.  One thread per marked contour; nearly always none.
+WB_KERNEL(wb_k_streamer_ties, WbStreamerArgs a) {
+    const int nsel = a.ctl->nsel;
+    for (int s = WB_BLOCK_ID * WB_NT + WB_TID; s < nsel; s += WB_GRID_DIM * WB_NT) {
+        const int M = a.tie_m[s];
+        if (M < 2) continue;
+        const int job = a.sel_job[s], k = a.sel_cont[s];
+        const size_t jb = (size_t)job * a.cap_seg;
+        const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+        const int N = a.c_len[jb + k];
+        const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
+        unsigned long long* best = a.hval + (size_t)s * a.hash_size;
+        const int* mi; const int* mj; const int* lab; const int* aux;
+        if (a.eager) {
+            mi = (int*)a.hkey + (size_t)s * a.hash_size * 2; mj = mi + M; lab = mj + M; aux = a.rowaux + a.poff[s];
+        } else {
+            const int w = (P < N ? P : N) + 1;
+            mi = (int*)(a.hkey + (size_t)s * a.hash_size); mj = mi + w; lab = mj + w; aux = lab + w;
+        }
+        const unsigned long long* gval = best + 2 * (size_t)M;
+        int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
+        for (int g = 0; g < M; ++g) {
+            if (lab[g] != g) continue;
+            int ntie = 0;
+            for (int m = 0; m < M; ++m) if (lab[m] == g && gval[m] == best[g]) ++ntie;
+            if (ntie < 2) continue;
+            wb_atomic_add(&a.ctl->group_ties, 1);
+            const int w = wb_group_tie_winner(lab, M, g, pts, mi, mj, gval, best[g], best + 3 * (size_t)M, (long long)a.hash_size - 3LL * M);
+            if (w >= 0 && aux[g] < a.cap_ev) { ev[2 * aux[g] + 0] = mi[w]; ev[2 * aux[g] + 1] = mj[w]; }
+        }
+    }
+}
+
 WB_KERNEL(wb_k_sel_scan, WbStreamerArgs a, int* tmp) {
     const int nsel = a.ctl->nsel;
     WB_SHARED(unsigned long long, pp, 1);

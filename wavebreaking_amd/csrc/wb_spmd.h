@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #define WB_HD
 #define WB_DEV
+#define WB_NOINLINE
 #define WB_KERNEL(name, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
 #define WB_KERNEL_LB(name, threads, waves, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
 #define WB_BLOCK_ID wb_block_id
@@ -69,6 +70,7 @@ static inline void wb_block_scan_excl_max(int* a, int n, int init) {
 #include <hip/hip_runtime.h>
 #define WB_HD __host__ __device__
 #define WB_DEV __device__
+#define WB_NOINLINE __attribute__((noinline))      // rare slow paths: kept out of the hot kernels' register allocation
 #define WB_KERNEL(name, ...) __global__ void name(__VA_ARGS__)
 // waves = minimum waves per SIMD the register allocator must leave room for
 #define WB_KERNEL_LB(name, threads, waves, ...) __global__ __launch_bounds__(threads, waves) void name(__VA_ARGS__)
