@@ -79,6 +79,8 @@ struct wb_ctx {
         double* base = nullptr;
         size_t o_lat = 0, o_latrad = 0, o_sphi2 = 0, o_cphi2 = 0, o_cphi = 0, o_wlat = 0, o_lonrad = 0, o_slam2 = 0, o_clam2 = 0;
         int* dxlim = nullptr;
+        double* on_tab = nullptr;             // [nlat][nlon][4] distance (km) of a grid point to its E, N, NE, NW neighbour: sklearn's
+                                              // haversine evaluated with the HOST's math library (wb_k_streamer_prep)
         int dy_max = 0;
         double hthr = 0;
     };
@@ -1219,6 +1221,32 @@ static wb_ctx::Tables* make_tables(wb_batch* b) {
     t->o_lat = put(b->lat); t->o_latrad = put(latrad); t->o_sphi2 = put(sphi2); t->o_cphi2 = put(cphi2); t->o_cphi = put(cphi);
     t->o_wlat = put(wlat); t->o_lonrad = put(lonrad); t->o_slam2 = put(slam2); t->o_clam2 = put(clam2);
     t->base = (double*)dmalloc(ctx, all.size() * sizeof(double));
+    {
+        // on[k] of the streamer index (streamer_index.py:130-133) is the distance between two consecutive contour points, i.e.
+        // between a grid point and one of its eight neighbours (a contour jumps further only where duplicate points were
+        // dropped).  check_groups compares SUMS of them that agree to the last bits, so every on[k] has to be the value the
+        // reference's math library gives -- the device's sin / cos / asin differ from it by an ulp here and there.  All
+        // unit steps, evaluated here in sklearn's operation order: 4 per grid point (the formula is symmetric in its points).
+        const size_t cells = (size_t)p.nlat * p.nlon;
+        std::vector<double> tab(cells * 4);
+        const int nth = 4;
+        std::vector<std::thread> th;
+        for (int w = 0; w < nth; ++w)
+            th.emplace_back([&, w]() {
+                for (int y = w; y < p.nlat; y += nth)
+                    for (int x = 0; x < p.nlon; ++x) {
+                        double* o = &tab[((size_t)y * p.nlon + x) * 4];
+                        const int xe = (x + 1) % p.nlon, xw = (x + p.nlon - 1) % p.nlon, yn = y + 1 < p.nlat ? y + 1 : y;
+                        o[0] = wb_haversine(latrad[y], lonrad[x], latrad[y], lonrad[xe]) * 6371.0;
+                        o[1] = wb_haversine(latrad[y], lonrad[x], latrad[yn], lonrad[x]) * 6371.0;
+                        o[2] = wb_haversine(latrad[y], lonrad[x], latrad[yn], lonrad[xe]) * 6371.0;
+                        o[3] = wb_haversine(latrad[y], lonrad[x], latrad[yn], lonrad[xw]) * 6371.0;
+                    }
+            });
+        for (auto& q : th) q.join();
+        t->on_tab = (double*)dmalloc(ctx, tab.size() * sizeof(double));
+        if (t->on_tab) h2d(ctx, t->on_tab, tab.data(), tab.size() * sizeof(double));
+    }
     // streamer thresholds
     { const double sv = sin(p.geo_dis / (2.0 * 6371.0)); t->hthr = sv * sv; }
     t->dy_max = (int)floor(p.geo_dis / (6371.0 * p.dlat * (M_PI / 180.0))) + 1;
@@ -1360,6 +1388,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.ctl = ctl; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.W = b->W; st.cap_ev = cap_ev;
             st.geo_dis = p.geo_dis; st.cont_dis = p.cont_dis; st.hthr = T->hthr; st.dy_max = T->dy_max; st.dxlim = T->dxlim;
             st.sel_job = b->sel_job; st.sel_cont = b->sel_cont; st.c_off = b->c_off; st.c_len = b->c_len; st.cpts = b->cpts;
+            st.on_tab = T->on_tab;
             st.lat_rad = T->base + T->o_latrad; st.lon_rad = T->base + T->o_lonrad; st.sphi2 = T->base + T->o_sphi2;
             st.cphi2 = T->base + T->o_cphi2; st.cphi = T->base + T->o_cphi; st.slam2 = T->base + T->o_slam2; st.clam2 = T->base + T->o_clam2;
             const long long NPT = npt_b;

@@ -235,6 +235,7 @@ struct WbStreamerArgs {
     int* item_tile;
     int* f2_off;               // [nsel+1] first 256-pair block of a contour in routine 2's work list
     double* on;                // on[k] = d(k-1, k) * 6371, on[0] = 0
+    const double* on_tab;      // [nlat][nlon][4]: unit steps E, N, NE, NW from the host's math library (or null)
     double* pre;               // inclusive prefix of on
     double* ptab;              // [5][npts_total] sin(phi/2), cos(phi/2), cos(phi), sin(lam/2), cos(lam/2) per point
     long long npts_total;      // capacity of the packed per-point arrays (plane stride of ptab)
@@ -291,7 +292,18 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
         double d = 0.0;
         if (i > 0) {
             const uint32_t p0 = pts[i - 1];
-            d = wb_haversine(a.lat_rad[wb_pt_y(p0)], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[y1], a.lon_rad[x1]) * 6371.0;
+            const int y0 = wb_pt_y(p0), dy = y1 - y0, dx = wb_pt_x(p1) - wb_pt_x(p0);        // dx in the extended coordinates
+            if (a.on_tab && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1 && (dx | dy)) {
+                // a step to a neighbouring grid point: the host's value (bit for bit the reference's), looked up from the
+                // lower of the two points (the lower-left one of a row step)
+                const int yb = dy < 0 ? y1 : y0;                                         // base row
+                const int xb = dy < 0 ? wb_pt_x(p1) : (dy > 0 ? wb_pt_x(p0) : (dx > 0 ? wb_pt_x(p0) : wb_pt_x(p1)));
+                const int dxs = dy < 0 ? -dx : dx;                                       // column step seen from the base point
+                const int kind = dy == 0 ? 0 : (dxs == 0 ? 1 : (dxs > 0 ? 2 : 3));
+                d = a.on_tab[((size_t)yb * a.nlon + (xb % a.nlon)) * 4 + kind];
+            } else {
+                d = wb_haversine(a.lat_rad[y0], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[y1], a.lon_rad[x1]) * 6371.0;
+            }
         }
         on[i] = d;
         tab[0 * a.npts_total + i] = a.sphi2[y1];
