@@ -122,7 +122,12 @@ NEAR_INTEGER_EVENTS = {}     # events seen by compare_events whose com quotient 
 def full_parity(ctx, data, lat, lon, times, levels, intensity=None, periodic_add=120.0, **kw):
     """Everything the path produces, ABI vs oracle.  Returns (abi tables, oracle tables)."""
     got = run_abi(ctx, data, lat, lon, levels, intensity=intensity, periodic_add=periodic_add, **kw)
-    ref = oapi.run_all(data, levels, lat, lon, times, intensity=intensity, periodic_add=periodic_add)
+    # index parameters go to both sides (the oracle has ONE min_exp, as run_all calls the two index functions with the same)
+    okw = {k: kw[k] for k in ("geo_dis", "cont_dis", "range_group") if k in kw}
+    if "ot_min_exp" in kw or "co_min_exp" in kw:
+        assert kw.get("ot_min_exp", 5.0) == kw.get("co_min_exp", 5.0)
+        okw["min_exp"] = kw.get("ot_min_exp", 5.0)
+    ref = oapi.run_all(data, levels, lat, lon, times, intensity=intensity, periodic_add=periodic_add, **okw)
     dlon = ocont.spatial_resolution(np.asarray(lon, dtype=np.float64), "lon")
     compare_contours(got["contours"], ref["contours"], levels, dlon)
     for kind in ("streamers", "overturnings", "cutoffs"):

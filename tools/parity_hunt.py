@@ -22,7 +22,13 @@ def case(args):
     pv = synth.pv_field(t0, nt, lat, lon, eps=eps, seed=1000 + seed)
     ctx = _hip.Context(0) if os.environ.get("WB_HUNT_GPU") else _hip.Context(0, helpers.hostsim_library())
     try:
-        helpers.full_parity(ctx, pv, lat, lon, synth.times(nt), levels, intensity=pv)
+        kw = {}
+        if os.environ.get("WB_HUNT_PARAMS"):           # random index parameters and periodic extension
+            me = float(rng.choice([3.0, 5.0, 8.0]))
+            kw = dict(geo_dis=float(rng.choice([400.0, 800.0, 1200.0])), cont_dis=float(rng.choice([1000.0, 1500.0, 2500.0])),
+                      range_group=float(rng.choice([3.0, 5.0, 8.0])), ot_min_exp=me, co_min_exp=me,
+                      periodic_add=float(rng.choice([60.0, 120.0, 180.0])))
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(nt), levels, intensity=pv, **kw)
         return (seed, eps, t0, levels, "ok")
     except Exception as e:
         return (seed, eps, t0, levels, "FAIL " + type(e).__name__ + " " + str(e)[:120])
