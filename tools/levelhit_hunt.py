@@ -14,7 +14,7 @@ def case(args):
     from oracle import synth
     from wavebreaking_amd import _hip
     pv, lat, lon = helpers.level_hit_field(seed, dlon=dlon, nhits=(4 + seed % 9) * int(os.environ.get("WB_HUNT_HITS", 1)))
-    ctx = _hip.Context(0, helpers.hostsim_library())
+    ctx = _hip.Context(0) if os.environ.get("WB_HUNT_GPU") else _hip.Context(0, helpers.hostsim_library())
     try:
         got = helpers.run_abi(ctx, pv, lat, lon, [2.0], intensity=pv)
         st = int(got["status"][0])
@@ -32,10 +32,11 @@ if __name__ == "__main__":
     first, count = int(sys.argv[1]), int(sys.argv[2])
     dlon = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     import helpers
-    helpers.build_hostsim()
+    if not os.environ.get("WB_HUNT_GPU"):
+        helpers.build_hostsim()
     t = time.time()
     tally = {}
-    with mp.get_context("spawn").Pool(6) as pool:
+    with mp.get_context("spawn").Pool(int(os.environ.get("WB_HUNT_WORKERS", 6))) as pool:
         for seed, res in pool.imap_unordered(case, [(s, dlon) for s in range(first, first + count)]):
             tally[res.split()[0]] = tally.get(res.split()[0], 0) + 1
             if res.startswith("FAIL"):

@@ -20,6 +20,8 @@ def case(args):
     lat, lon = synth.grid(dlon)
     nt = int(os.environ.get("WB_HUNT_NT", 1))
     pv = synth.pv_field(t0, nt, lat, lon, eps=eps, seed=1000 + seed)
+    if os.environ.get("WB_HUNT_F64"):
+        pv = pv.astype(np.float64)
     ctx = _hip.Context(0) if os.environ.get("WB_HUNT_GPU") else _hip.Context(0, helpers.hostsim_library())
     try:
         kw = {}
