@@ -125,6 +125,8 @@ def rings_area(rings):
     """even-odd area of a set of rings, exact"""
     ys = [int(y) for r in rings for _, y in r]
     total = Fraction(0)
+    if not ys:                                       # an empty geometry (transform_polygons can return one, index_utils.py:167-168)
+        return total
     for k in range(min(ys), max(ys)):
         for l, r in _spans(_row_pieces(rings, k)):
             total += ((r[0] - l[0]) + (r[1] - l[1])) / 2
@@ -137,6 +139,8 @@ def overlap_area(rings_a, rings_b):
     ya = [int(y) for r in rings_a for _, y in r]
     yb = [int(y) for r in rings_b for _, y in r]
     total = Fraction(0)
+    if not ya or not yb:
+        return total
     for k in range(max(min(ya), min(yb)), min(max(ya), max(yb))):
         sa = _spans(_row_pieces(rings_a, k))
         sb = _spans(_row_pieces(rings_b, k))
