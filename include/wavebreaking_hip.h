@@ -213,7 +213,8 @@ int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const double* la
      method 0 "by_overlap":  area(A n B) / (area A + area B - area(A n B)) > overlap (events.py:209-214) for the polygons
                              given as LATTICE rings: event k owns rings ring_offset[k] .. ring_offset[k+1], ring q the
                              vertices vert_offset[q] .. vert_offset[q+1] of vx / vy (grid indices, |v| < 32768; closed or
-                             not; parts of a MultiPolygon and holes alike: even-odd).  buffer = 0 only.
+                             not; parts of a MultiPolygon and holes alike: even-odd).  buffer = 0 only.  A ratio within 1e-13
+                             (relative) of `overlap` counts as equal to it: not above.
    label[n] <- events.py:224-238 (components named after their smallest row, renumbered 0, 1, 2, ...).  area[n] (may be
    NULL; method 0) <- even-odd area of every event in index units.  stats[4] (may be NULL) <- pairs in range, pairs whose
    bounding boxes overlap (method 0), pairs linked, 0. */

@@ -258,7 +258,9 @@ def _kernel_thresholds(ctx):
     dates = np.array(["2000-01-01T00", "2000-01-01T06"], dtype="datetime64[ns]")
     a, b = [SQ(0, 0, 10, 10)], [SQ(5, 0, 15, 10)]                        # IoU = 50 / 150
     third = 50.0 / 150.0
-    for ov, linked in ((third, False), (np.nextafter(third, 0), True), (0.0, True)):
+    # equality with the threshold is decided with a guard of 1e-13 relative (the trapezoid sum is rounded; lattice polygons
+    # give ratios like 1/2 or 1/5 on the dot, tools/track_hunt.py): at the threshold, and within the guard of it, not linked
+    for ov, linked in ((third, False), (np.nextafter(third, 0), False), (third * (1 - 1e-9), True), (third * (1 + 1e-9), False), (0.0, True)):
         label, _, _ = ctx.track_events(dates, "by_overlap", 6.0, overlap=ov, rings_per_event=[a, b])
         assert label.tolist() == ([0, 0] if linked else [0, 1]), ov
     touch = [SQ(10, 0, 20, 10)]
@@ -270,6 +272,19 @@ def _kernel_thresholds(ctx):
     for thr, linked in ((d0 * (1 + 1e-9), True), (d0 * (1 - 1e-9), False)):
         label, _, _ = ctx.track_events(dates, "by_distance", 6.0, distance=thr, com=com)
         assert label.tolist() == ([0, 0] if linked else [0, 1])
+
+
+def _kernel_ratio_on_the_threshold(ctx):
+    """intersection over union EXACTLY 1/2 and 1/5 (found by tools/track_hunt.py on the path's own polygons; here squares and
+    an L-shape): not above a threshold of 0.5 / 0.2, above anything smaller"""
+    dates = np.array(["2000-01-01T00", "2000-01-01T06"], dtype="datetime64[ns]")
+    a, b = [SQ(0, 0, 3, 3)], [np.array([(0, 0), (3, 0), (3, 3), (2, 3), (2, 1), (0, 1)])]     # area 9 and 5, b inside a: 5 / 9
+    c, d = [SQ(0, 0, 4, 2)], [SQ(0, 0, 2, 2)]                                                   # 4 / 8 = 1 / 2
+    e, f = [SQ(0, 0, 5, 1)], [SQ(0, 0, 1, 1)]                                                   # 1 / 5
+    for x, y, num, den in ((a, b, 5, 9), (c, d, 1, 2), (e, f, 1, 5)):
+        exact = num / den
+        assert ctx.track_events(dates, "by_overlap", 6.0, overlap=exact, rings_per_event=[x, y])[0].tolist() == [0, 1]
+        assert ctx.track_events(dates, "by_overlap", 6.0, overlap=exact * (1 - 1e-9), rings_per_event=[x, y])[0].tolist() == [0, 0]
 
 
 def _kernel_golden_distance(ctx):
@@ -300,6 +315,7 @@ def test_track_kernels_hostsim(hostsim_ctx, reverse):
         _kernel_overlaps(hostsim_ctx)
         _kernel_tracking(hostsim_ctx)
         _kernel_thresholds(hostsim_ctx)
+        _kernel_ratio_on_the_threshold(hostsim_ctx)
         _kernel_golden_distance(hostsim_ctx)
     finally:
         helpers.hostsim_library().lib.wb_hostsim_set_reverse(0)
@@ -312,6 +328,7 @@ def test_track_kernels_gpu():
         _kernel_overlaps(ctx)
         _kernel_tracking(ctx)
         _kernel_thresholds(ctx)
+        _kernel_ratio_on_the_threshold(ctx)
         _kernel_golden_distance(ctx)
     finally:
         ctx.close()

@@ -301,8 +301,11 @@ WB_KERNEL(wb_k_track_pairs, WbTrackArgs a) {
                 const double inter = wb_track_pair_overlap(a, i, j, term, &boxes);
                 WB_SINGLE
                     if (boxes) cnts[1] += 1;
-                    const double ratio = inter / (a.area[j] + a.area[i] - inter);          // events.py:210-212
-                    if (ratio > a.overlap) {
+                    // events.py:210-214: inter / (area_j + area_i - inter) > overlap, decided without the division and with a
+                    // guard of 1e-13 relative: a ratio that EQUALS the threshold in exact arithmetic (lattice polygons give
+                    // 1/2, 1/5, ... on the dot) is not above it, whatever the rounding of the trapezoid sum says
+                    const double uni = a.area[j] + a.area[i] - inter, rhs = a.overlap * uni;
+                    if (uni > 0.0 && inter > rhs && inter - rhs > 1e-13 * (fabs(inter) + fabs(rhs))) {
                         wb_uf_union(a.parent, a.orig[i], a.orig[j]);
                         cnts[2] += 1;
                     }
