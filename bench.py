@@ -63,6 +63,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch
     import torch.distributed as dist
+    if world > 1 or os.environ.get("WB_BENCH_FORCE_DIST"):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # see below; before the first HIP call
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local = local % max(1, torch.cuda.device_count())          # dry runs with more ranks than GPUs share devices
@@ -72,6 +74,10 @@ def main():
     # are -- with one rank it exercises the RCCL path on a one-GPU box
     multi = world > 1 or bool(os.environ.get("WB_BENCH_FORCE_DIST"))
     if multi:
+        # HSA_ENABLE_IPC_MODE_LEGACY=0 (set above, before the first HIP call): the host driver of this pool only supports
+        # dmabuf IPC; with the legacy mode RCCL's peer-to-peer set-up -- any sharing of device memory across processes -- fails
+        # with `hipIpcGetMemHandle: invalid argument`.  The image exports the variable already; a launcher with a scrubbed
+        # environment gets the same behaviour this way.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -202,10 +208,28 @@ def main():
     pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True), full_width=full_w)
     barrier()
     dt = time.perf_counter() - tic
+    verify = None
     if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+        cdev = device if dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # self-verification of the N > 1 run: an all-reduce(sum) of (1, this rank's events, this rank's polygon vertices) of the
+        # LAST timed pass -- the ranks the collective saw must be WORLD_SIZE, and what rank 0 gathered in that pass must be
+        # the sum over the ranks
+        mine = torch.tensor([1, counts.get("streamers", 0) + counts.get("overturnings", 0) + counts.get("cutoffs", 0),
+                             counts.get("polygon_vertices", 0)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        seen, ev_sum, vert_sum = (int(v) for v in mine.cpu().tolist())
+        verify = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen_by_allreduce": seen,
+                  "events_sum_over_ranks": ev_sum, "polygon_vertices_sum_over_ranks": vert_sum}
+        if rank == 0:
+            if seen != world or dist.get_world_size() != world:
+                raise SystemExit("bench.py: the collective saw %d ranks, WORLD_SIZE is %d" % (seen, world))
+            if counts.get("gathered_events") != ev_sum or counts.get("gathered_polygon_vertices") != vert_sum:
+                raise SystemExit("bench.py: rank 0 gathered %s events / %s vertices, the ranks hold %d / %d"
+                                 % (counts.get("gathered_events"), counts.get("gathered_polygon_vertices"), ev_sum, vert_sum))
+            verify["gather_verified"] = True
     out = None
 
     if rank == 0:
@@ -242,6 +266,8 @@ def main():
             "host_wall_ms": {k: float(np.mean(v)) for k, v in wall.items()},
             "counts": counts,
         }
+        if verify is not None:
+            out.update(verify)
         if world == 1 and a.e2e_steps > 0:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:
@@ -343,7 +369,14 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
     try:
         import multiprocessing as mp
         ncores = len(os.sched_getaffinity(0))
-        nw = max(1, min(ncores, 32))
+        # every host core this process may run on, capped only by what the host's memory carries: a worker
+        # (interpreter + numpy + one 0.25 degree step of the restatement) peaks near 0.7 GB
+        try:
+            import psutil
+            by_mem = int(psutil.virtual_memory().available // (1 << 30))
+        except Exception:
+            by_mem = ncores
+        nw = max(1, min(ncores, by_mem, int(os.environ.get("WB_BENCH_CPU_WORKERS", ncores))))
         steps = [int(round(i)) for i in np.linspace(0, nt - 1, nw)]
         jobs = []
         for t in steps:
@@ -356,7 +389,8 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
             pool.map(_cpu_step, jobs)
             t_all = time.perf_counter() - tic
         out["all_cores"] = {"value": len(jobs) / t_all, "unit": "timesteps/s", "cores": nw, "host_cores": ncores,
-                            "sample": "%d steps, one per worker process, %.1f s" % (len(jobs), t_all)}
+                            "sample": "%d steps, one per worker process (every core of the host the process may use%s), %.1f s"
+                                      % (len(jobs), "" if nw == ncores else "; capped by free memory / WB_BENCH_CPU_WORKERS", t_all)}
     except Exception as e:                                       # a reported extra, never fatal
         out["all_cores"] = {"error": repr(e)}
     return out

@@ -137,6 +137,12 @@ typedef struct wb_geometry {
     const double* y;            /* degrees north */
 } wb_geometry;
 int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* out);
+/* the same host code for polygons given by the caller (index_utils.py:129-184 as a function of its own): polygon k = the
+   index-lattice vertices poly_offset[k] .. poly_offset[k+1] of px / py.  index_space != 0: the rings as they are cut, in
+   index coordinates, before the truncation to the lattice (:135) and the lon / lat look-up (lon / lat may be NULL then).
+   The arrays of `out` belong to the context until its next call of this function. */
+int wb_transform_polygons(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, const int32_t* px, const int32_t* py,
+                          const double* lon, const double* lat, int nlon, int index_space, wb_geometry* out);
 int wb_get_contours(wb_batch* b, wb_contour_table* out);
 int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */

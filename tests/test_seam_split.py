@@ -1,5 +1,6 @@
-"""transform_polygons' seam split (index_utils.py:148-173): the product's vertical-line clip
-(wavebreaking_amd/utils/index_utils.py) against an oracle built on a DIFFERENT algorithm -- exact rational arithmetic,
+"""transform_polygons' seam split (index_utils.py:148-173): the product's vertical-line clip (csrc/wb_geometry.h, the code
+behind wb_get_event_geometry, reached here through wb_transform_polygons of the host-simulation build of the same sources)
+against an oracle built on a DIFFERENT algorithm -- exact rational arithmetic,
 line stretches assigned by point-in-polygon tests of their midpoints -- ring set against ring set, and both against a
 ring-free statement of the region's area (Green's theorem with the abscissa clamped at the line).  GEOS itself is not
 installable here: the restatement is unpinned, the two independent derivations agree."""
@@ -9,15 +10,25 @@ import numpy as np
 import pytest
 
 from oracle import properties as oprop
-from wavebreaking_amd.utils import index_utils as iu
+from tests import helpers
+from wavebreaking_amd import _hip
 
 NLON = 36
 LAT = np.linspace(-45.0, 45.0, 19)
 LON = np.arange(0.0, 360.0, 10.0)
 
 
+_ctx = []
+
+
+def _context():
+    if not _ctx:
+        _ctx.append(_hip.Context(0, helpers.hostsim_library()))
+    return _ctx[0]
+
+
 def _ring_sets(poly):
-    got = iu.transform_polygon_rings(np.asarray(poly), LON, LAT, NLON)
+    got = _context().transform_polygons([np.asarray(poly)], LON, LAT, NLON)[0]
     want = oprop.transform_polygon(np.asarray(poly), LAT, LON)
     return sorted(oprop.canonical_ring(r) for r in got), sorted(oprop.canonical_ring(r) for r in want)
 
@@ -26,7 +37,7 @@ def _check(poly):
     got, want = _ring_sets(poly)
     assert got == want, (poly, got, want)
     # the index-space pieces (before truncation and the lon / lat look-up) against the clamped-abscissa area
-    pieces = iu.split_index_polygon(np.asarray(poly), NLON)
+    pieces = _context().transform_polygons([np.asarray(poly)], LON, LAT, NLON, index_space=True)[0]
     area = sum(abs(oprop.ring_area(p)) for p in pieces)
     exact = oprop.clipped_area_exact(poly, NLON - 1, True) + oprop.clipped_area_exact(poly, NLON, False)
     assert abs(area - float(exact)) <= 1e-9 * max(1.0, float(exact)), (poly, area, float(exact))

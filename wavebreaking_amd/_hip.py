@@ -93,6 +93,8 @@ class Library:
         lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
         lib.wb_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbEventTable)]
         lib.wb_get_event_geometry.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbGeometry)]
+        lib.wb_transform_polygons.argtypes = [C.c_void_p, C.c_int64, i64p, i32p, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.c_int, C.c_int, C.POINTER(WbGeometry)]
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -366,7 +368,8 @@ class Context:
                                         stats.ctypes.data_as(C.POINTER(C.c_uint64)))
         if rc != 0:
             raise RuntimeError("wb_track_events failed: " + self.error())
-        return label, area, dict(pairs_in_range=int(stats[0]), pairs_boxes_overlap=int(stats[1]), pairs_linked=int(stats[2]))
+        return label, area, dict(pairs_in_range=int(stats[0]), pairs_boxes_overlap=int(stats[1]), pairs_linked=int(stats[2]),
+                                 polygons_not_simple=int(stats[3]))
 
     def track_overlaps(self, rings_per_event, pairs):
         """wb_track_overlaps: (intersection area of every pair, area of every event), index units"""
@@ -386,6 +389,29 @@ class Context:
 
     def last_op_ms(self):
         return float(self.L.lib.wb_last_op_ms(self.h))
+
+    def transform_polygons(self, polygons, lon, lat, nlon, index_space=False):
+        """wb_transform_polygons: index-lattice polygons (list of (n, 2) integer arrays) -> per polygon the list of its rings
+        ((m, 2) float64 arrays) in (lon, lat) -- or, with ``index_space``, in index coordinates as they are cut at the seam"""
+        polys = [np.asarray(q).astype("int").reshape(-1, 2) for q in polygons]
+        off = np.zeros(len(polys) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(q) for q in polys])
+        xy = np.concatenate(polys) if polys else np.zeros((0, 2), dtype=np.int64)
+        px = np.ascontiguousarray(xy[:, 0], dtype=np.int32)
+        py = np.ascontiguousarray(xy[:, 1], dtype=np.int32)
+        lon = np.ascontiguousarray(lon, dtype=np.float64)
+        lat = np.ascontiguousarray(lat, dtype=np.float64)
+        dp, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        g = WbGeometry()
+        if self.L.lib.wb_transform_polygons(self.h, len(polys), off.ctypes.data_as(i64p), px.ctypes.data_as(i32p), py.ctypes.data_as(i32p),
+                                            lon.ctypes.data_as(dp), lat.ctypes.data_as(dp), int(nlon), 1 if index_space else 0,
+                                            C.byref(g)) != 0:
+            raise RuntimeError("wb_transform_polygons failed: " + self.error())
+        ro = _arr(g.ring_offset, g.n + 1, np.int64)
+        vo = _arr(g.vert_offset, g.nrings + 1, np.int64)
+        nv = int(vo[-1]) if vo.size else 0
+        co = np.c_[_arr(g.x, nv, np.float64), _arr(g.y, nv, np.float64)]
+        return [[co[vo[q]:vo[q + 1]] for q in range(ro[k], ro[k + 1])] for k in range(len(polys))]
 
     # -- the hot path
     def _params(self, field, lat, lon, levels, dlon, dlat, periodic_add, intensity, geo_dis, cont_dis, range_group,

@@ -86,6 +86,7 @@ struct wb_ctx {
     };
     std::vector<Tables*> tables;
     WbCtl* h_ctl = nullptr;                   // pinned: where the control block of a batch lands (two snapshots)
+    WbRingSink geo;                           // result of the last wb_transform_polygons
 };
 
 #include <chrono>
@@ -909,6 +910,24 @@ extern "C" int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* o) {
         const int64_t a = t.polyoff[(size_t)k], e = t.polyoff[(size_t)k + 1];
         wb_event_rings(b->poly_x + t.pbase + a, b->poly_y + t.pbase + a, e - a, b->lon.data(), b->lat.data(), b->p.nlon, g);
     }
+    o->n = n;
+    o->ring_offset = g.ring_offset.data();
+    o->nrings = (int64_t)g.vert_offset.size() - 1;
+    o->vert_offset = g.vert_offset.data();
+    o->x = g.x.data();
+    o->y = g.y.data();
+    return 0;
+}
+extern "C" int wb_transform_polygons(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, const int32_t* px, const int32_t* py,
+                                     const double* lon, const double* lat, int nlon, int index_space, wb_geometry* o) {
+    if (!ctx || !o || n < 0 || (n && (!poly_offset || !px || !py))) return 1;
+    if (nlon < 1 || (!index_space && (!lon || !lat))) return wb_fail(ctx, "wb_transform_polygons: lon / lat / nlon missing");
+    WbRingSink& g = ctx->geo;
+    g = WbRingSink();
+    g.ring_offset.push_back(0);
+    g.vert_offset.push_back(0);
+    for (int64_t k = 0; k < n; ++k)
+        wb_event_rings(px + poly_offset[k], py + poly_offset[k], poly_offset[k + 1] - poly_offset[k], lon, lat, nlon, g, index_space != 0);
     o->n = n;
     o->ring_offset = g.ring_offset.data();
     o->nrings = (int64_t)g.vert_offset.size() - 1;

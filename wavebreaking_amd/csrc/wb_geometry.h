@@ -87,13 +87,15 @@ static void wb_clip_halfplane(const std::vector<WbPt>& v, double L, bool keep_le
     }
 }
 
-// one event: index polygon -> rings in (lon, lat)
+// one event: index polygon -> rings in (lon, lat); index_space: the rings as they are cut, in index coordinates, before the
+// truncation and the look-up (what the tests measure areas on)
 static void wb_event_rings(const int32_t* px, const int32_t* py, int64_t n, const double* lon, const double* lat, int nlon,
-                           WbRingSink& out) {
+                           WbRingSink& out, bool index_space = false) {
     bool split = false;
     for (int64_t k = 0; k < n; ++k) split |= px[k] >= nlon;                 // index_utils.py:136
     auto emit = [&](const std::vector<WbPt>& ring) {
         for (const WbPt& p : ring) {
+            if (index_space) { out.x.push_back(p.x); out.y.push_back(p.y); continue; }
             const long long xi = (long long)p.x, yi = (long long)p.y;       // :135 truncation
             out.x.push_back(lon[((xi % nlon) + nlon) % nlon]);              // :139-146
             out.y.push_back(lat[yi]);

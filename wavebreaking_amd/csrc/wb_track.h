@@ -48,7 +48,7 @@ struct WbTrackArgs {
     int* parent;                  // [n] indexed by caller's row
     int* flag;                    // [n] scratch: 1 where a row is its component's smallest row
     int* label;                   // [n] out
-    unsigned long long* stats;    // [0] pairs in range, [1] pairs whose boxes overlap, [2] pairs linked, [3] spare
+    unsigned long long* stats;    // [0] pairs in range, [1] pairs whose boxes overlap, [2] pairs linked, [3] events whose polygon crosses itself
 };
 
 // ----------------------------------------------------------------------------------------------------- union-find
@@ -151,6 +151,10 @@ static WB_HD inline double wb_span_overlap(const WbPiece& lA, const WbPiece& rA,
 // one workgroup per event: pieces per row counted, offsets by a block scan, pieces placed, every row sorted; the
 // even-odd area of the event falls out of the sorted rows
 WB_KERNEL(wb_k_track_build, WbTrackArgs a) {
+    WB_SHARED(int, xflag, 1);
+    WB_SINGLE
+        xflag[0] = 0;
+    WB_END_SINGLE
     for (long long e = WB_BLOCK_ID; e < a.n; e += WB_GRID_DIM) {
         const long long e0 = a.edge0[e], ne = a.edge0[e + 1] - e0;
         const int y0 = a.ymin[e], rows = a.ymax[e] - y0;
@@ -195,11 +199,25 @@ WB_KERNEL(wb_k_track_build, WbTrackArgs a) {
                 s += 0.5 * (((double)r.n0 + (double)r.n1) / (double)r.den - ((double)l.n0 + (double)l.n1) / (double)l.den);
             }
             rarea[k] = s;
+            // two pieces that swap sides between the row's bottom and top line cross inside it: the polygon is not simple (the
+            // reference repairs such geometries with buffer(0).make_valid(), events.py:203-204 -- GEOS, not restated: the event
+            // is counted and the caller warned; its region here is the even-odd one)
+            bool cross = false;
+            for (int i = b; i < c && !cross; ++i) {
+                const WbPiece qi = wb_piece_at(pc[i], y0 + (int)k);
+                for (int j = i + 1; j < c && j <= i + 8; ++j) {
+                    const WbPiece qj = wb_piece_at(pc[j], y0 + (int)k);
+                    const long long d0 = qi.n0 * qj.den - qj.n0 * qi.den, d1 = qi.n1 * qj.den - qj.n1 * qi.den;
+                    if ((d0 < 0 && d1 > 0) || (d0 > 0 && d1 < 0)) { cross = true; break; }
+                }
+            }
+            if (cross) xflag[0] = 1;
         WB_END_PFOR
         WB_SINGLE
             double s = 0.0;
             for (int k = 0; k < rows; ++k) s += rarea[k];
             a.area[e] = s;
+            if (xflag[0]) { if (a.stats) wb_atomic_add(&a.stats[3], 1ull); xflag[0] = 0; }
         WB_END_SINGLE
     }
 }

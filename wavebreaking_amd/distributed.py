@@ -158,8 +158,10 @@ ROW_FIELDS = dict(step=0, level_idx=1, contour=2, ind1=3, ind2=4, orientation=9,
 
 
 def rows_to_events(rows, poly_x, poly_y):
-    """packed device rows (n, 20) + the vertices of the same events -> the three event dictionaries of Batch.events()
-    (a formatting step for consumers that want the per-index tables; no per-event Python)"""
+    """packed device rows (n, 20) + the vertices of the same events -> three event dictionaries with the keys of
+    Batch.events() (a formatting step for consumers that want the per-index tables; no per-event Python).  One column
+    differs in meaning: ``contour`` is the contour's number INSIDE its (step, level) job, as the rows carry it -- a row of
+    the batch's contour table (what Batch.events() gives) means nothing once the shards of several ranks are concatenated."""
     rows = np.asarray(rows, dtype=np.float64).reshape(-1, 20)
     poly_x, poly_y = np.asarray(poly_x), np.asarray(poly_y)
     npoly = rows[:, 18].astype(np.int64)
@@ -333,7 +335,11 @@ def calculate_sharded(func, data, contour_levels, *args, dist=None, dst=0, **kwa
                 block_times = set(engine._time_key(t) for t in np.asarray(_time_block(data, tn, first, count)[tn].values))
                 keep = [engine._time_key(t) in block_times for t in kw["contours"]["date"]]
                 kw["contours"] = kw["contours"][np.asarray(keep, dtype=bool)].reset_index(drop=True)
-            frame = func(_time_block(data, tn, first, count), contour_levels, *args, **kw)
+                # no contour row on this rank's dates: an empty shard, not the "contours ... is empty!" error of a call that was
+                # handed an empty frame (the one-process call finds nothing on those dates either)
+                count = count if len(kw["contours"]) else 0
+            if count > 0:
+                frame = func(_time_block(data, tn, first, count), contour_levels, *args, **kw)
     except Exception as e:                                           # a failing rank still enters the collectives below:
         error = e                                                    # the others would wait for it forever otherwise
         frame = pd.DataFrame()

@@ -1,6 +1,8 @@
 """Event post-processing with the call surface of wavebreaking/processing/events.py: ``to_xarray`` (:37-110; the flagging
 runs in csrc/wb_flags.h, wb_flag_events) and ``track_events`` (:113-241; pairs, link test, components and labels run in
 csrc/wb_track.h, wb_track_events)."""
+import logging
+
 import numpy as np
 
 from wavebreaking_amd import engine
@@ -9,6 +11,8 @@ from wavebreaking_amd.engine import _time_key
 from wavebreaking_amd.utils.data_utils import check_argument_types, check_empty_dataframes, get_dimension_attributes
 
 _DA = _gf.data_array_types()
+
+logger = logging.getLogger(__name__)
 
 
 def _rings(geom):
@@ -205,6 +209,12 @@ def track_events(events, time_range=None, method="by_overlap", buffer=0, overlap
             raise NotImplementedError("track_events(method='by_overlap'): only buffer=0 is built (exact areas of grid "
                                       "polygons); buffered polygons need GEOS' arc approximation")
         label, _, stats = ctx.track_events(dates, method, time_range, overlap=overlap, rings_per_event=lattice_rings(events))
+        if stats["polygons_not_simple"]:
+            # the reference repairs such geometries with buffer(0).make_valid() before it intersects them (events.py:203-204):
+            # GEOS, not restated here -- their regions are taken by the even-odd rule and their labels may differ
+            logger.warning("track_events(method='by_overlap'): %d event polygons cross themselves; the reference repairs them with "
+                           "buffer(0).make_valid() (GEOS, not reproduced) -- the labels of these events may differ"
+                           % stats["polygons_not_simple"])
     events["label"] = label.astype(np.int64)                                 # events.py:224-238
     order = np.lexsort((key, label))                                         # events.py:241: stable, label then date
     out = events.iloc[order]

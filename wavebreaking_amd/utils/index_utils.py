@@ -21,84 +21,23 @@ def properties_from_sums(sums, lon, lat, nlon):
     return com, np.round(sums[:, 1] / areas, 2), np.round(sums[:, 2] / areas, 2), np.round(areas, 2)
 
 
-def _clip_halfplane(ring, L, keep_le):
-    """Pieces of a closed ring on one side of the vertical line x = L (see transform_polygons)."""
-    v = np.asarray(ring, dtype=np.float64)
-    n = len(v)
-    ins = (v[:, 0] <= L) if keep_le else (v[:, 0] >= L)
-    if ins.all():
-        return [v]
-    if not ins.any():
-        return []
-    s = int(np.argmin(ins))
-    chains, cur = [], None
-    for k in range(n):
-        ia, ib = (s + k) % n, (s + k + 1) % n
-        a, b = v[ia], v[ib]
-        if not ins[ia] and ins[ib]:
-            t = (L - a[0]) / (b[0] - a[0])
-            cur = [np.array([L, a[1] + t * (b[1] - a[1])]), b.copy()]
-        elif ins[ia] and ins[ib]:
-            cur.append(b.copy())
-        elif ins[ia] and not ins[ib]:
-            t = (L - a[0]) / (b[0] - a[0])
-            cur.append(np.array([L, a[1] + t * (b[1] - a[1])]))
-            chains.append(cur)
-            cur = None
-    pts = []
-    for ci, ch in enumerate(chains):
-        pts.append((ch[0][1], 0, ci))
-        pts.append((ch[-1][1], 1, ci))
-    pts.sort(key=lambda q: (q[0], q[1]))
-    partner = {}
-    for k in range(0, len(pts) - 1, 2):
-        partner[(pts[k][1], pts[k][2])] = (pts[k + 1][1], pts[k + 1][2])
-        partner[(pts[k + 1][1], pts[k + 1][2])] = (pts[k][1], pts[k][2])
-    used = [False] * len(chains)
-    pieces = []
-    for c0 in range(len(chains)):
-        if used[c0]:
-            continue
-        piece, c, guard = [], c0, 0
-        while not used[c] and guard <= len(chains):
-            used[c] = True
-            piece.extend(chains[c])
-            c = partner.get((1, c), (0, c))[1]
-            guard += 1
-        piece = np.asarray(piece)
-        x, y = piece[:, 0], piece[:, 1]
-        if len(piece) >= 3 and abs(np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y)) > 0:
-            pieces.append(piece)
-    return pieces
-
-
-def split_index_polygon(polygon, nlon):
-    """index_utils.py:148-166: the index polygon without the strip nlon - 1 < x < nlon, as float rings in index coordinates"""
-    coords = np.asarray(polygon).astype("int")
-    return _clip_halfplane(coords, nlon - 1, True) + _clip_halfplane(coords, nlon, False)
-
-
-def transform_polygon_rings(polygon, lon, lat, nlon):
+def transform_polygon_rings(polygon, lon, lat, nlon, index_space=False):
     """One event: index polygon -> list of (lon, lat) rings (index_utils.py:129-173).
 
-    A polygon reaching x >= nlon is split at the last meridian: the strip nlon-1 < x < nlon (between
-    lon[-1] and the repeated lon[0]) is removed and what lies right of it is shifted by -nlon.  The
-    reference does this with GEOS (linemerge / unary_union / polygonize / make_valid, :148-173); here it
-    is an exact vertical-line clip of the integer polygon (GEOS absent -> unpinned, areas compared)."""
-    coords = np.asarray(polygon).astype("int")
-
-    def to_lonlat(c):
-        c = np.asarray(c).astype("int")                                   # :135 truncation
-        return np.c_[np.asarray(lon)[c[:, 0] % nlon], np.asarray(lat)[c[:, 1]]]   # :139-146
-
-    if not (coords[:, 0] >= nlon).any():                                   # :136
-        return [to_lonlat(coords)]
-    return [to_lonlat(p) for p in split_index_polygon(coords, nlon)]
+    A polygon reaching x >= nlon is split at the last meridian: the strip nlon-1 < x < nlon (between lon[-1] and the repeated
+    lon[0]) is removed and what lies right of it is shifted by -nlon.  The reference does this with GEOS (linemerge /
+    unary_union / polygonize / make_valid, :148-173); here it is the library's exact vertical-line clip of the integer
+    polygon (csrc/wb_geometry.h behind ``wb_transform_polygons`` -- the code the index functions' frames come from; GEOS
+    absent -> unpinned, checked against an exact-rational splitter in tests/test_seam_split.py)."""
+    from wavebreaking_amd import engine
+    return engine.get_context().transform_polygons([polygon], lon, lat, nlon, index_space)[0]
 
 
 def transform_polygons(polygons, lon, lat, nlon):
     """index_utils.py:129-184: geometry objects for a list of index polygons."""
-    return [_gf.make_polygon(transform_polygon_rings(p, lon, lat, nlon)) for p in polygons]
+    from wavebreaking_amd import engine
+    rings = engine.get_context().transform_polygons(list(polygons), lon, lat, nlon)
+    return [_gf.make_polygon(r) for r in rings]
 
 
 def combine_shared(lst):
@@ -125,6 +64,7 @@ def combine_shared(lst):
     merged, slot = [], {}
     for g in groups:
         if not g:
+            merged.append([])                          # the reference emits an empty group for an empty list (:196-212)
             continue
         root = find(g[0])
         if root not in slot:
@@ -145,7 +85,8 @@ def _iterate_over(keyword, values_of):
         def wrapper(data, contour_levels, *args, **kwargs):
             import pandas as pd
             frames = []
-            for value in values_of(data, contour_levels, kwargs):
+            values, contour_levels = values_of(data, contour_levels, kwargs)
+            for value in values:
                 frames.append(func(data, contour_levels, *args, **dict(kwargs, **{keyword: value})))
             return pd.concat(frames).reset_index(drop=True)
 
@@ -155,13 +96,15 @@ def _iterate_over(keyword, values_of):
 
 
 def _levels_of(data, contour_levels, kwargs):
+    # a scalar becomes [scalar] and the wrapped function is handed the LIST, as the reference rebinds it (:246-256)
     try:
-        return list(contour_levels)
-    except TypeError:
-        return [contour_levels]
+        iter(contour_levels)
+    except Exception:
+        contour_levels = [contour_levels]
+    return contour_levels, contour_levels
 
 
-iterate_time_dimension = _iterate_over("step", lambda data, contour_levels, kwargs: data[kwargs["time_name"]])
+iterate_time_dimension = _iterate_over("step", lambda data, contour_levels, kwargs: (data[kwargs["time_name"]], contour_levels))
 iterate_time_dimension.__doc__ = "decorator: once per time step, kwargs['step'] set (index_utils.py:217-235)"
 iterate_contour_levels = _iterate_over("level", _levels_of)
 iterate_contour_levels.__doc__ = "decorator: once per contour level, kwargs['level'] set (index_utils.py:238-258)"
