@@ -100,6 +100,9 @@ def main():
         if os.environ.get("WB_BENCH_SCAN_GRID"):
             c.set_option("scan_grid_mult", int(os.environ["WB_BENCH_SCAN_GRID"]))
         c.set_option("keep_device", 1 if multi else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather
+        for kv in filter(None, os.environ.get("WB_BENCH_OPTS", "").split(",")):   # development: "name=value,..." context options (A/B runs)
+            name, _, val = kv.partition("=")
+            c.set_option(name.strip(), int(val))
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
     levels = [-2.0, 2.0]

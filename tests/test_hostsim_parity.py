@@ -285,3 +285,57 @@ def test_box_com_one_lane_walk():
 def test_polygon_that_crosses_itself_is_flagged(sim):
     lib, ctx = sim
     helpers.not_simple_polygon_case(ctx)
+
+
+def _streamer_tables(ctx, pv, lat, lon, **opts):
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    try:
+        got = helpers.run_abi(ctx, pv, lat, lon, [-2, 2], want_cells=False)
+    finally:
+        for k in opts:
+            ctx.set_option(k, 1)
+    return got
+
+
+def test_all_pairs_kernel_variants_agree(sim):
+    """wb_k_streamer_pairs2 (contour in LDS, sin^2 tables of the regular grid) and the tiled kernel with its per-point table
+    find the same streamers; a contour longer than the LDS holds takes the tiled kernel inside the same launch sequence."""
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(0)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(21, 3, lat, lon, eps=0.3)
+    a = _streamer_tables(ctx, pv, lat, lon, pairs_lds=1)
+    b = _streamer_tables(ctx, pv, lat, lon, pairs_lds=0)
+    assert a["streamers"]["step"].size > 5
+    for key in ("step", "level_idx", "contour", "ind1", "ind2", "poly_x", "poly_y", "ncells"):
+        assert np.array_equal(a["streamers"][key], b["streamers"][key]), key
+    assert np.array_equal(a["streamers"]["sums"], b["streamers"]["sums"])
+    assert a["band"] == (0, 0) and b["band"] == (0, 0)
+
+
+def test_all_pairs_tables_on_a_jittered_coordinate_axis(sim):
+    """coordinates off the regular grid by 1e-7 degrees (the reference's own check, data_utils.py:129-144, would not let
+    such an axis through -- the C ABI takes what it is given): the guard band of the table-driven great-circle term widens
+    by the deviation and the streamers stay those of the tiled kernel, which works from the coordinates as given"""
+    lib, ctx = sim
+    lat, lon = synth.grid(1.0)
+    rng = np.random.RandomState(3)
+    latj = lat + 1e-7 * rng.uniform(-1, 1, lat.size)
+    pv = synth.pv_field(22, 2, lat, lon, eps=0.2)
+
+    def run(flag):
+        ctx.set_option("pairs_lds", flag)
+        try:
+            b = ctx.contours(pv, latj, lon, [-2, 2], 1.0, 1.0)
+            b.indices()
+            ev = b.events(_hip.STREAMERS)
+            b.close()
+        finally:
+            ctx.set_option("pairs_lds", 1)
+        return ev
+
+    a, c = run(1), run(0)
+    assert a["step"].size > 3
+    for key in ("step", "level_idx", "ind1", "ind2", "poly_x", "poly_y"):
+        assert np.array_equal(a[key], c[key]), key

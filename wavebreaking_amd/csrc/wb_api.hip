@@ -51,9 +51,13 @@ struct wb_ctx {
     int scan_debug = 0;
     int scan_halo_lds = 1;                    // streaming scan: halo columns through LDS (0: scalar loads)
     int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
+    int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
+    int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
+    size_t p2_budget = 0;                     // dynamic LDS a workgroup of wb_k_streamer_pairs2 may use (found once)
+    int p2_budget_kb = 0, p2_split = 0;       // development: overrides of that budget / of the workgroups per contour
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
@@ -83,6 +87,13 @@ struct wb_ctx {
                                               // haversine evaluated with the HOST's math library (wb_k_streamer_prep)
         int dy_max = 0;
         double hthr = 0;
+        // wb_k_streamer_pairs2: sin^2 of the multiples of dlat / 2 and dlon / 2 (host math library), whether the grid is the
+        // regular global one the tables stand for, and the absolute guard band on h that covers what its coordinates
+        // deviate from lat[0] + j dlat / lon[0] + i dlon
+        double* sl_tab = nullptr;
+        double* sx_tab = nullptr;
+        bool p2_ok = false;
+        double geo_band = 0;
     };
     std::vector<Tables*> tables;
     WbCtl* h_ctl = nullptr;                   // pinned: where the control block of a batch lands (two snapshots)
@@ -662,7 +673,15 @@ static int run_phase1(wb_batch* b) {
         int ncu = 256;
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount; }
         if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
-        if (ctx->scan_split && nlat < 65536 && b->W <= 65536) {
+        // the streaming kernel keeps a patch buffer per strip (and the halo slots) in dynamic LDS and runs one wave per strip:
+        // fields whose strips do not fit the device's limits (float64 beyond 12 strips, any dtype beyond 16) take the
+        // single-kernel scan below
+        size_t lds_limit = 64 << 10;
+        int threads_limit = 1024;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { lds_limit = prop.sharedMemPerBlock; threads_limit = prop.maxThreadsPerBlock; } }
+        const size_t stream_lds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz) + (size_t)b->nwork_strips * 257 * (esz + 4) + 64;
+        const bool stream_fits = stream_lds <= lds_limit && 64 * b->nwork_strips <= threads_limit;
+        if (ctx->scan_split && nlat < 65536 && b->W <= 65536 && stream_fits) {
             // two kernels (wb_scan.h): the streaming kernel captures the patches that hold a crossing, the build
             // kernel turns them into the per-level segment lists
             const long long items = (long long)p.nt * b->nwork_strips;
@@ -699,6 +718,7 @@ static int run_phase1(wb_batch* b) {
             sa.halo_rows = (vec && p.dtype == 0 && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
             const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz)    // a patch buffer per wave
                                 + (size_t)b->nwork_strips * sa.halo_rows * (esz + 4);
+            sa.cursor = ctx->scan_dynamic ? &b->d_ctl->scan_cursor : nullptr;       // (the control block was zeroed above)
             long long mwg = slots * (ctx->scan_grid_mult > 0 ? ctx->scan_grid_mult : 1);
             if (mwg > (long long)p.nt * sa.nbands) mwg = (long long)p.nt * sa.nbands;
             const dim3 mgrid((unsigned)mwg), sblock(64 * b->nwork_strips), bgrid((unsigned)items);
@@ -724,6 +744,7 @@ static int run_phase1(wb_batch* b) {
 #undef WB_STREAM_F32
 #undef WB_STREAM_ANY
 #undef WB_SCAN_N
+            { const hipError_t le = hipGetLastError(); if (le != hipSuccess) return wb_fail(ctx, std::string("wb_k_scan_stream launch failed: ") + hipGetErrorString(le)); }
             b->timer.end(ctx);
             b->timer.begin(ctx, "scan_build");
 #define WB_BUILD_LAUNCH(T, N) hipLaunchKernelGGL((wb_k_scan_build<T, N>), bgrid, block, 0, ctx->stream, sa)
@@ -1211,6 +1232,33 @@ WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const l
     }
 }
 
+// dynamic LDS for a workgroup of wb_k_streamer_pairs2: half a CU's LDS, so that two workgroups (16 waves) share a CU
+static size_t wb_p2_lds_budget(wb_ctx* ctx) {
+    if (ctx->p2_budget) return ctx->p2_budget;
+#if defined(WB_HOSTSIM)
+    ctx->p2_budget = (size_t)80 << 10;
+#else
+    size_t per_block = 64 << 10, per_cu = 64 << 10;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) {
+        per_block = prop.sharedMemPerBlock;
+        per_cu = prop.maxSharedMemoryPerMultiProcessor > per_block ? prop.maxSharedMemoryPerMultiProcessor : per_block;
+    }
+    size_t want = per_cu / 2;
+    if (ctx->p2_budget_kb > 0) want = (size_t)ctx->p2_budget_kb << 10;
+    if (want > per_block) {
+        // more than the default limit of a launch: ask for it (gfx950 has 160 KiB per CU)
+        if (hipFuncSetAttribute((const void*)wb_k_streamer_pairs2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = per_block;
+        }
+    }
+    if (wb_debug()) fprintf(stderr, "[wb] LDS per block %zu, per CU %zu, pairs2 budget %zu\n", per_block, per_cu, want);
+    ctx->p2_budget = want;
+#endif
+    return ctx->p2_budget;
+}
+
 static wb_ctx::Tables* make_tables(wb_batch* b) {
     wb_ctx* ctx = b->ctx;
     const wb_params& p = b->p;
@@ -1286,6 +1334,24 @@ static wb_ctx::Tables* make_tables(wb_batch* b) {
             if (lim < 120.0) dxl[y] = (int)lim;
         }
     }
+    {
+        const double dlatr = p.dlat * (M_PI / 180.0);
+        std::vector<double> sl((size_t)t->dy_max + 2), sx(WB_P2_MAXDX + 2);
+        for (size_t k = 0; k < sl.size(); ++k) { const double v = sin(0.5 * (double)k * dlatr); sl[k] = v * v; }
+        for (size_t k = 0; k < sx.size(); ++k) { const double v = sin(0.5 * (double)k * dlr); sx[k] = v * v; }
+        t->sl_tab = (double*)dmalloc(ctx, sl.size() * sizeof(double));
+        t->sx_tab = (double*)dmalloc(ctx, sx.size() * sizeof(double));
+        if (t->sl_tab && t->sx_tab) { h2d(ctx, t->sl_tab, sl.data(), sl.size() * sizeof(double)); h2d(ctx, t->sx_tab, sx.data(), sx.size() * sizeof(double)); }
+        double dev = 0.0;                                         // largest deviation of a coordinate from the regular grid, radians
+        for (int y = 0; y < p.nlat; ++y) dev = std::max(dev, fabs(b->lat[y] - (b->lat[0] + (double)y * p.dlat)) * (M_PI / 180.0));
+        for (int x = 0; x < p.nlon; ++x) dev = std::max(dev, fabs(b->lon[x] - (b->lon[0] + (double)x * p.dlon)) * (M_PI / 180.0));
+        // |dh / d(coordinate)| <= 1.5 and four coordinates enter a pair
+        t->geo_band = std::max(WB_GEO_BAND * t->hthr, 8.0 * dev);
+        // lon[x % nlon] continues the grid across the seam only when the grid closes on itself; a band wider than 1e-4 of the
+        // threshold would send many pairs to the exact evaluation: such grids stay with the tiled kernel
+        t->p2_ok = t->sl_tab && t->sx_tab && fabs((double)p.nlon * p.dlon - 360.0) <= 1e-9 && t->geo_band <= 1e-4 * t->hthr &&
+                   (size_t)p.nlat <= 8192;
+    }
     t->dxlim = (int*)dmalloc(ctx, p.nlat * sizeof(int));
     if (!t->base || !t->dxlim) { delete t; return nullptr; }
     h2d(ctx, t->base, all.data(), all.size() * sizeof(double));
@@ -1336,6 +1402,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
 
     WbCtl fin;
     memset(&fin, 0, sizeof(fin));
+    bool p2_off = false;
     int* h_ev = nullptr; double* h_sums = nullptr; int* h_nc = nullptr; int* h_fl = nullptr; long long* h_poff = nullptr; long long* h_coff = nullptr;
     uint32_t* h_cells = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -1420,7 +1487,29 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             int* d_lens = (int*)talloc((nsel_b + 1) * sizeof(int));
             st.on = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
             st.pre = (double*)talloc((size_t)(NPT + 1) * sizeof(double));
-            st.ptab = (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double));
+            // the all-pairs test: contours that fit the LDS of wb_k_streamer_pairs2 go there (regular global grids), longer
+            // ones -- and every contour of other grids -- through the tiled kernel and its per-point table
+            size_t p2_lds = 0;
+            st.sl_tab = T->sl_tab; st.sx_tab = T->sx_tab; st.geo_band = T->geo_band;
+            if (ctx->pairs_lds && T->p2_ok && !p2_off) {
+                const size_t budget = wb_p2_lds_budget(ctx);
+                int fit = 0;
+                while (wb_p2_lds_bytes(fit + 256, p.nlat, T->dy_max) <= budget) fit += 256;
+                int want = ((h1.max_len + 255) / 256) * 256;
+                if (want < 512) want = 512;
+                st.p2_cap = want < fit ? want : fit;
+                if (st.p2_cap > 0) p2_lds = wb_p2_lds_bytes(st.p2_cap, p.nlat, T->dy_max);
+                st.p2_split = ctx->p2_split > 0 ? ctx->p2_split : (nsel_b >= 1024 ? 1 : (nsel_b >= 256 ? 2 : (nsel_b >= 64 ? 4 : 8)));
+                if (wb_debug()) fprintf(stderr, "[wb] pairs2: longest contour %d, capacity %d points, %zu B of LDS, %d workgroups per contour\n", h1.max_len, st.p2_cap, p2_lds, st.p2_split);
+            }
+            if (st.p2_cap > 0) {
+                st.recheck_cap = 65536;
+                st.recheck = (int*)talloc((size_t)st.recheck_cap * 4 * sizeof(int));
+                if (!st.recheck) { release(); return 1; }
+            }
+            const bool need_tiled = st.p2_cap <= 0 || h1.max_len > st.p2_cap;
+            st.ptab = need_tiled ? (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double)) : nullptr;
+            if (need_tiled && !st.ptab) { release(); return 1; }
             st.bbx = (int*)talloc((size_t)((NPT >> 5) + nsel_b + 1) * 4 * sizeof(int));
             st.tbx = (int*)talloc((size_t)((NPT >> 4) + nsel_b + 1) * 4 * sizeof(int));
             st.npairs = (int*)talloc(nsel_b * sizeof(int));
@@ -1440,6 +1529,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.hkey = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
             st.hval = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
             if (!st.hval || !st.rowaux || !st.rowmx || !ev_ind || !st.bbx || !st.tbx || !d_lens || !st.item_tile) { release(); return 1; }
+            (void)p2_lds;
             b->timer.begin(ctx, "streamer_lists");
             WB_LAUNCH(wb_k_sel_scan, 1, 1024, st, d_lens);
             WB_LAUNCH(wb_k_pair_items, nsel_b, 64, st);
@@ -1448,7 +1538,16 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             WB_LAUNCH(wb_k_streamer_prep, nsel_b, 256, st);
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_pairs");
-            if (items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
+            if (st.p2_cap > 0) {
+#if defined(WB_HOSTSIM)
+                WB_LAUNCH(wb_k_streamer_pairs2, (long long)nsel_b * st.p2_split, WB_P2_THREADS, st);
+#else
+                hipLaunchKernelGGL(wb_k_streamer_pairs2, dim3((unsigned)((long long)nsel_b * st.p2_split)), dim3(WB_P2_THREADS), p2_lds, ctx->stream, st);
+                { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { release(); return wb_fail(ctx, std::string("wb_k_streamer_pairs2 launch failed: ") + hipGetErrorString(le)); } }
+#endif
+                WB_LAUNCH(wb_k_streamer_recheck, 64, 64, st);              // pairs inside a guard band (normally none)
+            }
+            if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_streamer_f1, nsel_b, 256, st);
@@ -1527,6 +1626,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const WbCtl s1 = hc[0];
         bool again = false;
         if (do_st && s1.max_pairs > cap_pairs) { cap_pairs = next_pow2((long long)s1.max_pairs + s1.max_pairs / 8); again = true; }
+        if (do_st && s1.n_recheck > 65536) { p2_off = true; again = true; }    // more guard-band pairs than the recheck list holds: tiled kernel
         if (s1.overflow & 1) { cap_ne = next_pow2((long long)s1.ne_demand + s1.ne_demand / 4); again = true; }
         if (s1.overflow & 2) { cap_poly = s1.poly_total + s1.poly_total / 8 + 1024; again = true; }
         if (again) {
@@ -1910,6 +2010,10 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     if (!strcmp(name, "scan_grid_mult")) { ctx->scan_grid_mult = value; return 0; }
+    if (!strcmp(name, "scan_dynamic")) { ctx->scan_dynamic = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "pairs_lds")) { ctx->pairs_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "p2_budget_kb")) { ctx->p2_budget_kb = value; ctx->p2_budget = 0; return 0; }
+    if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;

@@ -83,7 +83,9 @@ struct WbCtl {
     long long npt_sel_max;       // points of the former / of the latter
     long long npt_closed;
     int pair_items_max;          // work items of the all-pairs kernel for the contours with nux == max_nux
-    int pad0;
+    int scan_cursor;             // streaming scan: the next (time step, band) work item (a workgroup takes one when it is free)
+    int max_len;                 // longest contour of the batch, in points
+    int pad1;
     // phase 2 (wb_indices)
     int nsel, ncut;              // selected contours / cutoff contours
     long long npt_sel;
@@ -101,6 +103,8 @@ struct WbCtl {
     unsigned long long cell_count;
     int props_cursor;            // next event of the property kernel's work queue
     int group_ties;              // check_groups: groups whose maximum length was shared by several members (exact ties)
+    int n_recheck;               // pairs wb_k_streamer_pairs2 left to wb_k_streamer_recheck (inside a guard band)
+    int pad2;
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.

@@ -259,6 +259,14 @@ struct WbStreamerArgs {
     int eager;                 // 1: the survivors were laid out by wb_k_streamer_f34, 0: by wb_k_streamer_f234
     int* ev_n;                 // [nsel]
     uint32_t* status;          // [njobs]
+    // wb_k_streamer_pairs2 (wb_pairs.h): the all-pairs test with the contour in LDS, regular grids
+    const double* sl_tab;      // [dy_max + 1] sin^2(k dlat / 2), host math library
+    const double* sx_tab;      // [121]        sin^2(k dlon / 2)
+    double geo_band;           // ABSOLUTE guard band on h around hthr (WB_GEO_BAND * hthr, widened by the grid's irregularity)
+    int p2_cap;                // contour points its LDS holds; 0: kernel not used (every contour in the tiled kernel's list)
+    int p2_split;              // workgroups per contour
+    int* recheck;              // [recheck_cap][4] pairs inside a guard band: contour, i, j, 0 (wb_k_streamer_recheck decides them)
+    int recheck_cap;
 };
 
 // sklearn's haversine on radians, float64 (streamer_index.py:130): 2 asin(sqrt(sin^2 + cos cos sin^2))
@@ -306,11 +314,13 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
             }
         }
         on[i] = d;
-        tab[0 * a.npts_total + i] = a.sphi2[y1];
-        tab[1 * a.npts_total + i] = a.cphi2[y1];
-        tab[2 * a.npts_total + i] = a.cphi[y1];
-        tab[3 * a.npts_total + i] = a.slam2[x1];
-        tab[4 * a.npts_total + i] = a.clam2[x1];
+        if (a.ptab) {                                         // per-point table of the tiled all-pairs kernel (absent when every
+            tab[0 * a.npts_total + i] = a.sphi2[y1];          // contour goes through wb_k_streamer_pairs2)
+            tab[1 * a.npts_total + i] = a.cphi2[y1];
+            tab[2 * a.npts_total + i] = a.cphi[y1];
+            tab[3 * a.npts_total + i] = a.slam2[x1];
+            tab[4 * a.npts_total + i] = a.clam2[x1];
+        }
     WB_END_PFOR
     int* tbx = a.tbx + 4 * ((po >> 4) + s);
     WB_PFOR(tl, (N + 15) / 16)
@@ -1319,7 +1329,7 @@ WB_KERNEL(wb_k_sel_scan, WbStreamerArgs a, int* tmp) {
         tmp[s] = len;
         wb_atomic_add(&pp[0], (unsigned long long)((long long)len * (len - 1) / 2));   // base-point pairs the all-pairs test covers
         const int tiles = (len - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
-        a.item_off[s] = (tiles + WB_PAIR_TPB - 1) / WB_PAIR_TPB;
+        a.item_off[s] = len <= a.p2_cap ? 0 : (tiles + WB_PAIR_TPB - 1) / WB_PAIR_TPB;   // (short enough for wb_k_streamer_pairs2: no items)
     WB_END_PFOR
     const int npt = wb_block_scan_excl(tmp, nsel);
     const int nit = wb_block_scan_excl(a.item_off, nsel);
@@ -1355,3 +1365,5 @@ WB_KERNEL(wb_k_f2_items, WbStreamerArgs a) {
     a.ctl->n_f2_items = n;
     WB_END_SINGLE
 }
+
+#include "wb_pairs.h"

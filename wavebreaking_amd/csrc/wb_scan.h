@@ -62,6 +62,8 @@ struct WbScanArgs {
     const void* spare_row;  // streaming scan: nlon values that every workgroup reads instead of rows past its band's end (always cached)
     int halo_rows;          // streaming scan: > 0 = the strips of a workgroup hand each other the halo column through LDS
                             // (band_rows + 1 slots per strip); 0 = every strip loads its halo itself (a scalar load)
+    int* cursor;            // streaming scan: next (time step, band) work item, zero at launch (WbCtl::scan_cursor); NULL = items
+                            // dealt out by workgroup number
 };
 
 // a segment is stored as its key + the four corner values of its square; the crossing coordinates

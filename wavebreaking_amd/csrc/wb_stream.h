@@ -110,7 +110,18 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     }
 
     const int nitems = a.nt * a.nbands;
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) { // persistent: a workgroup strides over (time step, row band) items
+    // persistent: a workgroup takes the next (time step, row band) item when it is free.  Dealing the items out by workgroup
+    // number (it += gridDim.x) assumes every workgroup is resident from the start: with another batch's kernels on the
+    // device some are not, start late, and their whole share sets the launch's duration.
+    __shared__ int wb_item;
+    int it = blockIdx.x;
+    for (uint32_t mine = 1;; ++mine) {                        // mine: items this workgroup has taken (the halo tags are built from it)
+        if (a.cursor) {
+            if (s == 0 && lane == 0) wb_item = atomicAdd(a.cursor, 1);
+            __syncthreads();
+            it = __builtin_amdgcn_readfirstlane(wb_item);
+        } else if (mine > 1) it += gridDim.x;
+        if (it >= nitems) break;
         const int t = it / a.nbands, band = it - t * a.nbands;
         const int rb0 = band * a.band_rows;                   // squares of rows rb0 .. rb1 - 1: field rows rb0 .. rb1
         const int rb1 = rb0 + a.band_rows < nlat - 1 ? rb0 + a.band_rows : nlat - 1;
@@ -152,7 +163,9 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
             if (!HL) hh = ((CT)row)[chs];
         };
         // slots of this item, indexed by the row number itself; the tag of a row is (work item, row)
-        const uint32_t tagbase = (((uint32_t)(it + 1) & 0xFFFFu) << 16) - (uint32_t)rb0 + 1u;
+        // (the item number of THIS workgroup, not the global one: two items 65536 apart would share their tags, and a
+        // workgroup could take both back to back on a grid that is a multiple of 65536; a slot is rewritten by every item)
+        const uint32_t tagbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((mine & 0xFFFFu) << 16) - (uint32_t)rb0 + 1u));
         const LdsT pubv = hval + (s * HR - rb0);
         const LdsU pubt = htag + (s * HR - rb0);
         const LdsT srcv = hval + ((hsrc < 0 ? 0 : hsrc) * HR - rb0);
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
 #pragma unroll
             for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
         }
-        if (HL) __syncthreads();                              // nobody overwrites a halo slot a slower strip still waits for
+        if (HL || a.cursor) __syncthreads();                  // nobody overwrites a halo slot a slower strip still waits for (nor wb_item)
     }
 }
 #endif

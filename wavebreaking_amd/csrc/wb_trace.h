@@ -866,11 +866,13 @@ WB_KERNEL(wb_k_phase1_summary, WbSummaryArgs a) {
     const int mx = a.ctl->max_nux;
     WB_PFOR(t, WB_NT)
         unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+        int longest = 0;
         for (int job = WB_BLOCK_ID * WB_NT + (int)t; job < a.njobs; job += WB_GRID_DIM * WB_NT) {
             const size_t jb = (size_t)job * a.cap_seg;
             const int C = a.ncont[job];
             for (int k = 0; k < C; ++k) {
                 const int len = a.c_len[jb + k];
+                longest = len > longest ? len : longest;
                 v[0] += 1; v[1] += (unsigned long long)len;
                 if (a.c_nux[jb + k] == mx) {
                     const int tiles = (len - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
@@ -880,9 +882,11 @@ WB_KERNEL(wb_k_phase1_summary, WbSummaryArgs a) {
             }
         }
         for (int k = 0; k < 7; ++k) if (v[k]) wb_atomic_add(&acc[k], v[k]);
+        if (longest) wb_atomic_max(&acc[7], (unsigned long long)longest);
     WB_END_PFOR
     WB_SINGLE
     if (acc[0]) {
+        wb_atomic_max(&a.ctl->max_len, (int)acc[7]);
         wb_atomic_add(&a.ctl->ncont_total, (int)acc[0]);
         wb_atomic_add((unsigned long long*)&a.ctl->npts_total, acc[1]);
         if (acc[2]) {
