@@ -116,6 +116,25 @@ def main():
         d_int = ctx.alloc(fbytes)
         ctx.synth_fill(d_int, np.float32, t0, nt, lat, lon, synth.wave_params(20241), a.eps, 20241)
 
+    # the two exchanges of an N > 1 run: on RCCL inside the library (wb_comm_*, the unique id travels through the process
+    # group the launcher made) -- or, WB_BENCH_GATHER=torch / a dry run over gloo / a library without RCCL, through
+    # torch.distributed (wavebreaking_amd.distributed.gather_device_tables)
+    libcomm, gather_path = None, "none"
+    if multi:
+        gather_path = "torch.distributed"
+        if os.environ.get("WB_BENCH_GATHER", "library") == "library" and dist.get_backend() == "nccl":
+            try:
+                libcomm = wd.LibraryComm(ctx, dist)
+                gather_path = "library (wb_comm_gather_tables: ncclAllGather of the counts + grouped ncclSend / ncclRecv)"
+            except Exception as e:                      # every rank fails alike (no librccl): all take the torch path
+                print("[bench] wb_comm_init failed (%s); exchanges through torch.distributed" % e, file=sys.stderr, flush=True)
+                libcomm = None
+            ok = torch.tensor([1 if libcomm is not None else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # one rank without it: nobody uses it
+            if int(ok.item()) == 0 and libcomm is not None:
+                libcomm.close()
+                libcomm, gather_path = None, "torch.distributed"
+
     def barrier():
         if multi:
             dist.barrier()
@@ -135,7 +154,9 @@ def main():
         return b
 
     def reduce_max(m):
-        return wd.global_max_nux(m, dist if multi else None)                # exchange (1): one int32 all-reduce(max)
+        if libcomm is not None:
+            return libcomm.max_nux(m)                                        # exchange (1): one int32 all-reduce(max)
+        return wd.global_max_nux(m, dist if multi else None)
 
     def phase2(c, k, b, g, copy=False):
         w1 = time.perf_counter()
@@ -164,7 +185,10 @@ def main():
             w = time.perf_counter()
             if multi:
                 # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there)
-                cat = wd.gather_device_tables(res["batch"], dist, dst=0, as_rows=True)   # (rows, poly_x, poly_y) on rank 0's host
+                if libcomm is not None:
+                    cat = libcomm.gather(res["batch"], dst=0)
+                else:
+                    cat = wd.gather_device_tables(res["batch"], dist, dst=0, as_rows=True)   # (rows, poly_x, poly_y) on rank 0's host
                 pipe.close_batch(k, res["batch"])          # a context is single-threaded: its own worker frees the batch
                 res["batch"] = None
                 if keep and cat is not None:
@@ -224,7 +248,7 @@ def main():
                              counts.get("polygon_vertices", 0)], dtype=torch.int64, device=cdev)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         seen, ev_sum, vert_sum = (int(v) for v in mine.cpu().tolist())
-        verify = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen_by_allreduce": seen,
+        verify = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "gather_path": gather_path, "ranks_seen_by_allreduce": seen,
                   "events_sum_over_ranks": ev_sum, "polygon_vertices_sum_over_ranks": vert_sum}
         if rank == 0:
             if seen != world or dist.get_world_size() != world:
@@ -275,6 +299,8 @@ def main():
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass)
+    if libcomm is not None:
+        libcomm.close()
     pipe.close()
     if multi:
         dist.barrier()
@@ -308,36 +334,80 @@ def pmc_traffic(nt):
 
 def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     """What a drop-in user pays (reported alongside, never `value`): a HOST-resident float32 cube handed to the
-    reference-shaped functions, README style -- wb.calculate_streamers / overturnings / cutoffs called one after the other,
-    each tracing its own contours -- from the numpy array to the finished frames with geometry: upload over PCIe
-    (double-buffered, pinned staging), kernels, tables, lon / lat polygons and frame construction included."""
+    reference-shaped functions, README style -- wb.calculate_streamers / overturnings / cutoffs called one after the other
+    on the same cube -- from the numpy array to the finished frames with geometry: upload over PCIe (double-buffered,
+    pinned staging), kernels, tables, lon / lat polygons and frame construction included.  `value`: the three calls from a
+    COLD input cache (the first call uploads cube + intensity and traces the contours; the package keeps both on the
+    device, so the other two do neither -- wavebreaking_amd/engine.py).  `no_cache`: every call uploads and traces
+    (WB_INPUT_CACHE=0, what round 2 measured).  `contours_reuse`: the reference's own way of sharing work,
+    calculate_contours once and `contours=` handed to the three calls."""
     import wavebreaking_amd as wb
+    from wavebreaking_amd import engine
     from wavebreaking_amd import synthetic as synth
     nlat, nlon = lat.size, lon.size
     pv = ctx.to_host(d_pv, (nt, nlat, nlon), np.float32)
     inten = ctx.to_host(d_int, (nt, nlat, nlon), np.float32) if d_int else None
     tm = synth.times(nt)
     coords = {"time": tm, "lat": wb.gridfield.Coord(lat, {"units": "degrees_north"}), "lon": wb.gridfield.Coord(lon, {"units": "degrees_east"})}
-    data = wb.GridField(pv, ("time", "lat", "lon"), coords, name="PV")
-    idata = wb.GridField(inten, data.dims, coords, name="intensity") if inten is not None else None
+
+    def fields(a, b):
+        return (wb.GridField(a, ("time", "lat", "lon"), coords, name="PV"),
+                wb.GridField(b, ("time", "lat", "lon"), coords, name="intensity") if b is not None else None)
+
+    data, idata = fields(pv, inten)
     tic = time.perf_counter()
     p = ctx.to_device(pv)                                     # the upload alone, for reference
     t_up = time.perf_counter() - tic
     ctx.free(p)
     calls = (("calculate_streamers", wb.calculate_streamers), ("calculate_overturnings", wb.calculate_overturnings),
              ("calculate_cutoffs", wb.calculate_cutoffs))
-    secs, rows = {}, {}
-    for rep in range(2):                                      # the second round is reported (contexts and tables warm)
+
+    def three(d, i, **kw):
+        secs, rows = {}, {}
         for name, f in calls:
             tic = time.perf_counter()
-            frame = f(data=data, contour_levels=levels, intensity=idata)
+            frame = f(data=d, contour_levels=levels, intensity=i, **kw)
             secs[name] = time.perf_counter() - tic
             rows[name] = int(len(frame))
+        return secs, rows
+
+    # warm-up on COPIES of the cubes (the package's context, per-grid tables, pinned buffers), then everything released:
+    # the measured calls start from a cold input cache
+    # (the copies stay alive until the end: giving 3 GB of host memory back to the system makes the kernel driver's MMU
+    # notifier evict and restore the process's GPU queues -- a ~100 ms stall in whichever call comes next)
+    warm = fields(pv.copy(), inten.copy() if inten is not None else None)
+    three(*warm)
+    wb.release_inputs()
+    runs = []
+    for rep in range(2):                                      # twice from a cold cache; the faster one is reported, both listed
+        runs.append(three(data, idata))
+        if rep == 0:
+            wb.release_inputs()
+    secs, rows = min(runs, key=lambda r: sum(r[0].values()))
     total = sum(secs.values())
-    return {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
-            "upload_GBps": pv.nbytes / t_up / 1e9,
-            "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, H2D included"
-                    % (nt, pv.nbytes / 1e9)}
+    out = {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
+           "upload_GBps": pv.nbytes / t_up / 1e9, "both_runs_s": [sum(r[0].values()) for r in runs],
+           "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, cold input "
+                   "cache at the first call, H2D included" % (nt, pv.nbytes / 1e9)}
+    # the reference's own sharing: contours once, handed to the three calls (cubes already resident from the calls above)
+    tic = time.perf_counter()
+    cont = wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False)
+    t_cont = time.perf_counter() - tic
+    secs_c, rows_c = three(data, idata, contours=cont)
+    out["contours_reuse"] = {"value": nt / (t_cont + sum(secs_c.values())), "unit": "timesteps/s", "calculate_contours_s": t_cont,
+                             "contour_rows": int(len(cont)), "seconds": secs_c, "rows_match": rows_c == rows,
+                             "what": "calculate_contours(original_coordinates=False) + the three calls with contours=frame"}
+    # every call uploads and traces for itself
+    wb.release_inputs()
+    engine.INPUT_CACHE = False
+    try:
+        three(data, idata)
+        secs_n, _ = three(data, idata)
+    finally:
+        engine.INPUT_CACHE = True
+    out["no_cache"] = {"value": nt / sum(secs_n.values()), "unit": "timesteps/s", "seconds": secs_n}
+    del warm
+    return out
 
 
 def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):

@@ -98,7 +98,10 @@ typedef struct wb_event_table {
 #define WB_STATUS_HASH_FULL 8u
 #define WB_STATUS_OVERFLOW_PAIRS 16u
 #define WB_STATUS_LEVEL_ORDER 32u  /* ... and two contour ends compete for one vertex: skimage's sequential assembly is order dependent
-                                      there (it may raise KeyError); this job's contours are NOT the reference's */
+                                      there; the job's pieces are then joined by a literal restatement of that walk ... */
+#define WB_STATUS_LEVEL_KEYERROR 64u /* ... which found the dictionary entry skimage pops missing: find_contours raises KeyError on
+                                      this field (contour_index.py:103), and so must the caller -- the job has no contours */
+#define WB_STATUS_LEVEL_WALKED 128u  /* ... or finished: the contours are those of the sequential walk */
 
 int wb_create(int device_id, wb_ctx** ctx);
 void wb_destroy(wb_ctx* ctx);
@@ -118,6 +121,10 @@ int wb_batch_from_contours(wb_ctx* ctx, const wb_params* p, int64_t n, const int
 /* index parameters of an existing batch (its contours do not depend on them); NaN keeps the current value */
 int wb_set_index_params(wb_batch* b, double geo_dis, double cont_dis, double range_group, double ot_min_exp,
                         double co_min_exp);
+/* intensity cube of an existing batch whose field lives on the device (on_device = 1): a device pointer of the field's shape
+   and dtype, or NULL -- a batch's contours do not depend on it, so the next wb_indices of a kept batch can serve another
+   `intensity=` (index_utils.py:77-89) */
+int wb_set_intensity(wb_batch* b, const void* dev_intensity);
 int wb_batch_max_nux(wb_batch* b);                  /* local max of len(set(x)); all-reduce(max) it across ranks */
 /* phase 2: indices.  global_max_nux plays contours.exp_lon.max() (streamer_index.py:106);
    which = bit mask 1 streamers | 2 overturnings | 4 cutoffs */
@@ -175,6 +182,24 @@ int wb_set_step_offset(wb_batch* b, int64_t first_step);
 int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[3], const int32_t** poly_x, const int32_t** poly_y,
                          int64_t* nverts);
 void wb_free_batch(wb_batch* b);
+
+/* ---- the two exchanges of a time-sharded run (one process per GPU), on RCCL inside the library -------------------------
+   The reference is single-process; its selection `contours.exp_lon.max()` (streamer_index.py:106, overturning_index.py:105,
+   cutoff_index.py:90) runs over the whole frame, so ranks that each hold a block of time steps need (1) the maximum over
+   all ranks and (2) the event tables on one rank.  wb_comm_unique_id: 128 bytes made on ONE rank, handed to all by the
+   launcher; wb_comm_init: every rank, collectively.  wb_comm_allreduce_max: *value <- max over the ranks.
+   wb_comm_gather_tables: what wb_indices left on the device (context option "keep_device") of every rank's batch (NULL: a
+   rank without time steps) arrives on rank dst -- counts by one ncclAllGather, payload by grouped ncclSend / ncclRecv of the
+   exact sizes -- in rank (= time) order: rows[nrows][WB_ROW_WIDTH], poly_x / poly_y[nverts], pinned host memory of the
+   context, valid until its next call; the other ranks get nrows = nverts = 0.  ranks_seen (may be NULL) <- the number of
+   ranks whose counts arrived.  librccl is looked up at run time; without it wb_comm_init fails and nothing else changes. */
+#define WB_COMM_ID_BYTES 128
+int wb_comm_unique_id(wb_ctx* ctx, void* id /* [WB_COMM_ID_BYTES] */);
+int wb_comm_init(wb_ctx* ctx, const void* id, int rank, int world);
+int wb_comm_allreduce_max(wb_ctx* ctx, int* value);
+int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
+                          const int32_t** poly_y, int64_t* nverts, int* ranks_seen);
+void wb_comm_destroy(wb_ctx* ctx);
 
 /* device memory + synthetic ERA5-shaped PV for the benchmark */
 void* wb_dev_alloc(wb_ctx* ctx, uint64_t bytes);

@@ -7,6 +7,7 @@ Run in the build container (the two interpreters hold different libraries):
 
     /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py skimage   # scikit-image 0.18.3
     /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py levelhit  # scikit-image 0.18.3, cells equal to the level
+    /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py levelwalk # scikit-image 0.18.3, order-dependent joins / KeyError
     python3 tests/golden/make_golden.py sklearn                             # scikit-learn 1.7.2
     python3 tests/golden/make_golden.py pandas                              # pandas 2.3.3
     python3 tests/golden/make_golden.py props                               # pandas 2.3.3 (groupby sums of calculate_properties)
@@ -186,6 +187,67 @@ def levelhit_fields():
         out["random%02d" % k] = (a, 0.0)
         k += 1
     return out
+
+
+def levelwalk_field(seed):
+    """the generator of tools/levelwalk_hunt.py:field (numpy's legacy RandomState: the same stream in every numpy)"""
+    rng = np.random.RandomState(seed)
+    shape = (int(rng.randint(6, 26)), int(rng.randint(6, 34)))
+    a = rng.standard_normal(shape)
+    for _ in range(int(rng.randint(0, 3))):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1)) / 5.0
+    a = (a / a.std()).astype(np.float32).astype(np.float64)
+    hi = a > 0.0
+    m = np.zeros_like(hi)
+    m[:-1] |= hi[:-1] != hi[1:]
+    m[1:] |= hi[:-1] != hi[1:]
+    m[:, :-1] |= hi[:, :-1] != hi[:, 1:]
+    m[:, 1:] |= hi[:, :-1] != hi[:, 1:]
+    c = np.argwhere(m)
+    for _ in range(int(rng.randint(2, 14))):
+        if len(c) == 0:
+            break
+        j, i = c[rng.randint(len(c))]
+        a[j, i] = 0.0
+        if rng.rand() < 0.5:
+            a[min(max(j + rng.randint(-1, 2), 0), shape[0] - 1), min(max(i + rng.randint(-1, 2), 0), shape[1] - 1)] = 0.0
+    if rng.rand() < 0.15:
+        a[rng.randint(shape[0]), rng.randint(shape[1])] = np.nan
+    return a
+
+
+def make_levelwalk():
+    """scikit-image's own find_contours on the fields of tests/golden/levelwalk_seeds.txt: the seeds (of 0 .. 1499) on which two
+    contour ends compete for a grid vertex -- the order-dependent joins (48) and the KeyError cases (6) that
+    tools/levelwalk_hunt.py found with the library's sequential walk and the oracle's restatement agreeing."""
+    from skimage.measure import find_contours
+    import skimage
+
+    store = {"skimage_version": np.array(skimage.__version__)}
+    seeds, kinds = [], []
+    for line in open(os.path.join(HERE, "levelwalk_seeds.txt")):
+        seed, kind = line.split()
+        a = levelwalk_field(int(seed))
+        name = "s%04d" % int(seed)
+        store[name + "__field"] = a.astype(np.float32)
+        store[name + "__level"] = np.array(0.0)
+        try:
+            cont = find_contours(a, 0.0)
+            cat, off = _pack([np.asarray(c) for c in cont])
+            store[name + "__raises"] = np.array(0)
+        except KeyError:
+            cat, off = np.zeros((0, 2)), np.zeros(1, dtype=np.int64)
+            store[name + "__raises"] = np.array(1)
+        assert (kind == "keyerror") == bool(store[name + "__raises"]), (seed, kind)
+        store[name + "__pts"] = cat
+        store[name + "__off"] = off
+        seeds.append(int(seed))
+        kinds.append(kind)
+    store["seeds"] = np.array(seeds)
+    store["kinds"] = np.array(kinds)
+    store["names"] = np.array(["s%04d" % q for q in seeds])
+    np.savez_compressed(os.path.join(HERE, "contours_levelwalk.npz"), **store)
+    print("levelwalk goldens written:", len(seeds), "fields,", kinds.count("keyerror"), "KeyError")
 
 
 def make_levelhit():
@@ -441,4 +503,4 @@ def make_track():
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else ""
     {"skimage": make_skimage, "sklearn": make_sklearn, "pandas": make_pandas, "props": make_props,
-     "levelhit": make_levelhit, "track": make_track}[which]()
+     "levelhit": make_levelhit, "levelwalk": make_levelwalk, "track": make_track}[which]()

@@ -211,13 +211,14 @@ def symmetric_cutoff_case(ctx, dlon=1.0, nsteps=2):
     return got, ref, rechecks, nnear
 
 
-def level_hit_goldens_case(ctx, golden_dir):
+def level_hit_goldens_case(ctx, golden_dir, fname="contours_levelhit.npz"):
     """Every field of tests/golden/contours_levelhit.npz (cells equal to the level; scikit-image's own outputs) through the
     ABI as a one-step batch without periodic columns: the contour table equals contour_index.py:103-156 applied to
-    skimage's contours, or the job carries STATUS_LEVEL_ORDER where two contour ends compete for a vertex (which
-    includes every field on which skimage raises KeyError).  Returns (fields equal, fields flagged)."""
+    skimage's contours -- also where two contour ends compete for a vertex (STATUS_LEVEL_ORDER: the job is then joined by
+    the sequential walk, STATUS_LEVEL_WALKED) -- or the job carries STATUS_LEVEL_KEYERROR exactly on the fields on which
+    skimage raises KeyError.  Returns (fields equal to skimage, fields flagged)."""
     from oracle import marching
-    g = np.load(os.path.join(golden_dir, "contours_levelhit.npz"))
+    g = np.load(os.path.join(golden_dir, fname))
     nequal = nflag = 0
     for name in g["names"]:
         a, lv = g[name + "__field"].astype(np.float64), float(g[name + "__level"])
@@ -228,10 +229,15 @@ def level_hit_goldens_case(ctx, golden_dir):
         b.close()
         overwritten = marching.find_contours_vertex_machine(a, lv)[1]
         assert bool(st & _hip.STATUS_LEVEL_ORDER) == (overwritten > 0), (name, st, overwritten)
-        if int(g[name + "__raises"]) or overwritten:
-            assert st & _hip.STATUS_LEVEL_ORDER, name
+        if int(g[name + "__raises"]):
+            # scikit-image raises KeyError on this field: the sequential walk of the flagged job finds the same missing entry
+            assert st & _hip.STATUS_LEVEL_ORDER and st & _hip.STATUS_LEVEL_KEYERROR, (name, st)
             nflag += 1
             continue
+        assert not (st & _hip.STATUS_LEVEL_KEYERROR), (name, st)
+        if overwritten:
+            assert st & _hip.STATUS_LEVEL_WALKED, (name, st)
+            nflag += 1
         off, pts = g[name + "__off"], g[name + "__pts"]
         raw = [pts[off[i]:off[i + 1]] for i in range(len(off) - 1)]            # scikit-image's contours themselves
         items, closed = [], []

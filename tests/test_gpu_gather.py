@@ -43,6 +43,21 @@ for rep in range(2):                                    # second call: the pinne
         assert np.array_equal(e["sums"], w["sums"])
 cat = wd.gather_device_tables(b, dist, dst=0)
 assert [e["step"].size for e in cat] == [w["step"].size for w in want]
+# the same gather INSIDE the library: wb_comm_init with the unique id carried by the process group, counts by ncclAllGather,
+# payload by grouped send / recv (one rank: the device-to-device copy of its own part), pinned buffers reused
+comm = wd.LibraryComm(ctx, dist)
+assert comm.max_nux(b.max_nux()) == b.max_nux() and comm.max_nux(7) == 7
+for rep in range(2):
+    rows, px, py = comm.gather(b, dst=0)
+    assert rows.shape == (sum(e["step"].size for e in want), 20) and int(rows[:, 18].sum()) == px.size == py.size
+    got = wd.rows_to_events(rows, px, py)
+    for e, w in zip(got, want):
+        for key in ("level_idx", "ind1", "ind2", "box", "orientation", "ncells", "flags", "poly_offset", "poly_x", "poly_y"):
+            assert np.array_equal(e[key], w[key]), key
+        assert np.array_equal(e["sums"], w["sums"]) and np.array_equal(e["step"], w["step"] + 100)
+rows, px, py = comm.gather(None, dst=0)                # a rank without time steps
+assert rows.shape == (0, 20) and px.size == 0
+comm.close()
 b.close()
 dist.barrier()
 dist.destroy_process_group()
@@ -54,6 +69,8 @@ print("GATHER_OK")
 def test_device_gather_over_rccl_single_rank(tmp_path):
     script = tmp_path / "worker_gather.py"
     script.write_text(WORKER)
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's
+    # peer-to-peer set-up fails with `hipIpcGetMemHandle: invalid argument` (the image exports it; bench.py sets it too)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)

@@ -209,6 +209,13 @@ def test_cells_equal_to_the_level_golden_fields(ctx, golden_dir):
     assert nequal >= 35 and nflag >= 4
 
 
+def test_order_dependent_joins_golden_fields(ctx, golden_dir):
+    """two contour ends on one grid vertex: the flagged job is joined by the sequential walk (wb_k_trace_walk) and equals
+    scikit-image on the 48 fields it returns contours on; STATUS_LEVEL_KEYERROR on the 6 it raises KeyError on"""
+    nequal, nflag = helpers.level_hit_goldens_case(ctx, golden_dir, "contours_levelwalk.npz")
+    assert nequal == 48 and nflag == 54
+
+
 @pytest.mark.parametrize("seed,dlon", [(0, 1.0), (1, 1.0), (2, 1.0), (3, 1.0), (4, 0.25)])
 def test_cells_equal_to_the_level_full_path(ctx, seed, dlon):
     pv, lat, lon = helpers.level_hit_field(seed, dlon=dlon, nhits=4 if dlon == 1.0 else 12)

@@ -258,6 +258,14 @@ def test_cells_equal_to_the_level_golden_fields(sim, golden_dir):
     assert nequal >= 35 and nflag >= 4
 
 
+def test_order_dependent_joins_golden_fields(sim, golden_dir):
+    """two contour ends on one grid vertex: the flagged job is joined by the sequential walk (wb_k_trace_walk) and equals
+    scikit-image on the 48 fields it returns contours on; STATUS_LEVEL_KEYERROR on the 6 it raises KeyError on"""
+    lib, ctx = sim
+    nequal, nflag = helpers.level_hit_goldens_case(ctx, golden_dir, "contours_levelwalk.npz")
+    assert nequal == 48 and nflag == 54
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_cells_equal_to_the_level_full_path(sim, seed):
     """contours AND events of a field with level hits equal the oracle's, whose find_contours follows skimage's

@@ -282,3 +282,27 @@ def test_lattice_rasterisation_interior_vs_matplotlib():
             assert np.array_equal(got.ravel(), want), trial
         checked += 1
     assert checked >= 60
+
+
+def test_order_dependent_joins_vs_skimage(golden_dir):
+    """the constellations in which two contour ends compete for one grid vertex (found by tools/levelwalk_hunt.py among 1 500
+    random rough fields, scikit-image's own outputs in contours_levelwalk.npz): the oracle's restatement of the sequential
+    walk returns skimage's contours on the 48 it returns on and raises KeyError on the 6 it raises on; the vertex state
+    machine sees an overwritten end on every one of them"""
+    g = np.load(golden_dir + "/contours_levelwalk.npz")
+    nraise = nwalk = 0
+    for name in g["names"]:
+        a, lv = g[name + "__field"].astype(np.float64), float(g[name + "__level"])
+        assert marching.find_contours_vertex_machine(a, lv)[1] > 0, name
+        if int(g[name + "__raises"]):
+            with pytest.raises(KeyError):
+                marching.find_contours(a, lv)
+            nraise += 1
+            continue
+        cont = marching.find_contours(a, lv)
+        off, pts = g[name + "__off"], g[name + "__pts"]
+        assert len(cont) == len(off) - 1, name
+        for i, c in enumerate(cont):
+            assert np.array_equal(c, pts[off[i]:off[i + 1]]), (name, i)
+        nwalk += 1
+    assert nraise == 6 and nwalk == 48

@@ -358,7 +358,8 @@ def test_index_parameters_reach_a_reused_contour_batch(hostsim_engine):
 
 def test_status_words_reach_the_caller(hostsim_engine, golden_dir, monkeypatch):
     """A frame that may differ from the reference's is never handed out silently: cells equal to the level are
-    followed exactly (skimage's coordinate joins) unless two contour ends compete for a vertex -> ValueError; truncated
+    followed exactly (skimage's coordinate joins, the order-dependent ones by the sequential walk); where skimage raises KeyError so
+    does the call; truncated
     tables -> RuntimeError; guard-band hits -> warning."""
     # (a) level hits that the vertex rule resolves: same frame as the oracle, no error
     pv, lat, lon = helpers.level_hit_field(2)
@@ -376,10 +377,24 @@ def test_status_words_reach_the_caller(hostsim_engine, golden_dir, monkeypatch):
     a = g[name + "__field"].astype(np.float64)
     f = wb.GridField(a[None], ("time", "lat", "lon"), {"time": tm, "lat": np.arange(a.shape[0], dtype=float),
                                                          "lon": np.arange(a.shape[1], dtype=float)})
-    with pytest.raises(ValueError, match="order-dependent"):
+    with pytest.raises(KeyError, match="raises KeyError"):                 # what the reference's call does on this field
         wb.calculate_contours(f, float(g[name + "__level"]), periodic_add=0, original_coordinates=False)
-    with pytest.raises(ValueError, match="order-dependent"):
+    with pytest.raises(KeyError, match="raises KeyError"):
         wb.calculate_cutoffs(f, float(g[name + "__level"]), periodic_add=0)
+    # (b') two contour ends on one vertex where skimage RETURNS contours (order-dependent join): the frame is the oracle's
+    g2 = np.load(golden_dir + "/contours_levelwalk.npz")
+    nwalked = 0
+    for name in [n for n in g2["names"] if not int(g2[n + "__raises"])][:12]:
+        a = g2[name + "__field"].astype(np.float64)
+        la, lo = np.arange(a.shape[0], dtype=float), np.arange(a.shape[1], dtype=float)
+        f = wb.GridField(a[None], ("time", "lat", "lon"), {"time": tm, "lat": la, "lon": lo})
+        c = wb.calculate_contours(f, 0.0, periodic_add=0, original_coordinates=False)
+        want = oapi.calculate_contours(a[None], [0.0], la, lo, tm, periodic_add=0, original_coordinates=False)
+        assert len(c) == len(want), name
+        for (_, row), r in zip(c.iterrows(), want):
+            assert np.array_equal(np.asarray(row.geometry.coords), r["geometry"]) and row.closed == r["closed"], name
+        nwalked += 1
+    assert nwalked == 12
     # (c) truncated event lists are an error, not a shorter frame
     class _B:
         nlev = 1
@@ -413,3 +428,45 @@ def test_guard_band_hits_are_reported(caplog):
     with caplog.at_level(logging.WARNING):
         engine.check_batch(_B(), "indices")
     assert "guard band" in caplog.text
+
+
+def test_inputs_and_contour_batches_stay_on_the_device_between_calls(hostsim_engine, monkeypatch):
+    """the second and third index call on the same cube skip the upload and the tracing (engine.resident_input, the kept
+    batches); a cube modified in place is uploaded again; release_inputs() gives everything back"""
+    data, pv, lat, lon, tm = _field()
+    inten_np = synth.pv_field(0, 3, lat, lon, eps=0.0, seed=20241)
+    inten = wb.GridField(inten_np, data.dims, data.coords)
+    ctx = engine.get_context()
+    uploads, traced = [], []
+    real_up, real_contours = ctx.to_device, ctx.contours
+    monkeypatch.setattr(ctx, "to_device", lambda a: (uploads.append(a.shape), real_up(a))[1])
+    monkeypatch.setattr(ctx, "contours", lambda *a, **k: (traced.append(1), real_contours(*a, **k))[1])
+    s1 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    assert len(uploads) == 2 and len(traced) == 1
+    o1 = wb.calculate_overturnings(data=data, contour_levels=[2], intensity=inten)
+    c1 = wb.calculate_cutoffs(data=data, contour_levels=[2])                    # no intensity this time: column of zeros / NaN as without it
+    s2 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten, geo_dis=700)
+    assert len(uploads) == 2 and len(traced) == 1                               # nothing uploaded or traced again
+    assert len(s1) > 0 and len(o1) > 0 and len(c1) > 0 and len(s2) != 0
+    # the same calls with the cache off give the same frames
+    monkeypatch.setattr(engine, "INPUT_CACHE", False)
+    s1n = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    c1n = wb.calculate_cutoffs(data=data, contour_levels=[2])
+    s2n = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten, geo_dis=700)
+    monkeypatch.setattr(engine, "INPUT_CACHE", True)
+    for a, b in ((s1, s1n), (c1, c1n), (s2, s2n)):
+        assert len(a) == len(b)
+        for col in ("date", "level", "com", "mean_var", "event_area"):
+            assert list(a[col]) == list(b[col]), col
+        assert [np.asarray(g.geoms[0].exterior.coords).tolist() for g in a["geometry"]] == \
+               [np.asarray(g.geoms[0].exterior.coords).tolist() for g in b["geometry"]]
+    assert np.allclose(list(s1["intensity"]), list(s1n["intensity"]), equal_nan=True)
+    # an in-place change of the cube is seen (sampled fingerprint): uploaded and traced again
+    n_up, n_tr = len(uploads), len(traced)
+    data.values[:] = np.roll(data.values, 30, axis=2)                            # the whole pattern 30 columns further east, in place
+    s3 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    assert len(uploads) == n_up + 1 and len(traced) == n_tr + 1
+    assert list(s3["com"]) != list(s1["com"])
+    wb.release_inputs()
+    resident, kept = engine._caches(ctx)
+    assert not resident and not kept

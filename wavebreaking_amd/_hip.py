@@ -56,6 +56,7 @@ STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
 EVENT_NOT_SIMPLE = 1
 ROW_WIDTH = 20
 STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS, STATUS_LEVEL_ORDER = 1, 2, 4, 8, 16, 32
+STATUS_LEVEL_KEYERROR, STATUS_LEVEL_WALKED = 64, 128
 
 
 def _arr(ptr, n, dtype, copy=True):
@@ -88,6 +89,7 @@ class Library:
         lib.wb_batch_from_contours.argtypes = [C.c_void_p, C.POINTER(WbParams), C.c_int64, i32p, i32p, i32p, i64p, i32p,
                                                i32p, i32p, C.POINTER(C.c_void_p)]
         lib.wb_batch_max_nux.argtypes = [C.c_void_p]
+        lib.wb_set_intensity.argtypes = [C.c_void_p, C.c_void_p]
         lib.wb_set_index_params.argtypes = [C.c_void_p] + [C.c_double] * 5
         lib.wb_indices.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
@@ -126,6 +128,14 @@ class Library:
                                         i64p, i32p, i32p, i32p, dp, C.POINTER(C.c_uint64)]
         lib.wb_track_overlaps.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, i32p, i32p, C.c_int64, i64p, i64p, dp, dp]
         lib.wb_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.wb_comm_unique_id.argtypes = [C.c_void_p, C.c_void_p]
+        lib.wb_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.wb_comm_allreduce_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.wb_comm_gather_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64),
+                                             C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int)]
+        lib.wb_comm_destroy.argtypes = [C.c_void_p]
+        lib.wb_comm_destroy.restype = None
         lib.wb_last_op_ms.argtypes = [C.c_void_p]
         lib.wb_last_op_ms.restype = C.c_float
 
@@ -390,6 +400,41 @@ class Context:
     def last_op_ms(self):
         return float(self.L.lib.wb_last_op_ms(self.h))
 
+    # -- time-sharded runs: the two exchanges on RCCL inside the library (wb_comm_*)
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        if self.L.lib.wb_comm_unique_id(self.h, buf) != 0:
+            raise RuntimeError("wb_comm_unique_id failed: " + self.error())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        assert len(unique_id) == self.COMM_ID_BYTES
+        if self.L.lib.wb_comm_init(self.h, C.c_char_p(bytes(unique_id)), int(rank), int(world)) != 0:
+            raise RuntimeError("wb_comm_init failed: " + self.error())
+
+    def comm_allreduce_max(self, value):
+        v = C.c_int(int(value))
+        if self.L.lib.wb_comm_allreduce_max(self.h, C.byref(v)) != 0:
+            raise RuntimeError("wb_comm_allreduce_max failed: " + self.error())
+        return int(v.value)
+
+    def comm_gather_tables(self, batch, dst=0):
+        """-> (rows (n, 20) float64, poly_x, poly_y, ranks seen): views of the context's pinned buffers on rank ``dst`` (valid
+        until the next call), empty arrays elsewhere; ``batch`` may be None on a rank without time steps"""
+        rows, px, py = C.POINTER(C.c_double)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        n, nv, seen = C.c_int64(), C.c_int64(), C.c_int()
+        if self.L.lib.wb_comm_gather_tables(self.h, batch.h if batch is not None else None, int(dst), C.byref(rows), C.byref(n),
+                                            C.byref(px), C.byref(py), C.byref(nv), C.byref(seen)) != 0:
+            raise RuntimeError("wb_comm_gather_tables failed: " + self.error())
+        r = _arr(rows, n.value * ROW_WIDTH, np.float64, copy=False).reshape(-1, ROW_WIDTH)
+        return r, _arr(px, nv.value, np.int32, copy=False), _arr(py, nv.value, np.int32, copy=False), int(seen.value)
+
+    def comm_destroy(self):
+        if self.h:
+            self.L.lib.wb_comm_destroy(self.h)
+
     def transform_polygons(self, polygons, lon, lat, nlon, index_space=False):
         """wb_transform_polygons: index-lattice polygons (list of (n, 2) integer arrays) -> per polygon the list of its rings
         ((m, 2) float64 arrays) in (lon, lat) -- or, with ``index_space``, in index coordinates as they are cut at the seam"""
@@ -515,6 +560,12 @@ class Batch:
         """Parameters of the indices for a batch whose contours exist already (None keeps the current value)."""
         v = [float('nan') if x is None else float(x) for x in (geo_dis, cont_dis, range_group, ot_min_exp, co_min_exp)]
         self.ctx.L.lib.wb_set_index_params(self.h, *v)
+
+    def set_intensity(self, dev_ptr):
+        """intensity cube (device pointer, the field's shape and dtype, or None) for the next indices() of a batch whose
+        field is device-resident"""
+        if self.ctx.L.lib.wb_set_intensity(self.h, C.c_void_p(int(dev_ptr)) if dev_ptr else None) != 0:
+            raise RuntimeError("wb_set_intensity failed: " + self.ctx.error())
 
     def indices(self, global_max_nux=None, streamers=True, overturnings=True, cutoffs=True):
         g = self.max_nux() if global_max_nux is None else int(global_max_nux)

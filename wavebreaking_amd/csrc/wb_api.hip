@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "wb_comm.h"
 #include "wb_core.h"
 #include "wb_geometry.h"
 #include "wb_indices.h"
@@ -98,6 +99,9 @@ struct wb_ctx {
     std::vector<Tables*> tables;
     WbCtl* h_ctl = nullptr;                   // pinned: where the control block of a batch lands (two snapshots)
     WbRingSink geo;                           // result of the last wb_transform_polygons
+#if !defined(WB_HOSTSIM)
+    WbComm* comm = nullptr;                   // RCCL communicator of a time-sharded run (wb_comm_init)
+#endif
 };
 
 #include <chrono>
@@ -222,19 +226,31 @@ static void* wb_pin(wb_ctx* c, size_t bytes) {
 // Host -> device copy of a large pageable buffer: chunks go through TWO pinned staging buffers, the host memcpy of chunk
 // k + 1 (split over a few threads: one core copies ~10 GB/s, PCIe Gen5 takes ~55) overlapping the DMA of chunk k.
 #define WB_H2D_CHUNK ((size_t)64 << 20)
-#define WB_H2D_THREADS 4
+#define WB_H2D_THREADS 8
+static int wb_h2d_threads() {
+    // one core copies ~10 GB/s into the staging buffer, the link takes ~55: eight copiers where the host has the cores
+    // (WB_H2D_THREADS overrides)
+    static int n = 0;
+    if (!n) {
+        const char* e = getenv("WB_H2D_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        n = v < 1 ? 1 : (v > WB_H2D_THREADS ? WB_H2D_THREADS : v);
+    }
+    return n;
+}
 static void wb_par_memcpy(char* dst, const char* src, size_t n) {
-    if (n < ((size_t)8 << 20)) { memcpy(dst, src, n); return; }
+    const int nth = wb_h2d_threads();
+    if (n < ((size_t)8 << 20) || nth == 1) { memcpy(dst, src, n); return; }
     std::thread th[WB_H2D_THREADS - 1];
-    const size_t part = (n / WB_H2D_THREADS + 4095) & ~(size_t)4095;
-    for (int t = 1; t < WB_H2D_THREADS; ++t) {
+    const size_t part = (n / nth + 4095) & ~(size_t)4095;
+    for (int t = 1; t < nth; ++t) {
         const size_t o = (size_t)t * part;
         if (o >= n) break;
         const size_t m = n - o < part ? n - o : part;
         th[t - 1] = std::thread([=]() { memcpy(dst + o, src + o, m); });
     }
     memcpy(dst, src, part < n ? part : n);
-    for (int t = 1; t < WB_H2D_THREADS; ++t) if (th[t - 1].joinable()) th[t - 1].join();
+    for (int t = 1; t < nth; ++t) if (th[t - 1].joinable()) th[t - 1].join();
 }
 static int h2d(wb_ctx* c, void* d, const void* s, size_t b) {
     if (b > WB_PIN_THRESHOLD) {
@@ -529,6 +545,7 @@ int wb_create(int device_id, wb_ctx** out) {
 
 void wb_destroy(wb_ctx* c) {
     if (!c) return;
+    wb_comm_destroy(c);
     for (auto& kv : c->hpool) hrelease(kv.second);
     for (wb_ctx::Tables* t : c->tables) delete t;
     if (c->h_ctl) {
@@ -781,6 +798,7 @@ static int run_phase1(wb_batch* b) {
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_rank");
     WB_LAUNCH(wb_k_trace_rank, J, 1024, ta);
+    WB_LAUNCH(wb_k_trace_walk, J, 64, ta);            // jobs flagged WB_ST_LEVEL_ORDER only: skimage's sequential walk, one lane each
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_finish");
     WB_LAUNCH(wb_k_trace_finish, J, 1024, ta);
@@ -902,6 +920,13 @@ extern "C" int wb_set_index_params(wb_batch* b, double geo_dis, double cont_dis,
     if (range_group == range_group) b->p.range_group = range_group;
     if (ot_min_exp == ot_min_exp) b->p.ot_min_exp = ot_min_exp;
     if (co_min_exp == co_min_exp) b->p.co_min_exp = co_min_exp;
+    return 0;
+}
+
+extern "C" int wb_set_intensity(wb_batch* b, const void* dev_intensity) {
+    if (!b) return 1;
+    if (!b->p.on_device) return wb_fail(b->ctx, "wb_set_intensity: the batch owns host-side inputs (on_device = 0)");
+    b->d_intensity = dev_intensity;
     return 0;
 }
 
@@ -1523,7 +1548,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.ev_ind = ev_ind; st.ev_n = ev_n; st.status = b->status;
             st.cap_pairs = cap_pairs;
             st.hash_size = next_pow2(2LL * cap_pairs);
-            if (st.hash_size < next_pow2(4LL * cap)) st.hash_size = next_pow2(4LL * cap);
+            // (room for 4 words per point of the longest contour: a traced job's stride bounds it, a frame's job has its own)
+            { const long long lenb = std::max((long long)cap, (long long)h1.max_len / 2 + 1);
+              if (st.hash_size < next_pow2(4LL * lenb)) st.hash_size = next_pow2(4LL * lenb); }
             st.pairs = (unsigned long long*)talloc((size_t)nsel_b * cap_pairs * 8);
             st.alive = (int*)talloc((size_t)nsel_b * cap_pairs * sizeof(int));
             st.hkey = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
@@ -1818,8 +1845,12 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
     b->W = W; b->padd = padd;
     const int J = (int)n;
     b->njobs = J;
-    const int cap = next_pow2((maxn + 1) / 2 < 4 ? 4 : (maxn + 1) / 2);
+    // one job per contour row (events come back in frame-row order).  A job's slot stride is kept minimal: its one contour
+    // lives in a packed point array behind the slots, addressed through c_off (the kernels add c_off to the job's base
+    // whatever its value) -- a stride of the longest contour cost 150 MB of zero-filled uploads for a year's frame
+    const int cap = 4;
     b->cap_seg = cap;
+    (void)maxn;
     const size_t esz = p.dtype == 0 ? 4 : 8;
     const size_t fbytes = (size_t)p.nt * p.nlat * p.nlon * esz;
     if (p.on_device) {
@@ -1839,7 +1870,11 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
             b->d_intensity = di;
         }
     }
-    std::vector<uint32_t> h_pts((size_t)J * 2 * cap, 0);
+    long long np_total = 0;
+    for (int j = 0; j < J; ++j) np_total += npts[j];
+    if ((long long)J * 2 * cap + np_total >= 0x7FFFFFFFLL) return wb_fail(ctx, "contour frame too large");
+    std::vector<uint32_t> h_pts((size_t)J * 2 * cap + (size_t)np_total, 0);
+    long long ppos = (long long)J * 2 * cap;
     std::vector<int> h_off((size_t)J * cap, 0), h_len((size_t)J * cap, 0), h_cl((size_t)J * cap, 0), h_nux((size_t)J * cap, 0),
         h_sy((size_t)J * cap, 0), h_nc(J, 1);
     std::vector<char> seen(W);
@@ -1852,10 +1887,12 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
         long long sy = 0;
         for (int i = 0; i < npts[j]; ++i) {
             const int xx = x[offset[j] + i], yy = y[offset[j] + i];
-            h_pts[(size_t)j * 2 * cap + i] = (uint32_t)xx | ((uint32_t)yy << 16);
+            h_pts[(size_t)ppos + i] = (uint32_t)xx | ((uint32_t)yy << 16);
             if (!seen[xx]) { seen[xx] = 1; ++nux; }
             sy += yy;
         }
+        h_off[(size_t)j * cap] = (int)(ppos - (long long)j * 2 * cap);       // relative to the job's base cpts + 2 * j * cap
+        ppos += npts[j];
         h_len[(size_t)j * cap] = npts[j];
         h_cl[(size_t)j * cap] = closed[j] ? 1 : 0;
         h_nux[(size_t)j * cap] = nux;
@@ -2419,6 +2456,170 @@ extern "C" int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_off
     wb_track_release(ctx, g);
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------------ RCCL exchanges
+#if defined(WB_HOSTSIM)
+extern "C" int wb_comm_unique_id(wb_ctx* ctx, void*) { return wb_fail(ctx, "the host simulation has no RCCL"); }
+extern "C" int wb_comm_init(wb_ctx* ctx, const void*, int, int) { return wb_fail(ctx, "the host simulation has no RCCL"); }
+extern "C" int wb_comm_allreduce_max(wb_ctx* ctx, int*) { return wb_fail(ctx, "the host simulation has no RCCL"); }
+extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch*, int, const double**, int64_t*, const int32_t**, const int32_t**, int64_t*, int*) {
+    return wb_fail(ctx, "the host simulation has no RCCL");
+}
+extern "C" void wb_comm_destroy(wb_ctx*) {}
+#else
+#define WB_NCCL(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) return wb_fail(ctx, std::string(#call) + ": " + cm.GetErrorString(r_)); } while (0)
+#define WB_HIPC(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return wb_fail(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" int wb_comm_unique_id(wb_ctx* ctx, void* id) {
+    if (!ctx || !id) return 1;
+    wb_use(ctx);
+    if (!ctx->comm) ctx->comm = new WbComm();
+    WbComm& cm = *ctx->comm;
+    const std::string e = wb_comm_load(cm);
+    if (!e.empty()) return wb_fail(ctx, "wb_comm_unique_id: " + e);
+    ncclUniqueId u;
+    WB_NCCL(cm.GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+extern "C" int wb_comm_init(wb_ctx* ctx, const void* id, int rank, int world) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return 1;
+    wb_use(ctx);
+    if (!ctx->comm) ctx->comm = new WbComm();
+    WbComm& cm = *ctx->comm;
+    if (cm.comm) return wb_fail(ctx, "wb_comm_init: the context has a communicator already");
+    const std::string e = wb_comm_load(cm);
+    if (!e.empty()) return wb_fail(ctx, "wb_comm_init: " + e);
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    WB_NCCL(cm.CommInitRank(&cm.comm, world, u, rank));
+    cm.rank = rank; cm.world = world;
+    WB_HIPC(hipStreamCreateWithFlags(&cm.stream, hipStreamNonBlocking));
+    WB_HIPC(hipMalloc((void**)&cm.d_counts, (size_t)(2 + 2 * world) * sizeof(long long)));
+    WB_HIPC(hipHostMalloc((void**)&cm.h_counts, (size_t)(2 * world + 2) * sizeof(long long), hipHostMallocDefault));
+    WB_HIPC(hipMalloc((void**)&cm.d_scalar, 2 * sizeof(int)));
+    WB_HIPC(hipHostMalloc((void**)&cm.h_scalar, 2 * sizeof(int), hipHostMallocDefault));
+    return 0;
+}
+
+extern "C" void wb_comm_destroy(wb_ctx* ctx) {
+    if (!ctx || !ctx->comm) return;
+    WbComm& cm = *ctx->comm;
+    (void)hipSetDevice(ctx->device);
+    if (cm.stream) (void)hipStreamSynchronize(cm.stream);
+    if (cm.comm && cm.CommDestroy) (void)cm.CommDestroy(cm.comm);
+    void* dev[] = {cm.d_counts, cm.d_scalar, cm.d_rows, cm.d_px, cm.d_py};
+    for (void* q : dev) if (q) (void)hipFree(q);
+    void* host[] = {cm.h_counts, cm.h_scalar, cm.h_rows, cm.h_px, cm.h_py};
+    for (void* q : host) if (q) (void)hipHostFree(q);
+    if (cm.stream) (void)hipStreamDestroy(cm.stream);
+    delete ctx->comm;                       // (the RCCL library stays loaded: it may be the host program's)
+    ctx->comm = nullptr;
+}
+
+extern "C" int wb_comm_allreduce_max(wb_ctx* ctx, int* value) {
+    if (!ctx || !value) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_allreduce_max: wb_comm_init first");
+    wb_use(ctx);
+    WbComm& cm = *ctx->comm;
+    cm.h_scalar[0] = *value;
+    WB_HIPC(hipMemcpyAsync(cm.d_scalar, cm.h_scalar, sizeof(int), hipMemcpyHostToDevice, cm.stream));
+    WB_NCCL(cm.AllReduce(cm.d_scalar, cm.d_scalar + 1, 1, ncclInt32, ncclMax, cm.comm, cm.stream));
+    WB_HIPC(hipMemcpyAsync(cm.h_scalar + 1, cm.d_scalar + 1, sizeof(int), hipMemcpyDeviceToHost, cm.stream));
+    WB_HIPC(hipStreamSynchronize(cm.stream));
+    *value = cm.h_scalar[1];
+    return 0;
+}
+
+extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
+                                     const int32_t** poly_y, int64_t* nverts, int* ranks_seen) {
+    if (!ctx || !rows || !nrows || !poly_x || !poly_y || !nverts) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_gather_tables: wb_comm_init first");
+    WbComm& cm = *ctx->comm;
+    if (dst < 0 || dst >= cm.world) return wb_fail(ctx, "wb_comm_gather_tables: bad destination rank");
+    if (b && !b->dev_rows) return wb_fail(ctx, "wb_comm_gather_tables: set the context option keep_device before wb_indices");
+    wb_use(ctx);
+    const int W = cm.world;
+    const long long ne = b ? b->dev_n[0] + b->dev_n[1] + b->dev_n[2] : 0, nv = b ? b->dev_nv : 0;
+    // (1) counts: one all-gather of (events, vertices)
+    cm.h_counts[2 * W] = ne; cm.h_counts[2 * W + 1] = nv;
+    WB_HIPC(hipMemcpyAsync(cm.d_counts, cm.h_counts + 2 * W, 2 * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
+    WB_NCCL(cm.AllGather(cm.d_counts, cm.d_counts + 2, 2, ncclInt64, cm.comm, cm.stream));
+    WB_HIPC(hipMemcpyAsync(cm.h_counts, cm.d_counts + 2, (size_t)2 * W * sizeof(long long), hipMemcpyDeviceToHost, cm.stream));
+    WB_HIPC(hipStreamSynchronize(cm.stream));
+    long long tot_e = 0, tot_v = 0;
+    int seen = 0;
+    for (int r = 0; r < W; ++r) { tot_e += cm.h_counts[2 * r]; tot_v += cm.h_counts[2 * r + 1]; seen += cm.h_counts[2 * r] >= 0 ? 1 : 0; }
+    if (ranks_seen) *ranks_seen = seen;
+    if (cm.h_counts[2 * cm.rank] != ne || cm.h_counts[2 * cm.rank + 1] != nv) return wb_fail(ctx, "wb_comm_gather_tables: the all-gather returned another count for this rank");
+    *rows = nullptr; *poly_x = *poly_y = nullptr; *nrows = 0; *nverts = 0;
+    if (cm.rank == dst) {
+        // room for the whole catalogue, on the device and in pinned host memory: grown when needed, kept between passes
+        if ((size_t)tot_e > cm.cap_rows) {
+            if (cm.d_rows) (void)hipFree(cm.d_rows);
+            cm.cap_rows = (size_t)tot_e + (size_t)tot_e / 4 + 1024;
+            WB_HIPC(hipMalloc((void**)&cm.d_rows, cm.cap_rows * WB_ROW_WIDTH * sizeof(double)));
+        }
+        if ((size_t)tot_v > cm.cap_v) {
+            if (cm.d_px) (void)hipFree(cm.d_px);
+            if (cm.d_py) (void)hipFree(cm.d_py);
+            cm.cap_v = (size_t)tot_v + (size_t)tot_v / 4 + 4096;
+            WB_HIPC(hipMalloc((void**)&cm.d_px, cm.cap_v * sizeof(int32_t)));
+            WB_HIPC(hipMalloc((void**)&cm.d_py, cm.cap_v * sizeof(int32_t)));
+        }
+        if ((size_t)tot_e > cm.hcap_rows) {
+            if (cm.h_rows) (void)hipHostFree(cm.h_rows);
+            cm.hcap_rows = (size_t)tot_e + (size_t)tot_e / 4 + 1024;
+            WB_HIPC(hipHostMalloc((void**)&cm.h_rows, cm.hcap_rows * WB_ROW_WIDTH * sizeof(double), hipHostMallocDefault));
+        }
+        if ((size_t)tot_v > cm.hcap_v) {
+            if (cm.h_px) (void)hipHostFree(cm.h_px);
+            if (cm.h_py) (void)hipHostFree(cm.h_py);
+            cm.hcap_v = (size_t)tot_v + (size_t)tot_v / 4 + 4096;
+            WB_HIPC(hipHostMalloc((void**)&cm.h_px, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
+            WB_HIPC(hipHostMalloc((void**)&cm.h_py, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
+        }
+    }
+    // (2) payload: exact sizes, rank order = time order
+    WB_NCCL(cm.GroupStart());
+    if (cm.rank == dst) {
+        long long oe = 0, ov = 0;
+        for (int r = 0; r < W; ++r) {
+            const long long ke = cm.h_counts[2 * r], kv = cm.h_counts[2 * r + 1];
+            if (r != dst) {
+                if (ke) WB_NCCL(cm.Recv(cm.d_rows + (size_t)oe * WB_ROW_WIDTH, (size_t)ke * WB_ROW_WIDTH, ncclDouble, r, cm.comm, cm.stream));
+                if (kv) { WB_NCCL(cm.Recv(cm.d_px + ov, (size_t)kv, ncclInt32, r, cm.comm, cm.stream)); WB_NCCL(cm.Recv(cm.d_py + ov, (size_t)kv, ncclInt32, r, cm.comm, cm.stream)); }
+            }
+            oe += ke; ov += kv;
+        }
+    } else {
+        if (ne) WB_NCCL(cm.Send(b->dev_rows, (size_t)ne * WB_ROW_WIDTH, ncclDouble, dst, cm.comm, cm.stream));
+        if (nv) { WB_NCCL(cm.Send(b->dev_px, (size_t)nv, ncclInt32, dst, cm.comm, cm.stream)); WB_NCCL(cm.Send(b->dev_py, (size_t)nv, ncclInt32, dst, cm.comm, cm.stream)); }
+    }
+    WB_NCCL(cm.GroupEnd());
+    if (cm.rank == dst) {
+        long long oe = 0, ov = 0;
+        for (int r = 0; r < dst; ++r) { oe += cm.h_counts[2 * r]; ov += cm.h_counts[2 * r + 1]; }
+        if (ne) WB_HIPC(hipMemcpyAsync(cm.d_rows + (size_t)oe * WB_ROW_WIDTH, b->dev_rows, (size_t)ne * WB_ROW_WIDTH * sizeof(double), hipMemcpyDeviceToDevice, cm.stream));
+        if (nv) {
+            WB_HIPC(hipMemcpyAsync(cm.d_px + ov, b->dev_px, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.stream));
+            WB_HIPC(hipMemcpyAsync(cm.d_py + ov, b->dev_py, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.stream));
+        }
+        // the one copy to the host
+        if (tot_e) WB_HIPC(hipMemcpyAsync(cm.h_rows, cm.d_rows, (size_t)tot_e * WB_ROW_WIDTH * sizeof(double), hipMemcpyDeviceToHost, cm.stream));
+        if (tot_v) {
+            WB_HIPC(hipMemcpyAsync(cm.h_px, cm.d_px, (size_t)tot_v * sizeof(int32_t), hipMemcpyDeviceToHost, cm.stream));
+            WB_HIPC(hipMemcpyAsync(cm.h_py, cm.d_py, (size_t)tot_v * sizeof(int32_t), hipMemcpyDeviceToHost, cm.stream));
+        }
+    }
+    WB_HIPC(hipStreamSynchronize(cm.stream));
+    if (cm.rank == dst) { *rows = cm.h_rows; *poly_x = cm.h_px; *poly_y = cm.h_py; *nrows = tot_e; *nverts = tot_v; }
+    return 0;
+}
+#undef WB_NCCL
+#undef WB_HIPC
+#endif
 
 #if defined(WB_HOSTSIM)
 extern "C" int wb_hostsim_group_order(const int* pp, const int* pq, int np, int cap, int* out) {

@@ -63,6 +63,7 @@ struct WbTraceArgs {
 #define WB_PT_VERTEX 0x8000u       // in a packed crossing point (x | y << 16): the crossing sits exactly on that grid vertex
 #define WB_PT_MASK 0xFFFF7FFFu
 #define WB_ST_LEVEL_ORDER 32u
+#define WB_ST_LEVEL_WALKED 128u      // ... and the job's pieces were joined by the sequential restatement of skimage's walk (wb_k_trace_walk)
 
 // does the crossing on `side` of a square sit on a grid vertex (one end of that edge equals the level)?
 WB_HD inline bool wb_side_on_vertex(int side, double ul, double ur, double ll, double lr, double level) {
@@ -461,6 +462,148 @@ WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
             if (segf[s] == segt[i]) t0[s] = 1;
         }
     WB_END_PFOR
+}
+
+// -------------------------------------------------------------------------------------------- 2b': the sequential walk
+// Jobs flagged WB_ST_LEVEL_ORDER by the link kernel: two contour ends competed for one dictionary key (cells equal to the
+// level), and what scikit-image returns there depends on the order its _assemble_contours (site-packages/skimage/measure/
+// _find_contours.py, 0.18.3; called at contour_index.py:103) takes the segments in -- or it raises KeyError.  For those
+// jobs only, ONE lane restates the walk literally (oracle/marching.py:join_by_coordinates): segments in raster order, two
+// dictionaries keyed by the exact coordinates of the pieces' first / last points -- a crossing's coordinate is identified
+// by its grid edge, or by the grid vertex it sits on --, a zero-length segment is skipped, the piece created first survives
+// a join.  A piece is a chain of segments, so the result is what the rank kernel writes: start segment and position of
+// every segment, closed flag of every chain.  ``last_at.pop(after[-1])`` / ``first_at.pop(before[0])`` on a key that is not
+// there is skimage's KeyError: the job gets WB_ST_LEVEL_KEYERROR and the Python layer raises it.
+#define WB_ST_LEVEL_KEYERROR 64u
+WB_DEV inline unsigned long long wb_walk_key(uint32_t segkey, int side, uint32_t pt, int W) {
+    if (pt & WB_PT_VERTEX) return (1ull << 62) | (unsigned long long)(pt & WB_PT_MASK);       // the grid vertex itself
+    const int sq = wb_key_sq(segkey), r = sq / W, c = sq - r * W;                              // the grid edge: H(r, c) even, V(r, c) odd
+    if (side == WB_TOP) return 2ull * (unsigned long long)(r * W + c);
+    if (side == WB_BOTTOM) return 2ull * (unsigned long long)((r + 1) * W + c);
+    if (side == WB_LEFT) return 2ull * (unsigned long long)(r * W + c) + 1ull;
+    return 2ull * (unsigned long long)(r * W + c + 1) + 1ull;
+}
+// dictionary: open addressing over (key << 1 | which); a popped entry keeps its key and holds WB_NIL
+WB_DEV inline uint32_t wb_walk_pop(unsigned long long* hk, uint32_t* hv, int hmask, unsigned long long key) {
+    uint32_t s = (uint32_t)wb_mix64(key) & (uint32_t)hmask;
+    for (int probe = 0; probe <= hmask; ++probe) {
+        if (hk[s] == key) { const uint32_t v = hv[s]; hv[s] = WB_NIL; return v; }
+        if (hk[s] == WB_HEMPTY) return WB_NIL;
+        s = (s + 1) & (uint32_t)hmask;
+    }
+    return WB_NIL;
+}
+WB_DEV inline void wb_walk_put(unsigned long long* hk, uint32_t* hv, int hmask, unsigned long long key, uint32_t val) {
+    uint32_t s = (uint32_t)wb_mix64(key) & (uint32_t)hmask;
+    for (int probe = 0; probe <= hmask; ++probe) {
+        if (hk[s] == key || hk[s] == WB_HEMPTY) { hk[s] = key; hv[s] = val; return; }
+        s = (s + 1) & (uint32_t)hmask;
+    }
+}
+WB_KERNEL(wb_k_trace_walk, WbTraceArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const int n = a.nseg[job];
+    if (n <= 0 || !(a.status[job] & WB_ST_LEVEL_ORDER)) return;
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* segk = a.mseg[0] + jb;
+    const uint32_t* segf = a.mseg[1] + jb;
+    const uint32_t* segt = a.mseg[2] + jb;
+    uint32_t* nxt = a.w[0] + jb;          // successor inside a piece (the link kernel's succ / pred are replaced)
+    uint32_t* prv = a.w[1] + jb;
+    uint32_t* p_first = a.w[2] + jb;      // per piece, by creation number
+    uint32_t* p_last = a.w[3] + jb;
+    uint32_t* p_alive = a.w[5] + jb;
+    uint32_t* start = a.w[4] + jb;
+    uint32_t* dist = a.w[6] + jb;
+    uint32_t* t0 = a.w[8] + jb;
+    unsigned long long* hk = a.hkey + (size_t)job * a.hash_size;
+    uint32_t* hv = a.hval + (size_t)job * a.hash_size;
+    int hsize = 1024;
+    while (hsize < 8 * n && hsize < a.hash_size) hsize <<= 1;
+    const int hmask = hsize - 1;
+    WB_PFOR(q, hsize)
+        hk[q] = WB_HEMPTY;
+        hv[q] = WB_NIL;
+    WB_END_PFOR
+    WB_PFOR(i, n)
+        nxt[i] = WB_NIL; prv[i] = WB_NIL; t0[i] = 0;
+    WB_END_PFOR
+    WB_SINGLE
+    uint32_t created = 0;
+    bool keyerror = false;
+    for (int i = 0; i < n && !keyerror; ++i) {
+        const uint32_t k = segk[i];
+        const int cs = wb_key_case(k), sub = wb_key_sub(k);
+        const unsigned long long f = wb_walk_key(k, wb_seg_from(cs, sub), segf[i], a.W), t = wb_walk_key(k, wb_seg_to(cs, sub), segt[i], a.W);
+        if (f == t) continue;                                               // from_point == to_point: skipped
+        const uint32_t after = wb_walk_pop(hk, hv, hmask, t << 1), before = wb_walk_pop(hk, hv, hmask, (f << 1) | 1ull);
+        if (before != WB_NIL && after != WB_NIL) {
+            // the segment goes behind `before` either way
+            const uint32_t bl = p_last[before];
+            nxt[bl] = (uint32_t)i; prv[i] = bl;
+            if (before == after) {                                          // the piece closes
+                p_last[before] = (uint32_t)i;
+            } else {
+                const uint32_t af = p_first[after], al = p_last[after], bf = p_first[before];
+                nxt[i] = af; prv[af] = (uint32_t)i;
+                const uint32_t alk = segk[al], bfk = segk[bf];
+                const unsigned long long a_end = wb_walk_key(alk, wb_seg_to(wb_key_case(alk), wb_key_sub(alk)), segt[al], a.W);
+                const unsigned long long b_beg = wb_walk_key(bfk, wb_seg_from(wb_key_case(bfk), wb_key_sub(bfk)), segf[bf], a.W);
+                if (after > before) {                                       // `after` was created second: before.extend(after)
+                    if (wb_walk_pop(hk, hv, hmask, (a_end << 1) | 1ull) == WB_NIL) { keyerror = true; break; }    // last_at.pop(after[-1])
+                    p_alive[after] = 0;
+                    p_last[before] = al;
+                    wb_walk_put(hk, hv, hmask, b_beg << 1, before);
+                    wb_walk_put(hk, hv, hmask, (a_end << 1) | 1ull, before);
+                } else {                                                    // after.extendleft(reversed(before))
+                    if (wb_walk_pop(hk, hv, hmask, b_beg << 1) == WB_NIL) { keyerror = true; break; }             // first_at.pop(before[0])
+                    p_alive[before] = 0;
+                    p_first[after] = bf;
+                    wb_walk_put(hk, hv, hmask, b_beg << 1, after);
+                    wb_walk_put(hk, hv, hmask, (a_end << 1) | 1ull, after);
+                }
+            }
+        } else if (before == WB_NIL && after == WB_NIL) {                   // a new piece
+            p_first[created] = (uint32_t)i; p_last[created] = (uint32_t)i; p_alive[created] = 1;
+            wb_walk_put(hk, hv, hmask, f << 1, created);
+            wb_walk_put(hk, hv, hmask, (t << 1) | 1ull, created);
+            ++created;
+        } else if (before == WB_NIL) {                                      // after.appendleft(from_point)
+            const uint32_t af = p_first[after];
+            nxt[i] = af; prv[af] = (uint32_t)i;
+            p_first[after] = (uint32_t)i;
+            wb_walk_put(hk, hv, hmask, f << 1, after);
+        } else {                                                            // before.append(to_point)
+            const uint32_t bl = p_last[before];
+            nxt[bl] = (uint32_t)i; prv[i] = bl;
+            p_last[before] = (uint32_t)i;
+            wb_walk_put(hk, hv, hmask, (t << 1) | 1ull, before);
+        }
+    }
+    if (keyerror) {
+        wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_KEYERROR);
+        // (start / dist keep the rank kernel's values: the job's contours are not handed out)
+    } else {
+        // skipped (zero-length) segments: chains of their own, as the rank kernel leaves them
+        for (int i = 0; i < n; ++i) { start[i] = (uint32_t)i; dist[i] = 1; }
+        for (uint32_t p = 0; p < created; ++p) {
+            if (!p_alive[p]) continue;
+            const uint32_t first = p_first[p], last = p_last[p];
+            uint32_t pos = 1;
+            for (uint32_t i = first;; i = nxt[i]) {
+                start[i] = first; dist[i] = pos++;
+                if (i == last) break;
+            }
+            // contour_index.py:109: closed = first and last float coordinates equal
+            const uint32_t fk = segk[first], lk = segk[last];
+            const unsigned long long f = wb_walk_key(fk, wb_seg_from(wb_key_case(fk), wb_key_sub(fk)), segf[first], a.W);
+            const unsigned long long t = wb_walk_key(lk, wb_seg_to(wb_key_case(lk), wb_key_sub(lk)), segt[last], a.W);
+            t0[first] = f == t ? 1 : 0;
+        }
+        wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_WALKED);
+    }
+    WB_END_SINGLE
 }
 
 // -------------------------------------------------------------------------------------------- 2c: finish

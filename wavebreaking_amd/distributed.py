@@ -266,6 +266,35 @@ def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
     return done(hr[:tot_e].numpy(), hx[:tot_v].numpy(), hy[:tot_v].numpy())
 
 
+# ------------------------------------------------------------------------------------------------ RCCL inside the library
+class LibraryComm:
+    """The two exchanges on RCCL INSIDE the library (wb_comm_init / wb_comm_allreduce_max / wb_comm_gather_tables,
+    include/wavebreaking_hip.h): the launcher's only part is to carry the 128 bytes of the unique id from rank 0 to the
+    others -- here through the torch.distributed group the ranks were started with (any backend; its store would do as
+    well).  ``max_nux`` is exchange (1), ``gather`` exchange (2): counts by one all-gather, payload by grouped send / recv
+    of the exact sizes into buffers that persist between passes, one copy into pinned host memory on ``dst``."""
+
+    def __init__(self, ctx, dist):
+        self.ctx, self.rank, self.world = ctx, dist.get_rank(), dist.get_world_size()
+        box = [ctx.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], self.rank, self.world)
+
+    def max_nux(self, local_max):
+        return self.ctx.comm_allreduce_max(local_max)
+
+    def gather(self, batch, dst=0):
+        """(rows, poly_x, poly_y) of the whole record on ``dst`` (views of pinned buffers, valid until the next call), None
+        elsewhere"""
+        rows, px, py, seen = self.ctx.comm_gather_tables(batch, dst)
+        if seen != self.world:
+            raise RuntimeError("wb_comm_gather_tables saw %d ranks, the group has %d" % (seen, self.world))
+        return (rows, px, py) if self.rank == dst else None
+
+    def close(self):
+        self.ctx.comm_destroy()
+
+
 # ------------------------------------------------------------------------------------------------ whole calls
 def _time_block(data, time_name, first, count):
     """``data`` restricted to time steps [first, first + count)."""

@@ -128,11 +128,23 @@ class LineString:
 
 
 class _Ring:
+    """a polygon ring; the closed coordinate sequence shapely would hold is built when somebody asks for it (an index
+    call makes thousands of these and most frames are only filtered or written out)"""
+    __slots__ = ("_raw", "_seq")
+
     def __init__(self, coords):
-        a = np.asarray(coords, dtype=np.float64).reshape(-1, 2)
-        if len(a) and not np.array_equal(a[0], a[-1]):
-            a = np.concatenate([a, a[:1]], axis=0)     # shapely closes rings
-        self.coords = _CoordSeq(a)
+        self._raw = coords
+        self._seq = None
+
+    @property
+    def coords(self):
+        if self._seq is None:
+            a = np.asarray(self._raw, dtype=np.float64).reshape(-1, 2)
+            if len(a) and not (a[0, 0] == a[-1, 0] and a[0, 1] == a[-1, 1]):
+                a = np.concatenate([a, a[:1]], axis=0)     # shapely closes rings
+            self._seq = _CoordSeq(a)
+            self._raw = None
+        return self._seq
 
 
 def _shoelace(a):

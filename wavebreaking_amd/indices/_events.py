@@ -83,8 +83,16 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
         several = nbatches > 1
     else:
         table, levels = engine.frame_to_table(contours, prep.times, engine.as_levels(contour_levels))
-        b = ctx.batch_from_contours(table, prep.values, prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
-                                    prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=prep.intensity, **params)
+        if engine._cacheable(prep.values) and (prep.intensity is None or (engine._cacheable(prep.intensity) and prep.intensity.dtype == prep.values.dtype)):
+            # the cubes stay on the device between calls (engine.resident_input): a frame handed in costs no upload either
+            fe = engine.resident_input(ctx, prep.values)
+            ie = engine.resident_input(ctx, prep.intensity) if prep.intensity is not None else None
+            b = ctx.batch_from_contours(table, fe["ptr"], prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
+                                        prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=ie["ptr"] if ie is not None else None,
+                                        device_shape=prep.values.shape, device_dtype=prep.values.dtype, **params)
+        else:
+            b = ctx.batch_from_contours(table, prep.values, prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
+                                        prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=prep.intensity, **params)
         g = b.max_nux()                                                        # contours.exp_lon.max(), streamer_index.py:106
         if global_max is not None:
             g = max(g, int(global_max))

@@ -58,7 +58,7 @@ def _contour_frame(tables, prep, levels, original_coordinates):
             geoms.append(_gf.make_linestring(seg))
     else:
         exp_lon = list(nux[order] * prep.dlon)                               # :154
-        mean_lat = [np.round(int(sum_y[k]) / int(npts[k]), 2) for k in order]   # :155
+        mean_lat = list(np.round(sum_y[order].astype(np.float64) / npts[order].astype(np.float64), 2))   # :155 (int / int: one rounding either way)
         xy = np.c_[x, y]
         for k in order:
             geoms.append(_gf.make_linestring(xy[off[k]:off[k] + npts[k]]))
