@@ -347,3 +347,28 @@ def test_all_pairs_tables_on_a_jittered_coordinate_axis(sim):
     assert a["step"].size > 3
     for key in ("step", "level_idx", "ind1", "ind2", "poly_x", "poly_y"):
         assert np.array_equal(a[key], c[key]), key
+
+
+@pytest.mark.parametrize("bands", [1, 2, 7])
+def test_two_kernel_scan_simulation_equals_the_single_scan(sim, bands):
+    """the host simulation of wb_k_scan_stream + wb_k_scan_build (patch capture per row band and strip in the field's own
+    precision, then the list build) against the plain square-by-square scan: same contours and status words on a rough
+    float32 field with NaN cells, a cell equal to a level and a non-default periodic_add, whatever the number of bands"""
+    lib, ctx = sim
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(5, 2, lat, lon, eps=0.4)
+    pv[0, 40:43, 100:104] = np.nan
+    pv[1, 60, 359] = 2.0                                         # a level hit on the last column: the halo wraps to column 0
+    out = []
+    for split in (1, 0):
+        ctx.set_option("scan_split", split)
+        ctx.set_option("scan_grid_mult", bands)
+        b = ctx.contours(pv, lat, lon, [-2.0, 2.0, 1.25], 1.0, 1.0, periodic_add=77.0)
+        out.append((b.contour_table(), b.status().copy()))
+        b.close()
+    ctx.set_option("scan_split", 1)
+    ctx.set_option("scan_grid_mult", 1)
+    (ta, sa), (tb, sb) = out
+    assert np.array_equal(sa, sb) and ta["step"].size > 6
+    for key in ta:
+        assert np.array_equal(ta[key], tb[key]), key

@@ -25,409 +25,7 @@
 #include "wb_trace.h"
 #include "wb_track.h"
 
-#if defined(WB_HOSTSIM)
-int wb_hostsim_reverse = 0;
-extern "C" void wb_hostsim_set_reverse(int r) { wb_hostsim_reverse = r; }
-#define WB_LAUNCH(kernel, grid, block, ...)                                       \
-    do {                                                                          \
-        const int wb_g_ = (int)(grid);                                            \
-        for (int wb_b_ = 0; wb_b_ < wb_g_; ++wb_b_) kernel(wb_b_, wb_g_, __VA_ARGS__); \
-    } while (0)
-#else
-#define WB_LAUNCH(kernel, grid, block, ...) \
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(block), 0, ctx->stream, __VA_ARGS__)
-#endif
-
-// ------------------------------------------------------------------------------------------------ context
-struct wb_ctx {
-    int device = 0;
-    std::string err;
-    // host buffers of the big result arrays are recycled between batches: a fresh 10 MB vector costs ~1 ms of page
-    // faults and zero-fill per pass
-    std::multimap<size_t, void*> hpool;
-    float last_op_ms = 0.f;
-    // 1 (default): scan as two kernels -- the streaming patch capture (wb_stream.h: 1.20 ms = 5.1 TB/s for 1460 steps of
-    // 1440 x 721 f32) + the list build (0.24 ms); 0: the single classify-and-emit kernel wb_k_scan (1.5-1.7 ms)
-    int scan_split = (getenv("WB_SCAN_SPLIT") && atoi(getenv("WB_SCAN_SPLIT")) == 0) ? 0 : 1;
-    int scan_debug = 0;
-    int scan_halo_lds = 1;                    // streaming scan: halo columns through LDS (0: scalar loads)
-    int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
-    int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
-    int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
-    int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
-    int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
-    int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
-    size_t p2_budget = 0;                     // dynamic LDS a workgroup of wb_k_streamer_pairs2 may use (found once)
-    int p2_budget_kb = 0, p2_split = 0;       // development: overrides of that budget / of the workgroups per contour
-#if !defined(WB_HOSTSIM)
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
-    hipEvent_t fork = nullptr, join = nullptr;
-    // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
-    // (measured: 0.7 ms for the first pass's ~40 allocations, 350 ms for every later pass), so blocks are
-    // kept for the life of the context and handed out again by size
-    std::multimap<size_t, void*> pool;        // free blocks by size
-    std::map<void*, size_t> live;             // blocks handed out
-    // pinned staging buffer for large device<->host copies.  Copying straight into pageable memory makes the
-    // runtime register those pages with the GPU; when the caller frees them the kernel driver's MMU notifier
-    // evicts and restores the process's queues (measured: ~20 ms stall on the next dispatch).
-    void* pin = nullptr;
-    size_t pin_bytes = 0;
-    void* h2d_pin[2] = {nullptr, nullptr};    // double-buffered staging of large uploads
-    hipEvent_t h2d_ev[2] = {nullptr, nullptr};
-#endif
-    // per-grid device tables (trigonometric tables, area weights, the all-pairs reach per latitude row): built once per
-    // (lat, lon, resolution, geo_dis) and shared by every batch of the context
-    struct Tables {
-        std::vector<double> lat, lon;
-        double dlon = 0, dlat = 0, geo_dis = 0;
-        double* base = nullptr;
-        size_t o_lat = 0, o_latrad = 0, o_sphi2 = 0, o_cphi2 = 0, o_cphi = 0, o_wlat = 0, o_lonrad = 0, o_slam2 = 0, o_clam2 = 0;
-        int* dxlim = nullptr;
-        double* on_tab = nullptr;             // [nlat][nlon][4] distance (km) of a grid point to its E, N, NE, NW neighbour: sklearn's
-                                              // haversine evaluated with the HOST's math library (wb_k_streamer_prep)
-        int dy_max = 0;
-        double hthr = 0;
-        // wb_k_streamer_pairs2: sin^2 of the multiples of dlat / 2 and dlon / 2 (host math library), whether the grid is the
-        // regular global one the tables stand for, and the absolute guard band on h that covers what its coordinates
-        // deviate from lat[0] + j dlat / lon[0] + i dlon
-        double* sl_tab = nullptr;
-        double* sx_tab = nullptr;
-        bool p2_ok = false;
-        double geo_band = 0;
-    };
-    std::vector<Tables*> tables;
-    WbCtl* h_ctl = nullptr;                   // pinned: where the control block of a batch lands (two snapshots)
-    WbRingSink geo;                           // result of the last wb_transform_polygons
-#if !defined(WB_HOSTSIM)
-    WbComm* comm = nullptr;                   // RCCL communicator of a time-sharded run (wb_comm_init)
-#endif
-};
-
-#include <chrono>
-static double wb_now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-static bool wb_debug() { static int v = -1; if (v < 0) v = getenv("WB_DEBUG_TIMING") ? 1 : 0; return v == 1; }
-#define WB_TICK(label) do { if (wb_debug()) { double t_ = wb_now_ms(); fprintf(stderr, "[wb] %-28s %9.3f ms\n", label, t_ - wb_t0_); wb_t0_ = t_; } } while (0)
-
-// Host buffers of the big result arrays (polygon vertices).  Product build: PINNED memory, so the device-to-host copy
-// lands in them directly (through the staging buffer it costs a second pass over the data on the host, ~0.3 ms per
-// array and batch); pinning is expensive, so blocks are rounded up to a power of two and recycled by the context.
-static void* hmalloc(wb_ctx* c, size_t bytes, size_t* got) {
-    size_t want = (size_t)1 << 20;
-    while (want < bytes) want <<= 1;
-    *got = want;
-    auto it = c->hpool.find(want);
-    if (it != c->hpool.end()) {
-        void* p = it->second;
-        c->hpool.erase(it);
-        return p;
-    }
-#if defined(WB_HOSTSIM)
-    return malloc(want);
-#else
-    void* p = nullptr;
-    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
-    return p;
-#endif
-}
-static void hrelease(void* p) {
-#if defined(WB_HOSTSIM)
-    free(p);
-#else
-    (void)hipHostFree(p);
-#endif
-}
-static void hfree(wb_ctx* c, void* p, size_t bytes) {
-    if (!p) return;
-    if (c->hpool.size() < 8) c->hpool.insert({bytes, p}); else hrelease(p);
-}
-
-// every entry point that touches the device selects the context's device first: the current device is per host thread
-// (worker threads of a pipeline, ranks driving GPUs other than 0)
-static inline void wb_use(wb_ctx* c) {
-#if !defined(WB_HOSTSIM)
-    if (c) (void)hipSetDevice(c->device);
-#else
-    (void)c;
-#endif
-}
-
-static int wb_fail(wb_ctx* c, const std::string& m) {
-    if (c) c->err = m;
-    return 1;
-}
-
-#if defined(WB_HOSTSIM)
-static void* dmalloc(wb_ctx*, size_t bytes) { return malloc(bytes ? bytes : 1); }
-static void dfree(wb_ctx*, void* p) { free(p); }
-static int dmemset(wb_ctx*, void* p, int v, size_t bytes) { memset(p, v, bytes); return 0; }
-static int h2d(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
-static int d2h(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
-static int d2h_pinned(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
-static int dsync(wb_ctx*) { return 0; }
-#else
-static void* dmalloc(wb_ctx* c, size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    if (bytes == 0) bytes = 256;
-    auto it = c->pool.lower_bound(bytes);
-    if (it != c->pool.end() && it->first <= bytes + bytes / 4 + 4096) {   // close enough: reuse
-        void* p = it->second;
-        c->live[p] = it->first;
-        c->pool.erase(it);
-        return p;
-    }
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-        // out of memory: give the cached blocks back and try once more
-        for (auto& kv : c->pool) (void)hipFree(kv.second);
-        c->pool.clear();
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            c->err = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
-            return nullptr;
-        }
-    }
-    c->live[p] = bytes;
-    return p;
-}
-static void dfree(wb_ctx* c, void* p) {
-    if (!p) return;
-    auto it = c->live.find(p);
-    if (it == c->live.end()) { (void)hipFree(p); return; }
-    c->pool.insert({it->second, p});
-    c->live.erase(it);
-}
-// zero / byte fill as our own kernel on the context's stream (hipMemsetAsync showed ~20 ms stalls on the first
-// call of every pass on this stack)
-__global__ void wb_k_fill(unsigned char* p, int v, size_t bytes) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += stride) p[i] = (unsigned char)v;
-}
-static int dmemset(wb_ctx* c, void* p, int v, size_t bytes) {
-    if (!bytes) return 0;
-    size_t blocks = (bytes + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(wb_k_fill, dim3((unsigned)blocks), dim3(256), 0, c->stream, (unsigned char*)p, v, bytes);
-    return 0;
-}
-#define WB_PIN_THRESHOLD (256u << 10)
-static void* wb_pin(wb_ctx* c, size_t bytes) {
-    if (c->pin_bytes >= bytes) return c->pin;
-    if (c->pin) (void)hipHostFree(c->pin);
-    c->pin = nullptr;
-    c->pin_bytes = 0;
-    size_t want = (size_t)32 << 20;
-    while (want < bytes && want < ((size_t)256 << 20)) want <<= 1;
-    if (hipHostMalloc(&c->pin, want, hipHostMallocDefault) != hipSuccess) { c->pin = nullptr; return nullptr; }
-    c->pin_bytes = want;
-    return c->pin;
-}
-// Host -> device copy of a large pageable buffer: chunks go through TWO pinned staging buffers, the host memcpy of chunk
-// k + 1 (split over a few threads: one core copies ~10 GB/s, PCIe Gen5 takes ~55) overlapping the DMA of chunk k.
-#define WB_H2D_CHUNK ((size_t)64 << 20)
-#define WB_H2D_THREADS 8
-static int wb_h2d_threads() {
-    // one core copies ~10 GB/s into the staging buffer, the link takes ~55: eight copiers where the host has the cores
-    // (WB_H2D_THREADS overrides)
-    static int n = 0;
-    if (!n) {
-        const char* e = getenv("WB_H2D_THREADS");
-        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
-        n = v < 1 ? 1 : (v > WB_H2D_THREADS ? WB_H2D_THREADS : v);
-    }
-    return n;
-}
-static void wb_par_memcpy(char* dst, const char* src, size_t n) {
-    const int nth = wb_h2d_threads();
-    if (n < ((size_t)8 << 20) || nth == 1) { memcpy(dst, src, n); return; }
-    std::thread th[WB_H2D_THREADS - 1];
-    const size_t part = (n / nth + 4095) & ~(size_t)4095;
-    for (int t = 1; t < nth; ++t) {
-        const size_t o = (size_t)t * part;
-        if (o >= n) break;
-        const size_t m = n - o < part ? n - o : part;
-        th[t - 1] = std::thread([=]() { memcpy(dst + o, src + o, m); });
-    }
-    memcpy(dst, src, part < n ? part : n);
-    for (int t = 1; t < nth; ++t) if (th[t - 1].joinable()) th[t - 1].join();
-}
-static int h2d(wb_ctx* c, void* d, const void* s, size_t b) {
-    if (b > WB_PIN_THRESHOLD) {
-        if (!c->h2d_pin[0]) {
-            for (int k = 0; k < 2; ++k) {
-                if (hipHostMalloc(&c->h2d_pin[k], WB_H2D_CHUNK, hipHostMallocDefault) != hipSuccess) { c->h2d_pin[k] = nullptr; break; }
-                (void)hipEventCreateWithFlags(&c->h2d_ev[k], hipEventDisableTiming);
-            }
-        }
-        if (c->h2d_pin[0] && c->h2d_pin[1]) {
-            int k = 0;
-            bool used[2] = {false, false};
-            for (size_t o = 0; o < b; o += WB_H2D_CHUNK, k ^= 1) {
-                const size_t n = b - o < WB_H2D_CHUNK ? b - o : WB_H2D_CHUNK;
-                if (used[k] && hipEventSynchronize(c->h2d_ev[k]) != hipSuccess) return 1;      // the buffer's previous DMA is done
-                wb_par_memcpy((char*)c->h2d_pin[k], (const char*)s + o, n);
-                if (hipMemcpyAsync((char*)d + o, c->h2d_pin[k], n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
-                (void)hipEventRecord(c->h2d_ev[k], c->stream);
-                used[k] = true;
-            }
-            return hipStreamSynchronize(c->stream) != hipSuccess;
-        }
-    }
-    return hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
-}
-static int d2h(wb_ctx* c, void* d, const void* s, size_t b) {
-    if (b > WB_PIN_THRESHOLD && wb_pin(c, b < ((size_t)256 << 20) ? b : ((size_t)256 << 20))) {
-        for (size_t o = 0; o < b; o += c->pin_bytes) {
-            const size_t n = b - o < c->pin_bytes ? b - o : c->pin_bytes;
-            if (hipMemcpyAsync(c->pin, (const char*)s + o, n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) return 1;
-            memcpy((char*)d + o, c->pin, n);
-        }
-        return 0;
-    }
-    return hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
-}
-// destination is pinned host memory: no staging
-static int d2h_pinned(wb_ctx* c, void* d, const void* s, size_t b) {
-    return hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
-}
-static int dsync(wb_ctx* c) {
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) { c->err = std::string("HIP error: ") + hipGetErrorString(e); return 1; }
-    return 0;
-}
-#endif
-
-// asynchronous device-to-host copy into PINNED memory on the context's current stream (no synchronisation)
-static int d2h_async(wb_ctx* c, void* dst_pinned, const void* src, size_t bytes) {
-    if (!bytes) return 0;
-#if defined(WB_HOSTSIM)
-    (void)c;
-    memcpy(dst_pinned, src, bytes);
-    return 0;
-#else
-    return hipMemcpyAsync(dst_pinned, src, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess;
-#endif
-}
-static WbCtl* host_ctl(wb_ctx* c) {
-    if (c->h_ctl) return c->h_ctl;
-#if defined(WB_HOSTSIM)
-    c->h_ctl = (WbCtl*)calloc(2, sizeof(WbCtl));
-#else
-    void* q = nullptr;
-    if (hipHostMalloc(&q, 2 * sizeof(WbCtl), hipHostMallocDefault) != hipSuccess) return nullptr;
-    c->h_ctl = (WbCtl*)q;
-#endif
-    return c->h_ctl;
-}
-// side stream: the launches between side_begin and side_end run next to whatever follows on the main stream
-static void side_begin(wb_ctx* ctx) {
-#if !defined(WB_HOSTSIM)
-    (void)hipEventRecord(ctx->fork, ctx->stream);
-    (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
-    std::swap(ctx->stream, ctx->stream2);
-#else
-    (void)ctx;
-#endif
-}
-static void side_end(wb_ctx* ctx) {
-#if !defined(WB_HOSTSIM)
-    (void)hipEventRecord(ctx->join, ctx->stream);
-    std::swap(ctx->stream, ctx->stream2);
-#else
-    (void)ctx;
-#endif
-}
-static void side_join(wb_ctx* ctx) {          // the main stream waits for the side stream's last side_end
-#if !defined(WB_HOSTSIM)
-    (void)hipStreamWaitEvent(ctx->stream, ctx->join, 0);
-#else
-    (void)ctx;
-#endif
-}
-static int side_sync(wb_ctx* ctx) {           // the HOST waits for the side stream
-#if !defined(WB_HOSTSIM)
-    return hipStreamSynchronize(ctx->stream2) != hipSuccess;
-#else
-    (void)ctx;
-    return 0;
-#endif
-}
-
-// stage timer: HIP events on the context's stream (host simulation: zeros)
-struct WbTimer {
-    std::vector<std::string> names;
-    std::vector<float> ms;
-#if !defined(WB_HOSTSIM)
-    std::vector<hipEvent_t> ev0, ev1;   // parallel to names; nullptr once collected
-#endif
-    void begin(wb_ctx* c, const char* name) {
-        names.push_back(name);
-        ms.push_back(0.f);
-#if !defined(WB_HOSTSIM)
-        hipEvent_t a = nullptr, b = nullptr;
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        ev0.push_back(a);
-        ev1.push_back(b);
-        (void)hipEventRecord(a, c->stream);
-#else
-        (void)c;
-#endif
-    }
-    void end(wb_ctx* c) {
-#if !defined(WB_HOSTSIM)
-        (void)hipEventRecord(ev1.back(), c->stream);
-#else
-        (void)c;
-#endif
-    }
-    void drop_last() {   // forget the most recent stage (a retried launch)
-#if !defined(WB_HOSTSIM)
-        if (ev0.back()) { (void)hipEventSynchronize(ev1.back()); (void)hipEventDestroy(ev0.back()); (void)hipEventDestroy(ev1.back()); }
-        ev0.pop_back();
-        ev1.pop_back();
-#endif
-        names.pop_back();
-        ms.pop_back();
-    }
-    void collect() {
-#if !defined(WB_HOSTSIM)
-        for (size_t i = 0; i < ev0.size(); ++i) {
-            if (!ev0[i]) continue;
-            (void)hipEventSynchronize(ev1[i]);
-            float t = 0.f;
-            (void)hipEventElapsedTime(&t, ev0[i], ev1[i]);
-            ms[i] = t;
-            (void)hipEventDestroy(ev0[i]);
-            (void)hipEventDestroy(ev1[i]);
-            ev0[i] = nullptr;
-            ev1[i] = nullptr;
-        }
-#endif
-    }
-    void truncate(size_t n) {               // forget the stages after the first n (a repeated phase)
-        collect();
-        if (n >= names.size()) return;
-        names.resize(n);
-        ms.resize(n);
-#if !defined(WB_HOSTSIM)
-        ev0.resize(n);
-        ev1.resize(n);
-#endif
-    }
-    void clear() {
-        collect();
-        names.clear();
-        ms.clear();
-#if !defined(WB_HOSTSIM)
-        ev0.clear();
-        ev1.clear();
-#endif
-    }
-};
+#include "wb_platform.h"
 
 // ------------------------------------------------------------------------------------------------ batch
 struct wb_batch {
@@ -514,31 +112,15 @@ static int next_pow2(long long v) {
 
 extern "C" {
 
-const char* wb_backend(void) {
-#if defined(WB_HOSTSIM)
-    return "hostsim";
-#else
-    return "hip";
-#endif
-}
+const char* wb_backend(void) { return wb_backend_name(); }
 
 int wb_create(int device_id, wb_ctx** out) {
     wb_ctx* c = new wb_ctx();
     c->device = device_id;
-#if !defined(WB_HOSTSIM)
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= device_id) {
+    if (!wb_platform_create(c)) {
         delete c;
         return 1;
     }
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
-        delete c;
-        return 1;
-    }
-#endif
     *out = c;
     return 0;
 }
@@ -548,24 +130,7 @@ void wb_destroy(wb_ctx* c) {
     wb_comm_destroy(c);
     for (auto& kv : c->hpool) hrelease(kv.second);
     for (wb_ctx::Tables* t : c->tables) delete t;
-    if (c->h_ctl) {
-#if defined(WB_HOSTSIM)
-        free(c->h_ctl);
-#else
-        (void)hipHostFree(c->h_ctl);
-#endif
-    }
-#if !defined(WB_HOSTSIM)
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto& kv : c->pool) (void)hipFree(kv.second);
-    for (auto& kv : c->live) (void)hipFree(kv.first);
-    if (c->pin) (void)hipHostFree(c->pin);
-    for (int k = 0; k < 2; ++k) { if (c->h2d_pin[k]) (void)hipHostFree(c->h2d_pin[k]); if (c->h2d_ev[k]) (void)hipEventDestroy(c->h2d_ev[k]); }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->fork) (void)hipEventDestroy(c->fork);
-    if (c->join) (void)hipEventDestroy(c->join);
-#endif
+    wb_platform_destroy(c);
     delete c;
 }
 
@@ -669,7 +234,25 @@ static int run_phase1(wb_batch* b) {
     sa.stg_k = b->stg_k; sa.stg_v = b->stg_v; sa.stg_n = b->stg_n; sa.status = b->status;
     b->timer.begin(ctx, "scan");
 #if defined(WB_HOSTSIM)
-    if (p.dtype == 0) wb_scan_host<float>(sa); else wb_scan_host<double>(sa);
+    if (ctx->scan_split && nlat < 65536 && b->W <= 65536) {
+        // the two-kernel scan as the product runs it: patch capture per (time step, row band, strip), then the list build
+        const size_t esz = p.dtype == 0 ? 4 : 8;
+        int nbands = ctx->scan_grid_mult > 1 ? ctx->scan_grid_mult : 3;          // (any band count gives the same lists)
+        if (nbands > nlat - 1) nbands = nlat - 1;
+        sa.band_rows = (nlat - 1 + nbands - 1) / nbands;
+        sa.nbands = (nlat - 1 + sa.band_rows - 1) / sa.band_rows;
+        sa.cap_rec = caps;
+        const long long lists = (long long)p.nt * b->nwork_strips * sa.nbands;
+        sa.cap_k = balloc<uint32_t>(b, (size_t)lists * caps);
+        sa.cap_v = balloc<unsigned char>(b, (size_t)lists * caps * 10 * esz);
+        sa.cap_n = balloc<int>(b, (size_t)lists);
+        if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
+        b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
+        if (p.dtype == 0) { wb_scan_capture_host<float>(sa); wb_scan_build_host<float>(sa); }
+        else { wb_scan_capture_host<double>(sa); wb_scan_build_host<double>(sa); }
+    } else {
+        if (p.dtype == 0) wb_scan_host<float>(sa); else wb_scan_host<double>(sa);
+    }
 #else
     {
         const size_t esz = p.dtype == 0 ? 4 : 8;
@@ -820,9 +403,7 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
     if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
     const int W = p.nlon + padd;
     if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large: nlon + periodic columns <= 4096, nlat <= 32767");
-#if !defined(WB_HOSTSIM)
-    if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
-#endif
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     wb_batch* b = new wb_batch();
     b->ctx = ctx;
     b->p = p;
@@ -1260,27 +841,21 @@ WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const l
 // dynamic LDS for a workgroup of wb_k_streamer_pairs2: half a CU's LDS, so that two workgroups (16 waves) share a CU
 static size_t wb_p2_lds_budget(wb_ctx* ctx) {
     if (ctx->p2_budget) return ctx->p2_budget;
-#if defined(WB_HOSTSIM)
-    ctx->p2_budget = (size_t)80 << 10;
-#else
-    size_t per_block = 64 << 10, per_cu = 64 << 10;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) {
-        per_block = prop.sharedMemPerBlock;
-        per_cu = prop.maxSharedMemoryPerMultiProcessor > per_block ? prop.maxSharedMemoryPerMultiProcessor : per_block;
-    }
+    size_t per_block, per_cu;
+    wb_lds_limits(ctx, &per_block, &per_cu);
     size_t want = per_cu / 2;
     if (ctx->p2_budget_kb > 0) want = (size_t)ctx->p2_budget_kb << 10;
+#if !defined(WB_HOSTSIM)
     if (want > per_block) {
-        // more than the default limit of a launch: ask for it (gfx950 has 160 KiB per CU)
+        // more than the default limit of a launch: ask for it
         if (hipFuncSetAttribute((const void*)wb_k_streamer_pairs2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
             (void)hipGetLastError();
             want = per_block;
         }
     }
+#endif
     if (wb_debug()) fprintf(stderr, "[wb] LDS per block %zu, per CU %zu, pairs2 budget %zu\n", per_block, per_cu, want);
     ctx->p2_budget = want;
-#endif
     return ctx->p2_budget;
 }
 
@@ -1394,9 +969,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     wb_ctx* ctx = b->ctx;
     const wb_params& p = b->p;
     const int J = b->njobs, cap = b->cap_seg;
-#if !defined(WB_HOSTSIM)
-    if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
-#endif
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     wb_ctx::Tables* T = make_tables(b);
     WbCtl* hc = host_ctl(ctx);
     if (!T || !hc) return wb_fail(ctx, "out of memory (tables)");
@@ -1566,12 +1139,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_pairs");
             if (st.p2_cap > 0) {
-#if defined(WB_HOSTSIM)
-                WB_LAUNCH(wb_k_streamer_pairs2, (long long)nsel_b * st.p2_split, WB_P2_THREADS, st);
-#else
-                hipLaunchKernelGGL(wb_k_streamer_pairs2, dim3((unsigned)((long long)nsel_b * st.p2_split)), dim3(WB_P2_THREADS), p2_lds, ctx->stream, st);
-                { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { release(); return wb_fail(ctx, std::string("wb_k_streamer_pairs2 launch failed: ") + hipGetErrorString(le)); } }
-#endif
+                WB_LAUNCH_LDS(wb_k_streamer_pairs2, (long long)nsel_b * st.p2_split, WB_P2_THREADS, p2_lds, st);
                 WB_LAUNCH(wb_k_streamer_recheck, 64, 64, st);              // pairs inside a guard band (normally none)
             }
             if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
@@ -1678,18 +1246,14 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->poly_x = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
         b->poly_y = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
         if (!h_ev || !h_poff || !h_sums || !h_nc || !h_fl || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
-#if !defined(WB_HOSTSIM)
-        std::swap(ctx->stream, ctx->stream2);
-#endif
+        wb_swap_streams(ctx);
         b->timer.begin(ctx, "polygons_d2h");
         d2h_async(ctx, h_ev, fa.ev, (size_t)NE * 8 * sizeof(int));
         d2h_async(ctx, h_poff, fa.poff, (size_t)(NE + 1) * sizeof(long long));
         d2h_async(ctx, b->poly_x, d_px, (size_t)NV * sizeof(int));
         d2h_async(ctx, b->poly_y, d_py, (size_t)NV * sizeof(int));
         b->timer.end(ctx);
-#if !defined(WB_HOSTSIM)
-        std::swap(ctx->stream, ctx->stream2);
-#endif
+        wb_swap_streams(ctx);
         b->timer.begin(ctx, "events_d2h");
         d2h_async(ctx, h_sums, pa.ev_sums, (size_t)NE * 5 * sizeof(double));
         d2h_async(ctx, h_nc, pa.ev_ncells, (size_t)NE * sizeof(int));
@@ -1822,9 +1386,7 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
     if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
     const int W = p.nlon + padd;
     if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large");
-#if !defined(WB_HOSTSIM)
-    if (hipSetDevice(ctx->device) != hipSuccess) return wb_fail(ctx, "hipSetDevice failed");
-#endif
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     int maxn = 1;
     for (int64_t k = 0; k < n; ++k) {
         if (npts[k] < 1) return wb_fail(ctx, "empty contour in frame");
@@ -1998,21 +1560,6 @@ extern "C" int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0
 #include <float.h>
 
 #if !defined(WB_HOSTSIM)
-struct WbOpTimer {
-    wb_ctx* c; hipEvent_t e0 = nullptr, e1 = nullptr;
-    explicit WbOpTimer(wb_ctx* ctx) : c(ctx) {
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, c->stream);
-    }
-    void stop() {
-        (void)hipEventRecord(e1, c->stream);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        c->last_op_ms = ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    }
-};
 template <typename T, bool CAST, bool UNIT4, bool FAST>
 static void wb_launch_smooth_plus2(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
     // four strips per workgroup (measured: 1, 2, 8, 13, 16 waves per workgroup are all slower)
@@ -2032,8 +1579,6 @@ static void wb_launch_smooth_plus(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
     if (a.unit4 && a.fastdiv == 2) wb_launch_smooth_plus2<T, CAST, true, true>(ctx, P, a);
     else wb_launch_smooth_plus2<T, CAST, false, false>(ctx, P, a);
 }
-#else
-struct WbOpTimer { explicit WbOpTimer(wb_ctx*) {} void stop() {} };
 #endif
 #define WB_SP_MAXFUSE 8
 

@@ -129,6 +129,115 @@ void wb_scan_host(const WbScanArgs& a) {
         }
     }
 }
+
+// Host simulation of the TWO-kernel scan (wb_k_scan_stream + wb_k_scan_build), statement by statement what the device
+// kernels decide: which 2 x 5 patches a (time step, row band, strip) list captures -- min(patch) <= lvl_lo < max(patch) in
+// the field's own precision for ANY level, NaN operands ignored as v_min / v_max ignore them, the halo column wrapping to
+// column 0 at the row's end, a band re-reading its neighbour's first row -- and how the build expands the patches into the
+// per-level segment lists (square cases against lvl_lo, raster positions, periodic copies, overflow counts).
+template <typename T> inline T wb_level_lo_host(double level);
+template <> inline float wb_level_lo_host<float>(double level) {
+    float f = (float)level;                                  // round to nearest, then down to the largest float <= level
+    if ((double)f > level) f = nextafterf(f, -INFINITY);
+    return f;
+}
+template <> inline double wb_level_lo_host<double>(double level) { return level; }
+template <typename T> inline T wb_minnum(T a, T b) { return a != a ? b : (b != b ? a : (a < b ? a : b)); }
+template <typename T> inline T wb_maxnum(T a, T b) { return a != a ? b : (b != b ? a : (a > b ? a : b)); }
+
+template <typename T>
+void wb_scan_capture_host(const WbScanArgs& a) {
+    const int nlon = a.nlon, nlat = a.nlat, NSB = a.nwork;
+    const int cmax = nlon < a.W - 1 ? nlon : a.W - 1;
+    T lvl[WB_MAX_LEVELS];
+    for (int l = 0; l < a.nlev; ++l) lvl[l] = wb_level_lo_host<T>(a.levels[l]);
+    for (int t = 0; t < a.nt; ++t) {
+        const T* f = (const T*)a.field + (size_t)t * nlat * nlon;
+        bool nan = false;
+        for (int band = 0; band < a.nbands; ++band) {
+            const int rb0 = band * a.band_rows, rb1 = rb0 + a.band_rows < nlat - 1 ? rb0 + a.band_rows : nlat - 1;
+            for (int s = 0; s < NSB; ++s) {
+                const size_t g = ((size_t)t * a.nbands + band) * NSB + s;
+                uint32_t* ck = a.cap_k + g * a.cap_rec;
+                T* cv = (T*)a.cap_v + g * a.cap_rec * 10;
+                int count = 0;
+                for (int r = rb0; r < rb1; ++r) {
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int c0 = s * WB_STRIP + 4 * lane;
+                        if (c0 >= cmax) continue;                              // the lane owns no square
+                        T v[10];
+                        for (int row = 0; row < 2; ++row)
+                            for (int k = 0; k < 5; ++k) {
+                                int c = c0 + k;
+                                if (c >= nlon) c -= nlon;                      // the halo past the row's end is column 0 (periodic wrap)
+                                if (c > nlon - 1) c = nlon - 1;
+                                v[5 * row + k] = f[(size_t)(r + row) * nlon + c];
+                            }
+                        for (int k = 0; k < 4; ++k) nan |= (v[k] != v[k]) || (v[5 + k] != v[5 + k]);
+                        T lo = v[0], hi = v[0];
+                        for (int k = 1; k < 10; ++k) { lo = wb_minnum(lo, v[k]); hi = wb_maxnum(hi, v[k]); }
+                        bool hit = false;
+                        for (int l = 0; l < a.nlev; ++l) hit |= (hi > lvl[l]) && !(lo > lvl[l]);
+                        if (!hit) continue;
+                        if (count < a.cap_rec) {
+                            ck[count] = ((uint32_t)r << 16) | (uint32_t)c0;
+                            for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_rec + count] = v[k];
+                        }
+                        ++count;
+                    }
+                }
+                a.cap_n[g] = count;
+            }
+        }
+        if (nan) for (int l = 0; l < a.nlev; ++l) a.status[t * a.nlev + l] |= WB_ST_HAS_NAN;
+    }
+}
+
+template <typename T>
+void wb_scan_build_host(const WbScanArgs& a) {
+    const int NS = a.nstrips, NSB = a.nwork, W = a.W, nlon = a.nlon;
+    const int cmax = nlon < W - 1 ? nlon : W - 1;
+    const size_t cs = (size_t)a.cap_rec;
+    for (int t = 0; t < a.nt; ++t)
+        for (int s = 0; s < NSB; ++s) {
+            const bool has_copy = NSB + s < NS;
+            int excess = 0;
+            for (int band = 0; band < a.nbands; ++band) {
+                const int n = a.cap_n[((size_t)t * a.nbands + band) * NSB + s];
+                if (n > a.cap_rec) excess += n - a.cap_rec;
+            }
+            for (int l = 0; l < a.nlev; ++l) {
+                const T lv = wb_level_lo_host<T>(a.levels[l]);
+                const size_t base = ((size_t)(t * a.nlev + l) * NS + s) * a.cap_strip;
+                const size_t cbase = ((size_t)(t * a.nlev + l) * NS + NSB + s) * a.cap_strip;
+                int mine = 0, cmine = 0;
+                for (int band = 0; band < a.nbands; ++band) {
+                    const size_t gl = ((size_t)t * a.nbands + band) * NSB + s;
+                    const int n = a.cap_n[gl] < a.cap_rec ? a.cap_n[gl] : a.cap_rec;
+                    for (int li = 0; li < n; ++li) {
+                        const uint32_t key = a.cap_k[gl * cs + li];
+                        const int r = (int)(key >> 16), c0 = (int)(key & 0xFFFFu);
+                        const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
+                        for (int k = 0; k < 4; ++k) {
+                            const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
+                            const bool ok = (c0 + k < cmax) && ul == ul && ur == ur && ll == ll && lr == lr;
+                            const int cs2 = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
+                            const int ns = wb_case_nseg(cs2);
+                            if (ns) {
+                                wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs2, ns, ul, ur, ll, lr, mine);
+                                if (has_copy && c0 + k < a.padd - 1)
+                                    wb_store_square<T>(a.stg_k + cbase, (T*)a.stg_v + cbase * 4, a.cap_strip, W, r, c0 + k + nlon, cs2, ns, ul, ur, ll, lr, cmine);
+                            }
+                            mine += ns;
+                            if (c0 + k < a.padd - 1) cmine += ns;
+                        }
+                    }
+                }
+                a.stg_n[(t * a.nlev + l) * NS + s] = excess ? a.cap_strip + 1 + excess : mine;
+                if (has_copy) a.stg_n[(t * a.nlev + l) * NS + NSB + s] = cmine;
+            }
+        }
+}
 #else
 // ------------------------------------------------------------------------------------------------
 // gfx950 kernel: blockDim.x = 256 = 4 independent persistent waves.
