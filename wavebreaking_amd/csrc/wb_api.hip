@@ -377,14 +377,14 @@ static int run_phase1(wb_batch* b) {
     ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
     ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.ctl = b->d_ctl;
     b->timer.begin(ctx, "trace_link");
-    WB_LAUNCH(wb_k_trace_link, J, 512, ta);
+    WB_LAUNCH(wb_k_trace_link, J, WB_LINK_THREADS, ta);
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_rank");
-    WB_LAUNCH(wb_k_trace_rank, J, 1024, ta);
+    WB_LAUNCH(wb_k_trace_rank, J, WB_RANK_THREADS, ta);
     WB_LAUNCH(wb_k_trace_walk, J, 64, ta);            // jobs flagged WB_ST_LEVEL_ORDER only: skimage's sequential walk, one lane each
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_finish");
-    WB_LAUNCH(wb_k_trace_finish, J, 1024, ta);
+    WB_LAUNCH(wb_k_trace_finish, J, WB_FINISH_THREADS, ta);
     b->timer.end(ctx);
     if (phase1_summary(b)) return 1;
     b->timer_phase1 = b->timer.names.size();
@@ -1145,7 +1145,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
-            WB_LAUNCH(wb_k_streamer_f1, nsel_b, 256, st);
+            WB_LAUNCH(wb_k_streamer_f1, nsel_b, WB_F1_THREADS, st);
             b->timer.end(ctx);
             if (ctx->eager_f2) {
                 // routine 2 for every candidate pair, then routines 3 + 4 on the survivors (option "eager_f2": the exhaustive

@@ -343,26 +343,18 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
         }
         bbx[4 * b + 0] = x0; bbx[4 * b + 1] = x1; bbx[4 * b + 2] = y0; bbx[4 * b + 3] = y1;
     WB_END_PFOR
-    // inclusive prefix, strictly sequential (same rounding as the reference's np.cumsum over `on`); staged through
-    // LDS in chunks so that the one summing lane reads at LDS instead of L2 latency
+    // Running sum of `on` (streamer_index.py:133-135).  Only DIFFERENCES of it are used, against cont_dis with a guard band of
+    // 1e-6 km inside which the pair's distance is summed again term by term in the reference's order (wb_k_streamer_recheck,
+    // wb_k_streamer_pairs) -- so the prefix itself may be formed as a parallel scan forms it (a few ulp of 4e4 km off the
+    // left-to-right sum).  A lane walking the contour's 2 500 terms alone set this kernel's duration before.
     WB_SHARED(double, stage, 2048);
-    WB_SHARED(double, carry, 1);
-    WB_SINGLE
-    carry[0] = 0.0;
-    WB_END_SINGLE
+    double carry = 0.0;
     for (int c0 = 0; c0 < N; c0 += 2048) {
         const int cn = N - c0 < 2048 ? N - c0 : 2048;
         WB_PFOR(i, cn)
             stage[i] = on[c0 + i];
         WB_END_PFOR
-        WB_SINGLE
-        double run = carry[0];
-        for (int i = 0; i < cn; ++i) {
-            run = run + stage[i];
-            stage[i] = run;
-        }
-        carry[0] = run;
-        WB_END_SINGLE
+        carry = wb_block_cumsum_f64(stage, cn, carry);
         WB_PFOR(i, cn)
             pre[c0 + i] = stage[i];
         WB_END_PFOR
@@ -529,36 +521,34 @@ WB_KERNEL_LB(wb_k_streamer_pairs, 64, 6, WbStreamerArgs a) {
 #endif
 WB_HD inline int wb_bits_for_i(int n) { int b = 0; while ((1 << b) < n) ++b; return b; }
 
-// routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264
-WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
-    const int s = WB_BLOCK_ID;
-    if (s >= a.ctl->nsel) return;
-    const int job = a.sel_job[s], k = a.sel_cont[s];
-    const size_t jb = (size_t)job * a.cap_seg;
-    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+// routine 1: check_duplicates (streamer_index.py:160-183); also fixes the stage bookkeeping of :261-264.  Every thread of the
+// workgroup calls the body.  (It was tried behind the sweep of wb_k_streamer_pairs2, where the contour's points are in LDS
+// already: the 16 waves and 64 KiB of that workgroup then sit through this routine's latency-bound passes over the pair list
+// -- 2.3 ms for the fused kernel against 1.0 + 0.4 apart.  `ltab_only` is what remains of that: no fall-back to the tables
+// in global memory; false is returned when the western pairs do not fit the LDS table.)
+WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, const uint32_t* pts, unsigned long long* ltab,
+                                       int ltab_cap, bool ltab_only) {
     unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     int* alive = a.alive + (size_t)s * a.cap_pairs;
     unsigned long long* hkey = a.hkey + (size_t)s * a.hash_size;
     unsigned long long* hval = a.hval + (size_t)s * a.hash_size;
     WB_SHARED(int, cnt, 1);
+    WB_SHARED(int, nwest, 1);
     int P = a.npairs[s];
-    WB_SINGLE
-    wb_atomic_max(&a.ctl->max_pairs, P);
-    wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
-    WB_END_SINGLE
     int hsize = 256;                       // table sized to this contour's pair count (clearing it is real traffic)
     while (hsize < 2 * P && hsize < a.hash_size) hsize <<= 1;
     const int hmask = hsize - 1;
     if (P > a.cap_pairs) {
         WB_SINGLE
+        wb_atomic_max(&a.ctl->max_pairs, P);
+        wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
         wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
         a.nalive[s] = 0;
         a.stage[s] = 4;
         WB_END_SINGLE
-        return;
+        return true;
     }
     const int padd = a.W - a.nlon;
-    WB_SHARED(int, nwest, 1);
     WB_SINGLE
     nwest[0] = 0;
     cnt[0] = 0;
@@ -568,69 +558,72 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
         const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
         if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) wb_atomic_add(&nwest[0], 1);
     WB_END_PFOR
+    const int bxx = wb_bits_for_i(a.nlon), byy = wb_bits_for_i(a.nlat), pb = wb_bits_for_i(P);
+    int lsize = ltab_cap < 256 ? ltab_cap : 256;
+    while (lsize < 2 * nwest[0] && lsize < ltab_cap) lsize <<= 1;
+    const bool use_ltab = P > 1 && 2 * (bxx + byy) + pb <= 63 && 2 * nwest[0] <= lsize;
+    if (P > 1 && !use_ltab && ltab_only) return false;          // (nothing the stand-alone kernel does not redo has been written)
+    WB_SINGLE
+    wb_atomic_max(&a.ctl->max_pairs, P);
+    wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
+    WB_END_SINGLE
     if (P <= 1) {
         WB_SINGLE
         a.nalive[s] = P;
         a.stage[s] = 0;   // no routine applied: `while len(df_bp.index) > 1`
         WB_END_SINGLE
-        return;
+        return true;
     }
     // Usual case: the western pairs (a quarter of all on a full-span contour) fit a table in LDS whose 64-bit entries
     // hold the key (x1 mod nlon, y1, x2 mod nlon, y2) above the pair index -- no table in global memory to clear and probe.
-    {
-        WB_SHARED(unsigned long long, ltab, WB_F1_LTAB);
-        const int bxx = wb_bits_for_i(a.nlon), byy = wb_bits_for_i(a.nlat), pb = wb_bits_for_i(P);
-        int lsize = WB_F1_LTAB < 256 ? WB_F1_LTAB : 256;
-        while (lsize < 2 * nwest[0] && lsize < WB_F1_LTAB) lsize <<= 1;
-        if (2 * (bxx + byy) + pb <= 63 && 2 * nwest[0] <= lsize) {
-            const int lmask = lsize - 1;
-            const unsigned long long pmask = (1ull << pb) - 1ull;
-            WB_PFOR(q, lsize)
-                ltab[q] = WB_HEMPTY;
-            WB_END_PFOR
-            WB_PFOR(p, P)
-                const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
-                if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
-                    const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
-                                                     (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
-                    const unsigned long long mine = (key << pb) | (unsigned long long)p;
-                    uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
-                    for (int probe = 0; probe <= lmask; ++probe) {
-                        unsigned long long cur = ltab[sl];
-                        if (cur == WB_HEMPTY) {
-                            cur = wb_atomic_cas(&ltab[sl], (unsigned long long)WB_HEMPTY, mine);
-                            if (cur == WB_HEMPTY) break;
-                        }
-                        if ((cur >> pb) == key) { wb_atomic_min(&ltab[sl], mine); break; }
-                        sl = (sl + 1) & (uint32_t)lmask;
-                    }
-                }
-            WB_END_PFOR
-            WB_PFOR(p, P)
-                const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
-                if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
-                    const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
-                                                     (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
-                    uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
-                    for (int probe = 0; probe <= lmask; ++probe) {
-                        const unsigned long long cur = ltab[sl];
+    if (use_ltab) {
+        const int lmask = lsize - 1;
+        const unsigned long long pmask = (1ull << pb) - 1ull;
+        WB_PFOR(q, lsize)
+            ltab[q] = WB_HEMPTY;
+        WB_END_PFOR
+        WB_PFOR(p, P)
+            const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+            if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
+                const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
+                                                 (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
+                const unsigned long long mine = (key << pb) | (unsigned long long)p;
+                uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
+                for (int probe = 0; probe <= lmask; ++probe) {
+                    unsigned long long cur = ltab[sl];
+                    if (cur == WB_HEMPTY) {
+                        cur = wb_atomic_cas(&ltab[sl], (unsigned long long)WB_HEMPTY, mine);
                         if (cur == WB_HEMPTY) break;
-                        if ((cur >> pb) == key) {
-                            const int pw = (int)(cur & pmask);
-                            alive[pairs[pw] < pairs[p] ? p : pw] = 0;       // the first in (ind1, ind2) order stays
-                            wb_atomic_add(&cnt[0], 1);
-                            break;
-                        }
-                        sl = (sl + 1) & (uint32_t)lmask;
                     }
+                    if ((cur >> pb) == key) { wb_atomic_min(&ltab[sl], mine); break; }
+                    sl = (sl + 1) & (uint32_t)lmask;
                 }
-            WB_END_PFOR
-            WB_SINGLE
-            a.nalive[s] = P - cnt[0];
-            a.stage[s] = 1;
-            WB_END_SINGLE
-            return;
-        }
+            }
+        WB_END_PFOR
+        WB_PFOR(p, P)
+            const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+            if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
+                const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
+                                                 (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
+                uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
+                for (int probe = 0; probe <= lmask; ++probe) {
+                    const unsigned long long cur = ltab[sl];
+                    if (cur == WB_HEMPTY) break;
+                    if ((cur >> pb) == key) {
+                        const int pw = (int)(cur & pmask);
+                        alive[pairs[pw] < pairs[p] ? p : pw] = 0;       // the first in (ind1, ind2) order stays
+                        wb_atomic_add(&cnt[0], 1);
+                        break;
+                    }
+                    sl = (sl + 1) & (uint32_t)lmask;
+                }
+            }
+        WB_END_PFOR
+        WB_SINGLE
+        a.nalive[s] = P - cnt[0];
+        a.stage[s] = 1;
+        WB_END_SINGLE
+        return true;
     }
     // Two pairs coincide after x mod nlon only if one is the copy of the other one period further east: both end points
     // of the western pair lie in x < W - nlon, both of the eastern one in x >= nlon (a mixed pair would need its copy in
@@ -672,6 +665,17 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     a.nalive[s] = P - cnt[0];
     a.stage[s] = 1;
     WB_END_SINGLE
+    return true;
+}
+
+WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
+    const int s = WB_BLOCK_ID;
+    if (s >= a.ctl->nsel) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    WB_SHARED(unsigned long long, ltab, WB_F1_LTAB);
+    (void)wb_streamer_f1_body(a, s, job, pts, ltab, WB_F1_LTAB, false);
 }
 
 // routine 2: check_intersections (:185-200): one lane per candidate pair; contour blocks whose bounding box
@@ -982,7 +986,12 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #ifndef WB_F234_LPTS
 #define WB_F234_LPTS 4096          // contour points (and per-row maxima) held in LDS; longer contours work in global memory
 #endif
+#ifndef WB_F234_THREADS
 #define WB_F234_THREADS 512
+#endif
+#ifndef WB_F1_THREADS
+#define WB_F1_THREADS 1024         // routine 1: its duration is that of the few contours with tens of thousands of pairs (0.39 -> 0.27 ms against 256)
+#endif
 #define WB_F234_CAND 1024          // candidates of one row collected after its first chord failed
 #define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
 WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {

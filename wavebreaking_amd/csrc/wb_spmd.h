@@ -65,6 +65,13 @@ static inline void wb_block_scan_excl_max(int* a, int n, int init) {
     for (int i = 0; i < n; ++i) { int v = a[i]; a[i] = run; if (v > run) run = v; }
 }
 
+// in-place inclusive running sum of a[0..n) (doubles) on top of `carry`; returns the new carry.  (On the GPU the terms are
+// combined as a parallel scan combines them: a running sum that differs from the left-to-right one in its last bits.)
+static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
+    for (int i = 0; i < n; ++i) { carry = carry + a[i]; a[i] = carry; }
+    return carry;
+}
+
 #else
 // ---------------------------------------------------------------- HIP / gfx950
 #include <hip/hip_runtime.h>
@@ -242,5 +249,37 @@ __device__ inline void wb_block_scan_excl_max(int* a, int n, int init) {
         }
         __syncthreads();
     }
+}
+// in-place inclusive running sum of a[0..n) (doubles, LDS or global; n <= 8 * blockDim.x) on top of `carry`; all threads of
+// the block call it, every thread gets the new carry.  A thread owns 8 consecutive terms; thread sums are scanned inside
+// the wave, wave totals across the block: the result differs from the left-to-right running sum in its last bits.
+__device__ inline double wb_block_cumsum_f64(double* a, int n, double carry) {
+    __shared__ double wb_cs_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const int i0 = 8 * tid;
+    double v[8], sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < n) ? a[i0 + k] : 0.0; sum += v[k]; }
+    double inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();                                     // (the previous call's readers of wb_cs_wave are done)
+    if (lane == 63) wb_cs_wave[wave] = inc;
+    __syncthreads();
+    double run = carry;
+    for (int w = 0; w < wave; ++w) run += wb_cs_wave[w];
+    double total = carry;
+    for (int w = 0; w < nw; ++w) total += wb_cs_wave[w];
+    run += inc - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        run += v[k];
+        if (i0 + k < n) a[i0 + k] = run;
+    }
+    __syncthreads();
+    return total;
 }
 #endif

@@ -212,6 +212,16 @@ WB_DEV inline int wb_bits_for(int n) {   // bits that hold every value in [0, n)
 #ifndef WB_TRACE_LDS_N
 #define WB_TRACE_LDS_N 8192      // jobs with at most this many segments take the LDS paths
 #endif
+// threads per (time step, level) job of the three trace kernels
+#ifndef WB_LINK_THREADS
+#define WB_LINK_THREADS 512
+#endif
+#ifndef WB_RANK_THREADS
+#define WB_RANK_THREADS 1024
+#endif
+#ifndef WB_FINISH_THREADS
+#define WB_FINISH_THREADS 1024
+#endif
 
 // -------------------------------------------------------------------------------------------- 2a: link
 WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
@@ -613,7 +623,7 @@ WB_KERNEL(wb_k_trace_walk, WbTraceArgs a) {
 #ifndef WB_TRACE_LTAB
 #define WB_TRACE_LTAB 8192        // 64-bit entries of the LDS table (= 16384 32-bit set entries)
 #endif
-WB_KERNEL_LB(wb_k_trace_finish, 1024, 8, WbTraceArgs a) {
+WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 8 : 4), WbTraceArgs a) {
     WB_SHARED(unsigned long long, ltab, WB_TRACE_LTAB);
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
