@@ -101,7 +101,54 @@ WB_HD inline bool wb_trunc_unsafe(double num, double den, double ulps) {
 WB_HD inline double wb_com_ulps(int rows) { return 4.0 * (2.0 * (double)rows + 16.0); }
 
 #define WB_PROPS_LONG 16
+// sum over the member cells of the box [x0, x0 + cols) x [y0, y0 + rows) of weight(y) * (data, intensity): the lanes run
+// ALONG the rows (adjacent lanes on adjacent cells: a load instruction touches two or three cache lines, not 64), eight
+// loads in flight per lane; bm == NULL: every cell is a member.  The lane's two partial sums go to out[2 * lane].  (These
+// sums are compared to 1e-6 relative: the order of summation is free.)
+WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
+                                       double* out) {
+    const int total = rows * cols;
+    double accv = 0.0, acci = 0.0;
+    int i = WB_TID, rr = i / cols, xx = i - rr * cols;
+    while (i < total) {
+        double dv[8], di[8], wq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const bool in = i < total && (bm == nullptr || ((bm[rr * wb + (xx >> 5)] >> (xx & 31)) & 1u));
+            const int gx = x0 + xx, y = y0 + (i < total ? rr : 0);
+            const size_t idx = tbase + (size_t)y * a.nlon + (size_t)((gx < a.W ? gx : a.W - 1) % a.nlon);
+            dv[q] = in ? wb_load_field(a.data, idx, a.dtype) : 0.0;
+            di[q] = (in && a.intensity) ? wb_load_field(a.intensity, idx, a.dtype) : 0.0;
+            wq[q] = in ? a.wlat[y] : 0.0;
+            i += WB_NT; xx += WB_NT;
+            while (xx >= cols) { xx -= cols; ++rr; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { accv += wq[q] * dv[q]; acci += wq[q] * di[q]; }
+    }
+    out[2 * WB_TID] = accv;
+    out[2 * WB_TID + 1] = acci;
+    WB_SYNC();
+}
+// The raster of an event in LDS: per row of its bounding box a short list of signed scanline crossings (sorted by the
+// row's lane, swept into winding numbers) and one bit per cell.  Events taller than WB_PROPS_LROWS rows, with more cells
+// than the bitmap holds or with a row crossed more than WB_PROPS_K times keep the raster in global memory (one int per
+// cell of the slot's W x nlat scratch: 1.2 GB fetched + 0.4 GB written per 0.25 degree year, rocprofv3 --pmc, before).
+#ifndef WB_PROPS_K
+#define WB_PROPS_K 12
+#endif
+#ifndef WB_PROPS_BM
+#define WB_PROPS_BM 768              // bitmap words (24 576 cells)
+#endif
+WB_DEV inline bool wb_bm_test(const uint32_t* bm, int wb, int rr, int xx) { return (bm[rr * wb + (xx >> 5)] >> (xx & 31)) & 1u; }
 WB_KERNEL(wb_k_props, WbPropsArgs a) {
+    WB_SHARED(unsigned long long, xlist8, (WB_PROPS_LROWS * WB_PROPS_K + 3) / 4 > 6 * 64 ? (WB_PROPS_LROWS * WB_PROPS_K + 3) / 4 : 6 * 64);
+    unsigned short* xlist = (unsigned short*)xlist8;                  // per row: crossing column (relative to x0) | 0x8000 for a downward edge
+    double* lrow6 = (double*)xlist8;                                  // ... and, once the raster stands, the lanes' partial sums over the rows
+    WB_SHARED(int, xcnt, WB_PROPS_LROWS);
+    WB_SHARED(uint32_t, bm, WB_PROPS_BM);
+    WB_SHARED(int, ovf, 1);
+    WB_SHARED(double, lred, 2 * 64);                                  // per-lane partial sums of (data, intensity) * weight
     WB_SHARED(int, longe, WB_PROPS_LONG);
     WB_SHARED(int, nlong, 1);
     WB_SHARED(int, bb, 4);
@@ -109,16 +156,15 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
     WB_SHARED(long long, sh_off, 1);
     // per-row partial sums of the current event: in LDS when the event spans at most WB_PROPS_LROWS rows (the final
     // accumulation over rows is sequential by contract; from global memory every row costs a dependent round trip)
-    WB_SHARED(double, lacc, 4 * WB_PROPS_LROWS);
-    WB_SHARED(double, lpart, 2 * WB_PROPS_PART);       // (data, intensity) partial sums of the box path's column chunks
+    WB_SHARED(double, lacc, 2 * WB_PROPS_LROWS);       // cells and sum of x per row (boxes and bitmap events; the global raster keeps four sums per row in rowacc)
     const int slot = WB_BLOCK_ID;
     int* cells = a.cells + (size_t)slot * a.W * a.nlat;
-    double* cells_d = (double*)cells;                     // box path, very wide boxes: chunk partials in the (then unused) cell scratch
     double* rowacc = a.rowacc + (size_t)slot * 4 * a.nlat;
     const int nev = a.ctl->NE;
     // events are handed out one by one (streamers, the expensive ones, come first in the table): with a fixed assignment a
     // slot that drew several long streamers finished long after the others
     WB_SHARED(int, cur, 1);
+    WB_RSTAMP_BEGIN                              // development stamps: 0 queue + box, 1 crossings, 2 sweep, 3 rim, 4 sums, 5 tail; +6 for boxes; 11 global raster
     for (;;) {
         WB_SINGLE
         cur[0] = wb_atomic_add(&a.ctl->props_cursor, 1);
@@ -137,13 +183,16 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         nlong[0] = 0;
         wseen[0] = 0;
         WB_END_SINGLE
-        WB_PFOR(k, n)
-            const uint32_t v = wb_event_vertex(d, pts, (int)k);
-            wb_atomic_min(&bb[0], wb_pt_x(v));
-            wb_atomic_min(&bb[1], wb_pt_y(v));
-            wb_atomic_max(&bb[2], wb_pt_x(v));
-            wb_atomic_max(&bb[3], wb_pt_y(v));
-        WB_END_PFOR
+        {   // a lane's vertices first, then one round of LDS atomics per lane (64 lanes hammering four words serialise)
+            int mx0 = 0x7FFFFFFF, my0 = 0x7FFFFFFF, mx1 = -1, my1 = -1;
+            for (int k = WB_TID; k < n; k += WB_NT) {
+                const uint32_t v = wb_event_vertex(d, pts, k);
+                const int x = wb_pt_x(v), y = wb_pt_y(v);
+                mx0 = x < mx0 ? x : mx0; my0 = y < my0 ? y : my0; mx1 = x > mx1 ? x : mx1; my1 = y > my1 ? y : my1;
+            }
+            if (mx1 >= 0) { wb_atomic_min(&bb[0], mx0); wb_atomic_min(&bb[1], my0); wb_atomic_max(&bb[2], mx1); wb_atomic_max(&bb[3], my1); }
+            WB_SYNC();
+        }
         // An overturning event is an axis-parallel box (overturning_index.py:211): with r <= 1 its cells are exactly the
         // lattice points of the closed box (every other lattice point is at least 1 away), so nothing is rasterised
         const bool full = kind == WB_EV_OVERTURNING && a.r2 <= 1.0;
@@ -153,9 +202,130 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         const int x1 = bb[2] + epad > a.W - 1 ? a.W - 1 : bb[2] + epad;
         const int y1 = bb[3] + epad > a.nlat - 1 ? a.nlat - 1 : bb[3] + epad;
         const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
-        const bool lrow = rows <= WB_PROPS_LROWS;
+        bool lrow = rows <= WB_PROPS_LROWS;                              // per-row counts in LDS (not for the global raster: decided below)
 #define WB_ACC(q, y) (lrow ? lacc[(q) * WB_PROPS_LROWS + ((y) - y0)] : rowacc[(q) * a.nlat + (y)])
-        if (!full) {
+        WB_RSTAMP(a.ctl, 0);
+        const int wb = (cols + 31) >> 5;                                  // bitmap words per row
+        bool use_bm = !full && lrow && (long long)rows * wb <= WB_PROPS_BM && cols <= 0x7FFF;
+        if (use_bm) {
+            // A': signed crossings per row.  Edge a->b spanning row y (half-open in y) covers all x < x_cross.
+            WB_PFOR(q, rows)
+                xcnt[q] = 0;
+                if (q == 0) ovf[0] = 0;
+            WB_END_PFOR
+            WB_PFOR(q, rows * wb)
+                bm[q] = 0u;
+            WB_END_PFOR
+            WB_PFOR(k, n)
+                const uint32_t va = wb_event_vertex(d, pts, (int)k), vb = wb_event_vertex(d, pts, (int)((k + 1) % n));
+                const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+                if (ay != by) {
+                    const int ylo = ay < by ? ay : by, yhi = ay < by ? by : ay;
+                    for (int y = ylo; y < yhi; ++y) {
+                        int num = (y - ay) * (bx - ax), den = by - ay;        // lattice coordinates are < 2^15: exact in 32 bits
+                        if (den < 0) { num = -num; den = -den; }
+                        const int cdiv = num >= 0 ? (num + den - 1) / den : -((-num) / den);
+                        int ecol = ax + cdiv - 1;                            // last lattice x strictly left of the crossing
+                        if (ecol >= x0) {
+                            if (ecol > x1) ecol = x1;
+                            const int slot = wb_atomic_add(&xcnt[y - y0], 1);
+                            if (slot < WB_PROPS_K) xlist[(y - y0) * WB_PROPS_K + slot] = (unsigned short)((ecol - x0) | (by > ay ? 0 : 0x8000));
+                            else ovf[0] = 1;
+                        }
+                    }
+                }
+            WB_END_PFOR
+            if (ovf[0]) use_bm = false;                                  // a row crossed more often than its list holds
+            WB_RSTAMP(a.ctl, 1);
+        }
+        if (use_bm) {
+            // B': a lane per row sorts its crossings by column (descending) and sweeps: cells left of a crossing column take its
+            //     sign; winding number != 0 -> member
+            WB_PFOR(rr, rows)
+                const int c = xcnt[rr];
+                unsigned short* e = xlist + (int)rr * WB_PROPS_K;          // the row's own slots: sorted in place
+                for (int i = 1; i < c; ++i) {                              // insertion sort, descending by column
+                    const unsigned short v = e[i];
+                    int j = i - 1;
+                    while (j >= 0 && (e[j] & 0x7FFF) < (v & 0x7FFF)) { e[j + 1] = e[j]; --j; }
+                    e[j + 1] = v;
+                }
+                int run = 0, seen = 0;
+                uint32_t* row = bm + (int)rr * wb;
+                for (int i = 0; i < c;) {
+                    const int col = e[i] & 0x7FFF;
+                    while (i < c && (e[i] & 0x7FFF) == col) { run += (e[i] & 0x8000) ? -1 : 1; ++i; }
+                    const int lo = i < c ? (e[i] & 0x7FFF) + 1 : 0;         // cells lo .. col carry this winding number
+                    if (run != 0) {
+                        seen |= (run > 0 ? 1 : 2) | ((run > 1 || run < -1) ? 4 : 0);
+                        for (int w = lo >> 5; w <= col >> 5; ++w) {
+                            const int b0 = w == lo >> 5 ? lo & 31 : 0, b1 = w == col >> 5 ? col & 31 : 31;
+                            row[w] |= (b1 == 31 ? 0xFFFFFFFFu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+                        }
+                    }
+                }
+                if (seen & ~wseen[0]) wb_atomic_or(&wseen[0], seen);
+            WB_END_PFOR
+            WB_RSTAMP(a.ctl, 2);
+            // C': rim: lattice points closer than r to an edge (boundary points included: d = 0)
+            WB_PFOR(k, n)
+                const uint32_t va = wb_event_vertex(d, pts, (int)k), vb = wb_event_vertex(d, pts, (int)((k + 1) % n));
+                const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+                const long long dx = bx - ax, dy = by - ay, L = dx * dx + dy * dy;
+                if ((double)L * a.r2 <= 1.0 && a.r2 <= 1.0) {
+                    // short edge: only the lattice points ON it count (gcd + 1 of them, end points included)
+                    int g = (int)(dx < 0 ? -dx : dx), h = (int)(dy < 0 ? -dy : dy);
+                    while (h) { const int t = g % h; g = h; h = t; }
+                    if (g == 0) g = 1;
+                    const int sx = (int)dx / g, sy = (int)dy / g;
+                    for (int t = 0; t <= g; ++t) {
+                        const int x = ax + t * sx, y = ay + t * sy;
+                        if (x >= x0 && x <= x1 && y >= y0 && y <= y1) wb_atomic_or(&bm[(y - y0) * wb + ((x - x0) >> 5)], 1u << ((x - x0) & 31));
+                    }
+                    continue;
+                }
+                // long edge (a streamer's closing chord): queued and tested by the whole workgroup below; only if the queue is
+                // full does this lane walk the box itself
+                const int slot_e = wb_atomic_add(&nlong[0], 1);
+                if (slot_e < WB_PROPS_LONG) { longe[slot_e] = (int)k; continue; }
+                int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
+                int ey0 = (ay < by ? ay : by) - a.pad, ey1 = (ay < by ? by : ay) + a.pad;
+                if (ex0 < x0) ex0 = x0;
+                if (ex1 > x1) ex1 = x1;
+                if (ey0 < y0) ey0 = y0;
+                if (ey1 > y1) ey1 = y1;
+                for (int y = ey0; y <= ey1; ++y)
+                    for (int x = ex0; x <= ex1; ++x)
+                        if (wb_near_segment(x, y, ax, ay, bx, by, a.r2)) wb_atomic_or(&bm[(y - y0) * wb + ((x - x0) >> 5)], 1u << ((x - x0) & 31));
+            WB_END_PFOR
+            {
+                const int nq = nlong[0] < WB_PROPS_LONG ? nlong[0] : WB_PROPS_LONG;
+                for (int qe = 0; qe < nq; ++qe) {
+                    const int k = longe[qe];
+                    const uint32_t va = wb_event_vertex(d, pts, k), vb = wb_event_vertex(d, pts, (k + 1) % n);
+                    const int ax = wb_pt_x(va), ay = wb_pt_y(va), bx = wb_pt_x(vb), by = wb_pt_y(vb);
+                    int ex0 = (ax < bx ? ax : bx) - a.pad, ex1 = (ax < bx ? bx : ax) + a.pad;
+                    int ey0 = (ay < by ? ay : by) - a.pad, ey1 = (ay < by ? by : ay) + a.pad;
+                    if (ex0 < x0) ex0 = x0;
+                    if (ex1 > x1) ex1 = x1;
+                    if (ey0 < y0) ey0 = y0;
+                    if (ey1 > y1) ey1 = y1;
+                    const int ew = ex1 - ex0 + 1, eh = ey1 - ey0 + 1;
+                    if (ew <= 0 || eh <= 0) continue;                        // block-uniform
+                    WB_PFOR(c, (int64_t)ew * eh)
+                        const int x = ex0 + (int)(c / eh), y = ey0 + (int)(c % eh);
+                        if (wb_near_segment(x, y, ax, ay, bx, by, a.r2)) wb_atomic_or(&bm[(y - y0) * wb + ((x - x0) >> 5)], 1u << ((x - x0) & 31));
+                    WB_END_PFOR
+                }
+            }
+        }
+        if (use_bm) WB_RSTAMP(a.ctl, 3);
+        if (!full && !use_bm) {
+        lrow = false;
+        WB_SINGLE
+        nlong[0] = 0;                                                     // (the LDS attempt may have queued long edges)
+        wseen[0] = 0;
+        WB_END_SINGLE
         WB_PFOR(idx, (int64_t)rows * cols)
             cells[idx] = 0;
         WB_END_PFOR
@@ -252,47 +422,29 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         }
         }   // !full
         if (full) {
-            // D for boxes: every cell counts, so the integer sums are closed forms and the field sums are taken in tasks
-            // of 8 consecutive columns of one row with adjacent lanes on adjacent chunks (lane-per-row reads touch 64
-            // different DRAM rows per instruction and run at the chip's random-sector rate); a row's chunk partials are
-            // then added in ascending x by the lane that owns the row.
-            const int nch = (cols + 7) >> 3;
-            int rblk = WB_PROPS_PART / nch;
-            if (rblk < 1) rblk = 1;
-            for (int rb = 0; rb < rows; rb += rblk) {
-                const int nr = rows - rb < rblk ? rows - rb : rblk;
-                WB_PFOR(t, (int64_t)nr * nch)
-                    const int rr = rb + (int)(t / nch), ch = (int)(t % nch);
-                    const int y = y0 + rr;
-                    double sv = 0.0, si = 0.0;
-                    double dv[8], di[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int gx = x0 + ch * 8 + q;
-                        const bool in = ch * 8 + q < cols;
-                        const size_t idx = tbase + (size_t)y * a.nlon + (size_t)((gx < a.W ? gx : a.W - 1) % a.nlon);
-                        dv[q] = in ? wb_load_field(a.data, idx, a.dtype) : 0.0;
-                        di[q] = (in && a.intensity) ? wb_load_field(a.intensity, idx, a.dtype) : 0.0;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (ch * 8 + q < cols) { sv += dv[q]; si += di[q]; }
-                    if (nch <= WB_PROPS_PART) { lpart[2 * t] = sv; lpart[2 * t + 1] = si; }
-                    else { cells_d[2 * ((size_t)rr * nch + ch)] = sv; cells_d[2 * ((size_t)rr * nch + ch) + 1] = si; }
-                WB_END_PFOR
-                WB_PFOR(r2, nr)
-                    const int rr = rb + (int)r2, y = y0 + rr;
-                    double sv = 0.0, si = 0.0;
-                    for (int ch = 0; ch < nch; ++ch) {
-                        if (nch <= WB_PROPS_PART) { sv += lpart[2 * (r2 * nch + ch)]; si += lpart[2 * (r2 * nch + ch) + 1]; }
-                        else { sv += cells_d[2 * ((size_t)rr * nch + ch)]; si += cells_d[2 * ((size_t)rr * nch + ch) + 1]; }
-                    }
-                    WB_ACC(0, y) = (double)cols;
-                    WB_ACC(1, y) = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
-                    WB_ACC(2, y) = sv;
-                    WB_ACC(3, y) = si;
-                WB_END_PFOR
-            }
+            // D for boxes: every cell counts, so the integer sums are closed forms; the field sums with the lanes along the rows
+            WB_PFOR(rr, rows)
+                WB_ACC(0, y0 + (int)rr) = (double)cols;
+                WB_ACC(1, y0 + (int)rr) = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
+            WB_END_PFOR
+            wb_props_field_sums(a, tbase, x0, y0, rows, cols, nullptr, 0, lred);
+        } else if (use_bm) {
+            // D': integer counts per row from the bitmap (a lane per row) ...
+            WB_PFOR(rr, rows)
+                const uint32_t* row = bm + (int)rr * wb;
+                long long cnt = 0, sx = 0;
+                for (int w = 0; w < wb; ++w) {
+                    uint32_t v = row[w];
+                    const int pc = wb_popc32(v);
+                    cnt += pc;
+                    sx += (long long)pc * (x0 + 32 * w);
+                    while (v) { sx += wb_ctz32(v); v &= v - 1u; }
+                }
+                WB_ACC(0, y0 + (int)rr) = (double)cnt;
+                WB_ACC(1, y0 + (int)rr) = (double)sx;
+            WB_END_PFOR
+            // ... and the field sums with the lanes along the rows
+            wb_props_field_sums(a, tbase, x0, y0, rows, cols, bm, wb, lred);
         } else {
         // D: per-row counts and sums
         WB_PFOR(rr, rows)
@@ -328,19 +480,36 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             WB_ACC(3, y) = si;
         WB_END_PFOR
         }   // full / generic D
+        WB_RSTAMP(a.ctl, full ? 10 : (use_bm ? 4 : 11));
+        // the rows' products: every lane adds up its rows (one lane walking them all, a load of wlat per row, was a fifth of the
+        // kernel), the lanes' partial sums are then added in lane order.  (The row-wise sums are the fast path: within
+        // wb_com_ulps(rows) of the reference's compensated cell-wise sums whatever their order; the truncation test below
+        // decides whether that is enough.)
+        const bool lane_sums = full || use_bm;                             // (data, intensity) came from wb_props_field_sums
+        {
+            double pa = 0.0, px = 0.0, py = 0.0, pv = 0.0, pi = 0.0, pn = 0.0;
+            for (int y = y0 + WB_TID; y <= y1; y += WB_NT) {
+                const double cnt = WB_ACC(0, y);
+                if (cnt == 0.0) continue;
+                const double w = a.wlat[y];
+                pa = pa + w * cnt;
+                px = px + w * WB_ACC(1, y);
+                py = py + w * ((double)y * cnt);
+                if (!lane_sums) { pv = pv + w * WB_ACC(2, y); pi = pi + w * WB_ACC(3, y); }
+                pn += cnt;
+            }
+            if (lane_sums) { pv = lred[2 * WB_TID]; pi = lred[2 * WB_TID + 1]; }
+            WB_SYNC();
+            lrow6[6 * WB_TID + 0] = pa; lrow6[6 * WB_TID + 1] = px; lrow6[6 * WB_TID + 2] = py;
+            lrow6[6 * WB_TID + 3] = pv; lrow6[6 * WB_TID + 4] = pi; lrow6[6 * WB_TID + 5] = pn;
+            WB_SYNC();
+        }
         WB_SINGLE
         double areas = 0.0, mv = 0.0, it = 0.0, xc = 0.0, yc = 0.0;
         long long nc = 0;
-        for (int y = y0; y <= y1; ++y) {
-            const double cnt = WB_ACC(0, y);
-            if (cnt == 0.0) continue;
-            const double w = a.wlat[y];
-            areas = areas + w * cnt;
-            xc = xc + w * WB_ACC(1, y);
-            yc = yc + w * ((double)y * cnt);
-            mv = mv + w * WB_ACC(2, y);
-            it = it + w * WB_ACC(3, y);
-            nc += (long long)cnt;
+        for (int l = 0; l < WB_NT; ++l) {
+            areas = areas + lrow6[6 * l + 0]; xc = xc + lrow6[6 * l + 1]; yc = yc + lrow6[6 * l + 2];
+            mv = mv + lrow6[6 * l + 3]; it = it + lrow6[6 * l + 4]; nc += (long long)lrow6[6 * l + 5];
         }
         // boxes: areas / x_com / y_com come from wb_k_box_com (which ran beside the streamer kernels)
         if (full) {
@@ -358,7 +527,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                     const double yw = (double)y * w;
                     const int* col = cells + (y - y0);
                     for (int x = 0; x < cols; ++x) {
-                        if (!col[(size_t)x * rows]) continue;
+                        if (use_bm ? !wb_bm_test(bm, wb, y - y0, x) : !col[(size_t)x * rows]) continue;
                         const double xw = (double)(x0 + x) * w;
                         WB_KAHAN(sa, ca, w);
                         WB_KAHAN(sx, cx, xw);
@@ -399,11 +568,13 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 const int* col = cells + rr;
                 long long o = (long long)WB_ACC(0, y);
                 for (int x = 0; x < cols; ++x)
-                    if (full || col[(size_t)x * rows]) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
+                    if (full || (use_bm ? wb_bm_test(bm, wb, (int)rr, x) : col[(size_t)x * rows] != 0)) a.cell_pool[o++] = (uint32_t)(x0 + x) | ((uint32_t)y << 16);
             WB_END_PFOR
         }
 #undef WB_ACC
+        WB_RSTAMP(a.ctl, 5);
     }
+    WB_RSTAMP_FLUSH(a.ctl);
 }
 
 // areas / x_com / y_com of the overturning boxes (the events wb_k_props does not rasterise): every cell of the closed box
