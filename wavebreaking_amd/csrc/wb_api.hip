@@ -1105,6 +1105,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 st.recheck = (int*)talloc((size_t)st.recheck_cap * 4 * sizeof(int));
                 if (!st.recheck) { release(); return 1; }
             }
+            st.f234_cap = ((h1.max_len + 255) / 256) * 256;
+            if (st.f234_cap < 512) st.f234_cap = 512;
+            if (st.f234_cap > WB_F234_LPTS) st.f234_cap = WB_F234_LPTS;
             const bool need_tiled = st.p2_cap <= 0 || h1.max_len > st.p2_cap;
             st.ptab = need_tiled ? (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double)) : nullptr;
             if (need_tiled && !st.ptab) { release(); return 1; }
@@ -1162,7 +1165,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
-                WB_LAUNCH(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, st);
+                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 8 + ((size_t)st.f234_cap / 32 + 2) * 4 + 32, st);
                 WB_LAUNCH(wb_k_streamer_ties, (nsel_b + 63) / 64, 64, st);
                 b->timer.end(ctx);
             }

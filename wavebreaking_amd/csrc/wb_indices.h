@@ -265,6 +265,7 @@ struct WbStreamerArgs {
     double geo_band;           // ABSOLUTE guard band on h around hthr (WB_GEO_BAND * hthr, widened by the grid's irregularity)
     int p2_cap;                // contour points its LDS holds; 0: kernel not used (every contour in the tiled kernel's list)
     int p2_split;              // workgroups per contour
+    int f234_cap;              // wb_k_streamer_f234: contour points its dynamic LDS holds (8 bytes each + a bit)
     int* recheck;              // [recheck_cap][4] pairs inside a guard band: contour, i, j, 0 (wb_k_streamer_recheck decides them)
     int recheck_cap;
 };
@@ -992,7 +993,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #ifndef WB_F1_THREADS
 #define WB_F1_THREADS 1024         // routine 1: its duration is that of the few contours with tens of thousands of pairs (0.39 -> 0.27 ms against 256)
 #endif
-#define WB_F234_CAND 1024          // candidates of one row collected after its first chord failed
+#define WB_F234_CAND 512           // candidates of one row collected after its first chord failed
 #define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
 WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
@@ -1012,9 +1013,12 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     int* mj = mi + (P < N ? P : N) + 1;                              // [M] ind2
     int* lab = mj + (P < N ? P : N) + 1;                             // [M] group label
     int* aux = lab + (P < N ? P : N) + 1;                            // [M] scratch of the group scan
-    WB_SHARED(uint32_t, lpts, WB_F234_LPTS);
-    WB_SHARED(int, lrmax, WB_F234_LPTS);         // per row: largest ind2 among its alive candidates
-    WB_SHARED(uint32_t, nebits, WB_F234_LPTS / 32);   // rows that still hold a candidate above M
+    // the contour's points and per-row maxima in LDS, sized by the launch for the batch's longest contour (a.f234_cap points,
+    // at most WB_F234_LPTS: with a fixed 4096 the kernel held three workgroups per CU, sized to a 0.25 degree contour four)
+    WB_DYN_SHARED_BEGIN
+    WB_DYN_SHARED(uint32_t, lpts, a.f234_cap);
+    WB_DYN_SHARED(int, lrmax, a.f234_cap);       // per row: largest ind2 among its alive candidates
+    WB_DYN_SHARED(uint32_t, nebits, a.f234_cap / 32 + 1);   // rows that still hold a candidate above M
     WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
     WB_SHARED(int, csort, WB_F234_CAND);
     WB_SHARED(int, hitf, WB_F234_BATCH);
@@ -1022,7 +1026,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
                                          // (words alternate between two slots: a slot is rewritten two barriers after its last read)
     const int stage = a.stage[s];
     const int nal = a.nalive[s];
-    const bool in_lds = N <= WB_F234_LPTS;
+    const bool in_lds = N <= a.f234_cap;
     const uint32_t* pts = in_lds ? lpts : gpts;
     int* rmax = in_lds ? lrmax : a.rowmx + a.poff[s];
     const int nw = (N + 31) >> 5;

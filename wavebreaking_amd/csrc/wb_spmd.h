@@ -37,6 +37,10 @@ extern int wb_hostsim_reverse;
 #define WB_END_SINGLE }
 #define WB_SYNC() ((void)0)
 #define WB_SHARED(type, name, n) type name[n]
+// arrays in the launch's dynamic LDS (WB_LAUNCH_LDS), carved in the order of their declarations, 8-byte aligned
+#include <vector>
+#define WB_DYN_SHARED_BEGIN
+#define WB_DYN_SHARED(type, name, n) std::vector<type> name##_store((size_t)(n) + 1); type* name = name##_store.data()
 template <class T> static inline T wb_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T wb_atomic_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T wb_atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
@@ -98,6 +102,9 @@ static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
     __syncthreads();
 #define WB_SYNC() __syncthreads()
 #define WB_SHARED(type, name, n) __shared__ type name[n]
+// arrays in the launch's dynamic LDS (WB_LAUNCH_LDS), carved in the order of their declarations, 8-byte aligned
+#define WB_DYN_SHARED_BEGIN extern __shared__ __attribute__((aligned(16))) unsigned char wb_dyn_lds_[]; size_t wb_dyn_off_ = 0;
+#define WB_DYN_SHARED(type, name, n) type* name = (type*)(wb_dyn_lds_ + wb_dyn_off_); wb_dyn_off_ += ((size_t)(n) * sizeof(type) + 7) & ~(size_t)7
 template <class T> __device__ inline T wb_atomic_add(T* p, T v) { return atomicAdd(p, v); }
 template <class T> __device__ inline T wb_atomic_min(T* p, T v) { return atomicMin(p, v); }
 template <class T> __device__ inline T wb_atomic_max(T* p, T v) { return atomicMax(p, v); }

@@ -236,8 +236,10 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     uint32_t* succ = a.w[0] + jb;
     uint32_t* pred = a.w[1] + jb;
     uint32_t* t0 = a.w[8] + jb;
-    WB_SHARED(uint32_t, ks, WB_TRACE_LDS_N);      // keys of all strips, strip after strip
-    WB_SHARED(uint32_t, mk, WB_TRACE_LDS_N);      // merged keys
+    // keys in LDS: first those of all strips, strip after strip (the merge's binary searches), then -- the same 32 KiB --
+    // the merged list (the successor searches): two arrays at once kept the kernel at two workgroups per CU
+    WB_SHARED(uint32_t, ks, WB_TRACE_LDS_N);
+    uint32_t* mk = ks;
     WB_SHARED(int, sbase, WB_MAX_LISTS + 1);
 
     // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
@@ -318,7 +320,6 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         // job is flagged for the caller's information
         if (ul == level || ur == level || ll == level || lr == level) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_HIT);
         segk[dest] = key;
-        if (lds) mk[dest] = key;
         const int sfrom = wb_seg_from(cs, sub), sto = wb_seg_to(cs, sub);
         segf[dest] = wb_crossing_point(sfrom, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sfrom, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
         segt[dest] = wb_crossing_point(sto, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sto, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
@@ -328,6 +329,11 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
 
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
     //          the edge this one ends on (binary search by square key in the merged list)
+    if (lds) {
+        WB_PFOR(i, n)
+            mk[i] = segk[i];                     // (the strips' keys are done with)
+        WB_END_PFOR
+    }
     const uint32_t* keys = lds ? mk : segk;
     WB_PFOR(i, n)
         const uint32_t k = keys[i];
@@ -436,6 +442,85 @@ WB_DEV inline void wb_rank_lists(int n, IT nil, const uint32_t* succ_g, uint32_t
     WB_END_PFOR
 }
 
+// The same two passes for a job whose links fit 16 bits, with ONE copy of every array in LDS (three arrays, 48 KiB for 8192
+// segments: two workgroups per CU; the double-buffered version above needs seven arrays, 112 KiB, one workgroup per CU).  A
+// round reads its new values into registers, waits, writes them back: a thread owns WB_RANK_EPT strided elements.  D shares
+// P's storage (P is dead once pass 2 has copied it).
+#define WB_RANK_EPT ((WB_TRACE_LDS_N + WB_RANK_THREADS - 1) / WB_RANK_THREADS)
+#if defined(WB_HOSTSIM)
+#define WB_RANK_TMP(name) std::vector<uint16_t> name((size_t)n + 1)
+#define WB_RANK_K_LOOP for (int k = 0; k < n; ++k)
+#define WB_RANK_I(k) (k)
+#else
+#define WB_RANK_TMP(name) uint16_t name[WB_RANK_EPT]
+#define WB_RANK_K_LOOP _Pragma("unroll") for (int k = 0; k < WB_RANK_EPT; ++k)
+#define WB_RANK_I(k) (WB_TID + (k) * WB_NT)
+#endif
+WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0_g, uint16_t* P, uint16_t* J, uint16_t* A,
+                                     uint32_t* start_g, uint32_t* dist_g) {
+    const uint16_t nil = (uint16_t)0xFFFF;
+    uint16_t* D = P;
+    int rounds = 0;
+    while ((1 << rounds) < n) ++rounds;
+    WB_RANK_TMP(tj);
+    WB_RANK_TMP(ta);
+    WB_RANK_TMP(td);
+    WB_PFOR(i, n)
+        J[i] = P[i];
+        A[i] = (uint16_t)i;
+    WB_END_PFOR
+    for (int it = 0; it < rounds; ++it) {               // pass 1: running maximum over the predecessors
+        WB_RANK_K_LOOP {
+            const int i = WB_RANK_I(k);
+            if (i < n) {
+                const uint16_t j = J[i];
+                if (j != nil) { const uint16_t m1 = A[i], m2 = A[j]; ta[k] = m1 > m2 ? m1 : m2; tj[k] = J[j]; }
+                else { ta[k] = A[i]; tj[k] = nil; }
+            }
+        }
+        WB_SYNC();
+        WB_RANK_K_LOOP {
+            const int i = WB_RANK_I(k);
+            if (i < n) { J[i] = tj[k]; A[i] = ta[k]; }
+        }
+        WB_SYNC();
+    }
+    WB_PFOR(i, n)   // cut every loop after its raster-last segment
+        if (J[i] != nil && A[i] == (uint16_t)i) {
+            const uint32_t s = succ_g[i];
+            t0_g[s] = 1;
+            P[s] = nil;
+        }
+    WB_END_PFOR
+    WB_PFOR(i, n)
+        J[i] = P[i];
+        A[i] = (uint16_t)i;
+    WB_END_PFOR
+    WB_PFOR(i, n)                                         // (every P has been copied: its storage becomes D)
+        D[i] = (uint16_t)1;
+    WB_END_PFOR
+    for (int it = 0; it < rounds; ++it) {               // pass 2: list ranking
+        WB_RANK_K_LOOP {
+            const int i = WB_RANK_I(k);
+            if (i < n) {
+                const uint16_t j = J[i];
+                if (j != nil) { ta[k] = A[j]; td[k] = (uint16_t)(D[i] + D[j]); tj[k] = J[j]; }
+                else { ta[k] = A[i]; td[k] = D[i]; tj[k] = nil; }
+            }
+        }
+        WB_SYNC();
+        WB_RANK_K_LOOP {
+            const int i = WB_RANK_I(k);
+            if (i < n) { J[i] = tj[k]; A[i] = ta[k]; D[i] = td[k]; }
+        }
+        WB_SYNC();
+    }
+    WB_PFOR(i, n)
+        start_g[i] = (uint32_t)A[i];
+        dist_g[i] = (uint32_t)D[i];
+    WB_END_PFOR
+}
+
 WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
@@ -448,15 +533,13 @@ WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
     uint32_t* start = a.w[4] + jb;
     uint32_t* dist = a.w[6] + jb;
     if (n <= WB_TRACE_LDS_N) {
-        WB_SHARED(uint16_t, lds, 7 * WB_TRACE_LDS_N);     // 112 KiB: P, J0, J1, A0, A1, D0, D1 (dist <= n <= 8192 fits)
+        WB_SHARED(uint16_t, lds, 3 * WB_TRACE_LDS_N);     // 48 KiB: P (later D), J, A (dist <= n <= 8192 fits 16 bits)
         uint16_t* P = lds;
         WB_PFOR(i, n)
             const uint32_t v = pred[i];
             P[i] = v == WB_NIL ? (uint16_t)0xFFFF : (uint16_t)v;
         WB_END_PFOR
-        wb_rank_lists<uint16_t>(n, (uint16_t)0xFFFF, succ, t0, P, lds + 1 * WB_TRACE_LDS_N, lds + 2 * WB_TRACE_LDS_N,
-                                lds + 3 * WB_TRACE_LDS_N, lds + 4 * WB_TRACE_LDS_N, lds + 5 * WB_TRACE_LDS_N,
-                                lds + 6 * WB_TRACE_LDS_N, start, dist);
+        wb_rank_lists_lds(n, succ, t0, P, lds + 1 * WB_TRACE_LDS_N, lds + 2 * WB_TRACE_LDS_N, start, dist);
     } else {
         // big job: same algorithm on 32-bit links in global memory; buffers J: w[2], w[3]; A: w[5], w[7]; D: w[9], w[10]
         wb_rank_lists<uint32_t>(n, (uint32_t)WB_NIL, succ, t0, pred, a.w[2] + jb, a.w[3] + jb, a.w[5] + jb, a.w[7] + jb,
