@@ -51,6 +51,8 @@ def parse():
                     help="1: streaming scan (patch capture) + list build kernel; 0: single classify-and-emit kernel")
     ap.add_argument("--scan-variant", type=int, default=int(os.environ.get("WB_BENCH_SCAN_VARIANT", 2)),
                     help="streaming scan: ring depth x waves per SIMD (0: 8x6, 1: 10x5, 2: 13x4, 3: 6x8)")
+    ap.add_argument("--stagger-steps", type=int, default=int(os.environ.get("WB_BENCH_STAGGER_STEPS", 20)),
+                    help="passes of the staggered-phases measurement after the timed region (N = 1, two batches in flight); 0 = skip")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WB_BENCH_STREAMS", 2)),
                     help="batches in flight per GPU (contexts = HIP streams + host threads); 1 = strictly one after the other")
     return ap.parse_args()
@@ -235,6 +237,28 @@ def main():
     pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True), full_width=full_w)
     barrier()
     dt = time.perf_counter() - tic
+    # the same passes with the phases staggered (one batch's scan + trace kernels beside the other's index kernels, never
+    # two scans at once): what the HBM-bound kernel keeps of the roofline when it does not share HBM with its twin, and
+    # what that ordering costs the whole job.  After the timed region; reported next to it, never as `value`.
+    staggered = None
+    if not multi and pipe.depth > 1 and a.stagger_steps > 0:
+        pipe.set_stagger(1)
+        st_ms = []
+
+        def collect_scan(k, res):
+            st_ms.append(dict(res["timings"]).get("scan", float("nan")))
+            return res
+        pipe.run(3, phase1, reduce_max, phase2, lambda k, res: res, full_width=full_w)
+        torch.cuda.synchronize()
+        tic_s = time.perf_counter()
+        pipe.run(a.stagger_steps, phase1, reduce_max, phase2, collect_scan, full_width=full_w)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - tic_s
+        pipe.set_stagger(0)
+        sc = float(np.mean(st_ms))
+        staggered = {"value": nt * a.stagger_steps / dt_s, "ms_per_step": 1e3 * dt_s / a.stagger_steps, "steps": a.stagger_steps,
+                     "scan_launch_ms": sc, "roofline_frac": nt * nlat * nlon * 4 / (sc * 1e-3) / HBM_PEAK,
+                     "what": "BatchPipeline.set_stagger(1): each ABI phase entered by one batch at a time"}
     verify = None
     if multi:
         cdev = device if dist.get_backend() == "nccl" else "cpu"
@@ -295,6 +319,8 @@ def main():
         }
         if verify is not None:
             out.update(verify)
+        if staggered is not None:
+            out["staggered_phases"] = staggered
         if world == 1 and a.e2e_steps > 0:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
 // level (square cases, block scan for the raster-ordered positions, key + four corner values per segment, periodic
 // copies) -- the staging format the trace kernels read.  It touches the captured patches only (a few % of the field).
 // Patch layout: value k (0..4 upper row, 5..9 lower row) of patch i of a list at cap_v[list][k * cap_rec + i].
-#define WB_BUILD_CHUNK 2048
+#define WB_BUILD_CHUNK 1024
 // in-place exclusive scan of 64-bit values in LDS (two 32-bit counters per word, no carry between them as long as each
 // stays below 2^32); every thread of the block calls it; returns the total
 __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* a, int n) {
@@ -524,48 +524,79 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
         gl = ((size_t)t * nbands + band) * NSB + s;
         li = i - boff[band];
     };
-    for (int l = 0; l < NLEV; ++l) {
-        const T lv = wb_level_lo<T>(a.levels[l]);
-        const size_t base = ((size_t)(t * NLEV + l) * NS + s) * a.cap_strip;
-        const size_t cbase = ((size_t)(t * NLEV + l) * NS + NSB + s) * a.cap_strip;
-        unsigned long long cur = 0ull;                         // segments written so far: base list | copy list << 32
-        for (int q0 = 0; q0 < total; q0 += WB_BUILD_CHUNK) {
-            const int nq = total - q0 < WB_BUILD_CHUNK ? total - q0 : WB_BUILD_CHUNK;
-            for (int i = threadIdx.x; i < nq; i += blockDim.x) {
-                size_t gl; int li;
-                locate(q0 + i, gl, li);
-                const uint32_t key = a.cap_k[gl * cs + li];
-                const int c0 = (int)(key & 0xFFFFu);
-                const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
-                unsigned nb = 0, nc = 0;
+    // A chunk of patches at a time: (1) every patch's ten values are read ONCE and the square cases of all levels go to LDS
+    // (four bits per square, sixteen per level); (2) per level: segment counts from the cached cases, block scan, and the
+    // values are read again only by the patches that hold a segment of THAT level (the two PV levels live in different
+    // hemispheres: half the patches).  Reading the values per level and pass cost four reads of every patch.
+    __shared__ unsigned long long lcase[WB_BUILD_CHUNK];
+    T lvl[NLEV];
+    unsigned long long cur[NLEV];                            // segments written so far: base list | copy list << 32
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
-                    const bool ok = (c0 + k < cmax) && ul == ul && ur == ur && ll == ll && lr == lr;
+    for (int l = 0; l < NLEV; ++l) { lvl[l] = wb_level_lo<T>(a.levels[l]); cur[l] = 0ull; }
+    for (int q0 = 0; q0 < total; q0 += WB_BUILD_CHUNK) {
+        const int nq = total - q0 < WB_BUILD_CHUNK ? total - q0 : WB_BUILD_CHUNK;
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+            size_t gl; int li;
+            locate(q0 + i, gl, li);
+            const uint32_t key = a.cap_k[gl * cs + li];
+            const int c0 = (int)(key & 0xFFFFu);
+            const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
+            T v[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v[k] = d[k * cs];
+            unsigned long long word = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const T ul = v[k], ur = v[k + 1], ll = v[5 + k], lr = v[6 + k];
+                const bool ok = (c0 + k < cmax) && ul == ul && ur == ur && ll == ll && lr == lr;
+#pragma unroll
+                for (int l = 0; l < NLEV; ++l) {
+                    const T lv = lvl[l];
                     const int cs2 = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
-                    const int ns = wb_case_nseg(cs2);
-                    nb += ns;
-                    if (c0 + k < a.padd - 1) nc += ns;
+                    word |= (unsigned long long)cs2 << (16 * l + 4 * k);
+                }
+            }
+            lcase[i] = word;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < NLEV; ++l) {
+            const size_t base = ((size_t)(t * NLEV + l) * NS + s) * a.cap_strip;
+            const size_t cbase = ((size_t)(t * NLEV + l) * NS + NSB + s) * a.cap_strip;
+            for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+                const unsigned cw = (unsigned)(lcase[i] >> (16 * l)) & 0xFFFFu;
+                unsigned nb = 0, nc = 0;
+                if (cw) {
+                    size_t gl; int li;
+                    locate(q0 + i, gl, li);
+                    const int c0 = (int)(a.cap_k[gl * cs + li] & 0xFFFFu);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int ns = wb_case_nseg((int)(cw >> (4 * k)) & 15);
+                        nb += ns;
+                        if (c0 + k < a.padd - 1) nc += ns;
+                    }
                 }
                 cb[i] = (unsigned long long)nb | ((unsigned long long)nc << 32);
             }
             __syncthreads();
             const unsigned long long tot = wb_block_scan_excl_u64(cb, nq);
             for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+                const unsigned cw = (unsigned)(lcase[i] >> (16 * l)) & 0xFFFFu;
+                if (!cw) continue;                                   // no segment of this level in the patch: nothing to read
                 size_t gl; int li;
                 locate(q0 + i, gl, li);
                 const uint32_t key = a.cap_k[gl * cs + li];
                 const int r = (int)(key >> 16), c0 = (int)(key & 0xFFFFu);
                 const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
-                const unsigned long long at = cur + cb[i];
+                const unsigned long long at = cur[l] + cb[i];
                 int mine = (int)(at & 0xFFFFFFFFull), cmine = (int)(at >> 32);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
-                    const bool ok = (c0 + k < cmax) && ul == ul && ur == ur && ll == ll && lr == lr;
-                    const int cs2 = ok ? ((ul > lv ? 1 : 0) | (ur > lv ? 2 : 0) | (ll > lv ? 4 : 0) | (lr > lv ? 8 : 0)) : 0;
+                    const int cs2 = (int)(cw >> (4 * k)) & 15;
                     const int ns = wb_case_nseg(cs2);
                     if (ns) {
+                        const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
                         wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs2, ns, ul, ur, ll, lr, mine);
                         if (has_copy && c0 + k < a.padd - 1)
                             wb_store_square<T>(a.stg_k + cbase, (T*)a.stg_v + cbase * 4, a.cap_strip, W, r, c0 + k + nlon, cs2, ns, ul, ur, ll, lr, cmine);
@@ -575,12 +606,15 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                 }
             }
             __syncthreads();
-            cur += tot;
+            cur[l] += tot;
         }
-        if (threadIdx.x == 0) {
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l < NLEV; ++l) {
             // an overflowed patch list makes the segment count overflow too: the host grows the capacities and re-runs
-            a.stg_n[(t * NLEV + l) * NS + s] = excess ? a.cap_strip + 1 + excess : (int)(cur & 0xFFFFFFFFull);
-            if (has_copy) a.stg_n[(t * NLEV + l) * NS + NSB + s] = (int)(cur >> 32);
+            a.stg_n[(t * NLEV + l) * NS + s] = excess ? a.cap_strip + 1 + excess : (int)(cur[l] & 0xFFFFFFFFull);
+            if (has_copy) a.stg_n[(t * NLEV + l) * NS + NSB + s] = (int)(cur[l] >> 32);
         }
     }
 }

@@ -33,7 +33,9 @@
 
 #if !defined(WB_HOSTSIM)
 #define WB_STREAM_FLUSH 32         // patches in the wave's LDS buffer that trigger a flush
+#ifndef WB_STREAM_LBUF
 #define WB_STREAM_LBUF 160         // its capacity: a row adds at most 64
+#endif
 // D = ring depth (D - 1 row loads in flight per wave); WPS = waves per SIMD the register allocation must leave room for
 // spin until the LDS word at byte address `lds_addr` equals `tag` (both wave-uniform).  One opaque instruction for the
 // compiler: a loop in the source would sit inside every unrolled step of the kernel below and cost it its register

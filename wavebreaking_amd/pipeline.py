@@ -18,15 +18,30 @@ order on ONE thread -- the all-reduce of the selection maximum between the phase
 a multi-GPU run -- is done by the caller's thread, batch after batch, so every rank issues its collectives in the same
 order no matter how the workers interleave.
 """
+import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 from wavebreaking_amd import _hip
 
 
 class BatchPipeline:
-    def __init__(self, device=0, depth=2, library=None):
+    def __init__(self, device=0, depth=2, library=None, stagger=None):
         self.contexts = [_hip.Context(device, library) for _ in range(max(1, int(depth)))]
         self._workers = [ThreadPoolExecutor(max_workers=1) for _ in self.contexts]
+        # stagger: the two phases of the ABI are each entered by one batch at a time, so that in steady state one batch's
+        # phase 1 (the HBM-bound scan + the trace kernels) runs beside the other's phase 2 instead of beside its twin
+        if stagger is None:
+            stagger = int(os.environ.get("WB_PIPE_STAGGER", "0"))
+        stagger = int(stagger)                                   # 1: both phases exclusive, 2: phase 1 only, 3: phase 2 only
+        self._locks = (threading.Lock() if stagger in (1, 2) else None, threading.Lock() if stagger in (1, 3) else None) if stagger else None
+
+    def set_stagger(self, mode):
+        """0: the batches' phases overlap freely (most timesteps/s); 1: each phase is entered by one batch at a time -- one
+        batch's scan + trace kernels then run beside the other's index kernels, never beside their twins (the scan keeps
+        ~0.62 of the HBM peak instead of ~0.55, the whole job loses ~12 %); 2 / 3: only phase 1 / only phase 2 exclusive"""
+        mode = int(mode)
+        self._locks = (threading.Lock() if mode in (1, 2) else None, threading.Lock() if mode in (1, 3) else None) if mode else None
 
     @property
     def depth(self):
@@ -48,6 +63,21 @@ class BatchPipeline:
         closes the batch).  Caller's thread, in batch order: ``reduce_max`` and ``collect(k, r)``.  Returns the list of
         ``collect`` results.  ``full_width``: the extent every batch's maximum must reach (see the module docstring)."""
         d = self.depth
+        if self._locks is not None:
+            l1, l2 = self._locks
+            raw_contours, raw_indices = contours, indices
+
+            def contours(ctx, k):
+                if l1 is None:
+                    return raw_contours(ctx, k)
+                with l1:
+                    return raw_contours(ctx, k)
+
+            def indices(ctx, k, b, g):
+                if l2 is None:
+                    return raw_indices(ctx, k, b, g)
+                with l2:
+                    return raw_indices(ctx, k, b, g)
         c_fut, i_fut, out = {}, {}, []
         for k in range(min(d, n)):
             c_fut[k] = self._workers[k % d].submit(contours, self.contexts[k % d], k)
