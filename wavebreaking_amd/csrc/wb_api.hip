@@ -209,6 +209,7 @@ static int run_phase1(wb_batch* b) {
     std::vector<void*>& sc = b->phase1_scratch;
     for (int i = 0; i < 11; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
     ta.nseg = balloc<int>(b, J); sc.push_back(ta.nseg);
+    ta.p4 = balloc<int>(b, 2 * (size_t)J); sc.push_back(ta.p4);
     for (int i = 0; i < 3; ++i) { ta.mseg[i] = balloc<uint32_t>(b, per); sc.push_back(ta.mseg[i]); }
     ta.rawpt = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawpt);
     ta.rawcid = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawcid);
@@ -381,6 +382,7 @@ static int run_phase1(wb_batch* b) {
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_rank");
     WB_LAUNCH(wb_k_trace_rank, J, WB_RANK_THREADS, ta);
+    WB_LAUNCH(wb_k_trace_rank_big, J, WB_RANK_THREADS, ta);   // jobs of more than WB_TRACE_LDS_N segments only
     WB_LAUNCH(wb_k_trace_walk, J, 64, ta);            // jobs flagged WB_ST_LEVEL_ORDER only: skimage's sequential walk, one lane each
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_finish");
@@ -1010,7 +1012,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.truncate(b->timer_phase1);
         WbCtl* ctl = b->d_ctl;
         // the phase-2 part of the control block starts from zero (phase-1 values stay)
+#if defined(WB_STAMPS) && WB_STAMPS == 4                                 // (the stamps of a phase-1 kernel survive into the snapshot)
+        dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, offsetof(WbCtl, dbg) - offsetof(WbCtl, nsel));
+#else
         dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, sizeof(WbCtl) - offsetof(WbCtl, nsel));
+#endif
 
         // ---- selection
         WbSelectArgs sa;

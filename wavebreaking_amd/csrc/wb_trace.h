@@ -47,6 +47,7 @@ struct WbTraceArgs {
     int* ncont;              // [njobs]
     uint32_t* status;        // [njobs]
     int* nseg;               // [njobs] merged segment count (-1: job skipped)
+    int* p4;                 // [njobs][2] contours and raw points of a job the rank kernel has numbered itself (-1: finish does it)
     WbCtl* ctl;              // batch counters (capacity checks, maxima)
 };
 
@@ -448,23 +449,34 @@ WB_DEV inline void wb_rank_lists(int n, IT nil, const uint32_t* succ_g, uint32_t
 // P's storage (P is dead once pass 2 has copied it).
 #define WB_RANK_EPT ((WB_TRACE_LDS_N + WB_RANK_THREADS - 1) / WB_RANK_THREADS)
 #if defined(WB_HOSTSIM)
-#define WB_RANK_TMP(name) std::vector<uint16_t> name((size_t)n + 1)
+#define WB_RANK_TMP(name) std::vector<uint32_t> name((size_t)n + 1)
 #define WB_RANK_K_LOOP for (int k = 0; k < n; ++k)
 #define WB_RANK_I(k) (k)
 #else
-#define WB_RANK_TMP(name) uint16_t name[WB_RANK_EPT]
+#define WB_RANK_TMP(name) uint32_t name[WB_RANK_EPT]
 #define WB_RANK_K_LOOP _Pragma("unroll") for (int k = 0; k < WB_RANK_EPT; ++k)
 #define WB_RANK_I(k) (WB_TID + (k) * WB_NT)
 #endif
+// With `nb` (not for jobs the sequential walk will redo) the kernel goes on while start and position are still in LDS:
+// contours numbered by their raster-first segment, the raw point layout and the raw points themselves -- what used to be
+// the first ten barrier-separated phases of the finish kernel, each a few round trips to L2 (40 % of its time).
+#ifndef WB_TRACE_FUSE_P4
+#define WB_TRACE_FUSE_P4 1
+#endif
+struct WbNumberOut {
+    const uint32_t* segf; const uint32_t* segt;
+    uint32_t* rawpt; uint32_t* rawcid;      // [2 * cap_seg]
+    int* cnt; int* rawbase; int* closed;     // per contour: segments, first raw point, closed flag
+    int* CR;                                 // [2]: contours, raw points
+};
 WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0_g, uint16_t* P, uint16_t* J, uint16_t* A,
-                                     uint32_t* start_g, uint32_t* dist_g) {
+                                     uint32_t* start_g, uint32_t* dist_g, const bool fuse, const WbNumberOut nb) {
     const uint16_t nil = (uint16_t)0xFFFF;
     uint16_t* D = P;
     int rounds = 0;
     while ((1 << rounds) < n) ++rounds;
-    WB_RANK_TMP(tj);
-    WB_RANK_TMP(ta);
-    WB_RANK_TMP(td);
+    WB_RANK_TMP(t1);                                     // a round's new values, two 16-bit fields per register
+    WB_RANK_TMP(t2);
     WB_PFOR(i, n)
         J[i] = P[i];
         A[i] = (uint16_t)i;
@@ -474,14 +486,14 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0
             const int i = WB_RANK_I(k);
             if (i < n) {
                 const uint16_t j = J[i];
-                if (j != nil) { const uint16_t m1 = A[i], m2 = A[j]; ta[k] = m1 > m2 ? m1 : m2; tj[k] = J[j]; }
-                else { ta[k] = A[i]; tj[k] = nil; }
+                if (j != nil) { const uint16_t m1 = A[i], m2 = A[j]; t1[k] = (uint32_t)(m1 > m2 ? m1 : m2) << 16 | J[j]; }
+                else t1[k] = (uint32_t)A[i] << 16 | nil;
             }
         }
         WB_SYNC();
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) { J[i] = tj[k]; A[i] = ta[k]; }
+            if (i < n) { J[i] = (uint16_t)t1[k]; A[i] = (uint16_t)(t1[k] >> 16); }
         }
         WB_SYNC();
     }
@@ -504,57 +516,172 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0
             const int i = WB_RANK_I(k);
             if (i < n) {
                 const uint16_t j = J[i];
-                if (j != nil) { ta[k] = A[j]; td[k] = (uint16_t)(D[i] + D[j]); tj[k] = J[j]; }
-                else { ta[k] = A[i]; td[k] = D[i]; tj[k] = nil; }
+                if (j != nil) { t1[k] = (uint32_t)(uint16_t)(D[i] + D[j]) << 16 | A[j]; t2[k] = J[j]; }
+                else { t1[k] = (uint32_t)D[i] << 16 | A[i]; t2[k] = nil; }
             }
         }
         WB_SYNC();
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) { J[i] = tj[k]; A[i] = ta[k]; D[i] = td[k]; }
+            if (i < n) { J[i] = (uint16_t)t2[k]; A[i] = (uint16_t)t1[k]; D[i] = (uint16_t)(t1[k] >> 16); }
         }
         WB_SYNC();
     }
-    WB_PFOR(i, n)
-        start_g[i] = (uint32_t)A[i];
-        dist_g[i] = (uint32_t)D[i];
+    if (!fuse) {
+        WB_PFOR(i, n)
+            start_g[i] = (uint32_t)A[i];
+            dist_g[i] = (uint32_t)D[i];
+        WB_END_PFOR
+        return;
+    }
+    // ---- numbering and raw points (contour_index.py:103: skimage's contours come in the order of their raster-first segments)
+    // t1 = start | position << 16 | TAIL (last segment of its chain: no successor, or a successor that heads a chain -- the
+    // cut of a loop) | LEAD (raster-first segment of its contour); positions are <= 8192, bits 30 and 31 are free
+    const uint32_t TAIL = 1u << 30, LEAD = 1u << 31;
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) {
+            const uint32_t s = succ_g[i];
+            t1[k] = (uint32_t)A[i] | (uint32_t)D[i] << 16 | ((s == WB_NIL || D[s] == 1) ? TAIL : 0u);
+        }
+    }
+    WB_SYNC();
+    // contour_index.py:109 calls a contour closed when its first and last float coordinates are equal: besides the loops
+    // cut above that is an OPEN chain that leaves and reaches the same grid vertex (cells equal to the level)
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n && succ_g[i] == WB_NIL && (nb.segt[i] & WB_PT_VERTEX)) {
+            const uint32_t s = t1[k] & 0xFFFFu;
+            if (nb.segf[s] == nb.segt[i]) t0_g[s] = 1;
+        }
+    }
+    uint32_t* M = (uint32_t*)P;                           // P's and J's storage as n 32-bit words; A's as 16-bit counts
+    uint16_t* cnt16 = A;
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) M[i] = WB_NIL;
+    }
+    WB_SYNC();
+    WB_RANK_K_LOOP {                                      // ascending i per thread: after the first sweep most compares fail without an atomic
+        const int i = WB_RANK_I(k);
+        if (i < n && (uint32_t)i < M[t1[k] & 0xFFFFu]) wb_atomic_min(&M[t1[k] & 0xFFFFu], (uint32_t)i);
+    }
+    WB_SYNC();
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n && M[t1[k] & 0xFFFFu] == (uint32_t)i) t1[k] |= LEAD;
+    }
+    WB_SYNC();
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) M[i] = (t1[k] & LEAD) ? 1u : 0u;
+    }
+    WB_SYNC();
+    const int C = wb_block_scan_excl((int*)M, n);
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n && (t1[k] & LEAD)) t2[k] = M[i];
+    }
+    WB_SYNC();
+    WB_RANK_K_LOOP {                                      // M becomes: contour number, by start segment
+        const int i = WB_RANK_I(k);
+        if (i < n && (t1[k] & LEAD)) M[t1[k] & 0xFFFFu] = t2[k];
+    }
+    WB_SYNC();
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) {
+            t2[k] = M[t1[k] & 0xFFFFu];
+            if (t1[k] & TAIL) cnt16[t2[k]] = (uint16_t)((t1[k] >> 16) & 0x3FFFu);   // the last segment's position = segments of the contour
+        }
+    }
+    WB_SYNC();
+    WB_PFOR(c, C)
+        M[c] = (uint32_t)cnt16[c] + 1u;
+        nb.cnt[c] = (int)cnt16[c];
     WB_END_PFOR
+    const int R = wb_block_scan_excl((int*)M, C);
+    WB_PFOR(c, C)
+        nb.rawbase[c] = (int)M[c];
+    WB_END_PFOR
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) {
+            const uint32_t c = t2[k];
+            const int pos = (int)((t1[k] >> 16) & 0x3FFFu), base = (int)M[c], p = base + pos;
+            nb.rawpt[p] = nb.segt[i] & WB_PT_MASK;
+            nb.rawcid[p] = c;
+            if (pos == 1) {
+                nb.rawpt[base] = nb.segf[i] & WB_PT_MASK;
+                nb.rawcid[base] = c;
+                nb.closed[c] = (int)t0_g[i];
+            }
+        }
+    }
+    WB_SINGLE
+    nb.CR[0] = C;
+    nb.CR[1] = R;
+    WB_END_SINGLE
 }
 
-WB_KERNEL(wb_k_trace_rank, WbTraceArgs a) {
-    const int job = WB_BLOCK_ID;
-    if (job >= a.njobs) return;
-    const int n = a.nseg[job];
-    if (n <= 0) return;
-    const size_t jb = (size_t)job * a.cap_seg;
-    const uint32_t* succ = a.w[0] + jb;
-    uint32_t* pred = a.w[1] + jb;
-    uint32_t* t0 = a.w[8] + jb;
-    uint32_t* start = a.w[4] + jb;
-    uint32_t* dist = a.w[6] + jb;
-    if (n <= WB_TRACE_LDS_N) {
-        WB_SHARED(uint16_t, lds, 3 * WB_TRACE_LDS_N);     // 48 KiB: P (later D), J, A (dist <= n <= 8192 fits 16 bits)
-        uint16_t* P = lds;
-        WB_PFOR(i, n)
-            const uint32_t v = pred[i];
-            P[i] = v == WB_NIL ? (uint16_t)0xFFFF : (uint16_t)v;
-        WB_END_PFOR
-        wb_rank_lists_lds(n, succ, t0, P, lds + 1 * WB_TRACE_LDS_N, lds + 2 * WB_TRACE_LDS_N, start, dist);
-    } else {
-        // big job: same algorithm on 32-bit links in global memory; buffers J: w[2], w[3]; A: w[5], w[7]; D: w[9], w[10]
-        wb_rank_lists<uint32_t>(n, (uint32_t)WB_NIL, succ, t0, pred, a.w[2] + jb, a.w[3] + jb, a.w[5] + jb, a.w[7] + jb,
-                                a.w[9] + jb, a.w[10] + jb, start, dist);
-    }
-    // contour_index.py:109 calls a contour closed when its first and last float coordinates are equal: besides the
-    // loops cut above that is an OPEN chain that leaves and reaches the same grid vertex (cells equal to the level)
-    const uint32_t* segf = a.mseg[1] + jb;
-    const uint32_t* segt = a.mseg[2] + jb;
+// contour_index.py:109 calls a contour closed when its first and last float coordinates are equal: besides the loops the
+// ranking cuts that is an OPEN chain that leaves and reaches the same grid vertex (cells equal to the level)
+WB_DEV inline void wb_rank_vertex_loops(int n, const uint32_t* succ, const uint32_t* segf, const uint32_t* segt, const uint32_t* start, uint32_t* t0) {
     WB_PFOR(i, n)
         if (succ[i] == WB_NIL && (segt[i] & WB_PT_VERTEX)) {
             const uint32_t s = start[i];
             if (segf[s] == segt[i]) t0[s] = 1;
         }
     WB_END_PFOR
+}
+WB_KERNEL_LB(wb_k_trace_rank, WB_RANK_THREADS, (WB_RANK_THREADS >= 1024 ? 8 : 4), WbTraceArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const int n = a.nseg[job];
+    if (n <= 0 || n > WB_TRACE_LDS_N) return;             // (longer jobs: wb_k_trace_rank_big)
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* succ = a.w[0] + jb;
+    uint32_t* pred = a.w[1] + jb;
+    uint32_t* t0 = a.w[8] + jb;
+    uint32_t* start = a.w[4] + jb;
+    uint32_t* dist = a.w[6] + jb;
+    const uint32_t* segf = a.mseg[1] + jb;
+    const uint32_t* segt = a.mseg[2] + jb;
+    WB_SHARED(uint16_t, lds, 3 * WB_TRACE_LDS_N);         // 48 KiB: P (later D), J, A (dist <= n <= 8192 fits 16 bits)
+    uint16_t* P = lds;
+    WB_PFOR(i, n)
+        const uint32_t v = pred[i];
+        P[i] = v == WB_NIL ? (uint16_t)0xFFFF : (uint16_t)v;
+    WB_END_PFOR
+    // the finish kernel's scratch roles: cnt = w[3], rawbase = w[5], closed_raw = w[7] (free here)
+    WbNumberOut nb;
+    nb.segf = segf; nb.segt = segt; nb.rawpt = a.rawpt + 2 * jb; nb.rawcid = a.rawcid + 2 * jb;
+    nb.cnt = (int*)(a.w[3] + jb); nb.rawbase = (int*)(a.w[5] + jb); nb.closed = (int*)(a.w[7] + jb); nb.CR = a.p4 + 2 * (size_t)job;
+    const bool fuse = WB_TRACE_FUSE_P4 && !(a.status[job] & WB_ST_LEVEL_ORDER);   // (those the walk kernel ranks again)
+    wb_rank_lists_lds(n, succ, t0, P, lds + 1 * WB_TRACE_LDS_N, lds + 2 * WB_TRACE_LDS_N, start, dist, fuse, nb);
+    if (fuse) return;
+    WB_SINGLE
+    a.p4[2 * (size_t)job] = -1;
+    WB_END_SINGLE
+    wb_rank_vertex_loops(n, succ, segf, segt, start, t0);
+}
+// big job: the same algorithm on 32-bit links in global memory; buffers J: w[2], w[3]; A: w[5], w[7]; D: w[9], w[10].  A
+// kernel of its own so that its registers are not the LDS kernel's (which has to stay within 64 for two workgroups per CU).
+WB_KERNEL(wb_k_trace_rank_big, WbTraceArgs a) {
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const int n = a.nseg[job];
+    if (n <= WB_TRACE_LDS_N) return;
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* succ = a.w[0] + jb;
+    uint32_t* t0 = a.w[8] + jb;
+    uint32_t* start = a.w[4] + jb;
+    WB_SINGLE
+    a.p4[2 * (size_t)job] = -1;
+    WB_END_SINGLE
+    wb_rank_lists<uint32_t>(n, (uint32_t)WB_NIL, succ, t0, a.w[1] + jb, a.w[2] + jb, a.w[3] + jb, a.w[5] + jb, a.w[7] + jb,
+                            a.w[9] + jb, a.w[10] + jb, start, a.w[6] + jb);
+    wb_rank_vertex_loops(n, succ, a.mseg[1] + jb, a.mseg[2] + jb, start, t0);
 }
 
 // -------------------------------------------------------------------------------------------- 2b': the sequential walk
@@ -746,7 +873,12 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     int* flag = (int*)jA;
     int* cnt = (int*)jB;           // per contour: number of segments, then raw base
 
-    // ---- P4: contour numbering (sorted by raster-first segment) and raw point layout
+    WB_TSTAMP_BEGIN                        // development stamps: 0 numbering, 1 raw points, 2 key count, 3 dedupe insert, 4 dedupe lookup, 5 compaction + table, 6 set-up of the sets, 7 set inserts, 8 duplicate rule, 9 queued subset tests, 10 final table
+    // ---- P4: contour numbering (sorted by raster-first segment) and raw point layout -- unless the rank kernel has done it
+    int* rawbase = (int*)spare0;   // [C+1]
+    int* closed_raw = (int*)spare1;  // [C]
+    int C = a.p4[2 * (size_t)job], R = a.p4[2 * (size_t)job + 1];
+    if (C < 0) {
     WB_PFOR(i, n)
         minidx[i] = WB_NIL;
         cnt[i] = 0;
@@ -758,19 +890,18 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_PFOR(i, n)
         flag[i] = (minidx[start[i]] == (uint32_t)i) ? 1 : 0;
     WB_END_PFOR
-    const int C = wb_block_scan_excl(flag, n);
+    C = wb_block_scan_excl(flag, n);
     WB_PFOR(i, n)
         if (minidx[start[i]] == (uint32_t)i) cid_of[start[i]] = (uint32_t)flag[i];
     WB_END_PFOR
     WB_PFOR(i, n)
         wb_atomic_add_agg(cnt, (int)cid_of[start[i]], 1);
     WB_END_PFOR
-    int* rawbase = (int*)spare0;   // [C+1]
+    WB_TSTAMP(a.ctl, 0);
     WB_PFOR(c, C)
         rawbase[c] = cnt[c] + 1;
     WB_END_PFOR
-    const int R = wb_block_scan_excl(rawbase, C);
-    int* closed_raw = (int*)spare1;  // [C]
+    R = wb_block_scan_excl(rawbase, C);
     WB_PFOR(i, n)
         const uint32_t c = cid_of[start[i]];
         const int pos = (int)dist[i] - 1;
@@ -783,7 +914,8 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             closed_raw[c] = (int)t0[i];
         }
     WB_END_PFOR
-
+    }
+    WB_TSTAMP(a.ctl, 1);
     // ---- P5: order-preserving first-occurrence dedupe inside each contour
     // A point equal to its predecessor in the same contour can never be a first occurrence: it is dropped without
     // touching the table (about half of all raw points: neighbouring crossings that round to the same lattice point).
@@ -795,6 +927,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_PFOR(p, R)
         wb_atomic_add_agg(nkeys, 0, (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) ? 0 : 1);
     WB_END_PFOR
+    WB_TSTAMP(a.ctl, 2);
     hsize = 1024;
     while (hsize < 2 * nkeys[0] && hsize < a.hash_size) hsize <<= 1;
     hmask = hsize - 1;
@@ -809,6 +942,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
             if (!wb_hash_put_min(ltab, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
         WB_END_PFOR
+        WB_TSTAMP(a.ctl, 3);
         WB_PFOR(p, R + 1)
             int kp = 0;
             if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
@@ -857,6 +991,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             keep[p] = kp;
         WB_END_PFOR
     }
+    WB_TSTAMP(a.ctl, 4);
     // keep[] becomes the exclusive scan = new position; remember the flags in t1 (bit per raw point
     // would do, but raw points can be 2*cap: use the rawcid high bit instead)
     WB_PFOR(p, R)
@@ -897,6 +1032,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
         }
     WB_END_PFOR
 
+    WB_TSTAMP(a.ctl, 5);
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
     int* setsize = (int*)jA;   // [Ck]
     int* dropped = (int*)jB;   // [Ck]
@@ -944,6 +1080,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_PFOR(w, nb * xw)
         xbits[(w / xw) * WB_TRACE_XWORDS + (w % xw)] = 0u;
     WB_END_PFOR
+    WB_TSTAMP(a.ctl, 6);
     const int npts = (Ck > 0) ? keep[R] : 0;
     WB_PFOR(q, npts)
         const uint32_t f = cown[q];
@@ -975,6 +1112,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
         if (v) wb_atomic_add(&c_nux[bigf[w / xw]], wb_popc32(v));
     WB_END_PFOR
 
+    WB_TSTAMP(a.ctl, 7);
     // ---- P7: periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1,i2)
     //          with set(i1) a subset of set(i2): equal array lengths -> drop max(i1,i2), else drop the shorter
     //          Almost every pair fails on the first point of i1; the few that pass it (a contour and its copy one period
@@ -1011,6 +1149,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             dropped[d] = 1;
         }
     WB_END_PFOR
+    WB_TSTAMP(a.ctl, 8);
     {
         const int nc = ncand[0] < WB_TRACE_NCAND ? ncand[0] : WB_TRACE_NCAND;
         for (int c = 0; c < nc; ++c) {
@@ -1044,6 +1183,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
         }
     }
 
+    WB_TSTAMP(a.ctl, 9);
     // ---- P8: final table = kept and not dropped, order preserved
     int* fin = (int*)t0;  // [Ck] -> exclusive scan
     WB_PFOR(f, Ck)
@@ -1075,6 +1215,8 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             wb_atomic_max(&a.ctl->max_nux, s_nux[f]);
         }
     WB_END_PFOR
+    WB_TSTAMP(a.ctl, 10);
+    WB_TSTAMP_FLUSH(a.ctl);
     WB_SINGLE
     a.ncont[job] = Cf;
     WB_END_SINGLE
