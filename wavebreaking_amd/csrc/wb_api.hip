@@ -1137,6 +1137,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.alive = (int*)talloc((size_t)nsel_b * cap_pairs * sizeof(int));
             st.hkey = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
             st.hval = (unsigned long long*)talloc((size_t)nsel_b * st.hash_size * 8);
+            st.order = (int*)talloc((size_t)(nsel_b + 1) * sizeof(int));
+            if (!st.order) { release(); return 1; }
             if (!st.hval || !st.rowaux || !st.rowmx || !ev_ind || !st.bbx || !st.tbx || !d_lens || !st.item_tile) { release(); return 1; }
             (void)p2_lds;
             b->timer.begin(ctx, "streamer_lists");
@@ -1154,6 +1156,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
+            WB_LAUNCH(wb_k_pairs_order, 1, 1024, st);
             WB_LAUNCH(wb_k_streamer_f1, nsel_b, WB_F1_THREADS, st);
             b->timer.end(ctx);
             if (ctx->eager_f2) {
@@ -1171,7 +1174,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
-                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 8 + ((size_t)st.f234_cap / 32 + 2) * 4 + 32, st);
+                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + 64, st);
                 WB_LAUNCH(wb_k_streamer_ties, (nsel_b + 63) / 64, 64, st);
                 b->timer.end(ctx);
             }

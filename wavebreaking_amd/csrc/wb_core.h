@@ -113,15 +113,20 @@ struct WbCtl {
 // sums kept in registers of thread 0, one global atomic per phase and workgroup at the end (..._FLUSH)
 #define WB_STAMPX_BEGIN long long wb_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
 #define WB_STAMPX(ctl, k) do { if (threadIdx.x == 0) { const long long wb_n_ = (long long)wall_clock64(); wb_acc_[k] += wb_n_ - wb_st_; wb_st_ = wb_n_; } } while (0)
-#define WB_STAMPX_FLUSH(ctl) do { if (threadIdx.x == 0) for (int wb_q_ = 0; wb_q_ < 12; ++wb_q_) if (wb_acc_[wb_q_]) atomicAdd((unsigned long long*)&(ctl)->dbg[wb_q_], (unsigned long long)wb_acc_[wb_q_]); } while (0)
+// (dbg[20]: the longest workgroup; dbg[21..23]: workgroups that took more than 200 / 400 / 800 us, printed as count * 1e-5)
+#define WB_STAMPX_FLUSH(ctl) do { if (threadIdx.x == 0) { long long wb_t_ = 0; for (int wb_q_ = 0; wb_q_ < 12; ++wb_q_) if (wb_acc_[wb_q_]) { wb_t_ += wb_acc_[wb_q_]; atomicAdd((unsigned long long*)&(ctl)->dbg[wb_q_], (unsigned long long)wb_acc_[wb_q_]); } \
+    if (atomicMax((unsigned long long*)&(ctl)->dbg[20], (unsigned long long)wb_t_) < (unsigned long long)wb_t_) for (int wb_q_ = 0; wb_q_ < 8; ++wb_q_) (ctl)->dbg[12 + wb_q_] = wb_acc_[wb_q_ < 3 ? 4 + wb_q_ : wb_q_ + 5];   /* the longest workgroup's own stamps 4, 5, 6 and 8 .. 11 (slots 12 ..) */ \
+    for (int wb_q_ = 0; wb_q_ < 3; ++wb_q_) if (wb_t_ > (20000ll << wb_q_)) atomicAdd((unsigned long long*)&(ctl)->dbg[21 + wb_q_], 1ull); } } while (0)
 #endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 1
 #define WB_STAMP_BEGIN WB_STAMPX_BEGIN
 #define WB_STAMP(ctl, k) WB_STAMPX(ctl, k)
+#define WB_STAMP_COUNT(k, v) do { if (threadIdx.x == 0) wb_acc_[k] += (long long)(v) * 100000; } while (0)   /* printed as the count itself */
 #define WB_STAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
 #else
 #define WB_STAMP_BEGIN
 #define WB_STAMP(ctl, k) ((void)0)
+#define WB_STAMP_COUNT(k, v) ((void)0)
 #define WB_STAMP_FLUSH(ctl) ((void)0)
 #endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 3

@@ -265,7 +265,8 @@ struct WbStreamerArgs {
     double geo_band;           // ABSOLUTE guard band on h around hthr (WB_GEO_BAND * hthr, widened by the grid's irregularity)
     int p2_cap;                // contour points its LDS holds; 0: kernel not used (every contour in the tiled kernel's list)
     int p2_split;              // workgroups per contour
-    int f234_cap;              // wb_k_streamer_f234: contour points its dynamic LDS holds (8 bytes each + a bit)
+    int f234_cap;              // wb_k_streamer_f234: contour points its dynamic LDS holds (12 bytes each + a bit)
+    int* order;                // [nsel] the selected contours, those with the most candidate pairs first (wb_k_pairs_order)
     int* recheck;              // [recheck_cap][4] pairs inside a guard band: contour, i, j, 0 (wb_k_streamer_recheck decides them)
     int recheck_cap;
 };
@@ -669,9 +670,29 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
     return true;
 }
 
+// The per-contour filters take the contours in descending order of their candidate pairs (by power of two): a contour's
+// cost grows with them, and one of the 2 920 contours of the 0.25 degree bench batch holds 50 000 pairs against a median of a
+// few hundred -- started last, it alone ran for as long again as all the others together.
+WB_KERNEL(wb_k_pairs_order, WbStreamerArgs a) {
+    WB_SHARED(int, hist, 33);
+    const int nsel = a.ctl->nsel;
+    WB_PFOR(q, 33)
+        hist[q] = 0;
+    WB_END_PFOR
+    WB_PFOR(s, nsel)
+        wb_atomic_add(&hist[32 - wb_clz32((uint32_t)a.npairs[s])], 1);
+    WB_END_PFOR
+    WB_SINGLE
+    int run = 0;
+    for (int q = 32; q >= 0; --q) { const int c = hist[q]; hist[q] = run; run += c; }
+    WB_END_SINGLE
+    WB_PFOR(s, nsel)
+        a.order[wb_atomic_add(&hist[32 - wb_clz32((uint32_t)a.npairs[s])], 1)] = (int)s;
+    WB_END_PFOR
+}
 WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
-    const int s = WB_BLOCK_ID;
-    if (s >= a.ctl->nsel) return;
+    if (WB_BLOCK_ID >= a.ctl->nsel) return;
+    const int s = a.order[WB_BLOCK_ID];
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
@@ -996,8 +1017,8 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #define WB_F234_CAND 512           // candidates of one row collected after its first chord failed
 #define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
 WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
-    const int s = WB_BLOCK_ID;
-    if (s >= a.ctl->nsel) return;
+    if (WB_BLOCK_ID >= a.ctl->nsel) return;
+    const int s = a.order[WB_BLOCK_ID];
     if (WB_TID == 0) a.tie_m[s] = 0;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
@@ -1013,15 +1034,17 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     int* mj = mi + (P < N ? P : N) + 1;                              // [M] ind2
     int* lab = mj + (P < N ? P : N) + 1;                             // [M] group label
     int* aux = lab + (P < N ? P : N) + 1;                            // [M] scratch of the group scan
+    int* bk = aux + (P < N ? P : N) + 1;                             // [P] ind2 of the alive candidates, bucketed by row (the table's 8 * hash_size bytes hold 16 (min(P, N) + 1) + 4 P: hash_size >= 2 cap_pairs and >= 4 N)
     // the contour's points and per-row maxima in LDS, sized by the launch for the batch's longest contour (a.f234_cap points,
     // at most WB_F234_LPTS: with a fixed 4096 the kernel held three workgroups per CU, sized to a 0.25 degree contour four)
     WB_DYN_SHARED_BEGIN
     WB_DYN_SHARED(uint32_t, lpts, a.f234_cap);
     WB_DYN_SHARED(int, lrmax, a.f234_cap);       // per row: largest ind2 among its alive candidates
-    WB_DYN_SHARED(uint32_t, nebits, a.f234_cap / 32 + 1);   // rows that still hold a candidate above M
+    WB_DYN_SHARED(int, rend, a.f234_cap);        // per row: its alive candidates, then the end of its bucket in bk
     WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
     WB_SHARED(int, csort, WB_F234_CAND);
-    WB_SHARED(int, hitf, WB_F234_BATCH);
+    WB_SHARED(uint32_t, hq, WB_F234_BATCH);     // far end points of the chords of a batch
+    WB_SHARED(uint32_t, hitm, 1);               // ... and which of them met the contour
     WB_SHARED(int, sh, 10);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate
                                          // (words alternate between two slots: a slot is rewritten two barriers after its last read)
     const int stage = a.stage[s];
@@ -1032,9 +1055,8 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     const int nw = (N + 31) >> 5;
     WB_STAMP_BEGIN
     WB_PFOR(i, N)
-        if (in_lds) lpts[i] = gpts[i];
+        if (in_lds) { lpts[i] = gpts[i]; rend[i] = 0; }
         rmax[i] = -1;
-        if (in_lds && (i & 31) == 0) nebits[i >> 5] = 0u;
     WB_END_PFOR
     WB_SINGLE
     sh[2] = 0;
@@ -1048,9 +1070,21 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
             if (alive[p]) {
                 const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
                 wb_atomic_max(&rmax[i], j);
-                if (in_lds) wb_atomic_or(&nebits[i >> 5], 1u << (i & 31));
+                if (in_lds) wb_atomic_add(&rend[i], 1);
             }
         WB_END_PFOR
+        // the candidates bucketed by row: a row whose largest candidate fails routine 2 looks its other candidates up here
+        // instead of scanning all P pairs (one contour of the 0.25 degree bench batch holds 50 000 pairs and 60 such rows:
+        // it alone set the kernel's duration)
+        if (in_lds) {
+            wb_block_scan_excl(rend, N);
+            WB_PFOR(p, P)
+                if (alive[p]) {
+                    const int i = (int)(pairs[p] >> 32);
+                    bk[wb_atomic_add(&rend[i], 1)] = (int)(pairs[p] & 0xFFFFFFFFull);
+                }
+            WB_END_PFOR
+        }
         WB_STAMP(a.ctl, 1);
         // The sweep.  M (largest ind2 kept so far), the next row and the survivor count are the same in every lane and
         // live in registers; the two words a step communicates through (row found, chord hit) alternate between two
@@ -1058,30 +1092,20 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
         int M = -1, cur = 0, nsurv = 0, ntest = 0;
         for (int step = 0;; ++step) {
             const int fs = 3 + (step & 1);
-            if (in_lds) {
-                // a lane per bitmap word: rows whose largest candidate is not above M can never matter again (M only
-                // grows) and leave the bitmap; the lowest remaining row at or after `cur` is the next one to handle
-                WB_PFOR(w, nw)
-                    uint32_t bits = nebits[w];
-                    uint32_t keep = bits;
-                    while (bits) {
-                        const int bit = wb_ctz32(bits);
-                        bits &= bits - 1u;
-                        const int i = ((int)w << 5) + bit;
-                        if (i < cur || rmax[i] <= M) keep &= ~(1u << bit);
-                        else { wb_atomic_min(&sh[fs], i); break; }
-                    }
-                    nebits[w] = keep;
-                WB_END_PFOR
-            } else {
+            // the next row at or after `cur` whose largest candidate is above M: a lane per row, WB_NT rows per pass (the next
+            // row is nearly always among the first few; a bitmap of non-empty rows walked bit by bit, as this was until
+            // round 3, cost a dependent LDS read per set bit: 2.5 us per step, as much as the chord test itself)
+            for (int base = cur; base < N; base += WB_NT) {
                 WB_PFOR(t, WB_NT)
-                    for (int i = cur + (int)t; i < N; i += WB_NT)
-                        if (rmax[i] > M) { wb_atomic_min(&sh[fs], i); break; }
+                    const int i = base + (int)t;
+                    wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
                 WB_END_PFOR
+                if (sh[fs] != 0x7FFFFFFF) break;
             }
             const int row = sh[fs];
             WB_STAMP(a.ctl, 4);
             if (row == 0x7FFFFFFF) break;
+            WB_STAMP_COUNT(9, 1);                          // (development counters of the longest workgroup: rows, candidates collected, batched sweeps)
             int jn = rmax[row];                 // the row's largest candidate first
             int bound = 0x7FFFFFFF;
             for (;;) {
@@ -1114,17 +1138,29 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
                     WB_SINGLE
                     sh[9] = 0;
                     WB_END_SINGLE
-                    WB_PFOR(p, P)
-                        if (alive[p] && (int)(pairs[p] >> 32) == row) {
-                            const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                    if (in_lds) {
+                        const int lo = row ? rend[row - 1] : 0;
+                        WB_PFOR(q, rend[row] - lo)
+                            const int j = bk[lo + q];
                             if (j > M && j < bound) {
                                 const int slot = wb_atomic_add(&sh[9], 1);
                                 if (slot < WB_F234_CAND) cand[slot] = j;
                             }
-                        }
-                    WB_END_PFOR
+                        WB_END_PFOR
+                    } else {
+                        WB_PFOR(p, P)
+                            if (alive[p] && (int)(pairs[p] >> 32) == row) {
+                                const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                                if (j > M && j < bound) {
+                                    const int slot = wb_atomic_add(&sh[9], 1);
+                                    if (slot < WB_F234_CAND) cand[slot] = j;
+                                }
+                            }
+                        WB_END_PFOR
+                    }
                     WB_STAMP(a.ctl, 5);
                     const int found = sh[9];
+                    WB_STAMP_COUNT(10, found);
                     if (found == 0) { done = true; break; }
                     int K = found < WB_F234_CAND ? found : WB_F234_CAND;
                     if (found > WB_F234_CAND) {
@@ -1133,12 +1169,20 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
                         WB_SINGLE
                         sh[9] = -1;
                         WB_END_SINGLE
-                        WB_PFOR(p, P)
-                            if (alive[p] && (int)(pairs[p] >> 32) == row) {
-                                const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                        if (in_lds) {
+                            const int lo = row ? rend[row - 1] : 0;
+                            WB_PFOR(q, rend[row] - lo)
+                                const int j = bk[lo + q];
                                 if (j > M && j < bound) wb_atomic_max(&sh[9], j);
-                            }
-                        WB_END_PFOR
+                            WB_END_PFOR
+                        } else {
+                            WB_PFOR(p, P)
+                                if (alive[p] && (int)(pairs[p] >> 32) == row) {
+                                    const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                                    if (j > M && j < bound) wb_atomic_max(&sh[9], j);
+                                }
+                            WB_END_PFOR
+                        }
                         K = 1;
                         WB_SINGLE
                         csort[0] = sh[9];
@@ -1153,24 +1197,28 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
                     }
                     for (int b0 = 0; b0 < K && !done; b0 += WB_F234_BATCH) {
                         const int nb = K - b0 < WB_F234_BATCH ? K - b0 : WB_F234_BATCH;
-                        WB_PFOR(c, nb)
-                            hitf[c] = 0;
+                        WB_PFOR(c, nb)                              // the chords' far ends side by side: the loop below reads them with nothing in between
+                            hq[c] = pts[csort[b0 + c]];
+                            if (c == 0) hitm[0] = 0u;
                         WB_END_PFOR
                         const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]);
                         WB_PFOR(m, N - 1)
                             const uint32_t pa = pts[m], pb = pts[m + 1];
                             const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                            uint32_t hits = 0u;
                             for (int c = 0; c < nb; ++c) {
-                                const uint32_t pq = pts[csort[b0 + c]];
+                                const uint32_t pq = hq[c];
                                 const int qx = wb_pt_x(pq), qy = wb_pt_y(pq);
                                 const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
                                 if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                                    if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) hitf[c] = 1;
+                                    if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) hits |= 1u << c;
                             }
+                            if (hits) wb_atomic_or(&hitm[0], hits);
                         WB_END_PFOR
                         WB_STAMP(a.ctl, 6);
+                        WB_STAMP_COUNT(11, 1);
                         for (int c = 0; c < nb; ++c) {
-                            if (!hitf[c]) {                        // the largest candidate that passes routine 2
+                            if (!((hitm[0] >> c) & 1u)) {             // the largest candidate that passes routine 2
                                 jn = csort[b0 + c];
                                 if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
                                 ++nsurv;
@@ -1179,7 +1227,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
                                 break;
                             }
                         }
-                        WB_SYNC();                                 // hitf is read by every lane before the next batch clears it
+                        WB_SYNC();                                 // hitm is read by every lane before the next batch clears it
                     }
                     if (!done) {
                         if (found > WB_F234_CAND) bound = csort[0];   // one chord was tested: the next round looks below it

@@ -48,9 +48,11 @@ template <class T> static inline T wb_atomic_or(T* p, T v) { T o = *p; *p = o | 
 template <class T> static inline T wb_atomic_cas(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline int wb_popc32(uint32_t v) { return __builtin_popcount(v); }
 static inline int wb_ctz32(uint32_t v) { return __builtin_ctz(v); }
+static inline int wb_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
 // base[idx] += val (no return value); on the GPU lanes of a wave that hit the same idx are combined first
 static inline void wb_atomic_add_agg(int* base, int idx, int val) { base[idx] += val; }
+static inline void wb_atomic_min_first(int* addr, bool want, int val) { if (want && val < *addr) *addr = val; }
 // slot of an append to a list whose length counter all calling lanes share (-1 for lanes with want == false)
 static inline int wb_append_slot(int* counter, bool want) { return want ? (*counter)++ : -1; }
 // first slot of n (0 <= n < 32) consecutive entries appended by the calling lane
@@ -112,10 +114,17 @@ template <class T> __device__ inline T wb_atomic_or(T* p, T v) { return atomicOr
 template <class T> __device__ inline T wb_atomic_cas(T* p, T cmp, T v) { return atomicCAS(p, cmp, v); }
 __device__ inline int wb_popc32(uint32_t v) { return __popc(v); }
 __device__ inline int wb_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
+__device__ inline int wb_clz32(uint32_t v) { return __clz((int)v); }
 __device__ inline int wb_popc64(uint64_t v) { return __popcll(v); }
 // base[idx] += val without return value.  Many lanes of a wave usually target the same idx (all points of one
 // long contour): they are summed inside the wave first, one atomic per distinct idx (atomics on one address
 // serialise at ~12 ns each on this chip).  Must be called by converged code paths only in the sense that every
+// atomicMin(addr, val) by the lowest lane that wants it -- for values that ascend with the lane (an index search): one
+// atomic per wave instead of one per hit
+__device__ inline void wb_atomic_min_first(int* addr, bool want, int val) {
+    const unsigned long long m = __ballot(want);
+    if (want && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicMin(addr, val);
+}
 // participating lane reaches it; inactive lanes are simply not in the ballot.
 __device__ inline void wb_atomic_add_agg(int* base, int idx, int val) {
     unsigned long long todo = __ballot(1);
