@@ -86,6 +86,16 @@ struct wb_batch {
     std::string timer_names;
 };
 
+static int wb_num_cus(wb_ctx* ctx) {
+    if (ctx->ncu <= 0) {
+        ctx->ncu = 256;
+#if !defined(WB_HOSTSIM)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->ncu = prop.multiProcessorCount;
+#endif
+    }
+    return ctx->ncu;
+}
 template <class T>
 static T* balloc(wb_batch* b, size_t n) {
     void* p = dmalloc(b->ctx, n * sizeof(T));
@@ -271,8 +281,7 @@ static int run_phase1(wb_batch* b) {
 #undef WB_SCAN_OCC_N
 #undef WB_SCAN_OCC
         if (per_cu < 1) per_cu = 1;
-        int ncu = 256;
-        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount; }
+        const int ncu = wb_num_cus(ctx);
         if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
         // the streaming kernel keeps a patch buffer per strip (and the halo slots) in dynamic LDS and runs one wave per strip:
         // fields whose strips do not fit the device's limits (float64 beyond 12 strips, any dtype beyond 16) take the
@@ -1150,7 +1159,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_pairs");
             if (st.p2_cap > 0) {
-                WB_LAUNCH_LDS(wb_k_streamer_pairs2, (long long)nsel_b * st.p2_split, WB_P2_THREADS, p2_lds, st);
+                { long long g2 = (long long)nsel_b * st.p2_split, res = 2LL * wb_num_cus(ctx);   // persistent: two workgroups of 16 waves per CU
+                  WB_LAUNCH_LDS(wb_k_streamer_pairs2, g2 < res ? g2 : res, WB_P2_THREADS, p2_lds, st); }
                 WB_LAUNCH(wb_k_streamer_recheck, 64, 64, st);              // pairs inside a guard band (normally none)
             }
             if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);

@@ -104,7 +104,7 @@ struct WbCtl {
     int props_cursor;            // next event of the property kernel's work queue
     int group_ties;              // check_groups: groups whose maximum length was shared by several members (exact ties)
     int n_recheck;               // pairs wb_k_streamer_pairs2 left to wb_k_streamer_recheck (inside a guard band)
-    int pad2;
+    int p2_cursor;               // next (contour, part) item of wb_k_streamer_pairs2's persistent workgroups
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.

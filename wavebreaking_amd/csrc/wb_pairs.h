@@ -84,13 +84,14 @@ WB_KERNEL(wb_k_streamer_recheck, WbStreamerArgs a) {
 #if defined(WB_HOSTSIM)
 // host simulation: the same tiles, block filter, tables and guard bands, one pair after the other
 WB_KERNEL(wb_k_streamer_pairs2, WbStreamerArgs a) {
-    const int s = WB_BLOCK_ID / a.p2_split, part = WB_BLOCK_ID - s * a.p2_split;
-    if (s >= a.ctl->nsel || part != 0) return;
+    for (int item = WB_BLOCK_ID; item < a.ctl->nsel * a.p2_split; item += WB_GRID_DIM) {      // (the launch is persistent: a grid of resident workgroups)
+    const int s = item / a.p2_split, part = item - s * a.p2_split;
+    if (part != 0) continue;
     const int job = a.sel_job[s], k = a.sel_cont[s];
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
-    if (N > a.p2_cap) return;
+    if (N > a.p2_cap) continue;
     const long long po = a.poff[s];
     const double* pre = a.pre + po;
     const int* bbx = a.bbx + 4 * ((po >> 5) + s);
@@ -131,6 +132,7 @@ WB_KERNEL(wb_k_streamer_pairs2, WbStreamerArgs a) {
         }
     }
     wb_atomic_add((unsigned long long*)&a.ctl->evaluated_pairs, (unsigned long long)evaluated);
+    }
 }
 #else
 __device__ inline double wb_readlane_f64(double v, int lane) {
@@ -140,20 +142,8 @@ __device__ inline double wb_readlane_f64(double v, int lane) {
 }
 __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStreamerArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wb_p2_lds[];
-    const int s = (int)blockIdx.x / a.p2_split, part = (int)blockIdx.x - s * a.p2_split;
-    if (s >= a.ctl->nsel) return;
+    __shared__ int wb_p2_item;
     WB_PSTAMP_BEGIN
-    const int job = a.sel_job[s], k = a.sel_cont[s];
-    const size_t jb = (size_t)job * a.cap_seg;
-    const uint32_t* gpts = a.cpts + 2 * jb + a.c_off[jb + k];
-    const int N = a.c_len[jb + k];
-    if (N > a.p2_cap) return;                                            // the tiled kernel's list holds this contour
-    const long long po = a.poff[s];
-    const double* gpre = a.pre + po;
-    const int* gbbx = a.bbx + 4 * ((po >> 5) + s);
-    const int* gtbx = a.tbx + 4 * ((po >> 4) + s);
-    const int nblk = (N + WB_BLK - 1) / WB_BLK;
-    unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     const int cap = a.p2_cap, nbmax = cap / WB_BLK + 1, ntmax = cap / WB_PAIR_ROWS + 1, nlat = a.nlat, dy_max = a.dy_max;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = WB_P2_THREADS / 64;
     // LDS: 8-byte arrays first
@@ -168,11 +158,36 @@ __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStrea
     int* lbb = ldxl + nlat;                                              // [nbmax][4] block boxes
     int* ltb = lbb + 4 * nbmax;                                          // [ntmax][4] tile boxes
     int* ltile = ltb + 4 * ntmax;                                        // [1] next tile of this workgroup
-    const int ntile = (N - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
-    for (int i = tid; i < N; i += WB_P2_THREADS) { lpts[i] = gpts[i]; lpre[i] = gpre[i]; }
+    // the grid's tables once per workgroup; the workgroups are persistent (two per CU) and take (contour, part) items from
+    // a device counter: launched one per contour, 2 920 workgroups of 1024 threads and 64 KB of LDS kept the device a third
+    // full (178 ms of workgroup time in a 1.05 ms launch = 170 of 512 possible workgroups resident on average)
     for (int y = tid; y < nlat; y += WB_P2_THREADS) { lcphi[y] = a.cphi[y]; ldxl[y] = a.dxlim[y]; }
     for (int q = tid; q <= dy_max; q += WB_P2_THREADS) lsl[q] = a.sl_tab[q];
     for (int q = tid; q <= WB_P2_MAXDX; q += WB_P2_THREADS) lsx[q] = a.sx_tab[q];
+    const int nitems = a.ctl->nsel * a.p2_split;
+    long long evaluated = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const double hthr = a.hthr, geo_band = a.geo_band, cont_dis = a.cont_dis;
+    for (;;) {
+    __syncthreads();                                                     // (the previous item's LDS is done with)
+    if (tid == 0) wb_p2_item = atomicAdd(&a.ctl->p2_cursor, 1);
+    __syncthreads();
+    const int item = wb_p2_item;
+    if (item >= nitems) break;
+    const int s = item / a.p2_split, part = item - s * a.p2_split;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* gpts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    if (N > a.p2_cap) continue;                                          // the tiled kernel's list holds this contour
+    const long long po = a.poff[s];
+    const double* gpre = a.pre + po;
+    const int* gbbx = a.bbx + 4 * ((po >> 5) + s);
+    const int* gtbx = a.tbx + 4 * ((po >> 4) + s);
+    const int nblk = (N + WB_BLK - 1) / WB_BLK;
+    unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
+    const int ntile = (N - 1 + WB_PAIR_ROWS - 1) / WB_PAIR_ROWS;
+    for (int i = tid; i < N; i += WB_P2_THREADS) { lpts[i] = gpts[i]; lpre[i] = gpre[i]; }
     for (int q = tid; q < 4 * nblk; q += WB_P2_THREADS) lbb[q] = gbbx[q];
     for (int q = tid; q < 4 * ntile && q < 4 * ntmax; q += WB_P2_THREADS) ltb[q] = gtbx[q];
     if (tid == 0) ltile[0] = 0;
@@ -186,8 +201,6 @@ __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStrea
 
     unsigned long long* stage = lstage + wave * WB_P2_STAGE;
     int fill = 0;                                                        // pairs waiting in this wave's buffer (wave-uniform)
-    long long evaluated = 0;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     auto flush = [&]() {
         // the buffer's pairs go to the contour's list: one returning atomic, consecutive slots
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -199,7 +212,6 @@ __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStrea
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         fill = 0;
     };
-    const double hthr = a.hthr, geo_band = a.geo_band, cont_dis = a.cont_dis;
     // tiles are taken one at a time from a counter in LDS (the part'th of every p2_split tiles belongs to this workgroup): a
     // tile that meets a streamer costs many sweeps, and the workgroup's 16 waves leave together
     for (;;) {
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStrea
     }
     if (fill) flush();
     WB_PSTAMP(a.ctl, 5);
+    }
     WB_PSTAMP_FLUSH(a.ctl);
     // one global atomic per wave
 #pragma unroll

@@ -43,6 +43,7 @@ struct wb_ctx {
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
     int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
+    int ncu = 0;                              // compute units of the device (found once)
     size_t p2_budget = 0;                     // dynamic LDS a workgroup of wb_k_streamer_pairs2 may use (found once)
     int p2_budget_kb = 0, p2_split = 0;       // development: overrides of that budget / of the workgroups per contour
 #if !defined(WB_HOSTSIM)
