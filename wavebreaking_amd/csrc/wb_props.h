@@ -654,6 +654,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     const int sel = WB_BLOCK_ID / WB_BOXCOM_SPLIT;
     if (sel >= a.ctl->nsel) return;
     const int nbox = a.ot_n[sel];
+    WB_BSTAMP_BEGIN                                              // development stamps: 0 closed forms, 1 .. 3 the passes, 4 the one-lane walk / output
     for (int g = WB_BLOCK_ID % WB_BOXCOM_SPLIT; g < nbox; g += WB_BOXCOM_SPLIT) {
     WB_SYNC();                                                   // the previous box's control words have been read by everyone
     const int* d = a.ot_box + ((size_t)sel * WB_OT_CAP + g) * 4;
@@ -692,6 +693,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
         wb_atomic_add(&a.ctl->com_rechecks[1], 1);
     }
     WB_END_SINGLE
+    WB_BSTAMP(a.ctl, 0);
     if (!ctl[0]) continue;
     const int ue = ctl[1];
     if (!ctl[2]) {
@@ -720,6 +722,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
             if (over) ctl[2] = 1;
         WB_END_PFOR
     }
+    WB_BSTAMP(a.ctl, 1);
     if (!ctl[2]) {
         // pass 2: predicted state at every row start; chains 0 areas (terms w), 1 x_com (x * w), 2 y_com (y * w)
         WB_PFOR(ch, 3)
@@ -758,6 +761,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
             if (!ok) ctl[2] = 1;
         WB_END_PFOR
     }
+    WB_BSTAMP(a.ctl, 2);
     if (!ctl[2]) {
         // pass 3: the real recurrence over every row from its predicted state; the end must be the next row's start
         WB_PFOR(r, rows)
@@ -777,6 +781,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                   sy == st[4 * (WB_BOXCOM_ROWS + 1) + r + 1] && cy == st[5 * (WB_BOXCOM_ROWS + 1) + r + 1])) ctl[2] = 1;
         WB_END_PFOR
     }
+    WB_BSTAMP(a.ctl, 3);
     WB_SINGLE
     double sa, sx, sy;
     if (ctl[2]) {                                                // not verified: one lane walks every cell in the reference's order
@@ -802,5 +807,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     out[1] = sx;
     out[2] = sy;
     WB_END_SINGLE
+    WB_BSTAMP(a.ctl, 4);
     }   // boxes of this contour
+    WB_BSTAMP_FLUSH(a.ctl);
 }
