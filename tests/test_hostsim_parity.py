@@ -279,14 +279,26 @@ def test_cells_equal_to_the_level_full_path(sim, seed):
 
 
 def test_box_com_one_lane_walk():
-    # a build whose row-parallel box evaluation never applies (2 rows at most): every box in the guard band is walked
-    # cell by cell by one lane -- same sums
-    lib = _hip.Library(helpers.build_hostsim(variant="boxlane", defines=("WB_BOXCOM_ROWS=2",)), allow_hostsim=True)
+    # a build whose row-parallel box evaluation never applies: every box in the guard band is walked cell by cell by one
+    # lane -- same sums
+    lib = _hip.Library(helpers.build_hostsim(variant="boxlane", defines=("WB_BOXCOM_FORCE_WALK=1", "WB_BOXCOM_ROWS=3")), allow_hostsim=True)
     ctx = _hip.Context(0, lib)
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(0, 6, lat, lon, eps=0.3)
     got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(6), [-2, 2], intensity=pv)
     assert got["com_rechecks"][1] >= 8 and got["com_rechecks"][2] == got["com_rechecks"][1]
+    ctx.close()
+
+
+def test_box_com_in_chunks_of_two_rows():
+    # the row-parallel evaluation with chunks of two rows and a single segment per row: state handed from chunk to chunk, wide
+    # rows walked chunk-wise by one lane and the prediction taken up again after them -- same sums
+    lib = _hip.Library(helpers.build_hostsim(variant="boxchunk", defines=("WB_BOXCOM_ROWS=2", "WB_BOXCOM_SEGS=1")), allow_hostsim=True)
+    ctx = _hip.Context(0, lib)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(0, 6, lat, lon, eps=0.3)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(6), [-2, 2], intensity=pv)
+    assert got["com_rechecks"][1] >= 8 and 0 < got["com_rechecks"][2] < got["com_rechecks"][1]
     ctx.close()
 
 

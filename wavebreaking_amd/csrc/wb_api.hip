@@ -86,6 +86,9 @@ struct wb_batch {
     std::string timer_names;
 };
 
+#ifndef WB_LIST_THREADS
+#define WB_LIST_THREADS 256          // single-workgroup list / offset kernels
+#endif
 static int wb_num_cus(wb_ctx* ctx) {
     if (ctx->ncu <= 0) {
         ctx->ncu = 256;
@@ -1049,6 +1052,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         // ---- overturnings + the centre-of-mass sums of their boxes: side stream, next to the streamer chain
         int *ot_n = nullptr, *ot_box = nullptr, *ot_orient = nullptr;
         double* ot_sums = nullptr;
+
         if (do_ot) {
             ot_n = (int*)talloc(nsel_b * sizeof(int));
             ot_box = (int*)talloc((size_t)nsel_b * WB_OT_CAP * 4 * sizeof(int));
@@ -1151,7 +1155,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             if (!st.hval || !st.rowaux || !st.rowmx || !ev_ind || !st.bbx || !st.tbx || !d_lens || !st.item_tile) { release(); return 1; }
             (void)p2_lds;
             b->timer.begin(ctx, "streamer_lists");
-            WB_LAUNCH(wb_k_sel_scan, 1, 1024, st, d_lens);
+            // (single workgroups of 256 threads: a 1024-thread workgroup waits for sixteen free wave slots on one CU, and beside the
+            //  side stream's 256-thread workgroups, which take every slot as it frees up, it waited 0.25 ms for them)
+            WB_LAUNCH(wb_k_sel_scan, 1, WB_LIST_THREADS, st, d_lens);
             WB_LAUNCH(wb_k_pair_items, nsel_b, 64, st);
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_prep");
@@ -1159,14 +1165,14 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_pairs");
             if (st.p2_cap > 0) {
-                { long long g2 = (long long)nsel_b * st.p2_split, res = 2LL * wb_num_cus(ctx);   // persistent: two workgroups of 16 waves per CU
+                { long long g2 = (long long)nsel_b * st.p2_split, res = (long long)ctx->p2_grid_x2 * wb_num_cus(ctx) / 2;   // persistent: two workgroups of 16 waves per CU
                   WB_LAUNCH_LDS(wb_k_streamer_pairs2, g2 < res ? g2 : res, WB_P2_THREADS, p2_lds, st); }
                 WB_LAUNCH(wb_k_streamer_recheck, 64, 64, st);              // pairs inside a guard band (normally none)
             }
             if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
-            WB_LAUNCH(wb_k_pairs_order, 1, 1024, st);
+            WB_LAUNCH(wb_k_pairs_order, 1, WB_LIST_THREADS, st);
             WB_LAUNCH(wb_k_streamer_f1, nsel_b, WB_F1_THREADS, st);
             b->timer.end(ctx);
             if (ctx->eager_f2) {
@@ -1224,9 +1230,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
         if (!d_py || !fa.poff || !pa.ev_flags || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
         b->timer.begin(ctx, "fill_events");
-        WB_LAUNCH(wb_k_event_offsets, 1, 1024, fa);
+        WB_LAUNCH(wb_k_event_offsets, 1, WB_LIST_THREADS, fa);
         if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa);
-        WB_LAUNCH(wb_k_poly_offsets, 1, 1024, fa);
+        WB_LAUNCH(wb_k_poly_offsets, 1, WB_LIST_THREADS, fa);
         b->timer.end(ctx);
         // descriptors are complete: vertices + the first control-block snapshot on the side stream, properties on the main one
         side_begin(ctx);
@@ -1618,6 +1624,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "pairs_lds")) { ctx->pairs_lds = value ? 1 : 0; return 0; }
     if (!strcmp(name, "p2_budget_kb")) { ctx->p2_budget_kb = value; ctx->p2_budget = 0; return 0; }
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
+    if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;

@@ -45,6 +45,7 @@ struct wb_ctx {
     int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
     int ncu = 0;                              // compute units of the device (found once)
     size_t p2_budget = 0;                     // dynamic LDS a workgroup of wb_k_streamer_pairs2 may use (found once)
+    int p2_grid_x2 = 4;                       // persistent grid of wb_k_streamer_pairs2 in half workgroups per CU (4 = two: every wave slot)
     int p2_budget_kb = 0, p2_split = 0;       // development: overrides of that budget / of the workgroups per contour
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
@@ -441,8 +442,13 @@ static bool wb_platform_create(wb_ctx* c) {
 #else
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= c->device) return false;
-    return hipSetDevice(c->device) == hipSuccess && hipStreamCreate(&c->stream) == hipSuccess &&
-           hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    // WB_SIDE_PRIORITY=1 (development): the side stream at the lowest priority the device offers
+    int lo = 0, hi = 0;
+    const char* sp = getenv("WB_SIDE_PRIORITY");
+    const bool low = sp && atoi(sp) == 1 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+    return hipStreamCreate(&c->stream) == hipSuccess &&
+           (low ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo) : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) == hipSuccess &&
            hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&c->join, hipEventDisableTiming) == hipSuccess;
 #endif

@@ -104,7 +104,10 @@ WB_HD inline double wb_com_ulps(int rows) { return 4.0 * (2.0 * (double)rows + 1
 // sum over the member cells of the box [x0, x0 + cols) x [y0, y0 + rows) of weight(y) * (data, intensity): the lanes run
 // ALONG the rows (adjacent lanes on adjacent cells: a load instruction touches two or three cache lines, not 64), eight
 // loads in flight per lane; bm == NULL: every cell is a member.  The lane's two partial sums go to out[2 * lane].  (These
-// sums are compared to 1e-6 relative: the order of summation is free.)
+// sums are compared to 1e-6 relative: the order of summation is free.)  A version without the division and modulo per cell
+// (a column's place in the field found once, eight ROWS in flight) was no faster -- the loads' latency is what the loop
+// waits for -- and took the kernel from 100 to 128 registers: four of its waves then fill a SIMD's register file and
+// nothing else runs beside them (wb_k_pack_polys on the side stream: 0.06 -> 0.5 ms; round 3).
 WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
                                        double* out) {
     const int total = rows * cols;
@@ -141,6 +144,9 @@ WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x
 #define WB_PROPS_BM 768              // bitmap words (24 576 cells)
 #endif
 WB_DEV inline bool wb_bm_test(const uint32_t* bm, int wb, int rr, int xx) { return (bm[rr * wb + (xx >> 5)] >> (xx & 31)) & 1u; }
+#if defined(WB_PROPS_VGPRS) && !defined(WB_HOSTSIM)
+__attribute__((amdgpu_waves_per_eu(WB_PROPS_VGPRS, WB_PROPS_VGPRS)))   // development: registers for that many waves per SIMD (the rest spills)
+#endif
 WB_KERNEL(wb_k_props, WbPropsArgs a) {
     WB_SHARED(unsigned long long, xlist8, (WB_PROPS_LROWS * WB_PROPS_K + 3) / 4 > 6 * 64 ? (WB_PROPS_LROWS * WB_PROPS_K + 3) / 4 : 6 * 64);
     unsigned short* xlist = (unsigned short*)xlist8;                  // per row: crossing column (relative to x0) | 0x8000 for a downward edge
@@ -423,6 +429,8 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         }   // !full
         if (full) {
             // D for boxes: every cell counts, so the integer sums are closed forms; the field sums with the lanes along the rows
+            // (a kernel of their own for these sums, on the side stream, was tried in round 3: it sat behind the persistent
+            // all-pairs kernel there and then ran beside routine 1 -- 0.3 ms MORE per pass)
             WB_PFOR(rr, rows)
                 WB_ACC(0, y0 + (int)rr) = (double)cols;
                 WB_ACC(1, y0 + (int)rr) = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
@@ -500,17 +508,16 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             }
             if (lane_sums) { pv = lred[2 * WB_TID]; pi = lred[2 * WB_TID + 1]; }
             WB_SYNC();
-            lrow6[6 * WB_TID + 0] = pa; lrow6[6 * WB_TID + 1] = px; lrow6[6 * WB_TID + 2] = py;
-            lrow6[6 * WB_TID + 3] = pv; lrow6[6 * WB_TID + 4] = pi; lrow6[6 * WB_TID + 5] = pn;
+            // the lanes' shares added by butterfly (a fixed order: the same bits on every run); lane 0 adding 64 x 6 values
+            // from LDS one after the other was 10 us per event
+            pa = wb_block_sum_f64(pa, lrow6); px = wb_block_sum_f64(px, lrow6); py = wb_block_sum_f64(py, lrow6);
+            pv = wb_block_sum_f64(pv, lrow6); pi = wb_block_sum_f64(pi, lrow6); pn = wb_block_sum_f64(pn, lrow6);
+            if (WB_TID == 0) { lrow6[0] = pa; lrow6[1] = px; lrow6[2] = py; lrow6[3] = pv; lrow6[4] = pi; lrow6[5] = pn; }
             WB_SYNC();
         }
         WB_SINGLE
-        double areas = 0.0, mv = 0.0, it = 0.0, xc = 0.0, yc = 0.0;
-        long long nc = 0;
-        for (int l = 0; l < WB_NT; ++l) {
-            areas = areas + lrow6[6 * l + 0]; xc = xc + lrow6[6 * l + 1]; yc = yc + lrow6[6 * l + 2];
-            mv = mv + lrow6[6 * l + 3]; it = it + lrow6[6 * l + 4]; nc += (long long)lrow6[6 * l + 5];
-        }
+        double areas = lrow6[0], xc = lrow6[1], yc = lrow6[2], mv = lrow6[3], it = lrow6[4];
+        long long nc = (long long)lrow6[5];
         // boxes: areas / x_com / y_com come from wb_k_box_com (which ran beside the streamer kernels)
         if (full) {
             a.ev_sums[(size_t)e * 5 + 0] = a.ot_sums[(size_t)d[7] * 3 + 0];
@@ -590,14 +597,22 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 //     exactly, E += rest; this predicts the state at the start of every row;
 //   * pass 3 (lane per row): the real recurrence over the whole row from the predicted state; its end state must equal the
 //     state predicted for the next row bit for bit.  All rows verified => the chained states are exactly those of the
-//     sequential walk (induction from the first row, whose start state 0, 0 is certain).  Any mismatch (a rounding tie, an
-//     inexact step elsewhere), more than WB_BOXCOM_SEGS segments in a row or more than WB_BOXCOM_ROWS rows => one lane walks
-//     all cells instead (counted in com_rechecks[2]); correctness never rests on the prediction.
+//     sequential walk (induction from the first row, whose start state 0, 0 is certain).  The rows are taken in chunks of
+//     WB_BOXCOM_ROWS; any mismatch in a chunk (a rounding tie, an inexact step elsewhere, more than WB_BOXCOM_SEGS segments
+//     in a row) => one lane walks THAT CHUNK's cells from the chunk's true start state, and the next chunk is predicted again
+//     (boxes with such a chunk are counted in com_rechecks[2]); correctness never rests on the prediction.  (Until round 3 a
+//     box taller than 128 rows, wider than 4 binades or with one mismatch was walked whole: 16 of the bench batch's 6 391
+//     boxes, the largest of them 1.6 ms on one lane -- the kernel's whole duration.)
 #ifndef WB_BOXCOM_ROWS
-#define WB_BOXCOM_ROWS 128           // taller boxes (more than 32 degrees of latitude on the 0.25 degree grid) take the one-lane walk
+#define WB_BOXCOM_ROWS 64            // rows of a chunk (a lane each)
+#endif
+#ifndef WB_BOXCOM_FORCE_WALK
+#define WB_BOXCOM_FORCE_WALK 0       // 1 (a test build): no chunk is predicted, one lane walks them all
 #endif
 #define WB_BOXCOM_SPLIT 2            // workgroups per selected contour (its boxes are dealt out round-robin)
-#define WB_BOXCOM_SEGS 4
+#ifndef WB_BOXCOM_SEGS
+#define WB_BOXCOM_SEGS 12            // binade steps of x * w along a row: x < 4096
+#endif
 typedef unsigned __int128 wb_u128;
 struct WbBoxComArgs {
     int nlat, W;
@@ -649,12 +664,12 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     WB_SHARED(unsigned long long, seglo, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);   // ... exact total of the segment's other terms
     WB_SHARED(unsigned long long, seghi, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);
     WB_SHARED(int, nseg, WB_BOXCOM_ROWS);
-    WB_SHARED(double, st, 6 * (WB_BOXCOM_ROWS + 1));             // per chain: predicted state s, c at the start of every row (+ after the last)
-    WB_SHARED(int, ctl, 4);                                      // [0] in band, [1] unit exponent, [2] not verified
+    WB_SHARED(double, st, 6 * (WB_BOXCOM_ROWS + 1));             // per chain: state s, c at the start of every row of the chunk (+ after its last)
+    WB_SHARED(int, ctl, 4);                                      // [0] in band, [1] unit exponent, [2] whole box by one lane, [3] this chunk by one lane
     const int sel = WB_BLOCK_ID / WB_BOXCOM_SPLIT;
     if (sel >= a.ctl->nsel) return;
     const int nbox = a.ot_n[sel];
-    WB_BSTAMP_BEGIN                                              // development stamps: 0 closed forms, 1 .. 3 the passes, 4 the one-lane walk / output
+    WB_BSTAMP_BEGIN                                              // development stamps: 0 closed forms, 1 .. 3 the passes, 4 the one-lane walks / output
     for (int g = WB_BLOCK_ID % WB_BOXCOM_SPLIT; g < nbox; g += WB_BOXCOM_SPLIT) {
     WB_SYNC();                                                   // the previous box's control words have been read by everyone
     const int* d = a.ot_box + ((size_t)sel * WB_OT_CAP + g) * 4;
@@ -684,107 +699,150 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     ctl[0] = band ? 1 : 0;
     ctl[1] = emin;
     // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
-    ctl[2] = (rows > WB_BOXCOM_ROWS || emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
+    ctl[2] = (emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
     if (!band) {
         out[0] = areas;
         out[1] = xc;
         out[2] = yc;
     } else {
         wb_atomic_add(&a.ctl->com_rechecks[1], 1);
+        for (int q = 0; q < 6; ++q) st[q * (WB_BOXCOM_ROWS + 1)] = 0.0;      // the sums start at s = c = 0: certain
     }
     WB_END_SINGLE
     WB_BSTAMP(a.ctl, 0);
     if (!ctl[0]) continue;
     const int ue = ctl[1];
-    if (!ctl[2]) {
-        // pass 1: segments of the x chain, row by row
-        WB_PFOR(r, rows)
-            const double w = a.wlat[y0 + (int)r];
-            int ns = 0, eprev = 0;
-            wb_u128 rest = 0;
-            bool over = false;
-            for (int x = x0; x <= x1; ++x) {
-                const double p = (double)x * w;
-                const int ep = wb_dbl_exp(p);
-                if (x == x0 || ep > eprev) {                     // row start or a step up into a higher binade: new segment
-                    if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
-                    if (ns == WB_BOXCOM_SEGS) { over = true; break; }
-                    segv[ns * WB_BOXCOM_ROWS + r] = p;
-                    rest = 0;
-                    ++ns;
-                } else {
-                    rest += wb_fix128(p, ue);
-                }
-                eprev = ep;
-            }
-            if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
-            nseg[r] = ns;
-            if (over) ctl[2] = 1;
-        WB_END_PFOR
-    }
-    WB_BSTAMP(a.ctl, 1);
-    if (!ctl[2]) {
-        // pass 2: predicted state at every row start; chains 0 areas (terms w), 1 x_com (x * w), 2 y_com (y * w)
-        WB_PFOR(ch, 3)
-            wb_u128 E = 0;
-            bool ok = true;
-            for (int r = 0; r < rows && ok; ++r) {
-                const int y = y0 + r;
-                const double w = a.wlat[y];
-                const int ns = ch == 1 ? nseg[r] : 1;
-                for (int k = 0; k < ns && ok; ++k) {
-                    double sv, cv;
-                    ok = wb_state_from_exact(E, ue, &sv, &cv);
-                    if (k == 0) { st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + r] = sv; st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + r] = cv; }
-                    double v;
-                    wb_u128 rest;
-                    if (ch == 1) {
-                        v = segv[k * WB_BOXCOM_ROWS + r];
-                        rest = ((wb_u128)seghi[k * WB_BOXCOM_ROWS + r] << 64) | seglo[k * WB_BOXCOM_ROWS + r];
+    bool walked = false;
+    // The box in chunks of WB_BOXCOM_ROWS rows.  A chunk starts from the TRUE state of the three sums (verified by the
+    // previous chunk, or walked) in st[..][0]; if it verifies, its end state is true as well and becomes the next start; if
+    // not (a rounding tie, an inexact step the prediction missed, more binade steps in a row than WB_BOXCOM_SEGS), one lane
+    // walks the chunk's cells in the reference's order from that start -- and the chunk after it is predicted again.
+    for (int r0 = 0; r0 < rows && !ctl[2]; r0 += WB_BOXCOM_ROWS) {
+        const int nr = rows - r0 < WB_BOXCOM_ROWS ? rows - r0 : WB_BOXCOM_ROWS;
+        WB_SINGLE
+        ctl[3] = WB_BOXCOM_FORCE_WALK;
+        WB_END_SINGLE
+        if (!ctl[3]) {
+            // pass 1: segments of the x chain, row by row
+            WB_PFOR(r, nr)
+                const double w = a.wlat[y0 + r0 + (int)r];
+                int ns = 0, eprev = 0;
+                wb_u128 rest = 0;
+                bool over = false;
+                for (int x = x0; x <= x1; ++x) {
+                    const double p = (double)x * w;
+                    const int ep = wb_dbl_exp(p);
+                    if (x == x0 || ep > eprev) {                     // row start or a step up into a higher binade: new segment
+                        if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
+                        if (ns == WB_BOXCOM_SEGS) { over = true; break; }
+                        segv[ns * WB_BOXCOM_ROWS + r] = p;
+                        rest = 0;
+                        ++ns;
                     } else {
-                        v = ch == 0 ? w : (double)y * w;
-                        unsigned long long m; int ex;
-                        wb_dbl_split(v, &m, &ex);
-                        rest = m ? (((wb_u128)m * (unsigned)(cols - 1)) << (ex - ue)) : (wb_u128)0;
+                        rest += wb_fix128(p, ue);
                     }
-                    WB_KAHAN(sv, cv, v);                          // the real step for the segment's first term
-                    E = wb_fix128(sv, ue);                         // s - c exactly
-                    if (cv > 0.0) { const wb_u128 f = wb_fix128(cv, ue); if (f > E) ok = false; else E -= f; }
-                    else if (cv < 0.0) E += wb_fix128(-cv, ue);
-                    E += rest;
+                    eprev = ep;
+                }
+                if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
+                nseg[r] = ns;
+                if (over) ctl[3] = 1;
+            WB_END_PFOR
+        }
+        WB_BSTAMP(a.ctl, 1);
+        if (!ctl[3]) {
+            // pass 2: predicted state at every row start; chains 0 areas (terms w), 1 x_com (x * w), 2 y_com (y * w)
+            WB_PFOR(ch, 3)
+                wb_u128 E = 0;
+                bool ok = true;
+                for (int r = 0; r < nr && ok; ++r) {
+                    const int y = y0 + r0 + r;
+                    const double w = a.wlat[y];
+                    const int ns = ch == 1 ? nseg[r] : 1;
+                    for (int k = 0; k < ns && ok; ++k) {
+                        double sv, cv;
+                        if (r == 0 && k == 0) {                      // the chunk's start: the true state, as it is
+                            sv = st[(2 * ch) * (WB_BOXCOM_ROWS + 1)]; cv = st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1)];
+                        } else {
+                            ok = wb_state_from_exact(E, ue, &sv, &cv);
+                            if (k == 0) { st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + r] = sv; st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + r] = cv; }
+                        }
+                        double v;
+                        wb_u128 rest;
+                        if (ch == 1) {
+                            v = segv[k * WB_BOXCOM_ROWS + r];
+                            rest = ((wb_u128)seghi[k * WB_BOXCOM_ROWS + r] << 64) | seglo[k * WB_BOXCOM_ROWS + r];
+                        } else {
+                            v = ch == 0 ? w : (double)y * w;
+                            unsigned long long m; int ex;
+                            wb_dbl_split(v, &m, &ex);
+                            rest = m ? (((wb_u128)m * (unsigned)(cols - 1)) << (ex - ue)) : (wb_u128)0;
+                        }
+                        WB_KAHAN(sv, cv, v);                          // the real step for the segment's first term
+                        E = wb_fix128(sv, ue);                         // s - c exactly
+                        if (cv > 0.0) { const wb_u128 f = wb_fix128(cv, ue); if (f > E) ok = false; else E -= f; }
+                        else if (cv < 0.0) E += wb_fix128(-cv, ue);
+                        E += rest;
+                    }
+                }
+                double sv = 0.0, cv = 0.0;
+                ok = ok && wb_state_from_exact(E, ue, &sv, &cv);
+                st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + nr] = sv;
+                st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + nr] = cv;
+                if (!ok) ctl[3] = 1;
+            WB_END_PFOR
+        }
+        WB_BSTAMP(a.ctl, 2);
+        if (!ctl[3]) {
+            // pass 3: the real recurrence over every row from its predicted state; the end must be the next row's start
+            WB_PFOR(r, nr)
+                const int y = y0 + r0 + (int)r;
+                const double w = a.wlat[y], yw = (double)y * w;
+                double sa = st[0 * (WB_BOXCOM_ROWS + 1) + r], ca = st[1 * (WB_BOXCOM_ROWS + 1) + r];
+                double sx = st[2 * (WB_BOXCOM_ROWS + 1) + r], cx = st[3 * (WB_BOXCOM_ROWS + 1) + r];
+                double sy = st[4 * (WB_BOXCOM_ROWS + 1) + r], cy = st[5 * (WB_BOXCOM_ROWS + 1) + r];
+                for (int x = x0; x <= x1; ++x) {
+                    const double xw = (double)x * w;
+                    WB_KAHAN(sa, ca, w);
+                    WB_KAHAN(sx, cx, xw);
+                    WB_KAHAN(sy, cy, yw);
+                }
+                if (!(sa == st[0 * (WB_BOXCOM_ROWS + 1) + r + 1] && ca == st[1 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
+                      sx == st[2 * (WB_BOXCOM_ROWS + 1) + r + 1] && cx == st[3 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
+                      sy == st[4 * (WB_BOXCOM_ROWS + 1) + r + 1] && cy == st[5 * (WB_BOXCOM_ROWS + 1) + r + 1])) ctl[3] = 1;
+            WB_END_PFOR
+        }
+        WB_BSTAMP(a.ctl, 3);
+        walked = walked || ctl[3] != 0;
+        WB_SINGLE
+        double sa, ca, sx, cx, sy, cy;
+        if (ctl[3]) {                                            // one lane, the chunk's cells in the reference's order, from the true start
+            sa = st[0 * (WB_BOXCOM_ROWS + 1)]; ca = st[1 * (WB_BOXCOM_ROWS + 1)];
+            sx = st[2 * (WB_BOXCOM_ROWS + 1)]; cx = st[3 * (WB_BOXCOM_ROWS + 1)];
+            sy = st[4 * (WB_BOXCOM_ROWS + 1)]; cy = st[5 * (WB_BOXCOM_ROWS + 1)];
+            for (int y = y0 + r0; y < y0 + r0 + nr; ++y) {
+                const double w = a.wlat[y];
+                const double yw = (double)y * w;
+                for (int x = x0; x <= x1; ++x) {
+                    const double xw = (double)x * w;
+                    WB_KAHAN(sa, ca, w);
+                    WB_KAHAN(sx, cx, xw);
+                    WB_KAHAN(sy, cy, yw);
                 }
             }
-            double sv = 0.0, cv = 0.0;
-            ok = ok && wb_state_from_exact(E, ue, &sv, &cv);
-            st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + rows] = sv;
-            st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + rows] = cv;
-            if (!ok) ctl[2] = 1;
-        WB_END_PFOR
+        } else {
+            sa = st[0 * (WB_BOXCOM_ROWS + 1) + nr]; ca = st[1 * (WB_BOXCOM_ROWS + 1) + nr];
+            sx = st[2 * (WB_BOXCOM_ROWS + 1) + nr]; cx = st[3 * (WB_BOXCOM_ROWS + 1) + nr];
+            sy = st[4 * (WB_BOXCOM_ROWS + 1) + nr]; cy = st[5 * (WB_BOXCOM_ROWS + 1) + nr];
+        }
+        st[0 * (WB_BOXCOM_ROWS + 1)] = sa; st[1 * (WB_BOXCOM_ROWS + 1)] = ca;      // the next chunk's start
+        st[2 * (WB_BOXCOM_ROWS + 1)] = sx; st[3 * (WB_BOXCOM_ROWS + 1)] = cx;
+        st[4 * (WB_BOXCOM_ROWS + 1)] = sy; st[5 * (WB_BOXCOM_ROWS + 1)] = cy;
+        WB_END_SINGLE
+        WB_BSTAMP(a.ctl, 4);
     }
-    WB_BSTAMP(a.ctl, 2);
-    if (!ctl[2]) {
-        // pass 3: the real recurrence over every row from its predicted state; the end must be the next row's start
-        WB_PFOR(r, rows)
-            const int y = y0 + (int)r;
-            const double w = a.wlat[y], yw = (double)y * w;
-            double sa = st[0 * (WB_BOXCOM_ROWS + 1) + r], ca = st[1 * (WB_BOXCOM_ROWS + 1) + r];
-            double sx = st[2 * (WB_BOXCOM_ROWS + 1) + r], cx = st[3 * (WB_BOXCOM_ROWS + 1) + r];
-            double sy = st[4 * (WB_BOXCOM_ROWS + 1) + r], cy = st[5 * (WB_BOXCOM_ROWS + 1) + r];
-            for (int x = x0; x <= x1; ++x) {
-                const double xw = (double)x * w;
-                WB_KAHAN(sa, ca, w);
-                WB_KAHAN(sx, cx, xw);
-                WB_KAHAN(sy, cy, yw);
-            }
-            if (!(sa == st[0 * (WB_BOXCOM_ROWS + 1) + r + 1] && ca == st[1 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
-                  sx == st[2 * (WB_BOXCOM_ROWS + 1) + r + 1] && cx == st[3 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
-                  sy == st[4 * (WB_BOXCOM_ROWS + 1) + r + 1] && cy == st[5 * (WB_BOXCOM_ROWS + 1) + r + 1])) ctl[2] = 1;
-        WB_END_PFOR
-    }
-    WB_BSTAMP(a.ctl, 3);
     WB_SINGLE
     double sa, sx, sy;
-    if (ctl[2]) {                                                // not verified: one lane walks every cell in the reference's order
+    if (ctl[2]) {                                                // exponents out of the fixed-point range: one lane walks every cell
         double ca = 0.0, cx = 0.0, cy = 0.0;
         sa = 0.0; sx = 0.0; sy = 0.0;
         for (int y = y0; y <= y1; ++y) {
@@ -797,12 +855,12 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                 WB_KAHAN(sy, cy, yw);
             }
         }
-        wb_atomic_add(&a.ctl->com_rechecks[2], 1);
     } else {
-        sa = st[0 * (WB_BOXCOM_ROWS + 1) + rows];
-        sx = st[2 * (WB_BOXCOM_ROWS + 1) + rows];
-        sy = st[4 * (WB_BOXCOM_ROWS + 1) + rows];
+        sa = st[0 * (WB_BOXCOM_ROWS + 1)];
+        sx = st[2 * (WB_BOXCOM_ROWS + 1)];
+        sy = st[4 * (WB_BOXCOM_ROWS + 1)];
     }
+    if (ctl[2] || walked) wb_atomic_add(&a.ctl->com_rechecks[2], 1);
     out[0] = sa;
     out[1] = sx;
     out[2] = sy;

@@ -53,6 +53,11 @@ static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
 // base[idx] += val (no return value); on the GPU lanes of a wave that hit the same idx are combined first
 static inline void wb_atomic_add_agg(int* base, int idx, int val) { base[idx] += val; }
 static inline void wb_atomic_min_first(int* addr, bool want, int val) { if (want && val < *addr) *addr = val; }
+// the block's sum of v, returned to every thread, added in a fixed order (butterfly inside a wave, then the waves in turn):
+// the same bits on every run; lw: LDS scratch of 16 doubles; all threads of the block call it
+static inline double wb_block_sum_f64(double v, double* lw) { (void)lw; return v; }
+// every thread's v added to *acc (LDS) -- one atomic per wave; all threads of the block call it, the sum stands after it
+static inline void wb_block_add_u64(unsigned long long* acc, unsigned long long v) { *acc += v; }
 // slot of an append to a list whose length counter all calling lanes share (-1 for lanes with want == false)
 static inline int wb_append_slot(int* counter, bool want) { return want ? (*counter)++ : -1; }
 // first slot of n (0 <= n < 32) consecutive entries appended by the calling lane
@@ -119,6 +124,27 @@ __device__ inline int wb_popc64(uint64_t v) { return __popcll(v); }
 // base[idx] += val without return value.  Many lanes of a wave usually target the same idx (all points of one
 // long contour): they are summed inside the wave first, one atomic per distinct idx (atomics on one address
 // serialise at ~12 ns each on this chip).  Must be called by converged code paths only in the sense that every
+// the block's sum of v, returned to every thread, added in a fixed order (butterfly inside a wave, then the waves in turn):
+// the same bits on every run; lw: LDS scratch of 16 doubles; all threads of the block call it
+__device__ inline double wb_block_sum_f64(double v, double* lw) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int nw = ((int)blockDim.x + 63) >> 6;
+    if (nw == 1) return v;
+    if ((threadIdx.x & 63) == 0) lw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += lw[w];
+    __syncthreads();
+    return t;
+}
+// every thread's v added to *acc (LDS) -- one atomic per wave; all threads of the block call it, the sum stands after it
+__device__ inline void wb_block_add_u64(unsigned long long* acc, unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(acc, v);
+    __syncthreads();
+}
 // atomicMin(addr, val) by the lowest lane that wants it -- for values that ascend with the lane (an index search): one
 // atomic per wave instead of one per hit
 __device__ inline void wb_atomic_min_first(int* addr, bool want, int val) {
