@@ -1067,7 +1067,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             oa.lat = T->base + T->o_lat; oa.ot_n = ot_n; oa.ot_box = ot_box; oa.ot_orient = ot_orient; oa.status = b->status;
             side_begin(ctx);
             b->timer.begin(ctx, "overturn");
-            WB_LAUNCH(wb_k_overturn, nsel_b, 256, oa);
+            WB_LAUNCH_LDS(wb_k_overturn, nsel_b, 256, (size_t)b->W * 8 + 32, oa);
             b->timer.end(ctx);
             if (r * r <= 1.0) {
                 WbBoxComArgs ba;

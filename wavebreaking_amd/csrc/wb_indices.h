@@ -114,7 +114,9 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
-    WB_SHARED(int, hist, WB_MAXW);
+    WB_DYN_SHARED_BEGIN
+    WB_DYN_SHARED(int, hist, a.W);               // visits per longitude, then 0 / 1 visited three times or more / 2 ... and first of its group
+    WB_DYN_SHARED(int, prevm, a.W);              // the last such longitude west of x, then the groups that start west of x
     WB_SHARED(int, gmin, WB_OT_CAP);
     WB_SHARED(int, gmax, WB_OT_CAP);
     WB_SHARED(int, gdrop, WB_OT_CAP);
@@ -132,23 +134,36 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
     WB_PFOR(i, N)
         wb_atomic_add(&hist[wb_pt_x(pts[i])], 1);
     WB_END_PFOR
-    // (1)-(3) longitudes visited >= 3 times, labelled by gaps > range_group/dlon, min/max per label
-    WB_SINGLE
-    int G = 0, prev = 0;
-    bool have = false, overflow = false;
-    for (int x = 0; x < a.W; ++x) {
-        if (hist[x] >= 3) {
-            if (!have || (double)(x - prev) > a.rg_over_dlon) {
-                if (G < WB_OT_CAP) { gmin[G] = x; gmax[G] = x; ++G; } else overflow = true;
-            } else if (!overflow) {
-                gmax[G - 1] = x;
+    // (1)-(3) longitudes visited >= 3 times, labelled by gaps > range_group/dlon, min/max per label: two block scans over the
+    // longitudes (the last marked longitude to the west; the groups that start to the west) -- one lane walking the W
+    // longitudes, a dependent LDS read each, was 80 us of a workgroup's 150
+    WB_PFOR(x, a.W)
+        prevm[x] = hist[x] >= 3 ? (int)x : -1;
+    WB_END_PFOR
+    wb_block_scan_excl_max(prevm, a.W, -1);
+    WB_PFOR(x, a.W)
+        const int pm = prevm[x];
+        const int code = hist[x] >= 3 ? ((pm < 0 || (double)((int)x - pm) > a.rg_over_dlon) ? 2 : 1) : 0;
+        hist[x] = code;
+        prevm[x] = code == 2 ? 1 : 0;
+    WB_END_PFOR
+    const int Gall = wb_block_scan_excl(prevm, a.W);
+    WB_PFOR(g, Gall < WB_OT_CAP ? Gall : WB_OT_CAP)
+        gmax[g] = -1;
+    WB_END_PFOR
+    WB_PFOR(x, a.W)
+        const int code = hist[x];
+        if (code) {
+            const int g = prevm[x] + (code == 2 ? 1 : 0) - 1;
+            if (g < WB_OT_CAP) {
+                if (code == 2) gmin[g] = (int)x;
+                wb_atomic_max(&gmax[g], (int)x);
             }
-            have = true;
-            prev = x;
         }
-    }
-    gcount[0] = G;
-    if (overflow) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+    WB_END_PFOR
+    WB_SINGLE
+    gcount[0] = Gall < WB_OT_CAP ? Gall : WB_OT_CAP;
+    if (Gall > WB_OT_CAP) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
     WB_END_SINGLE
     int G = gcount[0];
     // check_duplicates (:136-162)
