@@ -1024,7 +1024,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.truncate(b->timer_phase1);
         WbCtl* ctl = b->d_ctl;
         // the phase-2 part of the control block starts from zero (phase-1 values stay)
-#if defined(WB_STAMPS) && WB_STAMPS == 4                                 // (the stamps of a phase-1 kernel survive into the snapshot)
+#if defined(WB_STAMPS) && (WB_STAMPS == 4 || WB_STAMPS == 6)                                 // (the stamps of a phase-1 kernel survive into the snapshot)
         dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, offsetof(WbCtl, dbg) - offsetof(WbCtl, nsel));
 #else
         dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, sizeof(WbCtl) - offsetof(WbCtl, nsel));

@@ -268,11 +268,13 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         return;
     }
     const bool lds = n <= WB_TRACE_LDS_N;
+    WB_LSTAMP_BEGIN                              // development stamps: 0 strip bases, 1 keys to LDS, 2 merge + crossing points, 3 merged keys to LDS, 4 successors
     WB_SINGLE
     int run = 0;
     for (int s = 0; s < a.nstrips; ++s) { sbase[s] = run; run += a.stg_n[job * a.nstrips + s]; }
     sbase[a.nstrips] = run;
     WB_END_SINGLE
+    WB_LSTAMP(a.ctl, 0);
     if (lds) {
         WB_PFOR(g, n)
             int s = 0;
@@ -280,6 +282,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
             ks[g] = a.stg_k[((size_t)job * a.nstrips + s) * a.cap_strip + ((int)g - sbase[s])] & 0x07FFFFFFu;
         WB_END_PFOR
     }
+    WB_LSTAMP(a.ctl, 1);
     WB_PFOR(g, n)
         int s = 0;
         while ((int)g >= sbase[s + 1]) ++s;
@@ -288,7 +291,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         const uint32_t key = a.stg_k[sb + i];
         const uint32_t kk = key & 0x07FFFFFFu;
         int dest = i;
-        for (int s2 = 0; s2 < a.nstrips; ++s2) {
+        for (int s2 = 0; s2 < a.nstrips; ++s2) {       // (these searches in lockstep, eight independent LDS reads per step, changed nothing: the phase waits for its global loads and scattered stores)
             if (s2 == s) continue;
             int lo = 0, hi = sbase[s2 + 1] - sbase[s2];
             if (lds) {
@@ -328,6 +331,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         t0[g] = 0;  // "is first segment of a cut loop"
     WB_END_PFOR
 
+    WB_LSTAMP(a.ctl, 2);
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
     //          the edge this one ends on (binary search by square key in the merged list)
     if (lds) {
@@ -336,6 +340,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         WB_END_PFOR
     }
     const uint32_t* keys = lds ? mk : segk;
+    WB_LSTAMP(a.ctl, 3);
     WB_PFOR(i, n)
         const uint32_t k = keys[i];
         const int sq = wb_key_sq(k), r = sq / W, c = sq - r * W;
@@ -371,6 +376,8 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         succ[i] = s;
         if (s != WB_NIL) pred[s] = (uint32_t)i;
     WB_END_PFOR
+    WB_LSTAMP(a.ctl, 4);
+    WB_LSTAMP_FLUSH(a.ctl);
     WB_SINGLE
     a.nseg[job] = n;
     WB_END_SINGLE
