@@ -1220,13 +1220,24 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
                         WB_PFOR(m, N - 1)
                             const uint32_t pa = pts[m], pb = pts[m + 1];
                             const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
-                            uint32_t hits = 0u;
-                            for (int c = 0; c < nb; ++c) {
+                            // first the chords whose box meets the segment's (eight at a time: their LDS reads in flight together),
+                            // then the exact predicate for those few
+                            uint32_t near = 0u, hits = 0u;
+                            const int sx0 = ax < bx ? ax : bx, sx1 = ax < bx ? bx : ax, sy0 = ay < by ? ay : by, sy1 = ay < by ? by : ay;
+                            for (int c0 = 0; c0 < nb; c0 += 8) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) {
+                                    const uint32_t pq = hq[(c0 + q) & (WB_F234_BATCH - 1)];
+                                    const int qx = wb_pt_x(pq), qy = wb_pt_y(pq);
+                                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                                    if (c0 + q < nb && !(sx1 < cx0 || sx0 > cx1 || sy1 < cy0 || sy0 > cy1)) near |= 1u << (c0 + q);
+                                }
+                            }
+                            while (near) {
+                                const int c = wb_ctz32(near);
+                                near &= near - 1u;
                                 const uint32_t pq = hq[c];
-                                const int qx = wb_pt_x(pq), qy = wb_pt_y(pq);
-                                const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
-                                if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                                    if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) hits |= 1u << c;
+                                if (wb_chord_hits_segment(px, py, wb_pt_x(pq), wb_pt_y(pq), ax, ay, bx, by, m == 0, m == N - 2)) hits |= 1u << c;
                             }
                             if (hits) wb_atomic_or(&hitm[0], hits);
                         WB_END_PFOR
