@@ -414,7 +414,8 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     out = {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
            "upload_GBps": pv.nbytes / t_up / 1e9, "both_runs_s": [sum(r[0].values()) for r in runs],
            "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, cold input "
-                   "cache at the first call, H2D included" % (nt, pv.nbytes / 1e9)}
+                   "cache at the first call, H2D included (the first call computes a block of steps while the next one "
+                   "is uploaded: engine.resident_inputs)" % (nt, pv.nbytes / 1e9), "pipelined_upload": bool(engine.PIPELINED_UPLOAD)}
     # the reference's own sharing: contours once, handed to the three calls (cubes already resident from the calls above)
     tic = time.perf_counter()
     cont = wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False)

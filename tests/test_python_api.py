@@ -470,3 +470,51 @@ def test_inputs_and_contour_batches_stay_on_the_device_between_calls(hostsim_eng
     wb.release_inputs()
     resident, kept = engine._caches(ctx)
     assert not resident and not kept
+
+
+def test_first_call_uploads_in_blocks_while_it_computes(hostsim_engine, monkeypatch):
+    """a record of 128+ steps that is not on the device yet is cut into four blocks: a thread of its own uploads block k + 1
+    while block k is traced; same frames as with whole cubes first, the later calls reuse the blocks' contour batches"""
+    lat, lon = synth.grid(2.5)
+    nt = 130
+    pv = synth.pv_field(0, nt, lat, lon, eps=0.3).astype(np.float32)
+    inten_np = synth.pv_field(0, nt, lat, lon, eps=0.0, seed=20241).astype(np.float32)
+    coords = {"time": synth.times(nt), "lat": lat, "lon": lon}
+    data = wb.GridField(pv, ("time", "lat", "lon"), coords, name="PV")
+    inten = wb.GridField(inten_np, ("time", "lat", "lon"), coords, name="intensity")
+    ctx = engine.get_context()
+    traced, copied = [], []
+    real_contours = ctx.contours
+    monkeypatch.setattr(ctx, "contours", lambda *a, **k: (traced.append(k["device_shape"][0]), real_contours(*a, **k))[1])
+    copier = engine._copier(ctx)
+    real_copy = copier.copy_to_device
+    monkeypatch.setattr(copier, "copy_to_device", lambda p, a: (copied.append(a.shape[0]), real_copy(p, a))[1])
+    s1 = wb.calculate_streamers(data=data, contour_levels=[-2, 2], intensity=inten)
+    assert traced == [64, 64, 2] and copied == [64, 64, 64, 64, 2, 2]          # max(64, ceil(130 / 4)) steps per block, field then intensity
+    o1 = wb.calculate_overturnings(data=data, contour_levels=[-2, 2], intensity=inten)
+    assert len(traced) == 3 and len(copied) == 6                                 # the blocks' batches and the cubes are reused
+    wb.release_inputs()
+    monkeypatch.setattr(engine, "PIPELINED_UPLOAD", False)
+    s2 = wb.calculate_streamers(data=data, contour_levels=[-2, 2], intensity=inten)
+    o2 = wb.calculate_overturnings(data=data, contour_levels=[-2, 2], intensity=inten)
+    assert traced[3:] == [130]
+    for a, b in ((s1, s2), (o1, o2)):
+        assert len(a) == len(b) > 0
+        for col in ("date", "level", "com", "mean_var", "intensity", "event_area"):
+            assert list(a[col]) == list(b[col]), col
+        assert [np.asarray(g.geoms[0].exterior.coords).tolist() for g in a["geometry"]] == \
+               [np.asarray(g.geoms[0].exterior.coords).tolist() for g in b["geometry"]]
+    # a failing copy is reported by the call that waits for it
+    wb.release_inputs()
+    monkeypatch.setattr(engine, "PIPELINED_UPLOAD", True)
+
+    def broken(p, a):
+        raise RuntimeError("h2d failed: test")
+    monkeypatch.setattr(copier, "copy_to_device", broken)
+    with pytest.raises(RuntimeError, match="h2d failed"):
+        wb.calculate_streamers(data=data, contour_levels=[-2, 2], intensity=inten)
+    monkeypatch.setattr(copier, "copy_to_device", real_copy)
+    assert not engine._caches(ctx)[0]                                            # ... and nothing of the half-copied cubes is kept
+    s3 = wb.calculate_streamers(data=data, contour_levels=[-2, 2], intensity=inten)
+    assert list(s3["com"]) == list(s1["com"])
+    wb.release_inputs()

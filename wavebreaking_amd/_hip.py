@@ -196,6 +196,12 @@ class Context:
             raise RuntimeError("h2d failed")
         return p
 
+    def copy_to_device(self, p, arr):
+        """host array -> device memory at p (any context's allocation on this device)"""
+        arr = np.ascontiguousarray(arr)
+        if self.L.lib.wb_memcpy_h2d(self.h, C.c_void_p(p), arr.ctypes.data_as(C.c_void_p), arr.nbytes) != 0:
+            raise RuntimeError("h2d failed: " + self.error())
+
     def to_host(self, p, shape, dtype, offset_bytes=0):
         out = np.empty(shape, dtype=dtype)
         if self.L.lib.wb_memcpy_d2h(self.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(p + offset_bytes), out.nbytes) != 0:

@@ -2,6 +2,7 @@
 array extraction, level chunking (the ABI takes up to 4 levels per pass), frame <-> table conversion."""
 import logging
 import os
+import threading
 
 import numpy as np
 
@@ -117,6 +118,9 @@ class Prepared:
 # In-place edits of single cells between two calls can slip through that sample: WB_INPUT_CACHE=0 (or release_inputs())
 # uploads on every call.  WB_INPUT_CACHE_GB bounds the device memory kept (default 48).
 INPUT_CACHE = os.environ.get("WB_INPUT_CACHE", "1") != "0"
+# The first call on a cube that is not on the device yet cuts the record into blocks and computes block k while block k + 1
+# is uploaded (WB_PIPELINED_UPLOAD=0: whole cubes first, as until round 3)
+PIPELINED_UPLOAD = os.environ.get("WB_PIPELINED_UPLOAD", "1") != "0"
 _tick = [0]
 
 
@@ -141,11 +145,67 @@ def _cacheable(arr):
             and arr.flags.c_contiguous and arr.size > 0)
 
 
+class _Upload:
+    """One or two cubes on their way to the device, block of time steps after block (the field's block, then the
+    intensity's), copied by a thread of its own through a context of its own (stream + pinned staging buffers; a context is
+    driven by one thread at a time) into memory the calling context allocated.  ``wait(t1)``: until the steps below t1 of
+    every cube are there.  The first call on a host cube computes block k while block k + 1 crosses PCIe."""
+
+    def __init__(self, copier, jobs, nt, block):
+        self.cv = threading.Condition()
+        self.done, self.error, self.nt = 0, None, nt
+        self.thread = threading.Thread(target=self._run, args=(copier, jobs, nt, block), daemon=True)
+        self.thread.start()
+
+    def _run(self, copier, jobs, nt, block):
+        try:
+            for t0 in range(0, nt, block):
+                t1 = min(nt, t0 + block)
+                for ptr, arr, step_bytes in jobs:
+                    copier.copy_to_device(ptr + t0 * step_bytes, arr[t0:t1])
+                with self.cv:
+                    self.done = t1
+                    self.cv.notify_all()
+        except BaseException as e:                       # handed to whoever waits
+            with self.cv:
+                self.error = e
+                self.cv.notify_all()
+
+    def wait(self, t1=None):
+        t1 = self.nt if t1 is None else min(int(t1), self.nt)
+        with self.cv:
+            while self.done < t1 and self.error is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise self.error
+
+
+def _copier(ctx):
+    """the context whose stream and staging buffers carry the background uploads of ``ctx``"""
+    if getattr(ctx, "_wb_copier", None) is None:
+        ctx._wb_copier = _hip.Context(ctx.device, ctx.L)
+    return ctx._wb_copier
+
+
+def _settle(ent):
+    up = ent.get("upload")
+    if up is not None:
+        try:
+            up.wait()
+        finally:
+            up.thread.join()
+            ent["upload"] = None
+
+
 def _drop_resident(ctx, key):
     resident, kept = _caches(ctx)
     ent = resident.pop(key, None)
     if ent is None:
         return
+    try:
+        _settle(ent)                                 # (nobody frees memory a copy is still writing to)
+    except BaseException:
+        pass
     for bk in [k for k, v in kept.items() if v["field"] == key or v["intensity"] == key]:
         kept.pop(bk)["batch"].close()
     if ctx.h:
@@ -162,12 +222,52 @@ def release_inputs():
             _drop_resident(ctx, key)
 
 
+def resident_inputs(ctx, field, intensity, block):
+    """the entries of a call's cube(s).  Cubes that are not on the device yet are allocated here and uploaded in the
+    background, ``block`` time steps at a time (``ent["upload"].wait(t1)`` before steps below t1 are used; ``ent["block"]`` is
+    the block size the call should cut the record into so that computing overlaps the upload)"""
+    resident, _ = _caches(ctx)
+    arrs = [a for a in (field, intensity) if a is not None]
+    keys = [_array_key(a) for a in arrs]
+    fresh = [k not in resident for k in keys]
+    nt = field.shape[0]
+    if not any(fresh) or not PIPELINED_UPLOAD or block >= nt:
+        ents = [resident_input(ctx, a) for a in arrs]
+        return ents[0], (ents[1] if intensity is not None else None)
+    budget = float(os.environ.get("WB_INPUT_CACHE_GB", 48)) * 2.0 ** 30
+    need = sum(a.nbytes for a, f in zip(arrs, fresh) if f)
+    while resident and sum(v["nbytes"] for v in resident.values()) + need > budget:
+        victim = min((k for k in resident if k not in keys), key=lambda k: resident[k]["tick"], default=None)
+        if victim is None:
+            break
+        _drop_resident(ctx, victim)
+    jobs, ents, new = [], [], []
+    for a, k in zip(arrs, keys):
+        _tick[0] += 1
+        ent = resident.get(k)
+        if ent is None:
+            ent = dict(ptr=ctx.alloc(a.nbytes), nbytes=a.nbytes, key=k, block=block, upload=None)
+            resident[k] = ent
+            jobs.append((ent["ptr"], a, a[0].nbytes))
+            new.append(ent)
+        elif ent not in new:
+            _settle(ent)
+        ent["tick"] = _tick[0]
+        ents.append(ent)
+    up = _Upload(_copier(ctx), jobs, nt, block)
+    for ent in new:
+        ent["upload"] = up
+    return ents[0], (ents[1] if intensity is not None else None)
+
+
 def resident_input(ctx, arr):
     """device pointer entry of a host cube, uploading it unless this context still holds it"""
     resident, _ = _caches(ctx)
     key = _array_key(arr)
     _tick[0] += 1
     ent = resident.get(key)
+    if ent is not None:
+        _settle(ent)                                 # (a background upload of an earlier call: wait for all of it)
     if ent is None:
         budget = float(os.environ.get("WB_INPUT_CACHE_GB", 48)) * 2.0 ** 30
         while resident and sum(v["nbytes"] for v in resident.values()) + arr.nbytes > budget:
@@ -207,8 +307,10 @@ def iter_contour_batches(prep, levels, periodic_add, params, want_cells=False):
     if keep:
         # the cubes go to the device once (whole, whatever the block size) and stay there for the next call
         _, _kept = _caches(ctx)
-        fe = resident_input(ctx, prep.values)
-        ie = resident_input(ctx, prep.intensity) if prep.intensity is not None else None
+        # (a record of at least 128 steps that still has to cross PCIe: in four blocks, so that three of them are computed
+        # while the next one arrives; the kept contour batches are per block, later calls cut the record the same way)
+        fe, ie = resident_inputs(ctx, prep.values, prep.intensity, min(chunk, max(64, -(-nt // 4))) if nt >= 128 else chunk)
+        chunk = min(chunk, fe.get("block", chunk))
         grid = hash((prep.lat.tobytes(), prep.lon.tobytes(), float(prep.dlon), float(prep.dlat)))
         step_bytes = nlat * nlon * prep.values.dtype.itemsize
     for t0 in range(0, nt, chunk):
@@ -218,6 +320,15 @@ def iter_contour_batches(prep, levels, periodic_add, params, want_cells=False):
             pos = list(range(lo, min(lo + MAX_LEVELS, len(levels))))
             lev = [float(levels[i]) for i in pos]
             if keep:
+                try:
+                    for e in (fe, ie):
+                        if e is not None and e.get("upload") is not None:
+                            e["upload"].wait(t1)             # the block's steps are on the device (the later ones on their way)
+                except BaseException:
+                    for e in (fe, ie):                       # a copy failed: nothing of these cubes stays in the cache
+                        if e is not None:
+                            _drop_resident(ctx, e["key"])
+                    raise
                 d_int = ie["ptr"] + t0 * step_bytes if ie is not None else None
                 bkey = (fe["key"], grid, tuple(lev), float(periodic_add), t0, t1, bool(want_cells))
                 ent = _kept.get(bkey)
