@@ -403,6 +403,7 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     # notifier evict and restore the process's GPU queues -- a ~100 ms stall in whichever call comes next)
     warm = fields(pv.copy(), inten.copy() if inten is not None else None)
     three(*warm)
+    three(*warm, contours=wb.calculate_contours(data=warm[0], contour_levels=levels, original_coordinates=False))
     wb.release_inputs()
     runs = []
     for rep in range(2):                                      # twice from a cold cache; the faster one is reported, both listed
@@ -414,8 +415,7 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     out = {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
            "upload_GBps": pv.nbytes / t_up / 1e9, "both_runs_s": [sum(r[0].values()) for r in runs],
            "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, cold input "
-                   "cache at the first call, H2D included (the first call computes a block of steps while the next one "
-                   "is uploaded: engine.resident_inputs)" % (nt, pv.nbytes / 1e9), "pipelined_upload": bool(engine.PIPELINED_UPLOAD)}
+                   "cache at the first call, H2D included" % (nt, pv.nbytes / 1e9), "pipelined_upload": bool(engine.PIPELINED_UPLOAD)}
     # the reference's own sharing: contours once, handed to the three calls (cubes already resident from the calls above)
     tic = time.perf_counter()
     cont = wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False)

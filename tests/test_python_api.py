@@ -473,7 +473,7 @@ def test_inputs_and_contour_batches_stay_on_the_device_between_calls(hostsim_eng
 
 
 def test_first_call_uploads_in_blocks_while_it_computes(hostsim_engine, monkeypatch):
-    """a record of 128+ steps that is not on the device yet is cut into four blocks: a thread of its own uploads block k + 1
+    """WB_PIPELINED_UPLOAD=1: a record of 128+ steps that is not on the device yet is cut into four blocks: a thread of its own uploads block k + 1
     while block k is traced; same frames as with whole cubes first, the later calls reuse the blocks' contour batches"""
     lat, lon = synth.grid(2.5)
     nt = 130
@@ -486,6 +486,7 @@ def test_first_call_uploads_in_blocks_while_it_computes(hostsim_engine, monkeypa
     traced, copied = [], []
     real_contours = ctx.contours
     monkeypatch.setattr(ctx, "contours", lambda *a, **k: (traced.append(k["device_shape"][0]), real_contours(*a, **k))[1])
+    monkeypatch.setattr(engine, "PIPELINED_UPLOAD", True)                        # (an option: WB_PIPELINED_UPLOAD=1)
     copier = engine._copier(ctx)
     real_copy = copier.copy_to_device
     monkeypatch.setattr(copier, "copy_to_device", lambda p, a: (copied.append(a.shape[0]), real_copy(p, a))[1])

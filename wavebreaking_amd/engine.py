@@ -118,9 +118,12 @@ class Prepared:
 # In-place edits of single cells between two calls can slip through that sample: WB_INPUT_CACHE=0 (or release_inputs())
 # uploads on every call.  WB_INPUT_CACHE_GB bounds the device memory kept (default 48).
 INPUT_CACHE = os.environ.get("WB_INPUT_CACHE", "1") != "0"
-# The first call on a cube that is not on the device yet cuts the record into blocks and computes block k while block k + 1
-# is uploaded (WB_PIPELINED_UPLOAD=0: whole cubes first, as until round 3)
-PIPELINED_UPLOAD = os.environ.get("WB_PIPELINED_UPLOAD", "1") != "0"
+# WB_PIPELINED_UPLOAD=1: the first call on a cube that is not on the device yet cuts the record into blocks and computes
+# block k while block k + 1 is uploaded.  Off by default: measured on MI355X (365 steps of 0.25 degree, field + intensity)
+# the four blocks' fixed costs -- four wb_contours / wb_indices calls per index function instead of one -- were as large as
+# the 4 ms of computing they hid behind the 55 ms of PCIe (72.6 ms for the three calls without it, 84.6 ms with it on a
+# slower box), and a later call with ``contours=`` needs a whole-record batch the allocator has not seen yet.
+PIPELINED_UPLOAD = os.environ.get("WB_PIPELINED_UPLOAD", "0") == "1"
 _tick = [0]
 
 
