@@ -48,3 +48,13 @@ prof("streamers, contours=frame", lambda: wb.calculate_streamers(data=data, cont
 prof("calculate_contours(original_coordinates=False)", lambda: wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False))
 os.environ["WB_DEBUG_TIMING"] = "1"
 wb.calculate_streamers(data=data, contour_levels=levels, intensity=idata, contours=cont)
+
+
+def cold():
+    wb.release_inputs()
+    return wb.calculate_streamers(data=data, contour_levels=levels, intensity=idata)
+
+
+cold()
+prof("streamers, cold cache (two uploads + everything)", cold)
+prof("overturnings, cached", lambda: wb.calculate_overturnings(data=data, contour_levels=levels, intensity=idata))

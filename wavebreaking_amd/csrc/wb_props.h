@@ -103,35 +103,65 @@ WB_HD inline double wb_com_ulps(int rows) { return 4.0 * (2.0 * (double)rows + 1
 #define WB_PROPS_LONG 16
 // sum over the member cells of the box [x0, x0 + cols) x [y0, y0 + rows) of weight(y) * (data, intensity): the lanes run
 // ALONG the rows (adjacent lanes on adjacent cells: a load instruction touches two or three cache lines, not 64), eight
-// loads in flight per lane; bm == NULL: every cell is a member.  The lane's two partial sums go to out[2 * lane].  (These
-// sums are compared to 1e-6 relative: the order of summation is free.)  A version without the division and modulo per cell
-// (a column's place in the field found once, eight ROWS in flight) was no faster -- the loads' latency is what the loop
-// waits for -- and took the kernel from 100 to 128 registers: four of its waves then fill a SIMD's register file and
-// nothing else runs beside them (wb_k_pack_polys on the side stream: 0.06 -> 0.5 ms; round 3).
-WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
-                                       double* out) {
-    const int total = rows * cols;
+// cells' loads in flight per lane; BM false: every cell is a member.  The lane's two partial sums go to out[2 * lane].
+// (These sums are compared to 1e-6 relative: the order of summation is free.)
+// The loads are UNCONDITIONAL (a cell that is not a member is read all the same -- its address lies inside the field -- and
+// dropped afterwards) and the loop has no branch between them: written as `in ? load : 0` every load sat in a block of
+// its own with an s_waitcnt vmcnt(0) behind it (the float -> double conversion inside the branch needs the value), the
+// "eight loads in flight" were one, and the sums were 70 % of the kernel (seen in the ISA, round 3).
+template <class T, bool BM>
+WB_DEV inline void wb_props_field_sums_t(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
+                                         double* out) {
+    const T* data = (const T*)a.data + tbase;
+    const bool has_i = a.intensity != nullptr;
+    const T* inten = has_i ? (const T*)a.intensity + tbase : data;    // (no intensity: the same cells again, dropped below)
+    const int total = rows * cols, dq = WB_NT / cols, dr = WB_NT - dq * cols;
     double accv = 0.0, acci = 0.0;
     int i = WB_TID, rr = i / cols, xx = i - rr * cols;
     while (i < total) {
-        double dv[8], di[8], wq[8];
+        T dv[8], di[8];
+        double wq[8];
+        unsigned member = 0u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const bool in = i < total && (bm == nullptr || ((bm[rr * wb + (xx >> 5)] >> (xx & 31)) & 1u));
-            const int gx = x0 + xx, y = y0 + (i < total ? rr : 0);
-            const size_t idx = tbase + (size_t)y * a.nlon + (size_t)((gx < a.W ? gx : a.W - 1) % a.nlon);
-            dv[q] = in ? wb_load_field(a.data, idx, a.dtype) : 0.0;
-            di[q] = (in && a.intensity) ? wb_load_field(a.intensity, idx, a.dtype) : 0.0;
-            wq[q] = in ? a.wlat[y] : 0.0;
-            i += WB_NT; xx += WB_NT;
-            while (xx >= cols) { xx -= cols; ++rr; }
+            const bool live = i < total;
+            const int rq = live ? rr : 0, xq = live ? xx : 0;
+            bool in = live;
+            if (BM) in = in && ((bm[rq * wb + (xq >> 5)] >> (xq & 31)) & 1u);
+            int gx = x0 + xq;
+            gx = gx < a.W ? gx : a.W - 1;
+            const int col = gx >= a.nlon ? gx - a.nlon : gx;                   // W <= 2 nlon
+            const int y = y0 + rq;
+            const size_t idx = (size_t)y * a.nlon + (size_t)col;
+            dv[q] = data[idx];
+            di[q] = inten[idx];
+            wq[q] = a.wlat[y];
+            member |= (in ? 1u : 0u) << q;
+            i += WB_NT; xx += dr; rr += dq;
+            const bool wrap = xx >= cols;
+            xx = wrap ? xx - cols : xx;
+            rr = wrap ? rr + 1 : rr;
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { accv += wq[q] * dv[q]; acci += wq[q] * di[q]; }
+        for (int q = 0; q < 8; ++q) {
+            const double pv = wq[q] * (double)dv[q], pi = wq[q] * (double)di[q];
+            accv += ((member >> q) & 1u) ? pv : 0.0;
+            acci += (((member >> q) & 1u) && has_i) ? pi : 0.0;
+        }
     }
     out[2 * WB_TID] = accv;
     out[2 * WB_TID + 1] = acci;
     WB_SYNC();
+}
+WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
+                                       double* out) {
+    if (a.dtype == 0) {
+        if (bm) wb_props_field_sums_t<float, true>(a, tbase, x0, y0, rows, cols, bm, wb, out);
+        else wb_props_field_sums_t<float, false>(a, tbase, x0, y0, rows, cols, bm, wb, out);
+    } else {
+        if (bm) wb_props_field_sums_t<double, true>(a, tbase, x0, y0, rows, cols, bm, wb, out);
+        else wb_props_field_sums_t<double, false>(a, tbase, x0, y0, rows, cols, bm, wb, out);
+    }
 }
 // The raster of an event in LDS: per row of its bounding box a short list of signed scanline crossings (sorted by the
 // row's lane, swept into winding numbers) and one bit per cell.  Events taller than WB_PROPS_LROWS rows, with more cells
