@@ -289,6 +289,16 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         const int i = (int)g - sbase[s];
         const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
         const uint32_t key = a.stg_k[sb + i];
+        // (the square's four corner values requested together with its key: they are not needed before the searches below
+        //  are done, and loaded after them they were a second round trip to memory per segment)
+        double ul, ur, ll, lr;
+        if (a.dtype == 0) {
+            const float* v = (const float*)a.stg_v + (sb + i) * 4;
+            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
+        } else {
+            const double* v = (const double*)a.stg_v + (sb + i) * 4;
+            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
+        }
         const uint32_t kk = key & 0x07FFFFFFu;
         int dest = i;
         for (int s2 = 0; s2 < a.nstrips; ++s2) {       // (these searches in lockstep, eight independent LDS reads per step, changed nothing: the phase waits for its global loads and scattered stores)
@@ -310,14 +320,6 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
             dest += lo;
         }
         // crossing coordinates of the segment's two end points, rounded half-to-even (contour_index.py:111)
-        double ul, ur, ll, lr;
-        if (a.dtype == 0) {
-            const float* v = (const float*)a.stg_v + (sb + i) * 4;
-            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
-        } else {
-            const double* v = (const double*)a.stg_v + (sb + i) * 4;
-            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
-        }
         const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
         const double level = a.levels[job % a.nlev];
         // a corner that equals the level puts the crossing ON a grid vertex: joined by the vertex rule below; the
