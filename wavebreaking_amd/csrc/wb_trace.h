@@ -1001,37 +1001,30 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
         WB_END_PFOR
     }
     WB_TSTAMP(a.ctl, 4);
-    // keep[] becomes the exclusive scan = new position; remember the flags in t1 (bit per raw point
-    // would do, but raw points can be 2*cap: use the rawcid high bit instead)
-    WB_PFOR(p, R)
-        if (keep[p]) rawcid[p] |= 0x80000000u;
-    WB_END_PFOR
+    // keep[] becomes the exclusive scan = new position (R + 1 entries: a point was kept iff its successor's position is larger)
     const int Rk = wb_block_scan_excl(keep, R + 1);
     (void)Rk;
     // per contour: new length, kept flag (>= 4 points, contour_index.py:113-117)
     int* kc = (int*)t1;        // [C] kept flag -> scan -> id among kept
-    WB_PFOR(c, C)
-        const int b0 = rawbase[c], b1 = rawbase[c] + cnt[c] + 1;
-        kc[c] = (keep[b1] - keep[b0]) >= 4 ? 1 : 0;
-    WB_END_PFOR
     int* kcflag = (int*)t0;    // copy of the flag (t0 free now)
     WB_PFOR(c, C)
-        kcflag[c] = kc[c];
+        const int b0 = rawbase[c], b1 = rawbase[c] + cnt[c] + 1;
+        const int f = (keep[b1] - keep[b0]) >= 4 ? 1 : 0;
+        kc[c] = f;
+        kcflag[c] = f;
     WB_END_PFOR
     const int Ck = wb_block_scan_excl(kc, C);
-    // compact points; owner = id among kept contours (NIL for contours that are too short)
+    // compact points; owner = id among kept contours (NIL for contours that are too short) -- and, the first C lanes, the
+    // pre-drop contour table in the c_* arrays (indexed by id among kept)
     WB_PFOR(p, R)
-        if (rawcid[p] & 0x80000000u) {
-            const uint32_t c = rawcid[p] & 0x7FFFFFFFu;
-            const int q = keep[p];
+        const int q = keep[p];
+        if (keep[p + 1] != q) {
+            const uint32_t c = rawcid[p];
             cpts[q] = rawpt[p];
             cown[q] = kcflag[c] ? (uint32_t)kc[c] : WB_NIL;
         }
-    WB_END_PFOR
-    // pre-drop contour table in the c_* arrays (indexed by id among kept)
-    WB_PFOR(c, C)
-        if (kcflag[c]) {
-            const int f = kc[c];
+        if (p < C && kcflag[p]) {
+            const int c = (int)p, f = kc[c];
             const int b0 = rawbase[c], b1 = rawbase[c] + cnt[c] + 1;
             c_off[f] = keep[b0];
             c_len[f] = keep[b1] - keep[b0];
@@ -1195,10 +1188,6 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_TSTAMP(a.ctl, 9);
     // ---- P8: final table = kept and not dropped, order preserved
     int* fin = (int*)t0;  // [Ck] -> exclusive scan
-    WB_PFOR(f, Ck)
-        fin[f] = dropped[f] ? 0 : 1;
-    WB_END_PFOR
-    const int Cf = wb_block_scan_excl(fin, Ck);
     // move table entries down (read everything first, then write: entries only move to lower slots,
     // but different threads handle different slots, so stage through scratch)
     int* s_off = (int*)spare0;
@@ -1207,12 +1196,14 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     int* s_nux = (int*)succ;
     int* s_sy = (int*)pred;
     WB_PFOR(f, Ck)
+        fin[f] = dropped[f] ? 0 : 1;
         s_off[f] = c_off[f];
         s_len[f] = c_len[f];
         s_cl[f] = c_closed[f];
         s_nux[f] = c_nux[f];
         s_sy[f] = c_sumy[f];
     WB_END_PFOR
+    const int Cf = wb_block_scan_excl(fin, Ck);
     WB_PFOR(f, Ck)
         if (!dropped[f]) {
             const int g = fin[f];
