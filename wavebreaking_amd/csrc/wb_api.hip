@@ -1173,7 +1173,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_pairs_order, 1, WB_LIST_THREADS, st);
-            WB_LAUNCH(wb_k_streamer_f1, nsel_b, WB_F1_THREADS, st);
+            { const long long res = 2LL * wb_num_cus(ctx); WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
             b->timer.end(ctx);
             if (ctx->eager_f2) {
                 // routine 2 for every candidate pair, then routines 3 + 4 on the survivors (option "eager_f2": the exhaustive

@@ -105,6 +105,8 @@ struct WbCtl {
     int group_ties;              // check_groups: groups whose maximum length was shared by several members (exact ties)
     int n_recheck;               // pairs wb_k_streamer_pairs2 left to wb_k_streamer_recheck (inside a guard band)
     int p2_cursor;               // next (contour, part) item of wb_k_streamer_pairs2's persistent workgroups
+    int f1_cursor;               // next contour (in wb_k_pairs_order's order) of wb_k_streamer_f1's persistent workgroups
+    int pad3;
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.

@@ -543,6 +543,33 @@ WB_HD inline int wb_bits_for_i(int n) { int b = 0; while ((1 << b) < n) ++b; ret
 // already: the 16 waves and 64 KiB of that workgroup then sit through this routine's latency-bound passes over the pair list
 // -- 2.3 ms for the fused kernel against 1.0 + 0.4 apart.  `ltab_only` is what remains of that: no fall-back to the tables
 // in global memory; false is returned when the western pairs do not fit the LDS table.)
+// A sweep over a contour's candidate pairs, four per lane and step: the four pairs are requested together, then their eight
+// end points together, and only then the body runs (p, pr = pairs[p], pi, pj = the end points).  Pair after pair -- a load,
+// a dependent gather, the body -- the one contour with 50 000 pairs spent 49 steps x 2 round trips per sweep in each of the
+// three sweeps of routine 1, and it alone set the kernel's duration.
+#define WB_PAIRS_FOR4(P, pairs, pts)                                                                                  \
+    WB_PFOR(wb_g4, ((P) + 3) / 4)                                                                                     \
+        unsigned long long wb_pr4[4];                                                                                 \
+        uint32_t wb_pi4[4], wb_pj4[4];                                                                                \
+        _Pragma("unroll") for (int wb_u = 0; wb_u < 4; ++wb_u) {                                                      \
+            const int wb_pp = 4 * (int)wb_g4 + wb_u;                                                                  \
+            wb_pr4[wb_u] = (pairs)[wb_pp < (P) ? wb_pp : (P) - 1];                                                    \
+        }                                                                                                             \
+        _Pragma("unroll") for (int wb_u = 0; wb_u < 4; ++wb_u) {                                                      \
+            wb_pi4[wb_u] = (pts)[(int)(wb_pr4[wb_u] >> 32)];                                                          \
+            wb_pj4[wb_u] = (pts)[(int)(wb_pr4[wb_u] & 0xFFFFFFFFull)];                                                \
+        }                                                                                                             \
+        _Pragma("unroll") for (int wb_u = 0; wb_u < 4; ++wb_u) {                                                      \
+            const int p = 4 * (int)wb_g4 + wb_u;                                                                      \
+            if (p < (P)) {                                                                                            \
+                const unsigned long long pr = wb_pr4[wb_u];                                                           \
+                const uint32_t pi = wb_pi4[wb_u], pj = wb_pj4[wb_u];                                                  \
+                (void)pr;
+#define WB_PAIRS_END4 \
+            }         \
+        }             \
+    WB_END_PFOR
+
 WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, const uint32_t* pts, unsigned long long* ltab,
                                        int ltab_cap, bool ltab_only) {
     unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
@@ -552,9 +579,6 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
     WB_SHARED(int, cnt, 1);
     WB_SHARED(int, nwest, 1);
     int P = a.npairs[s];
-    int hsize = 256;                       // table sized to this contour's pair count (clearing it is real traffic)
-    while (hsize < 2 * P && hsize < a.hash_size) hsize <<= 1;
-    const int hmask = hsize - 1;
     if (P > a.cap_pairs) {
         WB_SINGLE
         wb_atomic_max(&a.ctl->max_pairs, P);
@@ -570,11 +594,10 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
     nwest[0] = 0;
     cnt[0] = 0;
     WB_END_SINGLE
-    WB_PFOR(p, P)
+    WB_PAIRS_FOR4(P, pairs, pts)
         alive[p] = 1;
-        const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
         if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) wb_atomic_add(&nwest[0], 1);
-    WB_END_PFOR
+    WB_PAIRS_END4
     const int bxx = wb_bits_for_i(a.nlon), byy = wb_bits_for_i(a.nlat), pb = wb_bits_for_i(P);
     int lsize = ltab_cap < 256 ? ltab_cap : 256;
     while (lsize < 2 * nwest[0] && lsize < ltab_cap) lsize <<= 1;
@@ -599,8 +622,7 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
         WB_PFOR(q, lsize)
             ltab[q] = WB_HEMPTY;
         WB_END_PFOR
-        WB_PFOR(p, P)
-            const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+        WB_PAIRS_FOR4(P, pairs, pts)
             if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
                 const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
                                                  (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
@@ -616,9 +638,8 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
                     sl = (sl + 1) & (uint32_t)lmask;
                 }
             }
-        WB_END_PFOR
-        WB_PFOR(p, P)
-            const uint32_t pi = pts[(int)(pairs[p] >> 32)], pj = pts[(int)(pairs[p] & 0xFFFFFFFFull)];
+        WB_PAIRS_END4
+        WB_PAIRS_FOR4(P, pairs, pts)
             if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
                 const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
                                                  (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
@@ -628,14 +649,14 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
                     if (cur == WB_HEMPTY) break;
                     if ((cur >> pb) == key) {
                         const int pw = (int)(cur & pmask);
-                        alive[pairs[pw] < pairs[p] ? p : pw] = 0;       // the first in (ind1, ind2) order stays
+                        alive[pairs[pw] < pr ? p : pw] = 0;             // the first in (ind1, ind2) order stays
                         wb_atomic_add(&cnt[0], 1);
                         break;
                     }
                     sl = (sl + 1) & (uint32_t)lmask;
                 }
             }
-        WB_END_PFOR
+        WB_PAIRS_END4
         WB_SINGLE
         a.nalive[s] = P - cnt[0];
         a.stage[s] = 1;
@@ -646,13 +667,14 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
     // of the western pair lie in x < W - nlon, both of the eastern one in x >= nlon (a mixed pair would need its copy in
     // the opposite index order).  Only western pairs are entered into the table and only eastern pairs look themselves
     // up -- a quarter of the pairs each on a full-span contour; everything else survives without touching it.
+    int hsize = 256;                       // table sized to the pairs that go in, the western ones (clearing it is real traffic)
+    while (hsize < 2 * nwest[0] && hsize < a.hash_size) hsize <<= 1;
+    const int hmask = hsize - 1;
     WB_PFOR(q, hsize)
         hkey[q] = WB_HEMPTY;
         hval[q] = WB_HEMPTY;
     WB_END_PFOR
-    WB_PFOR(p, P)
-        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
-        const uint32_t pi = pts[i], pj = pts[j];
+    WB_PAIRS_FOR4(P, pairs, pts)
         if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
             const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
                                            ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
@@ -661,10 +683,8 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
             const int slot = wb_hash_insert(hkey, hmask, key, &fresh);
             if (slot >= 0) wb_atomic_min(&hval[slot], (unsigned long long)p);
         }
-    WB_END_PFOR
-    WB_PFOR(p, P)
-        const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
-        const uint32_t pi = pts[i], pj = pts[j];
+    WB_PAIRS_END4
+    WB_PAIRS_FOR4(P, pairs, pts)
         if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
             const unsigned long long key = (unsigned long long)(wb_pt_x(pi) % a.nlon) | ((unsigned long long)wb_pt_y(pi) << 16) |
                                            ((unsigned long long)(wb_pt_x(pj) % a.nlon) << 32) |
@@ -673,11 +693,11 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
             if (slot >= 0) {
                 // of the two the first in frame order = (ind1, ind2) order stays
                 const int pw = (int)hval[slot];
-                alive[pairs[pw] < pairs[p] ? p : pw] = 0;
+                alive[pairs[pw] < pr ? p : pw] = 0;
                 wb_atomic_add(&cnt[0], 1);
             }
         }
-    WB_END_PFOR
+    WB_PAIRS_END4
     WB_SINGLE
     a.nalive[s] = P - cnt[0];
     a.stage[s] = 1;
@@ -705,14 +725,25 @@ WB_KERNEL(wb_k_pairs_order, WbStreamerArgs a) {
         a.order[wb_atomic_add(&hist[32 - wb_clz32((uint32_t)a.npairs[s])], 1)] = (int)s;
     WB_END_PFOR
 }
+// persistent (two workgroups per CU): a contour with a few hundred pairs is ten microseconds of work for 1024 threads, and
+// launched one workgroup per contour the kernel's duration was the launching of 2 920 fat workgroups
 WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
-    if (WB_BLOCK_ID >= a.ctl->nsel) return;
-    const int s = a.order[WB_BLOCK_ID];
-    const int job = a.sel_job[s], k = a.sel_cont[s];
-    const size_t jb = (size_t)job * a.cap_seg;
-    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     WB_SHARED(unsigned long long, ltab, WB_F1_LTAB);
-    (void)wb_streamer_f1_body(a, s, job, pts, ltab, WB_F1_LTAB, false);
+    WB_SHARED(int, item, 1);
+    const int nsel = a.ctl->nsel;
+    for (;;) {
+        WB_SYNC();                                   // (the previous contour's table and counters are done with)
+        WB_SINGLE
+        item[0] = wb_atomic_add(&a.ctl->f1_cursor, 1);
+        WB_END_SINGLE
+        const int it = item[0];
+        if (it >= nsel) break;
+        const int s = a.order[it];
+        const int job = a.sel_job[s], k = a.sel_cont[s];
+        const size_t jb = (size_t)job * a.cap_seg;
+        const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+        (void)wb_streamer_f1_body(a, s, job, pts, ltab, WB_F1_LTAB, false);
+    }
 }
 
 // routine 2: check_intersections (:185-200): one lane per candidate pair; contour blocks whose bounding box
@@ -1081,11 +1112,24 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
     WB_STAMP(a.ctl, 0);
     if (stage == 1 && nal > 1) {
         // per row: the largest ind2 among the alive candidates; rows that hold one
-        WB_PFOR(p, P)
-            if (alive[p]) {
-                const int i = (int)(pairs[p] >> 32), j = (int)(pairs[p] & 0xFFFFFFFFull);
-                wb_atomic_max(&rmax[i], j);
-                if (in_lds) wb_atomic_add(&rend[i], 1);
+        // (four pairs per lane and step, their flags and values requested together: the contour with 50 000 pairs)
+        WB_PFOR(g4, (P + 3) / 4)
+            int al[4];
+            unsigned long long pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = 4 * (int)g4 + u, pc = pp < P ? pp : P - 1;
+                const int av = alive[pc];                      // (unconditional: a load behind a branch is waited for on the spot)
+                al[u] = pp < P ? av : 0;
+                pr[u] = pairs[pc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (al[u]) {
+                    const int i = (int)(pr[u] >> 32), j = (int)(pr[u] & 0xFFFFFFFFull);
+                    wb_atomic_max(&rmax[i], j);
+                    if (in_lds) wb_atomic_add(&rend[i], 1);
+                }
             }
         WB_END_PFOR
         // the candidates bucketed by row: a row whose largest candidate fails routine 2 looks its other candidates up here
@@ -1093,11 +1137,19 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
         // it alone set the kernel's duration)
         if (in_lds) {
             wb_block_scan_excl(rend, N);
-            WB_PFOR(p, P)
-                if (alive[p]) {
-                    const int i = (int)(pairs[p] >> 32);
-                    bk[wb_atomic_add(&rend[i], 1)] = (int)(pairs[p] & 0xFFFFFFFFull);
+            WB_PFOR(g4, (P + 3) / 4)
+                int al[4];
+                unsigned long long pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = 4 * (int)g4 + u, pc = pp < P ? pp : P - 1;
+                    const int av = alive[pc];                      // (unconditional: a load behind a branch is waited for on the spot)
+                al[u] = pp < P ? av : 0;
+                    pr[u] = pairs[pc];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (al[u]) bk[wb_atomic_add(&rend[(int)(pr[u] >> 32)], 1)] = (int)(pr[u] & 0xFFFFFFFFull);
             WB_END_PFOR
         }
         WB_STAMP(a.ctl, 1);
