@@ -1166,6 +1166,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "streamer_pairs");
             if (st.p2_cap > 0) {
                 { long long g2 = (long long)nsel_b * st.p2_split, res = (long long)ctx->p2_grid_x2 * wb_num_cus(ctx) / 2;   // persistent: two workgroups of 16 waves per CU
+                  if (res < 1) res = 1;
                   WB_LAUNCH_LDS(wb_k_streamer_pairs2, g2 < res ? g2 : res, WB_P2_THREADS, p2_lds, st); }
                 WB_LAUNCH(wb_k_streamer_recheck, 64, 64, st);              // pairs inside a guard band (normally none)
             }
