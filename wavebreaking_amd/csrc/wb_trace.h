@@ -839,6 +839,12 @@ WB_KERNEL(wb_k_trace_walk, WbTraceArgs a) {
 // Workgroups of 1024 threads, two per CU: the same number of waves as eight workgroups of 256, but room for a 64 KiB
 // table in LDS per workgroup -- the dedupe table and the set table of a typical job (a few thousand keys) live there
 // instead of in L2 / HBM, where every probe costs a 64-byte sector.
+// raw point p and its predecessor, all four words requested at once (p may be R: clamped, the caller tests p < R): written
+// `p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]` the short-circuit made it three dependent round trips
+#define WB_RAW_LOAD(p, R)                                                                           \
+    const int wb_pc_ = (int)(p) < (R) ? (int)(p) : ((R) > 0 ? (R) - 1 : 0), wb_pm_ = wb_pc_ > 0 ? wb_pc_ - 1 : 0;   \
+    const uint32_t rc1 = rawcid[wb_pc_], rc0 = rawcid[wb_pm_], rp1 = rawpt[wb_pc_], rp0 = rawpt[wb_pm_]; \
+    const bool rdup = (wb_pc_ > 0) & (rc1 == rc0) & (rp1 == rp0)
 #ifndef WB_TRACE_LTAB
 #define WB_TRACE_LTAB 8192        // 64-bit entries of the LDS table (= 16384 32-bit set entries)
 #endif
@@ -934,7 +940,8 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     nkeys[0] = 0;
     WB_END_SINGLE
     WB_PFOR(p, R)
-        wb_atomic_add_agg(nkeys, 0, (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) ? 0 : 1);
+        WB_RAW_LOAD(p, R);
+        wb_atomic_add_agg(nkeys, 0, rdup ? 0 : 1);
     WB_END_PFOR
     WB_TSTAMP(a.ctl, 2);
     hsize = 1024;
@@ -947,15 +954,17 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             ltab[s] = WB_HEMPTY;
         WB_END_PFOR
         WB_PFOR(p, R)
-            if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
-            const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+            WB_RAW_LOAD(p, R);
+            if (rdup) continue;
+            const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
             if (!wb_hash_put_min(ltab, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
         WB_END_PFOR
         WB_TSTAMP(a.ctl, 3);
         WB_PFOR(p, R + 1)
             int kp = 0;
-            if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
-                const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+            WB_RAW_LOAD(p, R);
+            if (p < R && !rdup) {
+                const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
                 kp = wb_hash_get_min(ltab, hmask, key) == (uint32_t)p ? 1 : 0;
             }
             keep[p] = kp;
@@ -965,14 +974,16 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             hkey[s] = WB_HEMPTY;
         WB_END_PFOR
         WB_PFOR(p, R)
-            if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
-            const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+            WB_RAW_LOAD(p, R);
+            if (rdup) continue;
+            const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
             if (!wb_hash_put_min(hkey, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
         WB_END_PFOR
         WB_PFOR(p, R + 1)
             int kp = 0;
-            if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
-                const uint32_t key = (rawcid[p] << (bx + by)) | ((uint32_t)wb_pt_y(rawpt[p]) << bx) | (uint32_t)wb_pt_x(rawpt[p]);
+            WB_RAW_LOAD(p, R);
+            if (p < R && !rdup) {
+                const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
                 kp = wb_hash_get_min(hkey, hmask, key) == (uint32_t)p ? 1 : 0;
             }
             keep[p] = kp;
@@ -983,17 +994,19 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             hval[s] = WB_NIL;
         WB_END_PFOR
         WB_PFOR(p, R)
-            if (p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1]) continue;
+            WB_RAW_LOAD(p, R);
+            if (rdup) continue;
             int fresh;
-            const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
+            const unsigned long long key = ((unsigned long long)rc1 << 32) | rp1;
             const int s = wb_hash_insert(hkey, hmask, key, &fresh);
             if (s >= 0) wb_atomic_min(&hval[s], (uint32_t)p);
             else wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
         WB_END_PFOR
         WB_PFOR(p, R + 1)
             int kp = 0;
-            if (p < R && !(p > 0 && rawcid[p] == rawcid[p - 1] && rawpt[p] == rawpt[p - 1])) {
-                const unsigned long long key = ((unsigned long long)rawcid[p] << 32) | rawpt[p];
+            WB_RAW_LOAD(p, R);
+            if (p < R && !rdup) {
+                const unsigned long long key = ((unsigned long long)rc1 << 32) | rp1;
                 const int s = wb_hash_find(hkey, hmask, key);
                 kp = (s >= 0 && hval[s] == (uint32_t)p) ? 1 : 0;
             }
@@ -1086,8 +1099,8 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     const int npts = (Ck > 0) ? keep[R] : 0;
     WB_PFOR(q, npts)
         const uint32_t f = cown[q];
+        const uint32_t pt = cpts[q];                       // (with its owner, not after it)
         if (f != WB_NIL) {
-            const uint32_t pt = cpts[q];
             const int x = wb_pt_x(pt), y = wb_pt_y(pt);
             const int slot = bigof[f];
             int fresh1, fresh2 = 0;
