@@ -1060,9 +1060,12 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #ifndef WB_F1_THREADS
 #define WB_F1_THREADS 1024         // routine 1: its duration is that of the few contours with tens of thousands of pairs (0.39 -> 0.27 ms against 256)
 #endif
+#ifndef WB_F234_OCC
+#define WB_F234_OCC 6               // waves per SIMD the register allocation leaves room for (6: 80 registers, three workgroups per CU)
+#endif
 #define WB_F234_CAND 512           // candidates of one row collected after its first chord failed
 #define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
-WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, 6, WbStreamerArgs a) {
+WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a) {
     if (WB_BLOCK_ID >= a.ctl->nsel) return;
     const int s = a.order[WB_BLOCK_ID];
     if (WB_TID == 0) a.tie_m[s] = 0;
