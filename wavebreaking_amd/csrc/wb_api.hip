@@ -232,12 +232,10 @@ static int run_phase1(wb_batch* b) {
     if (!ta.hval) return 1;
     WB_TICK("phase1 allocations");
     if (wb_debug()) { dsync(ctx); WB_TICK("phase1 pre-sync"); }
-    dmemset(ctx, b->status, 0, (size_t)J * sizeof(uint32_t));
-    WB_TICK("phase1 memset launch call");
-    if (wb_debug()) { dsync(ctx); WB_TICK("phase1 memset status sync"); }
-    dmemset(ctx, b->d_ctl, 0, sizeof(WbCtl));
-    dmemset(ctx, b->stg_n, 0, (size_t)J * NS * sizeof(int));
-    if (wb_debug()) { dsync(ctx); WB_TICK("phase1 memsets+sync"); }
+    // the phase's zero fills: queued, ONE launch (dzero_flush, below: the streaming scan adds its spare row)
+    dzero_q(ctx, b->status, (size_t)J * sizeof(uint32_t));
+    dzero_q(ctx, b->d_ctl, sizeof(WbCtl));
+    dzero_q(ctx, b->stg_n, (size_t)J * NS * sizeof(int));
 
     WbScanArgs sa;
     memset(&sa, 0, sizeof(sa));
@@ -323,7 +321,8 @@ static int run_phase1(wb_batch* b) {
             sa.cap_n = balloc<int>(b, (size_t)lists);
             unsigned char* spare = balloc<unsigned char>(b, (size_t)p.nlon * esz + 64);
             if (!sa.cap_n || !sa.cap_v || !sa.cap_k || !spare) return 1;
-            dmemset(ctx, spare, 0, (size_t)p.nlon * esz + 64);
+            dzero_q(ctx, spare, (size_t)p.nlon * esz + 64);
+            dzero_flush(ctx);
             sa.spare_row = spare;
             b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
             b->phase1_scratch.push_back(spare);
@@ -368,6 +367,7 @@ static int run_phase1(wb_batch* b) {
 #undef WB_BUILD_N
 #undef WB_BUILD_LAUNCH
         } else {
+        dzero_flush(ctx);
         const dim3 grid((unsigned)nwg);
 #define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan<T, V, N>), grid, block, 0, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
@@ -394,13 +394,26 @@ static int run_phase1(wb_batch* b) {
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_rank");
     WB_LAUNCH(wb_k_trace_rank, J, WB_RANK_THREADS, ta);
-    WB_LAUNCH(wb_k_trace_rank_big, J, WB_RANK_THREADS, ta);   // jobs of more than WB_TRACE_LDS_N segments only
-    WB_LAUNCH(wb_k_trace_walk, J, 64, ta);            // jobs flagged WB_ST_LEVEL_ORDER only: skimage's sequential walk, one lane each
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_finish");
+    ta.slow_pass = 0;
     WB_LAUNCH(wb_k_trace_finish, J, WB_FINISH_THREADS, ta);
     b->timer.end(ctx);
     if (phase1_summary(b)) return 1;
+    if (b->h_ctl.n_slow > 0) {
+        // the second trace pass, for the jobs the first left out (the link kernel counted them): more segments than the LDS
+        // paths hold (wb_k_trace_rank_big), or an order-dependent join at cells equal to the level (wb_k_trace_walk: skimage's
+        // sequential walk, one lane each).  An ordinary batch has none and pays no launch for them.
+        b->timer.begin(ctx, "trace_slow");
+        WB_LAUNCH(wb_k_trace_rank_big, J, WB_RANK_THREADS, ta);
+        WB_LAUNCH(wb_k_trace_walk, J, 64, ta);
+        ta.slow_pass = 1;
+        WB_LAUNCH(wb_k_trace_finish, J, WB_FINISH_THREADS, ta);
+        // the summary again, from zero (max_nux and max_len are running maxima and stay)
+        dmemset(ctx, (char*)b->d_ctl + offsetof(WbCtl, ncont_total), 0, offsetof(WbCtl, scan_cursor) - offsetof(WbCtl, ncont_total));
+        b->timer.end(ctx);
+        if (phase1_summary(b)) return 1;
+    }
     b->timer_phase1 = b->timer.names.size();
     WB_TICK("phase1 launches + sync");
     return 0;
@@ -747,13 +760,19 @@ WB_KERNEL(wb_k_event_offsets, WbEvFillArgs a) {
     else a.ctl->NE = (int)NE;
     WB_END_SINGLE
 }
-WB_KERNEL(wb_k_fill_events, WbEvFillArgs a) {
+WB_KERNEL(wb_k_fill_events, WbEvFillArgs a, WbStreamerArgs st) {
     const int s = WB_BLOCK_ID;
     const int nsel = a.ctl->nsel;
     if (a.ctl->NE == 0) return;
     const int NS = a.ctl->NS, NO = a.ctl->NO;
     if (s < nsel) {
         if (a.ev_n) {
+            // check_groups, exact ties (streamer_index.py:241-246 in CPython set order): rare, rewrites the end points first
+            if (st.tie_m[s] >= 2) {
+                WB_SINGLE
+                wb_streamer_resolve_ties(st, s);
+                WB_END_SINGLE
+            }
             WB_PFOR(e, a.ev_n[s])
                 const int row = a.sbase[s] + (int)e;
                 int* d = a.ev + (size_t)row * 8;
@@ -1023,18 +1042,21 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         auto release = [&]() { for (void* q : tmp) bfree_one(b, q); tmp.clear(); };
         b->timer.truncate(b->timer_phase1);
         WbCtl* ctl = b->d_ctl;
-        // the phase-2 part of the control block starts from zero (phase-1 values stay)
+        // the phase-2 part of the control block starts from zero (phase-1 values stay): cleared by wb_k_select_count's first workgroup
 #if defined(WB_STAMPS) && (WB_STAMPS == 4 || WB_STAMPS == 6)                                 // (the stamps of a phase-1 kernel survive into the snapshot)
-        dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, offsetof(WbCtl, dbg) - offsetof(WbCtl, nsel));
+        const size_t zero_bytes = offsetof(WbCtl, dbg) - offsetof(WbCtl, nsel);
 #else
-        dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, sizeof(WbCtl) - offsetof(WbCtl, nsel));
+        const size_t zero_bytes = sizeof(WbCtl) - offsetof(WbCtl, nsel);
 #endif
+        static_assert(offsetof(WbCtl, nsel) % 4 == 0 && sizeof(WbCtl) % 4 == 0 && offsetof(WbCtl, dbg) % 4 == 0, "WbCtl is cleared in 32-bit words");
+        if (J <= 0) dmemset(ctx, (char*)ctl + offsetof(WbCtl, nsel), 0, zero_bytes);
 
         // ---- selection
         WbSelectArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.njobs = J; sa.cap_seg = cap; sa.gmax = gmax; sa.want_cut = (which & 4) ? 1 : 0; sa.dlon = p.dlon; sa.co_min_exp = p.co_min_exp;
         sa.ncont = b->ncont; sa.c_nux = b->c_nux; sa.c_closed = b->c_closed;
+        sa.zero_at = (uint32_t*)((char*)ctl + offsetof(WbCtl, nsel)); sa.zero_words = (int)(zero_bytes / 4);
         int* d_nsel = (int*)talloc(J * sizeof(int));
         int* d_ncut = (int*)talloc(J * sizeof(int));
         b->sel_job = (int*)talloc((nsel_b + 1) * sizeof(int)); b->sel_cont = (int*)talloc((nsel_b + 1) * sizeof(int));
@@ -1083,9 +1105,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
 
         // ---- streamers
         int *ev_n = nullptr, *ev_ind = nullptr;
+        WbStreamerArgs st;
+        memset(&st, 0, sizeof(st));
         if (do_st) {
-            WbStreamerArgs st;
-            memset(&st, 0, sizeof(st));
             ev_n = (int*)talloc(nsel_b * sizeof(int));
             ev_ind = (int*)talloc((size_t)nsel_b * cap_ev * 2 * sizeof(int));
             st.ctl = ctl; st.cap_seg = cap; st.nlon = p.nlon; st.nlat = p.nlat; st.W = b->W; st.cap_ev = cap_ev;
@@ -1187,12 +1209,10 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
                 b->timer.begin(ctx, "streamer_f34");
                 WB_LAUNCH(wb_k_streamer_f34, nsel_b, 256, st);
-                WB_LAUNCH(wb_k_streamer_ties, (nsel_b + 63) / 64, 64, st);
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
                 WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + 64, st);
-                WB_LAUNCH(wb_k_streamer_ties, (nsel_b + 63) / 64, 64, st);
                 b->timer.end(ctx);
             }
         }
@@ -1232,7 +1252,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         if (!d_py || !fa.poff || !pa.ev_flags || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
         b->timer.begin(ctx, "fill_events");
         WB_LAUNCH(wb_k_event_offsets, 1, WB_LIST_THREADS, fa);
-        if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa);
+        if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa, st);
         WB_LAUNCH(wb_k_poly_offsets, 1, WB_LIST_THREADS, fa);
         b->timer.end(ctx);
         // descriptors are complete: vertices + the first control-block snapshot on the side stream, properties on the main one
@@ -1627,6 +1647,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "timers")) { ctx->timers = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;
 }

@@ -85,7 +85,7 @@ struct WbCtl {
     int pair_items_max;          // work items of the all-pairs kernel for the contours with nux == max_nux
     int scan_cursor;             // streaming scan: the next (time step, band) work item (a workgroup takes one when it is free)
     int max_len;                 // longest contour of the batch, in points
-    int pad1;
+    int n_slow;                  // jobs the second trace pass redoes: more segments than the LDS paths hold, or an order-dependent join (cells equal to the level)
     // phase 2 (wb_indices)
     int nsel, ncut;              // selected contours / cutoff contours
     long long npt_sel;

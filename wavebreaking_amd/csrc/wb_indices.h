@@ -27,6 +27,9 @@ struct WbSelectArgs {
     int* sel_cont;                 // [total sel] contour index inside the job
     int* cut_job;
     int* cut_cont;
+    // the phase-2 part of the batch's control block, zeroed by the first workgroup of wb_k_select_count (zero_words 32-bit words)
+    uint32_t* zero_at;
+    int zero_words;
 };
 
 WB_HD inline bool wb_is_cutoff(int nux, int closed, int gmax, double dlon, double min_exp) {
@@ -38,6 +41,11 @@ WB_KERNEL(wb_k_select_count, WbSelectArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
     const size_t jb = (size_t)job * a.cap_seg;
+    if (job == 0) {          // (nothing in this kernel reads those counters; the next kernel is the first to write one)
+        WB_PFOR(w, a.zero_words)
+            a.zero_at[w] = 0u;
+        WB_END_PFOR
+    }
     WB_SINGLE
     int s = 0, c = 0;
     for (int k = 0; k < a.ncont[job]; ++k) {
@@ -270,7 +278,7 @@ struct WbStreamerArgs {
     int* rowaux;
     int* rowmx;
     int* ev_ind;               // [nsel][cap_ev][2]
-    int* tie_m;                // [nsel] 0, or the survivor count of a contour whose check_groups met an exact tie (wb_k_streamer_ties)
+    int* tie_m;                // [nsel] 0, or the survivor count of a contour whose check_groups met an exact tie (wb_streamer_resolve_ties)
     int eager;                 // 1: the survivors were laid out by wb_k_streamer_f34, 0: by wb_k_streamer_f234
     int* ev_n;                 // [nsel]
     uint32_t* status;          // [njobs]
@@ -1002,7 +1010,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
             if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
         // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
-        // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
+        // set's iteration order -- resolved by wb_streamer_resolve_ties (wb_k_fill_events) after this kernel (rare; kept out of this kernel's
         // registers); here the lowest such member stands in and the contour is marked
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
@@ -1391,7 +1399,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
         // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
-        // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
+        // set's iteration order -- resolved by wb_streamer_resolve_ties (wb_k_fill_events) after this kernel (rare; kept out of this kernel's
         // registers); here the lowest such member stands in and the contour is marked
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
@@ -1427,36 +1435,34 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
 // lengths of the selected contours -> packed point offsets, work items of the all-pairs kernel
 // check_groups, exact ties (after wb_k_streamer_f234 / f34): for the contours marked there, the survivor of every group whose
 // largest length is shared by several members becomes the member that comes first in the reference's CPython set
-// (wb_group_tie_winner), and the event's end points are rewritten.  One thread per marked contour; nearly always none.
-WB_KERNEL(wb_k_streamer_ties, WbStreamerArgs a) {
-    const int nsel = a.ctl->nsel;
-    for (int s = WB_BLOCK_ID * WB_NT + WB_TID; s < nsel; s += WB_GRID_DIM * WB_NT) {
-        const int M = a.tie_m[s];
-        if (M < 2) continue;
-        const int job = a.sel_job[s], k = a.sel_cont[s];
-        const size_t jb = (size_t)job * a.cap_seg;
-        const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
-        const int N = a.c_len[jb + k];
-        const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
-        unsigned long long* best = a.hval + (size_t)s * a.hash_size;
-        const int* mi; const int* mj; const int* lab; const int* aux;
-        if (a.eager) {
-            mi = (int*)a.hkey + (size_t)s * a.hash_size * 2; mj = mi + M; lab = mj + M; aux = a.rowaux + a.poff[s];
-        } else {
-            const int w = (P < N ? P : N) + 1;
-            mi = (int*)(a.hkey + (size_t)s * a.hash_size); mj = mi + w; lab = mj + w; aux = lab + w;
-        }
-        const unsigned long long* gval = best + 2 * (size_t)M;
-        int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
-        for (int g = 0; g < M; ++g) {
-            if (lab[g] != g) continue;
-            int ntie = 0;
-            for (int m = 0; m < M; ++m) if (lab[m] == g && gval[m] == best[g]) ++ntie;
-            if (ntie < 2) continue;
-            wb_atomic_add(&a.ctl->group_ties, 1);
-            const int w = wb_group_tie_winner(lab, M, g, pts, mi, mj, gval, best[g], best + 3 * (size_t)M, (long long)a.hash_size - 3LL * M);
-            if (w >= 0 && aux[g] < a.cap_ev) { ev[2 * aux[g] + 0] = mi[w]; ev[2 * aux[g] + 1] = mj[w]; }
-        }
+// (wb_group_tie_winner), and the event's end points are rewritten.  Called by one lane of the marked contour's workgroup in
+// wb_k_fill_events, before the contour's events are laid out (a kernel of its own cost a launch per pass for nearly always nothing).
+WB_DEV inline void wb_streamer_resolve_ties(const WbStreamerArgs& a, int s) {
+    const int M = a.tie_m[s];
+    if (M < 2) return;
+    const int job = a.sel_job[s], k = a.sel_cont[s];
+    const size_t jb = (size_t)job * a.cap_seg;
+    const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+    const int N = a.c_len[jb + k];
+    const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
+    unsigned long long* best = a.hval + (size_t)s * a.hash_size;
+    const int* mi; const int* mj; const int* lab; const int* aux;
+    if (a.eager) {
+        mi = (int*)a.hkey + (size_t)s * a.hash_size * 2; mj = mi + M; lab = mj + M; aux = a.rowaux + a.poff[s];
+    } else {
+        const int w = (P < N ? P : N) + 1;
+        mi = (int*)(a.hkey + (size_t)s * a.hash_size); mj = mi + w; lab = mj + w; aux = lab + w;
+    }
+    const unsigned long long* gval = best + 2 * (size_t)M;
+    int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
+    for (int g = 0; g < M; ++g) {
+        if (lab[g] != g) continue;
+        int ntie = 0;
+        for (int m = 0; m < M; ++m) if (lab[m] == g && gval[m] == best[g]) ++ntie;
+        if (ntie < 2) continue;
+        wb_atomic_add(&a.ctl->group_ties, 1);
+        const int w = wb_group_tie_winner(lab, M, g, pts, mi, mj, gval, best[g], best + 3 * (size_t)M, (long long)a.hash_size - 3LL * M);
+        if (w >= 0 && aux[g] < a.cap_ev) { ev[2 * aux[g] + 0] = mi[w]; ev[2 * aux[g] + 1] = mj[w]; }
     }
 }
 

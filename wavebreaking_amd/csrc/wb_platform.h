@@ -40,6 +40,7 @@ struct wb_ctx {
     int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
     int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
+    int timers = 2;                           // stage timers: 2 all, 1 the scan only, 0 none (WbTimer)
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
     int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
@@ -61,6 +62,9 @@ struct wb_ctx {
     // evicts and restores the process's queues (measured: ~20 ms stall on the next dispatch).
     void* pin = nullptr;
     size_t pin_bytes = 0;
+    void* zq_p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // queued zero fills (dzero_q / dzero_flush)
+    size_t zq_bytes[6] = {0, 0, 0, 0, 0, 0};
+    int zq_n = 0;
     void* h2d_pin[2] = {nullptr, nullptr};    // double-buffered staging of large uploads
     hipEvent_t h2d_ev[2] = {nullptr, nullptr};
 #endif
@@ -151,6 +155,8 @@ static int wb_fail(wb_ctx* c, const std::string& m) {
 static void* dmalloc(wb_ctx*, size_t bytes) { return malloc(bytes ? bytes : 1); }
 static void dfree(wb_ctx*, void* p) { free(p); }
 static int dmemset(wb_ctx*, void* p, int v, size_t bytes) { memset(p, v, bytes); return 0; }
+static void dzero_q(wb_ctx*, void* p, size_t bytes) { memset(p, 0, bytes); }     // (product build: queued, one launch at dzero_flush)
+static void dzero_flush(wb_ctx*) {}
 static int h2d(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
 static int d2h(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
 static int d2h_pinned(wb_ctx*, void* d, const void* s, size_t b) { memcpy(d, s, b); return 0; }
@@ -198,6 +204,41 @@ static int dmemset(wb_ctx* c, void* p, int v, size_t bytes) {
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(wb_k_fill, dim3((unsigned)blocks), dim3(256), 0, c->stream, (unsigned char*)p, v, bytes);
     return 0;
+}
+// several zero fills in ONE launch: dzero_q queues (pointer, bytes), dzero_flush launches (grid.y = the queued segments).
+// Phase 1 clears four small arrays before its first kernel; as four launches they were four dispatches on the stream.
+#define WB_ZERO_SEGS 6
+struct WbZeroSegs { unsigned char* p[WB_ZERO_SEGS]; size_t bytes[WB_ZERO_SEGS]; };
+__global__ void wb_k_zero_segs(WbZeroSegs z) {
+    unsigned char* p = z.p[blockIdx.y];
+    const size_t bytes = z.bytes[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16, head = ((16 - ((uintptr_t)p & 15)) & 15) < bytes ? ((16 - ((uintptr_t)p & 15)) & 15) : bytes;
+    const size_t body = (bytes - head) & ~(size_t)15;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < body; i += stride) *(uint4*)(p + head + i) = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < head; i += blockDim.x) p[i] = 0;
+        for (size_t i = head + body + threadIdx.x; i < bytes; i += blockDim.x) p[i] = 0;
+    }
+}
+static void dzero_flush(wb_ctx* c);
+static void dzero_q(wb_ctx* c, void* p, size_t bytes) {
+    if (!bytes) return;
+    if (c->zq_n == WB_ZERO_SEGS) dzero_flush(c);
+    c->zq_p[c->zq_n] = p; c->zq_bytes[c->zq_n] = bytes; ++c->zq_n;
+}
+static void dzero_flush(wb_ctx* c) {
+    if (!c->zq_n) return;
+    WbZeroSegs z;
+    size_t mx = 0;
+    for (int k = 0; k < WB_ZERO_SEGS; ++k) {
+        z.p[k] = k < c->zq_n ? (unsigned char*)c->zq_p[k] : nullptr; z.bytes[k] = k < c->zq_n ? c->zq_bytes[k] : 0;
+        if (z.bytes[k] > mx) mx = z.bytes[k];
+    }
+    size_t blocks = (mx + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wb_k_zero_segs, dim3((unsigned)blocks, (unsigned)c->zq_n), dim3(256), 0, c->stream, z);
+    c->zq_n = 0;
 }
 #define WB_PIN_THRESHOLD (256u << 10)
 static void* wb_pin(wb_ctx* c, size_t bytes) {
@@ -356,18 +397,22 @@ struct WbTimer {
         ms.push_back(0.f);
 #if !defined(WB_HOSTSIM)
         hipEvent_t a = nullptr, b = nullptr;
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
+        // option "timers": 2 every stage (default), 1 the scan kernel only (what the roofline is quoted on), 0 none -- an event
+        // pair is two more packets on the stream per stage; the stage keeps its name and reads 0 ms
+        if (c->timers >= 2 || (c->timers == 1 && !strcmp(name, "scan"))) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, c->stream);
+        }
         ev0.push_back(a);
         ev1.push_back(b);
-        (void)hipEventRecord(a, c->stream);
 #else
         (void)c;
 #endif
     }
     void end(wb_ctx* c) {
 #if !defined(WB_HOSTSIM)
-        (void)hipEventRecord(ev1.back(), c->stream);
+        if (ev1.back()) (void)hipEventRecord(ev1.back(), c->stream);
 #else
         (void)c;
 #endif

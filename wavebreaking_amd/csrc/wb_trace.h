@@ -48,6 +48,7 @@ struct WbTraceArgs {
     uint32_t* status;        // [njobs]
     int* nseg;               // [njobs] merged segment count (-1: job skipped)
     int* p4;                 // [njobs][2] contours and raw points of a job the rank kernel has numbered itself (-1: finish does it)
+    int slow_pass;           // 0: the ordinary launch (slow jobs are left out and counted in ctl->n_slow); 1: the slow jobs only
     WbCtl* ctl;              // batch counters (capacity checks, maxima)
 };
 
@@ -382,6 +383,9 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     WB_LSTAMP_FLUSH(a.ctl);
     WB_SINGLE
     a.nseg[job] = n;
+    // jobs for the second trace pass (wb_trace_is_slow): counted, so that the host launches that pass only when there is one
+    // (the flag was set with atomics by this workgroup's other threads: read it where they wrote it, not through this CU's L1)
+    if (n > WB_TRACE_LDS_N || (wb_atomic_or(&a.status[job], 0u) & WB_ST_LEVEL_ORDER)) wb_atomic_add(&a.ctl->n_slow, 1);
     WB_END_SINGLE
 }
 
@@ -676,6 +680,7 @@ WB_KERNEL_LB(wb_k_trace_rank, WB_RANK_THREADS, (WB_RANK_THREADS >= 1024 ? 8 : 4)
 }
 // big job: the same algorithm on 32-bit links in global memory; buffers J: w[2], w[3]; A: w[5], w[7]; D: w[9], w[10].  A
 // kernel of its own so that its registers are not the LDS kernel's (which has to stay within 64 for two workgroups per CU).
+// Launched in the second trace pass only (run_phase1: when ctl->n_slow says there is such a job).
 WB_KERNEL(wb_k_trace_rank_big, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
@@ -854,6 +859,17 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     if (job >= a.njobs) return;
     const int n = a.nseg[job];
     if (n <= 0) return;            // ncont already written by the link kernel
+    {   // the slow jobs (big, or to be walked sequentially) wait for the second pass, which takes nothing else
+        const bool slow = n > WB_TRACE_LDS_N || (a.status[job] & WB_ST_LEVEL_ORDER);
+        if (slow != (a.slow_pass != 0)) {
+            if (slow) {
+                WB_SINGLE
+                a.ncont[job] = 0;
+                WB_END_SINGLE
+            }
+            return;
+        }
+    }
     const int cap = a.cap_seg;
     const size_t jb = (size_t)job * cap;
     const uint32_t* segf = a.mseg[1] + jb;
