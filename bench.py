@@ -311,9 +311,9 @@ def main():
             # the all-pairs streamer test, reported separately: base-point pairs COVERED per second of its kernel
             # (N (N - 1) / 2 per contour; most are excluded as whole blocks) and pairs whose great-circle term is EVALUATED
             "pair_evaluations_per_s": counts["pair_stats"][0] / (float(np.mean(stage_ms["streamer_pairs"])) * 1e-3)
-            if stage_ms.get("streamer_pairs") else None,
+            if float(np.mean(stage_ms.get("streamer_pairs", [0.0]))) > 0 else None,
             "pairs_evaluated_per_s": counts["evaluated_pairs"] / (float(np.mean(stage_ms["streamer_pairs"])) * 1e-3)
-            if stage_ms.get("streamer_pairs") else None,
+            if float(np.mean(stage_ms.get("streamer_pairs", [0.0]))) > 0 else None,
             "host_wall_ms": {k: float(np.mean(v)) for k, v in wall.items()},
             "counts": counts,
         }

@@ -262,6 +262,12 @@ int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_offset, const 
    wb_flag_events / wb_track_events / wb_track_overlaps */
 float wb_last_op_ms(wb_ctx* ctx);
 
+/* 64-bit fingerprint of EVERY byte of a host buffer, computed by `threads` host threads (0: a default from the machine's core
+   count; the value does not depend on it).  The Python layer keeps input cubes on the device between calls and asks this
+   whether a cube it is handed again still holds the bytes it uploaded (the reference rereads its input on every call,
+   index_utils.py:66-75; an in-place edit between two calls must be seen).  No device work. */
+uint64_t wb_fingerprint(const void* host_buffer, uint64_t bytes, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,3 +322,80 @@ def not_simple_polygon_case(ctx):
         a, e = got["cell_offset"][k], got["cell_offset"][k + 1]
         assert np.array_equal(got["cell_x"][a:e], cx) and np.array_equal(got["cell_y"][a:e], cy)
     return got
+
+
+def reference_rules_case(ctx, golden_dir):
+    """tests/golden/reference_rules.npz -- outputs of the REFERENCE'S OWN statements (make_golden_reference.py) -- through the
+    C ABI: the contour table of every fixture field against contour_index.py:105-155 run on scikit-image's output; the
+    overturning boxes of every fixture contour (handed in as a frame, contour_index.py:197-249) against
+    overturning_index.py:123-188; the contour selection and the cutoff filter against streamer_index.py:106-108 /
+    cutoff_index.py:89-93.  Returns the numbers of contours, boxes and frames compared."""
+    g = np.load(os.path.join(golden_dir, "reference_rules.npz"))
+    unpack = lambda cat, off: [cat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+    ncont = nbox = nframes = 0
+    # ---- contours
+    for name in g["contours__names"]:
+        a = g["contours__%s__field" % name]
+        level, nlon, dlon, padd = g["contours__%s__par" % name]
+        nlon = int(nlon)
+        lat = np.linspace(-90, 90, a.shape[0])
+        lon = np.arange(nlon) * dlon - 180.0
+        b = ctx.contours(a[None], lat, lon, [float(level)], dlon, lat[1] - lat[0], periodic_add=float(padd))
+        got, st = b.contour_table(), int(b.status()[0])
+        b.close()
+        assert not st & ~(_hip.STATUS_LEVEL_HIT | 4), (name, st)          # (4: the field has NaN rows)
+        want = unpack(g["contours__%s__pts" % name], g["contours__%s__off" % name])
+        assert got["step"].size == len(want), (name, got["step"].size, len(want))
+        for k, w in enumerate(want):
+            o, n = int(got["offset"][k]), int(got["npts"][k])
+            assert np.array_equal(np.c_[got["x"][o:o + n], got["y"][o:o + n]], w), (name, k)
+            assert bool(got["closed"][k]) == bool(g["contours__%s__closed" % name][k]), (name, k)
+            assert got["nux"][k] * dlon == g["contours__%s__exp_lon" % name][k], (name, k)
+            assert np.round(got["sum_y"][k] / n, 2) == g["contours__%s__mean_lat" % name][k], (name, k)
+        ncont += len(want)
+
+    def frame(contours, closed):
+        npts = np.array([len(c) for c in contours], dtype=np.int32)
+        return dict(step=np.zeros(len(contours), np.int32), level_idx=np.zeros(len(contours), np.int32),
+                    closed=np.asarray(closed, dtype=np.int32), npts=npts, offset=(np.cumsum(npts) - npts).astype(np.int64),
+                    x=np.concatenate([c[:, 0] for c in contours]).astype(np.int32),
+                    y=np.concatenate([c[:, 1] for c in contours]).astype(np.int32))
+    # ---- overturnings
+    from oracle import synth
+    for k in range(int(g["overturn__count"])):
+        key = "overturn__o%03d" % k
+        xy = g[key + "__xy"]
+        dlon, nlon, range_group, min_exp = g[key + "__par"]
+        lat, lon = synth.grid(dlon)
+        data = np.zeros((1, lat.size, lon.size), dtype=np.float32)
+        b = ctx.batch_from_contours(frame([xy], [0]), data, lat, lon, [2.0], dlon, dlon, range_group=range_group, ot_min_exp=min_exp)
+        b.indices(streamers=False, cutoffs=False)
+        got = b.events(_hip.OVERTURNINGS)
+        b.close()
+        want = g[key + "__out"]                                            # min_lon, max_lon, min_lat, max_lat
+        assert np.array_equal(got["box"][:, [0, 2, 1, 3]], want), (key, got["box"], want)
+        nbox += len(want)
+    # ---- selection (exp_lon == max over the frame) and cutoff filter.  Row i is a zigzag over nux[i] columns whose first
+    # column holds three points: with min_exp = 0 every SELECTED contour carries exactly one overturning box, so the
+    # overturning table lists the selection; the cutoff table lists the filter's rows.
+    for k in range(int(g["select__count"])):
+        key = "select__%02d" % k
+        nux, closed = g[key + "__nux"], g[key + "__closed"]
+        dlon, min_exp = g[key + "__par"]
+        nlon = int(360 / dlon)
+        lon = np.arange(nlon) * dlon
+        lat = np.arange(-20, 21) * dlon
+        rows = []
+        for n in nux:
+            xs = np.arange(1, int(n))
+            rows.append(np.concatenate([np.array([[0, 10], [0, 11], [0, 12], [0, 13]][:3 if n > 1 else 4]), np.c_[xs, 12 + xs % 2]]).astype(np.int64))
+        data = np.zeros((1, lat.size, lon.size), dtype=np.float32)
+        b = ctx.batch_from_contours(frame(rows, closed), data, lat, lon, [2.0], dlon, dlon, ot_min_exp=0.0, co_min_exp=min_exp)
+        assert b.max_nux() == int(nux.max()), key
+        b.indices(streamers=False)
+        ot, cut = b.events(_hip.OVERTURNINGS), b.events(_hip.CUTOFFS)
+        b.close()
+        assert ot["contour"].tolist() == g[key + "__selected"].tolist(), key
+        assert cut["contour"].tolist() == g[key + "__cutoffs"].tolist(), key
+        nframes += 1
+    return ncont, nbox, nframes

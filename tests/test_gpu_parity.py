@@ -216,6 +216,15 @@ def test_order_dependent_joins_golden_fields(ctx, golden_dir):
     assert nequal == 48 and nflag == 54
 
 
+def test_reference_own_code_fixture_through_the_abi(ctx, golden_dir):
+    """the HIP path against outputs of the REFERENCE'S OWN statements (tests/golden/reference_rules.npz, made in the build
+    container by tests/golden/make_golden_reference.py): contour tables (contour_index.py:105-155 on scikit-image's output),
+    overturning boxes (overturning_index.py:123-188), contour selection and cutoff filter (streamer_index.py:106-108,
+    cutoff_index.py:89-93)"""
+    ncont, nbox, nframes = helpers.reference_rules_case(ctx, golden_dir)
+    assert ncont > 150 and nbox > 300 and nframes == 40
+
+
 @pytest.mark.parametrize("seed,dlon", [(0, 1.0), (1, 1.0), (2, 1.0), (3, 1.0), (4, 0.25)])
 def test_cells_equal_to_the_level_full_path(ctx, seed, dlon):
     pv, lat, lon = helpers.level_hit_field(seed, dlon=dlon, nhits=4 if dlon == 1.0 else 12)

@@ -266,6 +266,14 @@ def test_order_dependent_joins_golden_fields(sim, golden_dir):
     assert nequal == 48 and nflag == 54
 
 
+def test_reference_own_code_fixture_through_the_abi(sim, golden_dir):
+    """the contour table, the overturning boxes and the contour selection / cutoff filter against outputs of the reference's
+    own statements (tests/golden/reference_rules.npz)"""
+    lib, ctx = sim
+    ncont, nbox, nframes = helpers.reference_rules_case(ctx, golden_dir)
+    assert ncont > 150 and nbox > 300 and nframes == 40
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_cells_equal_to_the_level_full_path(sim, seed):
     """contours AND events of a field with level hits equal the oracle's, whose find_contours follows skimage's

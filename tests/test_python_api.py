@@ -461,7 +461,7 @@ def test_inputs_and_contour_batches_stay_on_the_device_between_calls(hostsim_eng
         assert [np.asarray(g.geoms[0].exterior.coords).tolist() for g in a["geometry"]] == \
                [np.asarray(g.geoms[0].exterior.coords).tolist() for g in b["geometry"]]
     assert np.allclose(list(s1["intensity"]), list(s1n["intensity"]), equal_nan=True)
-    # an in-place change of the cube is seen (sampled fingerprint): uploaded and traced again
+    # an in-place change of the cube is seen (every byte is fingerprinted): uploaded and traced again
     n_up, n_tr = len(uploads), len(traced)
     data.values[:] = np.roll(data.values, 30, axis=2)                            # the whole pattern 30 columns further east, in place
     s3 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
@@ -470,6 +470,85 @@ def test_inputs_and_contour_batches_stay_on_the_device_between_calls(hostsim_eng
     wb.release_inputs()
     resident, kept = engine._caches(ctx)
     assert not resident and not kept
+
+
+def test_an_edit_of_one_time_step_between_two_calls_is_seen(hostsim_engine, monkeypatch):
+    """the reference rereads its input on every call (index_utils.py:66-75): a region of ONE time step patched in place
+    between two calls -- far from any strided sample -- gives the new events, not the cached cube's; cubes registered with
+    keep_inputs() (a promise not to do that) are recognised without reading every byte"""
+    data, pv, lat, lon, tm = _field()
+    ctx = engine.get_context()
+    uploads = []
+    real_up = ctx.to_device
+    monkeypatch.setattr(ctx, "to_device", lambda a: (uploads.append(a.shape), real_up(a))[1])
+    c1 = wb.calculate_cutoffs(data=data, contour_levels=[2])
+    c1b = wb.calculate_cutoffs(data=data, contour_levels=[2])
+    assert len(uploads) == 1 and len(c1) == len(c1b)
+    # a new cutoff at step 1: a 9 x 9 patch well inside the stratosphere's side set below the level
+    v = data.values
+    j = int(np.argmin(np.abs(lat - 70.0)))
+    before = v[1, j - 4:j + 5, 101:110].copy()
+    assert (before > 2).all()
+    v[1, j - 4:j + 5, 101:110] = 0.5
+    c2 = wb.calculate_cutoffs(data=data, contour_levels=[2])
+    assert len(uploads) == 2                                                      # seen: uploaded again
+    n1 = sum(1 for d in c1["date"] if d == tm[1])
+    n2 = sum(1 for d in c2["date"] if d == tm[1])
+    assert n2 == n1 + 1 and len(c2) == len(c1) + 1
+    # the same edit undone: the first result again
+    v[1, j - 4:j + 5, 101:110] = before
+    c3 = wb.calculate_cutoffs(data=data, contour_levels=[2])
+    assert len(c3) == len(c1) and list(c3["com"]) == list(c1["com"])
+    # registered cubes: address + sample instead of a full fingerprint
+    n_up = len(uploads)
+    stats0 = dict(engine.FINGERPRINT_STATS)
+    wb.keep_inputs(data)
+    wb.calculate_cutoffs(data=data, contour_levels=[2])                           # (the key changes kind: one more upload)
+    wb.calculate_cutoffs(data=data, contour_levels=[2])
+    assert len(uploads) == n_up + 1
+    assert engine.FINGERPRINT_STATS["full"] == stats0["full"] and engine.FINGERPRINT_STATS["sampled"] >= stats0["sampled"] + 2
+    # a read-only array is recognised the same way
+    wb.release_inputs()
+    ro = wb.GridField(np.array(data.values), data.dims, data.coords)
+    ro.values.flags.writeable = False
+    stats0 = dict(engine.FINGERPRINT_STATS)
+    wb.calculate_cutoffs(data=ro, contour_levels=[2])
+    assert engine.FINGERPRINT_STATS["full"] == stats0["full"]
+    wb.release_inputs()
+
+
+def test_a_call_never_evicts_its_own_cubes(hostsim_engine, monkeypatch):
+    """WB_INPUT_CACHE_GB smaller than field + intensity: the intensity's upload must not evict (and free) the field the
+    same call is about to use -- the cube that does not fit is uploaded for the call only and freed after it"""
+    data, pv, lat, lon, tm = _field()
+    inten_np = synth.pv_field(0, 3, lat, lon, eps=0.0, seed=20241)
+    inten = wb.GridField(inten_np, data.dims, data.coords)
+    want_s = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    want_c = wb.calculate_contours(data=data, contour_levels=[2], original_coordinates=False)
+    wb.release_inputs()
+    ctx = engine.get_context()
+    freed = []
+    real_free = ctx.free
+    monkeypatch.setattr(ctx, "free", lambda p: (freed.append(p), real_free(p))[1])
+    monkeypatch.setenv("WB_INPUT_CACHE_GB", str(1.5 * pv.nbytes / 2.0 ** 30))
+    for rep in range(2):
+        got = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+        assert len(got) == len(want_s) and list(got["com"]) == list(want_s["com"])
+        assert np.allclose(list(got["intensity"]), list(want_s["intensity"]))
+        resident, kept = engine._caches(ctx)
+        assert len(resident) == 1 and not engine._call_transients(ctx)            # the field stays, the intensity was the call's alone
+    # a frame handed in takes the same path
+    got = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten, contours=want_c)
+    assert list(got["com"]) == list(want_s["com"])
+    # a bound below ONE cube: nothing is kept, everything is freed after the call
+    wb.release_inputs()
+    monkeypatch.setenv("WB_INPUT_CACHE_GB", str(0.5 * pv.nbytes / 2.0 ** 30))
+    n0 = len(freed)
+    got = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    assert list(got["com"]) == list(want_s["com"])
+    resident, kept = engine._caches(ctx)
+    assert not resident and not kept and len(freed) >= n0 + 2
+    wb.release_inputs()
 
 
 def test_first_call_uploads_in_blocks_while_it_computes(hostsim_engine, monkeypatch):

@@ -8,7 +8,7 @@ tracking track_events (wavebreaking/__init__.py:20-25) -- xarray.DataArray
 """
 __version__ = "0.1.0"
 
-from wavebreaking_amd.engine import release_inputs  # noqa: F401
+from wavebreaking_amd.engine import keep_inputs, release_inputs  # noqa: F401
 from wavebreaking_amd.gridfield import GridField  # noqa: F401
 from wavebreaking_amd.indices.contour_index import calculate_contours  # noqa: F401
 from wavebreaking_amd.indices.cutoff_index import calculate_cutoffs  # noqa: F401

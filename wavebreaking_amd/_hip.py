@@ -138,6 +138,12 @@ class Library:
         lib.wb_comm_destroy.restype = None
         lib.wb_last_op_ms.argtypes = [C.c_void_p]
         lib.wb_last_op_ms.restype = C.c_float
+        lib.wb_fingerprint.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        lib.wb_fingerprint.restype = C.c_uint64
+
+    def fingerprint(self, arr, threads=0):
+        """64-bit hash of every byte of a C-contiguous numpy array (wb_fingerprint: host threads, no device work)"""
+        return int(self.lib.wb_fingerprint(C.c_void_p(arr.__array_interface__["data"][0]), int(arr.nbytes), int(threads)))
 
 
 _default = None

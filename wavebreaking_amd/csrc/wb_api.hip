@@ -1633,6 +1633,46 @@ static void wb_launch_smooth_plus(wb_ctx* ctx, int P, const WbSmoothArgs& a) {
 
 extern "C" float wb_last_op_ms(wb_ctx* ctx) { return ctx ? ctx->last_op_ms : 0.f; }
 
+// ------------------------------------------------------------------------------------------------ fingerprint of a host buffer
+// Chunks of 4 MiB hashed independently (four multiply-rotate lanes over 32-byte blocks: memory-bound), combined in chunk
+// order: the same value whatever the number of threads.
+static uint64_t wb_rotl64(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+static uint64_t wb_hash_chunk(const unsigned char* p, size_t n, uint64_t seed) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
+    uint64_t h[4] = {seed + P1 + P2, seed + P2, seed, seed - P1};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; ++k) h[k] = wb_rotl64(h[k] + w[k] * P2, 31) * P1;
+    }
+    uint64_t t = wb_rotl64(h[0], 1) + wb_rotl64(h[1], 7) + wb_rotl64(h[2], 12) + wb_rotl64(h[3], 18) + (uint64_t)n;
+    for (; i < n; ++i) t = wb_rotl64(t ^ ((uint64_t)p[i] * P1), 11) * P2;
+    return wb_mix64(t);
+}
+extern "C" uint64_t wb_fingerprint(const void* host_buffer, uint64_t bytes, int threads) {
+    const unsigned char* p = (const unsigned char*)host_buffer;
+    if (!p || !bytes) return 0x5742ull;
+    const size_t chunk = (size_t)4 << 20, nchunks = (size_t)((bytes + chunk - 1) / chunk);
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency() / 2; if (threads > 16) threads = 16; }
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > nchunks) threads = (int)nchunks;
+    std::vector<uint64_t> part(nchunks);
+    auto work = [&](int t) {
+        for (size_t c = (size_t)t; c < nchunks; c += (size_t)threads) {
+            const size_t o = c * chunk, n = (size_t)bytes - o < chunk ? (size_t)bytes - o : chunk;
+            part[c] = wb_hash_chunk(p + o, n, (uint64_t)c);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    uint64_t h = 0x5742ull ^ (uint64_t)bytes;
+    for (size_t c = 0; c < nchunks; ++c) h = wb_mix64(h ^ part[c]) + 0x9E3779B97F4A7C15ull;
+    return h;
+}
+
 extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "scan_split")) { ctx->scan_split = value ? 1 : 0; return 0; }

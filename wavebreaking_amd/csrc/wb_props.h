@@ -639,7 +639,9 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 #ifndef WB_BOXCOM_FORCE_WALK
 #define WB_BOXCOM_FORCE_WALK 0       // 1 (a test build): no chunk is predicted, one lane walks them all
 #endif
+#ifndef WB_BOXCOM_SPLIT
 #define WB_BOXCOM_SPLIT 2            // workgroups per selected contour (its boxes are dealt out round-robin)
+#endif
 #ifndef WB_BOXCOM_SEGS
 #define WB_BOXCOM_SEGS 12            // binade steps of x * w along a row: x < 4096
 #endif

@@ -111,12 +111,19 @@ class Prepared:
 
 # ------------------------------------------------------------------------------------------------ inputs kept on the device
 # The reference's way of not repeating work across calculate_streamers / _overturnings / _cutoffs on one cube is the
-# ``contours=`` argument (contour_index.py:203-208); every call still reads the cube.  Here the expensive part of a call on
-# a host-resident cube is its trip over PCIe (4.15 MB per 0.25 degree step and cube), so the last cubes a context was given
-# stay on the device, and so do the contour batches traced from them: a second call on the same array -- same buffer,
-# shape, dtype, and the same values in a strided sample of 16 Ki elements plus both ends -- skips upload AND tracing.
-# In-place edits of single cells between two calls can slip through that sample: WB_INPUT_CACHE=0 (or release_inputs())
-# uploads on every call.  WB_INPUT_CACHE_GB bounds the device memory kept (default 48).
+# ``contours=`` argument (contour_index.py:203-208); every call still reads the cube (index_utils.py:66-75).  Here the
+# expensive part of a call on a host-resident cube is its trip over PCIe (4.15 MB per 0.25 degree step and cube), so the
+# last cubes a context was given stay on the device, and so do the contour batches traced from them: a later call that
+# presents the same buffer with the same bytes skips upload AND tracing.  "The same bytes" is VERIFIED, never assumed:
+#   * every call fingerprints the WHOLE buffer (wb_fingerprint: all bytes, several host threads -- a fraction of the PCIe
+#     trip it saves) and a cube whose fingerprint changed is uploaded again: an in-place edit of a single cell between two
+#     calls is seen, as it is by the reference;
+#   * cubes that cannot change under the caller -- ``arr.flags.writeable`` is False -- or that the caller promised not to
+#     modify (``wavebreaking_amd.keep_inputs(data, ...)``, until ``release_inputs()``) are recognised by buffer address,
+#     shape and dtype plus a strided 16 Ki-element sample (a tripwire, not the guarantee).
+# An entry lives as long as the host array it mirrors (weakref) and goes when that array is collected.
+# WB_INPUT_CACHE=0 switches the cache off; WB_INPUT_CACHE_GB bounds the device memory kept (default 48); a call whose own
+# cubes do not fit beside each other under the bound uploads them for the call only.
 INPUT_CACHE = os.environ.get("WB_INPUT_CACHE", "1") != "0"
 # WB_PIPELINED_UPLOAD=1: the first call on a cube that is not on the device yet cuts the record into blocks and computes
 # block k while block k + 1 is uploaded.  Off by default: measured on MI355X (365 steps of 0.25 degree, field + intensity)
@@ -125,6 +132,9 @@ INPUT_CACHE = os.environ.get("WB_INPUT_CACHE", "1") != "0"
 # slower box), and a later call with ``contours=`` needs a whole-record batch the allocator has not seen yet.
 PIPELINED_UPLOAD = os.environ.get("WB_PIPELINED_UPLOAD", "0") == "1"
 _tick = [0]
+_promised = {}          # (address, nbytes) -> weakref of the owner: buffers registered with keep_inputs()
+_dead = []              # (device, key) of cache entries whose host array was collected; purged by the next call
+FINGERPRINT_STATS = {"full": 0, "sampled": 0, "seconds": 0.0}
 
 
 def _caches(ctx):
@@ -135,17 +145,95 @@ def _caches(ctx):
     return ctx._wb_resident, ctx._wb_kept
 
 
-def _array_key(arr):
+def _owner(arr):
+    """the object that owns an array's memory (the end of its .base chain)"""
+    o = arr
+    while isinstance(o, np.ndarray) and o.base is not None:
+        o = o.base
+    return o
+
+
+def _as_array(obj):
+    """the numpy buffer behind a cube handed to keep_inputs(): ndarray, GridField / xarray.DataArray (.values)"""
+    if isinstance(obj, np.ndarray):
+        return obj
+    v = getattr(obj, "values", None)
+    if isinstance(v, np.ndarray):
+        return v
+    raise TypeError("keep_inputs: a numpy array, a GridField or an xarray.DataArray is expected")
+
+
+def keep_inputs(*cubes):
+    """Promise not to modify these cubes in place until ``release_inputs()``: calls on them then recognise the device copy
+    by the buffer's address (plus a strided sample) instead of fingerprinting every byte of every cube on every call."""
+    import weakref
+    for c in cubes:
+        if c is None:
+            continue
+        a = _as_array(c)
+        o = _owner(a)
+        try:
+            ref = weakref.ref(o)
+        except TypeError:                        # (an owner that cannot be weakly referenced: held until release_inputs())
+            ref = (lambda obj: (lambda: obj))(o)
+        _promised[(a.__array_interface__["data"][0], a.nbytes)] = ref
+
+
+def _is_promised(arr):
+    ref = _promised.get((arr.__array_interface__["data"][0], arr.nbytes))
+    if ref is None:
+        return False
+    if ref() is None:                            # the registered array is gone; the address belongs to something else now
+        _promised.pop((arr.__array_interface__["data"][0], arr.nbytes), None)
+        return False
+    return True
+
+
+def _array_key(arr, ctx=None):
+    """cache key of a cube: buffer address, shape, dtype and a fingerprint of its bytes -- of ALL of them unless the buffer
+    cannot change (not writeable) or was registered with keep_inputs()"""
+    import time
     flat = arr.reshape(-1)                      # a view: the array is C-contiguous
     n = flat.size
-    sample = np.ascontiguousarray(flat[:: max(1, n // 16384)])
-    edge = np.concatenate([flat[:256], flat[-256:]])
-    return (arr.__array_interface__["data"][0], arr.shape, arr.dtype.str, hash(sample.tobytes()), hash(edge.tobytes()))
+    head = (arr.__array_interface__["data"][0], arr.shape, arr.dtype.str)
+    if not arr.flags.writeable or _is_promised(arr):
+        sample = np.ascontiguousarray(flat[:: max(1, n // 16384)])
+        edge = np.concatenate([flat[:256], flat[-256:]])
+        FINGERPRINT_STATS["sampled"] += 1
+        return head + ("sampled", hash(sample.tobytes()), hash(edge.tobytes()))
+    tic = time.perf_counter()
+    lib = (ctx or get_context()).L
+    fp = lib.fingerprint(arr)
+    FINGERPRINT_STATS["full"] += 1
+    FINGERPRINT_STATS["seconds"] += time.perf_counter() - tic
+    return head + ("full", fp)
 
 
 def _cacheable(arr):
     return (INPUT_CACHE and isinstance(arr, np.ndarray) and arr.ndim == 3 and arr.dtype in (np.float32, np.float64)
             and arr.flags.c_contiguous and arr.size > 0)
+
+
+def _watch(ctx, arr, key):
+    """drop the entry when the host array it mirrors is collected (at the next call: a context is driven by one thread)"""
+    import weakref
+    try:
+        weakref.finalize(_owner(arr), _dead.append, (ctx.device, key))
+    except TypeError:
+        pass
+
+
+def _purge_dead(ctx):
+    resident, _ = _caches(ctx)
+    keep = []
+    while _dead:
+        dev, key = _dead.pop()
+        if dev == ctx.device:
+            if key in resident:
+                _drop_resident(ctx, key)
+        else:
+            keep.append((dev, key))
+    _dead.extend(keep)
 
 
 class _Upload:
@@ -216,7 +304,9 @@ def _drop_resident(ctx, key):
 
 
 def release_inputs():
-    """give back the device copies of input cubes (and the contour batches traced from them) kept between calls"""
+    """give back the device copies of input cubes (and the contour batches traced from them) kept between calls, and forget
+    the promises made with keep_inputs()"""
+    _promised.clear()
     for ctx in _contexts.values():
         resident, kept = _caches(ctx)
         for bk in list(kept):
@@ -225,25 +315,42 @@ def release_inputs():
             _drop_resident(ctx, key)
 
 
+def _budget():
+    return float(os.environ.get("WB_INPUT_CACHE_GB", 48)) * 2.0 ** 30
+
+
+def _make_room(ctx, need, protect):
+    """evict least-recently-used cubes -- never one of the running call's own (``protect``) -- until ``need`` more bytes fit
+    under the bound; False: they do not fit even then"""
+    resident, _ = _caches(ctx)
+    budget = _budget()
+    while sum(v["nbytes"] for v in resident.values()) + need > budget:
+        victim = min((k for k in resident if k not in protect), key=lambda k: resident[k]["tick"], default=None)
+        if victim is None:
+            return False
+        _drop_resident(ctx, victim)
+    return True
+
+
 def resident_inputs(ctx, field, intensity, block):
     """the entries of a call's cube(s).  Cubes that are not on the device yet are allocated here and uploaded in the
     background, ``block`` time steps at a time (``ent["upload"].wait(t1)`` before steps below t1 are used; ``ent["block"]`` is
-    the block size the call should cut the record into so that computing overlaps the upload)"""
+    the block size the call should cut the record into so that computing overlaps the upload).  An entry with
+    ``ent["transient"]`` belongs to this call alone (the call's cubes did not fit under WB_INPUT_CACHE_GB beside each
+    other): the caller frees it with ``release_transient`` when the call is over."""
+    _purge_dead(ctx)
     resident, _ = _caches(ctx)
     arrs = [a for a in (field, intensity) if a is not None]
-    keys = [_array_key(a) for a in arrs]
+    keys = [_array_key(a, ctx) for a in arrs]
     fresh = [k not in resident for k in keys]
     nt = field.shape[0]
     if not any(fresh) or not PIPELINED_UPLOAD or block >= nt:
-        ents = [resident_input(ctx, a) for a in arrs]
+        ents = [resident_input(ctx, a, k, protect=keys) for a, k in zip(arrs, keys)]
         return ents[0], (ents[1] if intensity is not None else None)
-    budget = float(os.environ.get("WB_INPUT_CACHE_GB", 48)) * 2.0 ** 30
     need = sum(a.nbytes for a, f in zip(arrs, fresh) if f)
-    while resident and sum(v["nbytes"] for v in resident.values()) + need > budget:
-        victim = min((k for k in resident if k not in keys), key=lambda k: resident[k]["tick"], default=None)
-        if victim is None:
-            break
-        _drop_resident(ctx, victim)
+    if not _make_room(ctx, need, keys):
+        ents = [resident_input(ctx, a, k, protect=keys) for a, k in zip(arrs, keys)]
+        return ents[0], (ents[1] if intensity is not None else None)
     jobs, ents, new = [], [], []
     for a, k in zip(arrs, keys):
         _tick[0] += 1
@@ -251,6 +358,7 @@ def resident_inputs(ctx, field, intensity, block):
         if ent is None:
             ent = dict(ptr=ctx.alloc(a.nbytes), nbytes=a.nbytes, key=k, block=block, upload=None)
             resident[k] = ent
+            _watch(ctx, a, k)
             jobs.append((ent["ptr"], a, a[0].nbytes))
             new.append(ent)
         elif ent not in new:
@@ -263,22 +371,45 @@ def resident_inputs(ctx, field, intensity, block):
     return ents[0], (ents[1] if intensity is not None else None)
 
 
-def resident_input(ctx, arr):
-    """device pointer entry of a host cube, uploading it unless this context still holds it"""
+def resident_input(ctx, arr, key=None, protect=()):
+    """device pointer entry of a host cube, uploading it unless this context still holds it.  ``protect``: keys of the
+    running call's cubes, which are never evicted to make room (the field of a call must outlive the upload of its
+    intensity).  A cube that does not fit under the bound beside them is uploaded for this call only (``transient``)."""
     resident, _ = _caches(ctx)
-    key = _array_key(arr)
+    if key is None:
+        _purge_dead(ctx)
+        key = _array_key(arr, ctx)
     _tick[0] += 1
     ent = resident.get(key)
     if ent is not None:
         _settle(ent)                                 # (a background upload of an earlier call: wait for all of it)
     if ent is None:
-        budget = float(os.environ.get("WB_INPUT_CACHE_GB", 48)) * 2.0 ** 30
-        while resident and sum(v["nbytes"] for v in resident.values()) + arr.nbytes > budget:
-            _drop_resident(ctx, min(resident, key=lambda k: resident[k]["tick"]))
+        fits = _make_room(ctx, arr.nbytes, set(protect) | {key})
         ent = dict(ptr=ctx.to_device(arr), nbytes=arr.nbytes, key=key)
-        resident[key] = ent
+        if fits:
+            resident[key] = ent
+            _watch(ctx, arr, key)
+        else:
+            ent["transient"] = True
     ent["tick"] = _tick[0]
     return ent
+
+
+def _call_transients(ctx):
+    if not hasattr(ctx, "_wb_transients"):
+        ctx._wb_transients = []
+    return ctx._wb_transients
+
+
+def release_call_transients(ctx):
+    """free the device copies that were made for the running call only (its cubes did not fit under the cache's bound);
+    the index functions and calculate_contours call this when their batches are closed"""
+    pending = _call_transients(ctx)
+    while pending:
+        e = pending.pop()
+        if e.get("ptr") and ctx.h:
+            ctx.free(e["ptr"])
+        e["ptr"] = None
 
 
 class _KeptBatch:
@@ -314,6 +445,10 @@ def iter_contour_batches(prep, levels, periodic_add, params, want_cells=False):
         # while the next one arrives; the kept contour batches are per block, later calls cut the record the same way)
         fe, ie = resident_inputs(ctx, prep.values, prep.intensity, min(chunk, max(64, -(-nt // 4))) if nt >= 128 else chunk)
         chunk = min(chunk, fe.get("block", chunk))
+        # cubes uploaded for this call only (they did not fit under the cache's bound): the consumer frees them when the
+        # call is over (release_call_transients), and the batches traced from them are not kept either
+        transient = [e for e in (fe, ie) if e is not None and e.get("transient")]
+        _call_transients(ctx).extend(transient)
         grid = hash((prep.lat.tobytes(), prep.lon.tobytes(), float(prep.dlon), float(prep.dlat)))
         step_bytes = nlat * nlon * prep.values.dtype.itemsize
     for t0 in range(0, nt, chunk):
@@ -353,7 +488,7 @@ def iter_contour_batches(prep, levels, periodic_add, params, want_cells=False):
             except Exception:
                 b.close()
                 raise
-            if keep:
+            if keep and not transient:
                 while len(_kept) >= int(os.environ.get("WB_KEPT_BATCHES", 8)):
                     _kept.pop(min(_kept, key=lambda k: _kept[k]["tick"]))["batch"].close()
                 _kept[bkey] = dict(batch=b, field=fe["key"], intensity=ie["key"] if ie is not None else None, tick=_tick[0])

@@ -21,6 +21,13 @@ class LazyContours:
 
 def run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max=None):
     """kind: _hip.STREAMERS / OVERTURNINGS / CUTOFFS.  Returns the reference-shaped frame."""
+    try:
+        return _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max)
+    finally:
+        engine.release_call_transients(engine.get_context())     # cubes uploaded for this call only (engine.resident_input)
+
+
+def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max):
     dim_kwargs = {k: kwargs[k] for k in DIM_KEYS}
     prep = engine.Prepared(data, intensity, dim_kwargs)
     ctx = engine.get_context()
@@ -85,8 +92,8 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
         table, levels = engine.frame_to_table(contours, prep.times, engine.as_levels(contour_levels))
         if engine._cacheable(prep.values) and (prep.intensity is None or (engine._cacheable(prep.intensity) and prep.intensity.dtype == prep.values.dtype)):
             # the cubes stay on the device between calls (engine.resident_input): a frame handed in costs no upload either
-            fe = engine.resident_input(ctx, prep.values)
-            ie = engine.resident_input(ctx, prep.intensity) if prep.intensity is not None else None
+            fe, ie = engine.resident_inputs(ctx, prep.values, prep.intensity, prep.values.shape[0])
+            engine._call_transients(ctx).extend(e for e in (fe, ie) if e is not None and e.get("transient"))
             b = ctx.batch_from_contours(table, fe["ptr"], prep.lat, prep.lon, [float(v) for v in levels][:4] or [0.0],
                                         prep.dlon, prep.dlat, periodic_add=periodic_add, intensity=ie["ptr"] if ie is not None else None,
                                         device_shape=prep.values.shape, device_dtype=prep.values.dtype, **params)

@@ -80,9 +80,12 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     levels = engine.as_levels(contour_levels)
     # every batch (block of time steps x group of <= 4 levels) is released as soon as its table is on the host
     tables = []
-    for b, pos, t0 in engine.iter_contour_batches(prep, levels, periodic_add, {}):
-        tables.append((b.contour_table(), pos, t0))
-        b.close()
+    try:
+        for b, pos, t0 in engine.iter_contour_batches(prep, levels, periodic_add, {}):
+            tables.append((b.contour_table(), pos, t0))
+            b.close()
+    finally:
+        engine.release_call_transients(engine.get_context())
     return _contour_frame(tables, prep, levels, original_coordinates)
 
 

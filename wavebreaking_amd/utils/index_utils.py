@@ -41,38 +41,32 @@ def transform_polygons(polygons, lon, lat, nlon):
 
 
 def combine_shared(lst):
-    """Merge the lists that share at least one element, transitively (index_utils.py:187-214): connected components
-    of the "shares an element" relation by union-find over the elements; components come out in the order of their
-    first list, each as a list of its distinct elements.  (The index kernels do the same by label propagation,
-    csrc/wb_indices.h; this host version exists because the reference's tests call it, tests/test_wavebreaking.py:101-104.)"""
-    groups = [list(g) for g in lst]
-    parent = {}
-
-    def find(x):
-        while parent[x] != x:
-            parent[x] = parent[parent[x]]
-            x = parent[x]
-        return x
-
-    for g in groups:
-        for x in g:
-            parent.setdefault(x, x)
-        for x in g[1:]:
-            ra, rb = find(g[0]), find(x)
-            if ra != rb:
-                parent[rb] = ra
-    merged, slot = [], {}
-    for g in groups:
-        if not g:
-            merged.append([])                          # the reference emits an empty group for an empty list (:196-212)
-            continue
-        root = find(g[0])
-        if root not in slot:
-            slot[root] = len(merged)
-            merged.append([])
-    for x in parent:                                   # elements in first-seen order
-        merged[slot[find(x)]].append(x)
-    return merged
+    """Merge the lists that share at least one element, transitively (index_utils.py:187-214).  Components come out in the
+    order of their first list, and the members of a component in the order the reference returns them: ``list(set)`` of a
+    CPython set that was built by exactly these operations -- the set of the first list, then, sweep after sweep over the
+    lists not yet absorbed, an in-place union with the set of every list that meets it (streamer_index.py:241-246 picks a
+    group's survivor by position in this list, so the order is part of the result: ``[[1, 8]] -> [[8, 1]]``).  Pinned
+    against the reference's own function by tests/golden/reference_rules.npz.  (The index kernels restate the same
+    insertion sequence on the device, csrc/wb_core.h:wb_pyset_*.)"""
+    waiting = list(lst)
+    components = []
+    while waiting:
+        grown = set(waiting[0])
+        others = waiting[1:]
+        size = -1
+        while len(grown) > size:                       # until a sweep adds nothing
+            size = len(grown)
+            apart = []
+            for member in others:
+                as_set = set(member)
+                if grown.intersection(as_set):
+                    grown |= as_set
+                else:
+                    apart.append(member)
+            others = apart
+        components.append(list(grown))
+        waiting = others
+    return components
 
 
 def _iterate_over(keyword, values_of):
