@@ -1080,24 +1080,32 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             ot_box = (int*)talloc((size_t)nsel_b * WB_OT_CAP * 4 * sizeof(int));
             ot_orient = (int*)talloc((size_t)nsel_b * WB_OT_CAP * sizeof(int));
             ot_sums = (double*)talloc((size_t)nsel_b * WB_OT_CAP * 3 * sizeof(double));
-            if (!ot_sums) { release(); return 1; }
+            int* boxq = (int*)talloc((size_t)nsel_b * WB_OT_CAP * sizeof(int));
+            if (!ot_sums || !boxq) { release(); return 1; }
+            const bool box_sums = r * r <= 1.0;        // (a wider rim: the property kernel rasterises the boxes like any polygon)
             WbOverturnArgs oa;
             memset(&oa, 0, sizeof(oa));
             oa.ctl = ctl; oa.cap_seg = cap; oa.nlon = p.nlon; oa.W = b->W;
             oa.rg_over_dlon = p.range_group / p.dlon; oa.minexp_over_dlon = p.ot_min_exp / p.dlon;
             oa.sel_job = b->sel_job; oa.sel_cont = b->sel_cont; oa.c_off = b->c_off; oa.c_len = b->c_len; oa.cpts = b->cpts;
             oa.lat = T->base + T->o_lat; oa.ot_n = ot_n; oa.ot_box = ot_box; oa.ot_orient = ot_orient; oa.status = b->status;
+            oa.nlat = p.nlat; oa.wlat = box_sums ? T->base + T->o_wlat : nullptr; oa.ot_sums = ot_sums; oa.boxq = boxq;
             side_begin(ctx);
             b->timer.begin(ctx, "overturn");
             WB_LAUNCH_LDS(wb_k_overturn, nsel_b, 256, (size_t)b->W * 8 + 32, oa);
             b->timer.end(ctx);
-            if (r * r <= 1.0) {
+            if (box_sums) {
+                // the boxes wb_k_overturn queued (their truncated centre of mass could turn on the last bits of the reference's
+                // cell-by-cell sums): a persistent grid of single-wave workgroups takes them one at a time
                 WbBoxComArgs ba;
                 memset(&ba, 0, sizeof(ba));
-                ba.nlat = p.nlat; ba.W = b->W; ba.ctl = ctl; ba.ot_n = ot_n; ba.ot_box = ot_box; ba.wlat = T->base + T->o_wlat;
+                ba.nlat = p.nlat; ba.W = b->W; ba.ctl = ctl; ba.boxq = boxq; ba.ot_box = ot_box; ba.wlat = T->base + T->o_wlat;
                 ba.ot_sums = ot_sums;
+                long long g = (long long)ctx->boxcom_per_cu * wb_num_cus(ctx), most = (long long)nsel_b * 4;
+                if (g > most) g = most;
+                if (g < 1) g = 1;
                 b->timer.begin(ctx, "box_com");
-                WB_LAUNCH(wb_k_box_com, (long long)nsel_b * WB_BOXCOM_SPLIT, 64, ba);
+                WB_LAUNCH(wb_k_box_com, g, 64, ba);
                 b->timer.end(ctx);
             }
             side_end(ctx);
@@ -1687,6 +1695,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }
     if (!strcmp(name, "timers")) { ctx->timers = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;

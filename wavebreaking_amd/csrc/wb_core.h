@@ -104,6 +104,7 @@ struct WbCtl {
     int props_cursor;            // next event of the property kernel's work queue
     int group_ties;              // check_groups: groups whose maximum length was shared by several members (exact ties)
     int n_recheck;               // pairs wb_k_streamer_pairs2 left to wb_k_streamer_recheck (inside a guard band)
+    int n_boxq, boxq_cursor;     // overturning boxes queued for wb_k_box_com (wb_k_overturn) / the next one its persistent workgroups take
     int p2_cursor;               // next (contour, part) item of wb_k_streamer_pairs2's persistent workgroups
     int f1_cursor;               // next contour (in wb_k_pairs_order's order) of wb_k_streamer_f1's persistent workgroups
     int pad3;
@@ -383,6 +384,26 @@ WB_HD inline bool wb_segments_intersect(int p1x, int p1y, int q1x, int q1y, int 
 }
 
 // 64-bit mix for the open-addressing tables (splitmix64 finaliser)
+// ---- shared by wb_k_overturn (which decides whether a box needs the reference-order sums) and wb_props.h
+// Is the truncation of num / den safe against an error of `ulps` units of 2^-53 (relative) in the quotient?
+WB_HD inline bool wb_trunc_unsafe(double num, double den, double ulps) {
+    const double q = num / den;
+    const double tol = (fabs(q) + 1.0) * ulps * 1.1102230246251565e-16;
+    return fabs(q - rint(q)) <= tol;
+}
+// relative error bound (in units of 2^-53) between the row-wise sums over `rows` rows and the reference's compensated
+// cell-wise sums, for the QUOTIENT of two such sums; x4 safety
+WB_HD inline double wb_com_ulps(int rows) { return 4.0 * (2.0 * (double)rows + 16.0); }
+
+// v = m * 2^e, m < 2^53 (v >= 0, finite)
+WB_HD inline void wb_dbl_split(double v, unsigned long long* m, int* e) {
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    const int ef = (int)((b >> 52) & 0x7FF);
+    const unsigned long long fr = b & 0xFFFFFFFFFFFFFull;
+    if (ef == 0) { *m = fr; *e = -1074; } else { *m = fr | (1ull << 52); *e = ef - 1075; }
+}
+
 WB_HD inline uint64_t wb_mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

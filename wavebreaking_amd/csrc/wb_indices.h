@@ -89,7 +89,7 @@ WB_KERNEL(wb_k_select_fill, WbSelectArgs a) {
 
 struct WbOverturnArgs {
     int cap_seg, nlon, W;
-    const WbCtl* ctl;          // ctl->nsel selected contours
+    WbCtl* ctl;                // ctl->nsel selected contours; n_boxq / com_rechecks[1]: boxes queued for wb_k_box_com
     double rg_over_dlon;       // range_group / dlon
     double minexp_over_dlon;   // min_exp / dlon
     const int* sel_job;
@@ -103,6 +103,12 @@ struct WbOverturnArgs {
     int* ot_box;               // [nsel][WB_OT_CAP][4] min_lon, min_lat, max_lon, max_lat (index units)
     int* ot_orient;            // [nsel][WB_OT_CAP]    0 cyclonic, 1 anticyclonic
     uint32_t* status;          // [njobs]
+    // centre-of-mass sums of the boxes (index_utils.py:91-110; every cell of the closed box counts): closed forms here, and
+    // the boxes whose truncated quotient could turn on the last bits of the reference's cell-by-cell sums go on a queue
+    int nlat;
+    const double* wlat;        // [nlat] area weight of a latitude row (null: no sums, the property kernel rasterises the boxes)
+    double* ot_sums;           // [nsel][WB_OT_CAP][3] areas, x_com, y_com
+    int* boxq;                 // [nsel * WB_OT_CAP] slot (contour * WB_OT_CAP + box) of a queued box
 };
 
 // set(range(a0, b0+1) % nlon) subset of set(range(a1, b1+1) % nlon)   (overturning_index.py:141-151)
@@ -225,6 +231,36 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
         box[4 * g + 1] = ylo[g];
         box[4 * g + 2] = gmax[g];
         box[4 * g + 3] = yhi[g];
+        if (a.wlat) {
+            // areas / x_com / y_com of the box row by row in closed form.  A box with min_lon + max_lon even has
+            // x_com / areas = an integer mathematically: when the quotient is that close to one, int() (index_utils.py:105-110)
+            // turns on the last bits of the reference's compensated cell-by-cell sums, and the box is queued for wb_k_box_com
+            int x0 = gmin[g], y0 = ylo[g], x1 = gmax[g], y1 = yhi[g];
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 > a.W - 1) x1 = a.W - 1;
+            if (y1 > a.nlat - 1) y1 = a.nlat - 1;
+            const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
+            const double cnt = (double)cols;
+            const double sxr = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
+            double areas = 0.0, xc = 0.0, yc = 0.0;
+            for (int y = y0; y <= y1; ++y) {
+                const double w = a.wlat[y];
+                areas = areas + w * cnt;
+                xc = xc + w * sxr;
+                yc = yc + w * ((double)y * cnt);
+            }
+            const double ulps = wb_com_ulps(rows);
+            double* out = a.ot_sums + ((size_t)s * WB_OT_CAP + g) * 3;
+            if (cols > 0 && rows > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps))) {
+                a.boxq[wb_atomic_add(&a.ctl->n_boxq, 1)] = s * WB_OT_CAP + (int)g;
+                wb_atomic_add(&a.ctl->com_rechecks[1], 1);
+            } else {
+                out[0] = areas;
+                out[1] = xc;
+                out[2] = yc;
+            }
+        }
     WB_END_PFOR
     WB_SINGLE
     a.ot_n[s] = G;

@@ -90,16 +90,6 @@ WB_DEV inline bool wb_near_segment(int x, int y, int ax, int ay, int bx, int by,
         (s) = wb_t_;                               \
     } while (0)
 
-// Is the truncation of num / den safe against an error of `ulps` units of 2^-53 (relative) in the quotient?
-WB_HD inline bool wb_trunc_unsafe(double num, double den, double ulps) {
-    const double q = num / den;
-    const double tol = (fabs(q) + 1.0) * ulps * 1.1102230246251565e-16;
-    return fabs(q - rint(q)) <= tol;
-}
-// relative error bound (in units of 2^-53) between the row-wise sums over `rows` rows and the reference's compensated
-// cell-wise sums, for the QUOTIENT of two such sums; x4 safety
-WB_HD inline double wb_com_ulps(int rows) { return 4.0 * (2.0 * (double)rows + 16.0); }
-
 #define WB_PROPS_LONG 16
 // sum over the member cells of the box [x0, x0 + cols) x [y0, y0 + rows) of weight(y) * (data, intensity): the lanes run
 // ALONG the rows (adjacent lanes on adjacent cells: a load instruction touches two or three cache lines, not 64), eight
@@ -615,9 +605,12 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 }
 
 // areas / x_com / y_com of the overturning boxes (the events wb_k_props does not rasterise): every cell of the closed box
-// counts, so the row-wise sums are closed forms.  A box with min_lon + max_lon even has x_com / areas = an integer
-// mathematically -- half of all boxes need the reference-order re-evaluation, a chain of rows x cols dependent compensated
-// additions (up to 10^5 cells).  One workgroup per box makes that chain row-parallel and still bit-exact:
+// counts, so the row-wise sums are closed forms -- wb_k_overturn evaluates them.  A box with min_lon + max_lon even has
+// x_com / areas = an integer mathematically -- half of all boxes need the reference-order re-evaluation, a chain of
+// rows x cols dependent compensated additions (up to 10^5 cells): wb_k_overturn puts those on a queue, and this kernel's
+// persistent single-wave workgroups take them one at a time (round 4; until then two workgroups per contour walked that
+// contour's boxes, most of them finding none in need: 1.05 ms, 0.55 now).  One wave per box makes the chain row-parallel
+// and still bit-exact:
 //   * a step of pandas' compensated sum (y = v - c; t = s + y; c = t - s - y) is EXACT -- s - c grows by exactly v -- unless
 //     v - c needs rounding, which happens where the terms step up into a higher binade (c still carries the finer bits of
 //     the previous terms); between such steps the state is a function of the exact running total E alone: s = RN(E), c = s - E;
@@ -639,29 +632,19 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 #ifndef WB_BOXCOM_FORCE_WALK
 #define WB_BOXCOM_FORCE_WALK 0       // 1 (a test build): no chunk is predicted, one lane walks them all
 #endif
-#ifndef WB_BOXCOM_SPLIT
-#define WB_BOXCOM_SPLIT 2            // workgroups per selected contour (its boxes are dealt out round-robin)
-#endif
 #ifndef WB_BOXCOM_SEGS
-#define WB_BOXCOM_SEGS 12            // binade steps of x * w along a row: x < 4096
+#define WB_BOXCOM_SEGS 6             // binade steps of x * w along a row the prediction follows (x < 4096 admits 12: a row with more is walked;
+                                     // 6 halve the kernel's LDS -- 13 KB a wave -- and what it takes from the all-pairs kernel it runs beside)
 #endif
 typedef unsigned __int128 wb_u128;
 struct WbBoxComArgs {
     int nlat, W;
-    WbCtl* ctl;                   // ctl->nsel selected contours; com_rechecks[1] boxes re-evaluated, [2] ... by the one-lane walk
-    const int* ot_n;              // [nsel] boxes of a selected contour
+    WbCtl* ctl;                   // n_boxq queued boxes, boxq_cursor; com_rechecks[2]: boxes with a chunk walked by one lane
+    const int* boxq;              // [n_boxq] slot (selected contour * WB_OT_CAP + box) of a queued box (wb_k_overturn)
     const int* ot_box;            // [nsel][WB_OT_CAP][4]
     const double* wlat;
     double* ot_sums;              // [nsel][WB_OT_CAP][3] areas, x_com, y_com
 };
-// v = m * 2^e, m < 2^53 (v >= 0, finite)
-WB_HD inline void wb_dbl_split(double v, unsigned long long* m, int* e) {
-    unsigned long long b;
-    memcpy(&b, &v, 8);
-    const int ef = (int)((b >> 52) & 0x7FF);
-    const unsigned long long fr = b & 0xFFFFFFFFFFFFFull;
-    if (ef == 0) { *m = fr; *e = -1074; } else { *m = fr | (1ull << 52); *e = ef - 1075; }
-}
 WB_HD inline wb_u128 wb_fix128(double v, int ue) {
     unsigned long long m; int e;
     wb_dbl_split(v, &m, &e);
@@ -697,52 +680,38 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     WB_SHARED(unsigned long long, seghi, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);
     WB_SHARED(int, nseg, WB_BOXCOM_ROWS);
     WB_SHARED(double, st, 6 * (WB_BOXCOM_ROWS + 1));             // per chain: state s, c at the start of every row of the chunk (+ after its last)
-    WB_SHARED(int, ctl, 4);                                      // [0] in band, [1] unit exponent, [2] whole box by one lane, [3] this chunk by one lane
-    const int sel = WB_BLOCK_ID / WB_BOXCOM_SPLIT;
-    if (sel >= a.ctl->nsel) return;
-    const int nbox = a.ot_n[sel];
+    WB_SHARED(int, ctl, 5);                                      // [0] the queue entry taken, [1] unit exponent, [2] whole box by one lane, [3] this chunk by one lane, [4] largest exponent
     WB_BSTAMP_BEGIN                                              // development stamps: 0 closed forms, 1 .. 3 the passes, 4 the one-lane walks / output
-    for (int g = WB_BLOCK_ID % WB_BOXCOM_SPLIT; g < nbox; g += WB_BOXCOM_SPLIT) {
-    WB_SYNC();                                                   // the previous box's control words have been read by everyone
-    const int* d = a.ot_box + ((size_t)sel * WB_OT_CAP + g) * 4;
-    double* out = a.ot_sums + ((size_t)sel * WB_OT_CAP + g) * 3;
+    // persistent: a workgroup (one wave) takes the next queued box until the queue is empty -- only the boxes that need the
+    // reference-order sums are here (wb_k_overturn queued them), dealt out one at a time whatever contour they belong to
+    for (;;) {
+    WB_SINGLE
+    ctl[0] = wb_atomic_add(&a.ctl->boxq_cursor, 1);
+    ctl[1] = 4096;
+    ctl[4] = -4096;
+    WB_END_SINGLE
+    if (ctl[0] >= a.ctl->n_boxq) break;
+    const int slot = a.boxq[ctl[0]];
+    const int* d = a.ot_box + (size_t)slot * 4;
+    double* out = a.ot_sums + (size_t)slot * 3;
     int x0 = d[0], y0 = d[1], x1 = d[2], y1 = d[3];
     if (x0 < 0) x0 = 0;
     if (y0 < 0) y0 = 0;
     if (x1 > a.W - 1) x1 = a.W - 1;
     if (y1 > a.nlat - 1) y1 = a.nlat - 1;
     const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
-    WB_SINGLE
-    const double cnt = (double)cols;
-    const double sxr = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
-    double areas = 0.0, xc = 0.0, yc = 0.0;
-    int emin = 4096, emax = -4096;
-    for (int y = y0; y <= y1; ++y) {
-        const double w = a.wlat[y];
-        areas = areas + w * cnt;
-        xc = xc + w * sxr;
-        yc = yc + w * ((double)y * cnt);
+    WB_PFOR(r, rows)                                             // exponent range of the rows' weights
         unsigned long long m; int ex;
-        wb_dbl_split(w, &m, &ex);
-        if (m) { emin = ex < emin ? ex : emin; emax = ex > emax ? ex : emax; }
-    }
-    const double ulps = wb_com_ulps(rows);
-    const bool band = cols > 0 && rows > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps));
-    ctl[0] = band ? 1 : 0;
-    ctl[1] = emin;
+        wb_dbl_split(a.wlat[y0 + (int)r], &m, &ex);
+        if (m) { wb_atomic_min(&ctl[1], ex); wb_atomic_max(&ctl[4], ex); }
+    WB_END_PFOR
+    WB_SINGLE
+    const int emin = ctl[1], emax = ctl[4];
     // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
     ctl[2] = (emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
-    if (!band) {
-        out[0] = areas;
-        out[1] = xc;
-        out[2] = yc;
-    } else {
-        wb_atomic_add(&a.ctl->com_rechecks[1], 1);
-        for (int q = 0; q < 6; ++q) st[q * (WB_BOXCOM_ROWS + 1)] = 0.0;      // the sums start at s = c = 0: certain
-    }
+    for (int q = 0; q < 6; ++q) st[q * (WB_BOXCOM_ROWS + 1)] = 0.0;          // the sums start at s = c = 0: certain
     WB_END_SINGLE
     WB_BSTAMP(a.ctl, 0);
-    if (!ctl[0]) continue;
     const int ue = ctl[1];
     bool walked = false;
     // The box in chunks of WB_BOXCOM_ROWS rows.  A chunk starts from the TRUE state of the three sums (verified by the
@@ -898,6 +867,6 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     out[2] = sy;
     WB_END_SINGLE
     WB_BSTAMP(a.ctl, 4);
-    }   // boxes of this contour
+    }   // the queue
     WB_BSTAMP_FLUSH(a.ctl);
 }
