@@ -760,19 +760,13 @@ WB_KERNEL(wb_k_event_offsets, WbEvFillArgs a) {
     else a.ctl->NE = (int)NE;
     WB_END_SINGLE
 }
-WB_KERNEL(wb_k_fill_events, WbEvFillArgs a, WbStreamerArgs st) {
+WB_KERNEL(wb_k_fill_events, WbEvFillArgs a) {
     const int s = WB_BLOCK_ID;
     const int nsel = a.ctl->nsel;
     if (a.ctl->NE == 0) return;
     const int NS = a.ctl->NS, NO = a.ctl->NO;
     if (s < nsel) {
         if (a.ev_n) {
-            // check_groups, exact ties (streamer_index.py:241-246 in CPython set order): rare, rewrites the end points first
-            if (st.tie_m[s] >= 2) {
-                WB_SINGLE
-                wb_streamer_resolve_ties(st, s);
-                WB_END_SINGLE
-            }
             WB_PFOR(e, a.ev_n[s])
                 const int row = a.sbase[s] + (int)e;
                 int* d = a.ev + (size_t)row * 8;
@@ -851,9 +845,11 @@ WB_KERNEL(wb_k_pack_rows, const WbCtl* ctl, const int* ev, const double* sums, c
     }
 }
 
-// event polygons: vertices of every event, back to back
+// event polygons: vertices of every event, back to back -- written straight into the batch's PINNED host arrays (the
+// device reaches them over PCIe; until round 4 the vertices went to device arrays first and two copy operations of 6.7 MB
+// each brought them over), and, for a time-sharded run's gather, into device arrays as well
 WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const long long* poff, const int* c_off, const uint32_t* cpts,
-          int* out_x, int* out_y) {
+          int* out_x, int* out_y, int* dev_x, int* dev_y) {
     if (ctl->overflow & 2) return;
     const int nev = ctl->NE;
     for (int e = WB_BLOCK_ID; e < nev; e += WB_GRID_DIM) {
@@ -867,6 +863,54 @@ WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const l
             const uint32_t v = wb_event_vertex(d, pts, (int)k);
             dx[k] = wb_pt_x(v);
             dy[k] = wb_pt_y(v);
+            if (dev_x) { dev_x[poff[e] + k] = wb_pt_x(v); dev_y[poff[e] + k] = wb_pt_y(v); }
+        WB_END_PFOR
+    }
+}
+
+// the event tables of a pass -> ONE pinned host block, written by the device: control block first (the pass's counters,
+// capacity flags included), then descriptors, polygon offsets, the five sums, cell counts, flags (and cell offsets).  One
+// launch where seven copy operations used to follow two read-backs of the control block.
+struct WbResultBlock {
+    WbCtl* ctl; int* ev; long long* poff; double* sums; int* ncells; int* flags; long long* cell_off;
+};
+static size_t wb_result_block_bytes(size_t cap_ne, bool cells) {
+    const size_t n = cap_ne + 1;
+    return 512 + n * (8 * sizeof(int) + sizeof(long long) + 5 * sizeof(double) + 2 * sizeof(int) + (cells ? sizeof(long long) : 0)) + 64;
+}
+static WbResultBlock wb_result_block(void* base, size_t cap_ne, bool cells) {
+    const size_t n = cap_ne + 1;
+    WbResultBlock r;
+    char* q = (char*)base;
+    r.ctl = (WbCtl*)q; q += 512;                      // (sizeof(WbCtl) <= 512, checked below)
+    r.sums = (double*)q; q += n * 5 * sizeof(double);
+    r.poff = (long long*)q; q += n * sizeof(long long);
+    r.cell_off = cells ? (long long*)q : nullptr; q += cells ? n * sizeof(long long) : 0;
+    r.ev = (int*)q; q += n * 8 * sizeof(int);
+    r.ncells = (int*)q; q += n * sizeof(int);
+    r.flags = (int*)q;
+    return r;
+}
+static_assert(sizeof(WbCtl) <= 512, "the result block reserves 512 bytes for the control block");
+WB_KERNEL(wb_k_pack_results, const WbCtl* ctl, const int* ev, const long long* poff, const double* sums, const int* ncells,
+          const int* flags, const long long* cell_off, WbResultBlock out) {
+    const int nev = (ctl->overflow & 1) ? 0 : ctl->NE;
+    if (WB_BLOCK_ID == 0) {
+        WB_PFOR(w, sizeof(WbCtl) / 4)
+            ((uint32_t*)out.ctl)[w] = ((const uint32_t*)ctl)[w];
+        WB_END_PFOR
+    }
+    for (int e0 = WB_BLOCK_ID * 256; e0 <= nev; e0 += WB_GRID_DIM * 256) {
+        WB_PFOR(k, 256)
+            const int e = e0 + (int)k;
+            if (e <= nev) out.poff[e] = poff[e];
+            if (e < nev) {
+                for (int q = 0; q < 8; ++q) out.ev[(size_t)e * 8 + q] = ev[(size_t)e * 8 + q];
+                for (int q = 0; q < 5; ++q) out.sums[(size_t)e * 5 + q] = sums[(size_t)e * 5 + q];
+                out.ncells[e] = ncells[e];
+                out.flags[e] = flags[e];
+                if (out.cell_off) out.cell_off[e] = cell_off[e];
+            }
         WB_END_PFOR
     }
 }
@@ -1004,8 +1048,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     const int J = b->njobs, cap = b->cap_seg;
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     wb_ctx::Tables* T = make_tables(b);
-    WbCtl* hc = host_ctl(ctx);
-    if (!T || !hc) return wb_fail(ctx, "out of memory (tables)");
+    if (!T) return wb_fail(ctx, "out of memory (tables)");
     const WbCtl& h1 = b->h_ctl;                 // phase-1 summary
     // bounds: the selected contours are those with nux == gmax; with gmax equal to this batch's maximum they are counted
     // exactly by the phase-1 summary, with a larger one (another rank holds the full-span contour) there are none
@@ -1217,10 +1260,12 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
                 b->timer.begin(ctx, "streamer_f34");
                 WB_LAUNCH(wb_k_streamer_f34, nsel_b, 256, st);
+                WB_LAUNCH(wb_k_streamer_ties, 1, 64, st);
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
                 WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + 64, st);
+                WB_LAUNCH(wb_k_streamer_ties, 1, 64, st);      // one wave: check_groups' exact ties (nearly always none)
                 b->timer.end(ctx);
             }
         }
@@ -1237,8 +1282,6 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         fa.ev = (int*)talloc((size_t)(cap_ne + 1) * 8 * sizeof(int));
         fa.plen = (int*)talloc((size_t)(cap_ne + 1) * sizeof(int));
         fa.poff = (long long*)talloc((size_t)(cap_ne + 1) * sizeof(long long));
-        int* d_px = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
-        int* d_py = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
         WbPropsArgs pa;
         memset(&pa, 0, sizeof(pa));
         // one wave per event slot, fed from the event queue; 4096 slots (4 waves per SIMD) for a year-sized batch, fewer for a
@@ -1257,93 +1300,89 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         pa.ev_cell_off = (long long*)talloc((size_t)(cap_ne + 1) * sizeof(long long));
         pa.cell_cap = cell_cap;
         pa.cell_pool = cell_cap ? (uint32_t*)talloc(cell_cap * sizeof(uint32_t)) : nullptr;
-        if (!d_py || !fa.poff || !pa.ev_flags || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
+        if (!fa.poff || !pa.ev_flags || !pa.ev_cell_off || !pa.rowacc || !pa.cells || (cell_cap && !pa.cell_pool)) { release(); return 1; }
         b->timer.begin(ctx, "fill_events");
         WB_LAUNCH(wb_k_event_offsets, 1, WB_LIST_THREADS, fa);
-        if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa, st);
+        if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa);
         WB_LAUNCH(wb_k_poly_offsets, 1, WB_LIST_THREADS, fa);
         b->timer.end(ctx);
-        // descriptors are complete: vertices + the first control-block snapshot on the side stream, properties on the main one
+        // descriptors are complete: the vertices go out on the side stream (straight into the batch's pinned host arrays,
+        // sized for the capacity -- the counts are only known on the device), properties on the main one; then ONE kernel
+        // writes the control block and the event tables into a pinned host block, and the host waits ONCE
+        size_t got = 0;
+        b->poly_x = (int32_t*)hmalloc(ctx, (size_t)(cap_poly + 1) * sizeof(int32_t), &b->poly_bytes);
+        b->poly_y = (int32_t*)hmalloc(ctx, (size_t)(cap_poly + 1) * sizeof(int32_t), &b->poly_bytes);
+        void* hblock = hmalloc(ctx, wb_result_block_bytes((size_t)cap_ne, p.want_cells != 0), &got);
+        if (hblock) b->hres.push_back({hblock, got});
+        if (!hblock || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
+        const WbResultBlock rb = wb_result_block(hblock, (size_t)cap_ne, p.want_cells != 0);
+        int *d_px = nullptr, *d_py = nullptr;
+        if (ctx->keep_device) {                                // device copies of the vertices for the gather
+            d_px = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
+            d_py = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
+            if (!d_py) { release(); return 1; }
+        }
         side_begin(ctx);
         b->timer.begin(ctx, "polygons");
-        WB_LAUNCH(wb_k_pack_polys, 2048, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, d_px, d_py);
+        WB_LAUNCH(wb_k_pack_polys, ctx->polys_grid, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, b->poly_x, b->poly_y, d_px, d_py);
         b->timer.end(ctx);
-        d2h_async(ctx, &hc[0], ctl, sizeof(WbCtl));
         side_end(ctx);
         b->timer.begin(ctx, "props");
         WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
         b->timer.end(ctx);
-        d2h_async(ctx, &hc[1], ctl, sizeof(WbCtl));              // second snapshot: property kernel's counters
-        if (side_sync(ctx)) { release(); return wb_fail(ctx, "HIP error on the side stream"); }
-        const WbCtl s1 = hc[0];
-        bool again = false;
-        if (do_st && s1.max_pairs > cap_pairs) { cap_pairs = next_pow2((long long)s1.max_pairs + s1.max_pairs / 8); again = true; }
-        if (do_st && s1.n_recheck > 65536) { p2_off = true; again = true; }    // more guard-band pairs than the recheck list holds: tiled kernel
-        if (s1.overflow & 1) { cap_ne = next_pow2((long long)s1.ne_demand + s1.ne_demand / 4); again = true; }
-        if (s1.overflow & 2) { cap_poly = s1.poly_total + s1.poly_total / 8 + 1024; again = true; }
-        if (again) {
-            if (dsync(ctx)) { release(); return 1; }
-            release();
-            if (attempt == 5) return wb_fail(ctx, "capacity overflow in the index phase");
-            if (p.want_cells) cell_cap = (unsigned long long)cap_ne * 1024ull;
-            continue;
-        }
-        const int NE = s1.NE;
-        const long long NV = s1.poly_total;
-        // result copies: vertices and descriptors on the side stream (the property kernel is still running), sums after it
-        size_t got = 0;
-        auto hbuf = [&](size_t bytes) -> void* { void* q = hmalloc(ctx, bytes ? bytes : 8, &got); if (q) b->hres.push_back({q, got}); return q; };
-        h_ev = (int*)hbuf((size_t)(NE + 1) * 8 * sizeof(int));
-        h_poff = (long long*)hbuf((size_t)(NE + 1) * sizeof(long long));
-        h_sums = (double*)hbuf((size_t)(NE + 1) * 5 * sizeof(double));
-        h_nc = (int*)hbuf((size_t)(NE + 1) * sizeof(int));
-        h_fl = (int*)hbuf((size_t)(NE + 1) * sizeof(int));
-        h_coff = p.want_cells ? (long long*)hbuf((size_t)(NE + 1) * sizeof(long long)) : nullptr;
-        b->poly_n = (size_t)NV;
-        b->poly_x = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
-        b->poly_y = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
-        if (!h_ev || !h_poff || !h_sums || !h_nc || !h_fl || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
-        wb_swap_streams(ctx);
-        b->timer.begin(ctx, "polygons_d2h");
-        d2h_async(ctx, h_ev, fa.ev, (size_t)NE * 8 * sizeof(int));
-        d2h_async(ctx, h_poff, fa.poff, (size_t)(NE + 1) * sizeof(long long));
-        d2h_async(ctx, b->poly_x, d_px, (size_t)NV * sizeof(int));
-        d2h_async(ctx, b->poly_y, d_py, (size_t)NV * sizeof(int));
-        b->timer.end(ctx);
-        wb_swap_streams(ctx);
-        b->timer.begin(ctx, "events_d2h");
-        d2h_async(ctx, h_sums, pa.ev_sums, (size_t)NE * 5 * sizeof(double));
-        d2h_async(ctx, h_nc, pa.ev_ncells, (size_t)NE * sizeof(int));
-        d2h_async(ctx, h_fl, pa.ev_flags, (size_t)NE * sizeof(int));
-        if (p.want_cells) d2h_async(ctx, h_coff, pa.ev_cell_off, (size_t)NE * sizeof(long long));
+        b->timer.begin(ctx, "results");
+        WB_LAUNCH(wb_k_pack_results, cap_ne < 64 * 256 ? (cap_ne + 255) / 256 + 1 : 64, 256, ctl, fa.ev, fa.poff, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
+                  pa.ev_cell_off, rb);
         b->timer.end(ctx);
         if (ctx->keep_device) {
-            // device copies for the gather: rows packed here, vertex arrays taken out of this attempt's scratch
-            if (b->dev_rows) { bfree_one(b, b->dev_rows); bfree_one(b, b->dev_px); bfree_one(b, b->dev_py); }
-            b->dev_rows = balloc<double>(b, (size_t)(NE + 1) * WB_ROW_WIDTH);
+            // device rows for the gather, packed here; the vertex arrays are taken out of this attempt's scratch
+            if (b->dev_rows) { bfree_one(b, b->dev_rows); bfree_one(b, b->dev_px); bfree_one(b, b->dev_py); b->dev_rows = nullptr; }
+            b->dev_rows = balloc<double>(b, (size_t)(cap_ne + 1) * WB_ROW_WIDTH);
             if (!b->dev_rows) { release(); return 1; }
             if (!b->job_level.empty() && !b->d_job_level) b->d_job_level = upload(b, b->job_level);
-            WB_LAUNCH(wb_k_pack_rows, NE < 256 * 1024 ? (NE + 255) / 256 + 1 : 1024, 256, ctl, fa.ev, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
+            WB_LAUNCH(wb_k_pack_rows, cap_ne < 256 * 1024 ? (cap_ne + 255) / 256 + 1 : 1024, 256, ctl, fa.ev, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
                       fa.poff, b->d_job_step, b->d_job_level, p.nlevels, b->step_offset, b->dev_rows);
+        }
+        side_join(ctx);
+        if (dsync(ctx) || side_sync(ctx)) { release(); return 1; }
+        fin = *rb.ctl;
+        bool again = false;
+        if (do_st && fin.max_pairs > cap_pairs) { cap_pairs = next_pow2((long long)fin.max_pairs + fin.max_pairs / 8); again = true; }
+        if (do_st && fin.n_recheck > 65536) { p2_off = true; again = true; }    // more guard-band pairs than the recheck list holds: tiled kernel
+        if (fin.overflow & 1) { cap_ne = next_pow2((long long)fin.ne_demand + fin.ne_demand / 4); again = true; }
+        if (fin.overflow & 2) { cap_poly = fin.poly_total + fin.poly_total / 8 + 1024; again = true; }
+        const bool other = again;
+        if (p.want_cells && !again && fin.cell_count > cell_cap) { cell_cap = fin.cell_count + 1024; again = true; }   // cell pool too small: again with the exact size
+        if (again) {
+            hfree(ctx, b->poly_x, b->poly_bytes);
+            hfree(ctx, b->poly_y, b->poly_bytes);
+            b->poly_x = b->poly_y = nullptr;
+            for (auto& hb : b->hres) hfree(ctx, hb.first, hb.second);
+            b->hres.clear();
+            if (ctx->keep_device && b->dev_rows) { bfree_one(b, b->dev_rows); b->dev_rows = nullptr; }
+            release();
+            if (attempt == 5) return wb_fail(ctx, "capacity overflow in the index phase");
+            if (p.want_cells && other) cell_cap = (unsigned long long)cap_ne * 1024ull;
+            continue;
+        }
+        const int NE = fin.NE;
+        const long long NV = fin.poly_total;
+        b->poly_n = (size_t)NV;
+        h_ev = rb.ev; h_poff = rb.poff; h_sums = rb.sums; h_nc = rb.ncells; h_fl = rb.flags; h_coff = rb.cell_off;
+        if (ctx->keep_device) {
             b->dev_px = d_px; b->dev_py = d_py;
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == (void*)d_px) { tmp.erase(tmp.begin() + i); break; }
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == (void*)d_py) { tmp.erase(tmp.begin() + i); break; }
             b->dev_nv = NV;
         }
-        if (dsync(ctx) || side_sync(ctx)) { release(); return 1; }
-        fin = hc[1];
         if (p.want_cells) {
-            if (fin.cell_count > cell_cap) {                    // cell pool too small: the phase again with the exact size
-                cell_cap = fin.cell_count + 1024;
-                release();
-                if (attempt == 5) return wb_fail(ctx, "cell pool overflow");
-                continue;
-            }
+            auto hbuf = [&](size_t bytes) -> void* { void* q = hmalloc(ctx, bytes ? bytes : 8, &got); if (q) b->hres.push_back({q, got}); return q; };
             h_cells = (uint32_t*)hbuf((size_t)(fin.cell_count + 1) * sizeof(uint32_t));
             if (!h_cells) { release(); return wb_fail(ctx, "out of host memory"); }
             d2h_async(ctx, h_cells, pa.cell_pool, (size_t)fin.cell_count * sizeof(uint32_t));
             if (dsync(ctx)) { release(); return 1; }
         }
+        (void)NE;
         release();
         break;
     }
@@ -1695,6 +1734,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }
     if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }
     if (!strcmp(name, "timers")) { ctx->timers = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     ctx->err = std::string("wb_set_option: unknown option ") + name;

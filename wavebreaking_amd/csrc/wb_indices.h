@@ -1046,7 +1046,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
             if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
         // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
-        // set's iteration order -- resolved by wb_streamer_resolve_ties (wb_k_fill_events) after this kernel (rare; kept out of this kernel's
+        // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
         // registers); here the lowest such member stands in and the contour is marked
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
@@ -1435,7 +1435,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             if (gval[m] == best[lab[m]]) wb_atomic_min(&best[M + lab[m]], (unsigned long long)m);
         WB_END_PFOR
         // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
-        // set's iteration order -- resolved by wb_streamer_resolve_ties (wb_k_fill_events) after this kernel (rare; kept out of this kernel's
+        // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
         // registers); here the lowest such member stands in and the contour is marked
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
@@ -1471,8 +1471,8 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
 // lengths of the selected contours -> packed point offsets, work items of the all-pairs kernel
 // check_groups, exact ties (after wb_k_streamer_f234 / f34): for the contours marked there, the survivor of every group whose
 // largest length is shared by several members becomes the member that comes first in the reference's CPython set
-// (wb_group_tie_winner), and the event's end points are rewritten.  Called by one lane of the marked contour's workgroup in
-// wb_k_fill_events, before the contour's events are laid out (a kernel of its own cost a launch per pass for nearly always nothing).
+// (wb_group_tie_winner), and the event's end points are rewritten.  ONE wave looks through the marks (nearly always none;
+// as a grid over the contours the launch queued behind the other batch's kernels for its 46 workgroups).
 WB_DEV inline void wb_streamer_resolve_ties(const WbStreamerArgs& a, int s) {
     const int M = a.tie_m[s];
     if (M < 2) return;
@@ -1500,6 +1500,11 @@ WB_DEV inline void wb_streamer_resolve_ties(const WbStreamerArgs& a, int s) {
         const int w = wb_group_tie_winner(lab, M, g, pts, mi, mj, gval, best[g], best + 3 * (size_t)M, (long long)a.hash_size - 3LL * M);
         if (w >= 0 && aux[g] < a.cap_ev) { ev[2 * aux[g] + 0] = mi[w]; ev[2 * aux[g] + 1] = mj[w]; }
     }
+}
+
+WB_KERNEL(wb_k_streamer_ties, WbStreamerArgs a) {
+    const int nsel = a.ctl->nsel;
+    for (int s = WB_BLOCK_ID * WB_NT + WB_TID; s < nsel; s += WB_GRID_DIM * WB_NT) wb_streamer_resolve_ties(a, s);
 }
 
 WB_KERNEL(wb_k_sel_scan, WbStreamerArgs a, int* tmp) {
