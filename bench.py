@@ -126,15 +126,10 @@ def main():
         gather_path = "torch.distributed"
         if os.environ.get("WB_BENCH_GATHER", "library") == "library" and dist.get_backend() == "nccl":
             try:
-                libcomm = wd.LibraryComm(ctx, dist)
-                gather_path = "library (wb_comm_gather_tables: ncclAllGather of the counts + grouped ncclSend / ncclRecv)"
-            except Exception as e:                      # every rank fails alike (no librccl): all take the torch path
+                libcomm = wd.LibraryComm(ctx, dist)         # (the ranks agree inside whether RCCL is usable: all succeed or all raise)
+                gather_path = "library (wb_comm_stage_tables + wb_comm_gather_staged on a gather thread: ncclAllGather of the counts + grouped ncclSend / ncclRecv)"
+            except Exception as e:
                 print("[bench] wb_comm_init failed (%s); exchanges through torch.distributed" % e, file=sys.stderr, flush=True)
-                libcomm = None
-            ok = torch.tensor([1 if libcomm is not None else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # one rank without it: nobody uses it
-            if int(ok.item()) == 0 and libcomm is not None:
-                libcomm.close()
                 libcomm, gather_path = None, "torch.distributed"
 
     def barrier():
@@ -182,21 +177,16 @@ def main():
                            free=1e3 * (time.perf_counter() - w3))
         return res
 
-    def collect_pass(keep):
+    def collect_pass(keep, gatherer=None):
         def collect(k, res):
             w = time.perf_counter()
             if multi:
-                # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there)
-                if libcomm is not None:
-                    cat = libcomm.gather(res["batch"], dst=0)
-                else:
-                    cat = wd.gather_device_tables(res["batch"], dist, dst=0, as_rows=True)   # (rows, poly_x, poly_y) on rank 0's host
+                # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there).
+                # Off the critical path: the batch's tables are STAGED (a device-to-device copy of a few MB), the batch is
+                # released, and the gather thread runs the collective while the next batches are computed
+                gatherer.submit(k, res["batch"])
                 pipe.close_batch(k, res["batch"])          # a context is single-threaded: its own worker frees the batch
                 res["batch"] = None
-                if keep and cat is not None:
-                    counts["gathered_events"] = int(cat[0].shape[0])
-                    counts["gathered_polygon_vertices"] = int(cat[1].size)
-                    assert int(cat[0][:, 18].sum()) == cat[1].size == cat[2].size
             if keep:
                 for name, ms in res["timings"]:
                     stage_ms.setdefault(name, []).append(ms)
@@ -206,6 +196,25 @@ def main():
                 wall.setdefault("gather", []).append(1e3 * (time.perf_counter() - w))
             return res
         return collect
+
+    def gathered(k, cat):
+        """on the gather thread, when batch k's catalogue stands in rank 0's pinned buffers"""
+        if cat is None:
+            return None
+        assert int(cat[0][:, 18].sum()) == cat[1].size == cat[2].size
+        return int(cat[0].shape[0]), int(cat[1].size)
+
+    def run_record(n, keep):
+        """n passes as ONE record: every batch selected against the full width of the extended grid at once, the ONE
+        all-reduce(max) that verifies it after the last batch (streamer_index.py:106: the maximum over the whole frame), the
+        gathers of a multi-GPU run on their own thread"""
+        gatherer = wd.TableGatherer(dist, comm=libcomm, dst=0, on_result=gathered) if multi else None
+        got = []
+        # (one order of collectives on every rank: the record's gathers -- the gather thread's -- and then its all-reduce)
+        pipe.run_record(n, phase1, reduce_max, phase2, collect_pass(keep, gatherer), full_w,
+                        before_reduce=(lambda: got.extend(gatherer.finish())) if gatherer is not None else None)
+        if keep and multi and rank == 0 and got:
+            counts["gathered_events"], counts["gathered_polygon_vertices"] = got[-1]
 
     def solo_pass(c, copy=False):
         """a single pass alone on the device"""
@@ -230,11 +239,12 @@ def main():
     solo_scan_ms = dict(solo["timings"]).get("scan", float("nan"))
     # every pass must select against the full width of the periodically extended grid, as one call over the record would
     full_w = lon.size + int(120.0 / a.dlon)                    # periodic_add = 120, the default of the calls above
-    full_w = full_w if solo["gmax"] == full_w else None
-    pipe.run(a.warmup, phase1, reduce_max, phase2, collect_pass(False), full_width=full_w)
+    if solo["gmax"] != full_w:
+        raise SystemExit("bench.py: the synthetic record holds no contour of the full width %d (largest: %d)" % (full_w, solo["gmax"]))
+    run_record(a.warmup, False)
     barrier()
     tic = time.perf_counter()
-    pipe.run(a.steps, phase1, reduce_max, phase2, collect_pass(True), full_width=full_w)
+    run_record(a.steps, True)                 # (returns when the last gather of the record has landed on rank 0)
     barrier()
     dt = time.perf_counter() - tic
     # the same passes with the phases staggered (one batch's scan + trace kernels beside the other's index kernels, never

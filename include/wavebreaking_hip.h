@@ -192,12 +192,21 @@ void wb_free_batch(wb_batch* b);
    rank without time steps) arrives on rank dst -- counts by one ncclAllGather, payload by grouped ncclSend / ncclRecv of the
    exact sizes -- in rank (= time) order: rows[nrows][WB_ROW_WIDTH], poly_x / poly_y[nverts], pinned host memory of the
    context, valid until its next call; the other ranks get nrows = nverts = 0.  ranks_seen (may be NULL) <- the number of
-   ranks whose counts arrived.  librccl is looked up at run time; without it wb_comm_init fails and nothing else changes. */
+   ranks whose (rank, counts) triple arrived in its own place (fewer than the group's size is an error).
+   wb_comm_stage_tables + wb_comm_gather_staged: the same exchange off the critical path -- stage copies the batch's tables
+   (device to device) into slot 0 <= slot < WB_COMM_SLOTS of the communicator, after which the batch may be freed;
+   gather_staged gathers a staged slot and frees it, and may run on ANOTHER host thread while the caller's thread goes on
+   with the next batches (every rank must gather its slots in the same order).
+   librccl is looked up at run time; without it wb_comm_init fails and nothing else changes. */
 #define WB_COMM_ID_BYTES 128
 int wb_comm_unique_id(wb_ctx* ctx, void* id /* [WB_COMM_ID_BYTES] */);
 int wb_comm_init(wb_ctx* ctx, const void* id, int rank, int world);
 int wb_comm_allreduce_max(wb_ctx* ctx, int* value);
 int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
+                          const int32_t** poly_y, int64_t* nverts, int* ranks_seen);
+#define WB_COMM_SLOTS 4
+int wb_comm_stage_tables(wb_ctx* ctx, wb_batch* b, int slot);
+int wb_comm_gather_staged(wb_ctx* ctx, int slot, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
                           const int32_t** poly_y, int64_t* nverts, int* ranks_seen);
 void wb_comm_destroy(wb_ctx* ctx);
 

@@ -257,3 +257,135 @@ def test_three_ranks_one_without_steps_gather_complete_catalogue(tmp_path):
         total += ev["step"].size
     assert total > 10
     b.close()
+
+
+WORKER_RECORD = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+from wavebreaking_amd import distributed as wd
+from wavebreaking_amd.pipeline import BatchPipeline, FullWidthNotReached
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+NT, PER = 8, 2                           # three ranks: two own four steps each = two batches of two, the third owns none
+lat, lon = synth.grid(2.5)
+full_w = lon.size + int(120 / 2.5)
+first, count = (rank * 4, 4) if rank < 2 else (0, 0)
+pv = synth.pv_field(first, max(count, 1), lat, lon, eps=0.2)
+if rank == 1:
+    pv[2:4] = 0.0                        # rank 1's second batch holds no contour at all: it does NOT reach the full width
+pipe = BatchPipeline(0, depth=2, library=helpers.hostsim_library())
+for c in pipe.contexts:
+    c.set_option("keep_device", 1)
+nb = 2
+
+def phase1(c, k):
+    return c.contours(pv[k * PER:(k + 1) * PER], lat, lon, [-2.0, 2.0], 2.5, 2.5, intensity=pv[k * PER:(k + 1) * PER])
+
+def phase2(c, k, b, g):
+    b.set_step_offset(first + k * PER)
+    b.indices(g)
+    return b
+
+reduces = []
+def reduce_max(m):
+    reduces.append(m)
+    return wd.global_max_nux(m, dist)
+
+cats = {}
+def gathered(k, cat):
+    if cat is not None:
+        cats[k] = tuple(np.array(a) for a in cat)       # (the buffers are reused by the next gather)
+    return k
+
+def record(field_ok):
+    g = wd.TableGatherer(dist, comm=None, dst=0, on_result=gathered)
+    done = []
+    def collect(k, b):
+        g.submit(k, b)
+        pipe.close_batch(k, b)
+    if count:
+        pipe.run_record(nb, phase1, reduce_max, phase2, collect, full_w, before_reduce=lambda: done.extend(g.finish()))
+    else:                                # a rank without time steps: the same collectives in the same order, nothing of its own
+        for k in range(nb):
+            g.submit(k, None)
+        done.extend(g.finish())
+        if reduce_max(0) != full_w:
+            raise FullWidthNotReached("nothing")
+    return done
+
+done = record(True)
+assert done == [0, 1] and len(reduces) == 1                    # ONE exchange of the maximum for the whole record
+if rank == 0:
+    rows = np.concatenate([cats[k][0] for k in (0, 1)])
+    px = np.concatenate([cats[k][1] for k in (0, 1)])
+    py = np.concatenate([cats[k][2] for k in (0, 1)])
+    np.savez(sys.argv[2], rows=rows, px=px, py=py)
+# a record in which NO contour spans the extended grid: every rank learns so from the one exchange
+pv[:, :, :12] = 0.0
+try:
+    record(False)
+    raised = False
+except FullWidthNotReached:
+    raised = True
+assert raised
+pipe.close()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_path):
+    """what bench.py --gpus N runs: every batch selected against the full width at once (BatchPipeline.run_record), ONE
+    all-reduce(max) per record that verifies it, every batch's tables staged and gathered by a thread of their own
+    (distributed.TableGatherer) -- three ranks over gloo, one without time steps, one batch without any contour; rank 0's
+    catalogue equals the single-process catalogue of the whole record"""
+    helpers.build_hostsim()
+    script = tmp_path / "worker_record.py"
+    script.write_text(WORKER_RECORD)
+    out = tmp_path / "rank0.npz"
+    port = _free_port()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env))
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:                                   # (a rank stuck in a collective must not outlive the test)
+            if p.poll() is None:
+                p.kill()
+    got = np.load(out)
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(0, 8, lat, lon, eps=0.2)
+    pv[6:8] = 0.0
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 2.5, 2.5, intensity=pv)
+    assert b.max_nux() == lon.size + 48
+    b.indices()
+    # the gathered rows come batch by batch (rank order inside a batch): time order = a stable sort by step inside each index
+    rows, px, py = got["rows"], got["px"], got["py"]
+    npoly = rows[:, 18].astype(np.int64)
+    start = np.cumsum(npoly) - npoly
+    total = 0
+    for kind in (0, 1, 2):
+        ev = b.events(kind)
+        m = np.nonzero(rows[:, 16] == kind)[0]
+        m = m[np.argsort(rows[m, 0], kind="stable")]
+        assert np.array_equal(rows[m, 0].astype(np.int32), ev["step"]), kind
+        assert np.array_equal(rows[m, 1].astype(np.int32), ev["level_idx"])
+        assert np.array_equal(rows[m, 10:15], ev["sums"])
+        assert np.array_equal(rows[m, 5:9].astype(np.int32), ev["box"])
+        gx = np.concatenate([px[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
+        gy = np.concatenate([py[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
+        assert np.array_equal(gx, ev["poly_x"]) and np.array_equal(gy, ev["poly_y"])
+        total += m.size
+    assert total == rows.shape[0] > 20
+    b.close()
+    ctx.close()

@@ -55,6 +55,7 @@ class WbGeometry(C.Structure):
 STREAMERS, OVERTURNINGS, CUTOFFS = 0, 1, 2
 EVENT_NOT_SIMPLE = 1
 ROW_WIDTH = 20
+COMM_SLOTS = 4
 STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS, STATUS_LEVEL_ORDER = 1, 2, 4, 8, 16, 32
 STATUS_LEVEL_KEYERROR, STATUS_LEVEL_WALKED = 64, 128
 
@@ -132,6 +133,10 @@ class Library:
         lib.wb_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         lib.wb_comm_allreduce_max.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.wb_comm_gather_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64),
+                                             C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int)]
+        lib.wb_comm_stage_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.wb_comm_gather_staged.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64),
                                              C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64),
                                              C.POINTER(C.c_int)]
         lib.wb_comm_destroy.argtypes = [C.c_void_p]
@@ -440,6 +445,22 @@ class Context:
         if self.L.lib.wb_comm_gather_tables(self.h, batch.h if batch is not None else None, int(dst), C.byref(rows), C.byref(n),
                                             C.byref(px), C.byref(py), C.byref(nv), C.byref(seen)) != 0:
             raise RuntimeError("wb_comm_gather_tables failed: " + self.error())
+        r = _arr(rows, n.value * ROW_WIDTH, np.float64, copy=False).reshape(-1, ROW_WIDTH)
+        return r, _arr(px, nv.value, np.int32, copy=False), _arr(py, nv.value, np.int32, copy=False), int(seen.value)
+
+    def comm_stage_tables(self, batch, slot):
+        """copy the batch's device tables (None: an empty shard) into slot ``slot`` (< COMM_SLOTS) of the communicator; the
+        batch may be closed when this returns"""
+        if self.L.lib.wb_comm_stage_tables(self.h, batch.h if batch is not None else None, int(slot)) != 0:
+            raise RuntimeError("wb_comm_stage_tables failed: " + self.error())
+
+    def comm_gather_staged(self, slot, dst=0):
+        """comm_gather_tables for the tables staged in ``slot``; may run on another thread than the one driving the batches"""
+        rows, px, py = C.POINTER(C.c_double)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        n, nv, seen = C.c_int64(), C.c_int64(), C.c_int()
+        if self.L.lib.wb_comm_gather_staged(self.h, int(slot), int(dst), C.byref(rows), C.byref(n), C.byref(px), C.byref(py),
+                                            C.byref(nv), C.byref(seen)) != 0:
+            raise RuntimeError("wb_comm_gather_staged failed: " + self.error())
         r = _arr(rows, n.value * ROW_WIDTH, np.float64, copy=False).reshape(-1, ROW_WIDTH)
         return r, _arr(px, nv.value, np.int32, copy=False), _arr(py, nv.value, np.int32, copy=False), int(seen.value)
 

@@ -2150,6 +2150,10 @@ extern "C" int wb_comm_allreduce_max(wb_ctx* ctx, int*) { return wb_fail(ctx, "t
 extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch*, int, const double**, int64_t*, const int32_t**, const int32_t**, int64_t*, int*) {
     return wb_fail(ctx, "the host simulation has no RCCL");
 }
+extern "C" int wb_comm_stage_tables(wb_ctx* ctx, wb_batch*, int) { return wb_fail(ctx, "the host simulation has no RCCL"); }
+extern "C" int wb_comm_gather_staged(wb_ctx* ctx, int, int, const double**, int64_t*, const int32_t**, const int32_t**, int64_t*, int*) {
+    return wb_fail(ctx, "the host simulation has no RCCL");
+}
 extern "C" void wb_comm_destroy(wb_ctx*) {}
 #else
 #define WB_NCCL(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) return wb_fail(ctx, std::string(#call) + ": " + cm.GetErrorString(r_)); } while (0)
@@ -2168,6 +2172,34 @@ extern "C" int wb_comm_unique_id(wb_ctx* ctx, void* id) {
     return 0;
 }
 
+static void wb_comm_release(wb_ctx* ctx) {
+    if (!ctx || !ctx->comm) return;
+    WbComm& cm = *ctx->comm;
+    (void)hipSetDevice(ctx->device);
+    if (cm.stream) (void)hipStreamSynchronize(cm.stream);
+    if (cm.copy_stream) (void)hipStreamSynchronize(cm.copy_stream);
+    if (cm.comm && cm.CommDestroy) (void)cm.CommDestroy(cm.comm);
+    void* dev[] = {cm.d_counts, cm.d_scalar, cm.d_rows, cm.d_px, cm.d_py};
+    for (void* q : dev) if (q) (void)hipFree(q);
+    for (auto& sl : cm.slot) { if (sl.rows) (void)hipFree(sl.rows); if (sl.px) (void)hipFree(sl.px); if (sl.py) (void)hipFree(sl.py); }
+    void* host[] = {cm.h_counts, cm.h_scalar, cm.h_rows, cm.h_px, cm.h_py};
+    for (void* q : host) if (q) (void)hipHostFree(q);
+    if (cm.stream) (void)hipStreamDestroy(cm.stream);
+    if (cm.copy_stream) (void)hipStreamDestroy(cm.copy_stream);
+    delete ctx->comm;                       // (the RCCL library stays loaded: it may be the host program's)
+    ctx->comm = nullptr;
+}
+
+static int wb_comm_init_buffers(wb_ctx* ctx, WbComm& cm, int world) {
+    WB_HIPC(hipStreamCreateWithFlags(&cm.stream, hipStreamNonBlocking));
+    WB_HIPC(hipStreamCreateWithFlags(&cm.copy_stream, hipStreamNonBlocking));
+    WB_HIPC(hipMalloc((void**)&cm.d_counts, (size_t)(3 + 3 * world) * sizeof(long long)));
+    WB_HIPC(hipHostMalloc((void**)&cm.h_counts, (size_t)(3 * world + 3) * sizeof(long long), hipHostMallocDefault));
+    WB_HIPC(hipMalloc((void**)&cm.d_scalar, 2 * sizeof(int)));
+    WB_HIPC(hipHostMalloc((void**)&cm.h_scalar, 2 * sizeof(int), hipHostMallocDefault));
+    return 0;
+}
+
 extern "C" int wb_comm_init(wb_ctx* ctx, const void* id, int rank, int world) {
     if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return 1;
     wb_use(ctx);
@@ -2180,28 +2212,15 @@ extern "C" int wb_comm_init(wb_ctx* ctx, const void* id, int rank, int world) {
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     WB_NCCL(cm.CommInitRank(&cm.comm, world, u, rank));
     cm.rank = rank; cm.world = world;
-    WB_HIPC(hipStreamCreateWithFlags(&cm.stream, hipStreamNonBlocking));
-    WB_HIPC(hipMalloc((void**)&cm.d_counts, (size_t)(2 + 2 * world) * sizeof(long long)));
-    WB_HIPC(hipHostMalloc((void**)&cm.h_counts, (size_t)(2 * world + 2) * sizeof(long long), hipHostMallocDefault));
-    WB_HIPC(hipMalloc((void**)&cm.d_scalar, 2 * sizeof(int)));
-    WB_HIPC(hipHostMalloc((void**)&cm.h_scalar, 2 * sizeof(int), hipHostMallocDefault));
+    if (wb_comm_init_buffers(ctx, cm, world)) {          // a partial set-up is undone: the call can be repeated
+        const std::string why = ctx->err;
+        wb_comm_release(ctx);
+        return wb_fail(ctx, "wb_comm_init: " + why);
+    }
     return 0;
 }
 
-extern "C" void wb_comm_destroy(wb_ctx* ctx) {
-    if (!ctx || !ctx->comm) return;
-    WbComm& cm = *ctx->comm;
-    (void)hipSetDevice(ctx->device);
-    if (cm.stream) (void)hipStreamSynchronize(cm.stream);
-    if (cm.comm && cm.CommDestroy) (void)cm.CommDestroy(cm.comm);
-    void* dev[] = {cm.d_counts, cm.d_scalar, cm.d_rows, cm.d_px, cm.d_py};
-    for (void* q : dev) if (q) (void)hipFree(q);
-    void* host[] = {cm.h_counts, cm.h_scalar, cm.h_rows, cm.h_px, cm.h_py};
-    for (void* q : host) if (q) (void)hipHostFree(q);
-    if (cm.stream) (void)hipStreamDestroy(cm.stream);
-    delete ctx->comm;                       // (the RCCL library stays loaded: it may be the host program's)
-    ctx->comm = nullptr;
-}
+extern "C" void wb_comm_destroy(wb_ctx* ctx) { wb_comm_release(ctx); }
 
 extern "C" int wb_comm_allreduce_max(wb_ctx* ctx, int* value) {
     if (!ctx || !value) return 1;
@@ -2217,50 +2236,59 @@ extern "C" int wb_comm_allreduce_max(wb_ctx* ctx, int* value) {
     return 0;
 }
 
-extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
-                                     const int32_t** poly_y, int64_t* nverts, int* ranks_seen) {
-    if (!ctx || !rows || !nrows || !poly_x || !poly_y || !nverts) return 1;
-    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_gather_tables: wb_comm_init first");
-    WbComm& cm = *ctx->comm;
-    if (dst < 0 || dst >= cm.world) return wb_fail(ctx, "wb_comm_gather_tables: bad destination rank");
-    if (b && !b->dev_rows) return wb_fail(ctx, "wb_comm_gather_tables: set the context option keep_device before wb_indices");
-    wb_use(ctx);
+// inside an open ncclGroupStart: a failing call closes the group before the error is reported
+#define WB_NCCL_G(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (void)cm.GroupEnd(); return wb_fail(ctx, std::string(#call) + ": " + cm.GetErrorString(r_)); } } while (0)
+
+// exchange (2) for tables that lie in device memory at src_*: counts, payload, the one copy to the host on dst
+static int wb_comm_gather_core(wb_ctx* ctx, WbComm& cm, const double* src_rows, const int32_t* src_px, const int32_t* src_py, long long ne,
+                               long long nv, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x, const int32_t** poly_y,
+                               int64_t* nverts, int* ranks_seen) {
     const int W = cm.world;
-    const long long ne = b ? b->dev_n[0] + b->dev_n[1] + b->dev_n[2] : 0, nv = b ? b->dev_nv : 0;
-    // (1) counts: one all-gather of (events, vertices)
-    cm.h_counts[2 * W] = ne; cm.h_counts[2 * W + 1] = nv;
-    WB_HIPC(hipMemcpyAsync(cm.d_counts, cm.h_counts + 2 * W, 2 * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
-    WB_NCCL(cm.AllGather(cm.d_counts, cm.d_counts + 2, 2, ncclInt64, cm.comm, cm.stream));
-    WB_HIPC(hipMemcpyAsync(cm.h_counts, cm.d_counts + 2, (size_t)2 * W * sizeof(long long), hipMemcpyDeviceToHost, cm.stream));
+    // (1) counts: one all-gather of (rank + 1, events, vertices); the landing area is poisoned first, so a rank whose triple
+    //     did not arrive -- or arrived in another rank's place -- is seen
+    for (int q = 0; q < 3 * W; ++q) cm.h_counts[q] = -1;
+    cm.h_counts[3 * W] = cm.rank + 1; cm.h_counts[3 * W + 1] = ne; cm.h_counts[3 * W + 2] = nv;
+    WB_HIPC(hipMemcpyAsync(cm.d_counts + 3, cm.h_counts, (size_t)3 * W * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
+    WB_HIPC(hipMemcpyAsync(cm.d_counts, cm.h_counts + 3 * W, 3 * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
+    WB_NCCL(cm.AllGather(cm.d_counts, cm.d_counts + 3, 3, ncclInt64, cm.comm, cm.stream));
+    WB_HIPC(hipMemcpyAsync(cm.h_counts, cm.d_counts + 3, (size_t)3 * W * sizeof(long long), hipMemcpyDeviceToHost, cm.stream));
     WB_HIPC(hipStreamSynchronize(cm.stream));
     long long tot_e = 0, tot_v = 0;
     int seen = 0;
-    for (int r = 0; r < W; ++r) { tot_e += cm.h_counts[2 * r]; tot_v += cm.h_counts[2 * r + 1]; seen += cm.h_counts[2 * r] >= 0 ? 1 : 0; }
+    for (int r = 0; r < W; ++r) {
+        if (cm.h_counts[3 * r] == r + 1 && cm.h_counts[3 * r + 1] >= 0 && cm.h_counts[3 * r + 2] >= 0) ++seen;
+        tot_e += cm.h_counts[3 * r + 1]; tot_v += cm.h_counts[3 * r + 2];
+    }
     if (ranks_seen) *ranks_seen = seen;
-    if (cm.h_counts[2 * cm.rank] != ne || cm.h_counts[2 * cm.rank + 1] != nv) return wb_fail(ctx, "wb_comm_gather_tables: the all-gather returned another count for this rank");
+    if (seen != W) return wb_fail(ctx, "wb_comm_gather_tables: the all-gather of the counts returned " + std::to_string(seen) + " of " + std::to_string(W) + " ranks in place");
+    if (cm.h_counts[3 * cm.rank + 1] != ne || cm.h_counts[3 * cm.rank + 2] != nv) return wb_fail(ctx, "wb_comm_gather_tables: the all-gather returned another count for this rank");
     *rows = nullptr; *poly_x = *poly_y = nullptr; *nrows = 0; *nverts = 0;
     if (cm.rank == dst) {
         // room for the whole catalogue, on the device and in pinned host memory: grown when needed, kept between passes
         if ((size_t)tot_e > cm.cap_rows) {
             if (cm.d_rows) (void)hipFree(cm.d_rows);
+            cm.d_rows = nullptr;
             cm.cap_rows = (size_t)tot_e + (size_t)tot_e / 4 + 1024;
             WB_HIPC(hipMalloc((void**)&cm.d_rows, cm.cap_rows * WB_ROW_WIDTH * sizeof(double)));
         }
         if ((size_t)tot_v > cm.cap_v) {
             if (cm.d_px) (void)hipFree(cm.d_px);
             if (cm.d_py) (void)hipFree(cm.d_py);
+            cm.d_px = cm.d_py = nullptr;
             cm.cap_v = (size_t)tot_v + (size_t)tot_v / 4 + 4096;
             WB_HIPC(hipMalloc((void**)&cm.d_px, cm.cap_v * sizeof(int32_t)));
             WB_HIPC(hipMalloc((void**)&cm.d_py, cm.cap_v * sizeof(int32_t)));
         }
         if ((size_t)tot_e > cm.hcap_rows) {
             if (cm.h_rows) (void)hipHostFree(cm.h_rows);
+            cm.h_rows = nullptr;
             cm.hcap_rows = (size_t)tot_e + (size_t)tot_e / 4 + 1024;
             WB_HIPC(hipHostMalloc((void**)&cm.h_rows, cm.hcap_rows * WB_ROW_WIDTH * sizeof(double), hipHostMallocDefault));
         }
         if ((size_t)tot_v > cm.hcap_v) {
             if (cm.h_px) (void)hipHostFree(cm.h_px);
             if (cm.h_py) (void)hipHostFree(cm.h_py);
+            cm.h_px = cm.h_py = nullptr;
             cm.hcap_v = (size_t)tot_v + (size_t)tot_v / 4 + 4096;
             WB_HIPC(hipHostMalloc((void**)&cm.h_px, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
             WB_HIPC(hipHostMalloc((void**)&cm.h_py, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
@@ -2271,25 +2299,25 @@ extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const do
     if (cm.rank == dst) {
         long long oe = 0, ov = 0;
         for (int r = 0; r < W; ++r) {
-            const long long ke = cm.h_counts[2 * r], kv = cm.h_counts[2 * r + 1];
+            const long long ke = cm.h_counts[3 * r + 1], kv = cm.h_counts[3 * r + 2];
             if (r != dst) {
-                if (ke) WB_NCCL(cm.Recv(cm.d_rows + (size_t)oe * WB_ROW_WIDTH, (size_t)ke * WB_ROW_WIDTH, ncclDouble, r, cm.comm, cm.stream));
-                if (kv) { WB_NCCL(cm.Recv(cm.d_px + ov, (size_t)kv, ncclInt32, r, cm.comm, cm.stream)); WB_NCCL(cm.Recv(cm.d_py + ov, (size_t)kv, ncclInt32, r, cm.comm, cm.stream)); }
+                if (ke) WB_NCCL_G(cm.Recv(cm.d_rows + (size_t)oe * WB_ROW_WIDTH, (size_t)ke * WB_ROW_WIDTH, ncclDouble, r, cm.comm, cm.stream));
+                if (kv) { WB_NCCL_G(cm.Recv(cm.d_px + ov, (size_t)kv, ncclInt32, r, cm.comm, cm.stream)); WB_NCCL_G(cm.Recv(cm.d_py + ov, (size_t)kv, ncclInt32, r, cm.comm, cm.stream)); }
             }
             oe += ke; ov += kv;
         }
     } else {
-        if (ne) WB_NCCL(cm.Send(b->dev_rows, (size_t)ne * WB_ROW_WIDTH, ncclDouble, dst, cm.comm, cm.stream));
-        if (nv) { WB_NCCL(cm.Send(b->dev_px, (size_t)nv, ncclInt32, dst, cm.comm, cm.stream)); WB_NCCL(cm.Send(b->dev_py, (size_t)nv, ncclInt32, dst, cm.comm, cm.stream)); }
+        if (ne) WB_NCCL_G(cm.Send(src_rows, (size_t)ne * WB_ROW_WIDTH, ncclDouble, dst, cm.comm, cm.stream));
+        if (nv) { WB_NCCL_G(cm.Send(src_px, (size_t)nv, ncclInt32, dst, cm.comm, cm.stream)); WB_NCCL_G(cm.Send(src_py, (size_t)nv, ncclInt32, dst, cm.comm, cm.stream)); }
     }
     WB_NCCL(cm.GroupEnd());
     if (cm.rank == dst) {
         long long oe = 0, ov = 0;
-        for (int r = 0; r < dst; ++r) { oe += cm.h_counts[2 * r]; ov += cm.h_counts[2 * r + 1]; }
-        if (ne) WB_HIPC(hipMemcpyAsync(cm.d_rows + (size_t)oe * WB_ROW_WIDTH, b->dev_rows, (size_t)ne * WB_ROW_WIDTH * sizeof(double), hipMemcpyDeviceToDevice, cm.stream));
+        for (int r = 0; r < dst; ++r) { oe += cm.h_counts[3 * r + 1]; ov += cm.h_counts[3 * r + 2]; }
+        if (ne) WB_HIPC(hipMemcpyAsync(cm.d_rows + (size_t)oe * WB_ROW_WIDTH, src_rows, (size_t)ne * WB_ROW_WIDTH * sizeof(double), hipMemcpyDeviceToDevice, cm.stream));
         if (nv) {
-            WB_HIPC(hipMemcpyAsync(cm.d_px + ov, b->dev_px, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.stream));
-            WB_HIPC(hipMemcpyAsync(cm.d_py + ov, b->dev_py, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.stream));
+            WB_HIPC(hipMemcpyAsync(cm.d_px + ov, src_px, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.stream));
+            WB_HIPC(hipMemcpyAsync(cm.d_py + ov, src_py, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.stream));
         }
         // the one copy to the host
         if (tot_e) WB_HIPC(hipMemcpyAsync(cm.h_rows, cm.d_rows, (size_t)tot_e * WB_ROW_WIDTH * sizeof(double), hipMemcpyDeviceToHost, cm.stream));
@@ -2302,6 +2330,71 @@ extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const do
     if (cm.rank == dst) { *rows = cm.h_rows; *poly_x = cm.h_px; *poly_y = cm.h_py; *nrows = tot_e; *nverts = tot_v; }
     return 0;
 }
+
+extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
+                                     const int32_t** poly_y, int64_t* nverts, int* ranks_seen) {
+    if (!ctx || !rows || !nrows || !poly_x || !poly_y || !nverts) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_gather_tables: wb_comm_init first");
+    WbComm& cm = *ctx->comm;
+    if (dst < 0 || dst >= cm.world) return wb_fail(ctx, "wb_comm_gather_tables: bad destination rank");
+    if (b && !b->dev_rows) return wb_fail(ctx, "wb_comm_gather_tables: set the context option keep_device before wb_indices");
+    wb_use(ctx);
+    const long long ne = b ? b->dev_n[0] + b->dev_n[1] + b->dev_n[2] : 0, nv = b ? b->dev_nv : 0;
+    return wb_comm_gather_core(ctx, cm, b ? b->dev_rows : nullptr, b ? b->dev_px : nullptr, b ? b->dev_py : nullptr, ne, nv, dst, rows, nrows,
+                               poly_x, poly_y, nverts, ranks_seen);
+}
+
+// The tables of batch b (NULL: none) copied into slot `slot` of the communicator; when the call returns the batch may be freed.
+extern "C" int wb_comm_stage_tables(wb_ctx* ctx, wb_batch* b, int slot) {
+    if (!ctx) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_stage_tables: wb_comm_init first");
+    if (slot < 0 || slot >= WB_COMM_SLOTS) return wb_fail(ctx, "wb_comm_stage_tables: bad slot");
+    if (b && !b->dev_rows) return wb_fail(ctx, "wb_comm_stage_tables: set the context option keep_device before wb_indices");
+    WbComm& cm = *ctx->comm;
+    WbComm::Slot& sl = cm.slot[slot];
+    if (sl.full) return wb_fail(ctx, "wb_comm_stage_tables: the slot still holds tables that were not gathered");
+    wb_use(ctx);
+    const long long ne = b ? b->dev_n[0] + b->dev_n[1] + b->dev_n[2] : 0, nv = b ? b->dev_nv : 0;
+    if ((size_t)ne > sl.cap_rows) {
+        if (sl.rows) (void)hipFree(sl.rows);
+        sl.rows = nullptr;
+        sl.cap_rows = (size_t)ne + (size_t)ne / 4 + 1024;
+        WB_HIPC(hipMalloc((void**)&sl.rows, sl.cap_rows * WB_ROW_WIDTH * sizeof(double)));
+    }
+    if ((size_t)nv > sl.cap_v) {
+        if (sl.px) (void)hipFree(sl.px);
+        if (sl.py) (void)hipFree(sl.py);
+        sl.px = sl.py = nullptr;
+        sl.cap_v = (size_t)nv + (size_t)nv / 4 + 4096;
+        WB_HIPC(hipMalloc((void**)&sl.px, sl.cap_v * sizeof(int32_t)));
+        WB_HIPC(hipMalloc((void**)&sl.py, sl.cap_v * sizeof(int32_t)));
+    }
+    if (ne) WB_HIPC(hipMemcpyAsync(sl.rows, b->dev_rows, (size_t)ne * WB_ROW_WIDTH * sizeof(double), hipMemcpyDeviceToDevice, cm.copy_stream));
+    if (nv) {
+        WB_HIPC(hipMemcpyAsync(sl.px, b->dev_px, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.copy_stream));
+        WB_HIPC(hipMemcpyAsync(sl.py, b->dev_py, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToDevice, cm.copy_stream));
+    }
+    WB_HIPC(hipStreamSynchronize(cm.copy_stream));
+    sl.ne = ne; sl.nv = nv; sl.full = true;
+    return 0;
+}
+
+// wb_comm_gather_tables for the tables staged in `slot`; may be called from another host thread than the one that drives the
+// context's batches (it touches the communicator's own streams and buffers only).  The slot is free again afterwards.
+extern "C" int wb_comm_gather_staged(wb_ctx* ctx, int slot, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
+                                     const int32_t** poly_y, int64_t* nverts, int* ranks_seen) {
+    if (!ctx || !rows || !nrows || !poly_x || !poly_y || !nverts) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_gather_staged: wb_comm_init first");
+    WbComm& cm = *ctx->comm;
+    if (slot < 0 || slot >= WB_COMM_SLOTS || !cm.slot[slot].full) return wb_fail(ctx, "wb_comm_gather_staged: nothing staged in this slot");
+    if (dst < 0 || dst >= cm.world) return wb_fail(ctx, "wb_comm_gather_staged: bad destination rank");
+    (void)hipSetDevice(ctx->device);
+    WbComm::Slot& sl = cm.slot[slot];
+    const int rc = wb_comm_gather_core(ctx, cm, sl.rows, sl.px, sl.py, sl.ne, sl.nv, dst, rows, nrows, poly_x, poly_y, nverts, ranks_seen);
+    sl.full = false;
+    return rc;
+}
+#undef WB_NCCL_G
 #undef WB_NCCL
 #undef WB_HIPC
 #endif

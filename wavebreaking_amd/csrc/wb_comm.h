@@ -8,6 +8,10 @@
 //                               "keep_device") to rank dst: the counts by one ncclAllGather, the payload by grouped
 //                               ncclSend / ncclRecv of the exact sizes into device buffers of dst that persist between
 //                               passes, one copy from there into pinned host buffers that persist too.
+//       wb_comm_stage_tables + wb_comm_gather_staged: the same exchange off the caller's critical path -- the batch's
+//                               tables are copied (device to device, a few MB) into one of WB_COMM_SLOTS buffers the
+//                               communicator owns, the batch can be released at once, and the gather of the staged slot
+//                               may run on another host thread while the next batches are computed.
 // RCCL is looked up at run time (dlopen; the copy a host program such as PyTorch already loaded is preferred): the library
 // neither links librccl nor needs it for single-GPU use.  Everything runs on a stream of its own (non-blocking: the NULL
 // stream would order it against every kernel the process has queued).
@@ -32,9 +36,13 @@ struct WbComm {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    hipStream_t copy_stream = nullptr;  // wb_comm_stage_tables (the caller's thread); `stream` may be driven by another thread
+    // staged tables of batches that have been released (wb_comm_stage_tables)
+    struct Slot { double* rows = nullptr; size_t cap_rows = 0; int32_t *px = nullptr, *py = nullptr; size_t cap_v = 0; long long ne = 0, nv = 0; bool full = false; };
+    Slot slot[WB_COMM_SLOTS];
     // persistent buffers: counts (device + pinned), the catalogue on dst (device + pinned)
-    long long* d_counts = nullptr;      // [2 + 2 * world]: mine, then everybody's
-    long long* h_counts = nullptr;      // pinned [2 * world]
+    long long* d_counts = nullptr;      // [3 + 3 * world]: (rank + 1, events, vertices) of this rank, then everybody's
+    long long* h_counts = nullptr;      // pinned [3 * world + 3]
     int* d_scalar = nullptr;
     int* h_scalar = nullptr;            // pinned
     double* d_rows = nullptr; size_t cap_rows = 0;          // rows of all ranks (dst only)

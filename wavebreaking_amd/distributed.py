@@ -195,6 +195,17 @@ def _pinned_host(name, shape, dtype):
     return t
 
 
+def _batch_tensors(batch, dist, single):
+    """(rows (ne, 20), vx, vy) of a batch's device tables as torch tensors -- zero-copy views of the library's buffers"""
+    if batch is None:
+        ptr, n3, px, py, nv, on_gpu = 0, (0, 0, 0), 0, 0, 0, (not single and dist.get_backend() == "nccl")
+    else:
+        ptr, n3, px, py, nv = batch.device_tables()
+        on_gpu = batch.ctx.L.backend == "hip"
+    ne = sum(n3)
+    return _wrap(ptr, (ne, 20), np.float64, on_gpu), _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+
+
 def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
     """exchange (2) without host staging: the packed event rows and polygon vertices that ``Batch.indices`` left on the
     device (context option "keep_device") travel device-to-device in one gather each (sizes first); ``dst`` copies every
@@ -205,24 +216,25 @@ def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
     Returns [streamers, overturnings, cutoffs] (the dictionaries of ``Batch.events``), or with ``as_rows`` the catalogue
     as it travelled: ``(rows (n, 20) float64, poly_x, poly_y)`` -- row k owns the next ``rows[k, 18]`` vertices, its index
     is ``rows[k, 16]`` (``rows_to_events`` converts; the arrays are views of the pinned buffers, valid until the next call)."""
-    import torch
     single = dist is None or not dist.is_initialized()      # an initialised group of ONE rank still takes the collective path
-    if batch is None:
-        ptr, n3, px, py, nv, on_gpu = 0, (0, 0, 0), 0, 0, 0, (not single and dist.get_backend() == "nccl")
-    else:
-        ptr, n3, px, py, nv = batch.device_tables()
-        on_gpu = batch.ctx.L.backend == "hip"
-    ne = sum(n3)
     done = (lambda r, x, y: (r, x, y)) if as_rows else rows_to_events
     if single:
-        rows = _wrap(ptr, (ne, 20), np.float64, on_gpu)
-        vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+        rows, vx, vy = _batch_tensors(batch, dist, True)
         return done(rows.cpu().numpy(), vx.cpu().numpy(), vy.cpu().numpy())
-    world, rank = dist.get_world_size(), dist.get_rank()
     dev = _device(dist)
     with _exchange_stream(dev):
-        rows = _wrap(ptr, (ne, 20), np.float64, on_gpu)
-        vx, vy = _wrap(px, (nv,), np.int32, on_gpu), _wrap(py, (nv,), np.int32, on_gpu)
+        rows, vx, vy = _batch_tensors(batch, dist, False)
+        out = _gather_tensors(rows, vx, vy, dist, dst, dev)
+    return None if out is None else done(*out)
+
+
+def _gather_tensors(rows, vx, vy, dist, dst, dev):
+    """the collective part of gather_device_tables on tensors that already exist (inside an _exchange_stream block);
+    (rows, vx, vy) numpy arrays on ``dst``, None elsewhere"""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ne, nv = int(rows.shape[0]), int(vx.shape[0])
+    if True:                                                # (one block: the tensors above are the caller's)
         if dev.type != "cuda":                              # dry runs of the N > 1 logic over gloo: CPU tensors
             rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
         counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
@@ -247,7 +259,7 @@ def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
         if dev.type != "cuda":
             rcat = torch.cat([rout[r][: int(allc[r, 0])] for r in range(world)]).numpy()
             vcat = torch.cat([vout[r][:, : int(allc[r, 1])] for r in range(world)], dim=1).numpy()
-            return done(rcat, vcat[0], vcat[1])
+            return rcat, vcat[0], vcat[1]
         # the one copy to the host: every rank's valid part straight into pinned memory
         hr = _pinned_host("rows", (max(tot_e, 1), 20), torch.float64)
         hx = _pinned_host("vx", (max(tot_v, 1),), torch.int32)
@@ -262,8 +274,77 @@ def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
                 hy[ov:ov + v].copy_(vout[r][1, :v], non_blocking=True)
             oe += k
             ov += v
+        torch.cuda.current_stream().synchronize()
     # rows are (streamers, overturnings, cutoffs) per rank, rank order = time order
-    return done(hr[:tot_e].numpy(), hx[:tot_v].numpy(), hy[:tot_v].numpy())
+    return hr[:tot_e].numpy(), hx[:tot_v].numpy(), hy[:tot_v].numpy()
+
+
+class TableGatherer:
+    """Exchange (2) off the critical path.  ``submit(k, batch)`` -- on the caller's thread, in batch order -- STAGES the
+    batch's device tables (a device-to-device copy of a few MB into a slot that outlives the batch: the batch can be closed
+    at once and its scratch goes back to the allocator) and hands the slot to ONE gather thread, which runs the collective
+    for slot after slot while the caller's thread and the workers go on with the next batches.  Every rank submits its
+    batches in the same order, so every rank's thread issues its collectives in the same order.  ``finish()`` waits for the
+    last gather and returns ``on_result``'s values in batch order.  ``comm``: a LibraryComm (RCCL inside the library) or
+    None for torch.distributed (``dist``).  ``on_result(k, (rows, poly_x, poly_y) or None)`` runs on the gather thread as
+    soon as batch k's catalogue stands in rank ``dst``'s pinned host buffers (views, valid until the next gather)."""
+
+    def __init__(self, dist, comm=None, dst=0, on_result=None, slots=None):
+        import queue
+        import threading
+        from wavebreaking_amd import _hip
+        self.dist, self.comm, self.dst = dist, comm, dst
+        self.on_result = on_result or (lambda k, cat: None)
+        self.nslots = int(slots or _hip.COMM_SLOTS)
+        self.free = threading.Semaphore(self.nslots)
+        self.q = queue.Queue()
+        self.results, self.error, self.next_slot = {}, None, 0
+        self.dev = _device(dist) if comm is None else None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def submit(self, k, batch):
+        if self.error is not None:
+            raise self.error
+        self.free.acquire()                                  # a slot the gather thread is done with (it may lag by nslots batches)
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % self.nslots
+        if self.comm is not None:
+            self.comm.ctx.comm_stage_tables(batch, slot)
+            item = slot
+        else:
+            with _exchange_stream(self.dev):                 # clones outlive the batch (leaving the block waits for the copies)
+                item = tuple(t.clone() for t in _batch_tensors(batch, self.dist, False))
+        self.q.put((k, item))
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            k, item = job
+            try:
+                if self.error is None:
+                    if self.comm is not None:
+                        rows, px, py, seen = self.comm.ctx.comm_gather_staged(item, self.dst)
+                        if seen != self.comm.world:
+                            raise RuntimeError("wb_comm_gather_staged saw %d ranks, the group has %d" % (seen, self.comm.world))
+                        cat = (rows, px, py) if self.comm.rank == self.dst else None
+                    else:
+                        with _exchange_stream(self.dev):
+                            cat = _gather_tensors(item[0], item[1], item[2], self.dist, self.dst, self.dev)
+                    self.results[k] = self.on_result(k, cat)
+            except BaseException as e:                       # kept for the caller; later slots are drained without collectives
+                self.error = e
+            finally:
+                self.free.release()
+
+    def finish(self):
+        self.q.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return [self.results[k] for k in sorted(self.results)]
 
 
 # ------------------------------------------------------------------------------------------------ RCCL inside the library
@@ -275,8 +356,24 @@ class LibraryComm:
     of the exact sizes into buffers that persist between passes, one copy into pinned host memory on ``dst``."""
 
     def __init__(self, ctx, dist):
+        import torch
         self.ctx, self.rank, self.world = ctx, dist.get_rank(), dist.get_world_size()
-        box = [ctx.comm_unique_id() if self.rank == 0 else None]
+        # every rank first finds out for itself whether it can use RCCL at all (making an id loads the library), and the
+        # ranks agree on that BEFORE any of them enters the collective set-up: a rank that cannot would leave the others
+        # waiting inside ncclCommInitRank -- or, if it is rank 0, inside the broadcast of the id
+        uid, why = None, ""
+        try:
+            uid = ctx.comm_unique_id()
+        except Exception as e:
+            why = str(e)
+        dev = _device(dist)
+        with _exchange_stream(dev):
+            ok = torch.tensor([1 if uid is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            ok = int(ok.item())
+        if not ok:
+            raise RuntimeError("RCCL is not usable on every rank" + (" (here: %s)" % why if why else ""))
+        box = [uid if self.rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         ctx.comm_init(box[0], self.rank, self.world)
 

@@ -1,9 +1,9 @@
 """Several batches in flight on one GPU.
 
-A context (``_hip.Context``) is one HIP stream driven synchronously by one host thread: between its kernels the host
-reads back counts and builds work lists, and most of its kernels are latency-bound per-(step, level) jobs with a tail.
-Two contexts on the same device, each fed by its own thread, fill those gaps with the other batch's kernels
-(measured on MI355X, 0.25 degree, 1460 steps per batch: 8.2 ms per batch alone, 6.5 ms with two in flight).
+A context (``_hip.Context``) is one HIP stream driven by one host thread, which waits for the device twice per batch (the
+summary of phase 1, the result tables of phase 2); most of its kernels are latency-bound per-(step, level) jobs with a
+tail.  Two contexts on the same device, each fed by its own thread, fill those waits and tails with the other batch's
+kernels (measured on MI355X, 0.25 degree, 1460 steps per batch: 5.6 ms per batch alone, 4.7 ms with two in flight).
 
 Selection maximum.  The reference selects contours with ``exp_lon == exp_lon.max()`` over the WHOLE frame it is given
 (streamer_index.py:106).  Here every batch is a frame of its own: batch ``k`` is selected against the maximum over
@@ -23,6 +23,10 @@ import threading
 from concurrent.futures import ThreadPoolExecutor
 
 from wavebreaking_amd import _hip
+
+
+class FullWidthNotReached(RuntimeError):
+    """BatchPipeline.run_record: the record holds no contour of the full width it was selected against"""
 
 
 class BatchPipeline:
@@ -56,6 +60,39 @@ class BatchPipeline:
     def close_batch(self, k, batch):
         """free batch k on the worker thread of its context (a context, including its allocator, belongs to one thread)"""
         return self._workers[k % self.depth].submit(batch.close)
+
+    def run_record(self, n, contours, reduce_max, indices, collect, full_width, before_reduce=None):
+        """``n`` batches of ONE record, selected against ``full_width`` WITHOUT waiting for an exchange: no contour can exceed
+        the width of the periodically extended grid, so if any batch of any rank holds a contour that spans it -- always, with
+        a circumglobal dynamical tropopause -- that IS ``contours.exp_lon.max()`` over the whole frame (streamer_index.py:106)
+        and every batch can go from phase 1 straight into phase 2 on its worker.  The assumption is verified by the ONE
+        ``reduce_max`` of the record -- the largest local maximum of this rank's batches, after the last batch -- and
+        ``FullWidthNotReached`` is raised if it fails (the caller then takes ``run``, which exchanges before every
+        selection).  ``collect(k, result)`` on the caller's thread in batch order, as in ``run``.  ``before_reduce()`` is
+        called after the last ``collect`` and before the exchange: a run whose gathers are issued by another thread
+        (distributed.TableGatherer) waits for them there -- every rank must issue its collectives in ONE order, all gathers of
+        the record, then the all-reduce."""
+        d = self.depth
+
+        def both(ctx, k):
+            b = contours(ctx, k)
+            return b.max_nux(), indices(ctx, k, b, full_width)
+        fut, out, local = {}, [], 0
+        for k in range(min(d, n)):
+            fut[k] = self._workers[k % d].submit(both, self.contexts[k % d], k)
+        for k in range(n):
+            m, r = fut.pop(k).result()
+            local = max(local, int(m))
+            if k + d < n:
+                fut[k + d] = self._workers[k % d].submit(both, self.contexts[k % d], k + d)
+            out.append(collect(k, r))
+        if before_reduce is not None:
+            before_reduce()
+        g = reduce_max(local)
+        if g != full_width:
+            raise FullWidthNotReached("no contour of this record spans the %d columns of the extended grid (largest: %d): the "
+                                      "selection maximum has to be exchanged before the index phase" % (full_width, g))
+        return out
 
     def run(self, n, contours, reduce_max, indices, collect, full_width=None):
         """``n`` batches.  Worker of context ``k % depth``:  ``b = contours(ctx, k)`` then, once the caller's thread has
