@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nt", type=int, default=int(os.environ.get("WB_BENCH_NT", 1460)), help="time steps per GPU per pass")
-    ap.add_argument("--dlon", type=float, default=0.25)
+    ap.add_argument("--dlon", type=float, default=None, help="grid spacing in degrees (default: 0.25, or what --config names)")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2),
+                    help="BASELINE.json configs[k]: 2 (default, the headline) 0.25 degree, levels [-2, 2], all three indices, intensity "
+                         "field; 1: 1.0 degree (360 x 181), level [2], the streamer index alone, no intensity field")
     ap.add_argument("--eps", type=float, default=0.0, help="cell noise amplitude (0 = smoothed PV, 0.3 = rough)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("WB_BENCH_CPU_SAMPLE", 24)),
                     help="time steps of the same workload timed on the CPU oracle (rank 0, N=1 only)")
@@ -105,9 +108,14 @@ def main():
         for kv in filter(None, os.environ.get("WB_BENCH_OPTS", "").split(",")):   # development: "name=value,..." context options (A/B runs)
             name, _, val = kv.partition("=")
             c.set_option(name.strip(), int(val))
+    if a.dlon is None:
+        a.dlon = 1.0 if a.config == 1 else 0.25
+    if a.config == 1:
+        a.no_intensity = True
+    which = dict(streamers=True, overturnings=a.config != 1, cutoffs=a.config != 1)
     lat, lon = synth.grid(a.dlon)
     nlat, nlon, nt = lat.size, lon.size, a.nt
-    levels = [-2.0, 2.0]
+    levels = [2.0] if a.config == 1 else [-2.0, 2.0]
     t0 = rank * nt
     par = synth.wave_params()
     fbytes = nt * nlat * nlon * 4
@@ -158,7 +166,7 @@ def main():
     def phase2(c, k, b, g, copy=False):
         w1 = time.perf_counter()
         b.set_step_offset(t0)
-        b.indices(g)
+        b.indices(g, **which)
         w2 = time.perf_counter()
         ev = [b.events(i, copy=copy) for i in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
         w3 = time.perf_counter()
@@ -300,17 +308,16 @@ def main():
         scan_ms = float(np.mean(stage_ms.get("scan", [float("nan")])))
         achieved = nt * bytes_per_ts / (scan_ms * 1e-3) / 1e9   # GB/s, live HIP-event duration of the scan kernel
         out = {
-            "metric": "timesteps/s (0.25deg global PV, contours + streamer/overturning/cutoff indices)",
+            "metric": "timesteps/s (%gdeg global PV, contours + %s)" % (a.dlon, "streamer/overturning/cutoff indices" if a.config != 1 else "streamer index"),
             "value": value, "unit": "timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "0.25deg global PV (1440x721 f32), %d 6-hourly steps per GPU, levels [-2,2], "
-                                   "streamers+overturnings+cutoffs, intensity field %s (BASELINE.json configs[2])"
-                                   % (nt, "off" if a.no_intensity else "on"),
+            "config": {"workload": "%gdeg global PV (%dx%d f32), %d 6-hourly steps per GPU, levels %s, %s, intensity field %s (BASELINE.json configs[%d])"
+                                   % (a.dlon, nlon, nlat, nt, levels, "+".join(k for k, v in which.items() if v), "off" if a.no_intensity else "on", a.config),
                        "nt_per_gpu": nt, "grid": [nlat, nlon], "levels": levels, "eps": a.eps,
                        "parallelism": "time-sharded x%d, %d batches in flight per GPU" % (world, pipe.depth)},
             "roofline": {"bound": "hbm", "kernel": "wb_k_scan_stream<float>" if a.scan_split else "wb_k_scan<float>", "achieved": achieved, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(nt),
+                         "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": pmc_traffic(nt) if (a.config == 2 and a.dlon == 0.25) else None,
                          "algorithmic_bytes_per_launch": nt * bytes_per_ts, "launch_ms": scan_ms,
                          # the same kernel with nothing else on the device (one pass before the warm-up); in the timed
                          # region it shares HBM with the other batch's kernels
@@ -331,10 +338,10 @@ def main():
             out.update(verify)
         if staggered is not None:
             out["staggered_phases"] = staggered
-        if world == 1 and a.e2e_steps > 0:
+        if world == 1 and a.e2e_steps > 0 and a.config == 2:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass)
+            out["cpu_baseline"] = cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, a.cpu_sample, one_pass, streamers_only=a.config == 1)
     if libcomm is not None:
         libcomm.close()
     pipe.close()
@@ -447,7 +454,7 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     return out
 
 
-def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
+def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass, streamers_only=False):
     """The oracle (kind 'port': numpy restatement of the reference, single thread) on a bounded sample of the
     SAME device-generated workload; the sampled steps' event counts must equal the GPU's."""
     from oracle import api as oapi
@@ -463,14 +470,17 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
         pv = ctx.to_host(d_pv, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4)
         it = ctx.to_host(d_int, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4) if d_int else None
         tic = time.perf_counter()
-        ref = oapi.run_all(pv, levels, lat, lon, synth.times(1), intensity=it)
+        if streamers_only:
+            ref = {"streamers": oapi.calculate_streamers(pv, levels, lat, lon, synth.times(1), intensity=it), "overturnings": [], "cutoffs": []}
+        else:
+            ref = oapi.run_all(pv, levels, lat, lon, synth.times(1), intensity=it)
         t_cpu += time.perf_counter() - tic
         for k, name in enumerate(("streamers", "overturnings", "cutoffs")):
             counts_ok &= int((ev[k]["step"] == t).sum()) == len(ref[name])
             _compare_step(ev[k], ref[name], t, levels, cmp)
     out = {"value": len(idx) / t_cpu, "unit": "timesteps/s", "cores": 1, "kind": "port",
-           "sample": "%d steps (%s ... %s) of the same device-generated batch, oracle.api.run_all (numpy, 1 thread), %.1f s"
-                     % (len(idx), idx[:3], idx[-2:], t_cpu), "event_counts_match_gpu": bool(counts_ok),
+           "sample": "%d steps (%s ... %s) of the same device-generated batch, oracle.api.%s (numpy, 1 thread), %.1f s"
+                     % (len(idx), idx[:3], idx[-2:], "calculate_streamers" if streamers_only else "run_all", t_cpu), "event_counts_match_gpu": bool(counts_ok),
            # the full tables of the sampled steps, GPU against oracle: level, polygon vertices, number of cells and the
            # truncated centre-of-mass indices bit for bit; area / mean_var / intensity sums to 1e-6 relative
            "tables_match_gpu": bool(counts_ok and cmp["mismatches"] == 0), "events_compared": cmp["events"],
@@ -492,7 +502,7 @@ def cpu_baseline(ctx, d_pv, d_int, lat, lon, levels, nt, nsample, one_pass):
         for t in steps:
             pv = ctx.to_host(d_pv, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4)
             it = ctx.to_host(d_int, (1, nlat, nlon), np.float32, offset_bytes=t * nlat * nlon * 4) if d_int else None
-            jobs.append((pv, it, levels, lat, lon))
+            jobs.append((pv, it, levels, lat, lon, streamers_only))
         with mp.get_context("spawn").Pool(nw) as pool:
             pool.map(_cpu_step, jobs[:nw])                      # imports / warm-up in every worker
             tic = time.perf_counter()
@@ -528,9 +538,11 @@ def _compare_step(table, rows, t, levels, cmp, rtol=1e-6):
 
 
 def _cpu_step(job):
-    pv, it, levels, lat, lon = job
+    pv, it, levels, lat, lon, streamers_only = job
     from oracle import api as oapi
     from oracle import synth
+    if streamers_only:
+        return len(oapi.calculate_streamers(pv, levels, lat, lon, synth.times(1), intensity=it))
     return len(oapi.run_all(pv, levels, lat, lon, synth.times(1), intensity=it)["streamers"])
 
 
