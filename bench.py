@@ -2,21 +2,32 @@
 """bench.py -- timesteps/s of the WaveBreaking hot path on synthetic ERA5-shaped 0.25 degree PV.
 
 One "step" = one pass of the whole hot path (contours of every (time step, level) + streamer,
-overturning and cutoff indices + event/contour tables back in host memory) over ONE resident batch of
-`--nt` synthetic time steps per GPU (default 1460 = one year 6-hourly, BASELINE.json configs[2]).
-Inputs are generated on the device and are resident in HBM when the timed region starts.
+overturning and cutoff indices + event tables back in host memory) over ONE resident batch of
+`--nt` synthetic time steps per GPU (default 1460 = one year 6-hourly, BASELINE.json configs[2]; `--config 1`:
+configs[1], 1.0 degree, level [2], the streamer index).  Inputs are generated on the device and are resident in
+HBM when the timed region starts.
+
+WHAT `value` IS: device-resident float32 field batch -> INDEX-SPACE event tables in host memory -- per event its
+step / level / contour, end points or box, orientation, the five area-weighted sums of calculate_properties
+(index_utils.py:66-102), cell count, flags, and the polygon vertices in grid indices.  NOT in `value`: the upload of
+the fields over PCIe (`end_to_end` measures the drop-in calls from a host cube, upload included), transform_polygons to
+lon / lat with the seam split (index_utils.py:129-184) and the last few flops of the property columns (:104-120) --
+host-side C++ / numpy, reported as `stage_ms.geometry_host` per pass -- and the construction of the (Geo)DataFrame.
+
 `--streams` passes (default 2) are in flight per GPU at any time, each on its own context = HIP stream +
-host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.
-(`--streams 3` gives a few % more timesteps/s but the scan kernel, which the roofline is quoted on, then
-shares HBM with two other batches; `--streams 1` runs the passes strictly one after the other.)
+host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.  The K passes are ONE
+record: every batch is selected against the full width of the periodically extended grid at once, and the ONE
+all-reduce(max) that verifies it (contours.exp_lon.max() over the whole frame, streamer_index.py:106) follows the last
+batch (BatchPipeline.run_record).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: time steps are sharded across ranks (weak scaling: every rank owns --nt steps of the synthetic
-40-year record, rank r starting at r*nt), one all-reduce(max) of the distinct-longitude count
-(contours.exp_lon.max() over the whole frame, streamer_index.py:106) and one gather of the event rows and
-polygon vertices to rank 0 over RCCL, device to device (wavebreaking_amd.distributed.gather_device_tables).
+40-year record, rank r starting at r*nt); the two exchanges of SURVEY 8e over RCCL: the one all-reduce(max) above and
+the gather of the event rows and polygon vertices to rank 0, device to device, batch by batch on a thread of its own
+(the tables are staged, the batch is released, wavebreaking_amd.distributed.TableGatherer): rank 0's copy of N x
+16.5 MB per pass to pinned host memory overlaps the next batches instead of ending the record with one serial tail.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -277,6 +288,26 @@ def main():
         staggered = {"value": nt * a.stagger_steps / dt_s, "ms_per_step": 1e3 * dt_s / a.stagger_steps, "steps": a.stagger_steps,
                      "scan_launch_ms": sc, "roofline_frac": nt * nlat * nlon * 4 / (sc * 1e-3) / HBM_PEAK,
                      "what": "BatchPipeline.set_stagger(1): each ABI phase entered by one batch at a time"}
+    # outside `value`, for the record: what transform_polygons (index_utils.py:129-184) and the frame's property columns
+    # (:104-120) cost per pass on the host -- one wb_get_event_geometry per index (the library's C++ seam split over the whole
+    # table) + properties_from_sums, timed on this thread after the timed region
+    geometry_host = None
+    if not multi:
+        from wavebreaking_amd.utils import index_utils as iu
+        b = phase1(ctx, 0)
+        b.indices(reduce_max(b.max_nux()), **which)
+        tic_g = time.perf_counter()
+        nrings = 0
+        for kind in (0, 1, 2):
+            ev_k = b.events(kind, copy=False)
+            if ev_k["step"].size:
+                ring_off, vert_off, gx, gy = b.event_geometry(kind)
+                nrings += int(vert_off.size) - 1
+                iu.properties_from_sums(ev_k["sums"], lon, lat, nlon)
+        geometry_host = {"ms": 1e3 * (time.perf_counter() - tic_g), "rings": nrings,
+                         "what": "wb_get_event_geometry (transform_polygons, index_utils.py:129-184) + properties_from_sums (:104-120) for the "
+                                 "three event tables of one pass, host only, outside `value`"}
+        b.close()
     verify = None
     if multi:
         cdev = device if dist.get_backend() == "nccl" else "cpu"
@@ -338,6 +369,13 @@ def main():
             out.update(verify)
         if staggered is not None:
             out["staggered_phases"] = staggered
+        if geometry_host is not None:
+            out["stage_ms"]["geometry_host"] = geometry_host["ms"]
+            out["geometry_host"] = geometry_host
+        out["value_is"] = ("device-resident f32 field batch -> index-space event tables of all requested indices in host memory (rows: step, "
+                           "level, contour, end points or box, orientation; the five area-weighted sums; cell counts; flags; polygon vertices "
+                           "in grid indices); NOT included: the upload of the fields (end_to_end has it), transform_polygons to lon / lat "
+                           "and the frame's property columns (stage_ms.geometry_host, host only), frame construction")
         if world == 1 and a.e2e_steps > 0 and a.config == 2:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:

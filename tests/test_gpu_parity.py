@@ -216,6 +216,26 @@ def test_order_dependent_joins_golden_fields(ctx, golden_dir):
     assert nequal == 48 and nflag == 54
 
 
+def test_link_merge_by_searches_equals_merge_by_row_tables(ctx):
+    """option link_rows = 0 (the binary-search merge of wb_k_trace_link: grids whose row tables do not fit its LDS) gives the
+    contour table of the row-table merge, at 0.25 degree and with a 360 degree periodic pad at 1 degree"""
+    for dlon, padd, nt in ((0.25, 120.0, 2), (1.0, 360.0, 3)):
+        lat, lon = synth.grid(dlon)
+        pv = synth.pv_field(7, nt, lat, lon, eps=0.3)
+        tabs = []
+        for rows in (1, 0):
+            ctx.set_option("link_rows", rows)
+            try:
+                b = ctx.contours(pv, lat, lon, [-2.0, 2.0], dlon, dlon, periodic_add=padd)
+                tabs.append(b.contour_table())
+                b.close()
+            finally:
+                ctx.set_option("link_rows", 1)
+        assert tabs[0]["step"].size > 10
+        for key in tabs[0]:
+            assert np.array_equal(tabs[0][key], tabs[1][key]), (dlon, key)
+
+
 def test_reference_own_code_fixture_through_the_abi(ctx, golden_dir):
     """the HIP path against outputs of the REFERENCE'S OWN statements (tests/golden/reference_rules.npz, made in the build
     container by tests/golden/make_golden_reference.py): contour tables (contour_index.py:105-155 on scikit-image's output),

@@ -266,6 +266,30 @@ def test_order_dependent_joins_golden_fields(sim, golden_dir):
     assert nequal == 48 and nflag == 54
 
 
+def test_link_merge_by_searches_equals_merge_by_row_tables(sim):
+    """wb_k_trace_link merges a job's strip lists through row tables in LDS; the binary-search merge (option link_rows = 0:
+    the path of grids whose tables do not fit) gives the same contours -- with NaN rows, a periodic pad of 360 degrees (as many
+    copy lists as base lists) and a rough field"""
+    lib, ctx = sim
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(3, 3, lat, lon, eps=0.4)
+    pv[:, [0, 1, -2, -1], :] = np.nan
+    for padd in (120.0, 360.0):
+        tabs = []
+        for rows in (1, 0):
+            ctx.set_option("link_rows", rows)
+            try:
+                b = ctx.contours(pv, lat, lon, [-2.0, 0.5, 2.0], 2.5, 2.5, periodic_add=padd)
+                tabs.append(b.contour_table())
+                b.close()
+            finally:
+                ctx.set_option("link_rows", 1)
+        assert tabs[0]["step"].size > 20
+        for key in tabs[0]:
+            assert np.array_equal(tabs[0][key], tabs[1][key]), (padd, key)
+    helpers.full_parity(ctx, pv[:, 2:-2], lat[2:-2], lon, synth.times(3), [-2, 2])
+
+
 def test_reference_own_code_fixture_through_the_abi(sim, golden_dir):
     """the contour table, the overturning boxes and the contour selection / cutoff filter against outputs of the reference's
     own statements (tests/golden/reference_rules.npz)"""

@@ -394,7 +394,11 @@ static int run_phase1(wb_batch* b) {
     ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
     ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.ctl = b->d_ctl;
     b->timer.begin(ctx, "trace_link");
-    WB_LAUNCH(wb_k_trace_link, J, WB_LINK_THREADS, ta);
+    {   // row tables in dynamic LDS when they fit (16-bit entries: a job of the LDS paths has at most 8192 segments)
+        const size_t tab = (size_t)(NS + 1) * nlat * sizeof(uint16_t) + 16;
+        ta.link_rows = (ctx->link_rows && tab <= (size_t)WB_LINK_ROWTAB_BYTES) ? 1 : 0;
+        WB_LAUNCH_LDS(wb_k_trace_link, J, WB_LINK_THREADS, ta.link_rows ? tab : 16, ta);
+    }
     b->timer.end(ctx);
     b->timer.begin(ctx, "trace_rank");
     WB_LAUNCH(wb_k_trace_rank, J, WB_RANK_THREADS, ta);
@@ -1738,6 +1742,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }
     if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }

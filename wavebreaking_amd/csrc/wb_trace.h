@@ -48,6 +48,7 @@ struct WbTraceArgs {
     uint32_t* status;        // [njobs]
     int* nseg;               // [njobs] merged segment count (-1: job skipped)
     int* p4;                 // [njobs][2] contours and raw points of a job the rank kernel has numbered itself (-1: finish does it)
+    int link_rows;           // wb_k_trace_link: 1 = its dynamic LDS holds the row tables ((nstrips + 1) * nlat 16-bit entries), 0 = merge by binary searches
     int slow_pass;           // 0: the ordinary launch (slow jobs are left out and counted in ctl->n_slow); 1: the slow jobs only
     WbCtl* ctl;              // batch counters (capacity checks, maxima)
 };
@@ -218,6 +219,9 @@ WB_DEV inline int wb_bits_for(int n) {   // bits that hold every value in [0, n)
 #ifndef WB_LINK_THREADS
 #define WB_LINK_THREADS 512
 #endif
+#ifndef WB_LINK_ROWTAB_BYTES
+#define WB_LINK_ROWTAB_BYTES (28 << 10)   // dynamic LDS of the link kernel's row tables at most (beside its 32 KiB of keys)
+#endif
 #ifndef WB_RANK_THREADS
 #define WB_RANK_THREADS 1024
 #endif
@@ -238,11 +242,20 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     uint32_t* succ = a.w[0] + jb;
     uint32_t* pred = a.w[1] + jb;
     uint32_t* t0 = a.w[8] + jb;
-    // keys in LDS: first those of all strips, strip after strip (the merge's binary searches), then -- the same 32 KiB --
-    // the merged list (the successor searches): two arrays at once kept the kernel at two workgroups per CU
+    // keys in LDS.  Row-table path (below): the merged list only.  Search path: first those of all strips, strip after strip
+    // (the merge's binary searches), then -- the same 32 KiB -- the merged list (the successor searches)
     WB_SHARED(uint32_t, ks, WB_TRACE_LDS_N);
     uint32_t* mk = ks;
     WB_SHARED(int, sbase, WB_MAX_LISTS + 1);
+    // row tables (dynamic LDS, a.link_rows > 0): rs[s * nrow1 + r] = first entry of strip list s whose square row is >= r, and
+    // behind the strips' tables the same for the merged list.  The lists are in raster order and strip s' lies left of strip s
+    // for s' < s (the periodic copies, columns >= nlon, come last), so the merged position of entry i of list s in row r is
+    // i + sum_{s' < s} rs[s'][r + 1] + sum_{s' > s} rs[s'][r] -- one independent LDS read per other list, where the search path
+    // makes a binary search per other list (seven searches of nine dependent reads each on the 0.25 degree grid: 70 % of this
+    // kernel's time until round 4); and a segment's successor is searched among the few entries of ONE row.
+    WB_DYN_SHARED_BEGIN
+    const int nrow1 = a.nlat;                      // rows of squares + 1
+    WB_DYN_SHARED(uint16_t, rs, a.link_rows > 0 ? (size_t)(a.nstrips + 1) * nrow1 : 1);
 
     // ---- P0: merge the sorted strip lists into one raster-ordered list: the rank of a segment is its
     //          position in its own list plus the number of smaller keys in every other list
@@ -269,14 +282,38 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         return;
     }
     const bool lds = n <= WB_TRACE_LDS_N;
-    WB_LSTAMP_BEGIN                              // development stamps: 0 strip bases, 1 keys to LDS, 2 merge + crossing points, 3 merged keys to LDS, 4 successors
+    const bool rows = lds && a.link_rows > 0;
+    WB_LSTAMP_BEGIN                              // development stamps: 0 strip bases, 1 keys to LDS / row tables, 2 merge + crossing points, 3 merged keys to LDS, 4 successors
     WB_SINGLE
     int run = 0;
     for (int s = 0; s < a.nstrips; ++s) { sbase[s] = run; run += a.stg_n[job * a.nstrips + s]; }
     sbase[a.nstrips] = run;
     WB_END_SINGLE
     WB_LSTAMP(a.ctl, 0);
-    if (lds) {
+    if (rows) {
+        // every table entry is written exactly once: entry i of a list opens the rows (row of entry i - 1, row of entry i]
+        WB_PFOR(g, n + a.nstrips)
+            if ((int)g < n) {
+                int s = 0;
+                while ((int)g >= sbase[s + 1]) ++s;
+                const int i = (int)g - sbase[s];
+                const uint32_t* lk = a.stg_k + ((size_t)job * a.nstrips + s) * a.cap_strip;
+                const int r = wb_key_sq(lk[i]) / W;
+                const int rp = i > 0 ? wb_key_sq(lk[i - 1]) / W : -1;
+                for (int q = rp + 1; q <= r; ++q) rs[s * nrow1 + q] = (uint16_t)i;
+            } else {                                   // ... and the rows behind a list's last entry (all of them for an empty list)
+                const int s = (int)g - n, c = sbase[s + 1] - sbase[s];
+                const uint32_t* lk = a.stg_k + ((size_t)job * a.nstrips + s) * a.cap_strip;
+                const int rl = c > 0 ? wb_key_sq(lk[c - 1]) / W : -1;
+                for (int q = rl + 1; q < nrow1; ++q) rs[s * nrow1 + q] = (uint16_t)c;
+            }
+        WB_END_PFOR
+        WB_PFOR(q, nrow1)                              // the merged list's table
+            int t = 0;
+            for (int s = 0; s < a.nstrips; ++s) t += rs[s * nrow1 + q];
+            rs[a.nstrips * nrow1 + q] = (uint16_t)t;
+        WB_END_PFOR
+    } else if (lds) {
         WB_PFOR(g, n)
             int s = 0;
             while ((int)g >= sbase[s + 1]) ++s;
@@ -301,7 +338,11 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
             ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
         }
         const uint32_t kk = key & 0x07FFFFFFu;
+        const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
         int dest = i;
+        if (rows) {
+            for (int s2 = 0; s2 < a.nstrips; ++s2) dest += s2 < s ? rs[s2 * nrow1 + r + 1] : (s2 > s ? rs[s2 * nrow1 + r] : 0);
+        } else {
         for (int s2 = 0; s2 < a.nstrips; ++s2) {       // (these searches in lockstep, eight independent LDS reads per step, changed nothing: the phase waits for its global loads and scattered stores)
             if (s2 == s) continue;
             int lo = 0, hi = sbase[s2 + 1] - sbase[s2];
@@ -320,13 +361,14 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
             }
             dest += lo;
         }
+        }
         // crossing coordinates of the segment's two end points, rounded half-to-even (contour_index.py:111)
-        const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
         const double level = a.levels[job % a.nlev];
         // a corner that equals the level puts the crossing ON a grid vertex: joined by the vertex rule below; the
         // job is flagged for the caller's information
         if (ul == level || ur == level || ll == level || lr == level) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_HIT);
         segk[dest] = key;
+        if (rows) mk[dest] = key;                      // (ks holds no strip keys on this path: the merged list goes straight to LDS)
         const int sfrom = wb_seg_from(cs, sub), sto = wb_seg_to(cs, sub);
         segf[dest] = wb_crossing_point(sfrom, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sfrom, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
         segt[dest] = wb_crossing_point(sto, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sto, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
@@ -337,12 +379,13 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     WB_LSTAMP(a.ctl, 2);
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
     //          the edge this one ends on (binary search by square key in the merged list)
-    if (lds) {
+    if (lds && !rows) {
         WB_PFOR(i, n)
             mk[i] = segk[i];                     // (the strips' keys are done with)
         WB_END_PFOR
     }
     const uint32_t* keys = lds ? mk : segk;
+    const uint16_t* mrow = rs + (size_t)a.nstrips * nrow1;
     WB_LSTAMP(a.ctl, 3);
     WB_PFOR(i, n)
         const uint32_t k = keys[i];
@@ -364,13 +407,14 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
                 if (overwritten) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_LEVEL_ORDER);
             }
         } else if (rr >= 0 && rr < a.nlat - 1 && cc >= 0 && cc < W - 1) {
-            int lo = 0, hi = n;
+            int lo = rows ? (int)mrow[rr] : 0, hi = rows ? (int)mrow[rr + 1] : n;     // (the entries of ONE row, where the table is there)
+            const int rhi = hi;
             const int target = rr * W + cc;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (wb_key_sq(keys[mid]) < target) lo = mid + 1; else hi = mid;
             }
-            if (lo < n && wb_key_sq(keys[lo]) == target) {
+            if (lo < rhi && wb_key_sq(keys[lo]) == target) {
                 const int cs2 = wb_key_case(keys[lo]);
                 if (wb_seg_from(cs2, 0) == want) s = (uint32_t)lo;
                 else if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) s = (uint32_t)lo + 1;

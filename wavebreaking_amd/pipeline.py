@@ -39,6 +39,7 @@ class BatchPipeline:
             stagger = int(os.environ.get("WB_PIPE_STAGGER", "0"))
         stagger = int(stagger)                                   # 1: both phases exclusive, 2: phase 1 only, 3: phase 2 only
         self._locks = (threading.Lock() if stagger in (1, 2) else None, threading.Lock() if stagger in (1, 3) else None) if stagger else None
+        self.offset_start = os.environ.get("WB_PIPE_OFFSET_START", "1") != "0"
 
     def set_stagger(self, mode):
         """0: the batches' phases overlap freely (most timesteps/s); 1: each phase is entered by one batch at a time -- one
@@ -74,8 +75,17 @@ class BatchPipeline:
         the record, then the all-reduce."""
         d = self.depth
 
+        # the workers run free of each other; the FIRST batch of worker j waits until worker j - 1 has finished phase 1 of its
+        # first batch, so that the contexts start out of step -- one batch's HBM-bound scan beside the other's index kernels
+        # rather than beside its twin -- and, taking equally long per batch, stay so (option offset_start, default on)
+        started = [threading.Event() for _ in range(d)]
+
         def both(ctx, k):
+            if self.offset_start and 0 < k < d:
+                started[k - 1].wait()
             b = contours(ctx, k)
+            if k < d:
+                started[k].set()
             return b.max_nux(), indices(ctx, k, b, full_width)
         fut, out, local = {}, [], 0
         for k in range(min(d, n)):
