@@ -244,6 +244,7 @@ static int run_phase1(wb_batch* b) {
     sa.field = b->d_field;
     for (int l = 0; l < p.nlevels; ++l) sa.levels[l] = b->levels[l];
     sa.stg_k = b->stg_k; sa.stg_v = b->stg_v; sa.stg_n = b->stg_n; sa.status = b->status;
+    wb_scan_gate_enter(ctx);                       // (option scan_exclusive: behind the other contexts' scans, before the stage's first event)
     b->timer.begin(ctx, "scan");
 #if defined(WB_HOSTSIM)
     if (ctx->scan_split && nlat < 65536 && b->W <= 65536) {
@@ -362,6 +363,7 @@ static int run_phase1(wb_batch* b) {
 #undef WB_SCAN_N
             { const hipError_t le = hipGetLastError(); if (le != hipSuccess) return wb_fail(ctx, std::string("wb_k_scan_stream launch failed: ") + hipGetErrorString(le)); }
             b->timer.end(ctx);
+            wb_scan_gate_leave(ctx);
             b->timer.begin(ctx, "scan_build");
 #define WB_BUILD_LAUNCH(T, N) hipLaunchKernelGGL((wb_k_scan_build<T, N>), bgrid, block, 0, ctx->stream, sa)
 #define WB_BUILD_N(T) \
@@ -1742,6 +1744,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "scan_exclusive")) { ctx->scan_exclusive = value ? 1 : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }

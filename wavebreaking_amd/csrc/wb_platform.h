@@ -41,6 +41,7 @@ struct wb_ctx {
     int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int boxcom_per_cu = 12;                   // persistent grid of wb_k_box_com: single-wave workgroups per CU (what its LDS admits)
+    int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
     int scan_bands = 0;                       // streaming scan: row bands per time step (0: chosen from the grid and the device)
     int polys_grid = 2048;                    // workgroups of wb_k_pack_polys (it writes over PCIe: more of them only hold wave slots)
@@ -56,6 +57,7 @@ struct wb_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t scan_done = nullptr;           // recorded behind this context's field scan (option scan_exclusive)
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
     // (measured: 0.7 ms for the first pass's ~40 allocations, 350 ms for every later pass), so blocks are
     // kept for the life of the context and handed out again by size
@@ -389,6 +391,38 @@ static int side_sync(wb_ctx* ctx) {           // the HOST waits for the side str
 #endif
 }
 
+// option "scan_exclusive": the HBM-bound field scans of the contexts of one device run one after the other -- ordered ON THE
+// DEVICE (a stream waits for the event behind the scan launched before it; no host thread waits) -- so that a scan shares the
+// memory system with the other batch's latency-bound kernels instead of with its twin
+#if !defined(WB_HOSTSIM)
+#include <mutex>
+static std::mutex wb_scan_gate_mutex;
+static hipEvent_t wb_scan_gate_last[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static void wb_scan_gate_enter(wb_ctx* c) {
+    if (!c->scan_exclusive || c->device < 0 || c->device >= 16) return;
+    std::lock_guard<std::mutex> g(wb_scan_gate_mutex);
+    hipEvent_t last = wb_scan_gate_last[c->device];
+    if (last && last != c->scan_done) (void)hipStreamWaitEvent(c->stream, last, 0);
+}
+static void wb_scan_gate_leave(wb_ctx* c) {
+    if (!c->scan_exclusive || c->device < 0 || c->device >= 16) return;
+    std::lock_guard<std::mutex> g(wb_scan_gate_mutex);
+    if (!c->scan_done && hipEventCreateWithFlags(&c->scan_done, hipEventDisableTiming) != hipSuccess) { c->scan_done = nullptr; return; }
+    (void)hipEventRecord(c->scan_done, c->stream);
+    wb_scan_gate_last[c->device] = c->scan_done;
+}
+static void wb_scan_gate_forget(wb_ctx* c) {
+    std::lock_guard<std::mutex> g(wb_scan_gate_mutex);
+    if (c->device >= 0 && c->device < 16 && wb_scan_gate_last[c->device] == c->scan_done) wb_scan_gate_last[c->device] = nullptr;
+    if (c->scan_done) (void)hipEventDestroy(c->scan_done);
+    c->scan_done = nullptr;
+}
+#else
+static void wb_scan_gate_enter(wb_ctx*) {}
+static void wb_scan_gate_leave(wb_ctx*) {}
+static void wb_scan_gate_forget(wb_ctx*) {}
+#endif
+
 // stage timer: HIP events on the context's stream (host simulation: zeros)
 struct WbTimer {
     std::vector<std::string> names;
@@ -512,6 +546,7 @@ static void wb_platform_destroy(wb_ctx* c) {
     }
 #if !defined(WB_HOSTSIM)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    wb_scan_gate_forget(c);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     for (auto& kv : c->live) (void)hipFree(kv.first);
     if (c->pin) (void)hipHostFree(c->pin);
