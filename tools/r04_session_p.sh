@@ -1,0 +1,19 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+O=gpurun_out/r04p; mkdir -p $O
+one() {  # label, streams, extra env ...
+  label=$1; st=$2; shift 2
+  env "$@" timeout 300 python bench.py --steps 40 --warmup 6 --cpu-sample 0 --e2e-steps 0 --stagger-steps 0 --streams $st > /tmp/ab.json 2> /tmp/ab.err || tail -5 /tmp/ab.err
+  python - "$label" $st <<'PY'
+import json, sys
+d = json.load(open("/tmp/ab.json"))
+s = d["stage_ms"]
+keys = ("scan", "scan_build", "trace_link", "trace_rank", "trace_finish", "streamer_pairs", "streamer_f234", "props")
+print(sys.argv[1], "streams", sys.argv[2], "value %d  ms/step %.3f frac %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["frac"]), " ".join("%s %.2f" % (k, s.get(k, -1)) for k in keys), flush=True)
+PY
+}
+{
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
+bash tools/r04_stamps.sh 7
+for rep in 1 2; do for st in 1 2; do one packed $st WB_X=1; done; done
+} 2>&1 | tee $O/ab.txt

@@ -1096,7 +1096,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.truncate(b->timer_phase1);
         WbCtl* ctl = b->d_ctl;
         // the phase-2 part of the control block starts from zero (phase-1 values stay): cleared by wb_k_select_count's first workgroup
-#if defined(WB_STAMPS) && (WB_STAMPS == 4 || WB_STAMPS == 6)                                 // (the stamps of a phase-1 kernel survive into the snapshot)
+#if defined(WB_STAMPS) && (WB_STAMPS == 4 || WB_STAMPS == 6 || WB_STAMPS == 7)              // (the stamps of a phase-1 kernel survive into the snapshot)
         const size_t zero_bytes = offsetof(WbCtl, dbg) - offsetof(WbCtl, nsel);
 #else
         const size_t zero_bytes = sizeof(WbCtl) - offsetof(WbCtl, nsel);

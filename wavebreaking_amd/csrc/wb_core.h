@@ -111,7 +111,7 @@ struct WbCtl {
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.
-// -DWB_STAMPS=1 instruments wb_k_streamer_f234 (WB_STAMP), =2 wb_k_streamer_pairs (WB_PSTAMP), =3 wb_k_props (WB_RSTAMP), =4 wb_k_trace_finish (WB_TSTAMP), =5 wb_k_box_com (WB_BSTAMP), =6 wb_k_trace_link (WB_LSTAMP); WB_DEBUG_STAMPS=1 prints.
+// -DWB_STAMPS=1 instruments wb_k_streamer_f234 (WB_STAMP), =2 wb_k_streamer_pairs (WB_PSTAMP), =3 wb_k_props (WB_RSTAMP), =4 wb_k_trace_finish (WB_TSTAMP), =5 wb_k_box_com (WB_BSTAMP), =6 wb_k_trace_link (WB_LSTAMP), =7 wb_k_trace_rank (WB_KSTAMP); WB_DEBUG_STAMPS=1 prints.
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS)
 // sums kept in registers of thread 0, one global atomic per phase and workgroup at the end (..._FLUSH)
 #define WB_STAMPX_BEGIN long long wb_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
@@ -149,6 +149,15 @@ struct WbCtl {
 #define WB_TSTAMP_BEGIN
 #define WB_TSTAMP(ctl, k) ((void)0)
 #define WB_TSTAMP_FLUSH(ctl) ((void)0)
+#endif
+#if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 7
+#define WB_KSTAMP_BEGIN WB_STAMPX_BEGIN
+#define WB_KSTAMP(ctl, k) WB_STAMPX(ctl, k)
+#define WB_KSTAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
+#else
+#define WB_KSTAMP_BEGIN
+#define WB_KSTAMP(ctl, k) ((void)0)
+#define WB_KSTAMP_FLUSH(ctl) ((void)0)
 #endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 6
 #define WB_LSTAMP_BEGIN WB_STAMPX_BEGIN

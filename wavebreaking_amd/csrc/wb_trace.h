@@ -525,70 +525,104 @@ struct WbNumberOut {
     uint32_t* rawpt; uint32_t* rawcid;      // [2 * cap_seg]
     int* cnt; int* rawbase; int* closed;     // per contour: segments, first raw point, closed flag
     int* CR;                                 // [2]: contours, raw points
+    WbCtl* ctl;                              // (development stamps)
 };
-WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0_g, uint16_t* P, uint16_t* J, uint16_t* A,
+// One element's (J, A, D) live in ONE 64-bit LDS word during the two passes -- bits 0..15 J (the jump pointer), 16..31 A (pass 1:
+// running maximum, pass 2: the chain's first segment), 32..47 D (pass 1: the predecessor, kept for pass 2; pass 2: the
+// position): a round reads its own word and the word it jumps to and writes one word, where three 16-bit arrays took five
+// reads and three writes -- the kernel's 32 waves per CU were bound by the LDS pipe (2.9 us per round of pass 2, round 4's
+// stamps).  After pass 2 the words are unpacked into the three 16-bit arrays the numbering below works on.
+#define WB_RANK_PACK(j, a, d) ((unsigned long long)(uint16_t)(j) | (unsigned long long)(uint16_t)(a) << 16 | (unsigned long long)(uint16_t)(d) << 32)
+WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32_t* pred_g, uint32_t* t0_g, unsigned long long* Q,
                                      uint32_t* start_g, uint32_t* dist_g, const bool fuse, const WbNumberOut nb) {
     const uint16_t nil = (uint16_t)0xFFFF;
+    uint16_t* P = (uint16_t*)Q;                          // the 16-bit arrays of the numbering part, over the same storage
     uint16_t* D = P;
+    uint16_t* J = P + WB_TRACE_LDS_N;
+    uint16_t* A = P + 2 * WB_TRACE_LDS_N;
+    (void)J;
     int rounds = 0;
     while ((1 << rounds) < n) ++rounds;
     WB_RANK_TMP(t1);                                     // a round's new values, two 16-bit fields per register
     WB_RANK_TMP(t2);
+    WB_KSTAMP_BEGIN                                      // development stamps: 0 set-up, 1 pass 1, 2 cut, 3 pass 2, 4 .. 7 numbering, 8 raw points
     WB_PFOR(i, n)
-        J[i] = P[i];
-        A[i] = (uint16_t)i;
+        const uint32_t v = pred_g[i];
+        const uint16_t p16 = v == WB_NIL ? nil : (uint16_t)v;
+        Q[i] = WB_RANK_PACK(p16, i, p16);
     WB_END_PFOR
+    WB_KSTAMP(nb.ctl, 0);
     for (int it = 0; it < rounds; ++it) {               // pass 1: running maximum over the predecessors
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
             if (i < n) {
-                const uint16_t j = J[i];
-                if (j != nil) { const uint16_t m1 = A[i], m2 = A[j]; t1[k] = (uint32_t)(m1 > m2 ? m1 : m2) << 16 | J[j]; }
-                else t1[k] = (uint32_t)A[i] << 16 | nil;
+                const unsigned long long wi = Q[i];
+                const uint16_t j = (uint16_t)wi, m1 = (uint16_t)(wi >> 16);
+                if (j != nil) { const unsigned long long wj = Q[j]; const uint16_t m2 = (uint16_t)(wj >> 16); t1[k] = (uint32_t)(m1 > m2 ? m1 : m2) << 16 | (uint16_t)wj; }
+                else t1[k] = (uint32_t)m1 << 16 | nil;
             }
         }
         WB_SYNC();
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) { J[i] = (uint16_t)t1[k]; A[i] = (uint16_t)(t1[k] >> 16); }
+            if (i < n) ((uint32_t*)(Q + i))[0] = t1[k];          // J and A: the word's low half (D keeps the predecessor)
         }
         WB_SYNC();
     }
+    WB_KSTAMP(nb.ctl, 1);
     WB_PFOR(i, n)   // cut every loop after its raster-last segment
-        if (J[i] != nil && A[i] == (uint16_t)i) {
+        const unsigned long long wi = Q[i];
+        if ((uint16_t)wi != nil && (uint16_t)(wi >> 16) == (uint16_t)i) {
             const uint32_t s = succ_g[i];
             t0_g[s] = 1;
-            P[s] = nil;
+            ((uint16_t*)(Q + s))[2] = nil;                       // the kept predecessor of the loop's first segment
         }
     WB_END_PFOR
-    WB_PFOR(i, n)
-        J[i] = P[i];
-        A[i] = (uint16_t)i;
-    WB_END_PFOR
-    WB_PFOR(i, n)                                         // (every P has been copied: its storage becomes D)
-        D[i] = (uint16_t)1;
-    WB_END_PFOR
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) {
+            const uint16_t p16 = ((const uint16_t*)(Q + i))[2];
+            Q[i] = WB_RANK_PACK(p16, i, 1);
+            t1[k] = (uint32_t)i | 1u << 16;              // (a job of one segment makes no round: its start and position stand)
+        }
+    }
+    WB_SYNC();
+    WB_KSTAMP(nb.ctl, 2);
     for (int it = 0; it < rounds; ++it) {               // pass 2: list ranking
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
             if (i < n) {
-                const uint16_t j = J[i];
-                if (j != nil) { t1[k] = (uint32_t)(uint16_t)(D[i] + D[j]) << 16 | A[j]; t2[k] = J[j]; }
-                else { t1[k] = (uint32_t)D[i] << 16 | A[i]; t2[k] = nil; }
+                const unsigned long long wi = Q[i];
+                const uint16_t j = (uint16_t)wi;
+                if (j != nil) {
+                    const unsigned long long wj = Q[j];
+                    t1[k] = (uint32_t)(uint16_t)((uint16_t)(wi >> 32) + (uint16_t)(wj >> 32)) << 16 | (uint16_t)(wj >> 16);
+                    t2[k] = (uint16_t)wj;
+                } else { t1[k] = (uint32_t)(uint16_t)(wi >> 32) << 16 | (uint16_t)(wi >> 16); t2[k] = nil; }
             }
         }
         WB_SYNC();
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) { J[i] = (uint16_t)t2[k]; A[i] = (uint16_t)t1[k]; D[i] = (uint16_t)(t1[k] >> 16); }
+            if (i < n) Q[i] = WB_RANK_PACK(t2[k], t1[k], t1[k] >> 16);
         }
         WB_SYNC();
     }
+    // unpack: A (start) and D (position) as 16-bit arrays over the same storage -- every word is in its thread's registers
+    // (t1 = A | D << 16) before the first array element is written
+    WB_SYNC();
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        if (i < n) { A[i] = (uint16_t)t1[k]; D[i] = (uint16_t)(t1[k] >> 16); }
+    }
+    WB_SYNC();
+    WB_KSTAMP(nb.ctl, 3);
     if (!fuse) {
         WB_PFOR(i, n)
             start_g[i] = (uint32_t)A[i];
             dist_g[i] = (uint32_t)D[i];
         WB_END_PFOR
+        WB_KSTAMP_FLUSH(nb.ctl);
         return;
     }
     // ---- numbering and raw points (contour_index.py:103: skimage's contours come in the order of their raster-first segments)
@@ -634,7 +668,9 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0
         if (i < n) M[i] = (t1[k] & LEAD) ? 1u : 0u;
     }
     WB_SYNC();
+    WB_KSTAMP(nb.ctl, 4);
     const int C = wb_block_scan_excl((int*)M, n);
+    WB_KSTAMP(nb.ctl, 5);
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
         if (i < n && (t1[k] & LEAD)) t2[k] = M[i];
@@ -657,10 +693,12 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0
         M[c] = (uint32_t)cnt16[c] + 1u;
         nb.cnt[c] = (int)cnt16[c];
     WB_END_PFOR
+    WB_KSTAMP(nb.ctl, 6);
     const int R = wb_block_scan_excl((int*)M, C);
     WB_PFOR(c, C)
         nb.rawbase[c] = (int)M[c];
     WB_END_PFOR
+    WB_KSTAMP(nb.ctl, 7);
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
         if (i < n) {
@@ -679,6 +717,8 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, uint32_t* t0
     nb.CR[0] = C;
     nb.CR[1] = R;
     WB_END_SINGLE
+    WB_KSTAMP(nb.ctl, 8);
+    WB_KSTAMP_FLUSH(nb.ctl);
 }
 
 // contour_index.py:109 calls a contour closed when its first and last float coordinates are equal: besides the loops the
@@ -704,18 +744,13 @@ WB_KERNEL_LB(wb_k_trace_rank, WB_RANK_THREADS, (WB_RANK_THREADS >= 1024 ? 8 : 4)
     uint32_t* dist = a.w[6] + jb;
     const uint32_t* segf = a.mseg[1] + jb;
     const uint32_t* segt = a.mseg[2] + jb;
-    WB_SHARED(uint16_t, lds, 3 * WB_TRACE_LDS_N);         // 48 KiB: P (later D), J, A (dist <= n <= 8192 fits 16 bits)
-    uint16_t* P = lds;
-    WB_PFOR(i, n)
-        const uint32_t v = pred[i];
-        P[i] = v == WB_NIL ? (uint16_t)0xFFFF : (uint16_t)v;
-    WB_END_PFOR
+    WB_SHARED(unsigned long long, q64, WB_TRACE_LDS_N);   // 64 KiB: one word per segment during the passes (wb_rank_lists_lds), three 16-bit arrays after
     // the finish kernel's scratch roles: cnt = w[3], rawbase = w[5], closed_raw = w[7] (free here)
     WbNumberOut nb;
     nb.segf = segf; nb.segt = segt; nb.rawpt = a.rawpt + 2 * jb; nb.rawcid = a.rawcid + 2 * jb;
-    nb.cnt = (int*)(a.w[3] + jb); nb.rawbase = (int*)(a.w[5] + jb); nb.closed = (int*)(a.w[7] + jb); nb.CR = a.p4 + 2 * (size_t)job;
+    nb.cnt = (int*)(a.w[3] + jb); nb.rawbase = (int*)(a.w[5] + jb); nb.closed = (int*)(a.w[7] + jb); nb.CR = a.p4 + 2 * (size_t)job; nb.ctl = a.ctl;
     const bool fuse = WB_TRACE_FUSE_P4 && !(a.status[job] & WB_ST_LEVEL_ORDER);   // (those the walk kernel ranks again)
-    wb_rank_lists_lds(n, succ, t0, P, lds + 1 * WB_TRACE_LDS_N, lds + 2 * WB_TRACE_LDS_N, start, dist, fuse, nb);
+    wb_rank_lists_lds(n, succ, pred, t0, q64, start, dist, fuse, nb);
     if (fuse) return;
     WB_SINGLE
     a.p4[2 * (size_t)job] = -1;
