@@ -35,9 +35,10 @@ _FATAL = (
 )
 LEVEL_ORDER_TEXT = ("cells equal to the contour level put two contour ends on one grid vertex and the order-dependent join of "
                     "scikit-image's find_contours (contour_index.py:103) was not reproduced for this job.")
-LEVEL_KEYERROR_TEXT = ("cells equal to the contour level put two contour ends on one grid vertex: scikit-image's find_contours "
-                       "(contour_index.py:103) raises KeyError on this field -- a piece end whose dictionary entry another piece "
-                       "overwrote -- and so does this call.  Perturb the level by one ulp to avoid it.")
+LEVEL_KEYERROR_TEXT = ("cells equal to the contour level put two contour ends on one grid vertex: find_contours of scikit-image 0.18.3 "
+                       "(contour_index.py:103; the release this package's assembly rules are pinned to -- the reference pins none, and "
+                       "later releases rewrote the routine) raises KeyError on this field -- a piece end whose dictionary entry another "
+                       "piece overwrote -- and so does this call.  Perturb the level by one ulp to avoid it.")
 
 
 def check_batch(batch, what, times=None, levels=None, pos=None, t0=0):
