@@ -467,10 +467,22 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
             wb.release_inputs()
     secs, rows = min(runs, key=lambda r: sum(r[0].values()))
     total = sum(secs.values())
+    fp = dict(engine.FINGERPRINT_STATS)
     out = {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
            "upload_GBps": pv.nbytes / t_up / 1e9, "both_runs_s": [sum(r[0].values()) for r in runs],
            "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, cold input "
                    "cache at the first call, H2D included" % (nt, pv.nbytes / 1e9), "pipelined_upload": bool(engine.PIPELINED_UPLOAD)}
+    # every call above fingerprinted every byte of both cubes (wb_fingerprint) to make sure the device copies still mirror them;
+    # a caller who promises not to modify the cubes in place (wb.keep_inputs) is recognised by address + a strided sample
+    out["fingerprint"] = {"calls": fp["full"], "seconds_total": fp["seconds"], "GBps": (fp["full"] * pv.nbytes / fp["seconds"] / 1e9) if fp["seconds"] > 0 else None,
+                          "what": "wb_fingerprint over whole cubes in the calls so far (several host threads)"}
+    wb.release_inputs()
+    wb.keep_inputs(data, idata)
+    secs_k, rows_k = three(data, idata)
+    out["keep_inputs"] = {"value": nt / sum(secs_k.values()), "unit": "timesteps/s", "seconds": secs_k, "rows_match": rows_k == rows,
+                          "what": "the same three calls from a cold cache after wb.keep_inputs(data, intensity): cubes recognised without reading every byte"}
+    wb.release_inputs()
+    three(data, idata)                                        # (resident again for the next measurement)
     # the reference's own sharing: contours once, handed to the three calls (cubes already resident from the calls above)
     tic = time.perf_counter()
     cont = wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False)

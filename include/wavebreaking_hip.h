@@ -264,6 +264,15 @@ int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double
                     uint64_t* stats);
 /* the overlap areas behind method 0 for an explicit list of pairs: inter[q] <- area(event pair_i[q] n event pair_j[q]),
    area[n] (may be NULL) <- area of every event; index units.  Exactly 0 when the interiors do not meet. */
+/* track_events(method="by_overlap", buffer > 0, overlap = 0) (events.py:203-214): the reference buffers both geometries by
+   `buffer` degrees (GEOS' round buffer) and links a pair whose buffered polygons overlap at all -- i.e. whose planar distance in
+   degrees is below 2 * buffer (exact for discs; GEOS' inscribed arcs can fall short by 0.24 % of that at corners: such pairs
+   are counted in stats[5] and decided by the disc; unpinned, GEOS is not in the image).  Rings as for wb_track_events on the
+   grid with step_x_deg / step_y_deg degrees per index step.  stats[6]: the four of wb_track_events, [4] pairs linked by the
+   distance alone (no overlap of the unbuffered polygons), [5] pairs inside the arc band. */
+int wb_track_events_buffered(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, double time_range,
+                             double buffer_deg, double step_x_deg, double step_y_deg, const int64_t* ring_offset,
+                             const int64_t* vert_offset, const int32_t* vx, const int32_t* vy, int32_t* label, uint64_t* stats);
 int wb_track_overlaps(wb_ctx* ctx, int64_t n, const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx,
                       const int32_t* vy, int64_t npairs, const int64_t* pair_i, const int64_t* pair_j, double* inter,
                       double* area);

@@ -167,6 +167,69 @@ def overlap_check(rings, pairs, overlap):
     return out, ratio
 
 
+# ------------------------------------------------------------------------------------------------------ by_overlap, buffer > 0
+def _seg_seg_d2_exact(a, b, c, d):
+    """squared distance of the closed segments [a, b] and [c, d] (points with Fraction coordinates), exact"""
+    def orient(p, q, r):
+        return (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
+
+    def on(p, q, r):
+        return min(p[0], q[0]) <= r[0] <= max(p[0], q[0]) and min(p[1], q[1]) <= r[1] <= max(p[1], q[1])
+    o1, o2, o3, o4 = orient(a, b, c), orient(a, b, d), orient(c, d, a), orient(c, d, b)
+    if o1 * o2 < 0 and o3 * o4 < 0:
+        return Fraction(0)
+    if (o1 == 0 and on(a, b, c)) or (o2 == 0 and on(a, b, d)) or (o3 == 0 and on(c, d, a)) or (o4 == 0 and on(c, d, b)):
+        return Fraction(0)
+
+    def pt_seg(p, q, r):
+        ux, uy, wx, wy = r[0] - q[0], r[1] - q[1], p[0] - q[0], p[1] - q[1]
+        L = ux * ux + uy * uy
+        t = (wx * ux + wy * uy) / L if L else Fraction(0)
+        t = min(max(t, Fraction(0)), Fraction(1))
+        ex, ey = wx - t * ux, wy - t * uy
+        return ex * ex + ey * ey
+    return min(pt_seg(a, c, d), pt_seg(b, c, d), pt_seg(c, a, b), pt_seg(d, a, b))
+
+
+def rings_distance2(rings_a, rings_b, sx=1, sy=1):
+    """squared planar distance, in degrees^2, of two events given as lattice rings on a grid with sx / sy degrees per step:
+    0 if the closed regions share a point (they overlap, touch, or one lies inside the other), else the smallest distance
+    between their boundaries.  Exact (Fractions of the floats sx, sy)."""
+    if overlap_area(rings_a, rings_b) > 0:
+        return Fraction(0)
+    fx, fy = Fraction(sx), Fraction(sy)
+    best = None
+    for ra in rings_a:
+        pa = [(Fraction(int(x)) * fx, Fraction(int(y)) * fy) for x, y in np.asarray(ra)]
+        for rb in rings_b:
+            pb = [(Fraction(int(x)) * fx, Fraction(int(y)) * fy) for x, y in np.asarray(rb)]
+            for i in range(len(pa)):
+                a, b = pa[i], pa[(i + 1) % len(pa)]
+                for j in range(len(pb)):
+                    d2 = _seg_seg_d2_exact(a, b, pb[j], pb[(j + 1) % len(pb)])
+                    if best is None or d2 < best:
+                        best = d2
+                        if best == 0:
+                            return best
+    return best
+
+
+def buffered_overlap_check(rings, pairs, buffer, steps=(1, 1)):
+    """events.py:203-214 with buffer > 0 and overlap == 0: the buffered geometries overlap at all.  GEOS' round buffer
+    (geopandas: 16 segments per quadrant) taken as the disc of radius ``buffer``: linked iff the polygons' planar distance
+    in degrees is BELOW 2 * buffer -- **parity unpinned** (no GEOS here); ``band`` marks the pairs within
+    2 * (1 - cos(pi / 64)) of that distance, where GEOS' inscribed arcs could fall short of the disc."""
+    reach = Fraction(2) * Fraction(buffer)
+    lo = reach * (1 - Fraction(0.0024091))
+    out = np.zeros(len(pairs), dtype=bool)
+    band = np.zeros(len(pairs), dtype=bool)
+    for n, (i, j) in enumerate(pairs):
+        d2 = rings_distance2(rings[i], rings[j], steps[0], steps[1])
+        out[n] = d2 < reach * reach
+        band[n] = out[n] and d2 >= lo * lo
+    return out, band
+
+
 # ------------------------------------------------------------------------------------------------------ labels
 def combine_shared(pairs):
     """index_utils.py:187-214 on pairs: connected components, as sets"""
@@ -196,7 +259,7 @@ def final_order(label, dates):
     return np.lexsort((d, np.asarray(label)))
 
 
-def track_events(dates, com=None, rings=None, time_range=None, method="by_overlap", overlap=0, distance=1000):
+def track_events(dates, com=None, rings=None, time_range=None, method="by_overlap", overlap=0, distance=1000, buffer=0, steps=(1, 1)):
     """events.py:113-241 -> (label per input row, row order of the returned frame, the pairs in range, which are linked)"""
     if time_range is None:
         time_range = default_time_range(dates)
@@ -205,6 +268,9 @@ def track_events(dates, com=None, rings=None, time_range=None, method="by_overla
         raise ValueError("No events detected in the time range: {}".format(time_range))
     if method == "by_distance":
         check = distance_check(com, pairs, distance)
+    elif method == "by_overlap" and buffer > 0:
+        assert overlap == 0, "buffer > 0 is restated for overlap == 0 only"
+        check, _ = buffered_overlap_check(rings, pairs, buffer, steps)
     elif method == "by_overlap":
         check, _ = overlap_check(rings, pairs, overlap)
     else:

@@ -301,6 +301,46 @@ def _kernel_golden_distance(ctx):
         assert stats["pairs_in_range"] == len(d) and stats["pairs_linked"] == int(g["c%d_check" % c].sum())
 
 
+def _kernel_buffered(ctx):
+    """track_events(buffer > 0, overlap = 0) (events.py:203-214): linked iff the polygons are closer than 2 * buffer degrees --
+    labels against the exact-rational oracle on random catalogues (isotropic and anisotropic grid steps), and the decisions
+    at the threshold: a gap of exactly 2 * buffer is NOT linked (the discs touch), anything closer is; one polygon inside the
+    other's hole-free interior is linked; corner-to-corner distances"""
+    for seed, n, steps, tr, buf, st in ((3, 40, 6, 6.0, 0.5, (0.25, 0.25)), (5, 48, 7, 12.0, 1.0, (0.25, 0.25)), (7, 36, 5, 6.0, 0.9, (1.0, 0.5)),
+                                        (11, 40, 4, 6.0, 2.0, (0.3, 0.3))):
+        dates, polys, com = _tracking_case(seed, n, steps, shuffle=True)
+        want, order, pairs, check = otrack.track_events(dates, rings=polys, time_range=tr, method="by_overlap", buffer=buf, steps=st)
+        plain = otrack.track_events(dates, rings=polys, time_range=tr, method="by_overlap", overlap=0)[3]
+        label, stats = ctx.track_events_buffered(dates, tr, buf, st, rings_per_event=polys)
+        assert np.array_equal(label, want), (seed, buf)
+        assert stats["pairs_in_range"] == len(pairs) and stats["pairs_linked"] == int(check.sum())
+        assert int(check.sum()) > int(plain.sum()) > 0                    # the buffer links pairs that do not overlap
+        assert stats["pairs_linked_by_distance"] == int((check & ~plain).sum())
+    dates = np.array(["2000-01-01T00", "2000-01-01T06"], dtype="datetime64[ns]")
+    a = [SQ(0, 0, 10, 10)]
+    for b, buf, st, linked in (([SQ(12, 0, 20, 10)], 0.25, (0.25, 0.25), False),      # gap 2 steps = 0.5 degrees = 2 * buffer: touching discs
+                               ([SQ(12, 0, 20, 10)], 0.2500001, (0.25, 0.25), True),
+                               ([SQ(11, 0, 20, 10)], 0.25, (0.25, 0.25), True),
+                               ([SQ(13, 13, 20, 20)], 0.5, (0.25, 0.25), False),       # corner to corner: 3 * sqrt(2) * 0.25 = 1.06 > 1
+                               ([SQ(13, 13, 20, 20)], 0.54, (0.25, 0.25), True),
+                               ([SQ(2, 2, 4, 4)], 0.001, (0.25, 0.25), True),           # inside
+                               ([SQ(10, 0, 20, 10)], 0.001, (0.25, 0.25), True),        # shared edge: distance 0
+                               ([SQ(12, 0, 20, 10)], 0.6, (0.5, 2.0), False),           # anisotropic: 2 steps in x = 1.0 degree < 1.2 ...
+                               ([SQ(0, 12, 10, 20)], 0.6, (0.5, 2.0), False)):          # ... 2 steps in y = 4.0 degrees
+        if b[0][0][0] == 12 and st == (0.5, 2.0):
+            linked = True                                                              # (1.0 < 1.2)
+        label, stats = ctx.track_events_buffered(dates, 6.0, buf, st, rings_per_event=[a, b])
+        want, _, _, check = otrack.track_events(dates, rings=[a, b], time_range=6.0, method="by_overlap", buffer=buf, steps=st)
+        assert label.tolist() == want.tolist() == ([0, 0] if linked else [0, 1]), (b, buf, st)
+    # the arc band: a corner-to-corner pair just inside the threshold is counted
+    b = [SQ(13, 13, 20, 20)]
+    d = 3 * 2 ** 0.5 * 0.25
+    label, stats = ctx.track_events_buffered(dates, 6.0, d / 2 * 1.001, (0.25, 0.25), rings_per_event=[a, b])
+    assert label.tolist() == [0, 0] and stats["pairs_in_arc_band"] == 1
+    label, stats = ctx.track_events_buffered(dates, 6.0, d / 2 * 1.01, (0.25, 0.25), rings_per_event=[a, b])
+    assert label.tolist() == [0, 0] and stats["pairs_in_arc_band"] == 0
+
+
 @pytest.fixture
 def hostsim_ctx():
     ctx = _hip.Context(0, helpers.hostsim_library())
@@ -317,6 +357,7 @@ def test_track_kernels_hostsim(hostsim_ctx, reverse):
         _kernel_thresholds(hostsim_ctx)
         _kernel_ratio_on_the_threshold(hostsim_ctx)
         _kernel_golden_distance(hostsim_ctx)
+        _kernel_buffered(hostsim_ctx)
     finally:
         helpers.hostsim_library().lib.wb_hostsim_set_reverse(0)
 
@@ -330,6 +371,7 @@ def test_track_kernels_gpu():
         _kernel_thresholds(ctx)
         _kernel_ratio_on_the_threshold(ctx)
         _kernel_golden_distance(ctx)
+        _kernel_buffered(ctx)
     finally:
         ctx.close()
 
@@ -416,8 +458,15 @@ def _public_function():
         wb.track_events([1, 2, 3])
     with pytest.raises(ValueError, match="is empty"):
         wb.track_events(events.iloc[:0])
+    # buffer > 0 with the default overlap: closer than 2 * buffer degrees (events.py:203-214); with overlap > 0: not built
+    want, order, _, check = otrack.track_events(dates, rings=polys, time_range=6.0, method="by_overlap", buffer=0.75, steps=(0.25, 0.25))
+    tracked = wb.track_events(events, buffer=0.75)
+    assert tracked.index.tolist() == order.tolist() and tracked.label.tolist() == want[order].tolist()
+    assert tracked.attrs["track_stats"]["pairs_linked"] == int(check.sum())
     with pytest.raises(NotImplementedError):
-        wb.track_events(events, buffer=1.0)
+        wb.track_events(events, buffer=1.0, overlap=0.1)
+    with pytest.raises(NotImplementedError):
+        wb.track_events(events, buffer=-1.0)
     off_grid = _frame(dates[:2], [[np.array([(0, 0), (1, 0), (2 ** 0.5 / 3, 0.77)])], [np.array([(0, 0), (1, 0), (0.5, 3 ** 0.5 / 2)])]])
     with pytest.raises(ValueError, match="regular grid"):
         wb.track_events(off_grid, time_range=1000)

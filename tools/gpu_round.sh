@@ -10,6 +10,8 @@ mkdir -p $O
 if [ "${2:-tests}" = "tests" ]; then (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > $O/gpu_tests.txt; fi
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --streams 1 --cpu-sample 0 > $O/bench_s1.json 2> $O/bench_s1.err
+timeout 600 python bench.py --config 1 > $O/bench_config1.json 2> $O/bench_config1.err
+WB_BENCH_FORCE_DIST=1 timeout 600 python bench.py --cpu-sample 0 --e2e-steps 0 --stagger-steps 0 > $O/bench_dist1.json 2> $O/bench_dist1.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_stats -- python3 $R/bench.py --cpu-sample 0 --e2e-steps 0 --streams 1 --stagger-steps 0 > $R/$O/prof_stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_stats2 -- python3 $R/bench.py --cpu-sample 0 --e2e-steps 0 --stagger-steps 0 > $R/$O/prof_stats2.log 2>&1

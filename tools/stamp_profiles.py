@@ -29,7 +29,8 @@ for name, cmd in what.items():
     with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as f:
         f.write("# %s\n# MI355X, tools/gpu_round.sh + tools/profile_summary.py\n" % cmd)
         f.write(body)
-for name, out in (("bench.json", "bench.json"), ("bench_s1.json", "bench_one_batch.json")):
+for name, out in (("bench.json", "bench.json"), ("bench_s1.json", "bench_one_batch.json"), ("bench_config1.json", "bench_config1_one_degree.json"),
+                  ("bench_dist1.json", "bench_rccl_library_1rank.json")):
     p = os.path.join(src, name)
     if os.path.exists(p):
         line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]

@@ -128,6 +128,8 @@ class Library:
         lib.wb_track_events.argtypes = [C.c_void_p, C.c_int64, i64p, dp, C.c_int, C.c_double, C.c_double, C.c_double, dp, i64p,
                                         i64p, i32p, i32p, i32p, dp, C.POINTER(C.c_uint64)]
         lib.wb_track_overlaps.argtypes = [C.c_void_p, C.c_int64, i64p, i64p, i32p, i32p, C.c_int64, i64p, i64p, dp, dp]
+        lib.wb_track_events_buffered.argtypes = [C.c_void_p, C.c_int64, i64p, dp, C.c_double, C.c_double, C.c_double, C.c_double, i64p, i64p,
+                                                 i32p, i32p, i32p, C.POINTER(C.c_uint64)]
         lib.wb_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         lib.wb_comm_unique_id.argtypes = [C.c_void_p, C.c_void_p]
         lib.wb_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -353,6 +355,36 @@ class Context:
         xy = np.concatenate(parts) if parts else np.zeros((0, 2), dtype=np.int32)
         return (ring_off, np.asarray(vert_off, dtype=np.int64), np.ascontiguousarray(xy[:, 0], dtype=np.int32),
                 np.ascontiguousarray(xy[:, 1], dtype=np.int32))
+
+    def track_events_buffered(self, dates, time_range, buffer, steps, rings_per_event=None, rings_csr=None):
+        """wb_track_events_buffered: labels of track_events(method="by_overlap", buffer=buffer > 0, overlap=0) -- a pair in time range
+        is linked when the planar distance of its polygons, in degrees, is below 2 * buffer.  ``steps`` = (degrees per grid step in
+        x, in y); rings as for ``track_events``.  Returns (label int32[n], stats dict)."""
+        d = np.asarray(dates)
+        n = d.shape[0]
+        i64p, i32p, dp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        ns = val = None
+        if np.issubdtype(d.dtype, np.datetime64):
+            ns = np.ascontiguousarray(d.astype("datetime64[ns]").astype(np.int64))
+        else:
+            val = np.ascontiguousarray(d, dtype=np.float64)
+        if rings_csr is not None:
+            ring_off, vert_off, vx, vy = (np.ascontiguousarray(rings_csr[0], dtype=np.int64), np.ascontiguousarray(rings_csr[1], dtype=np.int64),
+                                          np.ascontiguousarray(rings_csr[2], dtype=np.int32), np.ascontiguousarray(rings_csr[3], dtype=np.int32))
+        else:
+            ring_off, vert_off, vx, vy = self._lattice_rings(rings_per_event)
+        assert ring_off.size == n + 1
+        label = np.empty(n, dtype=np.int32)
+        stats = np.zeros(6, dtype=np.uint64)
+        rc = self.L.lib.wb_track_events_buffered(self.h, n, ns.ctypes.data_as(i64p) if ns is not None else None,
+                                                 val.ctypes.data_as(dp) if val is not None else None, float(time_range), float(buffer),
+                                                 float(steps[0]), float(steps[1]), ring_off.ctypes.data_as(i64p), vert_off.ctypes.data_as(i64p),
+                                                 vx.ctypes.data_as(i32p), vy.ctypes.data_as(i32p), label.ctypes.data_as(i32p),
+                                                 stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc != 0:
+            raise RuntimeError("wb_track_events_buffered failed: " + self.error())
+        return label, dict(pairs_in_range=int(stats[0]), pairs_boxes_within_reach=int(stats[1]), pairs_linked=int(stats[2]),
+                           polygons_not_simple=int(stats[3]), pairs_linked_by_distance=int(stats[4]), pairs_in_arc_band=int(stats[5]))
 
     def track_events(self, dates, method, time_range, overlap=0.0, distance=1000.0, com=None, rings_per_event=None, rings_csr=None):
         """wb_track_events: labels of track_events (events.py:113-241) for events in the caller's row order.  ``dates``:

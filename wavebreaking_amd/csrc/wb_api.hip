@@ -1711,7 +1711,7 @@ extern "C" uint64_t wb_fingerprint(const void* host_buffer, uint64_t bytes, int 
     const unsigned char* p = (const unsigned char*)host_buffer;
     if (!p || !bytes) return 0x5742ull;
     const size_t chunk = (size_t)4 << 20, nchunks = (size_t)((bytes + chunk - 1) / chunk);
-    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency() / 2; if (threads > 16) threads = 16; }
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency() / 2; if (threads > 32) threads = 32; }
     if (threads < 1) threads = 1;
     if ((size_t)threads > nchunks) threads = (int)nchunks;
     std::vector<uint64_t> part(nchunks);
@@ -1980,14 +1980,15 @@ extern "C" int wb_flag_events(wb_ctx* ctx, int64_t nt, int nlat, int nlon, const
 // ------------------------------------------------------------------------------------------------ track_events
 // the geometry of wb_track_events / wb_track_overlaps on the device, events in the order `order`
 struct WbTrackGeom {
-    std::vector<long long> edge0, row0, piece0;
+    std::vector<long long> edge0, row0, piece0, fedge0;
     std::vector<short> ex0, ey0, ex1, ey1;
+    std::vector<short> fx0, fy0, fx1, fy1;          // ALL ring edges (the reach test of buffered tracking needs the horizontal ones too)
     std::vector<int> ymin, ymax, xmin, xmax;
     std::vector<void*> dev;
 };
 static int wb_track_geometry(wb_ctx* ctx, const char* who, int64_t n, const int64_t* order, const int64_t* ring_offset,
                              const int64_t* vert_offset, const int32_t* vx, const int32_t* vy, WbTrackGeom& g, WbTrackArgs& a) {
-    g.edge0.assign((size_t)n + 1, 0); g.row0.assign((size_t)n + 1, 0); g.piece0.assign((size_t)n + 1, 0);
+    g.edge0.assign((size_t)n + 1, 0); g.row0.assign((size_t)n + 1, 0); g.piece0.assign((size_t)n + 1, 0); g.fedge0.assign((size_t)n + 1, 0);
     g.ymin.assign((size_t)n, 0); g.ymax.assign((size_t)n, 0); g.xmin.assign((size_t)n, 0); g.xmax.assign((size_t)n, 0);
     for (int64_t q = 0; q < n; ++q) {
         const int64_t e = order[q];
@@ -2003,6 +2004,9 @@ static int wb_track_geometry(wb_ctx* ctx, const char* who, int64_t n, const int6
                     return 1;
                 }
                 y0 = ay < y0 ? ay : y0; y1 = ay > y1 ? ay : y1; x0 = ax < x0 ? ax : x0; x1 = ax > x1 ? ax : x1;
+                if (a.reach > 0.0 && (ax != bx || ay != by || nv == 1)) {
+                    g.fx0.push_back((short)ax); g.fy0.push_back((short)ay); g.fx1.push_back((short)bx); g.fy1.push_back((short)by);
+                }
                 if (ay == by) continue;                                    // horizontal edges bound no row from the side
                 g.ex0.push_back((short)ax); g.ey0.push_back((short)ay); g.ex1.push_back((short)bx); g.ey1.push_back((short)by);
                 pieces += ay < by ? by - ay : ay - by;
@@ -2011,6 +2015,7 @@ static int wb_track_geometry(wb_ctx* ctx, const char* who, int64_t n, const int6
         if (y0 > y1) { y0 = y1 = 0; x0 = x1 = 0; }                        // an empty geometry
         g.ymin[(size_t)q] = y0; g.ymax[(size_t)q] = y1; g.xmin[(size_t)q] = x0; g.xmax[(size_t)q] = x1;
         g.edge0[(size_t)q + 1] = (long long)g.ex0.size();
+        g.fedge0[(size_t)q + 1] = (long long)g.fx0.size();
         g.row0[(size_t)q + 1] = g.row0[(size_t)q] + (y1 - y0);
         g.piece0[(size_t)q + 1] = g.piece0[(size_t)q] + pieces;
         if (pieces > INT32_MAX) { ctx->err = std::string(who) + ": polygon too large"; return 1; }
@@ -2028,6 +2033,12 @@ static int wb_track_geometry(wb_ctx* ctx, const char* who, int64_t n, const int6
     a.piece0 = (const long long*)up(g.piece0.data(), g.piece0.size() * 8);
     a.ex0 = (const short*)up(g.ex0.data(), ne * 2); a.ey0 = (const short*)up(g.ey0.data(), ne * 2);
     a.ex1 = (const short*)up(g.ex1.data(), ne * 2); a.ey1 = (const short*)up(g.ey1.data(), ne * 2);
+    if (a.reach > 0.0) {
+        const size_t nf = g.fx0.size();
+        a.fedge0 = (const long long*)up(g.fedge0.data(), g.fedge0.size() * 8);
+        a.fx0 = (const short*)up(g.fx0.data(), nf * 2); a.fy0 = (const short*)up(g.fy0.data(), nf * 2);
+        a.fx1 = (const short*)up(g.fx1.data(), nf * 2); a.fy1 = (const short*)up(g.fy1.data(), nf * 2);
+    }
     a.ymin = (const int*)up(g.ymin.data(), (size_t)n * 4); a.ymax = (const int*)up(g.ymax.data(), (size_t)n * 4);
     a.xmin = (const int*)up(g.xmin.data(), (size_t)n * 4); a.xmax = (const int*)up(g.xmax.data(), (size_t)n * 4);
     a.row_off = (int*)scratch(rows * 4); a.row_cnt = (int*)scratch(rows * 4);
@@ -2044,10 +2055,32 @@ static void wb_track_release(wb_ctx* ctx, WbTrackGeom& g) {
     g.dev.clear();
 }
 
+static int wb_track_events_impl(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, int method,
+                                double time_range, double overlap, double distance, const double* com,
+                                const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx, const int32_t* vy,
+                                int32_t* label, double* area, uint64_t* stats, double reach, double step_x, double step_y);
+
 extern "C" int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, int method,
                                double time_range, double overlap, double distance, const double* com,
                                const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx, const int32_t* vy,
                                int32_t* label, double* area, uint64_t* stats) {
+    return wb_track_events_impl(ctx, n, date_ns, date_val, method, time_range, overlap, distance, com, ring_offset, vert_offset, vx, vy,
+                                label, area, stats, 0.0, 1.0, 1.0);
+}
+
+extern "C" int wb_track_events_buffered(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, double time_range,
+                                        double buffer_deg, double step_x_deg, double step_y_deg, const int64_t* ring_offset,
+                                        const int64_t* vert_offset, const int32_t* vx, const int32_t* vy, int32_t* label, uint64_t* stats) {
+    if (!ctx) return 1;
+    if (!(buffer_deg > 0.0) || !(step_x_deg > 0.0) || !(step_y_deg > 0.0)) { ctx->err = "wb_track_events_buffered: buffer and grid steps must be positive"; return 1; }
+    return wb_track_events_impl(ctx, n, date_ns, date_val, 0, time_range, 0.0, 0.0, nullptr, ring_offset, vert_offset, vx, vy, label, nullptr,
+                                stats, 2.0 * buffer_deg, step_x_deg, step_y_deg);
+}
+
+static int wb_track_events_impl(wb_ctx* ctx, int64_t n, const int64_t* date_ns, const double* date_val, int method,
+                                double time_range, double overlap, double distance, const double* com,
+                                const int64_t* ring_offset, const int64_t* vert_offset, const int32_t* vx, const int32_t* vy,
+                                int32_t* label, double* area, uint64_t* stats, double reach, double step_x, double step_y) {
     if (!ctx) return 1;
     wb_use(ctx);
     if (n < 1 || n > INT32_MAX || (!date_ns == !date_val) || !label || (method != 0 && method != 1) ||
@@ -2062,6 +2095,8 @@ extern "C" int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, c
     WbTrackArgs a;
     memset(&a, 0, sizeof(a));
     a.n = n; a.method = method; a.date_kind = date_ns ? 0 : 1; a.time_range = time_range; a.overlap = overlap; a.distance = distance;
+    a.reach = reach; a.sx = step_x; a.sy = step_y;
+    const int nstats = reach > 0.0 ? 6 : 4;
     WbTrackGeom g;
     int rc = 0;
     if (method == 0) rc = wb_track_geometry(ctx, "wb_track_events", n, order.data(), ring_offset, vert_offset, vx, vy, g, a);
@@ -2088,11 +2123,11 @@ extern "C" int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, c
         a.parent = (int*)dmalloc(ctx, (size_t)n * 4); g.dev.push_back(a.parent);
         a.flag = (int*)dmalloc(ctx, (size_t)n * 4); g.dev.push_back(a.flag);
         a.label = (int*)dmalloc(ctx, (size_t)n * 4); g.dev.push_back(a.label);
-        a.stats = (unsigned long long*)dmalloc(ctx, 4 * 8); g.dev.push_back(a.stats);
+        a.stats = (unsigned long long*)dmalloc(ctx, 6 * 8); g.dev.push_back(a.stats);
         if (!a.parent || !a.flag || !a.label || !a.stats) { ctx->err = "wb_track_events: out of device memory"; rc = 1; }
     }
     if (!rc) {
-        dmemset(ctx, a.stats, 0, 4 * 8);
+        dmemset(ctx, a.stats, 0, 6 * 8);
         WbOpTimer timer(ctx);
         const int gl = n < 4096 ? (int)((n + 255) / 256) : 1024;         // flat kernels: a contiguous slice per workgroup
         WB_LAUNCH(wb_k_track_init, gl, 256, a);
@@ -2104,7 +2139,7 @@ extern "C" int wb_track_events(wb_ctx* ctx, int64_t n, const int64_t* date_ns, c
         WB_LAUNCH(wb_k_track_labels, gl, 256, a);
         timer.stop();
         rc = d2h(ctx, label, a.label, (size_t)n * 4);
-        if (!rc && stats) rc = d2h(ctx, stats, a.stats, 4 * 8);
+        if (!rc && stats) rc = d2h(ctx, stats, a.stats, (size_t)nstats * 8);
         if (!rc && area && method == 0) {
             std::vector<double> sa((size_t)n);
             rc = d2h(ctx, sa.data(), a.area, (size_t)n * 8);

@@ -139,7 +139,7 @@ static void hrelease(void* p) {
 }
 static void hfree(wb_ctx* c, void* p, size_t bytes) {
     if (!p) return;
-    if (c->hpool.size() < 8) c->hpool.insert({bytes, p}); else hrelease(p);
+    if (c->hpool.size() < 24) c->hpool.insert({bytes, p}); else hrelease(p);      // (24: the three index calls on a contour frame use three size classes of vertex arrays each; pinning a fresh 16-64 MB block costs tens of ms)
 }
 
 // every entry point that touches the device selects the context's device first: the current device is per host thread

@@ -48,7 +48,13 @@ struct WbTrackArgs {
     int* parent;                  // [n] indexed by caller's row
     int* flag;                    // [n] scratch: 1 where a row is its component's smallest row
     int* label;                   // [n] out
-    unsigned long long* stats;    // [0] pairs in range, [1] pairs whose boxes overlap, [2] pairs linked, [3] events whose polygon crosses itself
+    unsigned long long* stats;    // [0] pairs in range, [1] pairs whose boxes overlap, [2] pairs linked, [3] events whose polygon crosses itself,
+                                  // [4] pairs linked by the reach test alone (buffered tracking), [5] pairs inside the arc band of that test
+    // buffered tracking (events.py:203-214 with buffer > 0 and overlap == 0): two events are linked when their buffered polygons
+    // share interior points, i.e. when the planar distance of the polygons in degrees is below reach = 2 * buffer
+    double reach, sx, sy;         // reach in degrees (0: off), degrees per grid step in x and y
+    const long long* fedge0;      // [n+1] ALL ring edges of event e, the horizontal ones included
+    const short* fx0; const short* fy0; const short* fx1; const short* fy1;
 };
 
 // ----------------------------------------------------------------------------------------------------- union-find
@@ -288,11 +294,81 @@ WB_KERNEL(wb_k_track_overlap_list, WbTrackArgs a, long long npairs, const long l
     }
 }
 
+// ----------------------------------------------------------------------------------------------------- buffered tracking
+// events.py:203-214 with buffer > 0: geom.buffer(buffer) is GEOS' round buffer (geopandas: 16 segments per quadrant), and
+// with overlap == 0 the test `inter.area / union.area > 0` asks whether the two buffered polygons share interior points --
+// for discs of radius `buffer`: whether the planar distance of the two (closed) polygons, in degrees, is BELOW 2 * buffer.
+// GEOS' arcs are inscribed polygons: at a corner they fall short of the disc by at most buffer * (1 - cos(pi / 64)), so a
+// pair whose distance lies within 2 * that of the threshold could go either way there; such pairs are counted (stats[5])
+// and decided by the disc.  GEOS itself is not in the image: **unpinned**, like the other GEOS pieces.
+#define WB_TRACK_ARC_SLACK 0.0024091                         // 2 * (1 - cos(pi / 64))
+static WB_HD inline long long wb_tr_orient(long long ax, long long ay, long long bx, long long by, long long cx, long long cy) {
+    return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+}
+static WB_HD inline bool wb_tr_on(long long ax, long long ay, long long bx, long long by, long long px, long long py) {   // p on [a, b], given collinear
+    return (px >= (ax < bx ? ax : bx)) && (px <= (ax < bx ? bx : ax)) && (py >= (ay < by ? ay : by)) && (py <= (ay < by ? by : ay));
+}
+// do the closed segments [a, b] and [c, d] share a point? (exact: lattice coordinates)
+static WB_HD inline bool wb_tr_meet(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy) {
+    const long long o1 = wb_tr_orient(ax, ay, bx, by, cx, cy), o2 = wb_tr_orient(ax, ay, bx, by, dx, dy);
+    const long long o3 = wb_tr_orient(cx, cy, dx, dy, ax, ay), o4 = wb_tr_orient(cx, cy, dx, dy, bx, by);
+    if (((o1 > 0 && o2 < 0) || (o1 < 0 && o2 > 0)) && ((o3 > 0 && o4 < 0) || (o3 < 0 && o4 > 0))) return true;
+    if (o1 == 0 && wb_tr_on(ax, ay, bx, by, cx, cy)) return true;
+    if (o2 == 0 && wb_tr_on(ax, ay, bx, by, dx, dy)) return true;
+    if (o3 == 0 && wb_tr_on(cx, cy, dx, dy, ax, ay)) return true;
+    if (o4 == 0 && wb_tr_on(cx, cy, dx, dy, bx, by)) return true;
+    return false;
+}
+// squared distance of the point p to the segment [a, b], coordinates in degrees
+static WB_HD inline double wb_tr_point_seg_d2(double px, double py, double ax, double ay, double bx, double by) {
+    const double ux = bx - ax, uy = by - ay, wx = px - ax, wy = py - ay;
+    const double L = ux * ux + uy * uy;
+    double t = L > 0.0 ? (wx * ux + wy * uy) / L : 0.0;
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    const double ex = wx - t * ux, ey = wy - t * uy;
+    return ex * ex + ey * ey;
+}
+// squared distance of two lattice segments in degrees (sx, sy degrees per grid step); exactly 0 when they share a point
+static WB_HD inline double wb_tr_seg_seg_d2(int ax, int ay, int bx, int by, int cx, int cy, int dx, int dy, double sx, double sy) {
+    if (wb_tr_meet(ax, ay, bx, by, cx, cy, dx, dy)) return 0.0;
+    const double Ax = ax * sx, Ay = ay * sy, Bx = bx * sx, By = by * sy, Cx = cx * sx, Cy = cy * sy, Dx = dx * sx, Dy = dy * sy;
+    double d = wb_tr_point_seg_d2(Ax, Ay, Cx, Cy, Dx, Dy);
+    const double d2 = wb_tr_point_seg_d2(Bx, By, Cx, Cy, Dx, Dy), d3 = wb_tr_point_seg_d2(Cx, Cy, Ax, Ay, Bx, By), d4 = wb_tr_point_seg_d2(Dx, Dy, Ax, Ay, Bx, By);
+    d = d2 < d ? d2 : d; d = d3 < d ? d3 : d; d = d4 < d ? d4 : d;
+    return d;
+}
+// smallest squared distance between the rings of events i and j, in degrees^2 (all threads of the workgroup call it; best: one
+// LDS word holding the bit pattern of a non-negative double, which orders like the number)
+static WB_DEV inline double wb_track_pair_distance2(const WbTrackArgs& a, long long i, long long j, unsigned long long* best) {
+    const long long a0 = a.fedge0[i], na = a.fedge0[i + 1] - a0, b0 = a.fedge0[j], nb = a.fedge0[j + 1] - b0;
+    WB_SINGLE
+        const double inf = 1e300;
+        memcpy(best, &inf, 8);
+    WB_END_SINGLE
+    // (the other event's box, widened by the reach: an edge that lies outside it cannot be within reach of anything)
+    const double rx = a.reach / a.sx, ry = a.reach / a.sy;
+    const double jx0 = a.xmin[j] - rx, jx1 = a.xmax[j] + rx, jy0 = a.ymin[j] - ry, jy1 = a.ymax[j] + ry;
+    WB_PFOR(q, na * nb)
+        const long long ea = a0 + q / nb, eb = b0 + q % nb;
+        const int ax = a.fx0[ea], ay = a.fy0[ea], bx = a.fx1[ea], by = a.fy1[ea];
+        if (!((ax < jx0 && bx < jx0) || (ax > jx1 && bx > jx1) || (ay < jy0 && by < jy0) || (ay > jy1 && by > jy1))) {
+            const double d2 = wb_tr_seg_seg_d2(ax, ay, bx, by, a.fx0[eb], a.fy0[eb], a.fx1[eb], a.fy1[eb], a.sx, a.sy);
+            unsigned long long bits;
+            memcpy(&bits, &d2, 8);
+            if (bits < *((volatile unsigned long long*)best)) wb_atomic_min(best, bits);
+        }
+    WB_END_PFOR
+    double out;
+    memcpy(&out, best, 8);
+    return out;
+}
+
 // one workgroup per event i: its partners are the later events j (date order) with 0 < dt <= time_range
 WB_KERNEL(wb_k_track_pairs, WbTrackArgs a) {
     WB_SHARED(long long, jr, 2);
     WB_SHARED(double, term, WB_TRACK_MAXROWS);
     WB_SHARED(unsigned long long, cnts, 3);
+    WB_SHARED(unsigned long long, dbest, 1);
     for (long long i = WB_BLOCK_ID; i < a.n; i += WB_GRID_DIM) {
         WB_SINGLE
             long long lo = i + 1, hi = a.n;                            // first j with dt > 0
@@ -313,6 +389,27 @@ WB_KERNEL(wb_k_track_pairs, WbTrackArgs a) {
                     wb_atomic_add(&cnts[2], 1ull);
                 }
             WB_END_PFOR
+        } else if (a.reach > 0.0) {
+            for (long long j = j0; j < j1; ++j) {
+                // boxes further apart than the reach: nothing to do (block-uniform)
+                const int gx = (a.xmin[i] > a.xmin[j] ? a.xmin[i] : a.xmin[j]) - (a.xmax[i] < a.xmax[j] ? a.xmax[i] : a.xmax[j]);
+                const int gy = (a.ymin[i] > a.ymin[j] ? a.ymin[i] : a.ymin[j]) - (a.ymax[i] < a.ymax[j] ? a.ymax[i] : a.ymax[j]);
+                const double bx = gx > 0 ? gx * a.sx : 0.0, by = gy > 0 ? gy * a.sy : 0.0;
+                if (bx * bx + by * by >= a.reach * a.reach) continue;
+                bool boxes = false;
+                const double inter = wb_track_pair_overlap(a, i, j, term, &boxes);        // one inside the other: no edge need come near
+                const double d2 = inter > 0.0 ? 0.0 : wb_track_pair_distance2(a, i, j, dbest);
+                WB_SINGLE
+                    cnts[1] += 1;
+                    const double r2 = a.reach * a.reach, lo = a.reach * (1.0 - WB_TRACK_ARC_SLACK);
+                    if (d2 < r2) {                                     // the buffered polygons share interior points
+                        wb_uf_union(a.parent, a.orig[i], a.orig[j]);
+                        cnts[2] += 1;
+                        if (!(inter > 0.0)) wb_atomic_add(&a.stats[4], 1ull);
+                        if (d2 >= lo * lo) wb_atomic_add(&a.stats[5], 1ull);
+                    }
+                WB_END_SINGLE
+            }
         } else {
             for (long long j = j0; j < j1; ++j) {
                 bool boxes = false;

@@ -342,7 +342,13 @@ def resident_inputs(ctx, field, intensity, block):
     _purge_dead(ctx)
     resident, _ = _caches(ctx)
     arrs = [a for a in (field, intensity) if a is not None]
-    keys = [_array_key(a, ctx) for a in arrs]
+    if len(arrs) == 2 and arrs[0].nbytes >= (64 << 20):
+        # the two cubes' fingerprints side by side (wb_fingerprint releases the GIL; each uses its own host threads)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as pool:
+            keys = list(pool.map(lambda a: _array_key(a, ctx), arrs))
+    else:
+        keys = [_array_key(a, ctx) for a in arrs]
     fresh = [k not in resident for k in keys]
     nt = field.shape[0]
     if not any(fresh) or not PIPELINED_UPLOAD or block >= nt:

@@ -121,15 +121,16 @@ def _axis_lattice(coords, given=None):
     return float(u[0]), _float_gcd(np.diff(u))
 
 
-def lattice_rings(events):
-    """The event polygons as integer rings on the data's grid.  transform_polygons (index_utils.py:129-184) puts every
+def lattice_rings(events, with_steps=False):
+    """The event polygons as integer rings on the data's grid (``with_steps``: and the grid's (dlon, dlat)).  transform_polygons (index_utils.py:129-184) puts every
     vertex on a grid point (it truncates to indices, :135), so this loses nothing for frames the index functions made;
     the grid comes from ``events.attrs["wavebreaking_grid"]`` (set by this package's index functions) or is inferred from
     the coordinates.  Raises ValueError for polygons that are not on a regular grid."""
     rings = [_rings(g) for g in events["geometry"]]
     flat = [r for rs in rings for r in rs]
     if not flat:
-        return [[] for _ in rings]
+        return ([[] for _ in rings], (1.0, 1.0)) if with_steps else [[] for _ in rings]
+    steps = []
     allv = np.concatenate(flat)
     grid = getattr(events, "attrs", {}).get("wavebreaking_grid")
     out_axes = []
@@ -142,6 +143,7 @@ def lattice_rings(events):
             raise ValueError("track_events(method='by_overlap') needs polygons whose vertices lie on a regular grid "
                              "(as the index functions produce them); these do not")
         out_axes.append(np.rint(idx).astype(np.int32))
+        steps.append(step)
     xy = np.c_[out_axes[0], out_axes[1]]
     out, pos = [], 0
     for rs in rings:
@@ -150,7 +152,7 @@ def lattice_rings(events):
             mine.append(xy[pos:pos + len(r)])
             pos += len(r)
         out.append(mine)
-    return out
+    return (out, (steps[0], steps[1])) if with_steps else out
 
 
 @check_argument_types(["events"], [_pandas_frame_type()])
@@ -172,9 +174,12 @@ def track_events(events, time_range=None, method="by_overlap", buffer=0, overlap
             * "by_overlap": same label if the polygons overlap at step t and t + time_range
             * "by_distance": same label if the centres of mass are closer than "distance"
         buffer : float, optional
-            buffer around the event polygons in degrees for "by_overlap"; only 0 is built here (a buffered polygon is no
-            longer a grid polygon and its area depends on GEOS' arc approximation) -- anything else raises
-            NotImplementedError
+            buffer around the event polygons in degrees for "by_overlap".  0: exact intersection-over-union of the grid
+            polygons.  > 0 with ``overlap=0`` (the default): a pair is linked when its buffered polygons overlap at all,
+            i.e. when the polygons are closer than 2 * buffer degrees (GEOS' round buffer taken as a disc: pairs within
+            0.24 % of that distance, where GEOS' inscribed arcs may fall short, are counted in
+            ``attrs["track_stats"]["pairs_in_arc_band"]``).  > 0 with ``overlap > 0`` needs the AREA of buffered polygons
+            (GEOS' arc approximation) and raises NotImplementedError, as does a negative buffer
         overlap : float, optional
             minimum intersection-over-union for "by_overlap"
         distance : int or float, optional
@@ -205,10 +210,18 @@ def track_events(events, time_range=None, method="by_overlap", buffer=0, overlap
         com = np.asarray(list(events["com"]), dtype=np.float64).reshape(len(events), 2)
         label, _, stats = ctx.track_events(dates, method, time_range, distance=distance, com=com)
     else:
-        if buffer != 0:
-            raise NotImplementedError("track_events(method='by_overlap'): only buffer=0 is built (exact areas of grid "
-                                      "polygons); buffered polygons need GEOS' arc approximation")
-        label, _, stats = ctx.track_events(dates, method, time_range, overlap=overlap, rings_per_event=lattice_rings(events))
+        if buffer < 0 or (buffer > 0 and overlap != 0):
+            raise NotImplementedError("track_events(method='by_overlap'): buffer > 0 is built for overlap=0 only (do the buffered "
+                                      "polygons overlap at all = are the polygons closer than 2 * buffer); a ratio of AREAS of "
+                                      "buffered polygons needs GEOS' arc approximation, a negative buffer its erosion")
+        if buffer > 0:                                                      # events.py:203-214 with overlap == 0
+            rings, steps = lattice_rings(events, with_steps=True)
+            label, stats = ctx.track_events_buffered(dates, time_range, buffer, steps, rings_per_event=rings)
+            if stats["pairs_in_arc_band"]:
+                logger.warning("track_events(buffer=%g): %d pairs lie within 0.24 %% of the linking distance, where GEOS' polygonal "
+                               "arcs can decide differently from the disc used here" % (buffer, stats["pairs_in_arc_band"]))
+        else:
+            label, _, stats = ctx.track_events(dates, method, time_range, overlap=overlap, rings_per_event=lattice_rings(events))
         if stats["polygons_not_simple"]:
             # the reference repairs such geometries with buffer(0).make_valid() before it intersects them (events.py:203-204):
             # GEOS, not restated here -- their regions are taken by the even-odd rule and their labels may differ
