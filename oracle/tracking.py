@@ -191,26 +191,70 @@ def _seg_seg_d2_exact(a, b, c, d):
     return min(pt_seg(a, c, d), pt_seg(b, c, d), pt_seg(c, a, b), pt_seg(d, a, b))
 
 
+def _edges(rings):
+    out = []
+    for r in rings:
+        v = np.asarray(r, dtype=np.int64).reshape(-1, 2)
+        if len(v):
+            out.append(np.c_[v, np.roll(v, -1, axis=0)])
+    return np.concatenate(out) if out else np.zeros((0, 4), dtype=np.int64)
+
+
 def rings_distance2(rings_a, rings_b, sx=1, sy=1):
     """squared planar distance, in degrees^2, of two events given as lattice rings on a grid with sx / sy degrees per step:
     0 if the closed regions share a point (they overlap, touch, or one lies inside the other), else the smallest distance
-    between their boundaries.  Exact (Fractions of the floats sx, sy)."""
+    between their boundaries.  Exact: whether two edges meet is decided in integers for every pair of edges; the minimum
+    over the others is taken in Fractions over the pairs whose float64 distance comes within 1e-9 of the smallest (the
+    float evaluation is good to ~1e-13: the exact minimum is among them)."""
     if overlap_area(rings_a, rings_b) > 0:
         return Fraction(0)
+    ea, eb = _edges(rings_a), _edges(rings_b)
+    if not len(ea) or not len(eb):
+        return None
+    A = ea[:, None, :]
+    B = eb[None, :, :]
+
+    def orient(px, py, qx, qy, rx, ry):
+        return (qx - px) * (ry - py) - (qy - py) * (rx - px)
+
+    def on(px, py, qx, qy, rx, ry):
+        return (np.minimum(px, qx) <= rx) & (rx <= np.maximum(px, qx)) & (np.minimum(py, qy) <= ry) & (ry <= np.maximum(py, qy))
+    o1 = orient(A[..., 0], A[..., 1], A[..., 2], A[..., 3], B[..., 0], B[..., 1])
+    o2 = orient(A[..., 0], A[..., 1], A[..., 2], A[..., 3], B[..., 2], B[..., 3])
+    o3 = orient(B[..., 0], B[..., 1], B[..., 2], B[..., 3], A[..., 0], A[..., 1])
+    o4 = orient(B[..., 0], B[..., 1], B[..., 2], B[..., 3], A[..., 2], A[..., 3])
+    meet = ((o1 * o2 < 0) & (o3 * o4 < 0)) \
+        | ((o1 == 0) & on(A[..., 0], A[..., 1], A[..., 2], A[..., 3], B[..., 0], B[..., 1])) \
+        | ((o2 == 0) & on(A[..., 0], A[..., 1], A[..., 2], A[..., 3], B[..., 2], B[..., 3])) \
+        | ((o3 == 0) & on(B[..., 0], B[..., 1], B[..., 2], B[..., 3], A[..., 0], A[..., 1])) \
+        | ((o4 == 0) & on(B[..., 0], B[..., 1], B[..., 2], B[..., 3], A[..., 2], A[..., 3]))
+    if meet.any():
+        return Fraction(0)
+    fa = ea.astype(np.float64) * np.array([sx, sy, sx, sy], dtype=np.float64)
+    fb = eb.astype(np.float64) * np.array([sx, sy, sx, sy], dtype=np.float64)
+
+    def pt_seg(px, py, qx, qy, rx, ry):
+        ux, uy, wx, wy = rx - qx, ry - qy, px - qx, py - qy
+        L = ux * ux + uy * uy
+        t = np.clip(np.where(L > 0, (wx * ux + wy * uy) / np.where(L > 0, L, 1.0), 0.0), 0.0, 1.0)
+        ex, ey = wx - t * ux, wy - t * uy
+        return ex * ex + ey * ey
+    FA, FB = fa[:, None, :], fb[None, :, :]
+    d = np.minimum(np.minimum(pt_seg(FA[..., 0], FA[..., 1], FB[..., 0], FB[..., 1], FB[..., 2], FB[..., 3]),
+                              pt_seg(FA[..., 2], FA[..., 3], FB[..., 0], FB[..., 1], FB[..., 2], FB[..., 3])),
+                   np.minimum(pt_seg(FB[..., 0], FB[..., 1], FA[..., 0], FA[..., 1], FA[..., 2], FA[..., 3]),
+                              pt_seg(FB[..., 2], FB[..., 3], FA[..., 0], FA[..., 1], FA[..., 2], FA[..., 3])))
+    near = np.argwhere(d <= d.min() * (1 + 1e-9))
     fx, fy = Fraction(sx), Fraction(sy)
     best = None
-    for ra in rings_a:
-        pa = [(Fraction(int(x)) * fx, Fraction(int(y)) * fy) for x, y in np.asarray(ra)]
-        for rb in rings_b:
-            pb = [(Fraction(int(x)) * fx, Fraction(int(y)) * fy) for x, y in np.asarray(rb)]
-            for i in range(len(pa)):
-                a, b = pa[i], pa[(i + 1) % len(pa)]
-                for j in range(len(pb)):
-                    d2 = _seg_seg_d2_exact(a, b, pb[j], pb[(j + 1) % len(pb)])
-                    if best is None or d2 < best:
-                        best = d2
-                        if best == 0:
-                            return best
+    for i, j in near[:64]:
+        a = (Fraction(int(ea[i, 0])) * fx, Fraction(int(ea[i, 1])) * fy)
+        b = (Fraction(int(ea[i, 2])) * fx, Fraction(int(ea[i, 3])) * fy)
+        c = (Fraction(int(eb[j, 0])) * fx, Fraction(int(eb[j, 1])) * fy)
+        e = (Fraction(int(eb[j, 2])) * fx, Fraction(int(eb[j, 3])) * fy)
+        d2 = _seg_seg_d2_exact(a, b, c, e)
+        if best is None or d2 < best:
+            best = d2
     return best
 
 
@@ -225,7 +269,7 @@ def buffered_overlap_check(rings, pairs, buffer, steps=(1, 1)):
     band = np.zeros(len(pairs), dtype=bool)
     for n, (i, j) in enumerate(pairs):
         d2 = rings_distance2(rings[i], rings[j], steps[0], steps[1])
-        out[n] = d2 < reach * reach
+        out[n] = d2 is not None and d2 < reach * reach
         band[n] = out[n] and d2 >= lo * lo
     return out, band
 

@@ -34,6 +34,12 @@ def case(seed):
                 got = wb.track_events(ev, time_range=6, method="by_overlap", overlap=ov)
                 if got.index.tolist() != order.tolist() or got.label.tolist() != want[order].tolist():
                     return (seed, "FAIL " + fn.__name__ + " overlap %g" % ov)
+            # buffer > 0 with the default overlap: closer than 2 * buffer degrees (the path's own, seam-split polygons)
+            buf = float(rng.choice([0.5, 1.0, 2.5])) * dl
+            want, order, pairs, check = otrack.track_events(dates, rings=rings, time_range=6.0, method="by_overlap", buffer=buf, steps=(dl, dl))
+            got = wb.track_events(ev, time_range=6, method="by_overlap", buffer=buf)
+            if got.index.tolist() != order.tolist() or got.label.tolist() != want[order].tolist():
+                return (seed, "FAIL " + fn.__name__ + " buffer %g" % buf)
             com = np.asarray(list(ev["com"]), dtype=np.float64)
             want, order, pairs, check = otrack.track_events(dates, com=com, time_range=6.0, method="by_distance", distance=1500.0)
             got = wb.track_events(ev, time_range=6, method="by_distance", distance=1500.0)
