@@ -106,7 +106,7 @@ def main():
     from wavebreaking_amd import distributed as wd
 
     from wavebreaking_amd.pipeline import BatchPipeline
-    pipe = BatchPipeline(local, depth=a.streams)        # a.streams batches in flight, one context (stream + thread) each
+    pipe = BatchPipeline(local, depth=a.streams)        # a.streams batches in flight, one context (stream + thread) each (WB_PIPE_STAGGER=1: phases exclusive)
     ctx = pipe.contexts[0]
     for c in pipe.contexts:
         c.set_option("scan_split", a.scan_split)

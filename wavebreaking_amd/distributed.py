@@ -234,47 +234,46 @@ def _gather_tensors(rows, vx, vy, dist, dst, dev):
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     ne, nv = int(rows.shape[0]), int(vx.shape[0])
-    if True:                                                # (one block: the tensors above are the caller's)
-        if dev.type != "cuda":                              # dry runs of the N > 1 logic over gloo: CPU tensors
-            rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
-        counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
-        allc = [torch.zeros_like(counts) for _ in range(world)]
-        dist.all_gather(allc, counts)
-        allc = torch.stack(allc).cpu().numpy()
-        me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
-        rbuf = torch.zeros((max(me, 1), 20), dtype=torch.float64, device=dev)
-        vbuf = torch.zeros((2, max(mv, 1)), dtype=torch.int32, device=dev)
-        if ne:
-            rbuf[:ne] = rows
-        if nv:
-            vbuf[0, :nv] = vx
-            vbuf[1, :nv] = vy
-        rout = [torch.zeros_like(rbuf) for _ in range(world)] if rank == dst else None
-        vout = [torch.zeros_like(vbuf) for _ in range(world)] if rank == dst else None
-        dist.gather(rbuf, rout, dst=dst)
-        dist.gather(vbuf, vout, dst=dst)
-        if rank != dst:
-            return None                                     # (leaving the block waits for the staging copies and the sends)
-        tot_e, tot_v = int(allc[:, 0].sum()), int(allc[:, 1].sum())
-        if dev.type != "cuda":
-            rcat = torch.cat([rout[r][: int(allc[r, 0])] for r in range(world)]).numpy()
-            vcat = torch.cat([vout[r][:, : int(allc[r, 1])] for r in range(world)], dim=1).numpy()
-            return rcat, vcat[0], vcat[1]
-        # the one copy to the host: every rank's valid part straight into pinned memory
-        hr = _pinned_host("rows", (max(tot_e, 1), 20), torch.float64)
-        hx = _pinned_host("vx", (max(tot_v, 1),), torch.int32)
-        hy = _pinned_host("vy", (max(tot_v, 1),), torch.int32)
-        oe = ov = 0
-        for r in range(world):
-            k, v = int(allc[r, 0]), int(allc[r, 1])
-            if k:
-                hr[oe:oe + k].copy_(rout[r][:k], non_blocking=True)
-            if v:
-                hx[ov:ov + v].copy_(vout[r][0, :v], non_blocking=True)
-                hy[ov:ov + v].copy_(vout[r][1, :v], non_blocking=True)
-            oe += k
-            ov += v
-        torch.cuda.current_stream().synchronize()
+    if dev.type != "cuda":                              # dry runs of the N > 1 logic over gloo: CPU tensors
+        rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
+    counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts)
+    allc = torch.stack(allc).cpu().numpy()
+    me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
+    rbuf = torch.zeros((max(me, 1), 20), dtype=torch.float64, device=dev)
+    vbuf = torch.zeros((2, max(mv, 1)), dtype=torch.int32, device=dev)
+    if ne:
+        rbuf[:ne] = rows
+    if nv:
+        vbuf[0, :nv] = vx
+        vbuf[1, :nv] = vy
+    rout = [torch.zeros_like(rbuf) for _ in range(world)] if rank == dst else None
+    vout = [torch.zeros_like(vbuf) for _ in range(world)] if rank == dst else None
+    dist.gather(rbuf, rout, dst=dst)
+    dist.gather(vbuf, vout, dst=dst)
+    if rank != dst:
+        return None                                     # (leaving the block waits for the staging copies and the sends)
+    tot_e, tot_v = int(allc[:, 0].sum()), int(allc[:, 1].sum())
+    if dev.type != "cuda":
+        rcat = torch.cat([rout[r][: int(allc[r, 0])] for r in range(world)]).numpy()
+        vcat = torch.cat([vout[r][:, : int(allc[r, 1])] for r in range(world)], dim=1).numpy()
+        return rcat, vcat[0], vcat[1]
+    # the one copy to the host: every rank's valid part straight into pinned memory
+    hr = _pinned_host("rows", (max(tot_e, 1), 20), torch.float64)
+    hx = _pinned_host("vx", (max(tot_v, 1),), torch.int32)
+    hy = _pinned_host("vy", (max(tot_v, 1),), torch.int32)
+    oe = ov = 0
+    for r in range(world):
+        k, v = int(allc[r, 0]), int(allc[r, 1])
+        if k:
+            hr[oe:oe + k].copy_(rout[r][:k], non_blocking=True)
+        if v:
+            hx[ov:ov + v].copy_(vout[r][0, :v], non_blocking=True)
+            hy[ov:ov + v].copy_(vout[r][1, :v], non_blocking=True)
+        oe += k
+        ov += v
+    torch.cuda.current_stream().synchronize()
     # rows are (streamers, overturnings, cutoffs) per rank, rank order = time order
     return hr[:tot_e].numpy(), hx[:tot_v].numpy(), hy[:tot_v].numpy()
 

@@ -80,12 +80,21 @@ class BatchPipeline:
         # rather than beside its twin -- and, taking equally long per batch, stay so (option offset_start, default on)
         started = [threading.Event() for _ in range(d)]
 
+        l1, l2 = self._locks if self._locks is not None else (None, None)
+
         def both(ctx, k):
             if self.offset_start and 0 < k < d:
                 started[k - 1].wait()
-            b = contours(ctx, k)
+            if l1 is not None:                      # set_stagger: a phase is entered by one batch at a time
+                with l1:
+                    b = contours(ctx, k)
+            else:
+                b = contours(ctx, k)
             if k < d:
                 started[k].set()
+            if l2 is not None:
+                with l2:
+                    return b.max_nux(), indices(ctx, k, b, full_width)
             return b.max_nux(), indices(ctx, k, b, full_width)
         fut, out, local = {}, [], 0
         for k in range(min(d, n)):
