@@ -1,0 +1,21 @@
+#!/bin/bash
+# the field scan on a stream of the highest priority (option scan_priority): value and the scan's share of the HBM peak
+cd "$(dirname "$0")/.."
+one() {  # label, streams, extra env ...
+  label=$1; st=$2; shift 2
+  env "$@" timeout 300 python bench.py --steps 40 --warmup 6 --cpu-sample 0 --e2e-steps 0 --stagger-steps 0 --streams $st > /tmp/ab.json 2> /tmp/ab.err || tail -5 /tmp/ab.err
+  python - "$label" $st <<'PY'
+import json, sys
+d = json.load(open("/tmp/ab.json"))
+s = d["stage_ms"]
+keys = ("scan", "scan_build", "trace_link", "trace_rank", "trace_finish", "streamer_pairs", "streamer_f1", "streamer_f234", "props")
+print(sys.argv[1], "streams", sys.argv[2], "value %d  ms/step %.3f frac %.3f alone %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["frac_alone"]), " ".join("%s %.2f" % (k, s.get(k, -1)) for k in keys), flush=True)
+PY
+}
+for rep in 1 2 3; do
+one plain 2 WB_X=1
+one prio 2 WB_BENCH_OPTS=scan_priority=1
+one prio_excl 2 WB_BENCH_OPTS=scan_priority=1,scan_exclusive=1
+one plain 1 WB_X=1
+one prio 1 WB_BENCH_OPTS=scan_priority=1
+done

@@ -339,6 +339,11 @@ static int run_phase1(wb_batch* b) {
             long long mwg = slots * (ctx->scan_grid_mult > 0 ? ctx->scan_grid_mult : 1);
             if (mwg > (long long)p.nt * sa.nbands) mwg = (long long)p.nt * sa.nbands;
             const dim3 mgrid((unsigned)mwg), sblock(64 * b->nwork_strips), bgrid((unsigned)items);
+            if (ctx->scan_priority) {                      // (the stage's events go where the kernel goes)
+                b->timer.drop_last();
+                prio_begin(ctx);
+                b->timer.begin(ctx, "scan");
+            }
 #define WB_STREAM_F32(N) \
             if (!sa.halo_rows) hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6, false>), mgrid, sblock, slds, ctx->stream, sa); \
             else switch (variant) { \
@@ -363,6 +368,7 @@ static int run_phase1(wb_batch* b) {
 #undef WB_SCAN_N
             { const hipError_t le = hipGetLastError(); if (le != hipSuccess) return wb_fail(ctx, std::string("wb_k_scan_stream launch failed: ") + hipGetErrorString(le)); }
             b->timer.end(ctx);
+            prio_end(ctx);
             wb_scan_gate_leave(ctx);
             b->timer.begin(ctx, "scan_build");
 #define WB_BUILD_LAUNCH(T, N) hipLaunchKernelGGL((wb_k_scan_build<T, N>), bgrid, block, 0, ctx->stream, sa)
@@ -1274,7 +1280,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
-                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + 64, st);
+                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + (size_t)(st.f234_cap / WB_BLK + 1) * 20 + 64, st);
                 WB_LAUNCH(wb_k_streamer_ties, 1, 64, st);      // one wave: check_groups' exact ties (nearly always none)
                 b->timer.end(ctx);
             }
@@ -1745,6 +1751,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_exclusive")) { ctx->scan_exclusive = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "scan_priority")) { ctx->scan_priority = value ? 1 : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }

@@ -355,24 +355,32 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
     double* tab = a.ptab + po;
     int* bbx = a.bbx + 4 * ((po >> 5) + s);
     const int nblk = (N + WB_BLK - 1) / WB_BLK;
-    WB_PFOR(i, N)
-        const uint32_t p1 = pts[i];
+    // (WB_PFOR_B: four points with their predecessors requested, then -- straight-line, behind them -- the four table values;
+    //  written one point per iteration the loop waited twice per point, nine times over for a contour of 2 400 points)
+    uint32_t p1a[WB_PFOR_B_WIDTH], p0a[WB_PFOR_B_WIDTH];
+    double da[WB_PFOR_B_WIDTH];
+    WB_PFOR_B(i, ic, u, N)
+        const uint32_t p1 = pts[ic], p0 = pts[ic > 0 ? ic - 1 : 0];
+        p1a[u] = p1;
+        p0a[u] = p0;
+        const int y1 = wb_pt_y(p1), y0 = wb_pt_y(p0), dy = y1 - y0, dx = wb_pt_x(p1) - wb_pt_x(p0);        // dx in the extended coordinates
+        // a step to a neighbouring grid point: the host's value (bit for bit the reference's), looked up from the
+        // lower of the two points (the lower-left one of a row step)
+        const bool step = a.on_tab && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1 && (dx | dy);
+        const int yb = dy < 0 ? y1 : y0;                                         // base row
+        const int xb = dy < 0 ? wb_pt_x(p1) : (dy > 0 ? wb_pt_x(p0) : (dx > 0 ? wb_pt_x(p0) : wb_pt_x(p1)));
+        const int dxs = dy < 0 ? -dx : dx;                                       // column step seen from the base point
+        const int kind = dy == 0 ? 0 : (dxs == 0 ? 1 : (dxs > 0 ? 2 : 3));
+        const size_t idx = step ? ((size_t)yb * a.nlon + (xb % a.nlon)) * 4 + kind : 0;
+        da[u] = a.on_tab ? a.on_tab[idx] : 0.0;
+    WB_PFOR_B_USE(i, u)
+        const uint32_t p1 = p1a[u], p0 = p0a[u];
         const int y1 = wb_pt_y(p1), x1 = wb_pt_x(p1) % a.nlon;
         double d = 0.0;
         if (i > 0) {
-            const uint32_t p0 = pts[i - 1];
-            const int y0 = wb_pt_y(p0), dy = y1 - y0, dx = wb_pt_x(p1) - wb_pt_x(p0);        // dx in the extended coordinates
-            if (a.on_tab && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1 && (dx | dy)) {
-                // a step to a neighbouring grid point: the host's value (bit for bit the reference's), looked up from the
-                // lower of the two points (the lower-left one of a row step)
-                const int yb = dy < 0 ? y1 : y0;                                         // base row
-                const int xb = dy < 0 ? wb_pt_x(p1) : (dy > 0 ? wb_pt_x(p0) : (dx > 0 ? wb_pt_x(p0) : wb_pt_x(p1)));
-                const int dxs = dy < 0 ? -dx : dx;                                       // column step seen from the base point
-                const int kind = dy == 0 ? 0 : (dxs == 0 ? 1 : (dxs > 0 ? 2 : 3));
-                d = a.on_tab[((size_t)yb * a.nlon + (xb % a.nlon)) * 4 + kind];
-            } else {
-                d = wb_haversine(a.lat_rad[y0], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[y1], a.lon_rad[x1]) * 6371.0;
-            }
+            const int y0 = wb_pt_y(p0), dy = y1 - y0, dx = wb_pt_x(p1) - wb_pt_x(p0);
+            if (a.on_tab && dy >= -1 && dy <= 1 && dx >= -1 && dx <= 1 && (dx | dy)) d = da[u];
+            else d = wb_haversine(a.lat_rad[y0], a.lon_rad[wb_pt_x(p0) % a.nlon], a.lat_rad[y1], a.lon_rad[x1]) * 6371.0;
         }
         on[i] = d;
         if (a.ptab) {                                         // per-point table of the tiled all-pairs kernel (absent when every
@@ -382,23 +390,33 @@ WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
             tab[3 * a.npts_total + i] = a.slam2[x1];
             tab[4 * a.npts_total + i] = a.clam2[x1];
         }
-    WB_END_PFOR
+    WB_END_PFOR_B
+    // the boxes: a lane requests all points of its tile / block before it compares any (an index past the contour's end is
+    // clamped to its last point, which belongs to the box that asks for it)
     int* tbx = a.tbx + 4 * ((po >> 4) + s);
     WB_PFOR(tl, (N + 15) / 16)
+        const int lo = (int)tl * 16;
+        uint32_t q[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) q[e] = pts[lo + e < N ? lo + e : N - 1];
         int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
-        const int lo = (int)tl * 16, hi = lo + 16 < N ? lo + 16 : N;
-        for (int i = lo; i < hi; ++i) {
-            const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int x = wb_pt_x(q[e]), y = wb_pt_y(q[e]);
             x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1;
             y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
         }
         tbx[4 * tl + 0] = x0; tbx[4 * tl + 1] = x1; tbx[4 * tl + 2] = y0; tbx[4 * tl + 3] = y1;
     WB_END_PFOR
     WB_PFOR(b, nblk)
+        const int lo = (int)b * WB_BLK;                        // points lo .. lo + WB_BLK: one point past the block
+        uint32_t q[WB_BLK + 1];
+#pragma unroll
+        for (int e = 0; e <= WB_BLK; ++e) q[e] = pts[lo + e < N ? lo + e : N - 1];
         int x0 = 0x7FFFFFFF, x1 = -1, y0 = 0x7FFFFFFF, y1 = -1;
-        const int lo = (int)b * WB_BLK, hi = lo + WB_BLK < N - 1 ? lo + WB_BLK : N - 1;   // one point past the block
-        for (int i = lo; i <= hi; ++i) {
-            const int x = wb_pt_x(pts[i]), y = wb_pt_y(pts[i]);
+#pragma unroll
+        for (int e = 0; e <= WB_BLK; ++e) {
+            const int x = wb_pt_x(q[e]), y = wb_pt_y(q[e]);
             x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1;
             y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
         }
@@ -1107,6 +1125,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #ifndef WB_F234_OCC
 #define WB_F234_OCC 6               // waves per SIMD the register allocation leaves room for (6: 80 registers, three workgroups per CU)
 #endif
+#define WB_F234_R4 256             // survivors whose routine-4 arrays are held in LDS
 #define WB_F234_CAND 512           // candidates of one row collected after its first chord failed
 #define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
 WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a) {
@@ -1134,11 +1153,14 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     WB_DYN_SHARED(uint32_t, lpts, a.f234_cap);
     WB_DYN_SHARED(int, lrmax, a.f234_cap);       // per row: largest ind2 among its alive candidates
     WB_DYN_SHARED(int, rend, a.f234_cap);        // per row: its alive candidates, then the end of its bucket in bk
+    WB_DYN_SHARED(int, lbb, 4 * (a.f234_cap / WB_BLK + 1));   // boxes of the blocks of WB_BLK segments (wb_k_streamer_prep: points 32 b .. 32 b + 32)
+    WB_DYN_SHARED(int, hitb, a.f234_cap / WB_BLK + 1);        // the blocks whose box meets the chord's (chord test)
+    WB_SHARED(uint32_t, rowbits, WB_F234_LPTS / 32);   // bit i: row i holds an alive candidate that the sweep can still ask about
     WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
     WB_SHARED(int, csort, WB_F234_CAND);
     WB_SHARED(uint32_t, hq, WB_F234_BATCH);     // far end points of the chords of a batch
     WB_SHARED(uint32_t, hitm, 1);               // ... and which of them met the contour
-    WB_SHARED(int, sh, 10);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate
+    WB_SHARED(int, sh, 13);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate, [10..11] blocks met by a chord, [12] by a batch of chords
                                          // (words alternate between two slots: a slot is rewritten two barriers after its last read)
     const int stage = a.stage[s];
     const int nal = a.nalive[s];
@@ -1147,14 +1169,18 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     int* rmax = in_lds ? lrmax : a.rowmx + a.poff[s];
     const int nw = (N + 31) >> 5;
     WB_STAMP_BEGIN
+    const int nblk = (N + WB_BLK - 1) / WB_BLK;
     WB_PFOR(i, N)
         if (in_lds) { lpts[i] = gpts[i]; rend[i] = 0; }
         rmax[i] = -1;
+        if (in_lds && i < 4 * nblk) lbb[i] = a.bbx[4 * ((a.poff[s] >> 5) + s) + i];
+        if (in_lds && i < nw) rowbits[i] = 0u;
     WB_END_PFOR
     WB_SINGLE
     sh[2] = 0;
     sh[3] = 0x7FFFFFFF; sh[4] = 0x7FFFFFFF;     // search results of even / odd iterations
     sh[5] = 0; sh[6] = 0;                       // hit flags of even / odd chord tests
+    sh[10] = 0; sh[11] = 0; sh[12] = 0;         // blocks met by even / odd chord tests, by a batch
     WB_END_SINGLE
     WB_STAMP(a.ctl, 0);
     if (stage == 1 && nal > 1) {
@@ -1198,6 +1224,9 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                 for (int u = 0; u < 4; ++u)
                     if (al[u]) bk[wb_atomic_add(&rend[(int)(pr[u] >> 32)], 1)] = (int)(pr[u] & 0xFFFFFFFFull);
             WB_END_PFOR
+            WB_PFOR(i, N)
+                if (rmax[i] >= 0) wb_atomic_or(&rowbits[i >> 5], 1u << (i & 31));
+            WB_END_PFOR
         }
         WB_STAMP(a.ctl, 1);
         // The sweep.  M (largest ind2 kept so far), the next row and the survivor count are the same in every lane and
@@ -1209,12 +1238,32 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             // the next row at or after `cur` whose largest candidate is above M: a lane per row, WB_NT rows per pass (the next
             // row is nearly always among the first few; a bitmap of non-empty rows walked bit by bit, as this was until
             // round 3, cost a dependent LDS read per set bit: 2.5 us per step, as much as the chord test itself)
+            if (in_lds) {
+                // ... found in ONE pass whatever the distance to it: a lane per word of the bitmap of rows that hold candidates
+                // walks its word's bits from `cur` on (a row whose largest candidate is not above M never will be asked about
+                // again -- M only grows -- and loses its bit); the contour with 50 000 pairs has its next row thousands of
+                // points away, eight passes of the 512-row search with a barrier each
+                WB_PFOR(w, nw)
+                    if ((int)w >= (cur >> 5)) {
+                        uint32_t bits = rowbits[w], dead = 0u;
+                        if ((int)w == (cur >> 5)) bits &= ~0u << (cur & 31);
+                        while (bits) {
+                            const int i = (int)w * 32 + wb_ctz32(bits);
+                            if (rmax[i] > M) { wb_atomic_min(&sh[fs], i); break; }
+                            dead |= bits & (0u - bits);
+                            bits &= bits - 1u;
+                        }
+                        if (dead) rowbits[w] &= ~dead;                    // (this lane is the word's only writer during the sweep)
+                    }
+                WB_END_PFOR
+            } else {
             for (int base = cur; base < N; base += WB_NT) {
                 WB_PFOR(t, WB_NT)
                     const int i = base + (int)t;
                     wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
                 WB_END_PFOR
                 if (sh[fs] != 0x7FFFFFFF) break;
+            }
             }
             const int row = sh[fs];
             WB_STAMP(a.ctl, 4);
@@ -1224,10 +1273,30 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             int bound = 0x7FFFFFFF;
             for (;;) {
                 // routine 2 for this one chord: does the open chord meet the contour's interior? (all lanes, all segments)
-                const int hf = 5 + (ntest & 1);
+                const int hf = 5 + (ntest & 1), hc = 10 + (ntest & 1);
                 ++ntest;
                 const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]), qx = wb_pt_x(pts[jn]), qy = wb_pt_y(pts[jn]);
                 const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                if (in_lds) {
+                    // a chord spans a few dozen columns of a contour that goes around the globe: first the blocks of 32 segments
+                    // whose box meets the chord's (a lane per block), then the segments of those blocks only -- one pass of the
+                    // workgroup instead of one per 512 segments of the contour
+                    WB_PFOR(b, nblk)
+                        if (b == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; sh[10 + (ntest & 1)] = 0; }   // the next step's / test's slots
+                        const int* bb = lbb + 4 * b;
+                        if (!(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0)) hitb[wb_atomic_add(&sh[hc], 1)] = (int)b;
+                    WB_END_PFOR
+                    const int nh = sh[hc];
+                    WB_PFOR(t, nh * WB_BLK)
+                        const int m = hitb[t >> 5] * WB_BLK + ((int)t & (WB_BLK - 1));
+                        if (m < N - 1) {
+                            const uint32_t pa = pts[m], pb = pts[m + 1];
+                            const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                            if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
+                                if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) sh[hf] = 1;
+                        }
+                    WB_END_PFOR
+                } else {
                 WB_PFOR(m, N - 1)
                     if (m == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; }   // the next step's / test's slots
                     const uint32_t pa = pts[m], pb = pts[m + 1];
@@ -1236,6 +1305,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                     if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
                         if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) sh[hf] = 1;
                 WB_END_PFOR
+                }
                 WB_STAMP(a.ctl, 6);
                 if (!sh[hf]) {                             // passes routine 2: the row's survivor
                     if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
@@ -1313,10 +1383,26 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                         const int nb = K - b0 < WB_F234_BATCH ? K - b0 : WB_F234_BATCH;
                         WB_PFOR(c, nb)                              // the chords' far ends side by side: the loop below reads them with nothing in between
                             hq[c] = pts[csort[b0 + c]];
-                            if (c == 0) hitm[0] = 0u;
+                            if (c == 0) { hitm[0] = 0u; sh[12] = 0; }
                         WB_END_PFOR
                         const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]);
-                        WB_PFOR(m, N - 1)
+                        int nseg = N - 1;                          // segments to look at: all, or those of the blocks some chord's box meets
+                        if (in_lds) {
+                            WB_PFOR(b, nblk)
+                                const int* bb = lbb + 4 * b;
+                                bool any = false;
+                                for (int c = 0; c < nb && !any; ++c) {
+                                    const int qx = wb_pt_x(hq[c]), qy = wb_pt_y(hq[c]);
+                                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                                    any = !(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0);
+                                }
+                                if (any) hitb[wb_atomic_add(&sh[12], 1)] = (int)b;
+                            WB_END_PFOR
+                            nseg = sh[12] * WB_BLK;
+                        }
+                        WB_PFOR(t, nseg)
+                            const int m = in_lds ? hitb[t >> 5] * WB_BLK + ((int)t & (WB_BLK - 1)) : (int)t;
+                            if (m >= N - 1) continue;
                             const uint32_t pa = pts[m], pb = pts[m + 1];
                             const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
                             // first the chords whose box meets the segment's (eight at a time: their LDS reads in flight together),
@@ -1379,7 +1465,11 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     const int M = sh[2];
     WB_STAMP(a.ctl, 7);
 
-    if (M > 1) {   // routine 4: group chords that intersect; keep the longest of each group
+    // routine 4: group chords that intersect; keep the longest of each group.  Its arrays -- the survivors' end points, labels,
+    // group scan, best length / member per group, every member's length -- are a dozen barrier-separated phases over M entries
+    // each: in the contour's tables in global memory every phase was a round trip to L2 (22 us per contour, 15 % of the
+    // kernel); up to WB_F234_R4 survivors they live in LDS and go back to the tables once, for wb_k_streamer_ties.
+    auto groups = [&](const int* mi, const int* mj, int* lab, int* aux, unsigned long long* best) WB_LAMBDA_INLINE {
         WB_PFOR(m, M)
             lab[m] = (int)m;
         WB_END_PFOR
@@ -1455,6 +1545,25 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         a.ev_n[s] = Gn < a.cap_ev ? Gn : a.cap_ev;
         if (Gn > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
         WB_END_SINGLE
+    };
+    WB_SHARED(int, lr4, 4 * WB_F234_R4);
+    WB_SHARED(unsigned long long, lbest, 3 * WB_F234_R4);
+    if (M > 1 && M <= WB_F234_R4) {
+        int *lmi = lr4, *lmj = lr4 + WB_F234_R4, *llab = lr4 + 2 * WB_F234_R4, *laux = lr4 + 3 * WB_F234_R4;
+        WB_PFOR(m, M)
+            lmi[m] = mi[m];
+            lmj[m] = mj[m];
+        WB_END_PFOR
+        groups(lmi, lmj, llab, laux, lbest);
+        WB_PFOR(m, M)
+            lab[m] = llab[m];
+            aux[m] = laux[m];
+            best[m] = lbest[m];
+            best[M + m] = lbest[M + m];
+            best[2 * (size_t)M + m] = lbest[2 * (size_t)M + m];
+        WB_END_PFOR
+    } else if (M > 1) {
+        groups(mi, mj, lab, aux, best);
     } else {
         WB_SINGLE
         if (M == 1) { ev[0] = mi[0]; ev[1] = mj[0]; }

@@ -41,6 +41,7 @@ struct wb_ctx {
     int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int boxcom_per_cu = 12;                   // persistent grid of wb_k_box_com: single-wave workgroups per CU (what its LDS admits)
+    int scan_priority = 0;                    // 1: the field scan is launched on a stream of the device's highest priority
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
     int scan_bands = 0;                       // streaming scan: row bands per time step (0: chosen from the grid and the device)
@@ -56,6 +57,8 @@ struct wb_ctx {
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
+    hipStream_t stream3 = nullptr;            // option scan_priority: a stream of the device's highest priority for the field scan (made on first use)
+    hipEvent_t fork3 = nullptr, join3 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t scan_done = nullptr;           // recorded behind this context's field scan (option scan_exclusive)
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
@@ -382,6 +385,37 @@ static void side_join(wb_ctx* ctx) {          // the main stream waits for the s
     (void)ctx;
 #endif
 }
+// option "scan_priority": the launches between prio_begin and prio_end go to a stream of the device's highest priority, in
+// stream order with what came before and what follows on the main stream.  The field scan is one fat workgroup per CU (12
+// waves of 128 registers): beside another batch's thin workgroups the dispatcher otherwise hands every freed slot to those.
+static void prio_begin(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    if (!ctx->scan_priority) return;
+    if (!ctx->stream3) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->fork3, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->join3, hipEventDisableTiming) != hipSuccess) {
+            ctx->scan_priority = 0;
+            return;
+        }
+    }
+    (void)hipEventRecord(ctx->fork3, ctx->stream);
+    (void)hipStreamWaitEvent(ctx->stream3, ctx->fork3, 0);
+    std::swap(ctx->stream, ctx->stream3);
+#else
+    (void)ctx;
+#endif
+}
+static void prio_end(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    if (!ctx->scan_priority || !ctx->stream3) return;
+    (void)hipEventRecord(ctx->join3, ctx->stream);
+    std::swap(ctx->stream, ctx->stream3);
+    (void)hipStreamWaitEvent(ctx->stream, ctx->join3, 0);
+#else
+    (void)ctx;
+#endif
+}
 static int side_sync(wb_ctx* ctx) {           // the HOST waits for the side stream
 #if !defined(WB_HOSTSIM)
     return hipStreamSynchronize(ctx->stream2) != hipSuccess;
@@ -553,6 +587,9 @@ static void wb_platform_destroy(wb_ctx* c) {
     for (int k = 0; k < 2; ++k) { if (c->h2d_pin[k]) (void)hipHostFree(c->h2d_pin[k]); if (c->h2d_ev[k]) (void)hipEventDestroy(c->h2d_ev[k]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->fork3) (void)hipEventDestroy(c->fork3);
+    if (c->join3) (void)hipEventDestroy(c->join3);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
 #endif

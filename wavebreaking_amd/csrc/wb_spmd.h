@@ -22,6 +22,7 @@
 #define WB_HD
 #define WB_DEV
 #define WB_NOINLINE
+#define WB_LAMBDA_INLINE
 #define WB_KERNEL(name, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
 #define WB_KERNEL_LB(name, threads, waves, ...) void name(int wb_block_id, int wb_grid_dim, __VA_ARGS__)
 #define WB_BLOCK_ID wb_block_id
@@ -33,6 +34,21 @@ extern int wb_hostsim_reverse;
     for (int64_t wb_k_##i = 0, wb_n_##i = (int64_t)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
         const int64_t i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;
 #define WB_END_PFOR }
+// WB_PFOR_B(i, ic, u, n) <requests> WB_PFOR_B_USE(i, u) <the rest> WB_END_PFOR_B: a parallel loop whose body is cut in two -- the
+// first part only REQUESTS what element i needs (into arrays indexed [u], WB_PFOR_B_WIDTH long, declared in front of the loop;
+// ic = i clamped to n - 1), the second part uses it.  On the device a thread requests for WB_PFOR_B_WIDTH of its elements before it
+// uses any: one memory latency per WB_PFOR_B_WIDTH elements instead of one per element (the compiler does not move the loads
+// of a later iteration of WB_PFOR in front of the branches of an earlier one).  Here: one element after the other, u = 0.
+#define WB_PFOR_B_WIDTH 4
+#define WB_PFOR_B(i, ic, u, n)                                                            \
+    for (int64_t wb_k_##i = 0, wb_n_##i = (int64_t)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
+        const int64_t i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;       \
+        const int64_t ic = i;                                                              \
+        const int u = 0;                                                                   \
+        (void)ic; (void)u;                                                                 \
+        {
+#define WB_PFOR_B_USE(i, u) } {
+#define WB_END_PFOR_B } }
 #define WB_SINGLE {
 #define WB_END_SINGLE }
 #define WB_SYNC() ((void)0)
@@ -89,6 +105,7 @@ static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
 #define WB_HD __host__ __device__
 #define WB_DEV __device__
 #define WB_NOINLINE __attribute__((noinline))      // rare slow paths: kept out of the hot kernels' register allocation
+#define WB_LAMBDA_INLINE __attribute__((always_inline))
 #define WB_KERNEL(name, ...) __global__ void name(__VA_ARGS__)
 // waves = minimum waves per SIMD the register allocator must leave room for
 #define WB_KERNEL_LB(name, threads, waves, ...) __global__ __launch_bounds__(threads, waves) void name(__VA_ARGS__)
@@ -101,6 +118,24 @@ static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
         for (int64_t i = WB_TID, wb_n_##i = (int64_t)(n); i < wb_n_##i; i += WB_NT) {
 #define WB_END_PFOR \
         }           \
+        __syncthreads(); \
+    }
+#define WB_PFOR_B_WIDTH 4
+#define WB_PFOR_B(i, ic, u, n)                                                                                            \
+    {                                                                                                                      \
+        const int64_t wb_n_##i = (int64_t)(n);                                                                             \
+        for (int64_t wb_b_##i = WB_TID; wb_b_##i < wb_n_##i; wb_b_##i += (int64_t)WB_PFOR_B_WIDTH * WB_NT) {               \
+            _Pragma("unroll") for (int u = 0; u < WB_PFOR_B_WIDTH; ++u) {                                                  \
+                const int64_t i = wb_b_##i + (int64_t)u * WB_NT, ic = i < wb_n_##i ? i : wb_n_##i - 1;                     \
+                (void)i;
+#define WB_PFOR_B_USE(i, u)                                                                                                \
+            }                                                                                                              \
+            _Pragma("unroll") for (int u = 0; u < WB_PFOR_B_WIDTH; ++u) {                                                  \
+                const int64_t i = wb_b_##i + (int64_t)u * WB_NT;                                                           \
+                if (i >= wb_n_##i) break;
+#define WB_END_PFOR_B \
+            }         \
+        }             \
         __syncthreads(); \
     }
 #define WB_SINGLE if (WB_TID == 0) {

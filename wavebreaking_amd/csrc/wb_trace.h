@@ -321,22 +321,8 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         WB_END_PFOR
     }
     WB_LSTAMP(a.ctl, 1);
-    WB_PFOR(g, n)
-        int s = 0;
-        while ((int)g >= sbase[s + 1]) ++s;
-        const int i = (int)g - sbase[s];
-        const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
-        const uint32_t key = a.stg_k[sb + i];
-        // (the square's four corner values requested together with its key: they are not needed before the searches below
-        //  are done, and loaded after them they were a second round trip to memory per segment)
-        double ul, ur, ll, lr;
-        if (a.dtype == 0) {
-            const float* v = (const float*)a.stg_v + (sb + i) * 4;
-            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
-        } else {
-            const double* v = (const double*)a.stg_v + (sb + i) * 4;
-            ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3];
-        }
+    // one segment: its place in the merged list, its two crossing points
+    auto place = [&](const int g, const int s, const int i, const uint32_t key, const double ul, const double ur, const double ll, const double lr) {
         const uint32_t kk = key & 0x07FFFFFFu;
         const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
         int dest = i;
@@ -374,7 +360,35 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         segt[dest] = wb_crossing_point(sto, r, c, ul, ur, ll, lr, level) | (wb_side_on_vertex(sto, ul, ur, ll, lr, level) ? WB_PT_VERTEX : 0u);
         pred[g] = WB_NIL;
         t0[g] = 0;  // "is first segment of a cut loop"
-    WB_END_PFOR
+    };
+    // (the square's four corner values requested together with its key: they are not needed before the table reads / searches
+    //  are done, and loaded after them they were a second round trip to memory per segment; float32 fields: four segments'
+    //  keys and values requested before the first is placed, WB_PFOR_B)
+    if (a.dtype == 0) {
+        uint32_t keya[WB_PFOR_B_WIDTH];
+        int sa[WB_PFOR_B_WIDTH];
+        float va[WB_PFOR_B_WIDTH][4];
+        WB_PFOR_B(g, gc, u, n)
+            int s = 0;
+            while ((int)gc >= sbase[s + 1]) ++s;
+            const size_t e = ((size_t)job * a.nstrips + s) * a.cap_strip + (size_t)((int)gc - sbase[s]);
+            const float* v = (const float*)a.stg_v + e * 4;
+            sa[u] = s;
+            keya[u] = a.stg_k[e];
+            va[u][0] = v[0]; va[u][1] = v[1]; va[u][2] = v[2]; va[u][3] = v[3];
+        WB_PFOR_B_USE(g, u)
+            place((int)g, sa[u], (int)g - sbase[sa[u]], keya[u], (double)va[u][0], (double)va[u][1], (double)va[u][2], (double)va[u][3]);
+        WB_END_PFOR_B
+    } else {
+        WB_PFOR(g, n)
+            int s = 0;
+            while ((int)g >= sbase[s + 1]) ++s;
+            const int i = (int)g - sbase[s];
+            const size_t sb = ((size_t)job * a.nstrips + s) * a.cap_strip;
+            const double* v = (const double*)a.stg_v + (sb + i) * 4;
+            place((int)g, s, i, a.stg_k[sb + i], v[0], v[1], v[2], v[3]);
+        WB_END_PFOR
+    }
 
     WB_LSTAMP(a.ctl, 2);
     // ---- P1: successor of every segment = the segment of the neighbouring square that starts on
@@ -387,7 +401,10 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     const uint32_t* keys = lds ? mk : segk;
     const uint16_t* mrow = rs + (size_t)a.nstrips * nrow1;
     WB_LSTAMP(a.ctl, 3);
-    WB_PFOR(i, n)
+    uint32_t pta[WB_PFOR_B_WIDTH];
+    WB_PFOR_B(i, ic, u, n)
+        pta[u] = segt[ic];
+    WB_PFOR_B_USE(i, u)
         const uint32_t k = keys[i];
         const int sq = wb_key_sq(k), r = sq / W, c = sq - r * W;
         const int ts = wb_seg_to(wb_key_case(k), wb_key_sub(k));
@@ -398,7 +415,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         else cc = c - 1;
         const int want = ts ^ 2;  // opposite side
         uint32_t s = WB_NIL;
-        const uint32_t pt = segt[i];
+        const uint32_t pt = pta[u];
         if (pt & WB_PT_VERTEX) {
             // the crossing sits on a grid vertex (a cell equal to the level): joined by skimage's coordinate rule
             if (!((segf[i] & WB_PT_VERTEX) && segf[i] == pt)) {              // not a zero-length segment
@@ -422,7 +439,7 @@ WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
         }
         succ[i] = s;
         if (s != WB_NIL) pred[s] = (uint32_t)i;
-    WB_END_PFOR
+    WB_END_PFOR_B
     WB_LSTAMP(a.ctl, 4);
     WB_LSTAMP_FLUSH(a.ctl);
     WB_SINGLE
@@ -504,14 +521,16 @@ WB_DEV inline void wb_rank_lists(int n, IT nil, const uint32_t* succ_g, uint32_t
 // segments: two workgroups per CU; the double-buffered version above needs seven arrays, 112 KiB, one workgroup per CU).  A
 // round reads its new values into registers, waits, writes them back: a thread owns WB_RANK_EPT strided elements.  D shares
 // P's storage (P is dead once pass 2 has copied it).
-#define WB_RANK_EPT ((WB_TRACE_LDS_N + WB_RANK_THREADS - 1) / WB_RANK_THREADS)
+#define WB_RANK_EPT_MAX ((WB_TRACE_LDS_N + WB_RANK_THREADS - 1) / WB_RANK_THREADS)
 #if defined(WB_HOSTSIM)
 #define WB_RANK_TMP(name) std::vector<uint32_t> name((size_t)n + 1)
+#define WB_RANK_TMP64(name) std::vector<unsigned long long> name((size_t)n + 1)
 #define WB_RANK_K_LOOP for (int k = 0; k < n; ++k)
 #define WB_RANK_I(k) (k)
 #else
-#define WB_RANK_TMP(name) uint32_t name[WB_RANK_EPT]
-#define WB_RANK_K_LOOP _Pragma("unroll") for (int k = 0; k < WB_RANK_EPT; ++k)
+#define WB_RANK_TMP(name) uint32_t name[EPT]
+#define WB_RANK_TMP64(name) unsigned long long name[EPT]
+#define WB_RANK_K_LOOP _Pragma("unroll") for (int k = 0; k < EPT; ++k)
 #define WB_RANK_I(k) (WB_TID + (k) * WB_NT)
 #endif
 // With `nb` (not for jobs the sequential walk will redo) the kernel goes on while start and position are still in LDS:
@@ -532,7 +551,14 @@ struct WbNumberOut {
 // position): a round reads its own word and the word it jumps to and writes one word, where three 16-bit arrays took five
 // reads and three writes -- the kernel's 32 waves per CU were bound by the LDS pipe (2.9 us per round of pass 2, round 4's
 // stamps).  After pass 2 the words are unpacked into the three 16-bit arrays the numbering below works on.
+// A round is STRAIGHT-LINE code over the thread's EPT elements: the own words are requested together, then the words they
+// jump to (an element without a pointer, or past the job's end, reads a word it is entitled to -- its own, or word 0 -- and
+// the arithmetic selects), so that a round costs two LDS latencies, not two per element: written with `if (i < n)` /
+// `if (j != nil)` around the reads the compiler emitted a branch per element and the sixteen reads of a round waited for one
+// another (and the eight-element version spilled its new values to scratch memory inside the loop).  EPT is a template
+// parameter -- the job's segments / workgroup size rounded up to 3, 5 or 8 -- so that a job of 2 500 segments does not pay for 8 192.
 #define WB_RANK_PACK(j, a, d) ((unsigned long long)(uint16_t)(j) | (unsigned long long)(uint16_t)(a) << 16 | (unsigned long long)(uint16_t)(d) << 32)
+template <int EPT>
 WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32_t* pred_g, uint32_t* t0_g, unsigned long long* Q,
                                      uint32_t* start_g, uint32_t* dist_g, const bool fuse, const WbNumberOut nb) {
     const uint16_t nil = (uint16_t)0xFFFF;
@@ -545,6 +571,7 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32
     while ((1 << rounds) < n) ++rounds;
     WB_RANK_TMP(t1);                                     // a round's new values, two 16-bit fields per register
     WB_RANK_TMP(t2);
+    WB_RANK_TMP64(wq);                                   // pass 2: the element's word, old then new
     WB_KSTAMP_BEGIN                                      // development stamps: 0 set-up, 1 pass 1, 2 cut, 3 pass 2, 4 .. 7 numbering, 8 raw points
     WB_PFOR(i, n)
         const uint32_t v = pred_g[i];
@@ -555,12 +582,14 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32
     for (int it = 0; it < rounds; ++it) {               // pass 1: running maximum over the predecessors
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) {
-                const unsigned long long wi = Q[i];
-                const uint16_t j = (uint16_t)wi, m1 = (uint16_t)(wi >> 16);
-                if (j != nil) { const unsigned long long wj = Q[j]; const uint16_t m2 = (uint16_t)(wj >> 16); t1[k] = (uint32_t)(m1 > m2 ? m1 : m2) << 16 | (uint16_t)wj; }
-                else t1[k] = (uint32_t)m1 << 16 | nil;
-            }
+            wq[k] = Q[i < n ? i : 0];
+        }
+        WB_RANK_K_LOOP {
+            const int i = WB_RANK_I(k);
+            const uint16_t j = (uint16_t)wq[k], m1 = (uint16_t)(wq[k] >> 16);
+            const unsigned long long wj = Q[j != nil ? (int)j : (i < n ? i : 0)];   // (no pointer: the own word -- max(m1, m1), J stays nil)
+            const uint16_t m2 = (uint16_t)(wj >> 16);
+            t1[k] = (uint32_t)(m1 > m2 ? m1 : m2) << 16 | (uint16_t)wj;
         }
         WB_SYNC();
         WB_RANK_K_LOOP {
@@ -580,39 +609,39 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32
     WB_END_PFOR
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
-        if (i < n) {
-            const uint16_t p16 = ((const uint16_t*)(Q + i))[2];
-            Q[i] = WB_RANK_PACK(p16, i, 1);
-            t1[k] = (uint32_t)i | 1u << 16;              // (a job of one segment makes no round: its start and position stand)
-        }
+        const uint16_t p16 = ((const uint16_t*)(Q + (i < n ? i : 0)))[2];
+        wq[k] = WB_RANK_PACK(p16, i, 1);                 // (a job of one segment makes no round: its start and position stand)
+        if (i < n) Q[i] = wq[k];
     }
     WB_SYNC();
     WB_KSTAMP(nb.ctl, 2);
     for (int it = 0; it < rounds; ++it) {               // pass 2: list ranking
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) {
-                const unsigned long long wi = Q[i];
-                const uint16_t j = (uint16_t)wi;
-                if (j != nil) {
-                    const unsigned long long wj = Q[j];
-                    t1[k] = (uint32_t)(uint16_t)((uint16_t)(wi >> 32) + (uint16_t)(wj >> 32)) << 16 | (uint16_t)(wj >> 16);
-                    t2[k] = (uint16_t)wj;
-                } else { t1[k] = (uint32_t)(uint16_t)(wi >> 32) << 16 | (uint16_t)(wi >> 16); t2[k] = nil; }
-            }
+            wq[k] = Q[i < n ? i : 0];
+        }
+        WB_RANK_K_LOOP {
+            const int i = WB_RANK_I(k);
+            const unsigned long long wi = wq[k];
+            const uint16_t j = (uint16_t)wi;
+            const bool has = j != nil;
+            const unsigned long long wj = Q[has ? (int)j : (i < n ? i : 0)];       // (no pointer: the own word -- J stays nil, A stays)
+            const uint16_t d = (uint16_t)((uint16_t)(wi >> 32) + (has ? (uint16_t)(wj >> 32) : (uint16_t)0));
+            wq[k] = WB_RANK_PACK((uint16_t)wj, (uint16_t)(wj >> 16), d);
         }
         WB_SYNC();
         WB_RANK_K_LOOP {
             const int i = WB_RANK_I(k);
-            if (i < n) Q[i] = WB_RANK_PACK(t2[k], t1[k], t1[k] >> 16);
+            if (i < n) Q[i] = wq[k];
         }
         WB_SYNC();
     }
     // unpack: A (start) and D (position) as 16-bit arrays over the same storage -- every word is in its thread's registers
-    // (t1 = A | D << 16) before the first array element is written
+    // before the first array element is written
     WB_SYNC();
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
+        t1[k] = (uint32_t)(uint16_t)(wq[k] >> 16) | (uint32_t)(uint16_t)(wq[k] >> 32) << 16;      // start | position << 16
         if (i < n) { A[i] = (uint16_t)t1[k]; D[i] = (uint16_t)(t1[k] >> 16); }
     }
     WB_SYNC();
@@ -629,19 +658,22 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32
     // t1 = start | position << 16 | TAIL (last segment of its chain: no successor, or a successor that heads a chain -- the
     // cut of a loop) | LEAD (raster-first segment of its contour); positions are <= 8192, bits 30 and 31 are free
     const uint32_t TAIL = 1u << 30, LEAD = 1u << 31;
+    WB_RANK_K_LOOP {                                      // the successors together (global memory), then their positions (LDS)
+        const int i = WB_RANK_I(k);
+        t2[k] = succ_g[i < n ? i : 0];
+    }
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
-        if (i < n) {
-            const uint32_t s = succ_g[i];
-            t1[k] = (uint32_t)A[i] | (uint32_t)D[i] << 16 | ((s == WB_NIL || D[s] == 1) ? TAIL : 0u);
-        }
+        const uint32_t s = t2[k];
+        const uint16_t ds = D[s != WB_NIL ? (int)s : (i < n ? i : 0)];
+        t1[k] |= (s == WB_NIL || ds == 1) ? TAIL : 0u;   // (t1 = start | position << 16 from the unpacking)
     }
     WB_SYNC();
     // contour_index.py:109 calls a contour closed when its first and last float coordinates are equal: besides the loops
     // cut above that is an OPEN chain that leaves and reaches the same grid vertex (cells equal to the level)
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
-        if (i < n && succ_g[i] == WB_NIL && (nb.segt[i] & WB_PT_VERTEX)) {
+        if (i < n && t2[k] == WB_NIL && (nb.segt[i] & WB_PT_VERTEX)) {
             const uint32_t s = t1[k] & 0xFFFFu;
             if (nb.segf[s] == nb.segt[i]) t0_g[s] = 1;
         }
@@ -699,12 +731,19 @@ WB_DEV inline void wb_rank_lists_lds(int n, const uint32_t* succ_g, const uint32
         nb.rawbase[c] = (int)M[c];
     WB_END_PFOR
     WB_KSTAMP(nb.ctl, 7);
+    WB_RANK_TMP(sg);                                      // the segments' end points (global memory) and the contours' bases (LDS), requested together
+    WB_RANK_TMP(bs);
+    WB_RANK_K_LOOP {
+        const int i = WB_RANK_I(k);
+        sg[k] = nb.segt[i < n ? i : 0];
+        bs[k] = M[i < n ? t2[k] : 0u];
+    }
     WB_RANK_K_LOOP {
         const int i = WB_RANK_I(k);
         if (i < n) {
             const uint32_t c = t2[k];
-            const int pos = (int)((t1[k] >> 16) & 0x3FFFu), base = (int)M[c], p = base + pos;
-            nb.rawpt[p] = nb.segt[i] & WB_PT_MASK;
+            const int pos = (int)((t1[k] >> 16) & 0x3FFFu), base = (int)bs[k], p = base + pos;
+            nb.rawpt[p] = sg[k] & WB_PT_MASK;
             nb.rawcid[p] = c;
             if (pos == 1) {
                 nb.rawpt[base] = nb.segf[i] & WB_PT_MASK;
@@ -750,7 +789,9 @@ WB_KERNEL_LB(wb_k_trace_rank, WB_RANK_THREADS, (WB_RANK_THREADS >= 1024 ? 8 : 4)
     nb.segf = segf; nb.segt = segt; nb.rawpt = a.rawpt + 2 * jb; nb.rawcid = a.rawcid + 2 * jb;
     nb.cnt = (int*)(a.w[3] + jb); nb.rawbase = (int*)(a.w[5] + jb); nb.closed = (int*)(a.w[7] + jb); nb.CR = a.p4 + 2 * (size_t)job; nb.ctl = a.ctl;
     const bool fuse = WB_TRACE_FUSE_P4 && !(a.status[job] & WB_ST_LEVEL_ORDER);   // (those the walk kernel ranks again)
-    wb_rank_lists_lds(n, succ, pred, t0, q64, start, dist, fuse, nb);
+    if (n <= 3 * WB_RANK_THREADS) wb_rank_lists_lds<3>(n, succ, pred, t0, q64, start, dist, fuse, nb);
+    else if (n <= 5 * WB_RANK_THREADS) wb_rank_lists_lds<5>(n, succ, pred, t0, q64, start, dist, fuse, nb);
+    else wb_rank_lists_lds<WB_RANK_EPT_MAX>(n, succ, pred, t0, q64, start, dist, fuse, nb);
     if (fuse) return;
     WB_SINGLE
     a.p4[2 * (size_t)job] = -1;
@@ -929,6 +970,13 @@ WB_KERNEL(wb_k_trace_walk, WbTraceArgs a) {
     const int wb_pc_ = (int)(p) < (R) ? (int)(p) : ((R) > 0 ? (R) - 1 : 0), wb_pm_ = wb_pc_ > 0 ? wb_pc_ - 1 : 0;   \
     const uint32_t rc1 = rawcid[wb_pc_], rc0 = rawcid[wb_pm_], rp1 = rawpt[wb_pc_], rp0 = rawpt[wb_pm_]; \
     const bool rdup = (wb_pc_ > 0) & (rc1 == rc0) & (rp1 == rp0)
+// the same inside WB_PFOR_B: the request part for raw point `pc` (clamped by the caller), the use part for raw point p
+#define WB_RAW_REQ(pc)                                                                              \
+    { const int wb_pc_ = (int)(pc), wb_pm_ = wb_pc_ > 0 ? wb_pc_ - 1 : 0;                            \
+      rc1a[u] = rawcid[wb_pc_]; rc0a[u] = rawcid[wb_pm_]; rp1a[u] = rawpt[wb_pc_]; rp0a[u] = rawpt[wb_pm_]; }
+#define WB_RAW_USE(p)                                                                               \
+    const uint32_t rc1 = rc1a[u], rp1 = rp1a[u];                                                    \
+    const bool rdup = ((p) > 0) & (rc1 == rc0a[u]) & (rp1 == rp0a[u])
 #ifndef WB_TRACE_LTAB
 #define WB_TRACE_LTAB 8192        // 64-bit entries of the LDS table (= 16384 32-bit set entries)
 #endif
@@ -1034,10 +1082,14 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_SINGLE
     nkeys[0] = 0;
     WB_END_SINGLE
-    WB_PFOR(p, R)
-        WB_RAW_LOAD(p, R);
+    uint32_t rc1a[WB_PFOR_B_WIDTH], rc0a[WB_PFOR_B_WIDTH], rp1a[WB_PFOR_B_WIDTH], rp0a[WB_PFOR_B_WIDTH];   // (WB_PFOR_B: four raw points requested, then used)
+    const int Rl = R > 0 ? R - 1 : 0;
+    WB_PFOR_B(p, pc, u, R)
+        WB_RAW_REQ(pc);
+    WB_PFOR_B_USE(p, u)
+        WB_RAW_USE(p);
         wb_atomic_add_agg(nkeys, 0, rdup ? 0 : 1);
-    WB_END_PFOR
+    WB_END_PFOR_B
     WB_TSTAMP(a.ctl, 2);
     hsize = 1024;
     while (hsize < 2 * nkeys[0] && hsize < a.hash_size) hsize <<= 1;
@@ -1048,65 +1100,77 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
         WB_PFOR(s, hsize)
             ltab[s] = WB_HEMPTY;
         WB_END_PFOR
-        WB_PFOR(p, R)
-            WB_RAW_LOAD(p, R);
+        WB_PFOR_B(p, pc, u, R)
+            WB_RAW_REQ(pc);
+        WB_PFOR_B_USE(p, u)
+            WB_RAW_USE(p);
             if (rdup) continue;
             const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
             if (!wb_hash_put_min(ltab, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-        WB_END_PFOR
+        WB_END_PFOR_B
         WB_TSTAMP(a.ctl, 3);
-        WB_PFOR(p, R + 1)
+        WB_PFOR_B(p, pc, u, R + 1)
+            WB_RAW_REQ(pc < R ? pc : Rl);
+        WB_PFOR_B_USE(p, u)
             int kp = 0;
-            WB_RAW_LOAD(p, R);
+            WB_RAW_USE(p);
             if (p < R && !rdup) {
                 const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
                 kp = wb_hash_get_min(ltab, hmask, key) == (uint32_t)p ? 1 : 0;
             }
             keep[p] = kp;
-        WB_END_PFOR
+        WB_END_PFOR_B
     } else if (pk5) {
         WB_PFOR(s, hsize)
             hkey[s] = WB_HEMPTY;
         WB_END_PFOR
-        WB_PFOR(p, R)
-            WB_RAW_LOAD(p, R);
+        WB_PFOR_B(p, pc, u, R)
+            WB_RAW_REQ(pc);
+        WB_PFOR_B_USE(p, u)
+            WB_RAW_USE(p);
             if (rdup) continue;
             const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
             if (!wb_hash_put_min(hkey, hmask, key, (uint32_t)p)) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-        WB_END_PFOR
-        WB_PFOR(p, R + 1)
+        WB_END_PFOR_B
+        WB_PFOR_B(p, pc, u, R + 1)
+            WB_RAW_REQ(pc < R ? pc : Rl);
+        WB_PFOR_B_USE(p, u)
             int kp = 0;
-            WB_RAW_LOAD(p, R);
+            WB_RAW_USE(p);
             if (p < R && !rdup) {
                 const uint32_t key = (rc1 << (bx + by)) | ((uint32_t)wb_pt_y(rp1) << bx) | (uint32_t)wb_pt_x(rp1);
                 kp = wb_hash_get_min(hkey, hmask, key) == (uint32_t)p ? 1 : 0;
             }
             keep[p] = kp;
-        WB_END_PFOR
+        WB_END_PFOR_B
     } else {
         WB_PFOR(s, hsize)
             hkey[s] = WB_HEMPTY;
             hval[s] = WB_NIL;
         WB_END_PFOR
-        WB_PFOR(p, R)
-            WB_RAW_LOAD(p, R);
+        WB_PFOR_B(p, pc, u, R)
+            WB_RAW_REQ(pc);
+        WB_PFOR_B_USE(p, u)
+            WB_RAW_USE(p);
             if (rdup) continue;
             int fresh;
             const unsigned long long key = ((unsigned long long)rc1 << 32) | rp1;
             const int s = wb_hash_insert(hkey, hmask, key, &fresh);
             if (s >= 0) wb_atomic_min(&hval[s], (uint32_t)p);
             else wb_atomic_or(&a.status[job], (uint32_t)WB_ST_HASH_FULL);
-        WB_END_PFOR
-        WB_PFOR(p, R + 1)
+        WB_END_PFOR_B
+        WB_PFOR_B(p, pc, u, R + 1)
+            WB_RAW_REQ(pc < R ? pc : Rl);
+        WB_PFOR_B_USE(p, u)
             int kp = 0;
-            WB_RAW_LOAD(p, R);
+            WB_RAW_USE(p);
             if (p < R && !rdup) {
                 const unsigned long long key = ((unsigned long long)rc1 << 32) | rp1;
                 const int s = wb_hash_find(hkey, hmask, key);
                 kp = (s >= 0 && hval[s] == (uint32_t)p) ? 1 : 0;
             }
             keep[p] = kp;
-        WB_END_PFOR
+        WB_END_PFOR_B
     }
     WB_TSTAMP(a.ctl, 4);
     // keep[] becomes the exclusive scan = new position (R + 1 entries: a point was kept iff its successor's position is larger)
@@ -1124,12 +1188,18 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     const int Ck = wb_block_scan_excl(kc, C);
     // compact points; owner = id among kept contours (NIL for contours that are too short) -- and, the first C lanes, the
     // pre-drop contour table in the c_* arrays (indexed by id among kept)
-    WB_PFOR(p, R)
-        const int q = keep[p];
-        if (keep[p + 1] != q) {
-            const uint32_t c = rawcid[p];
-            cpts[q] = rawpt[p];
-            cown[q] = kcflag[c] ? (uint32_t)kc[c] : WB_NIL;
+    int k0a[WB_PFOR_B_WIDTH], k1a[WB_PFOR_B_WIDTH];
+    WB_PFOR_B(p, pc, u, R)                                 // (a point's old and new position, its contour -- and, behind that, the contour's fate)
+        k0a[u] = keep[pc];
+        k1a[u] = keep[pc + 1];
+        rp1a[u] = rawpt[pc];
+        const uint32_t c = rawcid[pc];
+        rc1a[u] = kcflag[c] ? (uint32_t)kc[c] : WB_NIL;
+    WB_PFOR_B_USE(p, u)
+        const int q = k0a[u];
+        if (k1a[u] != q) {
+            cpts[q] = rp1a[u];
+            cown[q] = rc1a[u];
         }
         if (p < C && kcflag[p]) {
             const int c = (int)p, f = kc[c];
@@ -1140,7 +1210,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             c_nux[f] = 0;
             c_sumy[f] = 0;
         }
-    WB_END_PFOR
+    WB_END_PFOR_B
 
     WB_TSTAMP(a.ctl, 5);
     // ---- P6: sets of (x mod nlon, y) and of x per contour, in one table (tag bit 63 = x-key)
@@ -1192,12 +1262,16 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_END_PFOR
     WB_TSTAMP(a.ctl, 6);
     const int npts = (Ck > 0) ? keep[R] : 0;
-    WB_PFOR(q, npts)
-        const uint32_t f = cown[q];
-        const uint32_t pt = cpts[q];                       // (with its owner, not after it)
+    WB_PFOR_B(q, qc, u, npts)                              // (a point, its owner -- and, behind that, whether the owner is a long contour)
+        rp1a[u] = cpts[qc];
+        rc1a[u] = cown[qc];
+        k0a[u] = bigof[rc1a[u] != WB_NIL ? rc1a[u] : 0u];
+    WB_PFOR_B_USE(q, u)
+        const uint32_t f = rc1a[u];
+        const uint32_t pt = rp1a[u];
         if (f != WB_NIL) {
             const int x = wb_pt_x(pt), y = wb_pt_y(pt);
-            const int slot = bigof[f];
+            const int slot = k0a[u];
             int fresh1, fresh2 = 0;
             if (slot >= 0) wb_atomic_or(&xbits[slot * WB_TRACE_XWORDS + (x >> 5)], 1u << (x & 31));
             if (pk6) {
@@ -1216,7 +1290,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
             if (fresh2 > 0) wb_atomic_add(&c_nux[f], 1);
             wb_atomic_add_agg(c_sumy, (int)f, y);
         }
-    WB_END_PFOR
+    WB_END_PFOR_B
     WB_PFOR(w, nb * xw)
         const uint32_t v = xbits[(w / xw) * WB_TRACE_XWORDS + (w % xw)];
         if (v) wb_atomic_add(&c_nux[bigf[w / xw]], wb_popc32(v));
