@@ -11,7 +11,7 @@ one() {  # label, streams, extra env ...
 import json, sys
 d = json.load(open("/tmp/ab.json"))
 s = d["stage_ms"]
-keys = ("scan", "scan_build", "trace_link", "trace_rank", "trace_finish", "streamer_pairs", "streamer_f1", "streamer_f234", "props")
+keys = ("scan", "scan_build", "trace_link", "trace_rank", "trace_finish", "box_com", "streamer_prep", "streamer_pairs", "streamer_f1", "streamer_f234", "props", "polygons")
 print(sys.argv[1], "streams", sys.argv[2], "value %d  ms/step %.3f frac %.3f alone %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["frac_alone"]), " ".join("%s %.2f" % (k, s.get(k, -1)) for k in keys), flush=True)
 PY
 }
@@ -20,8 +20,4 @@ one new 1 WB_X=1
 one new 2 WB_X=1
 one old 1 WB_HIP_LIBRARY=$PWD/build/ab/libwb_prev.so
 one old 2 WB_HIP_LIBRARY=$PWD/build/ab/libwb_prev.so
-done
-for n in 2 3 5; do
-echo "stamps $n"
-WB_HIP_LIBRARY=$PWD/build/ab/libwb_stamps$n.so WB_DEBUG_STAMPS=1 python bench.py --steps 2 --warmup 0 --cpu-sample 0 --e2e-steps 0 --streams 1 --stagger-steps 0 2>&1 | grep -E "stamps" | tail -1
 done

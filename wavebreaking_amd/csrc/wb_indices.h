@@ -1155,12 +1155,12 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     WB_DYN_SHARED(int, rend, a.f234_cap);        // per row: its alive candidates, then the end of its bucket in bk
     WB_DYN_SHARED(int, lbb, 4 * (a.f234_cap / WB_BLK + 1));   // boxes of the blocks of WB_BLK segments (wb_k_streamer_prep: points 32 b .. 32 b + 32)
     WB_DYN_SHARED(int, hitb, a.f234_cap / WB_BLK + 1);        // the blocks whose box meets the chord's (chord test)
-    WB_SHARED(uint32_t, rowbits, WB_F234_LPTS / 32);   // bit i: row i holds an alive candidate that the sweep can still ask about
+    WB_SHARED(int, wmax, WB_F234_LPTS / 32);     // per word of 32 rows: the largest ind2 among their alive candidates
     WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
     WB_SHARED(int, csort, WB_F234_CAND);
     WB_SHARED(uint32_t, hq, WB_F234_BATCH);     // far end points of the chords of a batch
     WB_SHARED(uint32_t, hitm, 1);               // ... and which of them met the contour
-    WB_SHARED(int, sh, 13);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate, [10..11] blocks met by a chord, [12] by a batch of chords
+    WB_SHARED(int, sh, 15);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate, [10..11] blocks met by a chord, [12] by a batch of chords
                                          // (words alternate between two slots: a slot is rewritten two barriers after its last read)
     const int stage = a.stage[s];
     const int nal = a.nalive[s];
@@ -1174,13 +1174,14 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         if (in_lds) { lpts[i] = gpts[i]; rend[i] = 0; }
         rmax[i] = -1;
         if (in_lds && i < 4 * nblk) lbb[i] = a.bbx[4 * ((a.poff[s] >> 5) + s) + i];
-        if (in_lds && i < nw) rowbits[i] = 0u;
+        if (in_lds && i < nw) wmax[i] = -1;
     WB_END_PFOR
     WB_SINGLE
     sh[2] = 0;
     sh[3] = 0x7FFFFFFF; sh[4] = 0x7FFFFFFF;     // search results of even / odd iterations
     sh[5] = 0; sh[6] = 0;                       // hit flags of even / odd chord tests
     sh[10] = 0; sh[11] = 0; sh[12] = 0;         // blocks met by even / odd chord tests, by a batch
+    sh[13] = 0x7FFFFFFF; sh[14] = 0x7FFFFFFF;   // word found by the far search of even / odd iterations
     WB_END_SINGLE
     WB_STAMP(a.ctl, 0);
     if (stage == 1 && nal > 1) {
@@ -1225,7 +1226,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                     if (al[u]) bk[wb_atomic_add(&rend[(int)(pr[u] >> 32)], 1)] = (int)(pr[u] & 0xFFFFFFFFull);
             WB_END_PFOR
             WB_PFOR(i, N)
-                if (rmax[i] >= 0) wb_atomic_or(&rowbits[i >> 5], 1u << (i & 31));
+                if (rmax[i] >= 0) wb_atomic_max(&wmax[i >> 5], rmax[i]);
             WB_END_PFOR
         }
         WB_STAMP(a.ctl, 1);
@@ -1238,32 +1239,39 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             // the next row at or after `cur` whose largest candidate is above M: a lane per row, WB_NT rows per pass (the next
             // row is nearly always among the first few; a bitmap of non-empty rows walked bit by bit, as this was until
             // round 3, cost a dependent LDS read per set bit: 2.5 us per step, as much as the chord test itself)
-            if (in_lds) {
-                // ... found in ONE pass whatever the distance to it: a lane per word of the bitmap of rows that hold candidates
-                // walks its word's bits from `cur` on (a row whose largest candidate is not above M never will be asked about
-                // again -- M only grows -- and loses its bit); the contour with 50 000 pairs has its next row thousands of
-                // points away, eight passes of the 512-row search with a barrier each
-                WB_PFOR(w, nw)
-                    if ((int)w >= (cur >> 5)) {
-                        uint32_t bits = rowbits[w], dead = 0u;
-                        if ((int)w == (cur >> 5)) bits &= ~0u << (cur & 31);
-                        while (bits) {
-                            const int i = (int)w * 32 + wb_ctz32(bits);
-                            if (rmax[i] > M) { wb_atomic_min(&sh[fs], i); break; }
-                            dead |= bits & (0u - bits);
-                            bits &= bits - 1u;
-                        }
-                        if (dead) rowbits[w] &= ~dead;                    // (this lane is the word's only writer during the sweep)
-                    }
+            const int win = WB_NT > 64 ? WB_NT : 64;          // rows of the first pass: up to the last word boundary within `win` rows of cur
+            const int wend = (cur + win) & ~31;
+            {
+                WB_PFOR(t, win)
+                    const int i = cur + (int)t;
+                    wb_atomic_min_first(&sh[fs], i < wend && i < N && rmax[i] > M, i);
                 WB_END_PFOR
-            } else {
-            for (int base = cur; base < N; base += WB_NT) {
-                WB_PFOR(t, WB_NT)
-                    const int i = base + (int)t;
-                    wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
-                WB_END_PFOR
-                if (sh[fs] != 0x7FFFFFFF) break;
             }
+            if (sh[fs] == 0x7FFFFFFF && wend < N) {
+                if (in_lds) {
+                    // not among those (the contour with 50 000 pairs has its next row thousands of points away: eight such
+                    // passes, a barrier each): the first WORD of 32 rows from wend on whose largest candidate is above M (wmax,
+                    // built once), then the first such row of that word -- two short passes whatever the distance
+                    const int fw = 13 + (step & 1);
+                    WB_PFOR(w, nw)
+                        if ((int)w >= (wend >> 5) && wmax[w] > M) wb_atomic_min(&sh[fw], (int)w);
+                    WB_END_PFOR
+                    const int w0 = sh[fw];
+                    if (w0 != 0x7FFFFFFF) {
+                        WB_PFOR(t, 32)
+                            const int i = w0 * 32 + (int)t;
+                            wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
+                        WB_END_PFOR
+                    }
+                } else {
+                    for (int base = wend; base < N; base += win) {
+                        WB_PFOR(t, win)
+                            const int i = base + (int)t;
+                            wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
+                        WB_END_PFOR
+                        if (sh[fs] != 0x7FFFFFFF) break;
+                    }
+                }
             }
             const int row = sh[fs];
             WB_STAMP(a.ctl, 4);
@@ -1282,7 +1290,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                     // whose box meets the chord's (a lane per block), then the segments of those blocks only -- one pass of the
                     // workgroup instead of one per 512 segments of the contour
                     WB_PFOR(b, nblk)
-                        if (b == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; sh[10 + (ntest & 1)] = 0; }   // the next step's / test's slots
+                        if (b == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[13 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; sh[10 + (ntest & 1)] = 0; }   // the next step's / test's slots
                         const int* bb = lbb + 4 * b;
                         if (!(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0)) hitb[wb_atomic_add(&sh[hc], 1)] = (int)b;
                     WB_END_PFOR

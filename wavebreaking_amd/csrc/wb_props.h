@@ -160,6 +160,9 @@ WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x
 #ifndef WB_PROPS_K
 #define WB_PROPS_K 12
 #endif
+#ifndef WB_PROPS_CHUNK
+#define WB_PROPS_CHUNK 4             // events a slot takes from the queue at a time
+#endif
 #ifndef WB_PROPS_BM
 #define WB_PROPS_BM 768              // bitmap words (24 576 cells)
 #endif
@@ -191,12 +194,15 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
     // slot that drew several long streamers finished long after the others
     WB_SHARED(int, cur, 1);
     WB_RSTAMP_BEGIN                              // development stamps: 0 queue + box, 1 crossings, 2 sweep, 3 rim, 4 sums, 5 tail; +6 for boxes; 11 global raster
+    // (WB_PROPS_CHUNK events per visit of the counter: 19 500 returning atomics on ONE word from 3 000 waves are served one after
+    //  the other by the L2 -- a quarter of this kernel's wave time was spent between asking for an event and having its box)
     for (;;) {
         WB_SINGLE
-        cur[0] = wb_atomic_add(&a.ctl->props_cursor, 1);
+        cur[0] = wb_atomic_add(&a.ctl->props_cursor, WB_PROPS_CHUNK);
         WB_END_SINGLE
-        const int e = cur[0];
-        if (e >= nev) break;
+        const int e0 = cur[0];
+        if (e0 >= nev) break;
+        for (int e = e0; e < e0 + WB_PROPS_CHUNK && e < nev; ++e) {
         const int* d = a.ev + (size_t)e * 8;
         const int kind = d[0] & 0xFF, job = d[1], cont = d[2];
         const size_t jb = (size_t)job * a.cap_seg;
@@ -600,6 +606,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         }
 #undef WB_ACC
         WB_RSTAMP(a.ctl, 5);
+        }
     }
     WB_RSTAMP_FLUSH(a.ctl);
 }
@@ -627,7 +634,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 //     box taller than 128 rows, wider than 4 binades or with one mismatch was walked whole: 16 of the bench batch's 6 391
 //     boxes, the largest of them 1.6 ms on one lane -- the kernel's whole duration.)
 #ifndef WB_BOXCOM_ROWS
-#define WB_BOXCOM_ROWS 64            // rows of a chunk (a lane each)
+#define WB_BOXCOM_ROWS 16            // rows of a box per chunk (a lane each; 64 / WB_BOXCOM_ROWS boxes share a wave)
 #endif
 #ifndef WB_BOXCOM_FORCE_WALK
 #define WB_BOXCOM_FORCE_WALK 0       // 1 (a test build): no chunk is predicted, one lane walks them all
@@ -674,59 +681,84 @@ WB_HD inline bool wb_state_from_exact(wb_u128 E, int ue, double* s, double* c) {
 
 WB_DEV inline int wb_dbl_exp(double v) { unsigned long long m; int e; wb_dbl_split(v, &m, &e); return m ? e : -100000; }
 
+// WB_BOXCOM_G boxes at a time per workgroup (one wave), WB_BOXCOM_ROWS rows of each per chunk: passes 1 and 3 have a lane per
+// (box, row), pass 2 -- the sequential one, three quarters of this kernel's wave time when a wave held ONE box and ran it on
+// three lanes -- a lane per (box, chain).
+#define WB_BOXCOM_G (64 / WB_BOXCOM_ROWS > 0 ? 64 / WB_BOXCOM_ROWS : 1)
+#define WB_BOXCOM_NL (WB_BOXCOM_G * WB_BOXCOM_ROWS)
+#define WB_BOXCOM_ST(q, g, r) st[((q) * WB_BOXCOM_G + (g)) * (WB_BOXCOM_ROWS + 1) + (r)]
 WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
-    WB_SHARED(double, segv, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);                // x chain: first term of a row's segment
-    WB_SHARED(unsigned long long, seglo, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);   // ... exact total of the segment's other terms
-    WB_SHARED(unsigned long long, seghi, WB_BOXCOM_SEGS * WB_BOXCOM_ROWS);
-    WB_SHARED(int, nseg, WB_BOXCOM_ROWS);
-    WB_SHARED(double, st, 6 * (WB_BOXCOM_ROWS + 1));             // per chain: state s, c at the start of every row of the chunk (+ after its last)
-    WB_SHARED(int, ctl, 5);                                      // [0] the queue entry taken, [1] unit exponent, [2] whole box by one lane, [3] this chunk by one lane, [4] largest exponent
+    WB_SHARED(double, segv, WB_BOXCOM_SEGS * WB_BOXCOM_NL);                // x chain: first term of a row's segment (index: segment, lane)
+    WB_SHARED(unsigned long long, seglo, WB_BOXCOM_SEGS * WB_BOXCOM_NL);   // ... exact total of the segment's other terms
+    WB_SHARED(unsigned long long, seghi, WB_BOXCOM_SEGS * WB_BOXCOM_NL);
+    WB_SHARED(int, nseg, WB_BOXCOM_NL);
+    WB_SHARED(double, st, 6 * WB_BOXCOM_G * (WB_BOXCOM_ROWS + 1));   // per chain and box: state s, c at the start of every row of the chunk (+ after its last)
+    WB_SHARED(int, bx, 12 * WB_BOXCOM_G);                         // per box: x0, y0, x1, y1, rows, first row of the chunk, rows of the chunk, unit exponent, largest exponent, whole box by one lane, this chunk by one lane, a chunk was walked
+    WB_SHARED(int, ctl, 2);                                      // [0] the first queue entry taken, [1] some box has a chunk left
     WB_BSTAMP_BEGIN                                              // development stamps: 0 closed forms, 1 .. 3 the passes, 4 the one-lane walks / output
-    // persistent: a workgroup (one wave) takes the next queued box until the queue is empty -- only the boxes that need the
-    // reference-order sums are here (wb_k_overturn queued them), dealt out one at a time whatever contour they belong to
+    // persistent: a workgroup (one wave) takes the next WB_BOXCOM_G queued boxes until the queue is empty -- only the boxes that
+    // need the reference-order sums are here (wb_k_overturn queued them), whatever contour they belong to
     for (;;) {
     WB_SINGLE
-    ctl[0] = wb_atomic_add(&a.ctl->boxq_cursor, 1);
-    ctl[1] = 4096;
-    ctl[4] = -4096;
+    ctl[0] = wb_atomic_add(&a.ctl->boxq_cursor, WB_BOXCOM_G);
     WB_END_SINGLE
-    if (ctl[0] >= a.ctl->n_boxq) break;
-    const int slot = a.boxq[ctl[0]];
-    const int* d = a.ot_box + (size_t)slot * 4;
-    double* out = a.ot_sums + (size_t)slot * 3;
-    int x0 = d[0], y0 = d[1], x1 = d[2], y1 = d[3];
-    if (x0 < 0) x0 = 0;
-    if (y0 < 0) y0 = 0;
-    if (x1 > a.W - 1) x1 = a.W - 1;
-    if (y1 > a.nlat - 1) y1 = a.nlat - 1;
-    const int cols = x1 - x0 + 1, rows = y1 - y0 + 1;
-    WB_PFOR(r, rows)                                             // exponent range of the rows' weights
-        unsigned long long m; int ex;
-        wb_dbl_split(a.wlat[y0 + (int)r], &m, &ex);
-        if (m) { wb_atomic_min(&ctl[1], ex); wb_atomic_max(&ctl[4], ex); }
+    const int q0 = ctl[0], nq = a.ctl->n_boxq;
+    if (q0 >= nq) break;
+    WB_PFOR(g, WB_BOXCOM_G)
+        int* b = bx + 12 * g;
+        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+        if (q0 + (int)g < nq) {
+            const int* d = a.ot_box + (size_t)a.boxq[q0 + (int)g] * 4;
+            x0 = d[0]; y0 = d[1]; x1 = d[2]; y1 = d[3];
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            if (x1 > a.W - 1) x1 = a.W - 1;
+            if (y1 > a.nlat - 1) y1 = a.nlat - 1;
+        }
+        b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1;
+        b[4] = (q0 + (int)g < nq) ? y1 - y0 + 1 : 0;             // rows (0: no box in this place, or an empty one)
+        b[5] = 0; b[6] = 0; b[7] = 4096; b[8] = -4096; b[9] = 0; b[10] = 0; b[11] = 0;
     WB_END_PFOR
-    WB_SINGLE
-    const int emin = ctl[1], emax = ctl[4];
-    // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
-    ctl[2] = (emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
-    for (int q = 0; q < 6; ++q) st[q * (WB_BOXCOM_ROWS + 1)] = 0.0;          // the sums start at s = c = 0: certain
-    WB_END_SINGLE
+    WB_PFOR(l, WB_BOXCOM_NL)                                     // exponent range of the rows' weights
+        const int g = (int)l / WB_BOXCOM_ROWS;
+        int* b = bx + 12 * g;
+        for (int r = (int)l % WB_BOXCOM_ROWS; r < b[4]; r += WB_BOXCOM_ROWS) {
+            unsigned long long m; int ex;
+            wb_dbl_split(a.wlat[b[1] + r], &m, &ex);
+            if (m) { wb_atomic_min(&b[7], ex); wb_atomic_max(&b[8], ex); }
+        }
+    WB_END_PFOR
+    WB_PFOR(g, WB_BOXCOM_G)
+        int* b = bx + 12 * g;
+        const int emin = b[7], emax = b[8];
+        // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
+        b[9] = (emin > emax || (emax - emin) + 53 + 16 + 32 > 126) ? 1 : 0;
+        for (int q = 0; q < 6; ++q) WB_BOXCOM_ST(q, g, 0) = 0.0;            // the sums start at s = c = 0: certain
+    WB_END_PFOR
     WB_BSTAMP(a.ctl, 0);
-    const int ue = ctl[1];
-    bool walked = false;
-    // The box in chunks of WB_BOXCOM_ROWS rows.  A chunk starts from the TRUE state of the three sums (verified by the
+    // The boxes in chunks of WB_BOXCOM_ROWS rows.  A chunk starts from the TRUE state of the three sums (verified by the
     // previous chunk, or walked) in st[..][0]; if it verifies, its end state is true as well and becomes the next start; if
     // not (a rounding tie, an inexact step the prediction missed, more binade steps in a row than WB_BOXCOM_SEGS), one lane
     // walks the chunk's cells in the reference's order from that start -- and the chunk after it is predicted again.
-    for (int r0 = 0; r0 < rows && !ctl[2]; r0 += WB_BOXCOM_ROWS) {
-        const int nr = rows - r0 < WB_BOXCOM_ROWS ? rows - r0 : WB_BOXCOM_ROWS;
+    for (;;) {
         WB_SINGLE
-        ctl[3] = WB_BOXCOM_FORCE_WALK;
+        ctl[1] = 0;
         WB_END_SINGLE
-        if (!ctl[3]) {
-            // pass 1: segments of the x chain, row by row
-            WB_PFOR(r, nr)
-                const double w = a.wlat[y0 + r0 + (int)r];
+        WB_PFOR(g, WB_BOXCOM_G)
+            int* b = bx + 12 * g;
+            const int left = b[9] ? 0 : b[4] - b[5];
+            b[6] = left < WB_BOXCOM_ROWS ? (left > 0 ? left : 0) : WB_BOXCOM_ROWS;
+            b[10] = WB_BOXCOM_FORCE_WALK;
+            if (b[6] > 0) ctl[1] = 1;
+        WB_END_PFOR
+        if (!ctl[1]) break;
+        // pass 1: segments of the x chain, row by row
+        WB_PFOR(l, WB_BOXCOM_NL)
+            const int g = (int)l / WB_BOXCOM_ROWS, r = (int)l % WB_BOXCOM_ROWS;
+            int* b = bx + 12 * g;
+            if (r < b[6] && !b[10]) {
+                const int x0 = b[0], x1 = b[2], ue = b[7];
+                const double w = a.wlat[b[1] + b[5] + r];
                 int ns = 0, eprev = 0;
                 wb_u128 rest = 0;
                 bool over = false;
@@ -734,9 +766,9 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                     const double p = (double)x * w;
                     const int ep = wb_dbl_exp(p);
                     if (x == x0 || ep > eprev) {                     // row start or a step up into a higher binade: new segment
-                        if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
+                        if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_NL + l] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_NL + l] = (unsigned long long)(rest >> 64); }
                         if (ns == WB_BOXCOM_SEGS) { over = true; break; }
-                        segv[ns * WB_BOXCOM_ROWS + r] = p;
+                        segv[ns * WB_BOXCOM_NL + l] = p;
                         rest = 0;
                         ++ns;
                     } else {
@@ -744,34 +776,38 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                     }
                     eprev = ep;
                 }
-                if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_ROWS + r] = (unsigned long long)(rest >> 64); }
-                nseg[r] = ns;
-                if (over) ctl[3] = 1;
-            WB_END_PFOR
-        }
+                if (ns > 0) { seglo[(ns - 1) * WB_BOXCOM_NL + l] = (unsigned long long)rest; seghi[(ns - 1) * WB_BOXCOM_NL + l] = (unsigned long long)(rest >> 64); }
+                nseg[l] = ns;
+                if (over) b[10] = 1;
+            }
+        WB_END_PFOR
         WB_BSTAMP(a.ctl, 1);
-        if (!ctl[3]) {
-            // pass 2: predicted state at every row start; chains 0 areas (terms w), 1 x_com (x * w), 2 y_com (y * w)
-            WB_PFOR(ch, 3)
+        // pass 2: predicted state at every row start; chains 0 areas (terms w), 1 x_com (x * w), 2 y_com (y * w)
+        WB_PFOR(l, WB_BOXCOM_NL)
+            const int g = (int)l / WB_BOXCOM_ROWS;
+            int* b = bx + 12 * g;
+            const int nr = b[6];
+            for (int ch = (int)l % WB_BOXCOM_ROWS; ch < 3 && nr > 0 && !b[10]; ch += WB_BOXCOM_ROWS) {   // (a lane per chain; chunks of fewer than three rows: a lane takes several)
+                const int ue = b[7], cols = b[2] - b[0] + 1;
                 wb_u128 E = 0;
                 bool ok = true;
                 for (int r = 0; r < nr && ok; ++r) {
-                    const int y = y0 + r0 + r;
+                    const int y = b[1] + b[5] + r, lr = g * WB_BOXCOM_ROWS + r;
                     const double w = a.wlat[y];
-                    const int ns = ch == 1 ? nseg[r] : 1;
+                    const int ns = ch == 1 ? nseg[lr] : 1;
                     for (int k = 0; k < ns && ok; ++k) {
                         double sv, cv;
                         if (r == 0 && k == 0) {                      // the chunk's start: the true state, as it is
-                            sv = st[(2 * ch) * (WB_BOXCOM_ROWS + 1)]; cv = st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1)];
+                            sv = WB_BOXCOM_ST(2 * ch, g, 0); cv = WB_BOXCOM_ST(2 * ch + 1, g, 0);
                         } else {
                             ok = wb_state_from_exact(E, ue, &sv, &cv);
-                            if (k == 0) { st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + r] = sv; st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + r] = cv; }
+                            if (k == 0) { WB_BOXCOM_ST(2 * ch, g, r) = sv; WB_BOXCOM_ST(2 * ch + 1, g, r) = cv; }
                         }
                         double v;
                         wb_u128 rest;
                         if (ch == 1) {
-                            v = segv[k * WB_BOXCOM_ROWS + r];
-                            rest = ((wb_u128)seghi[k * WB_BOXCOM_ROWS + r] << 64) | seglo[k * WB_BOXCOM_ROWS + r];
+                            v = segv[k * WB_BOXCOM_NL + lr];
+                            rest = ((wb_u128)seghi[k * WB_BOXCOM_NL + lr] << 64) | seglo[k * WB_BOXCOM_NL + lr];
                         } else {
                             v = ch == 0 ? w : (double)y * w;
                             unsigned long long m; int ex;
@@ -787,85 +823,96 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                 }
                 double sv = 0.0, cv = 0.0;
                 ok = ok && wb_state_from_exact(E, ue, &sv, &cv);
-                st[(2 * ch) * (WB_BOXCOM_ROWS + 1) + nr] = sv;
-                st[(2 * ch + 1) * (WB_BOXCOM_ROWS + 1) + nr] = cv;
-                if (!ok) ctl[3] = 1;
-            WB_END_PFOR
-        }
-        WB_BSTAMP(a.ctl, 2);
-        if (!ctl[3]) {
-            // pass 3: the real recurrence over every row from its predicted state; the end must be the next row's start
-            WB_PFOR(r, nr)
-                const int y = y0 + r0 + (int)r;
-                const double w = a.wlat[y], yw = (double)y * w;
-                double sa = st[0 * (WB_BOXCOM_ROWS + 1) + r], ca = st[1 * (WB_BOXCOM_ROWS + 1) + r];
-                double sx = st[2 * (WB_BOXCOM_ROWS + 1) + r], cx = st[3 * (WB_BOXCOM_ROWS + 1) + r];
-                double sy = st[4 * (WB_BOXCOM_ROWS + 1) + r], cy = st[5 * (WB_BOXCOM_ROWS + 1) + r];
-                for (int x = x0; x <= x1; ++x) {
-                    const double xw = (double)x * w;
-                    WB_KAHAN(sa, ca, w);
-                    WB_KAHAN(sx, cx, xw);
-                    WB_KAHAN(sy, cy, yw);
-                }
-                if (!(sa == st[0 * (WB_BOXCOM_ROWS + 1) + r + 1] && ca == st[1 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
-                      sx == st[2 * (WB_BOXCOM_ROWS + 1) + r + 1] && cx == st[3 * (WB_BOXCOM_ROWS + 1) + r + 1] &&
-                      sy == st[4 * (WB_BOXCOM_ROWS + 1) + r + 1] && cy == st[5 * (WB_BOXCOM_ROWS + 1) + r + 1])) ctl[3] = 1;
-            WB_END_PFOR
-        }
-        WB_BSTAMP(a.ctl, 3);
-        walked = walked || ctl[3] != 0;
-        WB_SINGLE
-        double sa, ca, sx, cx, sy, cy;
-        if (ctl[3]) {                                            // one lane, the chunk's cells in the reference's order, from the true start
-            sa = st[0 * (WB_BOXCOM_ROWS + 1)]; ca = st[1 * (WB_BOXCOM_ROWS + 1)];
-            sx = st[2 * (WB_BOXCOM_ROWS + 1)]; cx = st[3 * (WB_BOXCOM_ROWS + 1)];
-            sy = st[4 * (WB_BOXCOM_ROWS + 1)]; cy = st[5 * (WB_BOXCOM_ROWS + 1)];
-            for (int y = y0 + r0; y < y0 + r0 + nr; ++y) {
-                const double w = a.wlat[y];
-                const double yw = (double)y * w;
-                for (int x = x0; x <= x1; ++x) {
-                    const double xw = (double)x * w;
-                    WB_KAHAN(sa, ca, w);
-                    WB_KAHAN(sx, cx, xw);
-                    WB_KAHAN(sy, cy, yw);
-                }
+                WB_BOXCOM_ST(2 * ch, g, nr) = sv;
+                WB_BOXCOM_ST(2 * ch + 1, g, nr) = cv;
+                if (!ok) b[10] = 1;
             }
-        } else {
-            sa = st[0 * (WB_BOXCOM_ROWS + 1) + nr]; ca = st[1 * (WB_BOXCOM_ROWS + 1) + nr];
-            sx = st[2 * (WB_BOXCOM_ROWS + 1) + nr]; cx = st[3 * (WB_BOXCOM_ROWS + 1) + nr];
-            sy = st[4 * (WB_BOXCOM_ROWS + 1) + nr]; cy = st[5 * (WB_BOXCOM_ROWS + 1) + nr];
-        }
-        st[0 * (WB_BOXCOM_ROWS + 1)] = sa; st[1 * (WB_BOXCOM_ROWS + 1)] = ca;      // the next chunk's start
-        st[2 * (WB_BOXCOM_ROWS + 1)] = sx; st[3 * (WB_BOXCOM_ROWS + 1)] = cx;
-        st[4 * (WB_BOXCOM_ROWS + 1)] = sy; st[5 * (WB_BOXCOM_ROWS + 1)] = cy;
-        WB_END_SINGLE
+        WB_END_PFOR
+        WB_BSTAMP(a.ctl, 2);
+        // pass 3: the real recurrence over every row from its predicted state; the end must be the next row's start
+        WB_PFOR(l, WB_BOXCOM_NL)
+            const int g = (int)l / WB_BOXCOM_ROWS, r = (int)l % WB_BOXCOM_ROWS;
+            int* b = bx + 12 * g;
+            if (r < b[6] && !b[10]) {
+                const int x0 = b[0], x1 = b[2], y = b[1] + b[5] + r;
+                const double w = a.wlat[y], yw = (double)y * w;
+                double sa = WB_BOXCOM_ST(0, g, r), ca = WB_BOXCOM_ST(1, g, r);
+                double sx = WB_BOXCOM_ST(2, g, r), cx = WB_BOXCOM_ST(3, g, r);
+                double sy = WB_BOXCOM_ST(4, g, r), cy = WB_BOXCOM_ST(5, g, r);
+                for (int x = x0; x <= x1; ++x) {
+                    const double xw = (double)x * w;
+                    WB_KAHAN(sa, ca, w);
+                    WB_KAHAN(sx, cx, xw);
+                    WB_KAHAN(sy, cy, yw);
+                }
+                if (!(sa == WB_BOXCOM_ST(0, g, r + 1) && ca == WB_BOXCOM_ST(1, g, r + 1) &&
+                      sx == WB_BOXCOM_ST(2, g, r + 1) && cx == WB_BOXCOM_ST(3, g, r + 1) &&
+                      sy == WB_BOXCOM_ST(4, g, r + 1) && cy == WB_BOXCOM_ST(5, g, r + 1))) b[10] = 1;
+            }
+        WB_END_PFOR
+        WB_BSTAMP(a.ctl, 3);
+        WB_PFOR(g, WB_BOXCOM_G)                                      // a lane per box: the chunk's end state becomes the next chunk's start
+            int* b = bx + 12 * g;
+            const int nr = b[6];
+            if (nr > 0) {
+                double sa, ca, sx, cx, sy, cy;
+                if (b[10]) {                                         // one lane, the chunk's cells in the reference's order, from the true start
+                    b[11] = 1;
+                    sa = WB_BOXCOM_ST(0, g, 0); ca = WB_BOXCOM_ST(1, g, 0);
+                    sx = WB_BOXCOM_ST(2, g, 0); cx = WB_BOXCOM_ST(3, g, 0);
+                    sy = WB_BOXCOM_ST(4, g, 0); cy = WB_BOXCOM_ST(5, g, 0);
+                    for (int y = b[1] + b[5]; y < b[1] + b[5] + nr; ++y) {
+                        const double w = a.wlat[y];
+                        const double yw = (double)y * w;
+                        for (int x = b[0]; x <= b[2]; ++x) {
+                            const double xw = (double)x * w;
+                            WB_KAHAN(sa, ca, w);
+                            WB_KAHAN(sx, cx, xw);
+                            WB_KAHAN(sy, cy, yw);
+                        }
+                    }
+                } else {
+                    sa = WB_BOXCOM_ST(0, g, nr); ca = WB_BOXCOM_ST(1, g, nr);
+                    sx = WB_BOXCOM_ST(2, g, nr); cx = WB_BOXCOM_ST(3, g, nr);
+                    sy = WB_BOXCOM_ST(4, g, nr); cy = WB_BOXCOM_ST(5, g, nr);
+                }
+                WB_BOXCOM_ST(0, g, 0) = sa; WB_BOXCOM_ST(1, g, 0) = ca;
+                WB_BOXCOM_ST(2, g, 0) = sx; WB_BOXCOM_ST(3, g, 0) = cx;
+                WB_BOXCOM_ST(4, g, 0) = sy; WB_BOXCOM_ST(5, g, 0) = cy;
+                b[5] += nr;
+            }
+        WB_END_PFOR
         WB_BSTAMP(a.ctl, 4);
     }
-    WB_SINGLE
-    double sa, sx, sy;
-    if (ctl[2]) {                                                // exponents out of the fixed-point range: one lane walks every cell
-        double ca = 0.0, cx = 0.0, cy = 0.0;
-        sa = 0.0; sx = 0.0; sy = 0.0;
-        for (int y = y0; y <= y1; ++y) {
-            const double w = a.wlat[y];
-            const double yw = (double)y * w;
-            for (int x = x0; x <= x1; ++x) {
-                const double xw = (double)x * w;
-                WB_KAHAN(sa, ca, w);
-                WB_KAHAN(sx, cx, xw);
-                WB_KAHAN(sy, cy, yw);
+    WB_PFOR(g, WB_BOXCOM_G)
+        const int* b = bx + 12 * g;
+        if (q0 + (int)g < nq) {
+            double* out = a.ot_sums + (size_t)a.boxq[q0 + (int)g] * 3;
+            double sa, sx, sy;
+            if (b[9]) {                                              // exponents out of the fixed-point range: one lane walks every cell
+                double ca = 0.0, cx = 0.0, cy = 0.0;
+                sa = 0.0; sx = 0.0; sy = 0.0;
+                for (int y = b[1]; y <= b[3]; ++y) {
+                    const double w = a.wlat[y];
+                    const double yw = (double)y * w;
+                    for (int x = b[0]; x <= b[2]; ++x) {
+                        const double xw = (double)x * w;
+                        WB_KAHAN(sa, ca, w);
+                        WB_KAHAN(sx, cx, xw);
+                        WB_KAHAN(sy, cy, yw);
+                    }
+                }
+            } else {
+                sa = WB_BOXCOM_ST(0, g, 0);
+                sx = WB_BOXCOM_ST(2, g, 0);
+                sy = WB_BOXCOM_ST(4, g, 0);
             }
+            if (b[9] || b[11]) wb_atomic_add(&a.ctl->com_rechecks[2], 1);
+            out[0] = sa;
+            out[1] = sx;
+            out[2] = sy;
         }
-    } else {
-        sa = st[0 * (WB_BOXCOM_ROWS + 1)];
-        sx = st[2 * (WB_BOXCOM_ROWS + 1)];
-        sy = st[4 * (WB_BOXCOM_ROWS + 1)];
-    }
-    if (ctl[2] || walked) wb_atomic_add(&a.ctl->com_rechecks[2], 1);
-    out[0] = sa;
-    out[1] = sx;
-    out[2] = sy;
-    WB_END_SINGLE
+    WB_END_PFOR
     WB_BSTAMP(a.ctl, 4);
     }   // the queue
     WB_BSTAMP_FLUSH(a.ctl);
