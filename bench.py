@@ -74,6 +74,9 @@ def parse():
 
 def main():
     a = parse()
+    if os.environ.get("WB_BENCH_WATCHDOG"):                       # development: after that many seconds every thread's stack goes to stderr and the run ends
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["WB_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -634,7 +634,9 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 //     box taller than 128 rows, wider than 4 binades or with one mismatch was walked whole: 16 of the bench batch's 6 391
 //     boxes, the largest of them 1.6 ms on one lane -- the kernel's whole duration.)
 #ifndef WB_BOXCOM_ROWS
-#define WB_BOXCOM_ROWS 16            // rows of a box per chunk (a lane each; 64 / WB_BOXCOM_ROWS boxes share a wave)
+#define WB_BOXCOM_ROWS 64            // rows of a box per chunk (a lane each; 64 / WB_BOXCOM_ROWS boxes share a wave: 16 rows x 4 boxes
+                                     // ran pass 2 on twelve lanes instead of three and the kernel in 0.93 ms instead of 0.55 -- a quarter of
+                                     // the waves, each three times as long in passes 1 and 3: the kernel is short of waves, not of lanes)
 #endif
 #ifndef WB_BOXCOM_FORCE_WALK
 #define WB_BOXCOM_FORCE_WALK 0       // 1 (a test build): no chunk is predicted, one lane walks them all

@@ -85,13 +85,15 @@ class BatchPipeline:
         def both(ctx, k):
             if self.offset_start and 0 < k < d:
                 started[k - 1].wait()
-            if l1 is not None:                      # set_stagger: a phase is entered by one batch at a time
-                with l1:
+            try:
+                if l1 is not None:                  # set_stagger: a phase is entered by one batch at a time
+                    with l1:
+                        b = contours(ctx, k)
+                else:
                     b = contours(ctx, k)
-            else:
-                b = contours(ctx, k)
-            if k < d:
-                started[k].set()
+            finally:
+                if k < d:
+                    started[k].set()                # (also when phase 1 raised: the next worker must not wait for ever)
             if l2 is not None:
                 with l2:
                     return b.max_nux(), indices(ctx, k, b, full_width)
