@@ -1254,7 +1254,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_pairs");
             if (st.p2_cap > 0) {
-                { long long g2 = (long long)nsel_b * st.p2_split, res = (long long)ctx->p2_grid_x2 * wb_num_cus(ctx) / 2;   // persistent: two workgroups of 16 waves per CU
+                { long long g2 = (long long)nsel_b * st.p2_split, res = (long long)ctx->p2_grid_x2 * wb_num_cus(ctx) / 2 - ctx->persist_slack;   // persistent: two workgroups of 16 waves per CU (minus option persist_slack)
+                  if (res < 1) res = 1;
                   if (res < 1) res = 1;
                   WB_LAUNCH_LDS(wb_k_streamer_pairs2, g2 < res ? g2 : res, WB_P2_THREADS, p2_lds, st); }
                 WB_LAUNCH(wb_k_streamer_recheck, 64, 64, st);              // pairs inside a guard band (normally none)
@@ -1263,7 +1264,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_pairs_order, 1, WB_LIST_THREADS, st);
-            { const long long res = 2LL * wb_num_cus(ctx); WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
+            { long long res = 2LL * wb_num_cus(ctx) - ctx->persist_slack; if (res < 1) res = 1; WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
             b->timer.end(ctx);
             if (ctx->eager_f2) {
                 // routine 2 for every candidate pair, then routines 3 + 4 on the survivors (option "eager_f2": the exhaustive
@@ -1752,6 +1753,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_exclusive")) { ctx->scan_exclusive = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_priority")) { ctx->scan_priority = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "persist_slack")) { ctx->persist_slack = value > 0 ? (int)value : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }

@@ -41,6 +41,7 @@ struct wb_ctx {
     int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int boxcom_per_cu = 12;                   // persistent grid of wb_k_box_com: single-wave workgroups per CU (what its LDS admits)
+    int persist_slack = 0;                    // workgroup places the persistent 1024-thread launches (all-pairs, routine 1) leave free: a full grid holds EVERY wave slot of the device until its queue is empty, and the other batch's small kernels wait for that
     int scan_priority = 0;                    // 1: the field scan is launched on a stream of the device's highest priority
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
@@ -243,7 +244,9 @@ static void dzero_flush(wb_ctx* c) {
         z.p[k] = k < c->zq_n ? (unsigned char*)c->zq_p[k] : nullptr; z.bytes[k] = k < c->zq_n ? c->zq_bytes[k] : 0;
         if (z.bytes[k] > mx) mx = z.bytes[k];
     }
-    size_t blocks = (mx + 256 * 16 - 1) / (256 * 16);
+    // few workgroups, each with up to 64 stores per thread: the launch is over when its LAST workgroup has found a place, and
+    // beside the other batch's persistent kernels a hundred workgroups of 4 KB each waited 0.3 ms on average for theirs
+    size_t blocks = (mx + 256 * 16 * 64 - 1) / (256 * 16 * 64);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wb_k_zero_segs, dim3((unsigned)blocks, (unsigned)c->zq_n), dim3(256), 0, c->stream, z);
