@@ -286,7 +286,7 @@ def main():
         pipe.run(a.stagger_steps, phase1, reduce_max, phase2, collect_scan, full_width=full_w)
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - tic_s
-        pipe.set_stagger(0)
+        pipe.set_stagger(pipe.default_stagger)
         sc = float(np.mean(st_ms))
         staggered = {"value": nt * a.stagger_steps / dt_s, "ms_per_step": 1e3 * dt_s / a.stagger_steps, "steps": a.stagger_steps,
                      "scan_launch_ms": sc, "roofline_frac": nt * nlat * nlon * 4 / (sc * 1e-3) / HBM_PEAK,

@@ -33,18 +33,20 @@ class BatchPipeline:
     def __init__(self, device=0, depth=2, library=None, stagger=None):
         self.contexts = [_hip.Context(device, library) for _ in range(max(1, int(depth)))]
         self._workers = [ThreadPoolExecutor(max_workers=1) for _ in self.contexts]
-        # stagger: the two phases of the ABI are each entered by one batch at a time, so that in steady state one batch's
-        # phase 1 (the HBM-bound scan + the trace kernels) runs beside the other's phase 2 instead of beside its twin
+        # stagger (set_stagger): which of the two phases of the ABI are entered by one batch at a time.  Default 2: phase 1 (the HBM-bound scan + the trace kernels) is entered by one batch at a time.  Left free, two batches
+        # that happen to fall into step -- the same kernel of both at the same time, each on half the device -- stay in step
+        # (one run in ten, more often the longer the record: 300-320 k timesteps/s instead of 335-345 k on the bench batch); with
+        # phase 1 exclusive they cannot: 338-345 k in every run (tools/r04_session_s2.sh).  Phase 2 exclusive, or both, cost 5-8 %.
         if stagger is None:
-            stagger = int(os.environ.get("WB_PIPE_STAGGER", "0"))
-        stagger = int(stagger)                                   # 1: both phases exclusive, 2: phase 1 only, 3: phase 2 only
-        self._locks = (threading.Lock() if stagger in (1, 2) else None, threading.Lock() if stagger in (1, 3) else None) if stagger else None
+            stagger = int(os.environ.get("WB_PIPE_STAGGER", "2"))
+        self.default_stagger = int(stagger)
+        self.set_stagger(self.default_stagger)
         self.offset_start = os.environ.get("WB_PIPE_OFFSET_START", "1") != "0"
 
     def set_stagger(self, mode):
-        """0: the batches' phases overlap freely (most timesteps/s); 1: each phase is entered by one batch at a time -- one
-        batch's scan + trace kernels then run beside the other's index kernels, never beside their twins (the scan keeps
-        ~0.62 of the HBM peak instead of ~0.55, the whole job loses ~12 %); 2 / 3: only phase 1 / only phase 2 exclusive"""
+        """0: the batches' phases overlap freely; 1: each phase is entered by one batch at a time -- one batch's scan + trace
+        kernels then run beside the other's index kernels, never beside their twins (the scan keeps ~0.62 of the HBM peak
+        instead of ~0.5, the whole job loses 5-8 %); 2 (the default) / 3: only phase 1 / only phase 2 exclusive"""
         mode = int(mode)
         self._locks = (threading.Lock() if mode in (1, 2) else None, threading.Lock() if mode in (1, 3) else None) if mode else None
 
