@@ -236,6 +236,27 @@ def test_link_merge_by_searches_equals_merge_by_row_tables(ctx):
             assert np.array_equal(tabs[0][key], tabs[1][key]), (dlon, key)
 
 
+def test_launch_options_change_no_result(ctx):
+    """scan_priority (the field scan on a stream of the highest priority), persist_slack (places the persistent launches leave
+    free) and boxcom_per_cu only move work in time: same events, same sums"""
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(3, 4, lat, lon, eps=0.2)
+    base = None
+    for opts in ({}, {"scan_priority": 1}, {"persist_slack": 64, "boxcom_per_cu": 3}):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(4), [-2.0, 2.0], intensity=pv)
+        finally:
+            ctx.set_option("scan_priority", 0)
+            ctx.set_option("persist_slack", 0)
+            ctx.set_option("boxcom_per_cu", 12)
+        counts = tuple(int(got[kind]["step"].size) for kind in ("streamers", "overturnings", "cutoffs"))   # (full_parity has compared every column with the oracle)
+        if base is None:
+            base = counts
+        assert counts == base and sum(counts) > 10
+
+
 def test_reference_own_code_fixture_through_the_abi(ctx, golden_dir):
     """the HIP path against outputs of the REFERENCE'S OWN statements (tests/golden/reference_rules.npz, made in the build
     container by tests/golden/make_golden_reference.py): contour tables (contour_index.py:105-155 on scikit-image's output),
