@@ -213,6 +213,9 @@ void wb_comm_destroy(wb_ctx* ctx);
 /* device memory + synthetic ERA5-shaped PV for the benchmark */
 void* wb_dev_alloc(wb_ctx* ctx, uint64_t bytes);
 void wb_dev_free(wb_ctx* ctx, void* p);
+/* milliseconds of one streaming read of a device buffer (best of reps; -1: failed).  No counterpart in the reference: on this
+   platform an allocation's physical placement decides 15 % of the HBM throughput a kernel gets from it */
+double wb_probe_read_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, int reps);
 int wb_memcpy_h2d(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int wb_memcpy_d2h(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, int nlat, int nlon,

@@ -22,5 +22,19 @@ for k in range(6):
         b = ctx.contours(d, lat, lon, [-2.0, 2.0], 0.25, 0.25, device_shape=(nt, nlat, nlon), device_dtype=np.float32)
         ts.append(dict(b.timings())["scan"])
         b.close()
+    if os.environ.get("WB_PROBE_BANDS"):
+        per = []
+        for nb in [int(v) for v in os.environ["WB_PROBE_BANDS"].split(",")]:
+            ctx.set_option("scan_bands", nb)
+            tt = []
+            for rep in range(3):
+                b = ctx.contours(d, lat, lon, [-2.0, 2.0], 0.25, 0.25, device_shape=(nt, nlat, nlon), device_dtype=np.float32)
+                tt.append(dict(b.timings())["scan"])
+                b.close()
+            per.append("%d bands %.3f" % (nb, min(tt)))
+        ctx.set_option("scan_bands", 0)
+        print("   " + ", ".join(per), flush=True)
+    rd = ctx.probe_read_ms(d, fb, 3)
+    print("   streaming read of it: %.3f ms = %.2f TB/s" % (rd, fb / rd / 1e9), flush=True)
     print("buffer %d at 0x%x (mod 1 GiB: %d MiB, mod 2 MiB: %d KiB): scan %s ms" % (k, d, (d % (1 << 30)) >> 20, (d % (2 << 20)) >> 10, ["%.3f" % t for t in ts]), flush=True)
 ctx.close()

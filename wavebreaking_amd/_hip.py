@@ -100,6 +100,8 @@ class Library:
                                               C.c_int, C.c_int, C.POINTER(WbGeometry)]
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.wb_probe_read_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        lib.wb_probe_read_ms.restype = C.c_double
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_set_step_offset.argtypes = [C.c_void_p, C.c_int64]
         lib.wb_get_device_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
@@ -201,6 +203,10 @@ class Context:
 
     def free(self, p):
         self.L.lib.wb_dev_free(self.h, C.c_void_p(p))
+
+    def probe_read_ms(self, p, nbytes, reps=3):
+        """milliseconds of one streaming read of a device buffer (best of reps)"""
+        return float(self.L.lib.wb_probe_read_ms(self.h, C.c_void_p(p), int(nbytes), int(reps)))
 
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
