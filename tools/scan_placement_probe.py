@@ -22,6 +22,18 @@ for k in range(6):
         b = ctx.contours(d, lat, lon, [-2.0, 2.0], 0.25, 0.25, device_shape=(nt, nlat, nlon), device_dtype=np.float32)
         ts.append(dict(b.timings())["scan"])
         b.close()
+    if os.environ.get("WB_PROBE_BAND_ROWS"):
+        per = []
+        for br in [int(v) for v in os.environ["WB_PROBE_BAND_ROWS"].split(",")]:
+            ctx.set_option("scan_band_rows", br)
+            tt = []
+            for rep in range(3):
+                b = ctx.contours(d, lat, lon, [-2.0, 2.0], 0.25, 0.25, device_shape=(nt, nlat, nlon), device_dtype=np.float32)
+                tt.append(dict(b.timings())["scan"])
+                b.close()
+            per.append("%d rows %.3f" % (br, min(tt)))
+        ctx.set_option("scan_band_rows", 0)
+        print("   " + ", ".join(per), flush=True)
     if os.environ.get("WB_PROBE_BANDS"):
         per = []
         for nb in [int(v) for v in os.environ["WB_PROBE_BANDS"].split(",")]:

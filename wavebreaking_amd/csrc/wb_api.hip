@@ -360,6 +360,7 @@ static int run_phase1(wb_batch* b) {
             }
             if (nbands > nlat - 1) nbands = nlat - 1;
             sa.band_rows = (nlat - 1 + nbands - 1) / nbands;
+            if (ctx->scan_band_rows > 0 && ctx->scan_band_rows <= 255 && ctx->scan_band_rows >= sa.band_rows) sa.band_rows = ctx->scan_band_rows;   // (option "scan_band_rows": longer bands, a shorter last one -- other start addresses for the same number of lists)
             sa.nbands = (nlat - 1 + sa.band_rows - 1) / sa.band_rows;
             sa.cap_rec = caps;
             sa.debug = ctx->scan_debug;
@@ -1799,6 +1800,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "persist_slack")) { ctx->persist_slack = value > 0 ? (int)value : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
+    if (!strcmp(name, "scan_band_rows")) { ctx->scan_band_rows = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }
     if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }
     if (!strcmp(name, "timers")) { ctx->timers = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
