@@ -478,7 +478,9 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     # every call above fingerprinted every byte of both cubes (wb_fingerprint) to make sure the device copies still mirror them;
     # a caller who promises not to modify the cubes in place (wb.keep_inputs) is recognised by address + a strided sample
     out["fingerprint"] = {"calls": fp["full"], "seconds_total": fp["seconds"], "GBps": (fp["full"] * pv.nbytes / fp["seconds"] / 1e9) if fp["seconds"] > 0 else None,
-                          "what": "wb_fingerprint over whole cubes in the calls so far (several host threads)"}
+                          "beside_the_call": fp.get("speculated", 0),
+                          "what": "wb_fingerprint over whole cubes in the calls so far (several host threads); beside_the_call: taken on other "
+                                  "threads while the call went on with the device copy, checked before the call returned (engine.verify_pending)"}
     wb.release_inputs()
     wb.keep_inputs(data, idata)
     secs_k, rows_k = three(data, idata)

@@ -472,6 +472,35 @@ def test_inputs_and_contour_batches_stay_on_the_device_between_calls(hostsim_eng
     assert not resident and not kept
 
 
+@pytest.mark.parametrize("speculate", [True, False])
+def test_device_copy_used_on_trust_and_checked_before_the_call_returns(hostsim_engine, monkeypatch, speculate):
+    """a call whose cube is on the device already goes on with that copy while the cube's fingerprint is taken on other
+    threads, and checks it before it returns (engine.verify_pending): unchanged cube -> no upload; changed cube -> the call
+    starts over from the bytes as they are (one more upload) and returns the new events.  WB_INPUT_SPECULATE=0: the same
+    results with the fingerprint first"""
+    monkeypatch.setattr(engine, "SPECULATE", speculate)
+    data, pv, lat, lon, tm = _field()
+    ctx = engine.get_context()
+    uploads = []
+    real_up = ctx.to_device
+    monkeypatch.setattr(ctx, "to_device", lambda a: (uploads.append(a.shape), real_up(a))[1])
+    s0 = engine.FINGERPRINT_STATS.get("speculated", 0)
+    a1 = wb.calculate_overturnings(data=data, contour_levels=[2])
+    a2 = wb.calculate_overturnings(data=data, contour_levels=[2])
+    a3 = wb.calculate_contours(data=data, contour_levels=[2])
+    assert len(uploads) == 1 and len(a1) == len(a2) and len(a3) > 0
+    assert (engine.FINGERPRINT_STATS.get("speculated", 0) - s0 >= 2) == speculate
+    assert not engine._pending_by_head
+    v = data.values
+    v[2] = v[2][:, ::-1].copy()                                   # a whole time step mirrored in place
+    b1 = wb.calculate_overturnings(data=data, contour_levels=[2])
+    assert len(uploads) == 2 and not engine._pending_by_head
+    fresh = wb.GridField(np.array(v), data.dims, data.coords)     # the same bytes in a new array: no cache entry to trust
+    b2 = wb.calculate_overturnings(data=fresh, contour_levels=[2])
+    assert len(b1) == len(b2) and list(b1["com"]) == list(b2["com"]) and list(b1["date"]) == list(b2["date"])
+    assert list(b1["com"]) != list(a1["com"])
+
+
 def test_an_edit_of_one_time_step_between_two_calls_is_seen(hostsim_engine, monkeypatch):
     """the reference rereads its input on every call (index_utils.py:66-75): a region of ONE time step patched in place
     between two calls -- far from any strided sample -- gives the new events, not the cached cube's; cubes registered with

@@ -202,12 +202,77 @@ def _array_key(arr, ctx=None):
         edge = np.concatenate([flat[:256], flat[-256:]])
         FINGERPRINT_STATS["sampled"] += 1
         return head + ("sampled", hash(sample.tobytes()), hash(edge.tobytes()))
-    tic = time.perf_counter()
-    lib = (ctx or get_context()).L
-    fp = lib.fingerprint(arr)
-    FINGERPRINT_STATS["full"] += 1
-    FINGERPRINT_STATS["seconds"] += time.perf_counter() - tic
-    return head + ("full", fp)
+    ctx = ctx or get_context()
+    lib = ctx.L
+
+    def fingerprint():
+        tic = time.perf_counter()
+        fp = lib.fingerprint(arr)                # (releases the GIL; several host threads of its own)
+        FINGERPRINT_STATS["full"] += 1
+        FINGERPRINT_STATS["seconds"] += time.perf_counter() - tic
+        return fp
+    if SPECULATE:
+        # A cube of this address, shape and dtype is on the device already: go on with that copy while the fingerprint of the
+        # bytes as they are NOW is taken on other threads; the call checks it before it returns anything (verify_pending) and
+        # starts over with a fresh upload if the cube has changed -- the check costs the call nothing unless it fails.
+        with _pending_lock:
+            hit = _pending_by_head.get((ctx.device, head))
+            if hit is not None:
+                return hit[0]
+            resident, _ = _caches(ctx)
+            for k in resident:
+                if k[:3] == head and k[3] == "full":
+                    fut = _fp_pool().submit(fingerprint)
+                    _pending_by_head[(ctx.device, head)] = (k, fut, ctx)
+                    FINGERPRINT_STATS["speculated"] = FINGERPRINT_STATS.get("speculated", 0) + 1
+                    return k
+    return head + ("full", fingerprint())
+
+
+class StaleInput(Exception):
+    """a cube that a call took from the device cache turned out to have changed on the host (verify_pending)"""
+
+
+# WB_INPUT_SPECULATE=0: every call waits for the fingerprints of its cubes before it touches the device copies
+SPECULATE = os.environ.get("WB_INPUT_SPECULATE", "1") != "0"
+_pending_by_head = {}    # (device, (address, shape, dtype)) -> (speculated key, future of the fingerprint, context): the running call's
+_pending_lock = threading.Lock()
+_fp_executor = [None]
+
+
+def _fp_pool():
+    if _fp_executor[0] is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _fp_executor[0] = ThreadPoolExecutor(2)
+    return _fp_executor[0]
+
+
+def verify_pending():
+    """the end of a call that used device copies on trust: wait for the fingerprints taken meanwhile; a cube whose bytes no
+    longer match its copy is dropped from the cache (with the contour batches traced from it) and StaleInput is raised -- the
+    caller runs the call again, which then uploads the cube as it is"""
+    with _pending_lock:
+        items = list(_pending_by_head.values())
+        _pending_by_head.clear()
+    stale = False
+    for key, fut, ctx in items:
+        if fut.result() != key[4]:
+            stale = True
+            _drop_resident(ctx, key)
+    if stale:
+        raise StaleInput()
+
+
+def discard_pending():
+    """a call that ends with an exception: let its fingerprints finish, keep nothing"""
+    with _pending_lock:
+        items = list(_pending_by_head.values())
+        _pending_by_head.clear()
+    for _, fut, _ in items:
+        try:
+            fut.result()
+        except BaseException:
+            pass
 
 
 def _cacheable(arr):

@@ -21,10 +21,17 @@ class LazyContours:
 
 def run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max=None):
     """kind: _hip.STREAMERS / OVERTURNINGS / CUTOFFS.  Returns the reference-shaped frame."""
-    try:
-        return _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max)
-    finally:
-        engine.release_call_transients(engine.get_context())     # cubes uploaded for this call only (engine.resident_input)
+    for attempt in (0, 1):
+        try:
+            out = _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max)
+            engine.verify_pending()               # device copies used on trust: their cubes' fingerprints, taken meanwhile
+            return out
+        except engine.StaleInput:                 # a cube changed on the host since it was uploaded: once more, from its bytes as they are
+            if attempt:
+                raise RuntimeError("wavebreaking_amd: an input cube keeps changing while the call runs")
+        finally:
+            engine.discard_pending()
+            engine.release_call_transients(engine.get_context())     # cubes uploaded for this call only (engine.resident_input)
 
 
 def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max):

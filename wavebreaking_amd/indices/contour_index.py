@@ -79,13 +79,20 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     prep = engine.Prepared(data, None, kwargs)
     levels = engine.as_levels(contour_levels)
     # every batch (block of time steps x group of <= 4 levels) is released as soon as its table is on the host
-    tables = []
-    try:
-        for b, pos, t0 in engine.iter_contour_batches(prep, levels, periodic_add, {}):
-            tables.append((b.contour_table(), pos, t0))
-            b.close()
-    finally:
-        engine.release_call_transients(engine.get_context())
+    for attempt in (0, 1):
+        tables = []
+        try:
+            for b, pos, t0 in engine.iter_contour_batches(prep, levels, periodic_add, {}):
+                tables.append((b.contour_table(), pos, t0))
+                b.close()
+            engine.verify_pending()               # a device copy used on trust: the cube's fingerprint, taken meanwhile
+            break
+        except engine.StaleInput:                 # the cube changed on the host since it was uploaded: once more
+            if attempt:
+                raise RuntimeError("wavebreaking_amd: the input cube keeps changing while the call runs")
+        finally:
+            engine.discard_pending()
+            engine.release_call_transients(engine.get_context())
     return _contour_frame(tables, prep, levels, original_coordinates)
 
 
