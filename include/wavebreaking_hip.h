@@ -216,6 +216,9 @@ void wb_dev_free(wb_ctx* ctx, void* p);
 /* milliseconds of one streaming read of a device buffer (best of reps; -1: failed).  No counterpart in the reference: on this
    platform an allocation's physical placement decides 15 % of the HBM throughput a kernel gets from it */
 double wb_probe_read_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, int reps);
+/* ... and of a read by `grid` workgroups that each stream chunks of chunk_bytes from start to end (the scan's pattern: 256
+   workgroups, 1.4 MB chunks); development yardstick */
+double wb_probe_streams_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, uint64_t chunk_bytes, int grid, int reps);
 int wb_memcpy_h2d(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int wb_memcpy_d2h(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, int nlat, int nlon,

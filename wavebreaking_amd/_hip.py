@@ -102,6 +102,8 @@ class Library:
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_probe_read_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         lib.wb_probe_read_ms.restype = C.c_double
+        lib.wb_probe_streams_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+        lib.wb_probe_streams_ms.restype = C.c_double
         lib.wb_get_pair_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_set_step_offset.argtypes = [C.c_void_p, C.c_int64]
         lib.wb_get_device_tables.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
@@ -203,6 +205,10 @@ class Context:
 
     def free(self, p):
         self.L.lib.wb_dev_free(self.h, C.c_void_p(p))
+
+    def probe_streams_ms(self, p, nbytes, chunk_bytes, grid=0, reps=3):
+        """milliseconds of a read by `grid` workgroups each streaming chunks of chunk_bytes (best of reps)"""
+        return float(self.L.lib.wb_probe_streams_ms(self.h, C.c_void_p(p), int(nbytes), int(chunk_bytes), int(grid), int(reps)))
 
     def probe_read_ms(self, p, nbytes, reps=3):
         """milliseconds of one streaming read of a device buffer (best of reps)"""

@@ -165,7 +165,53 @@ __global__ __launch_bounds__(256) void wb_k_probe_read(const uint4* p, size_t n1
     for (; i < n16; i += stride) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
     if (acc == 0x9E3779B9u) sink[0] = acc;                         // (keeps the loads)
 }
+// the same bytes read as the scan reads them: `grid` workgroups of 512 threads, each streaming chunks of chunk16 16-byte words
+// from start to end (chunk b, b + grid, ...), eight 8 KB steps in flight
+__global__ __launch_bounds__(512) void wb_k_probe_streams(const uint4* p, size_t n16, size_t chunk16, unsigned* sink) {
+    unsigned acc = 0u;
+    const size_t nchunks = (n16 + chunk16 - 1) / chunk16;
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const size_t lo = c * chunk16, hi = lo + chunk16 < n16 ? lo + chunk16 : n16;
+        size_t i = lo + threadIdx.x;
+        for (; i + 7 * 512 < hi; i += 8 * 512) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p[i + (size_t)k * 512];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        }
+        for (; i < hi; i += 512) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
 #endif
+extern "C" double wb_probe_streams_ms(wb_ctx* c, const void* dev, uint64_t bytes, uint64_t chunk_bytes, int grid, int reps) {
+    wb_use(c);
+#if defined(WB_HOSTSIM)
+    (void)dev; (void)bytes; (void)chunk_bytes; (void)grid; (void)reps;
+    return 0.0;
+#else
+    unsigned* sink = (unsigned*)dmalloc(c, 256);
+    if (!sink) return -1.0;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { dfree(c, sink); return -1.0; }
+    double best = -1.0;
+    if (grid < 1) grid = wb_num_cus(c);
+    for (int r = 0; r < (reps > 0 ? reps : 1); ++r) {
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(wb_k_probe_streams, dim3((unsigned)grid), dim3(512), 0, c->stream, (const uint4*)dev, (size_t)(bytes / 16), (size_t)(chunk_bytes / 16 > 0 ? chunk_bytes / 16 : 512), sink);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) { best = -1.0; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (best < 0.0 || ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    dfree(c, sink);
+    return best;
+#endif
+}
 double wb_probe_read_ms(wb_ctx* c, const void* dev, uint64_t bytes, int reps) {
     wb_use(c);
 #if defined(WB_HOSTSIM)
@@ -298,9 +344,10 @@ static int run_phase1(wb_batch* b) {
         sa.band_rows = (nlat - 1 + nbands - 1) / nbands;
         sa.nbands = (nlat - 1 + sa.band_rows - 1) / sa.band_rows;
         sa.cap_rec = caps;
+        sa.cap_vs = caps + ctx->scan_pad;
         const long long lists = (long long)p.nt * b->nwork_strips * sa.nbands;
-        sa.cap_k = balloc<uint32_t>(b, (size_t)lists * caps);
-        sa.cap_v = balloc<unsigned char>(b, (size_t)lists * caps * 10 * esz);
+        sa.cap_k = balloc<uint32_t>(b, (size_t)lists * sa.cap_vs);
+        sa.cap_v = balloc<unsigned char>(b, (size_t)lists * sa.cap_vs * 10 * esz);
         sa.cap_n = balloc<int>(b, (size_t)lists);
         if (!sa.cap_n || !sa.cap_v || !sa.cap_k) return 1;
         b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
@@ -363,10 +410,11 @@ static int run_phase1(wb_batch* b) {
             if (ctx->scan_band_rows > 0 && ctx->scan_band_rows <= 255 && ctx->scan_band_rows >= sa.band_rows) sa.band_rows = ctx->scan_band_rows;   // (option "scan_band_rows": longer bands, a shorter last one -- other start addresses for the same number of lists)
             sa.nbands = (nlat - 1 + sa.band_rows - 1) / sa.band_rows;
             sa.cap_rec = caps;
+            sa.cap_vs = caps + ctx->scan_pad;
             sa.debug = ctx->scan_debug;
             const long long lists = items * sa.nbands;
-            sa.cap_k = balloc<uint32_t>(b, (size_t)lists * caps);
-            sa.cap_v = balloc<unsigned char>(b, (size_t)lists * caps * 10 * esz);
+            sa.cap_k = balloc<uint32_t>(b, (size_t)lists * sa.cap_vs);
+            sa.cap_v = balloc<unsigned char>(b, (size_t)lists * sa.cap_vs * 10 * esz);
             sa.cap_n = balloc<int>(b, (size_t)lists);
             unsigned char* spare = balloc<unsigned char>(b, (size_t)p.nlon * esz + 64);
             if (!sa.cap_n || !sa.cap_v || !sa.cap_k || !spare) return 1;
@@ -1800,6 +1848,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "persist_slack")) { ctx->persist_slack = value > 0 ? (int)value : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
+    if (!strcmp(name, "scan_pad")) { ctx->scan_pad = value >= 0 ? value : 0; return 0; }
     if (!strcmp(name, "scan_band_rows")) { ctx->scan_band_rows = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }
     if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }

@@ -46,6 +46,7 @@ struct wb_ctx {
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
     int scan_band_rows = 0;                   // streaming scan: rows of squares per band (0: the rows divided evenly over the bands)
+    int scan_pad = 0;                         // streaming scan: elements added to the stride of the patch lists' arrays (WbScanArgs.cap_vs)
     int scan_bands = 0;                       // streaming scan: row bands per time step (0: chosen from the grid and the device)
     int polys_grid = 2048;                    // workgroups of wb_k_pack_polys (it writes over PCIe: more of them only hold wave slots)
     int timers = 2;                           // stage timers: 2 all, 1 the scan only, 0 none (WbTimer)

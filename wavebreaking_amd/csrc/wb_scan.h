@@ -56,6 +56,9 @@ struct WbScanArgs {
     void* cap_v;            // [lists][10][cap_rec]  upper row v0..v4, lower row v0..v4 (T): value k of patch i at [k * cap_rec + i]
     int* cap_n;             // [nt][nwork] patches found (may exceed cap_rec: overflow)
     int cap_rec;
+    int cap_vs;             // stride (elements) between a list's key array and the next list's, and between the ten value planes of a
+                            // list: cap_rec + a pad -- with the power of two itself every plane of every list started on the same
+                            // 4 KB phase, and the scan's patch stores took 0.1 or 0.3 ms by where the scratch lay
     int debug;              // development: bit 0 = the streaming scan stores no patches (streaming ceiling of the traversal)
     int nbands, band_rows;  // streaming scan: a time step is cut into nbands bands of band_rows rows of squares; the lists above
                             // are then per (time step, band, strip): index (t * nbands + band) * nwork + strip
@@ -158,8 +161,8 @@ void wb_scan_capture_host(const WbScanArgs& a) {
             const int rb0 = band * a.band_rows, rb1 = rb0 + a.band_rows < nlat - 1 ? rb0 + a.band_rows : nlat - 1;
             for (int s = 0; s < NSB; ++s) {
                 const size_t g = ((size_t)t * a.nbands + band) * NSB + s;
-                uint32_t* ck = a.cap_k + g * a.cap_rec;
-                T* cv = (T*)a.cap_v + g * a.cap_rec * 10;
+                uint32_t* ck = a.cap_k + g * a.cap_vs;
+                T* cv = (T*)a.cap_v + g * a.cap_vs * 10;
                 int count = 0;
                 for (int r = rb0; r < rb1; ++r) {
                     for (int lane = 0; lane < 64; ++lane) {
@@ -181,7 +184,7 @@ void wb_scan_capture_host(const WbScanArgs& a) {
                         if (!hit) continue;
                         if (count < a.cap_rec) {
                             ck[count] = ((uint32_t)r << 16) | (uint32_t)c0;
-                            for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_rec + count] = v[k];
+                            for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_vs + count] = v[k];
                         }
                         ++count;
                     }
@@ -197,7 +200,7 @@ template <typename T>
 void wb_scan_build_host(const WbScanArgs& a) {
     const int NS = a.nstrips, NSB = a.nwork, W = a.W, nlon = a.nlon;
     const int cmax = nlon < W - 1 ? nlon : W - 1;
-    const size_t cs = (size_t)a.cap_rec;
+    const size_t cs = (size_t)a.cap_vs;                       // (strides; the capacity is cap_rec)
     for (int t = 0; t < a.nt; ++t)
         for (int s = 0; s < NSB; ++s) {
             const bool has_copy = NSB + s < NS;
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
     const int W = a.W, nlon = a.nlon;
     const int cmax = nlon < W - 1 ? nlon : W - 1;
     const int nbands = a.nbands > 0 ? a.nbands : 1;
-    const size_t cs = (size_t)a.cap_rec;
+    const size_t cs = (size_t)a.cap_vs;                       // (strides; the capacity is cap_rec)
     const bool has_copy = NSB + s < NS;
     if (threadIdx.x == 0) {
         int run = 0;

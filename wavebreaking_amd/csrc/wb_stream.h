@@ -32,7 +32,9 @@
 #include "wb_scan.h"
 
 #if !defined(WB_HOSTSIM)
-#define WB_STREAM_FLUSH 32         // patches in the wave's LDS buffer that trigger a flush
+#ifndef WB_STREAM_FLUSH
+#define WB_STREAM_FLUSH 64         // patches in the wave's LDS buffer that trigger a flush (of its whole 128-byte lines)
+#endif
 #ifndef WB_STREAM_LBUF
 #define WB_STREAM_LBUF 160         // its capacity: a row adds at most 64
 #endif
@@ -132,20 +134,42 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         bool nanflag = false;
         int count = 0;                                        // patches appended so far (wave-uniform)
         int fill = 0;                                         // patches waiting in the wave's LDS buffer (wave-uniform)
-        uint32_t* ck = a.cap_k + (size_t)g * a.cap_rec;       // the list in HBM: keys, and value k of patch i at cv[k * cap_rec + i]
-        T* cv = (T*)a.cap_v + (size_t)g * a.cap_rec * 10;
-        auto flush = [&]() {
-            // patches [count, count + fill) of the list <- the LDS buffer: eleven full-width stores per 64 patches
+        uint32_t* ck = a.cap_k + (size_t)g * a.cap_vs;        // the list in HBM: keys, and value k of patch i at cv[k * cap_vs + i]
+        T* cv = (T*)a.cap_v + (size_t)g * a.cap_vs * 10;
+        auto flush = [&](const bool all) {
+            // patches [count, count + n) of the list <- the LDS buffer, eleven stores per 64 patches.  Until the item's last
+            // flush only WHOLE 128-byte lines go out (n a multiple of 32, and count stays one: the arrays start on a line) and
+            // the few patches behind them move to the front of the buffer.  The scan WITHOUT its stores takes 1.02 ms wherever
+            // its buffers lie; the stores -- 0.2 GB beside 6 GB of reads -- add 0.1 ms in one process and 0.3 ms in the next
+            // (tools/stream_pattern_probe.py: that is the kernel's two modes).  Written as they came, 30 to 60 patches at a time
+            // with every one of the eleven stores beginning and ending inside a line, they added 0.13 / 0.30; whole lines: 0.10 /
+            // 0.25.  Padded strides (option scan_pad) and non-temporal stores moved another 1-2 %: the rest is not understood.
+            const int n = all ? fill : (fill & ~31);
             int w = a.cap_rec - count;
-            w = w < 0 ? 0 : (w < fill ? w : fill);
+            w = w < 0 ? 0 : (w < n ? w : n);
             if (a.debug & 1) w = 0;
             for (int j = lane; j < w; j += 64) {
                 ck[count + j] = lkey[j];
 #pragma unroll
-                for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_rec + count + j] = lval[k * WB_STREAM_LBUF + j];
+                for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_vs + count + j] = lval[k * WB_STREAM_LBUF + j];
             }
-            count += fill;
-            fill = 0;
+            const int rem = fill - n;                             // < 32, and n >= 32 whenever rem > 0: sources lie behind every destination
+            if (rem > 0) {
+                uint32_t kk = 0;
+                T vv[10];
+                if (lane < rem) {
+                    kk = lkey[n + lane];
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) vv[k] = lval[k * WB_STREAM_LBUF + n + lane];
+                }
+                if (lane < rem) {
+                    lkey[lane] = kk;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) lval[k * WB_STREAM_LBUF + lane] = vv[k];
+                }
+            }
+            count += n;
+            fill = rem;
         };
         V4 q[D];                                              // the ring: raw row data only (register-resident: every index
         T h[D];                                               // below is a compile-time constant after unrolling)
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
                     d[9 * WB_STREAM_LBUF] = n4;
                 }
                 fill += __popcll(m);
-                if (fill > WB_STREAM_LBUF - 64) flush();      // no room for another full row (rare: the regular flush is below)
+                if (fill > WB_STREAM_LBUF - 64) flush(false); // no room for another full row (rare: the regular flush is below)
             }
             p4 = n4; pmn = nmn; pmx = nmx;
         };
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
                 step(r + k, q[k], q[(k + 1) % D], h[(k + 1) % D]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (fill >= WB_STREAM_FLUSH) flush();             // once per D rows
+            if (fill >= WB_STREAM_FLUSH) flush(false);        // once per D rows
         }
 #pragma unroll
         for (int k = 0; k < D - 1; ++k) {
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
                 step(r + k, q[k], q[k + 1], h[k + 1]);
             }
         }
-        flush();
+        flush(true);
         if (lane == 0) a.cap_n[g] = count;
         if (__any(nanflag && (c0 < nlon)) && lane == 0) {
 #pragma unroll
