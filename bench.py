@@ -111,7 +111,7 @@ def main():
     from wavebreaking_amd.pipeline import BatchPipeline
     pipe = BatchPipeline(local, depth=a.streams)        # a.streams batches in flight, one context (stream + thread) each (WB_PIPE_STAGGER=1: phases exclusive)
     ctx = pipe.contexts[0]
-    for c in pipe.contexts:
+    for ci, c in enumerate(pipe.contexts):
         c.set_option("scan_split", a.scan_split)
         c.set_option("scan_variant", a.scan_variant)
         if os.environ.get("WB_BENCH_HALO_LDS"):
@@ -121,6 +121,10 @@ def main():
         c.set_option("keep_device", 1 if multi else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather
         for kv in filter(None, os.environ.get("WB_BENCH_OPTS", "").split(",")):   # development: "name=value,..." context options (A/B runs)
             name, _, val = kv.partition("=")
+            if ":" in name:                                   # "k:name=value": context k only (CU masks differ per context)
+                k, _, name = name.partition(":")
+                if int(k) != ci:
+                    continue
             c.set_option(name.strip(), int(val))
     if a.dlon is None:
         a.dlon = 1.0 if a.config == 1 else 0.25

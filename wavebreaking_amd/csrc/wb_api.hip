@@ -95,6 +95,7 @@ static int wb_num_cus(wb_ctx* ctx) {
 #if !defined(WB_HOSTSIM)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ctx->ncu = prop.multiProcessorCount;
+        if (ctx->cu_count > 0 && ctx->cu_count < ctx->ncu) ctx->ncu = ctx->cu_count;      // (option "cu_mask": persistent grids fill the context's share)
 #endif
     }
     return ctx->ncu;
@@ -373,7 +374,7 @@ static int run_phase1(wb_batch* b) {
 #undef WB_SCAN_OCC_N
 #undef WB_SCAN_OCC
         if (per_cu < 1) per_cu = 1;
-        const int ncu = wb_num_cus(ctx);
+        const int ncu = ctx->scan_cu_count > 0 ? ctx->scan_cu_count : wb_num_cus(ctx);   // (option "scan_cu_mask": the scan's own share)
         if (nwg > (long long)ncu * per_cu) nwg = (long long)ncu * per_cu;   // persistent: exactly the resident workgroups
         // the streaming kernel keeps a patch buffer per strip (and the halo slots) in dynamic LDS and runs one wave per strip:
         // fields whose strips do not fit the device's limits (float64 beyond 12 strips, any dtype beyond 16) take the
@@ -1853,6 +1854,20 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }
     if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }
     if (!strcmp(name, "timers")) { ctx->timers = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+#if !defined(WB_HOSTSIM)
+    // value = first * 1000 + count compute units (count 0: no mask)
+    if (!strcmp(name, "cu_mask")) {
+        if (!wb_remask_streams(ctx, value / 1000, value % 1000)) return wb_fail(ctx, "wb_set_option: cu_mask: the masked streams could not be made");
+        return 0;
+    }
+    if (!strcmp(name, "scan_cu_mask")) {         // before the first wb_contours of the context (its stream is made on first use)
+        if (ctx->stream3) return wb_fail(ctx, "wb_set_option: scan_cu_mask after the scan's stream was made");
+        ctx->scan_cu_first = value / 1000; ctx->scan_cu_count = value % 1000; ctx->scan_priority = ctx->scan_cu_count > 0 ? 1 : 0;
+        return 0;
+    }
+#else
+    if (!strcmp(name, "cu_mask") || !strcmp(name, "scan_cu_mask")) return 0;
+#endif
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;
 }

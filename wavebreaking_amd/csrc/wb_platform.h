@@ -42,7 +42,9 @@ struct wb_ctx {
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int boxcom_per_cu = 12;                   // persistent grid of wb_k_box_com: single-wave workgroups per CU (what its LDS admits)
     int persist_slack = 0;                    // workgroup places the persistent 1024-thread launches (all-pairs, routine 1) leave free: a full grid holds EVERY wave slot of the device until its queue is empty, and the other batch's small kernels wait for that
-    int scan_priority = 0;                    // 1: the field scan is launched on a stream of the device's highest priority
+    int scan_priority = 0;                    // 1: the field scan is launched on a stream of its own (stream3): the device's highest priority, or -- option "scan_cu_mask" -- a CU-masked one
+    int cu_first = 0, cu_count = 0;           // option "cu_mask": the context's main and side streams own the compute units [cu_first, cu_first + cu_count) only (0: the whole device)
+    int scan_cu_first = 0, scan_cu_count = 0; // option "scan_cu_mask": ... and the field scan's stream those
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
     int scan_band_rows = 0;                   // streaming scan: rows of squares per band (0: the rows divided evenly over the bands)
@@ -390,6 +392,34 @@ static void side_join(wb_ctx* ctx) {          // the main stream waits for the s
     (void)ctx;
 #endif
 }
+// A stream whose kernels run on the compute units [first, first + count) only (hipExtStreamCreateWithCUMask).  Two batches in
+// flight otherwise share the device by whole kernels, each sized to fill every wave slot: partitioning is the alternative
+// the round-4 review asked to be measured ("CU masks").
+#if !defined(WB_HOSTSIM)
+static bool wb_masked_stream(hipStream_t* out, int first, int count) {
+    uint32_t mask[16];
+    memset(mask, 0, sizeof(mask));
+    for (int cu = first; cu < first + count && cu < 512; ++cu) if (cu >= 0) mask[cu >> 5] |= 1u << (cu & 31);
+    return hipExtStreamCreateWithCUMask(out, 16, mask) == hipSuccess;
+}
+// option "cu_mask": the context's two streams are made again, masked (count == 0: plain streams)
+static bool wb_remask_streams(wb_ctx* c, int first, int count) {
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    hipStream_t a = nullptr, b = nullptr;
+    bool ok;
+    if (count > 0) ok = wb_masked_stream(&a, first, count) && wb_masked_stream(&b, first, count);
+    else ok = hipStreamCreate(&a) == hipSuccess && hipStreamCreateWithFlags(&b, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { if (a) (void)hipStreamDestroy(a); if (b) (void)hipStreamDestroy(b); return false; }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    c->stream = a; c->stream2 = b;
+    c->cu_first = first; c->cu_count = count;
+    c->ncu = 0;                               // (found again: wb_num_cus)
+    return true;
+}
+#endif
 // option "scan_priority": the launches between prio_begin and prio_end go to a stream of the device's highest priority, in
 // stream order with what came before and what follows on the main stream.  The field scan is one fat workgroup per CU (12
 // waves of 128 registers): beside another batch's thin workgroups the dispatcher otherwise hands every freed slot to those.
@@ -398,8 +428,10 @@ static void prio_begin(wb_ctx* ctx) {
     if (!ctx->scan_priority) return;
     if (!ctx->stream3) {
         int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->fork3, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->join3, hipEventDisableTiming) != hipSuccess) {
+        bool ok;
+        if (ctx->scan_cu_count > 0) ok = wb_masked_stream(&ctx->stream3, ctx->scan_cu_first, ctx->scan_cu_count);
+        else ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, hi) == hipSuccess;
+        if (!ok || hipEventCreateWithFlags(&ctx->fork3, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->join3, hipEventDisableTiming) != hipSuccess) {
             ctx->scan_priority = 0;
             return;
         }
