@@ -30,7 +30,7 @@ def build_hostsim(force=False, variant="", defines=(), sanitize=False):
     os.makedirs(HOSTSIM_DIR, exist_ok=True)
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"] if sanitize else []
     cmd = ["g++", "-O1" if sanitize else "-O2", "-g", *san, "-DWB_HOSTSIM", *["-D" + d for d in defines], "-x", "c++", "-std=c++17",
-           "-ffp-contract=off", "-shared", "-fPIC", os.path.join(CSRC, "wb_api.hip"), "-o", lib]
+           "-ffp-contract=off", "-fno-strict-aliasing", "-shared", "-fPIC", os.path.join(CSRC, "wb_api.hip"), "-o", lib]
     subprocess.check_call(cmd)
     return lib
 

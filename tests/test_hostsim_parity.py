@@ -290,6 +290,54 @@ def test_link_merge_by_searches_equals_merge_by_row_tables(sim):
     helpers.full_parity(ctx, pv[:, 2:-2], lat[2:-2], lon, synth.times(3), [-2, 2])
 
 
+def _contour_tables(ctx, pv, lat, lon, levels, d, padd, **opts):
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    try:
+        b = ctx.contours(pv, lat, lon, levels, d, d, periodic_add=padd)
+        tab = b.contour_table()
+        st = np.array(b.status())
+        b.close()
+    finally:
+        for k, v in dict(trace_fused=1, trace_nmax=0, trace_cmax=256).items():
+            ctx.set_option(k, v)
+    return tab, st
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_fused_trace_kernel_equals_the_three_kernel_chain(sim, reverse):
+    """wb_k_trace_fused (one launch per job, the job resident in LDS, list ranking over splitters, buckets by longitude instead
+    of hash tables) against link -> rank -> finish: smooth and rough fields (hundreds of small closed loops: loops without a
+    splitter, many chains), NaN rows, a periodic pad of 0 / 120 / 360 degrees, three levels -- and launches whose LDS admits
+    only SOME of the jobs (trace_nmax / trace_cmax small), so that both paths fill one batch's tables"""
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(reverse)
+    try:
+        cases = []
+        lat, lon = synth.grid(2.5)
+        cases.append((synth.pv_field(3, 3, lat, lon, eps=0.0), lat, lon, 2.5))
+        pv = synth.pv_field(7, 3, lat, lon, eps=0.4)
+        pv[:, [0, 1, -2, -1], :] = np.nan
+        cases.append((pv, lat, lon, 2.5))
+        lat1, lon1 = synth.grid(1.0)
+        cases.append((synth.pv_field(11, 2, lat1, lon1, eps=0.3), lat1, lon1, 1.0))
+        cases.append((synth.pv_field(40, 2, lat1, lon1, eps=0.02).astype(np.float32), lat1, lon1, 1.0))
+        total = 0
+        for pv, la, lo, d in cases:
+            for padd in (0.0, 120.0, 360.0):
+                ref, st0 = _contour_tables(ctx, pv, la, lo, [-2.0, 0.5, 2.0], d, padd, trace_fused=0)
+                total += ref["step"].size
+                for opts in (dict(trace_fused=1), dict(trace_fused=1, trace_nmax=600), dict(trace_fused=1, trace_cmax=8),
+                             dict(trace_fused=1, trace_nmax=512, trace_cmax=4)):
+                    got, st1 = _contour_tables(ctx, pv, la, lo, [-2.0, 0.5, 2.0], d, padd, **opts)
+                    for key in ref:
+                        assert np.array_equal(ref[key], got[key]), (d, padd, opts, key)
+                    assert np.array_equal(st0, st1), (d, padd, opts)
+        assert total > 250
+    finally:
+        lib.lib.wb_hostsim_set_reverse(0)
+
+
 def test_reference_own_code_fixture_through_the_abi(sim, golden_dir):
     """the contour table, the overturning boxes and the contour selection / cutoff filter against outputs of the reference's
     own statements (tests/golden/reference_rules.npz)"""

@@ -23,6 +23,7 @@
 #include "wb_scan.h"
 #include "wb_stream.h"
 #include "wb_trace.h"
+#include "wb_trace_fused.h"
 #include "wb_track.h"
 
 #include "wb_platform.h"
@@ -494,6 +495,52 @@ static int run_phase1(wb_batch* b) {
     for (int l = 0; l < p.nlevels; ++l) ta.levels[l] = b->levels[l];
     ta.cpts = b->cpts; ta.cown = b->cown; ta.c_off = b->c_off; ta.c_len = b->c_len; ta.c_closed = b->c_closed;
     ta.c_nux = b->c_nux; ta.c_sumy = b->c_sumy; ta.ncont = b->ncont; ta.status = b->status; ta.ctl = b->d_ctl;
+    // One kernel per job with the job resident in LDS (wb_trace_fused.h); what it declines -- counted in ctl->n_unfused, read with
+    // the phase's summary -- goes through the three kernels below, which then leave the finished jobs alone.
+    bool fused_all = false;
+    if (ctx->trace_fused && b->W <= 16384) {
+        if (ctx->fused_seen_W != b->W) { ctx->fused_seen_W = b->W; ctx->fused_seen = 0; }
+        int nmax = ctx->trace_nmax > 0 ? ctx->trace_nmax : (ctx->fused_seen > 0 ? ctx->fused_seen + ctx->fused_seen / 16 + 64 : 3 * b->W);
+        nmax = (nmax + 255) & ~255;
+        if (nmax < 512) nmax = 512;
+        if (nmax > 8184) nmax = 8184;
+        WbFusedArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.nmax = nmax; fa.smax = nmax / 16 + 160; fa.cmax = ctx->trace_cmax > 0 ? ctx->trace_cmax : 256; fa.nwork = b->nwork_strips;
+        size_t lds_block = 0, lds_cu = 0;
+        wb_lds_limits(ctx, &lds_block, &lds_cu);
+        WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
+        while (L.total > lds_cu / 2 && fa.nmax > 1024) {        // never more than half a CU's LDS: smaller jobs only
+            fa.nmax -= 256; fa.smax = fa.nmax / 16 + 160;
+            L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
+        }
+        bool ok = L.total <= lds_cu / 2;
+#if !defined(WB_HOSTSIM)
+        if (ok && L.total > lds_block && hipFuncSetAttribute((const void*)wb_k_trace_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+        }
+#endif
+        if (ok) {
+            unsigned char* fdone = balloc<unsigned char>(b, (size_t)J + 16);
+            if (!fdone) return 1;
+            sc.push_back(fdone);
+            fa.t = ta; fa.fdone = fdone;
+            b->timer.begin(ctx, "trace_fused");
+            WB_LAUNCH_LDS(wb_k_trace_fused, J, WB_FUSED_THREADS, L.total, fa);
+            b->timer.end(ctx);
+            if (phase1_summary(b)) return 1;
+            if (b->h_ctl.max_nseg > ctx->fused_seen) ctx->fused_seen = b->h_ctl.max_nseg;
+            if (wb_debug()) fprintf(stderr, "[wb] fused trace: nmax %d smax %d cmax %d, %zu B of LDS, %d of %d jobs declined, largest job %d\n", fa.nmax, fa.smax, fa.cmax, L.total, b->h_ctl.n_unfused, J, b->h_ctl.max_nseg);
+            if (b->h_ctl.n_unfused == 0) fused_all = true;
+            else {
+                ta.fdone = fdone;
+                // the summary again, from zero, behind the chain below (max_nux and max_len are running maxima and stay)
+                dmemset(ctx, (char*)b->d_ctl + offsetof(WbCtl, ncont_total), 0, offsetof(WbCtl, scan_cursor) - offsetof(WbCtl, ncont_total));
+            }
+        }
+    }
+    if (!fused_all) {
     b->timer.begin(ctx, "trace_link");
     {   // row tables in dynamic LDS when they fit (16-bit entries: a job of the LDS paths has at most 8192 segments)
         const size_t tab = (size_t)(NS + 1) * nlat * sizeof(uint16_t) + 16;
@@ -522,6 +569,7 @@ static int run_phase1(wb_batch* b) {
         dmemset(ctx, (char*)b->d_ctl + offsetof(WbCtl, ncont_total), 0, offsetof(WbCtl, scan_cursor) - offsetof(WbCtl, ncont_total));
         b->timer.end(ctx);
         if (phase1_summary(b)) return 1;
+    }
     }
     b->timer_phase1 = b->timer.names.size();
     WB_TICK("phase1 launches + sync");
@@ -1848,6 +1896,9 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "scan_priority")) { ctx->scan_priority = value ? 1 : 0; return 0; }
     if (!strcmp(name, "persist_slack")) { ctx->persist_slack = value > 0 ? (int)value : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "trace_fused")) { ctx->trace_fused = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
+    if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "scan_pad")) { ctx->scan_pad = value >= 0 ? value : 0; return 0; }
     if (!strcmp(name, "scan_band_rows")) { ctx->scan_band_rows = value; return 0; }

@@ -86,6 +86,8 @@ struct WbCtl {
     int scan_cursor;             // streaming scan: the next (time step, band) work item (a workgroup takes one when it is free)
     int max_len;                 // longest contour of the batch, in points
     int n_slow;                  // jobs the second trace pass redoes: more segments than the LDS paths hold, or an order-dependent join (cells equal to the level)
+    int n_unfused;               // jobs wb_k_trace_fused declined (cells equal to the level, more segments / chains than its LDS holds): the three-kernel chain takes them
+    int max_nseg;                // largest segment count of a job (sizes the fused kernel's LDS for the context's next batch)
     // phase 2 (wb_indices)
     int nsel, ncut;              // selected contours / cutoff contours
     long long npt_sel;

@@ -46,6 +46,9 @@ struct wb_ctx {
     int cu_first = 0, cu_count = 0;           // option "cu_mask": the context's main and side streams own the compute units [cu_first, cu_first + cu_count) only (0: the whole device)
     int scan_cu_first = 0, scan_cu_count = 0; // option "scan_cu_mask": ... and the field scan's stream those
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
+    int trace_fused = 1;                      // 1: the contours of a job by ONE kernel with the job resident in LDS (wb_trace_fused.h); 0: link -> rank -> finish (wb_trace.h), which also take the jobs the fused kernel declines
+    int trace_nmax = 0, trace_cmax = 256;     // fused kernel: segments / chains per job its LDS admits (trace_nmax 0: from the grid's width, then from the largest job the context has seen)
+    int fused_seen = 0, fused_seen_W = 0;     // largest segment count of a job in the context's batches so far on the grid of that width
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
     int scan_band_rows = 0;                   // streaming scan: rows of squares per band (0: the rows divided evenly over the bands)
     int scan_pad = 0;                         // streaming scan: elements added to the stride of the patch lists' arrays (WbScanArgs.cap_vs)

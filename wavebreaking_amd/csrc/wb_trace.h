@@ -51,7 +51,9 @@ struct WbTraceArgs {
     int link_rows;           // wb_k_trace_link: 1 = its dynamic LDS holds the row tables ((nstrips + 1) * nlat 16-bit entries), 0 = merge by binary searches
     int slow_pass;           // 0: the ordinary launch (slow jobs are left out and counted in ctl->n_slow); 1: the slow jobs only
     WbCtl* ctl;              // batch counters (capacity checks, maxima)
+    const unsigned char* fdone;  // [njobs] or NULL: jobs wb_k_trace_fused (wb_trace_fused.h) has finished -- the kernels below leave them alone
 };
+#define WB_TRACE_SKIP_DONE(a, job) if ((a).fdone && (a).fdone[job]) return
 
 #define WB_HEMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -233,6 +235,7 @@ WB_DEV inline int wb_bits_for(int n) {   // bits that hold every value in [0, n)
 WB_KERNEL(wb_k_trace_link, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
+    WB_TRACE_SKIP_DONE(a, job);
     const int cap = a.cap_seg;
     const int W = a.W;
     const size_t jb = (size_t)job * cap;
@@ -773,6 +776,7 @@ WB_DEV inline void wb_rank_vertex_loops(int n, const uint32_t* succ, const uint3
 WB_KERNEL_LB(wb_k_trace_rank, WB_RANK_THREADS, (WB_RANK_THREADS >= 1024 ? 8 : 4), WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
+    WB_TRACE_SKIP_DONE(a, job);
     const int n = a.nseg[job];
     if (n <= 0 || n > WB_TRACE_LDS_N) return;             // (longer jobs: wb_k_trace_rank_big)
     const size_t jb = (size_t)job * a.cap_seg;
@@ -804,6 +808,7 @@ WB_KERNEL_LB(wb_k_trace_rank, WB_RANK_THREADS, (WB_RANK_THREADS >= 1024 ? 8 : 4)
 WB_KERNEL(wb_k_trace_rank_big, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
+    WB_TRACE_SKIP_DONE(a, job);
     const int n = a.nseg[job];
     if (n <= WB_TRACE_LDS_N) return;
     const size_t jb = (size_t)job * a.cap_seg;
@@ -857,6 +862,7 @@ WB_DEV inline void wb_walk_put(unsigned long long* hk, uint32_t* hv, int hmask, 
 WB_KERNEL(wb_k_trace_walk, WbTraceArgs a) {
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
+    WB_TRACE_SKIP_DONE(a, job);
     const int n = a.nseg[job];
     if (n <= 0 || !(a.status[job] & WB_ST_LEVEL_ORDER)) return;
     const size_t jb = (size_t)job * a.cap_seg;
@@ -984,6 +990,7 @@ WB_KERNEL_LB(wb_k_trace_finish, WB_FINISH_THREADS, (WB_FINISH_THREADS >= 1024 ? 
     WB_SHARED(unsigned long long, ltab, WB_TRACE_LTAB);
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
+    WB_TRACE_SKIP_DONE(a, job);
     const int n = a.nseg[job];
     if (n <= 0) return;            // ncont already written by the link kernel
     {   // the slow jobs (big, or to be walked sequentially) wait for the second pass, which takes nothing else

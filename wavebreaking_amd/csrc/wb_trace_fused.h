@@ -1,0 +1,654 @@
+// wb_trace_fused.h -- kernel 2 (round 5): segments -> ordered, rounded, de-duplicated contours of one (time step, level) job in
+// ONE launch, the job's working set resident in LDS from the first key to the final table.
+//
+// Restates, for one job, wavebreaking/indices/contour_index.py:103-156 of the reference exactly as the three kernels of
+// wb_trace.h do (link -> rank -> finish; they stay: they are the host-simulation bodies' twins for the jobs this kernel
+// declines -- cells equal to the level, more segments / chains than its LDS holds, capacity overflows -- and the CPU suite runs
+// both).  What is different is the algorithm, chosen so that a job needs a few KB of LDS per thousand segments, a few
+// barriers per phase and no global scratch at all:
+//   * no merge of the strip lists.  A segment is known by its position g in the CONCATENATION of the job's raster-ordered lists;
+//     raster order, where it matters (a closed contour starts behind its raster-last segment, contours are numbered by their
+//     raster-first segment: SURVEY.md 8a row C2 (i)-(ii)), is the order of the 27-bit square keys themselves.  The successor of
+//     a segment that leaves its square to the right / left is the next / previous entry of its own list, one that leaves
+//     upwards / downwards is searched in the same list (the few entries between the two rows), one that crosses a strip's edge
+//     in the neighbouring list;
+//   * list ranking after Helman & JaJa instead of Wyllie's pointer jumping over every segment: every 16th segment and every
+//     chain head is a splitter, a thread walks from its splitter to the next one (sub-lists of a dozen segments), and only the
+//     few hundred splitters are ranked by pointer jumping -- O(n) work, ~20 barriers instead of ~50, 6 bytes of LDS per segment
+//     instead of 8 + 8;
+//   * closed loops: a loop that holds no splitter is found as the segments no walk visited and gets its key descents as
+//     splitters; the loop's raster-last segment is the maximum key of its chain, and the positions are rotated so that the
+//     contour starts behind it -- no second ranking of the segments;
+//   * first-occurrence dedupe (contour_index.py:110-112), distinct-x count (:154) and the periodic-duplicate rule (:119-147)
+//     without hash tables: the raw points are bucketed by x mod nlon (counting sort, 2 bytes per point); a bucket holds the
+//     handful of points of one meridian, and "was this lattice point seen before in this contour", "how many distinct x / (x mod
+//     nlon, y) has this contour", "does contour i2 hold this point of i1" are scans of one bucket.
+// Development order: written in the WB_PFOR idiom so that the host simulation runs it (tests/test_hostsim_parity.py runs every
+// parity case with the option trace_fused = 1 and = 0).
+#pragma once
+#include "wb_trace.h"
+
+#ifndef WB_FUSED_THREADS
+#define WB_FUSED_THREADS 256
+#endif
+#define WB_F_SPLIT 16                // every WB_F_SPLIT-th segment is a splitter
+#define WB_F_NIL 0x1FFFu             // 13-bit links: a job of the fused path has at most 8190 segments
+#define WB_F_HEAD 0x8000u            // flags in the upper bits of a link word
+#define WB_F_SPLITTER 0x4000u
+#define WB_F_NONE 0xFFFFu
+#define WB_F_NCAND 128
+
+// LDS layout (bytes) for a launch that admits jobs of up to nmax segments, smax splitters, cmax chains
+#define WB_F_XSHIFT 2                // a bucket holds the raw points of 1 << WB_F_XSHIFT neighbouring meridians (x mod nlon)
+struct WbFusedLayout {
+    // region A: keys (link) -> owner / local position (ranking) -> raw points, packed contour | y | x
+    // region B: links + flags (link, ranking) -> destination of a segment's point -> bucket order
+    // region T: tables
+    size_t oA, oB, oT, total;
+    size_t t_rawbase, t_closed;      // per contour, from the numbering to the end
+    // group 1 (link + ranking) and group 2 (finish) share what follows
+    size_t g1_hp, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_q1, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
+    size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
+};
+WB_HD inline size_t wb_f_al(size_t v) { return (v + 7) & ~(size_t)7; }
+WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlon, int nthreads) {
+    WbFusedLayout L;
+    const size_t R = (size_t)nmax + cmax + 2;
+    size_t o = 0;
+    L.oA = o; o += wb_f_al(4 * R);
+    L.oB = o; o += wb_f_al(2 * R);
+    L.oT = o;
+    size_t t = 0;
+    const size_t C1 = (size_t)cmax + 2;
+    L.t_rawbase = t; t += wb_f_al(4 * C1);
+    L.t_closed = t; t += wb_f_al(C1);
+    size_t g1 = t;
+    const size_t S1 = (size_t)smax + 2;
+    L.g1_hp = g1; g1 += wb_f_al(4 * (((size_t)nmax + 31) / 32 + 1));
+    L.g1_ndseg = g1; g1 += wb_f_al(2 * S1);
+    L.g1_nlen = g1; g1 += wb_f_al(2 * S1);
+    L.g1_ncp = g1; g1 += wb_f_al(2 * S1);
+    L.g1_nnext = g1; g1 += wb_f_al(2 * S1);
+    L.g1_cix = g1; g1 += wb_f_al(4 * S1);
+    L.g1_q0 = g1; g1 += wb_f_al(8 * S1);
+    L.g1_q1 = g1; g1 += wb_f_al(8 * S1);
+    L.g1_cmin = g1; g1 += wb_f_al(4 * C1);
+    L.g1_cmaxk = g1; g1 += wb_f_al(4 * C1);
+    L.g1_lnode = g1; g1 += wb_f_al(2 * C1);
+    L.g1_lpos = g1; g1 += wb_f_al(2 * C1);
+    L.g1_ctot = g1; g1 += wb_f_al(4 * C1);
+    L.g1_cloop = g1; g1 += wb_f_al(C1);
+    L.g1_cnum = g1; g1 += wb_f_al(2 * C1);
+    size_t g2 = t;
+    L.g2_cnt = g2; g2 += wb_f_al(4 * (((size_t)nlon >> WB_F_XSHIFT) + 3));
+    L.g2_keep = g2; g2 += wb_f_al(4 * ((R + 31) / 32 + 1));
+    L.g2_dup = g2; g2 += wb_f_al(4 * ((R + 31) / 32 + 1));
+    L.g2_blk = g2; g2 += wb_f_al(2 * ((R + 31) / 32 + 2));
+    L.g2_newstart = g2; g2 += wb_f_al(4 * C1);
+    L.g2_kid = g2; g2 += wb_f_al(4 * C1);
+    L.g2_nux = g2; g2 += wb_f_al(4 * C1);
+    L.g2_sumy = g2; g2 += wb_f_al(4 * C1);
+    L.g2_setsize = g2; g2 += wb_f_al(4 * C1);
+    L.g2_dropped = g2; g2 += wb_f_al(C1);
+    L.g2_ckept = g2; g2 += wb_f_al(2 * C1);
+    L.g2_fin = g2; g2 += wb_f_al(4 * C1);
+    L.g2_tcount = g2; g2 += wb_f_al(4 * ((size_t)nthreads + 2));
+    L.g2_cand = g2; g2 += wb_f_al(4 * 2 * WB_F_NCAND);
+    L.total = L.oT + (g1 > g2 ? g1 : g2);
+    return L;
+}
+
+// position g in the concatenation of a job's lists -> (list, index inside it)
+WB_DEV inline void wb_f_locate(const int* sbase, int g, int* s, int* i) {
+    int q = 0;
+    while (g >= sbase[q + 1]) ++q;
+    *s = q;
+    *i = g - sbase[q];
+}
+// first entry of K[lo, hi) whose square is >= target
+WB_DEV inline int wb_f_lower(const uint32_t* K, int lo, int hi, int target) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (wb_key_sq(K[mid]) < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct WbFusedArgs {
+    WbTraceArgs t;
+    int nmax, smax, cmax;            // what the launch's LDS admits
+    int nwork;                       // base strips (lists nwork .. nstrips - 1 are the periodic copies)
+    unsigned char* fdone;            // [njobs] 1: this kernel finished the job, 0: the three-kernel chain must
+};
+
+WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
+    const WbTraceArgs& a = fa.t;
+    const int job = WB_BLOCK_ID;
+    if (job >= a.njobs) return;
+    const int NS = a.nstrips, W = a.W, nlon = a.nlon, nlat = a.nlat;
+    const size_t jb = (size_t)job * a.cap_seg;
+    WB_SHARED(int, sbase, WB_MAX_LISTS + 2);
+    WB_SHARED(int, ctr, 8);          // [0] bail flag, [1] splitters, [2] chains, [3] any loop, [4] queued pairs, [5] pair failure flag, [6] points in buckets
+    WB_DYN_SHARED_BEGIN
+    const WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, nlon, WB_FUSED_THREADS);
+    WB_DYN_SHARED(unsigned char, lds, L.total);
+    uint32_t* const K = (uint32_t*)(lds + L.oA);               // keys; later raw points
+    uint16_t* const own = (uint16_t*)(lds + L.oA);             // (ranking) splitter ordinal that owns the segment
+    uint16_t* const lp = own + ((size_t)fa.nmax + 2);          // (ranking) position inside its sub-list, from 1
+    uint32_t* const rawpt = K;                                 // raw points in contour order: contour << (xb + yb) | y << xb | x
+    uint16_t* const S = (uint16_t*)(lds + L.oB);               // successor | flags; later: destination of the segment's point; later: bucket order
+    uint16_t* const dest = S;
+    uint16_t* const order = S;
+    unsigned char* const T = lds + L.oT;
+    int* const rawbase = (int*)(T + L.t_rawbase);
+    unsigned char* const closedn = T + L.t_closed;
+    uint32_t* const hp = (uint32_t*)(T + L.g1_hp);
+    uint16_t* const ndseg = (uint16_t*)(T + L.g1_ndseg);
+    uint16_t* const nlen = (uint16_t*)(T + L.g1_nlen);
+    uint16_t* const ncp = (uint16_t*)(T + L.g1_ncp);
+    uint16_t* const nnext = (uint16_t*)(T + L.g1_nnext);
+    uint16_t* const ndend = nnext;                             // (the sub-list's end, until it has become the next splitter's ordinal)
+    int* const cix = (int*)(T + L.g1_cix);
+    unsigned long long* const Q0 = (unsigned long long*)(T + L.g1_q0);
+    unsigned long long* const Q1 = (unsigned long long*)(T + L.g1_q1);
+    uint32_t* const cmin = (uint32_t*)(T + L.g1_cmin);
+    uint32_t* const cmaxk = (uint32_t*)(T + L.g1_cmaxk);
+    uint16_t* const lnode = (uint16_t*)(T + L.g1_lnode);
+    uint16_t* const lpos = (uint16_t*)(T + L.g1_lpos);
+    int* const ctot = (int*)(T + L.g1_ctot);
+    unsigned char* const cloop = T + L.g1_cloop;
+    uint16_t* const cnum = (uint16_t*)(T + L.g1_cnum);
+    int* const cnt = (int*)(T + L.g2_cnt);
+    uint32_t* const keepb = (uint32_t*)(T + L.g2_keep);
+    uint32_t* const dupb = (uint32_t*)(T + L.g2_dup);
+    uint16_t* const blk = (uint16_t*)(T + L.g2_blk);
+    int* const newstart = (int*)(T + L.g2_newstart);
+    int* const kid = (int*)(T + L.g2_kid);
+    int* const nuxl = (int*)(T + L.g2_nux);
+    int* const sumyl = (int*)(T + L.g2_sumy);
+    int* const setsize = (int*)(T + L.g2_setsize);
+    unsigned char* const dropped = T + L.g2_dropped;
+    uint16_t* const ckept = (uint16_t*)(T + L.g2_ckept);
+    int* const fin = (int*)(T + L.g2_fin);
+    int* const tcount = (int*)(T + L.g2_tcount);
+    int* const cand = (int*)(T + L.g2_cand);
+    // a raw point is one word: contour << (xb + yb) | y << xb | x (what does not fit -- a finer grid, more contours -- is declined)
+    const int xb = wb_bits_for(W), yb = wb_bits_for(nlat), sh = xb + yb;
+    const uint32_t xmask = (1u << xb) - 1u, ymask = (1u << yb) - 1u;
+    const int cmax = (sh <= 28 && (1 << (32 - sh)) < fa.cmax) ? (1 << (32 - sh)) : fa.cmax;
+
+    // ---- the job's lists
+    int n = 0;
+    bool over = false;
+    for (int s = 0; s < NS; ++s) {
+        const int c = a.stg_n[job * NS + s];
+        if (c > a.cap_strip) over = true;
+        n += c;
+    }
+    WB_SINGLE
+    int run = 0;
+    for (int s = 0; s < NS; ++s) { sbase[s] = run; run += a.stg_n[job * NS + s]; }
+    sbase[NS] = run;
+    sbase[NS + 1] = 0x7FFFFFFF;
+    for (int k = 0; k < 8; ++k) ctr[k] = 0;
+    if (n > 0 && !over && n <= a.cap_seg) wb_atomic_max(&a.ctl->max_nseg, n);
+    WB_END_SINGLE
+    // declined: the three-kernel chain takes the job (capacity overflows are reported by its link kernel)
+#define WB_F_DECLINE()                                   \
+    do {                                                 \
+        WB_SINGLE                                        \
+        fa.fdone[job] = 0;                               \
+        a.ncont[job] = 0;                                \
+        wb_atomic_add(&a.ctl->n_unfused, 1);             \
+        WB_END_SINGLE                                    \
+        return;                                          \
+    } while (0)
+    if (n == 0) {
+        WB_SINGLE
+        fa.fdone[job] = 1;
+        a.ncont[job] = 0;
+        a.nseg[job] = 0;
+        WB_END_SINGLE
+        return;
+    }
+    if (over || n > a.cap_seg || n > fa.nmax || n >= (int)WB_F_NIL || sh > 28) WB_F_DECLINE();
+    const double level = a.levels[job % a.nlev];
+    const int NSB = fa.nwork;
+
+    // ---- A: keys to LDS
+    WB_PFOR(g, n)
+        int s, i;
+        wb_f_locate(sbase, (int)g, &s, &i);
+        K[g] = a.stg_k[((size_t)job * NS + s) * a.cap_strip + i];
+    WB_END_PFOR
+    WB_PFOR(w, (n + 31) / 32 + 1)
+        hp[w] = 0u;
+    WB_END_PFOR
+
+    // ---- B: successor of every segment = the segment of the neighbouring square that starts on the edge this one ends on
+    WB_PFOR(g, n)
+        const uint32_t k = K[g];
+        const int sq = wb_key_sq(k), r = sq / W, c = sq - r * W, cs = wb_key_case(k), sub = wb_key_sub(k);
+        const int ts = wb_seg_to(cs, sub);
+        int rr = r, cc = c;
+        if (ts == WB_TOP) rr = r - 1;
+        else if (ts == WB_RIGHT) cc = c + 1;
+        else if (ts == WB_BOTTOM) rr = r + 1;
+        else cc = c - 1;
+        const int want = ts ^ 2;
+        uint32_t sc = WB_F_NIL;
+        if (rr >= 0 && rr < nlat - 1 && cc >= 0 && cc < W - 1) {
+            const int tl = cc < nlon ? cc / WB_STRIP : NSB + (cc - nlon) / WB_STRIP;      // the list that holds square (rr, cc)
+            if (tl < NS) {
+                const int lo = sbase[tl], hi = sbase[tl + 1];
+                const int target = rr * W + cc;
+                int f = -1;                                   // first entry of the target square
+                const bool same = (int)g >= lo && (int)g < hi;
+                if (same && ts == WB_RIGHT) {
+                    const int q = (int)g - sub + wb_case_nseg(cs);
+                    if (q < hi && wb_key_sq(K[q]) == target) f = q;
+                } else if (same && ts == WB_LEFT) {
+                    const int q = (int)g - sub - 1;
+                    if (q >= lo && wb_key_sq(K[q]) == target) f = q - wb_key_sub(K[q]);
+                } else if (same && ts == WB_BOTTOM) {
+                    // further down the same list: gallop from behind this square, then search the bracket
+                    int b0 = (int)g - sub + wb_case_nseg(cs), step = 4;
+                    while (b0 + step < hi && wb_key_sq(K[b0 + step]) < target) { b0 += step; step <<= 1; }
+                    const int b1 = b0 + step + 1 < hi ? b0 + step + 1 : hi;
+                    const int q = wb_f_lower(K, b0, b1, target);
+                    if (q < hi && wb_key_sq(K[q]) == target) f = q;
+                } else if (same && ts == WB_TOP) {
+                    int b1 = (int)g - sub, step = 4;            // entries [lo, b1) lie before this square
+                    while (b1 - step > lo && wb_key_sq(K[b1 - step]) > target) { b1 -= step; step <<= 1; }
+                    const int b0 = b1 - step - 1 > lo ? b1 - step - 1 : lo;
+                    const int q = wb_f_lower(K, b0, b1, target);
+                    if (q < b1 && wb_key_sq(K[q]) == target) f = q;
+                } else {
+                    const int q = wb_f_lower(K, lo, hi, target);
+                    if (q < hi && wb_key_sq(K[q]) == target) f = q;
+                }
+                if (f >= 0) {
+                    const int cs2 = wb_key_case(K[f]);
+                    if (wb_seg_from(cs2, 0) == want) sc = (uint32_t)f;
+                    else if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) sc = (uint32_t)f + 1u;
+                }
+            }
+        }
+        S[g] = (uint16_t)sc;
+        if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
+    WB_END_PFOR
+
+    // ---- C: list ranking.  C1: heads, splitters, their ordinals
+    int* const tmp = (int*)K;                                  // (the keys are done with: read again from the lists where needed)
+    WB_PFOR(g, n)
+        const bool head = !((hp[g >> 5] >> (g & 31)) & 1u);
+        const bool split = head || ((int)g % WB_F_SPLIT) == 0;
+        S[g] = (uint16_t)((S[g] & WB_F_NIL) | (head ? WB_F_HEAD : 0u) | (split ? WB_F_SPLITTER : 0u));
+        tmp[g] = split ? 1 : 0;
+    WB_END_PFOR
+    const int S1 = wb_block_scan_excl(tmp, n);
+    if (S1 > fa.smax) WB_F_DECLINE();
+    WB_PFOR(g, n)
+        if (S[g] & WB_F_SPLITTER) ndseg[tmp[g]] = (uint16_t)g;
+    WB_END_PFOR
+    WB_PFOR(g, n)
+        own[g] = (uint16_t)WB_F_NONE;
+    WB_END_PFOR
+    // C2: a thread walks from its splitter to the next one (no two walks meet: successors are one-to-one)
+    auto walk = [&](const int o) {
+        int j = (int)ndseg[o], cntw = 0;
+        uint32_t end = WB_F_NIL;
+        for (;;) {
+            ++cntw;
+            own[j] = (uint16_t)o;
+            lp[j] = (uint16_t)cntw;
+            const uint32_t nx = S[j] & WB_F_NIL;
+            if (nx == WB_F_NIL) break;
+            if (S[nx] & WB_F_SPLITTER) { end = nx; break; }
+            j = (int)nx;
+        }
+        nlen[o] = (uint16_t)cntw;
+        ndend[o] = (uint16_t)end;
+    };
+    WB_PFOR(o, S1)
+        walk((int)o);
+    WB_END_PFOR
+    // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
+    auto key_of = [&](const int g) -> uint32_t {
+        int s, i;
+        wb_f_locate(sbase, g, &s, &i);
+        return a.stg_k[((size_t)job * NS + s) * a.cap_strip + i] & 0x07FFFFFFu;
+    };
+    WB_SINGLE
+    ctr[1] = S1;
+    WB_END_SINGLE
+    WB_PFOR(g, n)
+        bool want = false;
+        if (own[g] == (uint16_t)WB_F_NONE) {
+            const uint32_t nx = S[g] & WB_F_NIL;
+            want = nx == WB_F_NIL || key_of((int)g) > key_of((int)nx);
+        }
+        const int slot = wb_append_slot(&ctr[1], want);
+        if (want && slot < fa.smax) ndseg[slot] = (uint16_t)g;
+    WB_END_PFOR
+    const int NSP = ctr[1];
+    if (NSP > fa.smax) WB_F_DECLINE();
+    WB_PFOR(o, NSP - S1)
+        S[ndseg[S1 + o]] |= (uint16_t)WB_F_SPLITTER;
+    WB_END_PFOR
+    WB_PFOR(o, NSP - S1)
+        walk(S1 + (int)o);
+    WB_END_PFOR
+    // C4: the splitters' own list: next splitter, previous splitter
+    const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
+    WB_PFOR(o, NSP)
+        const uint16_t e = ndend[o];
+        nnext[o] = e == (uint16_t)WB_F_NIL ? NN : own[e];     // (in place: ndend is nnext's storage)
+        ncp[o] = NN;
+    WB_END_PFOR
+    WB_PFOR(o, NSP)
+        if (nnext[o] != NN) ncp[nnext[o]] = (uint16_t)o;
+    WB_END_PFOR
+    // C5: pointer jumping over the splitters along the PREVIOUS links.  One 64-bit word per node:
+    // bits 0..15 J (jump pointer), 16..31 D (segments in front of the node), 32..47 H (first node of the chain), 48..63 M (smallest ordinal seen: names a loop)
+#define WB_FQ(j, d, h, m) ((unsigned long long)(uint16_t)(j) | (unsigned long long)(uint16_t)(d) << 16 | (unsigned long long)(uint16_t)(h) << 32 | (unsigned long long)(uint16_t)(m) << 48)
+    int rounds = 0;
+    while ((1 << rounds) < NSP) ++rounds;
+    auto rank_nodes = [&]() -> unsigned long long* {
+        WB_PFOR(o, NSP)
+            const uint16_t p = ncp[o];
+            Q0[o] = WB_FQ(p, p != NN ? nlen[p] : 0, o, o);
+        WB_END_PFOR
+        unsigned long long *qi = Q0, *qo = Q1;
+        for (int it = 0; it < rounds; ++it) {
+            WB_PFOR(o, NSP)
+                const unsigned long long w = qi[o];
+                const uint16_t j = (uint16_t)w;
+                unsigned long long nw = w;
+                if (j != NN) {
+                    const unsigned long long wj = qi[j];
+                    const uint16_t m1 = (uint16_t)(w >> 48), m2 = (uint16_t)(wj >> 48);
+                    nw = WB_FQ((uint16_t)wj, (uint16_t)(w >> 16) + (uint16_t)(wj >> 16), (uint16_t)(wj >> 32), m1 < m2 ? m1 : m2);
+                }
+                qo[o] = nw;
+            WB_END_PFOR
+            unsigned long long* t = qi; qi = qo; qo = t;
+        }
+        return qi;
+    };
+    unsigned long long* Q = rank_nodes();
+    // chains: an open chain is named by its first node, a loop (jump pointer still alive) by its smallest ordinal
+    WB_PFOR(o, NSP)
+        const unsigned long long w = Q[o];
+        const bool loop = (uint16_t)w != NN;
+        const uint16_t id = loop ? (uint16_t)(w >> 48) : (uint16_t)(w >> 32);
+        cix[o] = id == (uint16_t)o ? 1 : 0;
+        if (loop) ctr[3] = 1;
+    WB_END_PFOR
+    const int C = wb_block_scan_excl(cix, NSP);               // cix[o] (for a naming node): the chain's index
+    if (C > cmax) WB_F_DECLINE();
+    const bool any_loop = ctr[3] != 0;
+    // every node learns its chain's index (the naming node's entry is read before anything overwrites it: two steps)
+    WB_PFOR(o, NSP)
+        const unsigned long long w = Q[o];
+        const bool loop = (uint16_t)w != NN;
+        const uint16_t id = loop ? (uint16_t)(w >> 48) : (uint16_t)(w >> 32);
+        nnext[o] = (uint16_t)cix[id];                          // (nnext is done with: chain index of the node, for now)
+        if (id == (uint16_t)o) { cloop[cix[o]] = loop ? 1 : 0; cmin[cix[o]] = 0xFFFFFFFFu; cmaxk[cix[o]] = 0u; ctot[cix[o]] = 0; }
+    WB_END_PFOR
+    WB_PFOR(o, NSP)
+        cix[o] = (int)nnext[o];
+    WB_END_PFOR
+    // keys again (coalesced, from the lists): every chain's smallest key (it numbers the contours), every loop's largest
+    WB_PFOR(g, n)
+        const uint32_t key = key_of((int)g);
+        const int ch = cix[own[g]];
+        wb_atomic_min(&cmin[ch], key);
+        if (cloop[ch]) wb_atomic_max(&cmaxk[ch], key);
+    WB_END_PFOR
+    if (any_loop) {
+        // the loop's raster-last segment: the contour starts behind it.  Cut the splitters' loop in
+        // front of the node that holds it and rank again; the segments' positions are rotated below.
+        WB_PFOR(g, n)
+            const int ch = cix[own[g]];
+            if (cloop[ch] && key_of((int)g) == cmaxk[ch]) { lnode[ch] = own[g]; lpos[ch] = lp[g]; }
+        WB_END_PFOR
+        WB_PFOR(ch, C)
+            if (cloop[ch]) ncp[lnode[ch]] = NN;
+        WB_END_PFOR
+        Q = rank_nodes();
+    }
+    // chain lengths
+    WB_PFOR(o, NSP)
+        wb_atomic_max(&ctot[cix[o]], (int)(uint16_t)(Q[o] >> 16) + (int)nlen[o]);
+    WB_END_PFOR
+    // ---- D: contours in the order of their raster-first segments (contour_index.py:103: find_contours' list order)
+    WB_PFOR(ch, C)
+        const uint32_t mine = cmin[ch];
+        int num = 0;
+        for (int c2 = 0; c2 < C; ++c2) num += cmin[c2] < mine ? 1 : 0;
+        cnum[ch] = (uint16_t)num;
+    WB_END_PFOR
+    WB_PFOR(ch, C)
+        rawbase[cnum[ch]] = ctot[ch] + 1;                      // raw points of the contour: its segments' end points + the first start point
+        closedn[cnum[ch]] = cloop[ch];
+    WB_END_PFOR
+    const int R = wb_block_scan_excl(rawbase, C);
+    WB_SINGLE
+    rawbase[C] = R;
+    WB_END_SINGLE
+    // where every segment's end point goes (bit 15: the segment is its contour's first -- its start point goes in front).
+    // Reads region A (own / lp) and the ranking's tables, writes region B.
+    WB_PFOR(g, n)
+        const int o = (int)own[g], ch = cix[o];
+        int q = (int)(uint16_t)(Q[o] >> 16) + (int)lp[g];      // position along the chain, from 1
+        if (cloop[ch]) {
+            const int pl = (int)lpos[ch], tot = ctot[ch];
+            q = q > pl ? q - pl : q - pl + tot;
+        }
+        dest[g] = (uint16_t)((rawbase[cnum[ch]] + q) | (q == 1 ? 0x8000 : 0));
+    WB_END_PFOR
+    if (R >= 0x8000) WB_F_DECLINE();                            // (cannot happen: n < 8191, C <= cmax)
+    // the contour of raw point 32 b, for every b (the ranking's tables are done with: group 2 of the tables from here on)
+    WB_PFOR(b, (R + 31) / 32 + 1)
+        const int p = (int)b * 32;
+        int lo = 0, hi = C;                                      // first contour whose end lies behind p
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (rawbase[mid + 1] <= p) lo = mid + 1; else hi = mid;
+        }
+        blk[b] = (uint16_t)lo;
+    WB_END_PFOR
+    // ---- E: the crossing points, rounded half-to-even (contour_index.py:111), straight to their places in contour order.
+    // Region A becomes the raw points (own / lp are done with).
+    auto pack = [&](const int p, const uint32_t pt) -> uint32_t {
+        int c = (int)blk[p >> 5];
+        while (rawbase[c + 1] <= p) ++c;
+        return ((uint32_t)c << sh) | ((uint32_t)wb_pt_y(pt) << xb) | (uint32_t)wb_pt_x(pt);
+    };
+    WB_PFOR(g, n)
+        int s, i;
+        wb_f_locate(sbase, (int)g, &s, &i);
+        const size_t e = ((size_t)job * NS + s) * a.cap_strip + (size_t)i;
+        const uint32_t key = a.stg_k[e];
+        double ul, ur, ll, lr;
+        if (a.dtype == 0) { const float* v = (const float*)a.stg_v + e * 4; ul = (double)v[0]; ur = (double)v[1]; ll = (double)v[2]; lr = (double)v[3]; }
+        else { const double* v = (const double*)a.stg_v + e * 4; ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3]; }
+        // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
+        if (ul == level || ur == level || ll == level || lr == level) ctr[0] = 1;
+        const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
+        const uint16_t d = dest[g];
+        const int p = (int)(d & 0x7FFFu);
+        rawpt[p] = pack(p, wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level));
+        if (d & 0x8000u) rawpt[p - 1] = pack(p - 1, wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level));
+    WB_END_PFOR
+    if (ctr[0]) WB_F_DECLINE();
+
+    // ---- F: buckets of the raw points by x mod nlon (1 << WB_F_XSHIFT meridians each).  A point equal to its predecessor in
+    // the same contour can never be a first occurrence (about half of all raw points: neighbouring crossings that round to the
+    // same lattice point): it stays out.
+    const int NB = (nlon >> WB_F_XSHIFT) + 1;
+    WB_PFOR(x, NB + 1)
+        cnt[x] = 0;
+    WB_END_PFOR
+    WB_PFOR(w, (R + 31) / 32 + 1)
+        keepb[w] = 0u;
+        dupb[w] = 0u;
+    WB_END_PFOR
+    WB_PFOR(c, C + 1)
+        newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0;
+    WB_END_PFOR
+#define WB_F_BUCKET(pw) ((int)(((pw) & xmask) % (uint32_t)nlon) >> WB_F_XSHIFT)
+    WB_PFOR(p, R)
+        const uint32_t pw = rawpt[p];
+        const bool dup = p > 0 && pw == rawpt[p > 0 ? p - 1 : 0];        // (equal words: the same contour and the same lattice point)
+        if (dup) wb_atomic_or(&dupb[p >> 5], 1u << (p & 31));
+        else wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);
+    WB_END_PFOR
+    const int U = wb_block_scan_excl(cnt, NB);                  // cnt[b]: first entry of bucket b
+    WB_PFOR(p, R)
+        if (!((dupb[p >> 5] >> (p & 31)) & 1u)) {
+            const int e = wb_atomic_add(&cnt[WB_F_BUCKET(rawpt[p])], 1);          // (afterwards cnt[b] = END of bucket b = start of bucket b + 1)
+            order[e] = (uint16_t)p;
+        }
+    WB_END_PFOR
+    // first-occurrence dedupe (contour_index.py:110-112: dict.fromkeys over the contour's points)
+    WB_PFOR(e, U)
+        const int p = (int)order[e];
+        const uint32_t pw = rawpt[p];
+        const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
+        bool first = true;
+        for (int e2 = b0; e2 < b1; ++e2) {
+            const int p2 = (int)order[e2];
+            if (p2 < p && rawpt[p2] == pw) first = false;
+        }
+        if (first) wb_atomic_or(&keepb[p >> 5], 1u << (p & 31));
+    WB_END_PFOR
+    // compaction: a thread owns a run of consecutive raw points; the kept ones go to the job's output array (the points of
+    // contours that turn out too short included, as the finish kernel of wb_trace.h lays them out)
+    uint32_t* const cpts = a.cpts + 2 * jb;
+    const int chunk = (R + WB_NT - 1) / WB_NT;
+    WB_PFOR(t, WB_NT)
+        const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
+        int k = 0;
+        for (int p = p0; p < p1; ++p) k += (int)((keepb[p >> 5] >> (p & 31)) & 1u);
+        tcount[t] = k;
+    WB_END_PFOR
+    const int NK = wb_block_scan_excl(tcount, WB_NT);
+    WB_PFOR(t, WB_NT)
+        const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
+        int q = tcount[t];
+        for (int p = p0; p < p1; ++p) {
+            const uint32_t pw = rawpt[p];
+            const int c = (int)(pw >> sh);
+            if (p == rawbase[c]) newstart[c] = q;
+            if ((keepb[p >> 5] >> (p & 31)) & 1u) cpts[q++] = (pw & xmask) | (((pw >> xb) & ymask) << 16);
+        }
+    WB_END_PFOR
+    WB_SINGLE
+    newstart[C] = NK;
+    WB_END_SINGLE
+    // contours with at least four points stay (contour_index.py:113-117)
+    WB_PFOR(c, C)
+        kid[c] = (newstart[c + 1] - newstart[c]) >= 4 ? 1 : 0;
+        fin[c] = kid[c];
+    WB_END_PFOR
+    const int Ck = wb_block_scan_excl(kid, C);                  // kid[c]: number among the kept ones; fin[c]: kept flag
+    WB_PFOR(c, C)
+        if (fin[c]) ckept[kid[c]] = (uint16_t)c;
+    WB_END_PFOR
+    // ---- G: per kept contour: distinct x (-> exp_lon, :154), sum of y (-> mean_lat, :155), distinct (x mod nlon, y)
+    WB_PFOR(e, U)
+        const int p = (int)order[e];
+        const uint32_t pw = rawpt[p];
+        const int c = (int)(pw >> sh);
+        if (fin[c]) {
+            const uint32_t x = pw & xmask, xm = x % (uint32_t)nlon, cy = pw >> xb;     // cy: contour and y
+            const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0;
+            bool firstx = true, firsty = true;
+            for (int e2 = b0; e2 < (int)e; ++e2) {              // the entries in front of this one in its bucket
+                const uint32_t pw2 = rawpt[order[e2]];
+                if ((pw2 >> xb) == cy && (pw2 & xmask) % (uint32_t)nlon == xm) firsty = false;
+                if ((pw2 >> sh) == (uint32_t)c && (pw2 & xmask) == x) firstx = false;
+            }
+            const int f = kid[c];
+            if (firstx) wb_atomic_add(&nuxl[f], 1);
+            if (firsty) wb_atomic_add(&setsize[f], 1);
+            if ((keepb[p >> 5] >> (p & 31)) & 1u) wb_atomic_add(&sumyl[f], (int)((pw >> xb) & ymask));
+        }
+    WB_END_PFOR
+    // ---- periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1, i2) with set(i1) a subset of set(i2)
+    // (points taken x mod nlon): equal array lengths -> drop max(i1, i2), else drop the shorter.  Almost every pair fails on the
+    // first point of i1; the few that pass it are queued and checked by the whole workgroup.
+    auto in_set = [&](const uint32_t pw, const int c2) -> bool {
+        const uint32_t xm = (pw & xmask) % (uint32_t)nlon, cy = ((uint32_t)c2 << yb) | ((pw >> xb) & ymask);
+        const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
+        for (int e2 = b0; e2 < b1; ++e2) {
+            const uint32_t pw2 = rawpt[order[e2]];
+            if ((pw2 >> xb) == cy && (pw2 & xmask) % (uint32_t)nlon == xm) return true;
+        }
+        return false;
+    };
+    auto drop_of = [&](const int i1, const int i2) -> int {
+        const int c1 = (int)ckept[i1], c2 = (int)ckept[i2];
+        const int l1 = newstart[c1 + 1] - newstart[c1], l2 = newstart[c2 + 1] - newstart[c2];
+        return (l1 == l2) ? (i1 > i2 ? i1 : i2) : (l1 < l2 ? i1 : i2);
+    };
+    WB_PFOR(pair, (int64_t)Ck * Ck)
+        const int i1 = (int)(pair / Ck), i2 = (int)(pair - (int64_t)i1 * Ck);
+        if (i1 == i2 || setsize[i1] > setsize[i2]) continue;
+        const int c1 = (int)ckept[i1], c2 = (int)ckept[i2];
+        const int pa = rawbase[c1], pb = rawbase[c1 + 1];
+        if (!in_set(rawpt[pa], c2)) continue;
+        const int slot = wb_atomic_add(&ctr[4], 1);
+        if (slot < WB_F_NCAND) { cand[2 * slot] = i1; cand[2 * slot + 1] = i2; continue; }
+        bool sub = true;                                        // (queue full: this lane checks the pair by itself)
+        for (int p = pa + 1; p < pb && sub; ++p) sub = in_set(rawpt[p], c2);
+        if (sub) dropped[drop_of(i1, i2)] = 1;
+    WB_END_PFOR
+    {
+        const int nc = ctr[4] < WB_F_NCAND ? ctr[4] : WB_F_NCAND;
+        for (int q = 0; q < nc; ++q) {
+            const int i1 = cand[2 * q], i2 = cand[2 * q + 1];
+            const int c1 = (int)ckept[i1], c2 = (int)ckept[i2];
+            const int pa = rawbase[c1], pb = rawbase[c1 + 1];
+            WB_SINGLE
+            ctr[5] = 0;
+            WB_END_SINGLE
+            WB_PFOR(p, pb - pa)
+                if (!in_set(rawpt[pa + p], c2)) ctr[5] = 1;
+            WB_END_PFOR
+            if (ctr[5] == 0) {
+                WB_SINGLE
+                dropped[drop_of(i1, i2)] = 1;
+                WB_END_SINGLE
+            } else {
+                WB_SYNC();                                      // keep the barrier count of the two branches equal
+            }
+        }
+    }
+    // ---- H: final table = kept and not dropped, order preserved (fin: the kept flag by contour until here, by kept contour from here)
+    WB_PFOR(f, Ck)
+        fin[f] = dropped[f] ? 0 : 1;
+    WB_END_PFOR
+    const int Cf = wb_block_scan_excl(fin, Ck);
+    WB_PFOR(f, Ck)
+        if (!dropped[f]) {
+            const int g = fin[f], c = (int)ckept[f];
+            (a.c_off + jb)[g] = newstart[c];
+            (a.c_len + jb)[g] = newstart[c + 1] - newstart[c];
+            (a.c_closed + jb)[g] = (int)closedn[c];
+            (a.c_nux + jb)[g] = nuxl[f];
+            (a.c_sumy + jb)[g] = sumyl[f];
+            wb_atomic_max(&a.ctl->max_nux, nuxl[f]);
+        }
+    WB_END_PFOR
+    WB_SINGLE
+    a.ncont[job] = Cf;
+    a.nseg[job] = n;
+    fa.fdone[job] = 1;
+    WB_END_SINGLE
+#undef WB_F_DECLINE
+#undef WB_FQ
+#undef WB_F_BUCKET
+}
