@@ -7,12 +7,13 @@ overturning and cutoff indices + event tables back in host memory) over ONE resi
 configs[1], 1.0 degree, level [2], the streamer index).  Inputs are generated on the device and are resident in
 HBM when the timed region starts.
 
-WHAT `value` IS: device-resident float32 field batch -> INDEX-SPACE event tables in host memory -- per event its
-step / level / contour, end points or box, orientation, the five area-weighted sums of calculate_properties
-(index_utils.py:66-102), cell count, flags, and the polygon vertices in grid indices.  NOT in `value`: the upload of
-the fields over PCIe (`end_to_end` measures the drop-in calls from a host cube, upload included), transform_polygons to
-lon / lat with the seam split (index_utils.py:129-184) and the last few flops of the property columns (:104-120) --
-host-side C++ / numpy, reported as `stage_ms.geometry_host` per pass -- and the construction of the (Geo)DataFrame.
+WHAT `value` IS: device-resident float32 field batch -> event tables in host memory -- per event its step / level /
+contour, end points or box, orientation, the five area-weighted sums of calculate_properties (index_utils.py:66-102),
+cell count, flags, the polygon vertices in grid indices AND (since round 5) the polygon in lon / lat: transform_polygons
+with the seam split (index_utils.py:129-184), cut, truncated and mapped by the device into pinned host memory
+(csrc/wb_geom.h; `without_geometry` on the line: the same passes with the context option geometry = 0).  NOT in `value`:
+the upload of the fields over PCIe (`end_to_end` measures the drop-in calls from a host cube, upload included), the last
+few flops of the property columns (:104-120; `stage_ms.geometry_host`) and the construction of the (Geo)DataFrame.
 
 `--streams` passes (default 2) are in flight per GPU at any time, each on its own context = HIP stream +
 host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.  The K passes are ONE
@@ -166,6 +167,7 @@ def main():
     stage_ms = {}
     counts = {}
     wall = {}
+    geometry_on = [True]          # the timed region runs the product's default: wb_indices also leaves the events' lon / lat rings
 
     # one step = one pass of the hot path over the resident batch; the two ABI phases run on a worker thread of the
     # pass's context, the two exchanges of a multi-GPU run on this thread in pass order (wavebreaking_amd/pipeline.py)
@@ -187,6 +189,7 @@ def main():
         b.indices(g, **which)
         w2 = time.perf_counter()
         ev = [b.events(i, copy=copy) for i in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
+        geo = [b.event_geometry(i, copy=copy) for i in (0, 1, 2)] if geometry_on[0] else None   # lon / lat rings (transform_polygons), cut and mapped by the device
         w3 = time.perf_counter()
         res = dict(timings=b.timings(),
                    counts=dict(polygon_vertices=int(sum(e["poly_x"].size for e in ev)), streamers=int(ev[0]["step"].size),
@@ -194,7 +197,9 @@ def main():
                                band_hits=b.band_hits(), pair_stats=b.pair_stats(), evaluated_pairs=b.evaluated_pairs(),
                                com_rechecks=b.com_rechecks(), group_ties=b.group_ties(),
                                polygons_not_simple=int(sum(int(np.count_nonzero(e["flags"] & 1)) for e in ev)),
-                               status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0),
+                               status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0,
+                               geometry_rings=int(sum(g[1].size - 1 for g in geo)) if geo else 0,
+                               geometry_vertices=int(sum(g[2].size for g in geo)) if geo else 0),
                    batch=b if multi else None,
                    events=ev if copy else None)
         if not multi:
@@ -295,6 +300,24 @@ def main():
         staggered = {"value": nt * a.stagger_steps / dt_s, "ms_per_step": 1e3 * dt_s / a.stagger_steps, "steps": a.stagger_steps,
                      "scan_launch_ms": sc, "roofline_frac": nt * nlat * nlon * 4 / (sc * 1e-3) / HBM_PEAK,
                      "what": "BatchPipeline.set_stagger(1): each ABI phase entered by one batch at a time"}
+    # the same passes WITHOUT transform_polygons on the device (context option geometry = 0: index-space tables only, what
+    # `value` was until round 4) -- what the lon / lat rings cost per pass
+    without_geometry = None
+    if not multi and a.stagger_steps > 0:
+        geometry_on[0] = False
+        for c in pipe.contexts:
+            c.set_option("geometry", 0)
+        run_record(3, False)
+        torch.cuda.synchronize()
+        tic_g = time.perf_counter()
+        run_record(a.stagger_steps, False)
+        torch.cuda.synchronize()
+        dt_g = time.perf_counter() - tic_g
+        for c in pipe.contexts:
+            c.set_option("geometry", 1)
+        geometry_on[0] = True
+        without_geometry = {"value": nt * a.stagger_steps / dt_g, "ms_per_step": 1e3 * dt_g / a.stagger_steps, "steps": a.stagger_steps,
+                            "what": "context option geometry = 0: index-space event tables only (round 4's `value`)"}
     # outside `value`, for the record: what transform_polygons (index_utils.py:129-184) and the frame's property columns
     # (:104-120) cost per pass on the host -- one wb_get_event_geometry per index (the library's C++ seam split over the whole
     # table) + properties_from_sums, timed on this thread after the timed region
@@ -308,12 +331,12 @@ def main():
         for kind in (0, 1, 2):
             ev_k = b.events(kind, copy=False)
             if ev_k["step"].size:
-                ring_off, vert_off, gx, gy = b.event_geometry(kind)
+                ring_off, vert_off, gx, gy = b.event_geometry(kind, copy=False)
                 nrings += int(vert_off.size) - 1
                 iu.properties_from_sums(ev_k["sums"], lon, lat, nlon)
         geometry_host = {"ms": 1e3 * (time.perf_counter() - tic_g), "rings": nrings,
-                         "what": "wb_get_event_geometry (transform_polygons, index_utils.py:129-184) + properties_from_sums (:104-120) for the "
-                                 "three event tables of one pass, host only, outside `value`"}
+                         "what": "wb_get_event_geometry (since round 5: views of the rings the device wrote during wb_indices) + "
+                                 "properties_from_sums (index_utils.py:104-120) for the three event tables of one pass, host only"}
         b.close()
     verify = None
     if multi:
@@ -379,10 +402,17 @@ def main():
         if geometry_host is not None:
             out["stage_ms"]["geometry_host"] = geometry_host["ms"]
             out["geometry_host"] = geometry_host
-        out["value_is"] = ("device-resident f32 field batch -> index-space event tables of all requested indices in host memory (rows: step, "
-                           "level, contour, end points or box, orientation; the five area-weighted sums; cell counts; flags; polygon vertices "
-                           "in grid indices); NOT included: the upload of the fields (end_to_end has it), transform_polygons to lon / lat "
-                           "and the frame's property columns (stage_ms.geometry_host, host only), frame construction")
+        out["value_with_geometry"] = out["value"]
+        if without_geometry is not None:
+            out["without_geometry"] = without_geometry
+            out["geometry_adds_ms_per_step"] = out["ms_per_step"] - without_geometry["ms_per_step"]
+        out["value_is"] = ("device-resident f32 field batch -> event tables of all requested indices in host memory (rows: step, level, "
+                           "contour, end points or box, orientation; the five area-weighted sums; cell counts; flags; polygon vertices in "
+                           "grid indices) AND, since round 5, the events' polygons in lon / lat -- transform_polygons, index_utils.py:129-184: "
+                           "cut at the last meridian, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h; "
+                           "`without_geometry`: the same passes without it).  NOT included: the upload of the fields (end_to_end has it), "
+                           "the last flops of the frame's property columns (stage_ms.geometry_host: the views of the rings + "
+                           "properties_from_sums, host) and frame construction")
         if world == 1 and a.e2e_steps > 0 and a.config == 2:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:

@@ -150,6 +150,12 @@ int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* out);
    The arrays of `out` belong to the context until its next call of this function. */
 int wb_transform_polygons(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, const int32_t* px, const int32_t* py,
                           const double* lon, const double* lat, int nlon, int index_space, wb_geometry* out);
+/* ... and the same polygons through the DEVICE kernels that wb_indices runs for a pass's events (context option "geometry",
+   default 1: the rings of wb_get_event_geometry are then cut, truncated and mapped to lon / lat by the device and written into
+   pinned host memory beside the event tables; csrc/wb_geom.h): uploaded, transformed, read back -- ring for ring and bit for
+   bit what wb_transform_polygons returns (the parity tests compare the two).  lat: [nlat]. */
+int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, const int32_t* px, const int32_t* py,
+                                 const double* lon, const double* lat, int nlon, int nlat, int index_space, wb_geometry* out);
 int wb_get_contours(wb_batch* b, wb_contour_table* out);
 int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */

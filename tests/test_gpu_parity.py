@@ -275,3 +275,76 @@ def test_cells_equal_to_the_level_full_path(ctx, seed, dlon):
 
 def test_polygon_that_crosses_itself_is_flagged(ctx):
     helpers.not_simple_polygon_case(ctx)
+
+
+def _contour_tables_gpu(ctx, pv, lat, lon, levels, d, padd, **opts):
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    try:
+        b = ctx.contours(pv, lat, lon, levels, d, d, periodic_add=padd)
+        tab = b.contour_table()
+        st = np.array(b.status())
+        b.close()
+    finally:
+        for k, v in dict(trace_fused=1, trace_nmax=0, trace_cmax=256).items():
+            ctx.set_option(k, v)
+    return tab, st
+
+
+def test_fused_trace_kernel_equals_the_three_kernel_chain(ctx):
+    """wb_k_trace_fused (csrc/wb_trace_fused.h: one launch per job, LDS-resident, list ranking over splitters, longitude
+    buckets) against link -> rank -> finish on the device: smooth / rough / NaN-bordered fields, three periodic pads, three levels,
+    0.25 degree included, and launches whose LDS admits only some of the jobs (both paths fill one batch's tables)"""
+    cases = []
+    lat, lon = synth.grid(2.5)
+    pv = synth.pv_field(7, 3, lat, lon, eps=0.4)
+    pv[:, [0, 1, -2, -1], :] = np.nan
+    cases.append((pv, lat, lon, 2.5))
+    lat1, lon1 = synth.grid(1.0)
+    cases.append((synth.pv_field(11, 4, lat1, lon1, eps=0.3), lat1, lon1, 1.0))
+    cases.append((synth.pv_field(40, 4, lat1, lon1, eps=0.02).astype(np.float32), lat1, lon1, 1.0))
+    latq, lonq = synth.grid(0.25)
+    cases.append((synth.pv_field(300, 3, latq, lonq, eps=0.0).astype(np.float32), latq, lonq, 0.25))
+    cases.append((synth.pv_field(900, 2, latq, lonq, eps=0.05).astype(np.float32), latq, lonq, 0.25))
+    total = 0
+    for pv, la, lo, d in cases:
+        for padd in (0.0, 120.0, 360.0):
+            ref, st0 = _contour_tables_gpu(ctx, pv, la, lo, [-2.0, 0.5, 2.0], d, padd, trace_fused=0)
+            total += ref["step"].size
+            for opts in (dict(trace_fused=1), dict(trace_fused=1, trace_nmax=1024 if d > 0.5 else 4096), dict(trace_fused=1, trace_cmax=8)):
+                got, st1 = _contour_tables_gpu(ctx, pv, la, lo, [-2.0, 0.5, 2.0], d, padd, **opts)
+                for key in ref:
+                    assert np.array_equal(ref[key], got[key]), (d, padd, opts, key)
+                assert np.array_equal(st0, st1), (d, padd, opts)
+    assert total > 400
+
+
+def test_device_geometry_equals_host_geometry(ctx):
+    """transform_polygons (index_utils.py:129-184): the rings wb_indices leaves in pinned host memory (cut at the last meridian,
+    truncated and mapped to lon / lat by the device, csrc/wb_geom.h) against the host function on the same events -- ring for
+    ring, bit for bit -- through the batch and through wb_transform_polygons_device on hand-made polygons"""
+    from tests import test_seam_split as tss
+    polys = [np.asarray(tss.HAND[k]) for k in sorted(tss.HAND)] * 5
+    for ispace in (False, True):
+        host = ctx.transform_polygons(polys, tss.LON, tss.LAT, tss.NLON, index_space=ispace)
+        dev = ctx.transform_polygons(polys, tss.LON, tss.LAT, tss.NLON, index_space=ispace, device=True)
+        assert tss._same_rings(host, dev)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(20, 8, lat, lon, eps=0.2)
+    rings = {}
+    for flag in (1, 0):
+        ctx.set_option("geometry", flag)
+        try:
+            b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 1.0, 1.0, periodic_add=120.0, intensity=pv)
+            b.indices()
+            rings[flag] = [b.event_geometry(kind) for kind in (0, 1, 2)]
+            b.close()
+        finally:
+            ctx.set_option("geometry", 1)
+    nsplit = 0
+    for kind in (0, 1, 2):
+        for a, c in zip(rings[1][kind], rings[0][kind]):
+            assert np.array_equal(np.asarray(a), np.asarray(c)), kind
+        ro = np.asarray(rings[1][kind][0])
+        nsplit += int((np.diff(ro) != 1).sum())
+    assert sum(len(np.asarray(r[0])) for r in rings[1]) > 60 and nsplit > 0

@@ -33,9 +33,19 @@ def _ring_sets(poly):
     return sorted(oprop.canonical_ring(r) for r in got), sorted(oprop.canonical_ring(r) for r in want)
 
 
+def _same_rings(a, b):
+    return len(a) == len(b) and all(len(p) == len(q) and all(np.array_equal(u, v) for u, v in zip(p, q)) for p, q in zip(a, b))
+
+
 def _check(poly):
     got, want = _ring_sets(poly)
     assert got == want, (poly, got, want)
+    # the kernels wb_indices runs for a pass's events (csrc/wb_geom.h, here in the host simulation): ring for ring and bit for
+    # bit the host function's, in lon / lat and in index space
+    for ispace in (False, True):
+        host = _context().transform_polygons([np.asarray(poly)], LON, LAT, NLON, index_space=ispace)
+        dev = _context().transform_polygons([np.asarray(poly)], LON, LAT, NLON, index_space=ispace, device=True)
+        assert _same_rings(host, dev), (poly, ispace, host, dev)
     # the index-space pieces (before truncation and the lon / lat look-up) against the clamped-abscissa area
     pieces = _context().transform_polygons([np.asarray(poly)], LON, LAT, NLON, index_space=True)[0]
     area = sum(abs(oprop.ring_area(p)) for p in pieces)
@@ -143,6 +153,25 @@ def _simple(pts):
         if geom.orient(a[0], a[1], b[0], b[1], c[0], c[1]) == 0 and np.dot(b - a, c - b) < 0:
             return False
     return True
+
+
+def test_device_kernels_on_many_polygons_in_one_call():
+    """count -> offsets -> fill over a table of polygons (several workgroups, empty and whole and cut events mixed), and an
+    event with more cut edges than the kernel holds (sent to the host function)"""
+    rng = np.random.RandomState(5)
+    polys = [HAND[k] for k in sorted(HAND)] * 7
+    rng.shuffle(polys)
+    teeth = [(30, 0)]
+    for k in range(40):                                         # 40 teeth: 80 cut edges > WB_GEOM_XMAX
+        teeth += [(40, 2 * k), (40, 2 * k + 1), (33, 2 * k + 1), (33, 2 * k + 2)]
+    teeth += [(30, 80)]
+    lat = np.linspace(-45.0, 45.0, 91)
+    for extra in ([], [teeth]):
+        allp = [np.asarray(q) for q in polys + extra]
+        host = _context().transform_polygons(allp, LON, lat, NLON)
+        dev = _context().transform_polygons(allp, LON, lat, NLON, device=True)
+        assert _same_rings(host, dev)
+    assert len(host[-1]) == 41
 
 
 def test_clamped_area_formula_on_a_known_case():

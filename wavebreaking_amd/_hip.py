@@ -98,6 +98,8 @@ class Library:
         lib.wb_get_event_geometry.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbGeometry)]
         lib.wb_transform_polygons.argtypes = [C.c_void_p, C.c_int64, i64p, i32p, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.c_int, C.c_int, C.POINTER(WbGeometry)]
+        lib.wb_transform_polygons_device.argtypes = [C.c_void_p, C.c_int64, i64p, i32p, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                     C.c_int, C.c_int, C.c_int, C.POINTER(WbGeometry)]
         lib.wb_get_status.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]
         lib.wb_get_band_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.wb_probe_read_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
@@ -512,9 +514,11 @@ class Context:
         if self.h:
             self.L.lib.wb_comm_destroy(self.h)
 
-    def transform_polygons(self, polygons, lon, lat, nlon, index_space=False):
+    def transform_polygons(self, polygons, lon, lat, nlon, index_space=False, device=False):
         """wb_transform_polygons: index-lattice polygons (list of (n, 2) integer arrays) -> per polygon the list of its rings
-        ((m, 2) float64 arrays) in (lon, lat) -- or, with ``index_space``, in index coordinates as they are cut at the seam"""
+        ((m, 2) float64 arrays) in (lon, lat) -- or, with ``index_space``, in index coordinates as they are cut at the seam.
+        ``device``: through the kernels wb_indices runs for a pass's events (wb_transform_polygons_device) instead of the host
+        function"""
         polys = [np.asarray(q).astype("int").reshape(-1, 2) for q in polygons]
         off = np.zeros(len(polys) + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(q) for q in polys])
@@ -525,9 +529,15 @@ class Context:
         lat = np.ascontiguousarray(lat, dtype=np.float64)
         dp, i32p, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         g = WbGeometry()
-        if self.L.lib.wb_transform_polygons(self.h, len(polys), off.ctypes.data_as(i64p), px.ctypes.data_as(i32p), py.ctypes.data_as(i32p),
-                                            lon.ctypes.data_as(dp), lat.ctypes.data_as(dp), int(nlon), 1 if index_space else 0,
-                                            C.byref(g)) != 0:
+        if device:
+            rc = self.L.lib.wb_transform_polygons_device(self.h, len(polys), off.ctypes.data_as(i64p), px.ctypes.data_as(i32p), py.ctypes.data_as(i32p),
+                                                         lon.ctypes.data_as(dp), lat.ctypes.data_as(dp), int(nlon), int(lat.size),
+                                                         1 if index_space else 0, C.byref(g))
+        else:
+            rc = self.L.lib.wb_transform_polygons(self.h, len(polys), off.ctypes.data_as(i64p), px.ctypes.data_as(i32p), py.ctypes.data_as(i32p),
+                                                  lon.ctypes.data_as(dp), lat.ctypes.data_as(dp), int(nlon), 1 if index_space else 0,
+                                                  C.byref(g))
+        if rc != 0:
             raise RuntimeError("wb_transform_polygons failed: " + self.error())
         ro = _arr(g.ring_offset, g.n + 1, np.int64)
         vo = _arr(g.vert_offset, g.nrings + 1, np.int64)
@@ -684,14 +694,16 @@ class Batch:
             out["cell_y"] = A(t.cell_y, off[-1] if n else 0, np.int32)
         return out
 
-    def event_geometry(self, kind):
-        """transform_polygons for the whole table: (ring_offset per event, vert_offset per ring, lon, lat) arrays"""
+    def event_geometry(self, kind, copy=True):
+        """transform_polygons for the whole table: (ring_offset per event, vert_offset per ring, lon, lat) arrays.  ``copy=False``
+        hands out views of the library's host arrays -- the pinned blocks the device wrote the rings into during indices() --
+        valid until the batch's next indices() / close()."""
         g = WbGeometry()
         if self.ctx.L.lib.wb_get_event_geometry(self.h, int(kind), C.byref(g)) != 0:
             raise RuntimeError("wb_get_event_geometry failed: " + self.ctx.error())
-        voff = _arr(g.vert_offset, g.nrings + 1, np.int64)
+        voff = _arr(g.vert_offset, g.nrings + 1, np.int64, copy)
         nv = int(voff[-1]) if voff.size else 0
-        return _arr(g.ring_offset, g.n + 1, np.int64), voff, _arr(g.x, nv, np.float64), _arr(g.y, nv, np.float64)
+        return _arr(g.ring_offset, g.n + 1, np.int64, copy), voff, _arr(g.x, nv, np.float64, copy), _arr(g.y, nv, np.float64, copy)
 
     def status(self):
         p = C.POINTER(C.c_uint32)()

@@ -20,6 +20,7 @@
 #include "wb_geometry.h"
 #include "wb_indices.h"
 #include "wb_props.h"
+#include "wb_geom.h"
 #include "wb_scan.h"
 #include "wb_stream.h"
 #include "wb_trace.h"
@@ -80,6 +81,10 @@ struct wb_batch {
         std::vector<double> sums;
     } ev[3];
     WbRingSink geo[3];                              // event geometry in lon / lat (wb_get_event_geometry), built on demand
+    // ... or cut and mapped by the device during wb_indices (context option "geometry"): pinned host arrays over ALL events
+    std::vector<std::pair<void*, size_t>> gres;
+    long long* g_ring_offset = nullptr; long long* g_vert_offset = nullptr; double* g_x = nullptr; double* g_y = nullptr;
+    long long g_rings = -1, g_verts = 0;            // -1: not there (option off, or an event the kernel flagged: host function)
     int32_t *poly_x = nullptr, *poly_y = nullptr;   // polygon vertices of all events (streamers, overturnings, cutoffs)
     size_t poly_n = 0, poly_bytes = 0;
     WbTimer timer;
@@ -252,6 +257,7 @@ void wb_free_batch(wb_batch* b) {
     for (void* p : b->owned) dfree(b->ctx, p);
     hfree(b->ctx, b->poly_x, b->poly_bytes);
     hfree(b->ctx, b->poly_y, b->poly_bytes);
+    for (auto& hb : b->gres) hfree(b->ctx, hb.first, hb.second);
     WB_TICK("free_batch device");
     delete b;
     WB_TICK("free_batch host");
@@ -715,6 +721,22 @@ extern "C" int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* o) {
     WbRingSink& g = b->geo[kind];
     g = WbRingSink();
     const int64_t n = (int64_t)t.step.size();
+    if (b->g_rings >= 0) {
+        // cut and mapped by the device during wb_indices: this table's slice of the pass's arrays, offsets from zero
+        const int64_t lo = kind == 0 ? 0 : (kind == 1 ? b->dev_n[0] : b->dev_n[0] + b->dev_n[1]);
+        const long long r0 = b->g_ring_offset[lo], r1 = b->g_ring_offset[lo + n], v0 = b->g_vert_offset[r0];
+        g.ring_offset.resize((size_t)n + 1);
+        for (int64_t k = 0; k <= n; ++k) g.ring_offset[(size_t)k] = b->g_ring_offset[lo + k] - r0;
+        g.vert_offset.resize((size_t)(r1 - r0) + 1);
+        for (long long q = 0; q <= r1 - r0; ++q) g.vert_offset[(size_t)q] = b->g_vert_offset[r0 + q] - v0;
+        o->n = n;
+        o->ring_offset = g.ring_offset.data();
+        o->nrings = (int64_t)(r1 - r0);
+        o->vert_offset = g.vert_offset.data();
+        o->x = b->g_x + v0;
+        o->y = b->g_y + v0;
+        return 0;
+    }
     g.ring_offset.push_back(0);
     g.vert_offset.push_back(0);
     for (int64_t k = 0; k < n; ++k) {
@@ -742,6 +764,68 @@ extern "C" int wb_transform_polygons(wb_ctx* ctx, int64_t n, const int64_t* poly
     o->n = n;
     o->ring_offset = g.ring_offset.data();
     o->nrings = (int64_t)g.vert_offset.size() - 1;
+    o->vert_offset = g.vert_offset.data();
+    o->x = g.x.data();
+    o->y = g.y.data();
+    return 0;
+}
+// the same polygons through the device kernels of wb_geom.h (what wb_indices runs for a pass's events): uploaded, cut and
+// mapped on the device, read back.  An event the kernels flag (more than WB_GEOM_XMAX cut edges) sends the call to the host
+// function above.
+extern "C" int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, const int32_t* px, const int32_t* py,
+                                            const double* lon, const double* lat, int nlon, int nlat, int index_space, wb_geometry* o) {
+    if (!ctx || !o || n < 0 || (n && (!poly_offset || !px || !py))) return 1;
+    if (nlon < 1 || (!index_space && (!lon || !lat || nlat < 1))) return wb_fail(ctx, "wb_transform_polygons_device: lon / lat / nlon missing");
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
+    const long long NP = n ? poly_offset[n] : 0;
+    std::vector<void*> tmp;
+    auto talloc = [&](size_t bytes) { void* q = dmalloc(ctx, bytes ? bytes : 8); if (q) tmp.push_back(q); return q; };
+    auto release = [&]() { for (void* q : tmp) dfree(ctx, q); tmp.clear(); };
+    WbGeomArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.nev = n; ga.nlon = nlon; ga.index_space = index_space ? 1 : 0;
+    long long* d_po = (long long*)talloc((size_t)(n + 1) * sizeof(long long));
+    int32_t* d_px = (int32_t*)talloc((size_t)(NP + 1) * 4); int32_t* d_py = (int32_t*)talloc((size_t)(NP + 1) * 4);
+    double* d_lon = (double*)talloc((size_t)(lon ? nlon : 1) * 8); double* d_lat = (double*)talloc((size_t)(lat ? nlat : 1) * 8);
+    ga.cap_r = n + NP / 2 + 16; ga.cap_v = 2 * NP + 4 * n + 64;
+    ga.cnt_r = (int*)talloc((size_t)(n + 2) * 4); ga.cnt_v = (int*)talloc((size_t)(n + 2) * 4); ga.gflag = (int*)talloc((size_t)(n + 2) * 4);
+    ga.ring_offset = (long long*)talloc((size_t)(n + 2) * 8); ga.vert_offset = (long long*)talloc((size_t)(ga.cap_r + 2) * 8);
+    ga.x = (double*)talloc((size_t)(ga.cap_v + 2) * 8); ga.y = (double*)talloc((size_t)(ga.cap_v + 2) * 8);
+    if (!ga.y || !ga.x || !ga.vert_offset || !ga.ring_offset || !ga.gflag || !d_lat || !d_lon || !d_py) { release(); return wb_fail(ctx, "out of device memory"); }
+    std::vector<long long> po(poly_offset, poly_offset + n + 1);
+    if (n == 0) po.assign(1, 0);
+    h2d(ctx, d_po, po.data(), po.size() * sizeof(long long));
+    if (NP) { h2d(ctx, d_px, px, (size_t)NP * 4); h2d(ctx, d_py, py, (size_t)NP * 4); }
+    if (lon) h2d(ctx, d_lon, lon, (size_t)nlon * 8);
+    if (lat) h2d(ctx, d_lat, lat, (size_t)nlat * 8);
+    ga.poly_offset = d_po; ga.px = d_px; ga.py = d_py; ga.lon = d_lon; ga.lat = d_lat;
+    WbOpTimer tm(ctx);
+    WB_LAUNCH(wb_k_geom_count, n < 4096 ? (n > 0 ? n : 1) : 4096, WB_GEOM_THREADS, ga);
+    WB_LAUNCH(wb_k_geom_offsets, 1, WB_LIST_THREADS, ga);
+    WB_LAUNCH(wb_k_geom_fill, n < 4096 ? (n > 0 ? n : 1) : 4096, WB_GEOM_THREADS, ga);
+    tm.stop();
+    std::vector<int> cr((size_t)n + 1), fl((size_t)n + 1, 0);
+    std::vector<int> cv((size_t)n + 1);
+    d2h(ctx, cr.data(), ga.cnt_r, (size_t)(n + 1) * 4);
+    d2h(ctx, cv.data(), ga.cnt_v, (size_t)(n + 1) * 4);
+    if (n) d2h(ctx, fl.data(), ga.gflag, (size_t)n * 4);
+    bool flagged = false;
+    for (int64_t k = 0; k < n; ++k) flagged |= fl[(size_t)k] != 0;
+    const long long NR = cr[(size_t)n], NV = cv[(size_t)n];
+    if (flagged || NR > ga.cap_r || NV > ga.cap_v) {
+        release();
+        return wb_transform_polygons(ctx, n, poly_offset, px, py, lon, lat, nlon, index_space, o);
+    }
+    WbRingSink& g = ctx->geo;
+    g = WbRingSink();
+    g.ring_offset.resize((size_t)n + 1); g.vert_offset.resize((size_t)NR + 1); g.x.resize((size_t)NV); g.y.resize((size_t)NV);
+    d2h(ctx, g.ring_offset.data(), ga.ring_offset, (size_t)(n + 1) * 8);
+    d2h(ctx, g.vert_offset.data(), ga.vert_offset, (size_t)(NR + 1) * 8);
+    if (NV) { d2h(ctx, g.x.data(), ga.x, (size_t)NV * 8); d2h(ctx, g.y.data(), ga.y, (size_t)NV * 8); }
+    release();
+    o->n = n;
+    o->ring_offset = g.ring_offset.data();
+    o->nrings = NR;
     o->vert_offset = g.vert_offset.data();
     o->x = g.x.data();
     o->y = g.y.data();
@@ -1117,10 +1201,10 @@ static wb_ctx::Tables* make_tables(wb_batch* b) {
         clam2[x] = cos(0.5 * lonrad[x]);
     }
     std::vector<double> all;
-    all.reserve((size_t)6 * p.nlat + (size_t)3 * p.nlon);
+    all.reserve((size_t)6 * p.nlat + (size_t)4 * p.nlon);
     auto put = [&](const std::vector<double>& v) { const size_t o = all.size(); all.insert(all.end(), v.begin(), v.end()); return o; };
     t->o_lat = put(b->lat); t->o_latrad = put(latrad); t->o_sphi2 = put(sphi2); t->o_cphi2 = put(cphi2); t->o_cphi = put(cphi);
-    t->o_wlat = put(wlat); t->o_lonrad = put(lonrad); t->o_slam2 = put(slam2); t->o_clam2 = put(clam2);
+    t->o_wlat = put(wlat); t->o_lonrad = put(lonrad); t->o_slam2 = put(slam2); t->o_clam2 = put(clam2); t->o_lonval = put(b->lon);
     t->base = (double*)dmalloc(ctx, all.size() * sizeof(double));
     {
         // on[k] of the streamer index (streamer_index.py:130-133) is the distance between two consecutive contour points, i.e.
@@ -1230,6 +1314,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     b->poly_n = b->poly_bytes = 0;
     for (auto& hb : b->hres) hfree(ctx, hb.first, hb.second);
     b->hres.clear();
+    for (auto& hb : b->gres) hfree(ctx, hb.first, hb.second);
+    b->gres.clear();
+    b->g_rings = -1;
+    long long cap_gv = std::min<long long>(cap_poly + cap_poly / 8 + 1024, std::max<long long>(ctx->geom_seen + ctx->geom_seen / 4 + 4096, 1LL << 21));
+    long long cap_gr = (long long)cap_ne + cap_ne / 4 + 1024;
 
     WbCtl fin;
     memset(&fin, 0, sizeof(fin));
@@ -1243,7 +1332,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.truncate(b->timer_phase1);
         WbCtl* ctl = b->d_ctl;
         // the phase-2 part of the control block starts from zero (phase-1 values stay): cleared by wb_k_select_count's first workgroup
-#if defined(WB_STAMPS) && (WB_STAMPS == 4 || WB_STAMPS == 6 || WB_STAMPS == 7)              // (the stamps of a phase-1 kernel survive into the snapshot)
+#if defined(WB_STAMPS) && (WB_STAMPS == 4 || WB_STAMPS == 6 || WB_STAMPS == 7 || WB_STAMPS == 8)              // (the stamps of a phase-1 kernel survive into the snapshot)
         const size_t zero_bytes = offsetof(WbCtl, dbg) - offsetof(WbCtl, nsel);
 #else
         const size_t zero_bytes = sizeof(WbCtl) - offsetof(WbCtl, nsel);
@@ -1480,14 +1569,43 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             d_py = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
             if (!d_py) { release(); return 1; }
         }
+        // transform_polygons (index_utils.py:129-184) beside them: rings in lon / lat, cut at the last meridian, into pinned host
+        // arrays (wb_geom.h; count -> offsets -> fill)
+        WbGeomArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        const bool do_geom = ctx->geometry != 0;
+        if (do_geom) {
+            if (cap_gr < (long long)cap_ne + 16) cap_gr = (long long)cap_ne + cap_ne / 4 + 1024;
+            ga.nev = -1; ga.ctl = ctl; ga.ctl_out = ctl; ga.cap_seg = cap; ga.nlon = p.nlon; ga.index_space = 0;
+            ga.ev = fa.ev; ga.poff = fa.poff; ga.c_off = b->c_off; ga.cpts = b->cpts;
+            ga.lon = T->base + T->o_lonval; ga.lat = T->base + T->o_lat;
+            ga.cnt_r = (int*)talloc((size_t)(cap_ne + 2) * sizeof(int)); ga.cnt_v = (int*)talloc((size_t)(cap_ne + 2) * sizeof(int));
+            ga.gflag = (int*)talloc((size_t)(cap_ne + 2) * sizeof(int));
+            ga.cap_r = cap_gr; ga.cap_v = cap_gv;
+            size_t gg = 0;
+            auto gbuf = [&](size_t bytes) -> void* { void* q = hmalloc(ctx, bytes ? bytes : 8, &gg); if (q) b->gres.push_back({q, gg}); return q; };
+            ga.ring_offset = (long long*)gbuf((size_t)(cap_ne + 2) * sizeof(long long));
+            ga.vert_offset = (long long*)gbuf((size_t)(cap_gr + 2) * sizeof(long long));
+            ga.x = (double*)gbuf((size_t)(cap_gv + 2) * sizeof(double));
+            ga.y = (double*)gbuf((size_t)(cap_gv + 2) * sizeof(double));
+            if (!ga.gflag || !ga.cnt_v || !ga.y || !ga.x || !ga.vert_offset || !ga.ring_offset) { release(); return wb_fail(ctx, "out of memory (event geometry)"); }
+        }
         side_begin(ctx);
         b->timer.begin(ctx, "polygons");
         WB_LAUNCH(wb_k_pack_polys, ctx->polys_grid, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, b->poly_x, b->poly_y, d_px, d_py);
         b->timer.end(ctx);
+        if (do_geom) {
+            b->timer.begin(ctx, "geometry");
+            WB_LAUNCH(wb_k_geom_count, ctx->polys_grid, WB_GEOM_THREADS, ga);
+            WB_LAUNCH(wb_k_geom_offsets, 1, WB_LIST_THREADS, ga);
+            WB_LAUNCH(wb_k_geom_fill, ctx->polys_grid, WB_GEOM_THREADS, ga);
+            b->timer.end(ctx);
+        }
         side_end(ctx);
         b->timer.begin(ctx, "props");
         WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
         b->timer.end(ctx);
+        side_join(ctx);                                        // (the control block carries the geometry's totals)
         b->timer.begin(ctx, "results");
         WB_LAUNCH(wb_k_pack_results, cap_ne < 64 * 256 ? (cap_ne + 255) / 256 + 1 : 64, 256, ctl, fa.ev, fa.poff, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
                   pa.ev_cell_off, rb);
@@ -1509,6 +1627,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         if (do_st && fin.n_recheck > 65536) { p2_off = true; again = true; }    // more guard-band pairs than the recheck list holds: tiled kernel
         if (fin.overflow & 1) { cap_ne = next_pow2((long long)fin.ne_demand + fin.ne_demand / 4); again = true; }
         if (fin.overflow & 2) { cap_poly = fin.poly_total + fin.poly_total / 8 + 1024; again = true; }
+        if (do_geom && (fin.overflow & 4)) { cap_gv = (long long)fin.geom_verts + fin.geom_verts / 8 + 1024; cap_gr = (long long)fin.geom_rings + fin.geom_rings / 8 + 1024; again = true; }
         const bool other = again;
         if (p.want_cells && !again && fin.cell_count > cell_cap) { cell_cap = fin.cell_count + 1024; again = true; }   // cell pool too small: again with the exact size
         if (again) {
@@ -1517,6 +1636,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->poly_x = b->poly_y = nullptr;
             for (auto& hb : b->hres) hfree(ctx, hb.first, hb.second);
             b->hres.clear();
+            for (auto& hb : b->gres) hfree(ctx, hb.first, hb.second);
+            b->gres.clear();
             if (ctx->keep_device && b->dev_rows) { bfree_one(b, b->dev_rows); b->dev_rows = nullptr; }
             release();
             if (attempt == 5) return wb_fail(ctx, "capacity overflow in the index phase");
@@ -1526,6 +1647,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const int NE = fin.NE;
         const long long NV = fin.poly_total;
         b->poly_n = (size_t)NV;
+        if (do_geom && fin.geom_flagged == 0) {
+            b->g_ring_offset = ga.ring_offset; b->g_vert_offset = ga.vert_offset; b->g_x = ga.x; b->g_y = ga.y;
+            b->g_rings = fin.geom_rings; b->g_verts = fin.geom_verts;
+            if (fin.geom_verts > ctx->geom_seen) ctx->geom_seen = fin.geom_verts;
+        }
         h_ev = rb.ev; h_poff = rb.poff; h_sums = rb.sums; h_nc = rb.ncells; h_fl = rb.flags; h_coff = rb.cell_off;
         if (ctx->keep_device) {
             b->dev_px = d_px; b->dev_py = d_py;
@@ -1897,6 +2023,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "persist_slack")) { ctx->persist_slack = value > 0 ? (int)value : 0; return 0; }
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_fused")) { ctx->trace_fused = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "geometry")) { ctx->geometry = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }

@@ -109,11 +109,12 @@ struct WbCtl {
     int n_boxq, boxq_cursor;     // overturning boxes queued for wb_k_box_com (wb_k_overturn) / the next one its persistent workgroups take
     int p2_cursor;               // next (contour, part) item of wb_k_streamer_pairs2's persistent workgroups
     int f1_cursor;               // next contour (in wb_k_pairs_order's order) of wb_k_streamer_f1's persistent workgroups
-    int pad3;
+    int geom_rings, geom_verts;  // transform_polygons on the device (wb_geom.h): rings and vertices of the pass's events in lon / lat
+    int geom_flagged;            // events with more cut edges than its kernel holds (the host function does the pass's geometry then)
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.
-// -DWB_STAMPS=1 instruments wb_k_streamer_f234 (WB_STAMP), =2 wb_k_streamer_pairs (WB_PSTAMP), =3 wb_k_props (WB_RSTAMP), =4 wb_k_trace_finish (WB_TSTAMP), =5 wb_k_box_com (WB_BSTAMP), =6 wb_k_trace_link (WB_LSTAMP), =7 wb_k_trace_rank (WB_KSTAMP); WB_DEBUG_STAMPS=1 prints.
+// -DWB_STAMPS=1 instruments wb_k_streamer_f234 (WB_STAMP), =2 wb_k_streamer_pairs (WB_PSTAMP), =3 wb_k_props (WB_RSTAMP), =4 wb_k_trace_finish (WB_TSTAMP), =5 wb_k_box_com (WB_BSTAMP), =6 wb_k_trace_link (WB_LSTAMP), =7 wb_k_trace_rank (WB_KSTAMP), =8 wb_k_trace_fused (WB_FSTAMP); WB_DEBUG_STAMPS=1 prints.
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS)
 // sums kept in registers of thread 0, one global atomic per phase and workgroup at the end (..._FLUSH)
 #define WB_STAMPX_BEGIN long long wb_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
@@ -178,6 +179,15 @@ struct WbCtl {
 #define WB_BSTAMP_BEGIN
 #define WB_BSTAMP(ctl, k) ((void)0)
 #define WB_BSTAMP_FLUSH(ctl) ((void)0)
+#endif
+#if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 8
+#define WB_FSTAMP_BEGIN WB_STAMPX_BEGIN
+#define WB_FSTAMP(ctl, k) WB_STAMPX(ctl, k)
+#define WB_FSTAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
+#else
+#define WB_FSTAMP_BEGIN
+#define WB_FSTAMP(ctl, k) ((void)0)
+#define WB_FSTAMP_FLUSH(ctl) ((void)0)
 #endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 2
 #define WB_PSTAMP_BEGIN WB_STAMPX_BEGIN

@@ -46,6 +46,8 @@ struct wb_ctx {
     int cu_first = 0, cu_count = 0;           // option "cu_mask": the context's main and side streams own the compute units [cu_first, cu_first + cu_count) only (0: the whole device)
     int scan_cu_first = 0, scan_cu_count = 0; // option "scan_cu_mask": ... and the field scan's stream those
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
+    int geometry = 1;                         // 1: wb_indices also leaves the events' polygons in lon / lat (transform_polygons, index_utils.py:129-184) in pinned host memory, cut and mapped by the device (wb_geom.h); 0: wb_get_event_geometry computes them on the host when asked
+    long long geom_seen = 0;                  // vertices of the largest pass's geometry so far (sizes the pinned arrays)
     int trace_fused = 1;                      // 1: the contours of a job by ONE kernel with the job resident in LDS (wb_trace_fused.h); 0: link -> rank -> finish (wb_trace.h), which also take the jobs the fused kernel declines
     int trace_nmax = 0, trace_cmax = 256;     // fused kernel: segments / chains per job its LDS admits (trace_nmax 0: from the grid's width, then from the largest job the context has seen)
     int fused_seen = 0, fused_seen_W = 0;     // largest segment count of a job in the context's batches so far on the grid of that width
@@ -91,7 +93,7 @@ struct wb_ctx {
         std::vector<double> lat, lon;
         double dlon = 0, dlat = 0, geo_dis = 0;
         double* base = nullptr;
-        size_t o_lat = 0, o_latrad = 0, o_sphi2 = 0, o_cphi2 = 0, o_cphi = 0, o_wlat = 0, o_lonrad = 0, o_slam2 = 0, o_clam2 = 0;
+        size_t o_lat = 0, o_latrad = 0, o_sphi2 = 0, o_cphi2 = 0, o_cphi = 0, o_wlat = 0, o_lonrad = 0, o_slam2 = 0, o_clam2 = 0, o_lonval = 0;
         int* dxlim = nullptr;
         double* on_tab = nullptr;             // [nlat][nlon][4] distance (km) of a grid point to its E, N, NE, NW neighbour: sklearn's
                                               // haversine evaluated with the HOST's math library (wb_k_streamer_prep)

@@ -37,9 +37,10 @@
 #define WB_F_SPLITTER 0x4000u
 #define WB_F_NONE 0xFFFFu
 #define WB_F_NCAND 128
+#define WB_F_WALK 32                 // a walk hands over to a new splitter after this many segments (the longest walk sets the phase's duration)
 
 // LDS layout (bytes) for a launch that admits jobs of up to nmax segments, smax splitters, cmax chains
-#define WB_F_XSHIFT 2                // a bucket holds the raw points of 1 << WB_F_XSHIFT neighbouring meridians (x mod nlon)
+#define WB_F_XSHIFT 0                // a bucket holds the raw points of 1 << WB_F_XSHIFT neighbouring meridians (x mod nlon)
 struct WbFusedLayout {
     // region A: keys (link) -> owner / local position (ranking) -> raw points, packed contour | y | x
     // region B: links + flags (link, ranking) -> destination of a segment's point -> bucket order
@@ -104,6 +105,14 @@ WB_DEV inline void wb_f_locate(const int* sbase, int g, int* s, int* i) {
     while (g >= sbase[q + 1]) ++q;
     *s = q;
     *i = g - sbase[q];
+}
+// ... with the list of the thread's previous element as the starting guess (a thread's elements ascend: amortised O(1))
+WB_DEV inline int wb_f_locate_run(const int* sbase, int g, int* srun) {
+    int q = *srun;
+    while (g < sbase[q]) --q;
+    while (g >= sbase[q + 1]) ++q;
+    *srun = q;
+    return g - sbase[q];
 }
 // first entry of K[lo, hi) whose square is >= target
 WB_DEV inline int wb_f_lower(const uint32_t* K, int lo, int hi, int target) {
@@ -215,20 +224,25 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     const double level = a.levels[job % a.nlev];
     const int NSB = fa.nwork;
 
+    WB_FSTAMP_BEGIN                              // development stamps: 0 keys, 1 link, 2 splitters + first walk, 3 loops' walk + splitter links, 4 splitter ranking + chains, 5 key pass + loops, 6 numbering + destinations, 7 crossing points, 8 buckets, 9 dedupe + compaction, 10 per-contour counts, 11 duplicate rule + table
     // ---- A: keys to LDS
+    int srun = 0;                                               // (wb_f_locate_run: the list of this thread's previous element)
     WB_PFOR(g, n)
-        int s, i;
-        wb_f_locate(sbase, (int)g, &s, &i);
-        K[g] = a.stg_k[((size_t)job * NS + s) * a.cap_strip + i];
+        const int i = wb_f_locate_run(sbase, (int)g, &srun);
+        K[g] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
     WB_END_PFOR
     WB_PFOR(w, (n + 31) / 32 + 1)
         hp[w] = 0u;
     WB_END_PFOR
 
+    WB_FSTAMP(a.ctl, 0);
     // ---- B: successor of every segment = the segment of the neighbouring square that starts on the edge this one ends on
+    const float invW = 1.0f / (float)W;
     WB_PFOR(g, n)
         const uint32_t k = K[g];
-        const int sq = wb_key_sq(k), r = sq / W, c = sq - r * W, cs = wb_key_case(k), sub = wb_key_sub(k);
+        const int sq = wb_key_sq(k), cs = wb_key_case(k), sub = wb_key_sub(k);
+        int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;     // sq / W without the integer division (sq < 2^24: exact in float up to the fix-up)
+        if (c < 0) { --r; c += W; } else if (c >= W) { ++r; c -= W; }
         const int ts = wb_seg_to(cs, sub);
         int rr = r, cc = c;
         if (ts == WB_TOP) rr = r - 1;
@@ -251,18 +265,39 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
                     const int q = (int)g - sub - 1;
                     if (q >= lo && wb_key_sq(K[q]) == target) f = q - wb_key_sub(K[q]);
                 } else if (same && ts == WB_BOTTOM) {
-                    // further down the same list: gallop from behind this square, then search the bracket
-                    int b0 = (int)g - sub + wb_case_nseg(cs), step = 4;
-                    while (b0 + step < hi && wb_key_sq(K[b0 + step]) < target) { b0 += step; step <<= 1; }
-                    const int b1 = b0 + step + 1 < hi ? b0 + step + 1 : hi;
-                    const int q = wb_f_lower(K, b0, b1, target);
-                    if (q < hi && wb_key_sq(K[q]) == target) f = q;
+                    // further down the same list, past the few entries between the two rows: the next four entries are
+                    // requested together (independent LDS reads); beyond them gallop, then search the bracket
+                    const int b = (int)g - sub + wb_case_nseg(cs);
+                    const int s0 = b < hi ? wb_key_sq(K[b]) : 0x7FFFFFFF, s1 = b + 1 < hi ? wb_key_sq(K[b + 1]) : 0x7FFFFFFF;
+                    const int s2 = b + 2 < hi ? wb_key_sq(K[b + 2]) : 0x7FFFFFFF, s3 = b + 3 < hi ? wb_key_sq(K[b + 3]) : 0x7FFFFFFF;
+                    if (s0 >= target) { if (s0 == target) f = b; }
+                    else if (s1 >= target) { if (s1 == target) f = b + 1; }
+                    else if (s2 >= target) { if (s2 == target) f = b + 2; }
+                    else if (s3 >= target) { if (s3 == target) f = b + 3; }
+                    else {
+                        int b0 = b + 3, step = 4;
+                        while (b0 + step < hi && wb_key_sq(K[b0 + step]) < target) { b0 += step; step <<= 1; }
+                        const int b1 = b0 + step + 1 < hi ? b0 + step + 1 : hi;
+                        const int q = wb_f_lower(K, b0, b1, target);
+                        if (q < hi && wb_key_sq(K[q]) == target) f = q;
+                    }
                 } else if (same && ts == WB_TOP) {
-                    int b1 = (int)g - sub, step = 4;            // entries [lo, b1) lie before this square
-                    while (b1 - step > lo && wb_key_sq(K[b1 - step]) > target) { b1 -= step; step <<= 1; }
-                    const int b0 = b1 - step - 1 > lo ? b1 - step - 1 : lo;
-                    const int q = wb_f_lower(K, b0, b1, target);
-                    if (q < b1 && wb_key_sq(K[q]) == target) f = q;
+                    const int b = (int)g - sub - 1;               // entries [lo, b] lie before this square
+                    const int s0 = b >= lo ? wb_key_sq(K[b]) : -1, s1 = b - 1 >= lo ? wb_key_sq(K[b - 1]) : -1;
+                    const int s2 = b - 2 >= lo ? wb_key_sq(K[b - 2]) : -1, s3 = b - 3 >= lo ? wb_key_sq(K[b - 3]) : -1;
+                    int hit = -1;                                 // some entry of the target square (a saddle has two)
+                    if (s0 <= target) { if (s0 == target) hit = b; }
+                    else if (s1 <= target) { if (s1 == target) hit = b - 1; }
+                    else if (s2 <= target) { if (s2 == target) hit = b - 2; }
+                    else if (s3 <= target) { if (s3 == target) hit = b - 3; }
+                    else {
+                        int b1 = b - 3, step = 4;                  // entries [lo, b1) may hold it
+                        while (b1 - step > lo && wb_key_sq(K[b1 - step]) > target) { b1 -= step; step <<= 1; }
+                        const int b0 = b1 - step - 1 > lo ? b1 - step - 1 : lo;
+                        const int q = wb_f_lower(K, b0, b1, target);
+                        if (q < b1 && wb_key_sq(K[q]) == target) hit = q;
+                    }
+                    if (hit >= 0) f = hit - wb_key_sub(K[hit]);
                 } else {
                     const int q = wb_f_lower(K, lo, hi, target);
                     if (q < hi && wb_key_sq(K[q]) == target) f = q;
@@ -278,6 +313,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
     WB_END_PFOR
 
+    WB_FSTAMP(a.ctl, 1);
     // ---- C: list ranking.  C1: heads, splitters, their ordinals
     int* const tmp = (int*)K;                                  // (the keys are done with: read again from the lists where needed)
     WB_PFOR(g, n)
@@ -294,8 +330,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_PFOR(g, n)
         own[g] = (uint16_t)WB_F_NONE;
     WB_END_PFOR
-    // C2: a thread walks from its splitter to the next one (no two walks meet: successors are one-to-one)
-    auto walk = [&](const int o) {
+    // C2: a thread walks from its splitter to the next one (no two walks meet: successors are one-to-one).  The longest walk
+    // sets the phase's duration: after WB_F_WALK segments the walk makes the next segment a splitter of its own and goes on as
+    // that one.
+    WB_SINGLE
+    ctr[1] = S1;
+    WB_END_SINGLE
+    auto walk = [&](int o) {
         int j = (int)ndseg[o], cntw = 0;
         uint32_t end = WB_F_NIL;
         for (;;) {
@@ -306,6 +347,15 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             if (nx == WB_F_NIL) break;
             if (S[nx] & WB_F_SPLITTER) { end = nx; break; }
             j = (int)nx;
+            if (cntw == WB_F_WALK) {
+                const int o2 = wb_atomic_add(&ctr[1], 1);
+                if (o2 >= fa.smax) { ctr[0] = 1; end = nx; break; }
+                nlen[o] = (uint16_t)cntw;
+                ndend[o] = (uint16_t)nx;
+                o = o2;
+                ndseg[o] = (uint16_t)nx;
+                cntw = 0;
+            }
         }
         nlen[o] = (uint16_t)cntw;
         ndend[o] = (uint16_t)end;
@@ -319,9 +369,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         wb_f_locate(sbase, g, &s, &i);
         return a.stg_k[((size_t)job * NS + s) * a.cap_strip + i] & 0x07FFFFFFu;
     };
-    WB_SINGLE
-    ctr[1] = S1;
-    WB_END_SINGLE
+    const int S2 = ctr[1];
+    if (ctr[0] || S2 > fa.smax) WB_F_DECLINE();
     WB_PFOR(g, n)
         bool want = false;
         if (own[g] == (uint16_t)WB_F_NONE) {
@@ -331,14 +380,16 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         const int slot = wb_append_slot(&ctr[1], want);
         if (want && slot < fa.smax) ndseg[slot] = (uint16_t)g;
     WB_END_PFOR
+    const int S3 = ctr[1];
+    if (S3 > fa.smax) WB_F_DECLINE();
+    WB_PFOR(o, S3 - S2)
+        S[ndseg[S2 + o]] |= (uint16_t)WB_F_SPLITTER;
+    WB_END_PFOR
+    WB_PFOR(o, S3 - S2)
+        walk(S2 + (int)o);
+    WB_END_PFOR
     const int NSP = ctr[1];
-    if (NSP > fa.smax) WB_F_DECLINE();
-    WB_PFOR(o, NSP - S1)
-        S[ndseg[S1 + o]] |= (uint16_t)WB_F_SPLITTER;
-    WB_END_PFOR
-    WB_PFOR(o, NSP - S1)
-        walk(S1 + (int)o);
-    WB_END_PFOR
+    if (ctr[0] || NSP > fa.smax) WB_F_DECLINE();
     // C4: the splitters' own list: next splitter, previous splitter
     const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
     WB_PFOR(o, NSP)
@@ -349,6 +400,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_PFOR(o, NSP)
         if (nnext[o] != NN) ncp[nnext[o]] = (uint16_t)o;
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 3);
     // C5: pointer jumping over the splitters along the PREVIOUS links.  One 64-bit word per node:
     // bits 0..15 J (jump pointer), 16..31 D (segments in front of the node), 32..47 H (first node of the chain), 48..63 M (smallest ordinal seen: names a loop)
 #define WB_FQ(j, d, h, m) ((unsigned long long)(uint16_t)(j) | (unsigned long long)(uint16_t)(d) << 16 | (unsigned long long)(uint16_t)(h) << 32 | (unsigned long long)(uint16_t)(m) << 48)
@@ -399,9 +451,11 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_PFOR(o, NSP)
         cix[o] = (int)nnext[o];
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 4);
     // keys again (coalesced, from the lists): every chain's smallest key (it numbers the contours), every loop's largest
     WB_PFOR(g, n)
-        const uint32_t key = key_of((int)g);
+        const int i = wb_f_locate_run(sbase, (int)g, &srun);
+        const uint32_t key = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i] & 0x07FFFFFFu;
         const int ch = cix[own[g]];
         wb_atomic_min(&cmin[ch], key);
         if (cloop[ch]) wb_atomic_max(&cmaxk[ch], key);
@@ -411,7 +465,10 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         // front of the node that holds it and rank again; the segments' positions are rotated below.
         WB_PFOR(g, n)
             const int ch = cix[own[g]];
-            if (cloop[ch] && key_of((int)g) == cmaxk[ch]) { lnode[ch] = own[g]; lpos[ch] = lp[g]; }
+            if (cloop[ch]) {
+                const int i = wb_f_locate_run(sbase, (int)g, &srun);
+                if ((a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = own[g]; lpos[ch] = lp[g]; }
+            }
         WB_END_PFOR
         WB_PFOR(ch, C)
             if (cloop[ch]) ncp[lnode[ch]] = NN;
@@ -422,6 +479,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_PFOR(o, NSP)
         wb_atomic_max(&ctot[cix[o]], (int)(uint16_t)(Q[o] >> 16) + (int)nlen[o]);
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 5);
     // ---- D: contours in the order of their raster-first segments (contour_index.py:103: find_contours' list order)
     WB_PFOR(ch, C)
         const uint32_t mine = cmin[ch];
@@ -459,6 +517,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         }
         blk[b] = (uint16_t)lo;
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 6);
     // ---- E: the crossing points, rounded half-to-even (contour_index.py:111), straight to their places in contour order.
     // Region A becomes the raw points (own / lp are done with).
     auto pack = [&](const int p, const uint32_t pt) -> uint32_t {
@@ -467,9 +526,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         return ((uint32_t)c << sh) | ((uint32_t)wb_pt_y(pt) << xb) | (uint32_t)wb_pt_x(pt);
     };
     WB_PFOR(g, n)
-        int s, i;
-        wb_f_locate(sbase, (int)g, &s, &i);
-        const size_t e = ((size_t)job * NS + s) * a.cap_strip + (size_t)i;
+        const int i = wb_f_locate_run(sbase, (int)g, &srun);
+        const size_t e = ((size_t)job * NS + srun) * a.cap_strip + (size_t)i;
         const uint32_t key = a.stg_k[e];
         double ul, ur, ll, lr;
         if (a.dtype == 0) { const float* v = (const float*)a.stg_v + e * 4; ul = (double)v[0]; ur = (double)v[1]; ll = (double)v[2]; lr = (double)v[3]; }
@@ -484,6 +542,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     if (ctr[0]) WB_F_DECLINE();
 
+    WB_FSTAMP(a.ctl, 7);
     // ---- F: buckets of the raw points by x mod nlon (1 << WB_F_XSHIFT meridians each).  A point equal to its predecessor in
     // the same contour can never be a first occurrence (about half of all raw points: neighbouring crossings that round to the
     // same lattice point): it stays out.
@@ -498,7 +557,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_PFOR(c, C + 1)
         newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0;
     WB_END_PFOR
-#define WB_F_BUCKET(pw) ((int)(((pw) & xmask) % (uint32_t)nlon) >> WB_F_XSHIFT)
+#define WB_F_XM(pw) (((pw) & xmask) >= (uint32_t)nlon ? ((pw) & xmask) - (uint32_t)nlon : ((pw) & xmask))   /* x mod nlon: x < W <= 2 nlon */
+#define WB_F_BUCKET(pw) ((int)WB_F_XM(pw) >> WB_F_XSHIFT)
     WB_PFOR(p, R)
         const uint32_t pw = rawpt[p];
         const bool dup = p > 0 && pw == rawpt[p > 0 ? p - 1 : 0];        // (equal words: the same contour and the same lattice point)
@@ -512,6 +572,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             order[e] = (uint16_t)p;
         }
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 8);
     // first-occurrence dedupe (contour_index.py:110-112: dict.fromkeys over the contour's points)
     WB_PFOR(e, U)
         const int p = (int)order[e];
@@ -557,18 +618,19 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_PFOR(c, C)
         if (fin[c]) ckept[kid[c]] = (uint16_t)c;
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 9);
     // ---- G: per kept contour: distinct x (-> exp_lon, :154), sum of y (-> mean_lat, :155), distinct (x mod nlon, y)
     WB_PFOR(e, U)
         const int p = (int)order[e];
         const uint32_t pw = rawpt[p];
         const int c = (int)(pw >> sh);
         if (fin[c]) {
-            const uint32_t x = pw & xmask, xm = x % (uint32_t)nlon, cy = pw >> xb;     // cy: contour and y
+            const uint32_t x = pw & xmask, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
             const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0;
             bool firstx = true, firsty = true;
             for (int e2 = b0; e2 < (int)e; ++e2) {              // the entries in front of this one in its bucket
                 const uint32_t pw2 = rawpt[order[e2]];
-                if ((pw2 >> xb) == cy && (pw2 & xmask) % (uint32_t)nlon == xm) firsty = false;
+                if ((pw2 >> xb) == cy && WB_F_XM(pw2) == xm) firsty = false;
                 if ((pw2 >> sh) == (uint32_t)c && (pw2 & xmask) == x) firstx = false;
             }
             const int f = kid[c];
@@ -577,15 +639,16 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             if ((keepb[p >> 5] >> (p & 31)) & 1u) wb_atomic_add(&sumyl[f], (int)((pw >> xb) & ymask));
         }
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 10);
     // ---- periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1, i2) with set(i1) a subset of set(i2)
     // (points taken x mod nlon): equal array lengths -> drop max(i1, i2), else drop the shorter.  Almost every pair fails on the
     // first point of i1; the few that pass it are queued and checked by the whole workgroup.
     auto in_set = [&](const uint32_t pw, const int c2) -> bool {
-        const uint32_t xm = (pw & xmask) % (uint32_t)nlon, cy = ((uint32_t)c2 << yb) | ((pw >> xb) & ymask);
+        const uint32_t xm = WB_F_XM(pw), cy = ((uint32_t)c2 << yb) | ((pw >> xb) & ymask);
         const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
         for (int e2 = b0; e2 < b1; ++e2) {
             const uint32_t pw2 = rawpt[order[e2]];
-            if ((pw2 >> xb) == cy && (pw2 & xmask) % (uint32_t)nlon == xm) return true;
+            if ((pw2 >> xb) == cy && WB_F_XM(pw2) == xm) return true;
         }
         return false;
     };
@@ -643,6 +706,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             wb_atomic_max(&a.ctl->max_nux, nuxl[f]);
         }
     WB_END_PFOR
+    WB_FSTAMP(a.ctl, 11);
+    WB_FSTAMP_FLUSH(a.ctl);
     WB_SINGLE
     a.ncont[job] = Cf;
     a.nseg[job] = n;
@@ -651,4 +716,5 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
 #undef WB_F_DECLINE
 #undef WB_FQ
 #undef WB_F_BUCKET
+#undef WB_F_XM
 }
