@@ -627,3 +627,51 @@ def test_first_call_uploads_in_blocks_while_it_computes(hostsim_engine, monkeypa
     s3 = wb.calculate_streamers(data=data, contour_levels=[-2, 2], intensity=inten)
     assert list(s3["com"]) == list(s1["com"])
     wb.release_inputs()
+
+
+def test_a_call_that_raises_on_a_stale_device_copy_is_run_again_from_the_fresh_bytes(hostsim_engine, golden_dir):
+    """a cube on which find_contours raises KeyError (two contour ends on one grid vertex) is edited in place so that no cell
+    equals the level any more: the next call on the SAME array used the old device copy on trust, raised the old copy's
+    KeyError and never compared the fingerprints (the advisor's finding of round 4).  Now the failing call checks them, drops
+    the stale copy and runs once more -- the reference rereads its input on every call and succeeds"""
+    g = np.load(golden_dir + "/contours_levelhit.npz")
+    name = [n for n in g["names"] if int(g[n + "__raises"])][0]
+    a = np.ascontiguousarray(np.repeat(g[name + "__field"].astype(np.float64)[None], 3, axis=0))     # 3 steps: a cacheable cube
+    level = float(g[name + "__level"])
+    tm = synth.times(3, start="1959-06-01T00")
+    f = wb.GridField(a, ("time", "lat", "lon"), {"time": tm, "lat": np.arange(a.shape[1], dtype=float), "lon": np.arange(a.shape[2], dtype=float)})
+    with pytest.raises(KeyError):
+        wb.calculate_contours(f, level, periodic_add=0, original_coordinates=False)
+    with pytest.raises(KeyError):                                  # (the copy is resident now: this call goes on with it on trust)
+        wb.calculate_contours(f, level, periodic_add=0, original_coordinates=False)
+    a[a == level] += 0.25                                          # edited in place: no cell equals the level any more
+    got = wb.calculate_contours(f, level, periodic_add=0, original_coordinates=False)
+    fresh = wb.GridField(a.copy(), f.dims, f.coords)
+    want = wb.calculate_contours(fresh, level, periodic_add=0, original_coordinates=False)
+    assert len(got) == len(want) and len(got) > 0 and not engine._pending_by_head
+    # an exception on an UNCHANGED cube stands (no second run hides it)
+    b = np.ascontiguousarray(np.repeat(g[name + "__field"].astype(np.float64)[None], 3, axis=0))
+    fb = wb.GridField(b, f.dims, f.coords)
+    for _ in range(3):
+        with pytest.raises(KeyError):
+            wb.calculate_cutoffs(fb, level, periodic_add=0)
+
+
+def test_a_read_only_view_of_a_writeable_array_is_fingerprinted_in_full(hostsim_engine):
+    """``v = a.view(); v.flags.writeable = False``: the view cannot be written, its base can -- a 9 x 9 patch edited through the
+    base between two calls, away from every strided sample, must be seen (until round 5 `not arr.flags.writeable` alone chose
+    the address + sample key and the second call returned the cached cube's events)"""
+    data, pv, lat, lon, tm = _field(nt=12)
+    base = np.ascontiguousarray(data.values)
+    view = base.view()
+    view.flags.writeable = False
+    assert not engine._immutable(view) and engine._immutable(np.frombuffer(base.tobytes(), dtype=base.dtype))
+    fv = wb.GridField(view, data.dims, data.coords)
+    c1 = wb.calculate_cutoffs(data=fv, contour_levels=[2])
+    j = int(np.argmin(np.abs(lat - 70.0)))
+    assert (base[5, j - 4:j + 5, 101:110] > 2).all()
+    base[5, j - 4:j + 5, 101:110] = 0.5                             # through the base: a new cutoff at step 5
+    c2 = wb.calculate_cutoffs(data=fv, contour_levels=[2])
+    fresh = wb.GridField(base.copy(), data.dims, data.coords)
+    c3 = wb.calculate_cutoffs(data=fresh, contour_levels=[2])
+    assert len(c2) == len(c3) == len(c1) + 1

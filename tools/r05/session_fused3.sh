@@ -3,12 +3,12 @@
 # workgroup sizes, geometry with zero-copy views
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r05
-OUT=gpurun_out/r05/fused3.txt
+OUT=gpurun_out/r05/fused4.txt
 : > $OUT
 echo "== stamps (ms of workgroup time per launch)" | tee -a $OUT
 WB_HIP_LIBRARY=$PWD/build/ab/libwb_stamps8.so WB_DEBUG_STAMPS=1 timeout 300 python bench.py --steps 2 --warmup 0 --cpu-sample 0 --e2e-steps 0 --streams 1 --stagger-steps 0 2>&1 | grep -E "stamps" | tail -1 | tee -a $OUT
 echo "== gpu tests" | tee -a $OUT
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "fused or geometry or full_parity or quarter" 2>&1 | tail -5 | tee -a $OUT
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "fused or geometry or full_parity or quarter or python_surface or rough" 2>&1 | tail -5 | tee -a $OUT
 run() {
   label="$1"; shift
   lib="$4"
@@ -25,9 +25,9 @@ H="0:cu_mask=128,1:cu_mask=128128"
 for rep in 1 2; do
 run "one batch 256 thr" "" 1 12
 run "one batch 512 thr" "" 1 0 libwb_f512.so
-run "one batch 128 thr" "" 1 0 libwb_f128.so
+
 run "two" "" 2 20
 run "halves" "$H" 2 20
 run "halves 512 thr" "$H" 2 0 libwb_f512.so
-run "halves 128 thr" "$H" 2 0 libwb_f128.so
+
 done

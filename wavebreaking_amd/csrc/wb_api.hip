@@ -724,7 +724,11 @@ extern "C" int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* o) {
     if (b->g_rings >= 0) {
         // cut and mapped by the device during wb_indices: this table's slice of the pass's arrays, offsets from zero
         const int64_t lo = kind == 0 ? 0 : (kind == 1 ? b->dev_n[0] : b->dev_n[0] + b->dev_n[1]);
-        const long long r0 = b->g_ring_offset[lo], r1 = b->g_ring_offset[lo + n], v0 = b->g_vert_offset[r0];
+        const long long r0 = b->g_ring_offset[lo], r1 = b->g_ring_offset[lo + n];
+        if (r0 < 0 || r1 < r0 || r1 > b->g_rings)
+            return wb_fail(b->ctx, "wb_get_event_geometry: ring offsets out of order (kind " + std::to_string(kind) + ", events " + std::to_string(lo) + " + " + std::to_string(n) +
+                           ", rings " + std::to_string(r0) + " .. " + std::to_string(r1) + " of " + std::to_string(b->g_rings) + ")");
+        const long long v0 = b->g_vert_offset[r0];
         g.ring_offset.resize((size_t)n + 1);
         for (int64_t k = 0; k <= n; ++k) g.ring_offset[(size_t)k] = b->g_ring_offset[lo + k] - r0;
         g.vert_offset.resize((size_t)(r1 - r0) + 1);
@@ -1682,6 +1686,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     for (int q = 0; q < 3; ++q) b->com_rechecks[q] = fin.com_rechecks[q];
     b->group_ties = fin.group_ties;
     const int NS = fin.NS, NO = fin.NO, NE = fin.NE;
+    if (NS < 0 || NO < 0 || NE < NS + NO)
+        return wb_fail(ctx, "wb_indices: inconsistent event counts in the control block (NS " + std::to_string(NS) + ", NO " + std::to_string(NO) + ", NE " + std::to_string(NE) + ")");
     b->dev_n[0] = NS; b->dev_n[1] = NO; b->dev_n[2] = NE - NS - NO;
 
     // ---- host tables (sized once, filled with plain loops)

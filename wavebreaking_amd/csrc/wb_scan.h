@@ -489,7 +489,9 @@ __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* 
         }
         __syncthreads();
     }
-    return carry_s;
+    const unsigned long long total = carry_s;                // (as in wb_block_scan_excl: the total is read before the next scan may clear it)
+    __syncthreads();
+    return total;
 }
 
 template <typename T, int NLEV>

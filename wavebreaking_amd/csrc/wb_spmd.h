@@ -284,7 +284,11 @@ __device__ inline int wb_block_scan_excl(int* a, int n) {
         }
         __syncthreads();
     }
-    return wb_scan_carry;
+    // (every thread has the total before anyone may enter the next scan, whose first statement clears the carry: two scans back
+    //  to back handed some threads 0 for the first one's total -- wb_k_geom_offsets, round 5, one pass in a hundred)
+    const int total = wb_scan_carry;
+    __syncthreads();
+    return total;
 }
 
 // in-place exclusive running maximum of a[0..n): a[i] <- max(init, a[0..i-1]); all threads of the block call it.

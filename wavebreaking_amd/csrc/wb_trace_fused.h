@@ -35,7 +35,7 @@
 #define WB_F_NIL 0x1FFFu             // 13-bit links: a job of the fused path has at most 8190 segments
 #define WB_F_HEAD 0x8000u            // flags in the upper bits of a link word
 #define WB_F_SPLITTER 0x4000u
-#define WB_F_NONE 0xFFFFu
+#define WB_F_NONE 0xFFFFFFFFu
 #define WB_F_NCAND 128
 #define WB_F_WALK 32                 // a walk hands over to a new splitter after this many segments (the longest walk sets the phase's duration)
 
@@ -142,8 +142,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     const WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, nlon, WB_FUSED_THREADS);
     WB_DYN_SHARED(unsigned char, lds, L.total);
     uint32_t* const K = (uint32_t*)(lds + L.oA);               // keys; later raw points
-    uint16_t* const own = (uint16_t*)(lds + L.oA);             // (ranking) splitter ordinal that owns the segment
-    uint16_t* const lp = own + ((size_t)fa.nmax + 2);          // (ranking) position inside its sub-list, from 1
+    uint32_t* const ol = K;                                    // (ranking) splitter ordinal that owns the segment | position inside its sub-list (from 1) << 16
+#define WB_F_OWN(g) ((int)(ol[g] & 0xFFFFu))
+#define WB_F_LP(g) ((int)(ol[g] >> 16))
     uint32_t* const rawpt = K;                                 // raw points in contour order: contour << (xb + yb) | y << xb | x
     uint16_t* const S = (uint16_t*)(lds + L.oB);               // successor | flags; later: destination of the segment's point; later: bucket order
     uint16_t* const dest = S;
@@ -227,21 +228,31 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_FSTAMP_BEGIN                              // development stamps: 0 keys, 1 link, 2 splitters + first walk, 3 loops' walk + splitter links, 4 splitter ranking + chains, 5 key pass + loops, 6 numbering + destinations, 7 crossing points, 8 buckets, 9 dedupe + compaction, 10 per-contour counts, 11 duplicate rule + table
     // ---- A: keys to LDS
     int srun = 0;                                               // (wb_f_locate_run: the list of this thread's previous element)
-    WB_PFOR(g, n)
-        const int i = wb_f_locate_run(sbase, (int)g, &srun);
-        K[g] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
-    WB_END_PFOR
+    uint32_t ka[WB_PFOR_B_WIDTH];                               // (WB_PFOR_B: four elements' loads requested, then used)
+    WB_PFOR_B(g, gc, u, n)
+        const int i = wb_f_locate_run(sbase, (int)gc, &srun);
+        ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
+    WB_PFOR_B_USE(g, u)
+        K[g] = ka[u];
+    WB_END_PFOR_B
     WB_PFOR(w, (n + 31) / 32 + 1)
         hp[w] = 0u;
     WB_END_PFOR
 
     WB_FSTAMP(a.ctl, 0);
-    // ---- B: successor of every segment = the segment of the neighbouring square that starts on the edge this one ends on
+    // ---- B: successor of every segment = the segment of the neighbouring square that starts on the edge this one ends on.
+    // Every lane does the SAME thing (a wave runs the sum of its lanes' branches, and a data-dependent search loop per branch
+    // cost 40 us per job): the four entries of its own list next to the segment -- behind it when it leaves its square to the
+    // right or downwards, in front of it when to the left or upwards -- are requested together and hold the successor, or show
+    // that there is none, for nearly every segment (the entries between two rows of a strip are few).  What they leave open --
+    // the target square lies in another strip's list, or further away -- goes to a short queue that is searched afterwards.
     const float invW = 1.0f / (float)W;
-    WB_PFOR(g, n)
-        const uint32_t k = K[g];
+    uint16_t* const queue = (uint16_t*)(K + n);                 // (behind the keys: region A has room for cmax + 2 more words)
+    const int QMAX = 2 * fa.cmax;
+    // square and side a segment leads to -> the list that holds the square, or -1 (off the grid: the contour ends there)
+    auto aim = [&](const uint32_t k, int* target, int* want) -> int {
         const int sq = wb_key_sq(k), cs = wb_key_case(k), sub = wb_key_sub(k);
-        int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;     // sq / W without the integer division (sq < 2^24: exact in float up to the fix-up)
+        int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;     // sq / W without the integer division (sq < 2^24: exact up to the fix-up)
         if (c < 0) { --r; c += W; } else if (c >= W) { ++r; c -= W; }
         const int ts = wb_seg_to(cs, sub);
         int rr = r, cc = c;
@@ -249,69 +260,75 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         else if (ts == WB_RIGHT) cc = c + 1;
         else if (ts == WB_BOTTOM) rr = r + 1;
         else cc = c - 1;
-        const int want = ts ^ 2;
+        *want = ts ^ 2;
+        *target = rr * W + cc;
+        if (!(rr >= 0 && rr < nlat - 1 && cc >= 0 && cc < W - 1)) return -1;
+        const int tl = cc < nlon ? cc / WB_STRIP : NSB + (cc - nlon) / WB_STRIP;
+        return tl < NS ? tl : -1;
+    };
+    // the segment of square entry f (its first) that starts on side `want`
+    auto pick = [&](const int f, const int want) -> uint32_t {
+        const int cs2 = wb_key_case(K[f]);
+        if (wb_seg_from(cs2, 0) == want) return (uint32_t)f;
+        if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) return (uint32_t)f + 1u;
+        return WB_F_NIL;
+    };
+    int lrun = 0;
+    WB_PFOR(g, n)
+        const uint32_t k = K[g];
+        int target, want;
+        const int tl = aim(k, &target, &want);
+        (void)wb_f_locate_run(sbase, (int)g, &lrun);              // the segment's own list
+        const int lo = sbase[lrun], hi = sbase[lrun + 1];
+        const int cs = wb_key_case(k), sub = wb_key_sub(k);
+        const bool fwd = (want ^ 2) == WB_RIGHT || (want ^ 2) == WB_BOTTOM;
+        const int b = fwd ? (int)g - sub + wb_case_nseg(cs) : (int)g - sub - 1;
+        uint32_t kw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int at = fwd ? b + q : b - q;
+            kw[q] = (at >= lo && at < hi) ? K[at] : (fwd ? 0x07FFFFFFu : 0u);      // (past the list's end: beyond every target / in front of every target)
+        }
         uint32_t sc = WB_F_NIL;
-        if (rr >= 0 && rr < nlat - 1 && cc >= 0 && cc < W - 1) {
-            const int tl = cc < nlon ? cc / WB_STRIP : NSB + (cc - nlon) / WB_STRIP;      // the list that holds square (rr, cc)
-            if (tl < NS) {
-                const int lo = sbase[tl], hi = sbase[tl + 1];
-                const int target = rr * W + cc;
-                int f = -1;                                   // first entry of the target square
-                const bool same = (int)g >= lo && (int)g < hi;
-                if (same && ts == WB_RIGHT) {
-                    const int q = (int)g - sub + wb_case_nseg(cs);
-                    if (q < hi && wb_key_sq(K[q]) == target) f = q;
-                } else if (same && ts == WB_LEFT) {
-                    const int q = (int)g - sub - 1;
-                    if (q >= lo && wb_key_sq(K[q]) == target) f = q - wb_key_sub(K[q]);
-                } else if (same && ts == WB_BOTTOM) {
-                    // further down the same list, past the few entries between the two rows: the next four entries are
-                    // requested together (independent LDS reads); beyond them gallop, then search the bracket
-                    const int b = (int)g - sub + wb_case_nseg(cs);
-                    const int s0 = b < hi ? wb_key_sq(K[b]) : 0x7FFFFFFF, s1 = b + 1 < hi ? wb_key_sq(K[b + 1]) : 0x7FFFFFFF;
-                    const int s2 = b + 2 < hi ? wb_key_sq(K[b + 2]) : 0x7FFFFFFF, s3 = b + 3 < hi ? wb_key_sq(K[b + 3]) : 0x7FFFFFFF;
-                    if (s0 >= target) { if (s0 == target) f = b; }
-                    else if (s1 >= target) { if (s1 == target) f = b + 1; }
-                    else if (s2 >= target) { if (s2 == target) f = b + 2; }
-                    else if (s3 >= target) { if (s3 == target) f = b + 3; }
-                    else {
-                        int b0 = b + 3, step = 4;
-                        while (b0 + step < hi && wb_key_sq(K[b0 + step]) < target) { b0 += step; step <<= 1; }
-                        const int b1 = b0 + step + 1 < hi ? b0 + step + 1 : hi;
-                        const int q = wb_f_lower(K, b0, b1, target);
-                        if (q < hi && wb_key_sq(K[q]) == target) f = q;
-                    }
-                } else if (same && ts == WB_TOP) {
-                    const int b = (int)g - sub - 1;               // entries [lo, b] lie before this square
-                    const int s0 = b >= lo ? wb_key_sq(K[b]) : -1, s1 = b - 1 >= lo ? wb_key_sq(K[b - 1]) : -1;
-                    const int s2 = b - 2 >= lo ? wb_key_sq(K[b - 2]) : -1, s3 = b - 3 >= lo ? wb_key_sq(K[b - 3]) : -1;
-                    int hit = -1;                                 // some entry of the target square (a saddle has two)
-                    if (s0 <= target) { if (s0 == target) hit = b; }
-                    else if (s1 <= target) { if (s1 == target) hit = b - 1; }
-                    else if (s2 <= target) { if (s2 == target) hit = b - 2; }
-                    else if (s3 <= target) { if (s3 == target) hit = b - 3; }
-                    else {
-                        int b1 = b - 3, step = 4;                  // entries [lo, b1) may hold it
-                        while (b1 - step > lo && wb_key_sq(K[b1 - step]) > target) { b1 -= step; step <<= 1; }
-                        const int b0 = b1 - step - 1 > lo ? b1 - step - 1 : lo;
-                        const int q = wb_f_lower(K, b0, b1, target);
-                        if (q < b1 && wb_key_sq(K[q]) == target) hit = q;
-                    }
-                    if (hit >= 0) f = hit - wb_key_sub(K[hit]);
-                } else {
-                    const int q = wb_f_lower(K, lo, hi, target);
-                    if (q < hi && wb_key_sq(K[q]) == target) f = q;
-                }
-                if (f >= 0) {
-                    const int cs2 = wb_key_case(K[f]);
-                    if (wb_seg_from(cs2, 0) == want) sc = (uint32_t)f;
-                    else if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) sc = (uint32_t)f + 1u;
-                }
+        bool open = false;
+        if (tl == lrun) {
+            open = true;
+            int hit = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int at = fwd ? b + q : b - q;
+                const int sq2 = (at >= lo && at < hi) ? wb_key_sq(kw[q]) : (fwd ? 0x7FFFFFFF : -1);
+                if (open && (fwd ? sq2 >= target : sq2 <= target)) { open = false; if (sq2 == target) hit = at - (fwd ? 0 : wb_key_sub(kw[q])); }
+            }
+            if (hit >= 0) sc = pick(hit, want);
+        } else if (tl >= 0) open = true;                           // another strip's list
+        const int slot = wb_append_slot(&ctr[6], open);
+        if (open) {
+            if (slot < QMAX) queue[slot] = (uint16_t)g;
+            else {                                                 // (queue full: searched here)
+                const int q = wb_f_lower(K, sbase[tl], sbase[tl + 1], target);
+                if (q < sbase[tl + 1] && wb_key_sq(K[q]) == target) sc = pick(q, want);
+                open = false;
             }
         }
-        S[g] = (uint16_t)sc;
-        if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
+        if (!open) {
+            S[g] = (uint16_t)sc;
+            if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
+        }
     WB_END_PFOR
+    {
+        const int nq = ctr[6] < QMAX ? ctr[6] : QMAX;
+        WB_PFOR(qi, nq)
+            const int g = (int)queue[qi];
+            int target, want;
+            const int tl = aim(K[g], &target, &want);
+            uint32_t sc = WB_F_NIL;
+            const int q = wb_f_lower(K, sbase[tl], sbase[tl + 1], target);
+            if (q < sbase[tl + 1] && wb_key_sq(K[q]) == target) sc = pick(q, want);
+            S[g] = (uint16_t)sc;
+            if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
+        WB_END_PFOR
+    }
 
     WB_FSTAMP(a.ctl, 1);
     // ---- C: list ranking.  C1: heads, splitters, their ordinals
@@ -328,7 +345,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         if (S[g] & WB_F_SPLITTER) ndseg[tmp[g]] = (uint16_t)g;
     WB_END_PFOR
     WB_PFOR(g, n)
-        own[g] = (uint16_t)WB_F_NONE;
+        ol[g] = WB_F_NONE;
     WB_END_PFOR
     // C2: a thread walks from its splitter to the next one (no two walks meet: successors are one-to-one).  The longest walk
     // sets the phase's duration: after WB_F_WALK segments the walk makes the next segment a splitter of its own and goes on as
@@ -338,15 +355,16 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_SINGLE
     auto walk = [&](int o) {
         int j = (int)ndseg[o], cntw = 0;
-        uint32_t end = WB_F_NIL;
+        uint32_t end = WB_F_NIL, w = S[j];
         for (;;) {
             ++cntw;
-            own[j] = (uint16_t)o;
-            lp[j] = (uint16_t)cntw;
-            const uint32_t nx = S[j] & WB_F_NIL;
+            ol[j] = (uint32_t)o | ((uint32_t)cntw << 16);
+            const uint32_t nx = w & WB_F_NIL;
             if (nx == WB_F_NIL) break;
-            if (S[nx] & WB_F_SPLITTER) { end = nx; break; }
+            const uint32_t wn = S[nx];                       // (the one dependent read of a step: flags now, successor next time round)
+            if (wn & WB_F_SPLITTER) { end = nx; break; }
             j = (int)nx;
+            w = wn;
             if (cntw == WB_F_WALK) {
                 const int o2 = wb_atomic_add(&ctr[1], 1);
                 if (o2 >= fa.smax) { ctr[0] = 1; end = nx; break; }
@@ -373,7 +391,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     if (ctr[0] || S2 > fa.smax) WB_F_DECLINE();
     WB_PFOR(g, n)
         bool want = false;
-        if (own[g] == (uint16_t)WB_F_NONE) {
+        if (ol[g] == WB_F_NONE) {
             const uint32_t nx = S[g] & WB_F_NIL;
             want = nx == WB_F_NIL || key_of((int)g) > key_of((int)nx);
         }
@@ -394,7 +412,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
     WB_PFOR(o, NSP)
         const uint16_t e = ndend[o];
-        nnext[o] = e == (uint16_t)WB_F_NIL ? NN : own[e];     // (in place: ndend is nnext's storage)
+        nnext[o] = e == (uint16_t)WB_F_NIL ? NN : (uint16_t)WB_F_OWN(e);     // (in place: ndend is nnext's storage)
         ncp[o] = NN;
     WB_END_PFOR
     WB_PFOR(o, NSP)
@@ -453,23 +471,26 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 4);
     // keys again (coalesced, from the lists): every chain's smallest key (it numbers the contours), every loop's largest
-    WB_PFOR(g, n)
-        const int i = wb_f_locate_run(sbase, (int)g, &srun);
-        const uint32_t key = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i] & 0x07FFFFFFu;
-        const int ch = cix[own[g]];
+    WB_PFOR_B(g, gc, u, n)
+        const int i = wb_f_locate_run(sbase, (int)gc, &srun);
+        ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
+    WB_PFOR_B_USE(g, u)
+        const uint32_t key = ka[u] & 0x07FFFFFFu;
+        const int ch = cix[WB_F_OWN(g)];
         wb_atomic_min(&cmin[ch], key);
         if (cloop[ch]) wb_atomic_max(&cmaxk[ch], key);
-    WB_END_PFOR
+    WB_END_PFOR_B
     if (any_loop) {
         // the loop's raster-last segment: the contour starts behind it.  Cut the splitters' loop in
         // front of the node that holds it and rank again; the segments' positions are rotated below.
-        WB_PFOR(g, n)
-            const int ch = cix[own[g]];
-            if (cloop[ch]) {
-                const int i = wb_f_locate_run(sbase, (int)g, &srun);
-                if ((a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = own[g]; lpos[ch] = lp[g]; }
-            }
-        WB_END_PFOR
+        WB_PFOR_B(g, gc, u, n)
+            const int i = wb_f_locate_run(sbase, (int)gc, &srun);
+            ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
+        WB_PFOR_B_USE(g, u)
+            const uint32_t olw = ol[g];
+            const int ch = cix[olw & 0xFFFFu];
+            if (cloop[ch] && (ka[u] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = (uint16_t)(olw & 0xFFFFu); lpos[ch] = (uint16_t)(olw >> 16); }
+        WB_END_PFOR_B
         WB_PFOR(ch, C)
             if (cloop[ch]) ncp[lnode[ch]] = NN;
         WB_END_PFOR
@@ -498,8 +519,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // where every segment's end point goes (bit 15: the segment is its contour's first -- its start point goes in front).
     // Reads region A (own / lp) and the ranking's tables, writes region B.
     WB_PFOR(g, n)
-        const int o = (int)own[g], ch = cix[o];
-        int q = (int)(uint16_t)(Q[o] >> 16) + (int)lp[g];      // position along the chain, from 1
+        const uint32_t olw = ol[g];
+        const int o = (int)(olw & 0xFFFFu), ch = cix[o];
+        int q = (int)(uint16_t)(Q[o] >> 16) + (int)(olw >> 16);      // position along the chain, from 1
         if (cloop[ch]) {
             const int pl = (int)lpos[ch], tot = ctot[ch];
             q = q > pl ? q - pl : q - pl + tot;
@@ -525,21 +547,29 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         while (rawbase[c + 1] <= p) ++c;
         return ((uint32_t)c << sh) | ((uint32_t)wb_pt_y(pt) << xb) | (uint32_t)wb_pt_x(pt);
     };
-    WB_PFOR(g, n)
-        const int i = wb_f_locate_run(sbase, (int)g, &srun);
-        const size_t e = ((size_t)job * NS + srun) * a.cap_strip + (size_t)i;
-        const uint32_t key = a.stg_k[e];
-        double ul, ur, ll, lr;
-        if (a.dtype == 0) { const float* v = (const float*)a.stg_v + e * 4; ul = (double)v[0]; ur = (double)v[1]; ll = (double)v[2]; lr = (double)v[3]; }
-        else { const double* v = (const double*)a.stg_v + e * 4; ul = v[0]; ur = v[1]; ll = v[2]; lr = v[3]; }
-        // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
-        if (ul == level || ur == level || ll == level || lr == level) ctr[0] = 1;
-        const int sq = wb_key_sq(key), r = sq / W, c = sq - r * W, cs = wb_key_case(key), sub = wb_key_sub(key);
-        const uint16_t d = dest[g];
-        const int p = (int)(d & 0x7FFFu);
-        rawpt[p] = pack(p, wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level));
-        if (d & 0x8000u) rawpt[p - 1] = pack(p - 1, wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level));
-    WB_END_PFOR
+    {
+        uint32_t keya[WB_PFOR_B_WIDTH];
+        double va[WB_PFOR_B_WIDTH][4];
+        WB_PFOR_B(g, gc, u, n)                                  // (a segment's key and the four corner values of its square, four segments' worth requested together)
+            const int i = wb_f_locate_run(sbase, (int)gc, &srun);
+            const size_t e = ((size_t)job * NS + srun) * a.cap_strip + (size_t)i;
+            keya[u] = a.stg_k[e];
+            if (a.dtype == 0) { const float* v = (const float*)a.stg_v + e * 4; va[u][0] = (double)v[0]; va[u][1] = (double)v[1]; va[u][2] = (double)v[2]; va[u][3] = (double)v[3]; }
+            else { const double* v = (const double*)a.stg_v + e * 4; va[u][0] = v[0]; va[u][1] = v[1]; va[u][2] = v[2]; va[u][3] = v[3]; }
+        WB_PFOR_B_USE(g, u)
+            const uint32_t key = keya[u];
+            const double ul = va[u][0], ur = va[u][1], ll = va[u][2], lr = va[u][3];
+            // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
+            if (ul == level || ur == level || ll == level || lr == level) ctr[0] = 1;
+            const int sq = wb_key_sq(key), cs = wb_key_case(key), sub = wb_key_sub(key);
+            int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;
+            if (c < 0) { --r; c += W; } else if (c >= W) { ++r; c -= W; }
+            const uint16_t d = dest[g];
+            const int p = (int)(d & 0x7FFFu);
+            rawpt[p] = pack(p, wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level));
+            if (d & 0x8000u) rawpt[p - 1] = pack(p - 1, wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level));
+        WB_END_PFOR_B
+    }
     if (ctr[0]) WB_F_DECLINE();
 
     WB_FSTAMP(a.ctl, 7);
@@ -579,9 +609,15 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         const uint32_t pw = rawpt[p];
         const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
         bool first = true;
-        for (int e2 = b0; e2 < b1; ++e2) {
-            const int p2 = (int)order[e2];
-            if (p2 < p && rawpt[p2] == pw) first = false;
+        for (int e2 = b0; e2 < b1; e2 += 4) {                   // (four entries' positions, then their points: two LDS latencies per four)
+            int p2[4];
+            uint32_t w2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p2[q] = (int)order[e2 + q < b1 ? e2 + q : b1 - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w2[q] = rawpt[p2[q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (p2[q] < p && w2[q] == pw) first = false;
         }
         if (first) wb_atomic_or(&keepb[p >> 5], 1u << (p & 31));
     WB_END_PFOR
@@ -628,10 +664,16 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             const uint32_t x = pw & xmask, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
             const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0;
             bool firstx = true, firsty = true;
-            for (int e2 = b0; e2 < (int)e; ++e2) {              // the entries in front of this one in its bucket
-                const uint32_t pw2 = rawpt[order[e2]];
-                if ((pw2 >> xb) == cy && WB_F_XM(pw2) == xm) firsty = false;
-                if ((pw2 >> sh) == (uint32_t)c && (pw2 & xmask) == x) firstx = false;
+            for (int e2 = b0; e2 < (int)e; e2 += 4) {           // the entries in front of this one in its bucket, four at a time
+                uint32_t w2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w2[q] = rawpt[order[e2 + q < (int)e ? e2 + q : (int)e]];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (e2 + q >= (int)e) continue;             // (past the last one in front: the entry itself was read, skipped)
+                    if ((w2[q] >> xb) == cy && WB_F_XM(w2[q]) == xm) firsty = false;
+                    if ((w2[q] >> sh) == (uint32_t)c && (w2[q] & xmask) == x) firstx = false;
+                }
             }
             const int f = kid[c];
             if (firstx) wb_atomic_add(&nuxl[f], 1);

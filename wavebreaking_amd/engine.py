@@ -190,6 +190,19 @@ def _is_promised(arr):
     return True
 
 
+def _immutable(arr):
+    """can nobody change these bytes?  A read-only VIEW of a writeable array can still change through its base: every array
+    of the .base chain has to be read-only, and the chain has to end in an array or an immutable buffer (bytes)"""
+    o = arr
+    while isinstance(o, np.ndarray):
+        if o.flags.writeable:
+            return False
+        if o.base is None:
+            return True
+        o = o.base
+    return isinstance(o, bytes)
+
+
 def _array_key(arr, ctx=None):
     """cache key of a cube: buffer address, shape, dtype and a fingerprint of its bytes -- of ALL of them unless the buffer
     cannot change (not writeable) or was registered with keep_inputs()"""
@@ -197,7 +210,7 @@ def _array_key(arr, ctx=None):
     flat = arr.reshape(-1)                      # a view: the array is C-contiguous
     n = flat.size
     head = (arr.__array_interface__["data"][0], arr.shape, arr.dtype.str)
-    if not arr.flags.writeable or _is_promised(arr):
+    if _immutable(arr) or _is_promised(arr):
         sample = np.ascontiguousarray(flat[:: max(1, n // 16384)])
         edge = np.concatenate([flat[:256], flat[-256:]])
         FINGERPRINT_STATS["sampled"] += 1
@@ -216,14 +229,14 @@ def _array_key(arr, ctx=None):
         # bytes as they are NOW is taken on other threads; the call checks it before it returns anything (verify_pending) and
         # starts over with a fresh upload if the cube has changed -- the check costs the call nothing unless it fails.
         with _pending_lock:
-            hit = _pending_by_head.get((ctx.device, head))
+            hit = _pending_by_head.get((ctx.device, threading.get_ident(), head))
             if hit is not None:
                 return hit[0]
             resident, _ = _caches(ctx)
             for k in resident:
                 if k[:3] == head and k[3] == "full":
                     fut = _fp_pool().submit(fingerprint)
-                    _pending_by_head[(ctx.device, head)] = (k, fut, ctx)
+                    _pending_by_head[(ctx.device, threading.get_ident(), head)] = (k, fut, ctx)
                     FINGERPRINT_STATS["speculated"] = FINGERPRINT_STATS.get("speculated", 0) + 1
                     return k
     return head + ("full", fingerprint())
@@ -235,7 +248,7 @@ class StaleInput(Exception):
 
 # WB_INPUT_SPECULATE=0: every call waits for the fingerprints of its cubes before it touches the device copies
 SPECULATE = os.environ.get("WB_INPUT_SPECULATE", "1") != "0"
-_pending_by_head = {}    # (device, (address, shape, dtype)) -> (speculated key, future of the fingerprint, context): the running call's
+_pending_by_head = {}    # (device, thread, (address, shape, dtype)) -> (speculated key, future of the fingerprint, context): the running calls', one per thread
 _pending_lock = threading.Lock()
 _fp_executor = [None]
 
@@ -251,28 +264,36 @@ def verify_pending():
     """the end of a call that used device copies on trust: wait for the fingerprints taken meanwhile; a cube whose bytes no
     longer match its copy is dropped from the cache (with the contour batches traced from it) and StaleInput is raised -- the
     caller runs the call again, which then uploads the cube as it is"""
-    with _pending_lock:
-        items = list(_pending_by_head.values())
-        _pending_by_head.clear()
-    stale = False
-    for key, fut, ctx in items:
-        if fut.result() != key[4]:
-            stale = True
-            _drop_resident(ctx, key)
-    if stale:
+    if _take_pending(True):
         raise StaleInput()
 
 
-def discard_pending():
-    """a call that ends with an exception: let its fingerprints finish, keep nothing"""
+def _take_pending(strict):
+    """the RUNNING call's entries (this thread's: calls on other contexts / threads keep theirs): wait for their
+    fingerprints, drop the device copies whose cube has changed; True if there was one"""
+    me = threading.get_ident()
     with _pending_lock:
-        items = list(_pending_by_head.values())
-        _pending_by_head.clear()
-    for _, fut, _ in items:
+        mine = [k for k in _pending_by_head if k[1] == me]
+        items = [_pending_by_head.pop(k) for k in mine]
+    stale = False
+    for key, fut, ctx in items:
         try:
-            fut.result()
+            fp = fut.result()
         except BaseException:
-            pass
+            if strict:
+                raise
+            continue
+        if fp != key[4]:
+            stale = True
+            _drop_resident(ctx, key)
+    return stale
+
+
+def discard_pending():
+    """a call that ends with an exception: let its fingerprints finish -- and still COMPARE them: the exception may be the
+    old copy's (a cube whose cells equal to the level were edited away keeps raising KeyError from the stale copy
+    otherwise).  True if a cube had changed (its copy is dropped: the caller runs the call once more)"""
+    return _take_pending(False)
 
 
 def _cacheable(arr):

@@ -21,6 +21,7 @@ class LazyContours:
 
 def run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max=None):
     """kind: _hip.STREAMERS / OVERTURNINGS / CUTOFFS.  Returns the reference-shaped frame."""
+    ctx = engine.get_context()                    # (once, in front of the try: a failing look-up must not mask the call's own exception)
     for attempt in (0, 1):
         try:
             out = _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max)
@@ -29,9 +30,15 @@ def run_index(kind, data, contour_levels, contours, intensity, periodic_add, par
         except engine.StaleInput:                 # a cube changed on the host since it was uploaded: once more, from its bytes as they are
             if attempt:
                 raise RuntimeError("wavebreaking_amd: an input cube keeps changing while the call runs")
+        except Exception:
+            # the call raised on a device copy used on trust: if that cube has changed on the host, the error may be the OLD
+            # bytes' (find_contours' KeyError on cells equal to the level that were edited away since) -- the reference rereads
+            # its input on every call: once more from the fresh bytes; otherwise the exception stands
+            if attempt or not engine.discard_pending():
+                raise
         finally:
             engine.discard_pending()
-            engine.release_call_transients(engine.get_context())     # cubes uploaded for this call only (engine.resident_input)
+            engine.release_call_transients(ctx)   # cubes uploaded for this call only (engine.resident_input)
 
 
 def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, params, kwargs, global_max):

@@ -79,6 +79,7 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
     prep = engine.Prepared(data, None, kwargs)
     levels = engine.as_levels(contour_levels)
     # every batch (block of time steps x group of <= 4 levels) is released as soon as its table is on the host
+    ctx = engine.get_context()
     for attempt in (0, 1):
         tables = []
         try:
@@ -90,9 +91,14 @@ def calculate_contours(data, contour_levels, periodic_add=120, original_coordina
         except engine.StaleInput:                 # the cube changed on the host since it was uploaded: once more
             if attempt:
                 raise RuntimeError("wavebreaking_amd: the input cube keeps changing while the call runs")
+        except Exception:
+            # raised on a device copy used on trust (find_contours' KeyError, say): if the cube has changed on the host since,
+            # the error may be the old bytes' -- once more from the fresh ones; otherwise the exception stands
+            if attempt or not engine.discard_pending():
+                raise
         finally:
             engine.discard_pending()
-            engine.release_call_transients(engine.get_context())
+            engine.release_call_transients(ctx)
     return _contour_frame(tables, prep, levels, original_coordinates)
 
 
