@@ -75,9 +75,13 @@ def parse():
 
 def main():
     a = parse()
-    if os.environ.get("WB_BENCH_WATCHDOG"):                       # development: after that many seconds every thread's stack goes to stderr and the run ends
+    # watchdog, ON by default: a default run takes 2-3 minutes (most of it the cpu_baseline leg); after WB_BENCH_WATCHDOG seconds
+    # (default 1200, ~10 x the GPU part; 0 = off) every thread's stack goes to stderr and the process ends with a non-zero exit
+    # code instead of sitting in the driver's time-out
+    wd_s = float(os.environ.get("WB_BENCH_WATCHDOG", "1200"))
+    if wd_s > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["WB_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(wd_s, exit=True)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -242,8 +246,13 @@ def main():
         gatherer = wd.TableGatherer(dist, comm=libcomm, dst=0, on_result=gathered) if multi else None
         got = []
         # (one order of collectives on every rank: the record's gathers -- the gather thread's -- and then its all-reduce)
-        pipe.run_record(n, phase1, reduce_max, phase2, collect_pass(keep, gatherer), full_w,
-                        before_reduce=(lambda: got.extend(gatherer.finish())) if gatherer is not None else None)
+        try:
+            pipe.run_record(n, phase1, reduce_max, phase2, collect_pass(keep, gatherer), full_w,
+                            before_reduce=(lambda: got.extend(gatherer.finish())) if gatherer is not None else None)
+        except BaseException as e:
+            if gatherer is not None:                    # the peers must not be left inside a collective: abort, then fail
+                gatherer.abort(e)
+            raise
         if keep and multi and rank == 0 and got:
             counts["gathered_events"], counts["gathered_polygon_vertices"] = got[-1]
 

@@ -102,6 +102,8 @@ typedef struct wb_event_table {
 #define WB_STATUS_LEVEL_KEYERROR 64u /* ... which found the dictionary entry skimage pops missing: find_contours raises KeyError on
                                       this field (contour_index.py:103), and so must the caller -- the job has no contours */
 #define WB_STATUS_LEVEL_WALKED 128u  /* ... or finished: the contours are those of the sequential walk */
+#define WB_STATUS_SCAN_TIMEOUT 256u  /* the field scan's halo exchange between the strips of a workgroup ran out of its (bounded) spin
+                                        budget: an internal error -- the job's contours must not be used (the Python layer raises) */
 
 int wb_create(int device_id, wb_ctx** ctx);
 void wb_destroy(wb_ctx* ctx);
@@ -214,17 +216,20 @@ int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows
 int wb_comm_stage_tables(wb_ctx* ctx, wb_batch* b, int slot);
 int wb_comm_gather_staged(wb_ctx* ctx, int slot, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
                           const int32_t** poly_y, int64_t* nverts, int* ranks_seen);
+/* Failure handling of a time-sharded run ("RCCL error -> abort").  A rank that cannot deliver a staged slot calls
+   wb_comm_gather_staged with slot = -1: it still takes part in the exchange of the counts, with -1 for its own, so every
+   rank's call for that slot FAILS ("... ranks in place") instead of waiting for a payload that never comes, and the ranks'
+   sequences of collectives stay matched.  wb_comm_abort: ncclCommAbort -- peers blocked in a collective with this rank get an
+   error from RCCL; every later exchange of this context fails at once.  wb_comm_reserve: the destination rank's device and
+   pinned buffers for the whole group's catalogue, made before the record's batches are in flight (growing them inside a
+   gather is a hipFree / hipMalloc beside the workers' kernels). */
+int wb_comm_abort(wb_ctx* ctx);
+int wb_comm_reserve(wb_ctx* ctx, int64_t rows, int64_t polygon_vertices);
 void wb_comm_destroy(wb_ctx* ctx);
 
 /* device memory + synthetic ERA5-shaped PV for the benchmark */
 void* wb_dev_alloc(wb_ctx* ctx, uint64_t bytes);
 void wb_dev_free(wb_ctx* ctx, void* p);
-/* milliseconds of one streaming read of a device buffer (best of reps; -1: failed).  No counterpart in the reference: on this
-   platform an allocation's physical placement decides 15 % of the HBM throughput a kernel gets from it */
-double wb_probe_read_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, int reps);
-/* ... and of a read by `grid` workgroups that each stream chunks of chunk_bytes from start to end (the scan's pattern: 256
-   workgroups, 1.4 MB chunks); development yardstick */
-double wb_probe_streams_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, uint64_t chunk_bytes, int grid, int reps);
 int wb_memcpy_h2d(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int wb_memcpy_d2h(wb_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int wb_synth_fill(wb_ctx* ctx, void* dev_field, int dtype, int64_t t0, int nt, int nlat, int nlon,

@@ -24,6 +24,7 @@ def build_hostsim(force=False, variant="", defines=(), sanitize=False):
     lib = HOSTSIM_LIB if not variant else HOSTSIM_LIB.replace(".so", "_%s.so" % variant)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     srcs.append(os.path.join(ROOT, "include", "wavebreaking_hip.h"))
+    srcs.append(os.path.join(ROOT, "include", "wavebreaking_hip_dev.h"))
     if (not force and os.path.exists(lib)
             and os.path.getmtime(lib) >= max(os.path.getmtime(s) for s in srcs)):
         return lib

@@ -389,3 +389,96 @@ def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_
     assert total == rows.shape[0] > 20
     b.close()
     ctx.close()
+
+
+FAIL_WORKER = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import datetime
+import torch.distributed as dist
+from oracle import synth
+from tests import helpers
+from wavebreaking_amd import _hip
+from wavebreaking_amd import distributed as wd
+from wavebreaking_amd.pipeline import BatchPipeline
+
+mode = sys.argv[2]
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]), timeout=datetime.timedelta(seconds=60))
+rank, world = dist.get_rank(), dist.get_world_size()
+lat, lon = synth.grid(2.5)
+PER, NB = 1, 4
+pv = synth.pv_field(rank * PER * NB, PER * NB, lat, lon, eps=0.2)
+full_w = lon.size + int(120.0 / 2.5)
+pipe = BatchPipeline(0, depth=2, library=helpers.hostsim_library())
+for c in pipe.contexts:
+    c.set_option("keep_device", 1)
+
+def phase1(c, k):
+    return c.contours(pv[k * PER:(k + 1) * PER], lat, lon, [-2.0, 2.0], 2.5, 2.5)
+
+def phase2(c, k, b, g):
+    if mode == "raise" and rank == 1 and k == 2:
+        raise ValueError("rank 1 fails in batch 2")          # a worker raises: the record cannot be finished on this rank
+    b.indices(g)
+    return b
+
+def on_result(k, cat):
+    if mode == "poison" and rank == 1 and k == 1:
+        raise ValueError("rank 1 fails behind the gather of batch 1")   # ... or the gather thread itself fails
+    if mode == "kill" and rank == 1 and k == 1:
+        os._exit(7)                                          # ... or the process dies mid-record
+    return k
+
+g = wd.TableGatherer(dist, comm=None, dst=0, on_result=on_result)
+def collect(k, b):
+    g.submit(k, b)
+    pipe.close_batch(k, b)
+t0 = time.time()
+try:
+    pipe.run_record(NB, phase1, lambda m: wd.global_max_nux(m, dist), phase2, collect, full_w, before_reduce=lambda: g.finish())
+except BaseException as e:
+    g.abort(e)
+    print("rank", rank, "failed after %.1f s:" % (time.time() - t0), type(e).__name__, str(e)[:100], flush=True)
+    os._exit(3)                                              # a failed gather group ends the process non-zero
+print("rank", rank, "finished", flush=True)
+os._exit(0)
+'''
+
+
+def _run_failing_record(tmp_path, mode):
+    helpers.build_hostsim()
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   WB_PIPE_TIMEOUT="90")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append((p.wait(timeout=150), p.stdout.read()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append((None, "TIMEOUT " + p.stdout.read()))
+    return outs
+
+
+def test_a_rank_that_fails_behind_a_gather_poisons_the_later_slots_and_every_rank_raises(tmp_path):
+    """rank 1's gather thread fails after batch 1: it still takes part in the exchange of the counts of batches 2 and 3, with -1
+    for its own (GatherPoisoned on every rank, before any payload), so ranks 0 and 2 end with an error within seconds instead
+    of waiting inside a collective for ever (until round 5 the failing rank drained its slots without collectives)"""
+    outs = _run_failing_record(tmp_path, "poison")
+    for rc, text in outs:
+        assert rc == 3, outs
+    assert "GatherPoisoned" in outs[0][1] and "GatherPoisoned" in outs[2][1], outs
+
+
+def test_a_rank_whose_worker_raises_or_that_dies_mid_record_ends_the_others_non_zero(tmp_path):
+    """the review's case: one of three ranks raises in a worker (its gatherer is aborted) or is killed mid-record; the others must
+    exit non-zero within the time-out, not hang"""
+    for mode in ("raise", "kill"):
+        outs = _run_failing_record(tmp_path, mode)
+        assert all(rc is not None and rc != 0 for rc, _ in outs), (mode, outs)

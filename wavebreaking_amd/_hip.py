@@ -57,7 +57,7 @@ EVENT_NOT_SIMPLE = 1
 ROW_WIDTH = 20
 COMM_SLOTS = 4
 STATUS_OVERFLOW_SEG, STATUS_LEVEL_HIT, STATUS_HAS_NAN, STATUS_HASH_FULL, STATUS_OVERFLOW_PAIRS, STATUS_LEVEL_ORDER = 1, 2, 4, 8, 16, 32
-STATUS_LEVEL_KEYERROR, STATUS_LEVEL_WALKED = 64, 128
+STATUS_LEVEL_KEYERROR, STATUS_LEVEL_WALKED, STATUS_SCAN_TIMEOUT = 64, 128, 256
 
 
 def _arr(ptr, n, dtype, copy=True):
@@ -149,6 +149,8 @@ class Library:
                                              C.POINTER(C.c_int)]
         lib.wb_comm_destroy.argtypes = [C.c_void_p]
         lib.wb_comm_destroy.restype = None
+        lib.wb_comm_abort.argtypes = [C.c_void_p]
+        lib.wb_comm_reserve.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         lib.wb_last_op_ms.argtypes = [C.c_void_p]
         lib.wb_last_op_ms.restype = C.c_float
         lib.wb_fingerprint.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
@@ -509,6 +511,16 @@ class Context:
             raise RuntimeError("wb_comm_gather_staged failed: " + self.error())
         r = _arr(rows, n.value * ROW_WIDTH, np.float64, copy=False).reshape(-1, ROW_WIDTH)
         return r, _arr(px, nv.value, np.int32, copy=False), _arr(py, nv.value, np.int32, copy=False), int(seen.value)
+
+    def comm_abort(self):
+        """ncclCommAbort: peers blocked in a collective with this rank fail instead of waiting for ever"""
+        if self.h:
+            self.L.lib.wb_comm_abort(self.h)
+
+    def comm_reserve(self, rows, verts):
+        """the destination rank's buffers for the whole group's catalogue, before the record's batches are in flight"""
+        if self.L.lib.wb_comm_reserve(self.h, int(rows), int(verts)) != 0:
+            raise RuntimeError("wb_comm_reserve failed: " + self.error())
 
     def comm_destroy(self):
         if self.h:

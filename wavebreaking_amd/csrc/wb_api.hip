@@ -3,6 +3,7 @@
 // by g++, into tests/_hostsim/libwb_hostsim.so (test infrastructure: same sources, kernels executed
 // block by block on the host under ASan/UBSan; never loaded by the package).
 #include "../../include/wavebreaking_hip.h"
+#include "../../include/wavebreaking_hip_dev.h"
 
 #include <math.h>
 #include <stddef.h>
@@ -2505,6 +2506,8 @@ extern "C" int wb_comm_gather_staged(wb_ctx* ctx, int, int, const double**, int6
     return wb_fail(ctx, "the host simulation has no RCCL");
 }
 extern "C" void wb_comm_destroy(wb_ctx*) {}
+extern "C" int wb_comm_abort(wb_ctx* ctx) { return wb_fail(ctx, "the host simulation has no RCCL"); }
+extern "C" int wb_comm_reserve(wb_ctx* ctx, int64_t, int64_t) { return wb_fail(ctx, "the host simulation has no RCCL"); }
 #else
 #define WB_NCCL(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) return wb_fail(ctx, std::string(#call) + ": " + cm.GetErrorString(r_)); } while (0)
 #define WB_HIPC(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return wb_fail(ctx, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
@@ -2684,6 +2687,7 @@ static int wb_comm_gather_core(wb_ctx* ctx, WbComm& cm, const double* src_rows, 
 extern "C" int wb_comm_gather_tables(wb_ctx* ctx, wb_batch* b, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
                                      const int32_t** poly_y, int64_t* nverts, int* ranks_seen) {
     if (!ctx || !rows || !nrows || !poly_x || !poly_y || !nverts) return 1;
+    if (ctx->comm && ctx->comm->aborted) return wb_fail(ctx, "wb_comm_gather_tables: the communicator was aborted (wb_comm_abort)");
     if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_gather_tables: wb_comm_init first");
     WbComm& cm = *ctx->comm;
     if (dst < 0 || dst >= cm.world) return wb_fail(ctx, "wb_comm_gather_tables: bad destination rank");
@@ -2734,15 +2738,71 @@ extern "C" int wb_comm_stage_tables(wb_ctx* ctx, wb_batch* b, int slot) {
 extern "C" int wb_comm_gather_staged(wb_ctx* ctx, int slot, int dst, const double** rows, int64_t* nrows, const int32_t** poly_x,
                                      const int32_t** poly_y, int64_t* nverts, int* ranks_seen) {
     if (!ctx || !rows || !nrows || !poly_x || !poly_y || !nverts) return 1;
+    if (ctx->comm && ctx->comm->aborted) return wb_fail(ctx, "wb_comm_gather_staged: the communicator was aborted (wb_comm_abort)");
     if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_gather_staged: wb_comm_init first");
     WbComm& cm = *ctx->comm;
-    if (slot < 0 || slot >= WB_COMM_SLOTS || !cm.slot[slot].full) return wb_fail(ctx, "wb_comm_gather_staged: nothing staged in this slot");
+    if (cm.aborted) return wb_fail(ctx, "wb_comm_gather_staged: the communicator was aborted (wb_comm_abort)");
     if (dst < 0 || dst >= cm.world) return wb_fail(ctx, "wb_comm_gather_staged: bad destination rank");
     (void)hipSetDevice(ctx->device);
+    if (slot == -1) {
+        // POISON: this rank cannot deliver a slot (an error upstream) but still takes part in the exchange of the counts -- with
+        // -1 for its own --, so that EVERY rank's call fails for this slot with "... ranks in place" instead of waiting for ever
+        // for a payload that will not come (the ranks' sequences of collectives stay matched)
+        (void)wb_comm_gather_core(ctx, cm, nullptr, nullptr, nullptr, -1, -1, dst, rows, nrows, poly_x, poly_y, nverts, ranks_seen);
+        return wb_fail(ctx, "wb_comm_gather_staged: poisoned slot (this rank reported a failure to the group)");
+    }
+    if (slot < 0 || slot >= WB_COMM_SLOTS || !cm.slot[slot].full) return wb_fail(ctx, "wb_comm_gather_staged: nothing staged in this slot");
     WbComm::Slot& sl = cm.slot[slot];
     const int rc = wb_comm_gather_core(ctx, cm, sl.rows, sl.px, sl.py, sl.ne, sl.nv, dst, rows, nrows, poly_x, poly_y, nverts, ranks_seen);
     sl.full = false;
     return rc;
+}
+// ncclCommAbort: the communicator is torn down without waiting for outstanding operations -- peers blocked in a collective with
+// this rank get an error from RCCL instead of waiting for ever ("RCCL error -> abort").  Every later wb_comm_* call
+// of this context fails; wb_comm_destroy releases what is left.
+extern "C" int wb_comm_abort(wb_ctx* ctx) {
+    if (!ctx) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return 0;
+    WbComm& cm = *ctx->comm;
+    (void)hipSetDevice(ctx->device);
+    cm.aborted = true;
+    if (cm.CommAbort) (void)cm.CommAbort(cm.comm);
+    cm.comm = nullptr;
+    return 0;
+}
+// room for `rows` event rows and `verts` polygon vertices of the WHOLE group's catalogue on this rank (the destination of the
+// gathers), device and pinned host, made NOW -- before the record's batches are in flight: growing them inside a gather is a
+// hipFree / hipMalloc beside the workers' kernels (device-wide synchronisations on the first passes)
+extern "C" int wb_comm_reserve(wb_ctx* ctx, int64_t rows, int64_t verts) {
+    if (!ctx || rows < 0 || verts < 0) return 1;
+    if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_reserve: wb_comm_init first");
+    WbComm& cm = *ctx->comm;
+    (void)hipSetDevice(ctx->device);
+    if ((size_t)rows > cm.cap_rows) {
+        if (cm.d_rows) (void)hipFree(cm.d_rows);
+        cm.d_rows = nullptr; cm.cap_rows = (size_t)rows;
+        WB_HIPC(hipMalloc((void**)&cm.d_rows, cm.cap_rows * WB_ROW_WIDTH * sizeof(double)));
+    }
+    if ((size_t)verts > cm.cap_v) {
+        if (cm.d_px) (void)hipFree(cm.d_px);
+        if (cm.d_py) (void)hipFree(cm.d_py);
+        cm.d_px = cm.d_py = nullptr; cm.cap_v = (size_t)verts;
+        WB_HIPC(hipMalloc((void**)&cm.d_px, cm.cap_v * sizeof(int32_t)));
+        WB_HIPC(hipMalloc((void**)&cm.d_py, cm.cap_v * sizeof(int32_t)));
+    }
+    if ((size_t)rows > cm.hcap_rows) {
+        if (cm.h_rows) (void)hipHostFree(cm.h_rows);
+        cm.h_rows = nullptr; cm.hcap_rows = (size_t)rows;
+        WB_HIPC(hipHostMalloc((void**)&cm.h_rows, cm.hcap_rows * WB_ROW_WIDTH * sizeof(double), hipHostMallocDefault));
+    }
+    if ((size_t)verts > cm.hcap_v) {
+        if (cm.h_px) (void)hipHostFree(cm.h_px);
+        if (cm.h_py) (void)hipHostFree(cm.h_py);
+        cm.h_px = cm.h_py = nullptr; cm.hcap_v = (size_t)verts;
+        WB_HIPC(hipHostMalloc((void**)&cm.h_px, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
+        WB_HIPC(hipHostMalloc((void**)&cm.h_py, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
+    }
+    return 0;
 }
 #undef WB_NCCL_G
 #undef WB_NCCL

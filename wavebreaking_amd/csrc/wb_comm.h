@@ -29,6 +29,8 @@ struct WbComm {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    bool aborted = false;                 // wb_comm_abort: every later exchange fails at once
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -60,7 +62,7 @@ static std::string wb_comm_load(WbComm& c) {
 #define WB_NCCL_SYM(field, name) \
     c.field = (decltype(c.field))dlsym(c.lib, name); \
     if (!c.field) return std::string("librccl lacks ") + name;
-    WB_NCCL_SYM(GetUniqueId, "ncclGetUniqueId") WB_NCCL_SYM(CommInitRank, "ncclCommInitRank") WB_NCCL_SYM(CommDestroy, "ncclCommDestroy")
+    WB_NCCL_SYM(GetUniqueId, "ncclGetUniqueId") WB_NCCL_SYM(CommInitRank, "ncclCommInitRank") WB_NCCL_SYM(CommDestroy, "ncclCommDestroy") WB_NCCL_SYM(CommAbort, "ncclCommAbort")
     WB_NCCL_SYM(GetErrorString, "ncclGetErrorString") WB_NCCL_SYM(AllReduce, "ncclAllReduce") WB_NCCL_SYM(AllGather, "ncclAllGather")
     WB_NCCL_SYM(Send, "ncclSend") WB_NCCL_SYM(Recv, "ncclRecv") WB_NCCL_SYM(GroupStart, "ncclGroupStart") WB_NCCL_SYM(GroupEnd, "ncclGroupEnd")
 #undef WB_NCCL_SYM

@@ -38,6 +38,7 @@
 #define WB_ST_HAS_NAN 4u
 #define WB_ST_HASH_FULL 8u
 #define WB_ST_OVERFLOW_PAIRS 16u
+#define WB_ST_SCAN_TIMEOUT 256u  // the streaming scan's halo exchange ran out of its spin budget (wb_stream.h): the step's contours are not to be trusted
 
 struct WbScanArgs {
     int nt, nlat, nlon, W, nlev, cap_strip;

@@ -42,23 +42,33 @@
 // spin until the LDS word at byte address `lds_addr` equals `tag` (both wave-uniform).  One opaque instruction for the
 // compiler: a loop in the source would sit inside every unrolled step of the kernel below and cost it its register
 // allocation (the ring rows rotate by name; with back-edges in between they were copied and spilled).
-__device__ inline float wb_lds_wait_eq(uint32_t addr_tag, uint32_t tag, uint32_t addr_val) {
+// The spin is BOUNDED (round 5): `budget` (wave-uniform, an SGPR) counts the sleeps a wave may still spend waiting in this
+// launch; at zero every wait falls through at once (the value is then whatever the slot holds) and the caller flags the time
+// step (WB_ST_SCAN_TIMEOUT -> RuntimeError in the Python layer): a lost tag -- none has been seen since the tags are
+// cleared at kernel start -- ends the launch with an error instead of hanging the device until the driver's watchdog.
+__device__ inline float wb_lds_wait_eq(uint32_t addr_tag, uint32_t tag, uint32_t addr_val, uint32_t& budget) {
     uint32_t tmp;
     float val;
     asm volatile(
         "1:\n\t"
-        "ds_read_b32 %0, %2\n\t"
+        "ds_read_b32 %0, %3\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u32 vcc, %0, %3\n\t"
+        "v_cmp_eq_u32 vcc, %0, %4\n\t"
         "s_cbranch_vccnz 2f\n\t"
+        "s_cmp_eq_u32 %2, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_u32 %2, %2, 1\n\t"
         "s_sleep 1\n\t"
         "s_branch 1b\n\t"
         "2:\n\t"
-        "ds_read_b32 %1, %4\n\t"
+        "ds_read_b32 %1, %5\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        : "=&v"(tmp), "=&v"(val) : "v"(addr_tag), "s"(tag), "v"(addr_val) : "vcc", "memory");
+        : "=&v"(tmp), "=&v"(val), "+s"(budget) : "v"(addr_tag), "s"(tag), "v"(addr_val) : "vcc", "scc", "memory");
     return val;
 }
+#ifndef WB_STREAM_SPIN_BUDGET
+#define WB_STREAM_SPIN_BUDGET (1u << 22)     // sleeps of ~64 clocks + an LDS read each: a few tenths of a second per wave and launch
+#endif
 
 // HL: the strips of a workgroup exchange their halo columns through LDS (a.halo_rows slots per strip); else scalar loads
 // (deeper rings at three waves per SIMD -- 16 x 3, 18 x 3 with a 512-thread launch bound -- were slower: 1.33 ms against 1.17)
@@ -113,6 +123,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         __syncthreads();
     }
 
+    uint32_t spin_budget = WB_STREAM_SPIN_BUDGET;            // (wb_lds_wait_eq: the halo waits of this wave are bounded)
     const int nitems = a.nt * a.nbands;
     // persistent: a workgroup takes the next (time step, row band) item when it is free.  Dealing the items out by workgroup
     // number (it += gridDim.x) assumes every workgroup is resident from the start: with another batch's kernels on the
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
             pubv[r] = x0;
             pubt[r] = tag;
             if (hsrc < 0) return hh;
-            return (T)wb_lds_wait_eq((uint32_t)(uintptr_t)(srct + r), tag, (uint32_t)(uintptr_t)(srcv + r));
+            return (T)wb_lds_wait_eq((uint32_t)(uintptr_t)(srct + r), tag, (uint32_t)(uintptr_t)(srcv + r), spin_budget);
         };
         T p4, pmn, pmx;                                       // previous row, completed: its halo, minimum and maximum
         auto finish = [&](const V4& qq, T hh, T& v4, T& mn, T& mx) {
@@ -266,6 +277,10 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
         if (__any(nanflag && (c0 < nlon)) && lane == 0) {
 #pragma unroll
             for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_HAS_NAN);
+        }
+        if (HL && spin_budget == 0u && lane == 0) {             // a halo tag never came: this step's contours are not to be trusted
+#pragma unroll
+            for (int l = 0; l < NLEV; ++l) atomicOr(&a.status[t * NLEV + l], WB_ST_SCAN_TIMEOUT);
         }
         if (HL || a.cursor) __syncthreads();                  // nobody overwrites a halo slot a slower strip still waits for (nor wb_item)
     }

@@ -228,18 +228,26 @@ def gather_device_tables(batch, dist=None, dst=0, as_rows=False):
     return None if out is None else done(*out)
 
 
-def _gather_tensors(rows, vx, vy, dist, dst, dev):
+class GatherPoisoned(RuntimeError):
+    """some rank took part in a gather's exchange of the counts with -1: it cannot deliver that slot (an error upstream);
+    every rank's call for the slot raises this BEFORE the payload is exchanged, so no rank waits for data that never comes"""
+
+
+def _gather_tensors(rows, vx, vy, dist, dst, dev, poison=False):
     """the collective part of gather_device_tables on tensors that already exist (inside an _exchange_stream block);
-    (rows, vx, vy) numpy arrays on ``dst``, None elsewhere"""
+    (rows, vx, vy) numpy arrays on ``dst``, None elsewhere.  ``poison``: this rank has nothing to deliver for the slot
+    (rows / vx / vy may be None): it sends -1 for its counts, and every rank raises GatherPoisoned."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    ne, nv = int(rows.shape[0]), int(vx.shape[0])
-    if dev.type != "cuda":                              # dry runs of the N > 1 logic over gloo: CPU tensors
+    ne, nv = (-1, -1) if poison else (int(rows.shape[0]), int(vx.shape[0]))
+    if not poison and dev.type != "cuda":               # dry runs of the N > 1 logic over gloo: CPU tensors
         rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
     counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(allc, counts)
     allc = torch.stack(allc).cpu().numpy()
+    if (allc < 0).any():
+        raise GatherPoisoned("rank(s) %s reported a failure for this slot of the gather" % [int(r) for r in np.nonzero((allc < 0).any(axis=1))[0]])
     me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
     rbuf = torch.zeros((max(me, 1), 20), dtype=torch.float64, device=dev)
     vbuf = torch.zeros((2, max(mv, 1)), dtype=torch.int32, device=dev)
@@ -298,6 +306,7 @@ class TableGatherer:
         self.free = threading.Semaphore(self.nslots)
         self.q = queue.Queue()
         self.results, self.error, self.next_slot = {}, None, 0
+        self.reserved, self.aborted = False, False
         self.dev = _device(dist) if comm is None else None
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
@@ -305,6 +314,12 @@ class TableGatherer:
     def submit(self, k, batch):
         if self.error is not None:
             raise self.error
+        if not self.reserved and self.comm is not None and self.comm.rank == self.dst and batch is not None:
+            # the destination's buffers for the WHOLE group's catalogue, sized from the first batch and made now -- growing them
+            # inside a gather is a hipFree / hipMalloc on the gather thread while the workers' kernels run
+            _, n3, _, _, nv = batch.device_tables()
+            self.comm.ctx.comm_reserve(int(1.5 * self.comm.world * (sum(n3) + 64)), int(1.5 * self.comm.world * (nv + 4096)))
+            self.reserved = True
         self.free.acquire()                                  # a slot the gather thread is done with (it may lag by nslots batches)
         slot = self.next_slot
         self.next_slot = (slot + 1) % self.nslots
@@ -316,6 +331,17 @@ class TableGatherer:
                 item = tuple(t.clone() for t in _batch_tensors(batch, self.dist, False))
         self.q.put((k, item))
 
+    def _gather(self, item, poison):
+        if self.comm is not None:
+            rows, px, py, seen = self.comm.ctx.comm_gather_staged(-1 if poison else item, self.dst)
+            if seen != self.comm.world:
+                raise RuntimeError("wb_comm_gather_staged saw %d ranks, the group has %d" % (seen, self.comm.world))
+            return (rows, px, py) if self.comm.rank == self.dst else None
+        with _exchange_stream(self.dev):
+            if poison:
+                return _gather_tensors(None, None, None, self.dist, self.dst, self.dev, poison=True)
+            return _gather_tensors(item[0], item[1], item[2], self.dist, self.dst, self.dev)
+
     def _run(self):
         while True:
             job = self.q.get()
@@ -324,19 +350,36 @@ class TableGatherer:
             k, item = job
             try:
                 if self.error is None:
-                    if self.comm is not None:
-                        rows, px, py, seen = self.comm.ctx.comm_gather_staged(item, self.dst)
-                        if seen != self.comm.world:
-                            raise RuntimeError("wb_comm_gather_staged saw %d ranks, the group has %d" % (seen, self.comm.world))
-                        cat = (rows, px, py) if self.comm.rank == self.dst else None
-                    else:
-                        with _exchange_stream(self.dev):
-                            cat = _gather_tensors(item[0], item[1], item[2], self.dist, self.dst, self.dev)
-                    self.results[k] = self.on_result(k, cat)
-            except BaseException as e:                       # kept for the caller; later slots are drained without collectives
+                    self.results[k] = self.on_result(k, self._gather(item, False))
+                elif not self.aborted:
+                    # A failure here must not leave the peers inside a collective: this rank still takes part in the exchange of
+                    # the counts of every slot it owes, with -1 for its own, so every rank's gather for the slot raises and the
+                    # sequences of collectives stay matched (until round 5 the slots were drained WITHOUT collectives: the peers
+                    # then waited in ncclAllGather for ever)
+                    try:
+                        self._gather(item, True)
+                    except BaseException:
+                        pass
+            except BaseException as e:                       # kept for the caller
                 self.error = e
             finally:
                 self.free.release()
+
+    def abort(self, why=None):
+        """the record cannot be finished on this rank (a worker raised): no further collective is issued, the library's
+        communicator is aborted (ncclCommAbort: peers blocked in a collective with this rank get an error instead of
+        waiting for ever), the gather thread is stopped.  The process should end non-zero; a gather group cannot be
+        restarted in place."""
+        self.aborted = True
+        if self.error is None:
+            self.error = why if isinstance(why, BaseException) else RuntimeError("TableGatherer aborted: %s" % (why,))
+        if self.comm is not None:
+            try:
+                self.comm.ctx.comm_abort()
+            except Exception:
+                pass
+        self.q.put(None)
+        self.thread.join(timeout=30)
 
     def finish(self):
         self.q.put(None)

@@ -32,6 +32,7 @@ _FATAL = (
     (_hip.STATUS_HASH_FULL, "a hash table of the contour assembly ran full"),
     (_hip.STATUS_OVERFLOW_PAIRS, "more candidate base-point pairs, streamers or overturning groups per contour than the "
                                  "kernels hold; the event list would be truncated"),
+    (_hip.STATUS_SCAN_TIMEOUT, "the field scan's halo exchange ran out of its spin budget (an internal error: please report the field)"),
 )
 LEVEL_ORDER_TEXT = ("cells equal to the contour level put two contour ends on one grid vertex and the order-dependent join of "
                     "scikit-image's find_contours (contour_index.py:103) was not reproduced for this job.")

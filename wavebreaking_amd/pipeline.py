@@ -29,6 +29,25 @@ class FullWidthNotReached(RuntimeError):
     """BatchPipeline.run_record: the record holds no contour of the full width it was selected against"""
 
 
+class PipelineTimeout(RuntimeError):
+    """a worker did not come back within WB_PIPE_TIMEOUT seconds (default 600): a batch is stuck on the device or in an
+    exchange.  The waiting thread raises instead of waiting for ever; the stuck worker thread cannot be interrupted, so a
+    program that catches this should end (bench.py exits non-zero)."""
+
+
+def _timeout():
+    t = float(os.environ.get("WB_PIPE_TIMEOUT", "600"))
+    return t if t > 0 else None
+
+
+def _result(fut, what):
+    from concurrent.futures import TimeoutError as _FT
+    try:
+        return fut.result(timeout=_timeout())
+    except _FT:
+        raise PipelineTimeout("BatchPipeline: %s did not finish within %s s (WB_PIPE_TIMEOUT)" % (what, os.environ.get("WB_PIPE_TIMEOUT", "600")))
+
+
 class BatchPipeline:
     def __init__(self, device=0, depth=2, library=None, stagger=None):
         self.contexts = [_hip.Context(device, library) for _ in range(max(1, int(depth)))]
@@ -86,7 +105,8 @@ class BatchPipeline:
 
         def both(ctx, k):
             if self.offset_start and 0 < k < d:
-                started[k - 1].wait()
+                if not started[k - 1].wait(_timeout()):
+                    raise PipelineTimeout("BatchPipeline: batch %d waited for batch %d to enter phase 1 for more than WB_PIPE_TIMEOUT s" % (k, k - 1))
             try:
                 if l1 is not None:                  # set_stagger: a phase is entered by one batch at a time
                     with l1:
@@ -104,7 +124,7 @@ class BatchPipeline:
         for k in range(min(d, n)):
             fut[k] = self._workers[k % d].submit(both, self.contexts[k % d], k)
         for k in range(n):
-            m, r = fut.pop(k).result()
+            m, r = _result(fut.pop(k), "batch %d" % k)
             local = max(local, int(m))
             if k + d < n:
                 fut[k + d] = self._workers[k % d].submit(both, self.contexts[k % d], k + d)
@@ -142,7 +162,7 @@ class BatchPipeline:
         for k in range(min(d, n)):
             c_fut[k] = self._workers[k % d].submit(contours, self.contexts[k % d], k)
         for k in range(n):
-            b = c_fut.pop(k).result()
+            b = _result(c_fut.pop(k), "phase 1 of batch %d" % k)
             g = reduce_max(b.max_nux())
             if full_width is not None and g != full_width:
                 raise RuntimeError("BatchPipeline: batch %d has no contour of extent %d (largest: %d): its selection would "
@@ -152,7 +172,7 @@ class BatchPipeline:
                 c_fut[k + d] = self._workers[k % d].submit(contours, self.contexts[k % d], k + d)
             if k >= d - 1:
                 j = k - (d - 1)
-                out.append(collect(j, i_fut.pop(j).result()))
+                out.append(collect(j, _result(i_fut.pop(j), "phase 2 of batch %d" % j)))
         for j in sorted(i_fut):
-            out.append(collect(j, i_fut.pop(j).result()))
+            out.append(collect(j, _result(i_fut.pop(j), "phase 2 of batch %d" % j)))
         return out
