@@ -506,16 +506,26 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
     three(*warm)
     three(*warm, contours=wb.calculate_contours(data=warm[0], contour_levels=levels, original_coordinates=False))
     wb.release_inputs()
-    runs = []
-    for rep in range(2):                                      # twice from a cold cache; the faster one is reported, both listed
-        runs.append(three(data, idata))
-        if rep == 0:
+    REPS = int(os.environ.get("WB_BENCH_E2E_REPS", 5))
+
+    def cold(n, prepare=None, **kw):
+        """n runs of the three calls, each from a cold input cache; (median run by total seconds, all totals)"""
+        runs = []
+        for rep in range(n):
             wb.release_inputs()
-    secs, rows = min(runs, key=lambda r: sum(r[0].values()))
+            if prepare is not None:
+                prepare()
+            runs.append(three(data, idata, **kw))
+        runs.sort(key=lambda r: sum(r[0].values()))
+        return runs[len(runs) // 2], [sum(r[0].values()) for r in runs]
+
+    # every variant: the MEDIAN of REPS cold runs (round 4 reported the faster of two, and one slow call -- 115 ms for
+    # calculate_cutoffs on the driver's box -- turned a variant's figure by a factor of two: all totals are listed)
+    (secs, rows), totals = cold(REPS)
     total = sum(secs.values())
     fp = dict(engine.FINGERPRINT_STATS)
     out = {"value": nt / total, "unit": "timesteps/s", "nt": nt, "seconds": secs, "rows": rows,
-           "upload_GBps": pv.nbytes / t_up / 1e9, "both_runs_s": [sum(r[0].values()) for r in runs],
+           "upload_GBps": pv.nbytes / t_up / 1e9, "cold_runs_s": totals, "reported": "median of %d cold runs" % REPS,
            "what": "host numpy f32 cube (%d steps, %.2f GB + intensity) -> three frames via the drop-in functions, cold input "
                    "cache at the first call, H2D included" % (nt, pv.nbytes / 1e9), "pipelined_upload": bool(engine.PIPELINED_UPLOAD)}
     # every call above fingerprinted every byte of both cubes (wb_fingerprint) to make sure the device copies still mirror them;
@@ -524,30 +534,33 @@ def end_to_end(ctx, d_pv, d_int, lat, lon, levels, nt):
                           "beside_the_call": fp.get("speculated", 0),
                           "what": "wb_fingerprint over whole cubes in the calls so far (several host threads); beside_the_call: taken on other "
                                   "threads while the call went on with the device copy, checked before the call returned (engine.verify_pending)"}
-    wb.release_inputs()
-    wb.keep_inputs(data, idata)
-    secs_k, rows_k = three(data, idata)
-    out["keep_inputs"] = {"value": nt / sum(secs_k.values()), "unit": "timesteps/s", "seconds": secs_k, "rows_match": rows_k == rows,
-                          "what": "the same three calls from a cold cache after wb.keep_inputs(data, intensity): cubes recognised without reading every byte"}
+    (secs_k, rows_k), totals_k = cold(REPS, prepare=lambda: wb.keep_inputs(data, idata))
+    out["keep_inputs"] = {"value": nt / sum(secs_k.values()), "unit": "timesteps/s", "seconds": secs_k, "rows_match": rows_k == rows, "cold_runs_s": totals_k,
+                          "what": "the same three calls from a cold cache after wb.keep_inputs(data, intensity): cubes recognised without reading every byte (median of %d cold runs)" % REPS}
     wb.release_inputs()
     three(data, idata)                                        # (resident again for the next measurement)
     # the reference's own sharing: contours once, handed to the three calls (cubes already resident from the calls above)
-    tic = time.perf_counter()
-    cont = wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False)
-    t_cont = time.perf_counter() - tic
-    secs_c, rows_c = three(data, idata, contours=cont)
-    out["contours_reuse"] = {"value": nt / (t_cont + sum(secs_c.values())), "unit": "timesteps/s", "calculate_contours_s": t_cont,
-                             "contour_rows": int(len(cont)), "seconds": secs_c, "rows_match": rows_c == rows,
-                             "what": "calculate_contours(original_coordinates=False) + the three calls with contours=frame"}
+    reuse = []
+    for rep in range(REPS):
+        tic = time.perf_counter()
+        cont = wb.calculate_contours(data=data, contour_levels=levels, original_coordinates=False)
+        t_cont = time.perf_counter() - tic
+        secs_c, rows_c = three(data, idata, contours=cont)
+        reuse.append((t_cont + sum(secs_c.values()), t_cont, secs_c, rows_c, int(len(cont))))
+    reuse.sort(key=lambda r: r[0])
+    tot_c, t_cont, secs_c, rows_c, ncont = reuse[len(reuse) // 2]
+    out["contours_reuse"] = {"value": nt / tot_c, "unit": "timesteps/s", "calculate_contours_s": t_cont,
+                             "contour_rows": ncont, "seconds": secs_c, "rows_match": rows_c == rows, "runs_s": [r[0] for r in reuse],
+                             "what": "calculate_contours(original_coordinates=False) + the three calls with contours=frame (cubes resident; median of %d runs)" % REPS}
     # every call uploads and traces for itself
     wb.release_inputs()
     engine.INPUT_CACHE = False
     try:
-        three(data, idata)
-        secs_n, _ = three(data, idata)
+        nocache = sorted((three(data, idata) for _ in range(max(3, REPS // 2 + 1))), key=lambda r: sum(r[0].values()))
+        secs_n = nocache[len(nocache) // 2][0]
     finally:
         engine.INPUT_CACHE = True
-    out["no_cache"] = {"value": nt / sum(secs_n.values()), "unit": "timesteps/s", "seconds": secs_n}
+    out["no_cache"] = {"value": nt / sum(secs_n.values()), "unit": "timesteps/s", "seconds": secs_n, "runs_s": [sum(r[0].values()) for r in nocache]}
     del warm
     return out
 

@@ -13,6 +13,15 @@ double wb_probe_read_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, int reps);
 /* ... and of a read by `grid` workgroups that each stream chunks of chunk_bytes from start to end (the scan's pattern: 256
    workgroups, 1.4 MB chunks); development yardstick */
 double wb_probe_streams_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, uint64_t chunk_bytes, int grid, int reps);
+/* The two lattice predicates of the streamer index evaluated ON THE DEVICE by the very functions wb_k_streamer_f234 calls
+   (csrc/wb_core.h: wb_chord_hits_segment -- `not chord.touches(contour)`, streamer_index.py:192-198 -- and
+   wb_segments_intersect, :233-236), for the randomized differential tests against an independent exact-rational statement
+   (tests/ogc_reference.py).  contour: n lattice points x / y; chord k joins the contour's vertices i1[k] and i2[k];
+   touches[k] <- 1 when the open chord meets the contour's interior nowhere.  pairs: segment (ax, ay)-(bx, by) against
+   (cx, cy)-(dx, dy), 8 ints each; intersects[k] <- 1 when the closed segments share a point. */
+int wb_test_chord_touches(wb_ctx* ctx, int n, const int32_t* x, const int32_t* y, int nchords, const int32_t* i1, const int32_t* i2,
+                          int32_t* touches);
+int wb_test_segments_intersect(wb_ctx* ctx, int npairs, const int32_t* seg8, int32_t* intersects);
 #ifdef __cplusplus
 }
 #endif

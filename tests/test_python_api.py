@@ -32,14 +32,31 @@ def _ring_area(r):
     return abs(oprop.ring_area(r))
 
 
+ROUNDING_FLIPS = {"checked": 0, "flips": 0}      # 2-decimal values compared by _check_events / how many differed by one unit
+
+
 def _check_events(frame, ref_rows, cols):
+    """every column against the oracle.  mean_var / intensity are ``(sum / areas).round(2)`` (index_utils.py:113-116): the sums
+    agree to 1e-6 relative (north_star; tests/helpers.py enforces that on the sums themselves), so the ROUNDED values are equal
+    unless the quotient sits within that distance of a rounding boundary x.xx5 -- then they may differ by exactly one unit of
+    the second decimal.  Such a flip is not absorbed silently: it must be explained by a quotient that close to a boundary
+    (recomputed here from the oracle's own sums), and it is counted (ROUNDING_FLIPS; test_rounding_flips_are_counted)."""
     assert frame.columns.to_list() == cols
     assert len(frame) == len(ref_rows)
     for (_, row), r in zip(frame.iterrows(), ref_rows):
         assert np.datetime64(row["date"]) == r["date"]
         assert row["level"] == r["level"]
         assert tuple(row["com"]) == tuple(r["com"])
-        assert abs(row["mean_var"] - r["mean_var"]) <= 0.0100001 and abs(row["intensity"] - r["intensity"]) <= 0.0100001
+        for col, q in (("mean_var", 1), ("intensity", 2)):
+            ROUNDING_FLIPS["checked"] += 1
+            if row[col] == r[col]:
+                continue
+            assert abs(row[col] - r[col]) <= 0.0100001, (col, row[col], r[col])
+            sums = np.asarray(r["_sums"], dtype=np.float64)
+            quot = sums[q] / sums[0]
+            frac = abs(quot * 100.0 - np.floor(quot * 100.0) - 0.5)                 # distance from a rounding boundary, in units of 0.01
+            assert frac <= 1e-6 * max(1.0, abs(quot) * 100.0), (col, row[col], r[col], quot)
+            ROUNDING_FLIPS["flips"] += 1
         assert row["event_area"] == r["event_area"]
         if "orientation" in r:
             assert row["orientation"] == r["orientation"]
@@ -675,3 +692,12 @@ def test_a_read_only_view_of_a_writeable_array_is_fingerprinted_in_full(hostsim_
     fresh = wb.GridField(base.copy(), data.dims, data.coords)
     c3 = wb.calculate_cutoffs(data=fresh, contour_levels=[2])
     assert len(c2) == len(c3) == len(c1) + 1
+
+
+def test_rounding_flips_are_counted():
+    """the 2-decimal columns of the frames checked by this module (run after the tests above): compared exactly; a difference of
+    one unit is only accepted next to a rounding boundary and is reported here instead of hiding in a 0.01 tolerance"""
+    if ROUNDING_FLIPS["checked"] == 0:
+        pytest.skip("no frame was compared in this session")
+    print("2-decimal values compared: %(checked)d, differing by one unit next to a rounding boundary: %(flips)d" % ROUNDING_FLIPS)
+    assert ROUNDING_FLIPS["flips"] <= max(1, ROUNDING_FLIPS["checked"] // 200)

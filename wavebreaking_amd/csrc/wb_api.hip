@@ -422,8 +422,13 @@ static int run_phase1(wb_batch* b) {
             sa.cap_vs = caps + ctx->scan_pad;
             sa.debug = ctx->scan_debug;
             const long long lists = items * sa.nbands;
+            // the strips of a workgroup hand each other the halo column through LDS when a band's rows fit (vector loads only)
+            sa.halo_rows = (vec && p.dtype == 0 && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
+            // keys only (option "scan_keys_only", the default where the 13 x 4 streaming kernel runs): a patch is stored as its
+            // key, wb_k_scan_build reads the values from the field
+            sa.keys_only = (ctx->scan_keys_only && p.dtype == 0 && vec && sa.halo_rows && variant == 2) ? 1 : 0;
             sa.cap_k = balloc<uint32_t>(b, (size_t)lists * sa.cap_vs);
-            sa.cap_v = balloc<unsigned char>(b, (size_t)lists * sa.cap_vs * 10 * esz);
+            sa.cap_v = balloc<unsigned char>(b, sa.keys_only ? 256 : (size_t)lists * sa.cap_vs * 10 * esz);
             sa.cap_n = balloc<int>(b, (size_t)lists);
             unsigned char* spare = balloc<unsigned char>(b, (size_t)p.nlon * esz + 64);
             if (!sa.cap_n || !sa.cap_v || !sa.cap_k || !spare) return 1;
@@ -432,9 +437,7 @@ static int run_phase1(wb_batch* b) {
             sa.spare_row = spare;
             b->phase1_scratch.push_back(sa.cap_k); b->phase1_scratch.push_back(sa.cap_v); b->phase1_scratch.push_back(sa.cap_n);
             b->phase1_scratch.push_back(spare);
-            // the strips of a workgroup hand each other the halo column through LDS when a band's rows fit (vector loads only)
-            sa.halo_rows = (vec && p.dtype == 0 && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
-            const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz)    // a patch buffer per wave
+            const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (sa.keys_only ? 4 : 4 + 10 * esz)    // a patch buffer per wave
                                 + (size_t)b->nwork_strips * sa.halo_rows * (esz + 4);
             sa.cursor = ctx->scan_dynamic ? &b->d_ctl->scan_cursor : nullptr;       // (the control block was zeroed above)
             long long mwg = slots * (ctx->scan_grid_mult > 0 ? ctx->scan_grid_mult : 1);
@@ -449,7 +452,9 @@ static int run_phase1(wb_batch* b) {
             if (!sa.halo_rows) hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6, false>), mgrid, sblock, slds, ctx->stream, sa); \
             else switch (variant) { \
                 case 1: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 10, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
-                case 2: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 13, 4, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
+                case 2: if (sa.keys_only) hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 13, 4, true, true>), mgrid, sblock, slds, ctx->stream, sa); \
+                        else hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 13, 4, true>), mgrid, sblock, slds, ctx->stream, sa); \
+                        break; \
                 case 3: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 6, 8, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
                 case 4: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 9, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
                 case 5: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
@@ -513,12 +518,12 @@ static int run_phase1(wb_batch* b) {
         if (nmax > 8184) nmax = 8184;
         WbFusedArgs fa;
         memset(&fa, 0, sizeof(fa));
-        fa.nmax = nmax; fa.smax = nmax / 16 + 160; fa.cmax = ctx->trace_cmax > 0 ? ctx->trace_cmax : 256; fa.nwork = b->nwork_strips;
+        fa.nmax = nmax; fa.smax = nmax / 16 + 128; fa.cmax = ctx->trace_cmax > 0 ? ctx->trace_cmax : 256; fa.nwork = b->nwork_strips;
         size_t lds_block = 0, lds_cu = 0;
         wb_lds_limits(ctx, &lds_block, &lds_cu);
         WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
         while (L.total > lds_cu / 2 && fa.nmax > 1024) {        // never more than half a CU's LDS: smaller jobs only
-            fa.nmax -= 256; fa.smax = fa.nmax / 16 + 160;
+            fa.nmax -= 256; fa.smax = fa.nmax / 16 + 128;
             L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
         }
         bool ok = L.total <= lds_cu / 2;
@@ -836,6 +841,61 @@ extern "C" int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_
     o->y = g.y.data();
     return 0;
 }
+// ---- development: the streamer index' two lattice predicates on the device (include/wavebreaking_hip_dev.h)
+WB_KERNEL(wb_k_test_chord_touches, int n, const int* x, const int* y, int nchords, const int* i1, const int* i2, int* out) {
+    for (int k = WB_BLOCK_ID; k < nchords; k += WB_GRID_DIM) {
+        WB_SHARED(int, hit, 1);
+        WB_SINGLE
+        hit[0] = 0;
+        WB_END_SINGLE
+        const int px = x[i1[k]], py = y[i1[k]], qx = x[i2[k]], qy = y[i2[k]];
+        WB_PFOR(m, n - 1)
+            if (wb_chord_hits_segment(px, py, qx, qy, x[m], y[m], x[m + 1], y[m + 1], x[0], y[0], x[n - 1], y[n - 1])) hit[0] = 1;
+        WB_END_PFOR
+        WB_SINGLE
+        out[k] = hit[0] ? 0 : 1;
+        WB_END_SINGLE
+    }
+}
+WB_KERNEL(wb_k_test_segments_intersect, int np, const int* s8, int* out) {
+    for (int b0 = WB_BLOCK_ID * 256; b0 < np; b0 += WB_GRID_DIM * 256) {
+        WB_PFOR(t, 256)
+            const int k = b0 + (int)t;
+            if (k < np) {
+                const int* s = s8 + (size_t)k * 8;
+                out[k] = wb_segments_intersect(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]) ? 1 : 0;
+            }
+        WB_END_PFOR
+    }
+}
+extern "C" int wb_test_chord_touches(wb_ctx* ctx, int n, const int32_t* x, const int32_t* y, int nchords, const int32_t* i1, const int32_t* i2,
+                                     int32_t* touches) {
+    if (!ctx || n < 2 || nchords < 0 || !x || !y || (nchords && (!i1 || !i2 || !touches))) return 1;
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
+    int* d = (int*)dmalloc(ctx, ((size_t)2 * n + (size_t)3 * nchords + 4) * sizeof(int));
+    if (!d) return wb_fail(ctx, "out of device memory");
+    int *dx = d, *dy = d + n, *d1 = d + 2 * n, *d2 = d1 + nchords, *dout = d2 + nchords;
+    h2d(ctx, dx, x, (size_t)n * 4); h2d(ctx, dy, y, (size_t)n * 4);
+    if (nchords) { h2d(ctx, d1, i1, (size_t)nchords * 4); h2d(ctx, d2, i2, (size_t)nchords * 4); }
+    WB_LAUNCH(wb_k_test_chord_touches, nchords < 1024 ? (nchords > 0 ? nchords : 1) : 1024, 256, n, dx, dy, nchords, d1, d2, dout);
+    int rc = dsync(ctx);
+    if (!rc && nchords) rc = d2h(ctx, touches, dout, (size_t)nchords * 4);
+    dfree(ctx, d);
+    return rc;
+}
+extern "C" int wb_test_segments_intersect(wb_ctx* ctx, int npairs, const int32_t* seg8, int32_t* intersects) {
+    if (!ctx || npairs < 0 || (npairs && (!seg8 || !intersects))) return 1;
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
+    int* d = (int*)dmalloc(ctx, ((size_t)9 * npairs + 4) * sizeof(int));
+    if (!d) return wb_fail(ctx, "out of device memory");
+    if (npairs) h2d(ctx, d, seg8, (size_t)npairs * 8 * 4);
+    WB_LAUNCH(wb_k_test_segments_intersect, (npairs + 255) / 256 > 0 ? ((npairs + 255) / 256 < 1024 ? (npairs + 255) / 256 : 1024) : 1, 256, npairs, d, d + (size_t)8 * npairs);
+    int rc = dsync(ctx);
+    if (!rc && npairs) rc = d2h(ctx, intersects, d + (size_t)8 * npairs, (size_t)npairs * 4);
+    dfree(ctx, d);
+    return rc;
+}
+
 extern "C" int wb_set_step_offset(wb_batch* b, int64_t first_step) {
     if (!b) return 1;
     b->step_offset = first_step;
@@ -1369,6 +1429,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         int *ot_n = nullptr, *ot_box = nullptr, *ot_orient = nullptr;
         double* ot_sums = nullptr;
 
+        WbBoxComArgs ba;
+        long long boxcom_grid = 0;
         if (do_ot) {
             ot_n = (int*)talloc(nsel_b * sizeof(int));
             ot_box = (int*)talloc((size_t)nsel_b * WB_OT_CAP * 4 * sizeof(int));
@@ -1388,22 +1450,37 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "overturn");
             WB_LAUNCH_LDS(wb_k_overturn, nsel_b, 256, (size_t)b->W * 8 + 32, oa);
             b->timer.end(ctx);
+            // the boxes wb_k_overturn queued (their truncated centre of mass could turn on the last bits of the reference's
+            // cell-by-cell sums): a persistent grid of single-wave workgroups takes them one at a time.  WHEN it runs is an
+            // option ("boxcom_after"): its twelve workgroups per CU hold 156 KB of a CU's LDS for half a millisecond, and right
+            // behind wb_k_overturn that is beside wb_k_streamer_prep, which then waits for LDS (0.40 ms instead of 0.13)
             if (box_sums) {
-                // the boxes wb_k_overturn queued (their truncated centre of mass could turn on the last bits of the reference's
-                // cell-by-cell sums): a persistent grid of single-wave workgroups takes them one at a time
-                WbBoxComArgs ba;
                 memset(&ba, 0, sizeof(ba));
                 ba.nlat = p.nlat; ba.W = b->W; ba.ctl = ctl; ba.boxq = boxq; ba.ot_box = ot_box; ba.wlat = T->base + T->o_wlat;
                 ba.ot_sums = ot_sums;
-                long long g = (long long)ctx->boxcom_per_cu * wb_num_cus(ctx), most = (long long)nsel_b * 4;
-                if (g > most) g = most;
-                if (g < 1) g = 1;
-                b->timer.begin(ctx, "box_com");
-                WB_LAUNCH(wb_k_box_com, g, 64, ba);
-                b->timer.end(ctx);
+                boxcom_grid = (long long)ctx->boxcom_per_cu * wb_num_cus(ctx);
+                const long long most = (long long)nsel_b * 4;
+                if (boxcom_grid > most) boxcom_grid = most;
+                if (boxcom_grid < 1) boxcom_grid = 1;
+                if (ctx->boxcom_after == 0 || !do_st) {
+                    b->timer.begin(ctx, "box_com");
+                    WB_LAUNCH(wb_k_box_com, boxcom_grid, 64, ba);
+                    b->timer.end(ctx);
+                    boxcom_grid = 0;
+                }
             }
             side_end(ctx);
         }
+        // (option boxcom_after = 1 / 2: on the side stream behind wb_k_streamer_prep / wb_k_streamer_pairs2 of the main stream)
+        auto boxcom_here = [&](int stage) {
+            if (boxcom_grid <= 0 || ctx->boxcom_after != stage) return;
+            side_begin(ctx);
+            b->timer.begin(ctx, "box_com");
+            WB_LAUNCH(wb_k_box_com, boxcom_grid, 64, ba);
+            b->timer.end(ctx);
+            side_end(ctx);
+            boxcom_grid = 0;
+        };
 
         // ---- streamers
         int *ev_n = nullptr, *ev_ind = nullptr;
@@ -1487,6 +1564,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "streamer_prep");
             WB_LAUNCH(wb_k_streamer_prep, nsel_b, 256, st);
             b->timer.end(ctx);
+            boxcom_here(1);
             b->timer.begin(ctx, "streamer_pairs");
             if (st.p2_cap > 0) {
                 { long long g2 = (long long)nsel_b * st.p2_split, res = (long long)ctx->p2_grid_x2 * wb_num_cus(ctx) / 2 - ctx->persist_slack;   // persistent: two workgroups of 16 waves per CU (minus option persist_slack)
@@ -1497,6 +1575,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             }
             if (need_tiled && items_b > 0) WB_LAUNCH(wb_k_streamer_pairs, items_b, 64, st);
             b->timer.end(ctx);
+            boxcom_here(2);
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_pairs_order, 1, WB_LIST_THREADS, st);
             { long long res = 2LL * wb_num_cus(ctx) - ctx->persist_slack; if (res < 1) res = 1; WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
@@ -2017,6 +2096,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "eager_f2")) { ctx->eager_f2 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "keep_device")) { ctx->keep_device = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
+    if (!strcmp(name, "scan_keys_only")) { ctx->scan_keys_only = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     if (!strcmp(name, "scan_grid_mult")) { ctx->scan_grid_mult = value; return 0; }
     if (!strcmp(name, "scan_dynamic")) { ctx->scan_dynamic = value ? 1 : 0; return 0; }
@@ -2038,6 +2118,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "scan_band_rows")) { ctx->scan_band_rows = value; return 0; }
     if (!strcmp(name, "polys_grid")) { ctx->polys_grid = value > 0 ? value : 2048; return 0; }
     if (!strcmp(name, "boxcom_per_cu")) { ctx->boxcom_per_cu = value > 0 ? value : 12; return 0; }
+    if (!strcmp(name, "boxcom_after")) { ctx->boxcom_after = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (!strcmp(name, "timers")) { ctx->timers = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
 #if !defined(WB_HOSTSIM)
     // value = first * 1000 + count compute units (count 0: no mask)

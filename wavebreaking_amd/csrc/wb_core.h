@@ -361,29 +361,46 @@ WB_HD inline int64_t wb_orient(int64_t ax, int64_t ay, int64_t bx, int64_t by, i
 }
 WB_HD inline bool wb_opposite(int64_t a, int64_t b) { return (a > 0 && b < 0) || (a < 0 && b > 0); }
 
-// Does the OPEN chord (p,q) meet the closed contour segment [a,b] in a point that is interior to
-// the contour?  a_end / b_end: a (b) is an end vertex of the contour polyline (contour boundary).
-// This is the per-segment term of `not chord.touches(contour)`, streamer_index.py:192-198.
-WB_HD inline bool wb_chord_hits_segment(int px, int py, int qx, int qy, int ax, int ay, int bx, int by,
-                                        bool a_end, bool b_end) {
+// Does the OPEN chord (p,q) meet the closed contour segment [a,b] in a point that is interior to the contour?  This is the
+// per-segment term of `not chord.touches(contour)`, streamer_index.py:192-198 (DE-9IM: the interiors must not meet).  The
+// contour's boundary is the POINT SET of its two end vertices e0, e1 (packed x | y << 16; equal: a closed line, no
+// boundary): a location that is an end vertex is boundary wherever else the line passes through it -- a later segment with a
+// long step, (3,0) after the first-occurrence dedupe of contour_index.py:110-112, runs OVER earlier vertices, the first one
+// included.  Until round 5 "end vertex" was decided by the segment's index, which differs exactly there: a chord through
+// the first vertex that crosses such a segment AT that vertex (found by the randomized differential test against
+// tests/ogc_reference.py, an independent exact-rational statement; never on a traced full-span contour, whose end
+// vertices lie on the grid's edge columns).
+WB_HD inline bool wb_chord_hits_segment(int px, int py, int qx, int qy, int ax, int ay, int bx, int by, uint32_t e0, uint32_t e1) {
     const int64_t d1 = wb_orient(px, py, qx, qy, ax, ay);
     const int64_t d2 = wb_orient(px, py, qx, qy, bx, by);
     const int64_t dx = qx - px, dy = qy - py;
     const int64_t L = dx * dx + dy * dy;
     const int64_t ta = (int64_t)(ax - px) * dx + (int64_t)(ay - py) * dy;
     const int64_t tb = (int64_t)(bx - px) * dx + (int64_t)(by - py) * dy;
-    if (d1 == 0 && d2 == 0) {  // collinear: overlap of positive length
+    if (d1 == 0 && d2 == 0) {  // collinear: overlap of positive length (infinitely many points, at most two of them boundary)
         int64_t lo = ta < tb ? ta : tb, hi = ta < tb ? tb : ta;
         if (lo < 0) lo = 0;
         if (hi > L) hi = L;
         return hi > lo;
     }
+    const bool open_ends = e0 != e1;
+    const int e0x = (int)(e0 & 0xFFFFu), e0y = (int)(e0 >> 16), e1x = (int)(e1 & 0xFFFFu), e1y = (int)(e1 >> 16);
     const int64_t d3 = wb_orient(ax, ay, bx, by, px, py);
     const int64_t d4 = wb_orient(ax, ay, bx, by, qx, qy);
-    if (wb_opposite(d1, d2) && wb_opposite(d3, d4)) return true;  // proper crossing
-    if (d1 == 0 && ta > 0 && ta < L && !a_end) return true;        // contour vertex on the open chord
-    if (d2 == 0 && tb > 0 && tb < L && !b_end) return true;
+    if (wb_opposite(d1, d2) && wb_opposite(d3, d4)) {
+        // proper crossing, in the ONE point the two lines share: interior unless that point is an end vertex of the contour
+        if (open_ends && wb_orient(px, py, qx, qy, e0x, e0y) == 0 && wb_orient(ax, ay, bx, by, e0x, e0y) == 0) return false;
+        if (open_ends && wb_orient(px, py, qx, qy, e1x, e1y) == 0 && wb_orient(ax, ay, bx, by, e1x, e1y) == 0) return false;
+        return true;
+    }
+    // a contour vertex on the open chord
+    if (d1 == 0 && ta > 0 && ta < L && !(open_ends && ((ax == e0x && ay == e0y) || (ax == e1x && ay == e1y)))) return true;
+    if (d2 == 0 && tb > 0 && tb < L && !(open_ends && ((bx == e0x && by == e0y) || (bx == e1x && by == e1y)))) return true;
     return false;
+}
+// ... for callers that hold the end vertices as coordinates
+WB_HD inline bool wb_chord_hits_segment(int px, int py, int qx, int qy, int ax, int ay, int bx, int by, int e0x, int e0y, int e1x, int e1y) {
+    return wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, (uint32_t)e0x | ((uint32_t)e0y << 16), (uint32_t)e1x | ((uint32_t)e1y << 16));
 }
 
 WB_HD inline bool wb_on_closed(int ax, int ay, int bx, int by, int cx, int cy) {

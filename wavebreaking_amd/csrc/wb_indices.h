@@ -831,6 +831,7 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a) {
     const size_t jb = (size_t)job * a.cap_seg;
     const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
     const int N = a.c_len[jb + k];
+    const uint32_t pe0 = pts[0], pe1 = pts[N - 1];            // the contour's end vertices: its boundary, as a point set (wb_chord_hits_segment)
     const int* bbx = a.bbx + 4 * ((a.poff[s] >> 5) + s);
     const int nblk = (N + WB_BLK - 1) / WB_BLK;
     const unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
@@ -874,7 +875,7 @@ WB_KERNEL(wb_k_streamer_f2, WbStreamerArgs a) {
                 pa = pb;
                 // a segment whose box misses the chord's box cannot meet the chord: skip the exact predicate
                 if ((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)) continue;
-                hit = wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2);
+                hit = wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1);
             }
         }
         if (hit) alive[p] = 2;   // 2 = rejected by routine 2 (turned into 0 by f3)
@@ -1166,6 +1167,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     const int nal = a.nalive[s];
     const bool in_lds = N <= a.f234_cap;
     const uint32_t* pts = in_lds ? lpts : gpts;
+    const uint32_t pe0 = gpts[0], pe1 = gpts[N - 1];          // the contour's end vertices: its boundary, as a point set (wb_chord_hits_segment)
     int* rmax = in_lds ? lrmax : a.rowmx + a.poff[s];
     const int nw = (N + 31) >> 5;
     WB_STAMP_BEGIN
@@ -1301,7 +1303,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                             const uint32_t pa = pts[m], pb = pts[m + 1];
                             const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
                             if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                                if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) sh[hf] = 1;
+                                if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) sh[hf] = 1;
                         }
                     WB_END_PFOR
                 } else {
@@ -1311,7 +1313,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                     const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
                     // a segment whose box misses the chord's box cannot meet the chord
                     if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, m == 0, m == N - 2)) sh[hf] = 1;
+                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) sh[hf] = 1;
                 WB_END_PFOR
                 }
                 WB_STAMP(a.ctl, 6);
@@ -1430,7 +1432,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                                 const int c = wb_ctz32(near);
                                 near &= near - 1u;
                                 const uint32_t pq = hq[c];
-                                if (wb_chord_hits_segment(px, py, wb_pt_x(pq), wb_pt_y(pq), ax, ay, bx, by, m == 0, m == N - 2)) hits |= 1u << c;
+                                if (wb_chord_hits_segment(px, py, wb_pt_x(pq), wb_pt_y(pq), ax, ay, bx, by, pe0, pe1)) hits |= 1u << c;
                             }
                             if (hits) wb_atomic_or(&hitm[0], hits);
                         WB_END_PFOR

@@ -61,6 +61,7 @@ struct WbScanArgs {
                             // list: cap_rec + a pad -- with the power of two itself every plane of every list started on the same
                             // 4 KB phase, and the scan's patch stores took 0.1 or 0.3 ms by where the scratch lay
     int debug;              // development: bit 0 = the streaming scan stores no patches (streaming ceiling of the traversal)
+    int keys_only;          // two-kernel scan: the patch lists hold keys only (cap_v unused); wb_k_scan_build reads the values from the field
     int nbands, band_rows;  // streaming scan: a time step is cut into nbands bands of band_rows rows of squares; the lists above
                             // are then per (time step, band, strip): index (t * nbands + band) * nwork + strip
     const void* spare_row;  // streaming scan: nlon values that every workgroup reads instead of rows past its band's end (always cached)
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
 // copies) -- the staging format the trace kernels read.  It touches the captured patches only (a few % of the field).
 // Patch layout: value k (0..4 upper row, 5..9 lower row) of patch i of a list at cap_v[list][k * cap_rec + i].
 #define WB_BUILD_CHUNK 1024
+#define WB_BUILD_KO_CHUNK 512
 // in-place exclusive scan of 64-bit values in LDS (two 32-bit counters per word, no carry between them as long as each
 // stays below 2^32); every thread of the block calls it; returns the total
 __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* a, int n) {
@@ -539,17 +541,35 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
     unsigned long long cur[NLEV];                            // segments written so far: base list | copy list << 32
 #pragma unroll
     for (int l = 0; l < NLEV; ++l) { lvl[l] = wb_level_lo<T>(a.levels[l]); cur[l] = 0ull; }
-    for (int q0 = 0; q0 < total; q0 += WB_BUILD_CHUNK) {
-        const int nq = total - q0 < WB_BUILD_CHUNK ? total - q0 : WB_BUILD_CHUNK;
+    // keys only: a patch's ten values are read from the FIELD (two short runs of a row each: not coalesced) -- once: they stay in
+    // LDS for the levels' emit passes below (chunks of 512 patches then: 20 KB)
+    __shared__ float lvf[10 * WB_BUILD_KO_CHUNK];
+    const int CH = a.keys_only ? WB_BUILD_KO_CHUNK : WB_BUILD_CHUNK;
+    for (int q0 = 0; q0 < total; q0 += CH) {
+        const int nq = total - q0 < CH ? total - q0 : CH;
         for (int i = threadIdx.x; i < nq; i += blockDim.x) {
             size_t gl; int li;
             locate(q0 + i, gl, li);
             const uint32_t key = a.cap_k[gl * cs + li];
             const int c0 = (int)(key & 0xFFFFu);
-            const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
             T v[10];
+            if (a.keys_only) {
+                // the patch's 2 x 5 values from the field: columns c0 .. c0 + 4 (mod nlon) of rows r and r + 1, as the streaming
+                // kernel saw them (a lane's four columns + its right neighbour's first / column 0 behind the row's end)
+                const T* f0 = (const T*)a.field + ((size_t)t * a.nlat + (key >> 16)) * nlon;
 #pragma unroll
-            for (int k = 0; k < 10; ++k) v[k] = d[k * cs];
+                for (int k = 0; k < 5; ++k) {
+                    const int cc = c0 + k >= nlon ? c0 + k - nlon : c0 + k;
+                    v[k] = f0[cc];
+                    v[5 + k] = f0[nlon + cc];
+                }
+#pragma unroll
+                for (int k = 0; k < 10; ++k) lvf[k * WB_BUILD_KO_CHUNK + i] = (float)v[k];     // (keys only runs on float fields)
+            } else {
+                const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) v[k] = d[k * cs];
+            }
             unsigned long long word = 0ull;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                 locate(q0 + i, gl, li);
                 const uint32_t key = a.cap_k[gl * cs + li];
                 const int r = (int)(key >> 16), c0 = (int)(key & 0xFFFFu);
-                const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
+                const T* d = a.keys_only ? nullptr : (const T*)a.cap_v + gl * cs * 10 + li;
                 const unsigned long long at = cur[l] + cb[i];
                 int mine = (int)(at & 0xFFFFFFFFull), cmine = (int)(at >> 32);
 #pragma unroll
@@ -602,7 +622,11 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                     const int cs2 = (int)(cw >> (4 * k)) & 15;
                     const int ns = wb_case_nseg(cs2);
                     if (ns) {
-                        const T ul = d[k * cs], ur = d[(k + 1) * cs], ll = d[(5 + k) * cs], lr = d[(6 + k) * cs];
+                        T ul, ur, ll, lr;
+                        if (a.keys_only) {
+                            ul = (T)lvf[k * WB_BUILD_KO_CHUNK + i]; ur = (T)lvf[(k + 1) * WB_BUILD_KO_CHUNK + i];
+                            ll = (T)lvf[(5 + k) * WB_BUILD_KO_CHUNK + i]; lr = (T)lvf[(6 + k) * WB_BUILD_KO_CHUNK + i];
+                        } else { ul = d[k * cs]; ur = d[(k + 1) * cs]; ll = d[(5 + k) * cs]; lr = d[(6 + k) * cs]; }
                         wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs2, ns, ul, ur, ll, lr, mine);
                         if (has_copy && c0 + k < a.padd - 1)
                             wb_store_square<T>(a.stg_k + cbase, (T*)a.stg_v + cbase * 4, a.cap_strip, W, r, c0 + k + nlon, cs2, ns, ul, ur, ll, lr, cmine);

@@ -72,7 +72,11 @@ __device__ inline float wb_lds_wait_eq(uint32_t addr_tag, uint32_t tag, uint32_t
 
 // HL: the strips of a workgroup exchange their halo columns through LDS (a.halo_rows slots per strip); else scalar loads
 // (deeper rings at three waves per SIMD -- 16 x 3, 18 x 3 with a 512-thread launch bound -- were slower: 1.33 ms against 1.17)
-template <typename T, bool VEC, int NLEV, int D, int WPS, bool HL>
+// KO ("keys only", round 5): a captured patch is stored as its key alone -- 4 bytes instead of 44 -- and wb_k_scan_build takes the
+// ten values from the field itself (the rows were just streamed: a few hundred KB per time step, mostly still in the L2).  The
+// patch stores were what made this kernel take 1.10 ms in one placement of its scratch and 1.28 ms in the next (0.2 GB of
+// stores beside 6 GB of reads): with a tenth of the bytes the dependence goes with them.
+template <typename T, bool VEC, int NLEV, int D, int WPS, bool HL, bool KO = false>
 __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // strip = wave of the workgroup
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
     typedef const __attribute__((address_space(4))) T* CT;
     // this wave's patch buffer in LDS: keys, then the ten values as ten arrays (plain 4 / 8 byte LDS stores, no tuples)
     extern __shared__ __attribute__((aligned(16))) uint32_t wb_stream_lds[];
-    constexpr int LW = WB_STREAM_LBUF * (1 + 10 * (int)(sizeof(T) / 4));      // dwords per wave
+    constexpr int LW = KO ? WB_STREAM_LBUF : WB_STREAM_LBUF * (1 + 10 * (int)(sizeof(T) / 4));      // dwords per wave
     uint32_t* lkey = wb_stream_lds + (size_t)s * LW;
     T* lval = reinterpret_cast<T*>(lkey + WB_STREAM_LBUF);
     // halo exchange between the strips of the workgroup (when a.halo_rows > 0): strip s publishes, for every row of the
@@ -161,8 +165,10 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
             if (a.debug & 1) w = 0;
             for (int j = lane; j < w; j += 64) {
                 ck[count + j] = lkey[j];
+                if (!KO) {
 #pragma unroll
-                for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_vs + count + j] = lval[k * WB_STREAM_LBUF + j];
+                    for (int k = 0; k < 10; ++k) cv[(size_t)k * a.cap_vs + count + j] = lval[k * WB_STREAM_LBUF + j];
+                }
             }
             const int rem = fill - n;                             // < 32, and n >= 32 whenever rem > 0: sources lie behind every destination
             if (rem > 0) {
@@ -170,13 +176,17 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
                 T vv[10];
                 if (lane < rem) {
                     kk = lkey[n + lane];
+                    if (!KO) {
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) vv[k] = lval[k * WB_STREAM_LBUF + n + lane];
+                        for (int k = 0; k < 10; ++k) vv[k] = lval[k * WB_STREAM_LBUF + n + lane];
+                    }
                 }
                 if (lane < rem) {
                     lkey[lane] = kk;
+                    if (!KO) {
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) lval[k * WB_STREAM_LBUF + lane] = vv[k];
+                        for (int k = 0; k < 10; ++k) lval[k * WB_STREAM_LBUF + lane] = vv[k];
+                    }
                 }
             }
             count += n;
@@ -241,10 +251,12 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
                 if (hit) {
                     const int pos = fill + __popcll(m & ltmask);
                     lkey[pos] = ((uint32_t)r << 16) | (uint32_t)c0;
-                    T* d = lval + pos;                        // value k of the buffered patch pos at lval[k * WB_STREAM_LBUF + pos]
-                    d[0] = P.x; d[WB_STREAM_LBUF] = P.y; d[2 * WB_STREAM_LBUF] = P.z; d[3 * WB_STREAM_LBUF] = P.w; d[4 * WB_STREAM_LBUF] = p4;
-                    d[5 * WB_STREAM_LBUF] = N.x; d[6 * WB_STREAM_LBUF] = N.y; d[7 * WB_STREAM_LBUF] = N.z; d[8 * WB_STREAM_LBUF] = N.w;
-                    d[9 * WB_STREAM_LBUF] = n4;
+                    if (!KO) {
+                        T* d = lval + pos;                    // value k of the buffered patch pos at lval[k * WB_STREAM_LBUF + pos]
+                        d[0] = P.x; d[WB_STREAM_LBUF] = P.y; d[2 * WB_STREAM_LBUF] = P.z; d[3 * WB_STREAM_LBUF] = P.w; d[4 * WB_STREAM_LBUF] = p4;
+                        d[5 * WB_STREAM_LBUF] = N.x; d[6 * WB_STREAM_LBUF] = N.y; d[7 * WB_STREAM_LBUF] = N.z; d[8 * WB_STREAM_LBUF] = N.w;
+                        d[9 * WB_STREAM_LBUF] = n4;
+                    }
                 }
                 fill += __popcll(m);
                 if (fill > WB_STREAM_LBUF - 64) flush(false); // no room for another full row (rare: the regular flush is below)

@@ -48,7 +48,7 @@ struct WbFusedLayout {
     size_t oA, oB, oT, total;
     size_t t_rawbase, t_closed;      // per contour, from the numbering to the end
     // group 1 (link + ranking) and group 2 (finish) share what follows
-    size_t g1_hp, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_q1, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
+    size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_q1, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
     size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
 };
 WB_HD inline size_t wb_f_al(size_t v) { return (v + 7) & ~(size_t)7; }
@@ -66,6 +66,7 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     size_t g1 = t;
     const size_t S1 = (size_t)smax + 2;
     L.g1_hp = g1; g1 += wb_f_al(4 * (((size_t)nmax + 31) / 32 + 1));
+    L.g1_wpre = g1; g1 += wb_f_al(4 * (((size_t)nmax + 31) / 32 + 2));
     L.g1_ndseg = g1; g1 += wb_f_al(2 * S1);
     L.g1_nlen = g1; g1 += wb_f_al(2 * S1);
     L.g1_ncp = g1; g1 += wb_f_al(2 * S1);
@@ -142,9 +143,12 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     const WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, nlon, WB_FUSED_THREADS);
     WB_DYN_SHARED(unsigned char, lds, L.total);
     uint32_t* const K = (uint32_t*)(lds + L.oA);               // keys; later raw points
-    uint32_t* const ol = K;                                    // (ranking) splitter ordinal that owns the segment | position inside its sub-list (from 1) << 16
-#define WB_F_OWN(g) ((int)(ol[g] & 0xFFFFu))
-#define WB_F_LP(g) ((int)(ol[g] >> 16))
+    // (ranking) a link word S[g]: 0x8000 | successor until a walk has visited the segment, then owner << 5 | (position in its
+    // sub-list - 1) -- 10 + 5 bits: at most 1023 splitters, sub-lists of at most WB_F_WALK = 32 segments.  The keys stay in
+    // region A until the raw points replace them: the chains' smallest / largest keys are read from LDS, not from the lists again.
+#define WB_F_UNVISITED 0x8000u
+#define WB_F_OWN(g) ((int)(S[g] >> 5))
+#define WB_F_LP(g) ((int)(S[g] & 31u) + 1)
     uint32_t* const rawpt = K;                                 // raw points in contour order: contour << (xb + yb) | y << xb | x
     uint16_t* const S = (uint16_t*)(lds + L.oB);               // successor | flags; later: destination of the segment's point; later: bucket order
     uint16_t* const dest = S;
@@ -152,7 +156,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     unsigned char* const T = lds + L.oT;
     int* const rawbase = (int*)(T + L.t_rawbase);
     unsigned char* const closedn = T + L.t_closed;
-    uint32_t* const hp = (uint32_t*)(T + L.g1_hp);
+    uint32_t* const hp = (uint32_t*)(T + L.g1_hp);             // has-predecessor bits (link); then: splitter bits (ranking)
+    uint32_t* const spb = hp;
+    int* const wpre = (int*)(T + L.g1_wpre);                   // splitters in front of a word of spb
     uint16_t* const ndseg = (uint16_t*)(T + L.g1_ndseg);
     uint16_t* const nlen = (uint16_t*)(T + L.g1_nlen);
     uint16_t* const ncp = (uint16_t*)(T + L.g1_ncp);
@@ -312,7 +318,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             }
         }
         if (!open) {
-            S[g] = (uint16_t)sc;
+            S[g] = (uint16_t)(sc | WB_F_UNVISITED);
             if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
         }
     WB_END_PFOR
@@ -325,31 +331,35 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             uint32_t sc = WB_F_NIL;
             const int q = wb_f_lower(K, sbase[tl], sbase[tl + 1], target);
             if (q < sbase[tl + 1] && wb_key_sq(K[q]) == target) sc = pick(q, want);
-            S[g] = (uint16_t)sc;
+            S[g] = (uint16_t)(sc | WB_F_UNVISITED);
             if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
         WB_END_PFOR
     }
 
     WB_FSTAMP(a.ctl, 1);
-    // ---- C: list ranking.  C1: heads, splitters, their ordinals
-    int* const tmp = (int*)K;                                  // (the keys are done with: read again from the lists where needed)
-    WB_PFOR(g, n)
-        const bool head = !((hp[g >> 5] >> (g & 31)) & 1u);
-        const bool split = head || ((int)g % WB_F_SPLIT) == 0;
-        S[g] = (uint16_t)((S[g] & WB_F_NIL) | (head ? WB_F_HEAD : 0u) | (split ? WB_F_SPLITTER : 0u));
-        tmp[g] = split ? 1 : 0;
+    // ---- C: list ranking.  C1: splitters = chain heads (no predecessor) + every 16th segment, a word of 32 flags at a time:
+    // the has-predecessor bits turn into the splitter bits in place; a splitter's ordinal is the number of flags in front of it
+    const int nwords = (n + 31) / 32;
+    WB_PFOR(w, nwords)
+        const uint32_t valid = ((int)w + 1) * 32 <= n ? 0xFFFFFFFFu : ((1u << (n & 31)) - 1u);
+        const uint32_t f = (~hp[w] | 0x00010001u) & valid;           // (WB_F_SPLIT = 16: bits 0 and 16 of every word)
+        spb[w] = f;
+        wpre[w] = wb_popc32(f);
     WB_END_PFOR
-    const int S1 = wb_block_scan_excl(tmp, n);
-    if (S1 > fa.smax) WB_F_DECLINE();
-    WB_PFOR(g, n)
-        if (S[g] & WB_F_SPLITTER) ndseg[tmp[g]] = (uint16_t)g;
-    WB_END_PFOR
-    WB_PFOR(g, n)
-        ol[g] = WB_F_NONE;
+    const int S1 = wb_block_scan_excl(wpre, nwords);
+    if (S1 > fa.smax || fa.smax > 1023) WB_F_DECLINE();
+    WB_PFOR(w, nwords)
+        uint32_t f = spb[w];
+        int o = wpre[w];
+        while (f) {
+            const int bit = wb_ctz32(f);
+            f &= f - 1u;
+            ndseg[o++] = (uint16_t)((int)w * 32 + bit);
+        }
     WB_END_PFOR
     // C2: a thread walks from its splitter to the next one (no two walks meet: successors are one-to-one).  The longest walk
     // sets the phase's duration: after WB_F_WALK segments the walk makes the next segment a splitter of its own and goes on as
-    // that one.
+    // that one.  A visited segment's link word becomes owner | position (the walk has read the successor before).
     WB_SINGLE
     ctr[1] = S1;
     WB_END_SINGLE
@@ -357,12 +367,12 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         int j = (int)ndseg[o], cntw = 0;
         uint32_t end = WB_F_NIL, w = S[j];
         for (;;) {
+            S[j] = (uint16_t)(((uint32_t)o << 5) | (uint32_t)cntw);    // (position - 1 = cntw before the increment)
             ++cntw;
-            ol[j] = (uint32_t)o | ((uint32_t)cntw << 16);
             const uint32_t nx = w & WB_F_NIL;
             if (nx == WB_F_NIL) break;
-            const uint32_t wn = S[nx];                       // (the one dependent read of a step: flags now, successor next time round)
-            if (wn & WB_F_SPLITTER) { end = nx; break; }
+            const uint32_t fl = spb[nx >> 5], wn = S[nx];                // (independent reads: the next segment's flag word and its link)
+            if ((fl >> (nx & 31u)) & 1u) { end = nx; break; }
             j = (int)nx;
             w = wn;
             if (cntw == WB_F_WALK) {
@@ -382,27 +392,20 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         walk((int)o);
     WB_END_PFOR
     // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
-    auto key_of = [&](const int g) -> uint32_t {
-        int s, i;
-        wb_f_locate(sbase, g, &s, &i);
-        return a.stg_k[((size_t)job * NS + s) * a.cap_strip + i] & 0x07FFFFFFu;
-    };
     const int S2 = ctr[1];
     if (ctr[0] || S2 > fa.smax) WB_F_DECLINE();
     WB_PFOR(g, n)
         bool want = false;
-        if (ol[g] == WB_F_NONE) {
-            const uint32_t nx = S[g] & WB_F_NIL;
-            want = nx == WB_F_NIL || key_of((int)g) > key_of((int)nx);
+        const uint32_t w = S[g];
+        if (w & WB_F_UNVISITED) {
+            const uint32_t nx = w & WB_F_NIL;
+            want = nx == WB_F_NIL || (K[g] & 0x07FFFFFFu) > (K[nx] & 0x07FFFFFFu);
         }
         const int slot = wb_append_slot(&ctr[1], want);
-        if (want && slot < fa.smax) ndseg[slot] = (uint16_t)g;
+        if (want && slot < fa.smax) { ndseg[slot] = (uint16_t)g; wb_atomic_or(&spb[g >> 5], 1u << (g & 31)); }
     WB_END_PFOR
     const int S3 = ctr[1];
     if (S3 > fa.smax) WB_F_DECLINE();
-    WB_PFOR(o, S3 - S2)
-        S[ndseg[S2 + o]] |= (uint16_t)WB_F_SPLITTER;
-    WB_END_PFOR
     WB_PFOR(o, S3 - S2)
         walk(S2 + (int)o);
     WB_END_PFOR
@@ -471,26 +474,19 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 4);
     // keys again (coalesced, from the lists): every chain's smallest key (it numbers the contours), every loop's largest
-    WB_PFOR_B(g, gc, u, n)
-        const int i = wb_f_locate_run(sbase, (int)gc, &srun);
-        ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
-    WB_PFOR_B_USE(g, u)
-        const uint32_t key = ka[u] & 0x07FFFFFFu;
+    WB_PFOR(g, n)
+        const uint32_t key = K[g] & 0x07FFFFFFu;
         const int ch = cix[WB_F_OWN(g)];
         wb_atomic_min(&cmin[ch], key);
         if (cloop[ch]) wb_atomic_max(&cmaxk[ch], key);
-    WB_END_PFOR_B
+    WB_END_PFOR
     if (any_loop) {
         // the loop's raster-last segment: the contour starts behind it.  Cut the splitters' loop in
         // front of the node that holds it and rank again; the segments' positions are rotated below.
-        WB_PFOR_B(g, gc, u, n)
-            const int i = wb_f_locate_run(sbase, (int)gc, &srun);
-            ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
-        WB_PFOR_B_USE(g, u)
-            const uint32_t olw = ol[g];
-            const int ch = cix[olw & 0xFFFFu];
-            if (cloop[ch] && (ka[u] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = (uint16_t)(olw & 0xFFFFu); lpos[ch] = (uint16_t)(olw >> 16); }
-        WB_END_PFOR_B
+        WB_PFOR(g, n)
+            const int o = WB_F_OWN(g), ch = cix[o];
+            if (cloop[ch] && (K[g] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = (uint16_t)o; lpos[ch] = (uint16_t)WB_F_LP(g); }
+        WB_END_PFOR
         WB_PFOR(ch, C)
             if (cloop[ch]) ncp[lnode[ch]] = NN;
         WB_END_PFOR
@@ -519,9 +515,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // where every segment's end point goes (bit 15: the segment is its contour's first -- its start point goes in front).
     // Reads region A (own / lp) and the ranking's tables, writes region B.
     WB_PFOR(g, n)
-        const uint32_t olw = ol[g];
-        const int o = (int)(olw & 0xFFFFu), ch = cix[o];
-        int q = (int)(uint16_t)(Q[o] >> 16) + (int)(olw >> 16);      // position along the chain, from 1
+        const int o = WB_F_OWN(g), ch = cix[o];
+        int q = (int)(uint16_t)(Q[o] >> 16) + WB_F_LP(g);       // position along the chain, from 1 (dest is S's storage: read, then written, by this thread)
         if (cloop[ch]) {
             const int pl = (int)lpos[ch], tot = ctot[ch];
             q = q > pl ? q - pl : q - pl + tot;
@@ -757,6 +752,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_SINGLE
 #undef WB_F_DECLINE
 #undef WB_FQ
+#undef WB_F_OWN
+#undef WB_F_LP
 #undef WB_F_BUCKET
 #undef WB_F_XM
 }
