@@ -7,13 +7,14 @@ overturning and cutoff indices + event tables back in host memory) over ONE resi
 configs[1], 1.0 degree, level [2], the streamer index).  Inputs are generated on the device and are resident in
 HBM when the timed region starts.
 
-WHAT `value` IS: device-resident float32 field batch -> event tables in host memory -- per event its step / level /
-contour, end points or box, orientation, the five area-weighted sums of calculate_properties (index_utils.py:66-102),
-cell count, flags, the polygon vertices in grid indices AND (since round 5) the polygon in lon / lat: transform_polygons
-with the seam split (index_utils.py:129-184), cut, truncated and mapped by the device into pinned host memory
-(csrc/wb_geom.h; `without_geometry` on the line: the same passes with the context option geometry = 0).  NOT in `value`:
-the upload of the fields over PCIe (`end_to_end` measures the drop-in calls from a host cube, upload included), the last
-few flops of the property columns (:104-120; `stage_ms.geometry_host`) and the construction of the (Geo)DataFrame.
+WHAT `value` IS: device-resident float32 field batch -> INDEX-SPACE event tables in host memory -- per event its
+step / level / contour, end points or box, orientation, the five area-weighted sums of calculate_properties
+(index_utils.py:66-102), cell count, flags, and the polygon vertices in grid indices (the figure of the earlier rounds).
+`value_with_geometry` (since round 5, timed right behind it): the same passes with the library's default, which also leaves
+the polygons in lon / lat -- transform_polygons with the seam split (index_utils.py:129-184), cut, truncated and mapped by
+the device into pinned host memory (csrc/wb_geom.h).  NOT in either: the upload of the fields over PCIe (`end_to_end`
+measures the drop-in calls from a host cube, upload included), the last few flops of the property columns (:104-120;
+`stage_ms.geometry_host`) and the construction of the (Geo)DataFrame.
 
 `--streams` passes (default 2) are in flight per GPU at any time, each on its own context = HIP stream +
 host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.  The K passes are ONE
@@ -171,7 +172,11 @@ def main():
     stage_ms = {}
     counts = {}
     wall = {}
-    geometry_on = [True]          # the timed region runs the product's default: wb_indices also leaves the events' lon / lat rings
+    # `value` is the index-space figure of the earlier rounds (context option geometry = 0 in the timed region); the same passes WITH
+    # transform_polygons on the device -- the product's default -- are timed right behind it: `value_with_geometry`
+    geometry_on = [False]
+    for c in pipe.contexts:
+        c.set_option("geometry", 0)
 
     # one step = one pass of the hot path over the resident batch; the two ABI phases run on a worker thread of the
     # pass's context, the two exchanges of a multi-GPU run on this thread in pass order (wavebreaking_amd/pipeline.py)
@@ -309,24 +314,30 @@ def main():
         staggered = {"value": nt * a.stagger_steps / dt_s, "ms_per_step": 1e3 * dt_s / a.stagger_steps, "steps": a.stagger_steps,
                      "scan_launch_ms": sc, "roofline_frac": nt * nlat * nlon * 4 / (sc * 1e-3) / HBM_PEAK,
                      "what": "BatchPipeline.set_stagger(1): each ABI phase entered by one batch at a time"}
-    # the same passes WITHOUT transform_polygons on the device (context option geometry = 0: index-space tables only, what
-    # `value` was until round 4) -- what the lon / lat rings cost per pass
-    without_geometry = None
+    # the same passes WITH transform_polygons on the device (context option geometry = 1, the product's default): the events' polygons
+    # in lon / lat, cut at the last meridian, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h)
+    with_geometry = None
     if not multi and a.stagger_steps > 0:
-        geometry_on[0] = False
-        for c in pipe.contexts:
-            c.set_option("geometry", 0)
-        run_record(3, False)
-        torch.cuda.synchronize()
-        tic_g = time.perf_counter()
-        run_record(a.stagger_steps, False)
-        torch.cuda.synchronize()
-        dt_g = time.perf_counter() - tic_g
+        geometry_on[0] = True
         for c in pipe.contexts:
             c.set_option("geometry", 1)
-        geometry_on[0] = True
-        without_geometry = {"value": nt * a.stagger_steps / dt_g, "ms_per_step": 1e3 * dt_g / a.stagger_steps, "steps": a.stagger_steps,
-                            "what": "context option geometry = 0: index-space event tables only (round 4's `value`)"}
+        run_record(3, False)
+        torch.cuda.synchronize()
+        main_stage = {k: list(v) for k, v in stage_ms.items()}      # (the timed region's stage times stay what they are)
+        main_wall = {k: list(v) for k, v in wall.items()}
+        stage_ms.clear()
+        tic_g = time.perf_counter()
+        run_record(a.stagger_steps, True)             # (kept: its stage times carry the geometry kernels, its counts the rings)
+        torch.cuda.synchronize()
+        dt_g = time.perf_counter() - tic_g
+        geo_stage = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+        stage_ms.clear(); stage_ms.update(main_stage)
+        wall.clear(); wall.update(main_wall)
+        with_geometry = {"value": nt * a.stagger_steps / dt_g, "ms_per_step": 1e3 * dt_g / a.stagger_steps, "steps": a.stagger_steps,
+                         "rings": counts.get("geometry_rings"), "vertices": counts.get("geometry_vertices"),
+                         "stage_ms": {k: geo_stage.get(k) for k in ("polygons", "geometry", "props", "results") if k in geo_stage},
+                         "what": "context option geometry = 1 (the library's default): wb_indices also leaves the events' lon / lat rings "
+                                 "(transform_polygons, index_utils.py:129-184) in pinned host memory"}
     # outside `value`, for the record: what transform_polygons (index_utils.py:129-184) and the frame's property columns
     # (:104-120) cost per pass on the host -- one wb_get_event_geometry per index (the library's C++ seam split over the whole
     # table) + properties_from_sums, timed on this thread after the timed region
@@ -411,17 +422,18 @@ def main():
         if geometry_host is not None:
             out["stage_ms"]["geometry_host"] = geometry_host["ms"]
             out["geometry_host"] = geometry_host
-        out["value_with_geometry"] = out["value"]
-        if without_geometry is not None:
-            out["without_geometry"] = without_geometry
-            out["geometry_adds_ms_per_step"] = out["ms_per_step"] - without_geometry["ms_per_step"]
-        out["value_is"] = ("device-resident f32 field batch -> event tables of all requested indices in host memory (rows: step, level, "
-                           "contour, end points or box, orientation; the five area-weighted sums; cell counts; flags; polygon vertices in "
-                           "grid indices) AND, since round 5, the events' polygons in lon / lat -- transform_polygons, index_utils.py:129-184: "
-                           "cut at the last meridian, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h; "
-                           "`without_geometry`: the same passes without it).  NOT included: the upload of the fields (end_to_end has it), "
-                           "the last flops of the frame's property columns (stage_ms.geometry_host: the views of the rings + "
-                           "properties_from_sums, host) and frame construction")
+        if with_geometry is not None:
+            out["value_with_geometry"] = with_geometry["value"]
+            out["with_geometry"] = with_geometry
+            out["geometry_adds_ms_per_step"] = with_geometry["ms_per_step"] - out["ms_per_step"]
+        out["value_is"] = ("device-resident f32 field batch -> index-space event tables of all requested indices in host memory (rows: step, "
+                           "level, contour, end points or box, orientation; the five area-weighted sums; cell counts; flags; polygon vertices "
+                           "in grid indices) -- the figure of the earlier rounds.  `value_with_geometry`: the same passes with the library's "
+                           "default (context option geometry = 1): additionally the events' polygons in lon / lat -- transform_polygons, "
+                           "index_utils.py:129-184: cut at the last meridian, truncated and mapped by the device into pinned host memory "
+                           "(csrc/wb_geom.h).  NOT included in either: the upload of the fields (end_to_end has it), the last flops of the "
+                           "frame's property columns (stage_ms.geometry_host: the views of the rings + properties_from_sums, host) and "
+                           "frame construction")
         if world == 1 and a.e2e_steps > 0 and a.config == 2:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:

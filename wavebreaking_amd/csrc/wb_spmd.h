@@ -34,6 +34,18 @@ extern int wb_hostsim_reverse;
     for (int64_t wb_k_##i = 0, wb_n_##i = (int64_t)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
         const int64_t i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;
 #define WB_END_PFOR }
+// the same with a 32-bit index (extents that fit an int: a per-job kernel's loops; the 64-bit index costs two instructions per
+// add / compare / address on the device)
+#define WB_PFOR32(i, n)                                                          \
+    for (int wb_k_##i = 0, wb_n_##i = (int)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
+        const int i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;
+#define WB_PFOR_B32(i, ic, u, n)                                                 \
+    for (int wb_k_##i = 0, wb_n_##i = (int)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
+        const int i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;   \
+        const int ic = i;                                                          \
+        const int u = 0;                                                           \
+        (void)ic; (void)u;                                                         \
+        {
 // WB_PFOR_B(i, ic, u, n) <requests> WB_PFOR_B_USE(i, u) <the rest> WB_END_PFOR_B: a parallel loop whose body is cut in two -- the
 // first part only REQUESTS what element i needs (into arrays indexed [u], WB_PFOR_B_WIDTH long, declared in front of the loop;
 // ic = i clamped to n - 1), the second part uses it.  On the device a thread requests for WB_PFOR_B_WIDTH of its elements before it
@@ -48,6 +60,7 @@ extern int wb_hostsim_reverse;
         (void)ic; (void)u;                                                                 \
         {
 #define WB_PFOR_B_USE(i, u) } {
+#define WB_PFOR_B32_USE(i, u) } {
 #define WB_END_PFOR_B } }
 #define WB_SINGLE {
 #define WB_END_SINGLE }
@@ -120,6 +133,21 @@ static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
         }           \
         __syncthreads(); \
     }
+#define WB_PFOR32(i, n)                                                            \
+    {                                                                              \
+        for (int i = WB_TID, wb_n_##i = (int)(n); i < wb_n_##i; i += WB_NT) {
+#define WB_PFOR_B32(i, ic, u, n)                                                                                          \
+    {                                                                                                                      \
+        const int wb_n_##i = (int)(n);                                                                                     \
+        for (int wb_b_##i = WB_TID; wb_b_##i < wb_n_##i; wb_b_##i += WB_PFOR_B_WIDTH * WB_NT) {                            \
+            _Pragma("unroll") for (int u = 0; u < WB_PFOR_B_WIDTH; ++u) {                                                  \
+                const int i = wb_b_##i + u * WB_NT, ic = i < wb_n_##i ? i : wb_n_##i - 1;                                  \
+                (void)i;
+#define WB_PFOR_B32_USE(i, u)                                                                                              \
+            }                                                                                                              \
+            _Pragma("unroll") for (int u = 0; u < WB_PFOR_B_WIDTH; ++u) {                                                  \
+                const int i = wb_b_##i + u * WB_NT;                                                                        \
+                if (i >= wb_n_##i) break;
 #define WB_PFOR_B_WIDTH 4
 #define WB_PFOR_B(i, ic, u, n)                                                                                            \
     {                                                                                                                      \

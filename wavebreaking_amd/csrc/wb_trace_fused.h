@@ -235,13 +235,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // ---- A: keys to LDS
     int srun = 0;                                               // (wb_f_locate_run: the list of this thread's previous element)
     uint32_t ka[WB_PFOR_B_WIDTH];                               // (WB_PFOR_B: four elements' loads requested, then used)
-    WB_PFOR_B(g, gc, u, n)
+    WB_PFOR_B32(g, gc, u, n)
         const int i = wb_f_locate_run(sbase, (int)gc, &srun);
         ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
-    WB_PFOR_B_USE(g, u)
+    WB_PFOR_B32_USE(g, u)
         K[g] = ka[u];
     WB_END_PFOR_B
-    WB_PFOR(w, (n + 31) / 32 + 1)
+    WB_PFOR32(w, (n + 31) / 32 + 1)
         hp[w] = 0u;
     WB_END_PFOR
 
@@ -280,7 +280,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         return WB_F_NIL;
     };
     int lrun = 0;
-    WB_PFOR(g, n)
+    WB_PFOR32(g, n)
         const uint32_t k = K[g];
         int target, want;
         const int tl = aim(k, &target, &want);
@@ -324,7 +324,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     {
         const int nq = ctr[6] < QMAX ? ctr[6] : QMAX;
-        WB_PFOR(qi, nq)
+        WB_PFOR32(qi, nq)
             const int g = (int)queue[qi];
             int target, want;
             const int tl = aim(K[g], &target, &want);
@@ -340,7 +340,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // ---- C: list ranking.  C1: splitters = chain heads (no predecessor) + every 16th segment, a word of 32 flags at a time:
     // the has-predecessor bits turn into the splitter bits in place; a splitter's ordinal is the number of flags in front of it
     const int nwords = (n + 31) / 32;
-    WB_PFOR(w, nwords)
+    WB_PFOR32(w, nwords)
         const uint32_t valid = ((int)w + 1) * 32 <= n ? 0xFFFFFFFFu : ((1u << (n & 31)) - 1u);
         const uint32_t f = (~hp[w] | 0x00010001u) & valid;           // (WB_F_SPLIT = 16: bits 0 and 16 of every word)
         spb[w] = f;
@@ -348,7 +348,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     const int S1 = wb_block_scan_excl(wpre, nwords);
     if (S1 > fa.smax || fa.smax > 1023) WB_F_DECLINE();
-    WB_PFOR(w, nwords)
+    WB_PFOR32(w, nwords)
         uint32_t f = spb[w];
         int o = wpre[w];
         while (f) {
@@ -388,13 +388,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         nlen[o] = (uint16_t)cntw;
         ndend[o] = (uint16_t)end;
     };
-    WB_PFOR(o, S1)
+    WB_PFOR32(o, S1)
         walk((int)o);
     WB_END_PFOR
     // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
     const int S2 = ctr[1];
     if (ctr[0] || S2 > fa.smax) WB_F_DECLINE();
-    WB_PFOR(g, n)
+    WB_PFOR32(g, n)
         bool want = false;
         const uint32_t w = S[g];
         if (w & WB_F_UNVISITED) {
@@ -406,19 +406,19 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     const int S3 = ctr[1];
     if (S3 > fa.smax) WB_F_DECLINE();
-    WB_PFOR(o, S3 - S2)
+    WB_PFOR32(o, S3 - S2)
         walk(S2 + (int)o);
     WB_END_PFOR
     const int NSP = ctr[1];
     if (ctr[0] || NSP > fa.smax) WB_F_DECLINE();
     // C4: the splitters' own list: next splitter, previous splitter
     const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
-    WB_PFOR(o, NSP)
+    WB_PFOR32(o, NSP)
         const uint16_t e = ndend[o];
         nnext[o] = e == (uint16_t)WB_F_NIL ? NN : (uint16_t)WB_F_OWN(e);     // (in place: ndend is nnext's storage)
         ncp[o] = NN;
     WB_END_PFOR
-    WB_PFOR(o, NSP)
+    WB_PFOR32(o, NSP)
         if (nnext[o] != NN) ncp[nnext[o]] = (uint16_t)o;
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 3);
@@ -428,13 +428,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     int rounds = 0;
     while ((1 << rounds) < NSP) ++rounds;
     auto rank_nodes = [&]() -> unsigned long long* {
-        WB_PFOR(o, NSP)
+        WB_PFOR32(o, NSP)
             const uint16_t p = ncp[o];
             Q0[o] = WB_FQ(p, p != NN ? nlen[p] : 0, o, o);
         WB_END_PFOR
         unsigned long long *qi = Q0, *qo = Q1;
         for (int it = 0; it < rounds; ++it) {
-            WB_PFOR(o, NSP)
+            WB_PFOR32(o, NSP)
                 const unsigned long long w = qi[o];
                 const uint16_t j = (uint16_t)w;
                 unsigned long long nw = w;
@@ -451,7 +451,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     };
     unsigned long long* Q = rank_nodes();
     // chains: an open chain is named by its first node, a loop (jump pointer still alive) by its smallest ordinal
-    WB_PFOR(o, NSP)
+    WB_PFOR32(o, NSP)
         const unsigned long long w = Q[o];
         const bool loop = (uint16_t)w != NN;
         const uint16_t id = loop ? (uint16_t)(w >> 48) : (uint16_t)(w >> 32);
@@ -462,19 +462,19 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     if (C > cmax) WB_F_DECLINE();
     const bool any_loop = ctr[3] != 0;
     // every node learns its chain's index (the naming node's entry is read before anything overwrites it: two steps)
-    WB_PFOR(o, NSP)
+    WB_PFOR32(o, NSP)
         const unsigned long long w = Q[o];
         const bool loop = (uint16_t)w != NN;
         const uint16_t id = loop ? (uint16_t)(w >> 48) : (uint16_t)(w >> 32);
         nnext[o] = (uint16_t)cix[id];                          // (nnext is done with: chain index of the node, for now)
         if (id == (uint16_t)o) { cloop[cix[o]] = loop ? 1 : 0; cmin[cix[o]] = 0xFFFFFFFFu; cmaxk[cix[o]] = 0u; ctot[cix[o]] = 0; }
     WB_END_PFOR
-    WB_PFOR(o, NSP)
+    WB_PFOR32(o, NSP)
         cix[o] = (int)nnext[o];
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 4);
     // keys again (coalesced, from the lists): every chain's smallest key (it numbers the contours), every loop's largest
-    WB_PFOR(g, n)
+    WB_PFOR32(g, n)
         const uint32_t key = K[g] & 0x07FFFFFFu;
         const int ch = cix[WB_F_OWN(g)];
         wb_atomic_min(&cmin[ch], key);
@@ -483,28 +483,28 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     if (any_loop) {
         // the loop's raster-last segment: the contour starts behind it.  Cut the splitters' loop in
         // front of the node that holds it and rank again; the segments' positions are rotated below.
-        WB_PFOR(g, n)
+        WB_PFOR32(g, n)
             const int o = WB_F_OWN(g), ch = cix[o];
             if (cloop[ch] && (K[g] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = (uint16_t)o; lpos[ch] = (uint16_t)WB_F_LP(g); }
         WB_END_PFOR
-        WB_PFOR(ch, C)
+        WB_PFOR32(ch, C)
             if (cloop[ch]) ncp[lnode[ch]] = NN;
         WB_END_PFOR
         Q = rank_nodes();
     }
     // chain lengths
-    WB_PFOR(o, NSP)
+    WB_PFOR32(o, NSP)
         wb_atomic_max(&ctot[cix[o]], (int)(uint16_t)(Q[o] >> 16) + (int)nlen[o]);
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 5);
     // ---- D: contours in the order of their raster-first segments (contour_index.py:103: find_contours' list order)
-    WB_PFOR(ch, C)
+    WB_PFOR32(ch, C)
         const uint32_t mine = cmin[ch];
         int num = 0;
         for (int c2 = 0; c2 < C; ++c2) num += cmin[c2] < mine ? 1 : 0;
         cnum[ch] = (uint16_t)num;
     WB_END_PFOR
-    WB_PFOR(ch, C)
+    WB_PFOR32(ch, C)
         rawbase[cnum[ch]] = ctot[ch] + 1;                      // raw points of the contour: its segments' end points + the first start point
         closedn[cnum[ch]] = cloop[ch];
     WB_END_PFOR
@@ -514,7 +514,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_SINGLE
     // where every segment's end point goes (bit 15: the segment is its contour's first -- its start point goes in front).
     // Reads region A (own / lp) and the ranking's tables, writes region B.
-    WB_PFOR(g, n)
+    WB_PFOR32(g, n)
         const int o = WB_F_OWN(g), ch = cix[o];
         int q = (int)(uint16_t)(Q[o] >> 16) + WB_F_LP(g);       // position along the chain, from 1 (dest is S's storage: read, then written, by this thread)
         if (cloop[ch]) {
@@ -525,7 +525,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     if (R >= 0x8000) WB_F_DECLINE();                            // (cannot happen: n < 8191, C <= cmax)
     // the contour of raw point 32 b, for every b (the ranking's tables are done with: group 2 of the tables from here on)
-    WB_PFOR(b, (R + 31) / 32 + 1)
+    WB_PFOR32(b, (R + 31) / 32 + 1)
         const int p = (int)b * 32;
         int lo = 0, hi = C;                                      // first contour whose end lies behind p
         while (lo < hi) {
@@ -545,13 +545,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     {
         uint32_t keya[WB_PFOR_B_WIDTH];
         double va[WB_PFOR_B_WIDTH][4];
-        WB_PFOR_B(g, gc, u, n)                                  // (a segment's key and the four corner values of its square, four segments' worth requested together)
+        WB_PFOR_B32(g, gc, u, n)                                  // (a segment's key and the four corner values of its square, four segments' worth requested together)
             const int i = wb_f_locate_run(sbase, (int)gc, &srun);
             const size_t e = ((size_t)job * NS + srun) * a.cap_strip + (size_t)i;
             keya[u] = a.stg_k[e];
             if (a.dtype == 0) { const float* v = (const float*)a.stg_v + e * 4; va[u][0] = (double)v[0]; va[u][1] = (double)v[1]; va[u][2] = (double)v[2]; va[u][3] = (double)v[3]; }
             else { const double* v = (const double*)a.stg_v + e * 4; va[u][0] = v[0]; va[u][1] = v[1]; va[u][2] = v[2]; va[u][3] = v[3]; }
-        WB_PFOR_B_USE(g, u)
+        WB_PFOR_B32_USE(g, u)
             const uint32_t key = keya[u];
             const double ul = va[u][0], ur = va[u][1], ll = va[u][2], lr = va[u][3];
             // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
@@ -572,26 +572,26 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // the same contour can never be a first occurrence (about half of all raw points: neighbouring crossings that round to the
     // same lattice point): it stays out.
     const int NB = (nlon >> WB_F_XSHIFT) + 1;
-    WB_PFOR(x, NB + 1)
+    WB_PFOR32(x, NB + 1)
         cnt[x] = 0;
     WB_END_PFOR
-    WB_PFOR(w, (R + 31) / 32 + 1)
+    WB_PFOR32(w, (R + 31) / 32 + 1)
         keepb[w] = 0u;
         dupb[w] = 0u;
     WB_END_PFOR
-    WB_PFOR(c, C + 1)
+    WB_PFOR32(c, C + 1)
         newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0;
     WB_END_PFOR
 #define WB_F_XM(pw) (((pw) & xmask) >= (uint32_t)nlon ? ((pw) & xmask) - (uint32_t)nlon : ((pw) & xmask))   /* x mod nlon: x < W <= 2 nlon */
 #define WB_F_BUCKET(pw) ((int)WB_F_XM(pw) >> WB_F_XSHIFT)
-    WB_PFOR(p, R)
+    WB_PFOR32(p, R)
         const uint32_t pw = rawpt[p];
         const bool dup = p > 0 && pw == rawpt[p > 0 ? p - 1 : 0];        // (equal words: the same contour and the same lattice point)
         if (dup) wb_atomic_or(&dupb[p >> 5], 1u << (p & 31));
         else wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);
     WB_END_PFOR
     const int U = wb_block_scan_excl(cnt, NB);                  // cnt[b]: first entry of bucket b
-    WB_PFOR(p, R)
+    WB_PFOR32(p, R)
         if (!((dupb[p >> 5] >> (p & 31)) & 1u)) {
             const int e = wb_atomic_add(&cnt[WB_F_BUCKET(rawpt[p])], 1);          // (afterwards cnt[b] = END of bucket b = start of bucket b + 1)
             order[e] = (uint16_t)p;
@@ -599,7 +599,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 8);
     // first-occurrence dedupe (contour_index.py:110-112: dict.fromkeys over the contour's points)
-    WB_PFOR(e, U)
+    WB_PFOR32(e, U)
         const int p = (int)order[e];
         const uint32_t pw = rawpt[p];
         const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
@@ -620,14 +620,14 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // contours that turn out too short included, as the finish kernel of wb_trace.h lays them out)
     uint32_t* const cpts = a.cpts + 2 * jb;
     const int chunk = (R + WB_NT - 1) / WB_NT;
-    WB_PFOR(t, WB_NT)
+    WB_PFOR32(t, WB_NT)
         const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
         int k = 0;
         for (int p = p0; p < p1; ++p) k += (int)((keepb[p >> 5] >> (p & 31)) & 1u);
         tcount[t] = k;
     WB_END_PFOR
     const int NK = wb_block_scan_excl(tcount, WB_NT);
-    WB_PFOR(t, WB_NT)
+    WB_PFOR32(t, WB_NT)
         const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
         int q = tcount[t];
         for (int p = p0; p < p1; ++p) {
@@ -641,17 +641,17 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     newstart[C] = NK;
     WB_END_SINGLE
     // contours with at least four points stay (contour_index.py:113-117)
-    WB_PFOR(c, C)
+    WB_PFOR32(c, C)
         kid[c] = (newstart[c + 1] - newstart[c]) >= 4 ? 1 : 0;
         fin[c] = kid[c];
     WB_END_PFOR
     const int Ck = wb_block_scan_excl(kid, C);                  // kid[c]: number among the kept ones; fin[c]: kept flag
-    WB_PFOR(c, C)
+    WB_PFOR32(c, C)
         if (fin[c]) ckept[kid[c]] = (uint16_t)c;
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 9);
     // ---- G: per kept contour: distinct x (-> exp_lon, :154), sum of y (-> mean_lat, :155), distinct (x mod nlon, y)
-    WB_PFOR(e, U)
+    WB_PFOR32(e, U)
         const int p = (int)order[e];
         const uint32_t pw = rawpt[p];
         const int c = (int)(pw >> sh);
@@ -715,7 +715,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
             WB_SINGLE
             ctr[5] = 0;
             WB_END_SINGLE
-            WB_PFOR(p, pb - pa)
+            WB_PFOR32(p, pb - pa)
                 if (!in_set(rawpt[pa + p], c2)) ctr[5] = 1;
             WB_END_PFOR
             if (ctr[5] == 0) {
@@ -728,11 +728,11 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         }
     }
     // ---- H: final table = kept and not dropped, order preserved (fin: the kept flag by contour until here, by kept contour from here)
-    WB_PFOR(f, Ck)
+    WB_PFOR32(f, Ck)
         fin[f] = dropped[f] ? 0 : 1;
     WB_END_PFOR
     const int Cf = wb_block_scan_excl(fin, Ck);
-    WB_PFOR(f, Ck)
+    WB_PFOR32(f, Ck)
         if (!dropped[f]) {
             const int g = fin[f], c = (int)ckept[f];
             (a.c_off + jb)[g] = newstart[c];
