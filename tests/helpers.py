@@ -55,9 +55,37 @@ def run_abi(ctx, data, lat, lon, levels, intensity=None, periodic_add=120.0, wan
     out = dict(contours=b.contour_table(), streamers=b.events(_hip.STREAMERS), overturnings=b.events(_hip.OVERTURNINGS),
                cutoffs=b.events(_hip.CUTOFFS), status=b.status(), band=b.band_hits(), max_nux=b.max_nux(),
                com_rechecks=b.com_rechecks(),
-               timings=b.timings())
+               timings=b.timings(),
+               geometry=[b.event_geometry(k) for k in (_hip.STREAMERS, _hip.OVERTURNINGS, _hip.CUTOFFS)])
     b.close()
     return out
+
+
+GEOMETRY_CHECKED = {"events": 0, "split": 0}
+
+
+def check_event_geometry(ctx, got, lat, lon):
+    """transform_polygons (index_utils.py:129-184): the rings wb_indices left in host memory -- cut, truncated and mapped by the
+    device kernels of csrc/wb_geom.h (the host simulation runs the same sources) -- against the HOST function on the very
+    polygons of the event tables, ring for ring and bit for bit.  (The host function itself is checked against the exact
+    oracle splitter in tests/test_seam_split.py and, frame by frame, in tests/test_python_api.py.)"""
+    lon = np.ascontiguousarray(lon, dtype=np.float64)
+    lat = np.ascontiguousarray(lat, dtype=np.float64)
+    for kind, name in enumerate(("streamers", "overturnings", "cutoffs")):
+        ev = got[name]
+        ro, vo, gx, gy = (np.asarray(a) for a in got["geometry"][kind])
+        po = np.asarray(ev["poly_offset"])
+        n = len(po) - 1
+        assert len(ro) == n + 1, (name, len(ro), n)
+        if n == 0:
+            continue
+        polys = [np.c_[ev["poly_x"][po[k]:po[k + 1]], ev["poly_y"][po[k]:po[k + 1]]] for k in range(n)]
+        host = ctx.transform_polygons(polys, lon, lat, lon.size)
+        for k in range(n):
+            rings = [np.c_[gx[vo[q]:vo[q + 1]], gy[vo[q]:vo[q + 1]]] for q in range(ro[k], ro[k + 1])]
+            assert len(rings) == len(host[k]) and all(np.array_equal(a, b) for a, b in zip(rings, host[k])), (name, k)
+            GEOMETRY_CHECKED["split"] += len(rings) != 1
+        GEOMETRY_CHECKED["events"] += n
 
 
 def compare_contours(got, ref_rows, levels, dlon):
@@ -133,6 +161,7 @@ def full_parity(ctx, data, lat, lon, times, levels, intensity=None, periodic_add
     compare_contours(got["contours"], ref["contours"], levels, dlon)
     for kind in ("streamers", "overturnings", "cutoffs"):
         compare_events(got[kind], got["contours"], ref[kind], kind, levels)
+    check_event_geometry(ctx, got, lat, lon)
     return got, ref
 
 
