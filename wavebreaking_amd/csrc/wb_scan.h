@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
 // copies) -- the staging format the trace kernels read.  It touches the captured patches only (a few % of the field).
 // Patch layout: value k (0..4 upper row, 5..9 lower row) of patch i of a list at cap_v[list][k * cap_rec + i].
 #define WB_BUILD_CHUNK 1024
-#define WB_BUILD_KO_CHUNK 512
+#define WB_BUILD_KO_CHUNK 256
 // in-place exclusive scan of 64-bit values in LDS (two 32-bit counters per word, no carry between them as long as each
 // stays below 2^32); every thread of the block calls it; returns the total
 __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* a, int n) {
@@ -499,7 +499,13 @@ __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* 
 
 template <typename T, int NLEV>
 __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
-    __shared__ unsigned long long cb[WB_BUILD_CHUNK];         // per patch: segments for the base list | periodic-copy list << 32 -> scan
+    // one 16 KB pool: key + values: cb[1024] + lcase[1024]; keys only: cb[256] + lcase[256] + the patches' ten values (10 KB) -- the
+    // kernel's LDS decides how many of its 8 760 workgroups a CU holds beside the other batch's kernels
+    __shared__ unsigned long long wb_build_pool[2 * WB_BUILD_CHUNK];
+    const int CH = a.keys_only ? WB_BUILD_KO_CHUNK : WB_BUILD_CHUNK;
+    unsigned long long* const cb = wb_build_pool;              // per patch: segments for the base list | periodic-copy list << 32 -> scan
+    unsigned long long* const lcase = wb_build_pool + CH;
+    float* const lvf = (float*)(wb_build_pool + 2 * CH);      // (keys only: 2 * 256 words in front, 10 * 256 floats = 10 KB behind them: inside the pool)
     __shared__ int boff[17];                                   // first patch of a band in the concatenation of the bands' lists
     const int g = blockIdx.x;
     const int NS = a.nstrips, NSB = a.nwork;
@@ -536,15 +542,12 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
     // (four bits per square, sixteen per level); (2) per level: segment counts from the cached cases, block scan, and the
     // values are read again only by the patches that hold a segment of THAT level (the two PV levels live in different
     // hemispheres: half the patches).  Reading the values per level and pass cost four reads of every patch.
-    __shared__ unsigned long long lcase[WB_BUILD_CHUNK];
     T lvl[NLEV];
     unsigned long long cur[NLEV];                            // segments written so far: base list | copy list << 32
 #pragma unroll
     for (int l = 0; l < NLEV; ++l) { lvl[l] = wb_level_lo<T>(a.levels[l]); cur[l] = 0ull; }
     // keys only: a patch's ten values are read from the FIELD (two short runs of a row each: not coalesced) -- once: they stay in
     // LDS for the levels' emit passes below (chunks of 512 patches then: 20 KB)
-    __shared__ float lvf[10 * WB_BUILD_KO_CHUNK];
-    const int CH = a.keys_only ? WB_BUILD_KO_CHUNK : WB_BUILD_CHUNK;
     for (int q0 = 0; q0 < total; q0 += CH) {
         const int nq = total - q0 < CH ? total - q0 : CH;
         for (int i = threadIdx.x; i < nq; i += blockDim.x) {
