@@ -174,9 +174,9 @@ def main():
     wall = {}
     # `value` is the index-space figure of the earlier rounds (context option geometry = 0 in the timed region); the same passes WITH
     # transform_polygons on the device -- the product's default -- are timed right behind it: `value_with_geometry`
-    geometry_on = [False]
+    geometry_on = [os.environ.get("WB_BENCH_GEOMETRY", "0") == "1"]        # (WB_BENCH_GEOMETRY=1: development, the timed region itself with geometry -- profiles of the geometry kernels)
     for c in pipe.contexts:
-        c.set_option("geometry", 0)
+        c.set_option("geometry", 1 if geometry_on[0] else 0)
 
     # one step = one pass of the hot path over the resident batch; the two ABI phases run on a worker thread of the
     # pass's context, the two exchanges of a multi-GPU run on this thread in pass order (wavebreaking_amd/pipeline.py)

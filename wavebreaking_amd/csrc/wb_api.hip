@@ -318,16 +318,22 @@ static int run_phase1(wb_batch* b) {
     WbTraceArgs ta;
     memset(&ta, 0, sizeof(ta));
     std::vector<void*>& sc = b->phase1_scratch;
-    for (int i = 0; i < 11; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
     ta.nseg = balloc<int>(b, J); sc.push_back(ta.nseg);
     ta.p4 = balloc<int>(b, 2 * (size_t)J); sc.push_back(ta.p4);
-    for (int i = 0; i < 3; ++i) { ta.mseg[i] = balloc<uint32_t>(b, per); sc.push_back(ta.mseg[i]); }
-    ta.rawpt = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawpt);
-    ta.rawcid = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawcid);
-    ta.keep = balloc<int>(b, (size_t)J * (2 * cap + 1)); sc.push_back(ta.keep);
-    ta.hkey = balloc<unsigned long long>(b, (size_t)J * b->hash_size); sc.push_back(ta.hkey);
-    ta.hval = balloc<uint32_t>(b, (size_t)J * b->hash_size); sc.push_back(ta.hval);
-    if (!ta.hval) return 1;
+    if (!ta.p4) return 1;
+    // the global scratch of the three-kernel chain (merged segments, links, raw points, hash tables: 20 GB for a year of 0.25
+    // degree) is only made when that chain runs -- a job the fused kernel declined, or the option trace_fused = 0
+    auto chain_scratch = [&]() -> bool {
+        if (ta.hval) return true;
+        for (int i = 0; i < 11; ++i) { ta.w[i] = balloc<uint32_t>(b, per); sc.push_back(ta.w[i]); }
+        for (int i = 0; i < 3; ++i) { ta.mseg[i] = balloc<uint32_t>(b, per); sc.push_back(ta.mseg[i]); }
+        ta.rawpt = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawpt);
+        ta.rawcid = balloc<uint32_t>(b, 2 * per); sc.push_back(ta.rawcid);
+        ta.keep = balloc<int>(b, (size_t)J * (2 * cap + 1)); sc.push_back(ta.keep);
+        ta.hkey = balloc<unsigned long long>(b, (size_t)J * b->hash_size); sc.push_back(ta.hkey);
+        ta.hval = balloc<uint32_t>(b, (size_t)J * b->hash_size); sc.push_back(ta.hval);
+        return ta.hval != nullptr;
+    };
     WB_TICK("phase1 allocations");
     if (wb_debug()) { dsync(ctx); WB_TICK("phase1 pre-sync"); }
     // the phase's zero fills: queued, ONE launch (dzero_flush, below: the streaming scan adds its spare row)
@@ -553,6 +559,7 @@ static int run_phase1(wb_batch* b) {
         }
     }
     if (!fused_all) {
+    if (!chain_scratch()) return 1;
     b->timer.begin(ctx, "trace_link");
     {   // row tables in dynamic LDS when they fit (16-bit entries: a job of the LDS paths has at most 8192 segments)
         const size_t tab = (size_t)(NS + 1) * nlat * sizeof(uint16_t) + 16;
