@@ -49,7 +49,7 @@ struct WbFusedLayout {
     size_t t_rawbase, t_closed;      // per contour, from the numbering to the end
     // group 1 (link + ranking) and group 2 (finish) share what follows
     size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_q1, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
-    size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
+    size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_nuxc, g2_sumyc, g2_setc, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
 };
 WB_HD inline size_t wb_f_al(size_t v) { return (v + 7) & ~(size_t)7; }
 WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlon, int nthreads) {
@@ -91,6 +91,9 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     L.g2_nux = g2; g2 += wb_f_al(4 * C1);
     L.g2_sumy = g2; g2 += wb_f_al(4 * C1);
     L.g2_setsize = g2; g2 += wb_f_al(4 * C1);
+    L.g2_nuxc = g2; g2 += wb_f_al(4 * C1);
+    L.g2_sumyc = g2; g2 += wb_f_al(4 * C1);
+    L.g2_setc = g2; g2 += wb_f_al(4 * C1);
     L.g2_dropped = g2; g2 += wb_f_al(C1);
     L.g2_ckept = g2; g2 += wb_f_al(2 * C1);
     L.g2_fin = g2; g2 += wb_f_al(4 * C1);
@@ -183,6 +186,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     int* const nuxl = (int*)(T + L.g2_nux);
     int* const sumyl = (int*)(T + L.g2_sumy);
     int* const setsize = (int*)(T + L.g2_setsize);
+    int* const nuxc = (int*)(T + L.g2_nuxc);                  // the same three counters per contour BEFORE the >= 4 points filter (one bucket scan serves the dedupe and them)
+    int* const sumyc = (int*)(T + L.g2_sumyc);
+    int* const setc = (int*)(T + L.g2_setc);
     unsigned char* const dropped = T + L.g2_dropped;
     uint16_t* const ckept = (uint16_t*)(T + L.g2_ckept);
     int* const fin = (int*)(T + L.g2_fin);
@@ -580,7 +586,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         dupb[w] = 0u;
     WB_END_PFOR
     WB_PFOR32(c, C + 1)
-        newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0;
+        newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0; nuxc[c] = 0; sumyc[c] = 0; setc[c] = 0;
     WB_END_PFOR
 #define WB_F_XM(pw) (((pw) & xmask) >= (uint32_t)nlon ? ((pw) & xmask) - (uint32_t)nlon : ((pw) & xmask))   /* x mod nlon: x < W <= 2 nlon */
 #define WB_F_BUCKET(pw) ((int)WB_F_XM(pw) >> WB_F_XSHIFT)
@@ -598,12 +604,15 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         }
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 8);
-    // first-occurrence dedupe (contour_index.py:110-112: dict.fromkeys over the contour's points)
+    // first-occurrence dedupe (contour_index.py:110-112: dict.fromkeys over the contour's points) -- and, in the same scan of the
+    // point's bucket, the contour's distinct x (-> exp_lon, :154), distinct (x mod nlon, y) and sum of y over the kept points
+    // (-> mean_lat, :155): an entry counts for x / (x mod nlon, y) when no entry IN FRONT of it in the bucket has them
     WB_PFOR32(e, U)
         const int p = (int)order[e];
         const uint32_t pw = rawpt[p];
-        const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
-        bool first = true;
+        const uint32_t c = pw >> sh, x = pw & xmask, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
+        const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
+        bool first = true, firstx = true, firsty = true;
         for (int e2 = b0; e2 < b1; e2 += 4) {                   // (four entries' positions, then their points: two LDS latencies per four)
             int p2[4];
             uint32_t w2[4];
@@ -612,9 +621,17 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) w2[q] = rawpt[p2[q]];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (p2[q] < p && w2[q] == pw) first = false;
+            for (int q = 0; q < 4; ++q) {
+                if (p2[q] < p && w2[q] == pw) first = false;
+                if (e2 + q < (int)e) {
+                    if ((w2[q] >> xb) == cy && WB_F_XM(w2[q]) == xm) firsty = false;
+                    if ((w2[q] >> sh) == c && (w2[q] & xmask) == x) firstx = false;
+                }
+            }
         }
-        if (first) wb_atomic_or(&keepb[p >> 5], 1u << (p & 31));
+        if (first) { wb_atomic_or(&keepb[p >> 5], 1u << (p & 31)); wb_atomic_add(&sumyc[c], (int)((pw >> xb) & ymask)); }
+        if (firstx) wb_atomic_add(&nuxc[c], 1);
+        if (firsty) wb_atomic_add(&setc[c], 1);
     WB_END_PFOR
     // compaction: a thread owns a run of consecutive raw points; the kept ones go to the job's output array (the points of
     // contours that turn out too short included, as the finish kernel of wb_trace.h lays them out)
@@ -650,31 +667,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         if (fin[c]) ckept[kid[c]] = (uint16_t)c;
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 9);
-    // ---- G: per kept contour: distinct x (-> exp_lon, :154), sum of y (-> mean_lat, :155), distinct (x mod nlon, y)
-    WB_PFOR32(e, U)
-        const int p = (int)order[e];
-        const uint32_t pw = rawpt[p];
-        const int c = (int)(pw >> sh);
-        if (fin[c]) {
-            const uint32_t x = pw & xmask, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
-            const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0;
-            bool firstx = true, firsty = true;
-            for (int e2 = b0; e2 < (int)e; e2 += 4) {           // the entries in front of this one in its bucket, four at a time
-                uint32_t w2[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w2[q] = rawpt[order[e2 + q < (int)e ? e2 + q : (int)e]];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (e2 + q >= (int)e) continue;             // (past the last one in front: the entry itself was read, skipped)
-                    if ((w2[q] >> xb) == cy && WB_F_XM(w2[q]) == xm) firsty = false;
-                    if ((w2[q] >> sh) == (uint32_t)c && (w2[q] & xmask) == x) firstx = false;
-                }
-            }
-            const int f = kid[c];
-            if (firstx) wb_atomic_add(&nuxl[f], 1);
-            if (firsty) wb_atomic_add(&setsize[f], 1);
-            if ((keepb[p >> 5] >> (p & 31)) & 1u) wb_atomic_add(&sumyl[f], (int)((pw >> xb) & ymask));
-        }
+    // ---- G: the kept contours' counters, by their number among the kept ones
+    WB_PFOR32(c, C)
+        if (fin[c]) { const int f = kid[c]; nuxl[f] = nuxc[c]; setsize[f] = setc[c]; sumyl[f] = sumyc[c]; }
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 10);
     // ---- periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1, i2) with set(i1) a subset of set(i2)
