@@ -35,6 +35,23 @@ def test_full_parity_1deg_two_levels(sim, reverse, eager):
     ctx.set_option("eager_f2", 0)
 
 
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_streamer_filters_on_contours_longer_than_their_lds(sim, reverse):
+    # wb_k_streamer_f234 holds a contour of up to f234_lpts points in LDS (records of the rows' largest candidates tested a batch
+    # at a time); a longer one is swept row after row in global memory: the same events either way
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(reverse)
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(10, 3, lat, lon, eps=0.3)
+    for lpts in (64, 256, 0):
+        ctx.set_option("f234_lpts", lpts)
+        try:
+            got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(3), [-2, 2], intensity=pv)
+            assert len(ref["streamers"]) > 5
+        finally:
+            ctx.set_option("f234_lpts", 0)
+
+
 def test_demo_shaped_config0(sim):
     # BASELINE.json configs[0]: demo-data shape 360 x 179 (lat -89..89), one step, level 2, all three indices
     lib, ctx = sim

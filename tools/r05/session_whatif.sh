@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 5: what the streamer filters (routine 1, routines 2-4) cost without the contours of more than 20 000 / 4 000 candidate pairs
+# (development builds -DWB_WHATIF_BIG=n that drop those contours' events: an upper bound for spreading them over several workgroups);
+# phase stamps of wb_k_streamer_f234 with its longest workgroup
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out/r05
+OUT=gpurun_out/r05/whatif.txt
+: > $OUT
+echo "== f234 stamps (ms of workgroup time per launch; 12..: the longest workgroup's 4 5 6 8 9 10 11)" | tee -a $OUT
+WB_HIP_LIBRARY=$PWD/build/ab/libwb_stamps1.so WB_DEBUG_STAMPS=1 timeout 300 python bench.py --steps 2 --warmup 0 --cpu-sample 0 --e2e-steps 0 --streams 1 --stagger-steps 0 2>&1 | grep -E "stamps|pairs" | tail -3 | tee -a $OUT
+run() {
+  label="$1"; lib="$2"
+  WB_HIP_LIBRARY="$lib" timeout 300 python bench.py --steps 40 --warmup 6 --cpu-sample 0 --e2e-steps 0 --stagger-steps ${4:-0} --streams ${3:-2} > /tmp/ab.json 2>/tmp/ab.err || { echo "$label FAILED" | tee -a $OUT; tail -5 /tmp/ab.err | tee -a $OUT; return; }
+  python - "$label" <<'PY' | tee -a $OUT
+import json, sys
+d = json.load(open("/tmp/ab.json")); s = d["stage_ms"]
+keys = ["scan", "scan_build", "trace_fused", "streamer_prep", "streamer_pairs", "streamer_f1", "streamer_f234", "props"]
+print("%-24s value %6d  ms/step %.3f frac %.3f alone %.3f | " % (sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["frac_alone"]) + " ".join("%s %.2f" % (k.replace("streamer_", "").replace("trace_", ""), s.get(k, float("nan"))) for k in keys) + " | max_pairs %s cand_pairs %s" % (d.get("counts", {}).get("max_pairs"), d.get("counts", {}).get("cand_pairs")), flush=True)
+PY
+}
+NEW=$PWD/wavebreaking_amd/csrc/libwb_hip.so
+for rep in 1 2 3; do
+for v in new 20000 4000; do
+lib=$NEW; [ $v != new ] && lib=$PWD/build/ab/libwb_whatif_$v.so
+run "$v one batch" $lib 1
+run "$v two" $lib 2 16
+done
+done

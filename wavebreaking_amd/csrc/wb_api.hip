@@ -15,6 +15,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <algorithm>
 
 #include "wb_comm.h"
 #include "wb_core.h"
@@ -1535,6 +1536,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.f234_cap = ((h1.max_len + 255) / 256) * 256;
             if (st.f234_cap < 512) st.f234_cap = 512;
             if (st.f234_cap > WB_F234_LPTS) st.f234_cap = WB_F234_LPTS;
+            if (ctx->f234_lpts > 0 && st.f234_cap > ctx->f234_lpts) st.f234_cap = ctx->f234_lpts;
             const bool need_tiled = st.p2_cap <= 0 || h1.max_len > st.p2_cap;
             st.ptab = need_tiled ? (double*)talloc((size_t)(NPT + 1) * 5 * sizeof(double)) : nullptr;
             if (need_tiled && !st.ptab) { release(); return 1; }
@@ -1602,9 +1604,26 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
-                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + (size_t)(st.f234_cap / WB_BLK + 1) * 20 + 64, st);
+                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + (size_t)(st.f234_cap / WB_BLK + 1) * 16 + 64, st);
                 WB_LAUNCH(wb_k_streamer_ties, 1, 64, st);      // one wave: check_groups' exact ties (nearly always none)
                 b->timer.end(ctx);
+            }
+            if (getenv("WB_DEBUG_SEL")) {      // development: the selected contours' lengths and candidate pairs (largest first)
+                dsync(ctx);
+                std::vector<int> hl(nsel_b), hp(nsel_b), ha(nsel_b);
+                std::vector<long long> hoff(nsel_b + 1);
+                d2h(ctx, hoff.data(), st.poff, (nsel_b + 1) * sizeof(long long));
+                for (int q = 0; q < nsel_b; ++q) hl[q] = (int)(hoff[q + 1] - hoff[q]);
+                d2h(ctx, hp.data(), st.npairs, nsel_b * sizeof(int));
+                d2h(ctx, ha.data(), st.nalive, nsel_b * sizeof(int));
+                std::vector<int> idx(nsel_b);
+                for (int q = 0; q < nsel_b; ++q) idx[q] = q;
+                std::sort(idx.begin(), idx.end(), [&](int x, int y) { return hp[x] > hp[y]; });
+                fprintf(stderr, "[wb] selected contours %d, longest %d points, f234 holds %d; (points, pairs, alive) by pairs:", nsel_b, h1.max_len, st.f234_cap);
+                for (int q = 0; q < nsel_b && q < 40; ++q) fprintf(stderr, " (%d %d %d)", hl[idx[q]], hp[idx[q]], ha[idx[q]]);
+                long long over = 0, npair_over = 0; int nbig = 0;
+                for (int q = 0; q < nsel_b; ++q) { if (hl[q] > st.f234_cap) { ++over; npair_over += hp[q]; } if (hp[q] > 4000) ++nbig; }
+                fprintf(stderr, "\n[wb] contours longer than the f234 capacity: %lld (%lld pairs); with more than 4000 pairs: %d\n", over, npair_over, nbig);
             }
         }
         if (do_ot) side_join(ctx);
@@ -2120,6 +2139,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "geometry")) { ctx->geometry = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }
+    if (!strcmp(name, "f234_lpts")) { ctx->f234_lpts = value >= 64 ? value : 0; return 0; }      // (tests: longer contours take wb_k_streamer_f234's path through global memory)
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "scan_pad")) { ctx->scan_pad = value >= 0 ? value : 0; return 0; }
     if (!strcmp(name, "scan_band_rows")) { ctx->scan_band_rows = value; return 0; }

@@ -804,6 +804,9 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
         const int job = a.sel_job[s], k = a.sel_cont[s];
         const size_t jb = (size_t)job * a.cap_seg;
         const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + k];
+#ifdef WB_WHATIF_BIG
+        if (a.npairs[s] > WB_WHATIF_BIG) { if (WB_TID == 0) { a.nalive[s] = 0; a.stage[s] = 4; } continue; }
+#endif
         (void)wb_streamer_f1_body(a, s, job, pts, ltab, WB_F1_LTAB, false);
     }
 }
@@ -1143,6 +1146,9 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     int* ev = a.ev_ind + (size_t)s * a.cap_ev * 2;
     unsigned long long* best = a.hval + (size_t)s * a.hash_size;  // routine 4: per group best value / index
     const int P = a.npairs[s] > a.cap_pairs ? 0 : a.npairs[s];
+#ifdef WB_WHATIF_BIG                   // development: what the launch costs without its few largest contours (their events are dropped)
+    if (P > WB_WHATIF_BIG) { if (WB_TID == 0) a.ev_n[s] = 0; return; }
+#endif
     int* mi = (int*)(a.hkey + (size_t)s * a.hash_size);             // [M] ind1 of survivor m (M <= min(P, N))
     int* mj = mi + (P < N ? P : N) + 1;                              // [M] ind2
     int* lab = mj + (P < N ? P : N) + 1;                             // [M] group label
@@ -1155,8 +1161,10 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     WB_DYN_SHARED(int, lrmax, a.f234_cap);       // per row: largest ind2 among its alive candidates
     WB_DYN_SHARED(int, rend, a.f234_cap);        // per row: its alive candidates, then the end of its bucket in bk
     WB_DYN_SHARED(int, lbb, 4 * (a.f234_cap / WB_BLK + 1));   // boxes of the blocks of WB_BLK segments (wb_k_streamer_prep: points 32 b .. 32 b + 32)
-    WB_DYN_SHARED(int, hitb, a.f234_cap / WB_BLK + 1);        // the blocks whose box meets the chord's (chord test)
-    WB_SHARED(int, wmax, WB_F234_LPTS / 32);     // per word of 32 rows: the largest ind2 among their alive candidates
+    WB_SHARED(int, chain, WB_F234_BATCH);        // the next records of rmax[] above M: the rows whose largest candidates are tested together
+    WB_SHARED(uint32_t, hp, WB_F234_BATCH);      // near end points of the chords of a batch
+    WB_SHARED(uint32_t, skipm, 1);               // chords of the batch whose result is known already
+    WB_SHARED(uint32_t, tbits, WB_F234_LPTS / 16);   // two bits per row: its largest candidate has been tested / meets the contour
     WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
     WB_SHARED(int, csort, WB_F234_CAND);
     WB_SHARED(uint32_t, hq, WB_F234_BATCH);     // far end points of the chords of a batch
@@ -1169,14 +1177,13 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     const uint32_t* pts = in_lds ? lpts : gpts;
     const uint32_t pe0 = gpts[0], pe1 = gpts[N - 1];          // the contour's end vertices: its boundary, as a point set (wb_chord_hits_segment)
     int* rmax = in_lds ? lrmax : a.rowmx + a.poff[s];
-    const int nw = (N + 31) >> 5;
     WB_STAMP_BEGIN
     const int nblk = (N + WB_BLK - 1) / WB_BLK;
     WB_PFOR(i, N)
         if (in_lds) { lpts[i] = gpts[i]; rend[i] = 0; }
+        if (in_lds && i < (N + 15) / 16) tbits[i] = 0u;
         rmax[i] = -1;
         if (in_lds && i < 4 * nblk) lbb[i] = a.bbx[4 * ((a.poff[s] >> 5) + s) + i];
-        if (in_lds && i < nw) wmax[i] = -1;
     WB_END_PFOR
     WB_SINGLE
     sh[2] = 0;
@@ -1227,156 +1234,129 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                 for (int u = 0; u < 4; ++u)
                     if (al[u]) bk[wb_atomic_add(&rend[(int)(pr[u] >> 32)], 1)] = (int)(pr[u] & 0xFFFFFFFFull);
             WB_END_PFOR
-            WB_PFOR(i, N)
-                if (rmax[i] >= 0) wb_atomic_max(&wmax[i >> 5], rmax[i]);
-            WB_END_PFOR
         }
         WB_STAMP(a.ctl, 1);
-        // The sweep.  M (largest ind2 kept so far), the next row and the survivor count are the same in every lane and
-        // live in registers; the two words a step communicates through (row found, chord hit) alternate between two
-        // slots, and the slot of the NEXT step is reset after this step's first barrier -- two barriers per step.
-        int M = -1, cur = 0, nsurv = 0, ntest = 0;
-        for (int step = 0;; ++step) {
-            const int fs = 3 + (step & 1);
-            // the next row at or after `cur` whose largest candidate is above M: a lane per row, WB_NT rows per pass (the next
-            // row is nearly always among the first few; a bitmap of non-empty rows walked bit by bit, as this was until
-            // round 3, cost a dependent LDS read per set bit: 2.5 us per step, as much as the chord test itself)
-            const int win = WB_NT > 64 ? WB_NT : 64;          // rows of the first pass: up to the last word boundary within `win` rows of cur
-            const int wend = (cur + win) & ~31;
-            {
-                WB_PFOR(t, win)
-                    const int i = cur + (int)t;
-                    wb_atomic_min_first(&sh[fs], i < wend && i < N && rmax[i] > M, i);
+        // The sweep.  A row contributes the largest of its candidates above M whose chord passes routine 2; whether a chord
+        // passes does not depend on M.  So as long as every row's LARGEST candidate passes, the rows that contribute are the
+        // records of rmax[] above M -- known without a single chord test -- and their chords are tested together, WB_F234_BATCH
+        // records per sweep over the contour's segments.  Only a record whose largest candidate fails makes the sweep look at
+        // that row's other candidates (in descending order, again a batch at a time) and at the records behind it anew.
+        // (Until round 5 the rows were visited one after the other, a search for the next row and a chord test each: 18 rows per
+        // contour of the 0.25 degree bench batch, 4.5 + 1.9 us per row, three quarters of the kernel.)
+        // M, the next row and the survivor count are the same in every lane and live in registers.
+        int M = -1, cur = 0, nsurv = 0;
+        if (in_lds) {
+            // hp / hq: the end points of the chords of a batch (skipm: chords not to test).  First the (chord, block of 32 segments)
+            // items whose boxes meet -- a lane per chord and block --, then a lane per item and segment: box, then the exact
+            // predicate.  hitm: the chords that meet the contour.  (Testing the union of the chords' blocks against every chord of
+            // the batch, as the row's candidates were until round 5, is 7 us per sweep when the chords lie all over the contour.)
+            auto test_batch = [&](int nb) WB_LAMBDA_INLINE {
+                const uint32_t skip = skipm[0];
+                WB_PFOR32(t, nb * nblk)
+                    const int c = t / nblk, b = t - c * nblk;
+                    if ((skip >> c) & 1u) continue;
+                    const int px = wb_pt_x(hp[c]), py = wb_pt_y(hp[c]), qx = wb_pt_x(hq[c]), qy = wb_pt_y(hq[c]);
+                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                    const int* bb = lbb + 4 * b;
+                    if (!(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0)) {
+                        const int slot = wb_atomic_add(&sh[12], 1);
+                        if (slot < WB_F234_CAND) cand[slot] = (c << 16) | b;
+                    }
                 WB_END_PFOR
-            }
-            if (sh[fs] == 0x7FFFFFFF && wend < N) {
-                if (in_lds) {
-                    // not among those (the contour with 50 000 pairs has its next row thousands of points away: eight such
-                    // passes, a barrier each): the first WORD of 32 rows from wend on whose largest candidate is above M (wmax,
-                    // built once), then the first such row of that word -- two short passes whatever the distance
-                    const int fw = 13 + (step & 1);
-                    WB_PFOR(w, nw)
-                        if ((int)w >= (wend >> 5) && wmax[w] > M) wb_atomic_min(&sh[fw], (int)w);
-                    WB_END_PFOR
-                    const int w0 = sh[fw];
-                    if (w0 != 0x7FFFFFFF) {
-                        WB_PFOR(t, 32)
-                            const int i = w0 * 32 + (int)t;
-                            wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
-                        WB_END_PFOR
-                    }
-                } else {
-                    for (int base = wend; base < N; base += win) {
-                        WB_PFOR(t, win)
-                            const int i = base + (int)t;
-                            wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
-                        WB_END_PFOR
-                        if (sh[fs] != 0x7FFFFFFF) break;
-                    }
-                }
-            }
-            const int row = sh[fs];
-            WB_STAMP(a.ctl, 4);
-            if (row == 0x7FFFFFFF) break;
-            WB_STAMP_COUNT(9, 1);                          // (development counters of the longest workgroup: rows, candidates collected, batched sweeps)
-            int jn = rmax[row];                 // the row's largest candidate first
-            int bound = 0x7FFFFFFF;
-            for (;;) {
-                // routine 2 for this one chord: does the open chord meet the contour's interior? (all lanes, all segments)
-                const int hf = 5 + (ntest & 1), hc = 10 + (ntest & 1);
-                ++ntest;
-                const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]), qx = wb_pt_x(pts[jn]), qy = wb_pt_y(pts[jn]);
-                const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
-                if (in_lds) {
-                    // a chord spans a few dozen columns of a contour that goes around the globe: first the blocks of 32 segments
-                    // whose box meets the chord's (a lane per block), then the segments of those blocks only -- one pass of the
-                    // workgroup instead of one per 512 segments of the contour
-                    WB_PFOR(b, nblk)
-                        if (b == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[13 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; sh[10 + (ntest & 1)] = 0; }   // the next step's / test's slots
-                        const int* bb = lbb + 4 * b;
-                        if (!(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0)) hitb[wb_atomic_add(&sh[hc], 1)] = (int)b;
-                    WB_END_PFOR
-                    const int nh = sh[hc];
-                    WB_PFOR(t, nh * WB_BLK)
-                        const int m = hitb[t >> 5] * WB_BLK + ((int)t & (WB_BLK - 1));
-                        if (m < N - 1) {
-                            const uint32_t pa = pts[m], pb = pts[m + 1];
-                            const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
-                            if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                                if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) sh[hf] = 1;
-                        }
-                    WB_END_PFOR
-                } else {
-                WB_PFOR(m, N - 1)
-                    if (m == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; }   // the next step's / test's slots
-                    const uint32_t pa = pts[m], pb = pts[m + 1];
+                const int nit = sh[12];
+                auto seg_test = [&](int c, int m) WB_LAMBDA_INLINE {
+                    const uint32_t pa = pts[m], pb = pts[m + 1], pp = hp[c], pq = hq[c];
                     const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                    const int px = wb_pt_x(pp), py = wb_pt_y(pp), qx = wb_pt_x(pq), qy = wb_pt_y(pq);
+                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
                     // a segment whose box misses the chord's box cannot meet the chord
                     if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) sh[hf] = 1;
+                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) wb_atomic_or(&hitm[0], 1u << c);
+                };
+                if (nit <= WB_F234_CAND) {
+                    WB_PFOR32(t, nit * WB_BLK)
+                        const int it = cand[t >> 5], m = (it & 0xFFFF) * WB_BLK + (t & (WB_BLK - 1));
+                        if (m < N - 1) seg_test(it >> 16, m);
+                    WB_END_PFOR
+                } else {
+                    // (more items than the list holds: every chord against every segment)
+                    WB_PFOR32(t, nb * (N - 1))
+                        const int c = t / (N - 1), m = t - c * (N - 1);
+                        if (!((skip >> c) & 1u)) seg_test(c, m);
+                    WB_END_PFOR
+                }
+            };
+            for (;;) {
+                if (WB_TID == 0) { hitm[0] = 0u; skipm[0] = 0u; sh[12] = 0; }       // (read last before the barrier that ended the previous round)
+                const int nc = wb_block_records(rmax, cur, N, M, chain, WB_F234_BATCH);
+                WB_STAMP(a.ctl, 4);
+                if (nc == 0) break;
+                // a record whose chord was tested in an earlier round (it stood behind a record that failed) is not tested again:
+                // tbits holds, two bits per row, "largest candidate tested" and "... and it meets the contour"
+                WB_PFOR32(c, nc)
+                    const int r = chain[c];
+                    const uint32_t st = (tbits[r >> 4] >> (2 * (r & 15))) & 3u;
+                    hp[c] = pts[r];
+                    hq[c] = pts[rmax[r]];
+                    if (st & 1u) wb_atomic_or(&skipm[0], 1u << c);
+                    if (st & 2u) wb_atomic_or(&hitm[0], 1u << c);
                 WB_END_PFOR
+                const int ntested = nc - wb_popc32(skipm[0]);
+                if (ntested > 0) {
+                    WB_STAMP_COUNT(9, ntested);                  // (development counters of the longest workgroup: chords of records tested, candidates collected, batched sweeps)
+                    test_batch(nc);
+                    WB_STAMP_COUNT(11, 1);
                 }
                 WB_STAMP(a.ctl, 6);
-                if (!sh[hf]) {                             // passes routine 2: the row's survivor
-                    if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
+                const uint32_t hm = hitm[0];
+                int failed = -1;
+                for (int c = 0; c < nc; ++c) {
+                    const int r = chain[c];
+                    const bool hit = (hm >> c) & 1u;
+                    if (WB_TID == 0) tbits[r >> 4] |= (hit ? 3u : 1u) << (2 * (r & 15));
+                    if (failed >= 0) continue;
+                    if (hit) { failed = c; continue; }
+                    const int u = rmax[r];                          // passes routine 2: the row's survivor
+                    if (WB_TID == 0) { mi[nsurv] = r; mj[nsurv] = u; }
                     ++nsurv;
-                    M = jn;
-                    break;
+                    M = u;
+                    cur = r + 1;
                 }
-                // The chord meets the contour.  The row's other candidates in (M, jn) are collected once, sorted in descending
-                // order and tested WB_F234_BATCH at a time (every lane takes a few contour segments against all chords of the
-                // batch); the first one in that order that passes is the row's survivor.
-                bound = jn;
+                if (failed < 0 && nc < WB_F234_BATCH) break;       // every record of the contour has been seen
+                const int row = failed >= 0 ? chain[failed] : -1;
+                WB_SYNC();                                         // chain[] and hitm are read by every lane before they are rewritten
+                if (failed < 0) continue;
+                // The record's chord meets the contour.  The row's other candidates in (M, its largest) are collected once, sorted
+                // in descending order and tested WB_F234_BATCH at a time; the first one in that order that passes is the row's
+                // survivor.  Then the records behind the row are looked for again: rows that stood in this record's shadow count now.
+                int bound = rmax[row];
                 bool done = false;
                 while (!done) {
                     WB_SINGLE
                     sh[9] = 0;
                     WB_END_SINGLE
-                    if (in_lds) {
-                        const int lo = row ? rend[row - 1] : 0;
-                        WB_PFOR(q, rend[row] - lo)
-                            const int j = bk[lo + q];
-                            if (j > M && j < bound) {
-                                const int slot = wb_atomic_add(&sh[9], 1);
-                                if (slot < WB_F234_CAND) cand[slot] = j;
-                            }
-                        WB_END_PFOR
-                    } else {
-                        WB_PFOR(p, P)
-                            if (alive[p] && (int)(pairs[p] >> 32) == row) {
-                                const int j = (int)(pairs[p] & 0xFFFFFFFFull);
-                                if (j > M && j < bound) {
-                                    const int slot = wb_atomic_add(&sh[9], 1);
-                                    if (slot < WB_F234_CAND) cand[slot] = j;
-                                }
-                            }
-                        WB_END_PFOR
-                    }
+                    const int lo = row ? rend[row - 1] : 0;
+                    WB_PFOR(q, rend[row] - lo)
+                        const int j = bk[lo + q];
+                        if (j > M && j < bound) {
+                            const int slot = wb_atomic_add(&sh[9], 1);
+                            if (slot < WB_F234_CAND) cand[slot] = j;
+                        }
+                    WB_END_PFOR
                     WB_STAMP(a.ctl, 5);
                     const int found = sh[9];
                     WB_STAMP_COUNT(10, found);
-                    if (found == 0) { done = true; break; }
+                    if (found == 0) break;
                     int K = found < WB_F234_CAND ? found : WB_F234_CAND;
                     if (found > WB_F234_CAND) {
-                        // more candidates than the list holds: keep only those above the list's K-th largest is not possible
-                        // without the full set -- take the single largest instead (one chord per round)
+                        // more candidates than the list holds: the single largest instead (one chord per round)
                         WB_SINGLE
                         sh[9] = -1;
                         WB_END_SINGLE
-                        if (in_lds) {
-                            const int lo = row ? rend[row - 1] : 0;
-                            WB_PFOR(q, rend[row] - lo)
-                                const int j = bk[lo + q];
-                                if (j > M && j < bound) wb_atomic_max(&sh[9], j);
-                            WB_END_PFOR
-                        } else {
-                            WB_PFOR(p, P)
-                                if (alive[p] && (int)(pairs[p] >> 32) == row) {
-                                    const int j = (int)(pairs[p] & 0xFFFFFFFFull);
-                                    if (j > M && j < bound) wb_atomic_max(&sh[9], j);
-                                }
-                            WB_END_PFOR
-                        }
+                        WB_PFOR(q, rend[row] - lo)
+                            const int j = bk[lo + q];
+                            if (j > M && j < bound) wb_atomic_max(&sh[9], j);
+                        WB_END_PFOR
                         K = 1;
                         WB_SINGLE
                         csort[0] = sh[9];
@@ -1391,56 +1371,17 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                     }
                     for (int b0 = 0; b0 < K && !done; b0 += WB_F234_BATCH) {
                         const int nb = K - b0 < WB_F234_BATCH ? K - b0 : WB_F234_BATCH;
-                        WB_PFOR(c, nb)                              // the chords' far ends side by side: the loop below reads them with nothing in between
+                        WB_PFOR32(c, nb)
+                            hp[c] = pts[row];
                             hq[c] = pts[csort[b0 + c]];
-                            if (c == 0) { hitm[0] = 0u; sh[12] = 0; }
+                            if (c == 0) { hitm[0] = 0u; skipm[0] = 0u; sh[12] = 0; }
                         WB_END_PFOR
-                        const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]);
-                        int nseg = N - 1;                          // segments to look at: all, or those of the blocks some chord's box meets
-                        if (in_lds) {
-                            WB_PFOR(b, nblk)
-                                const int* bb = lbb + 4 * b;
-                                bool any = false;
-                                for (int c = 0; c < nb && !any; ++c) {
-                                    const int qx = wb_pt_x(hq[c]), qy = wb_pt_y(hq[c]);
-                                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
-                                    any = !(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0);
-                                }
-                                if (any) hitb[wb_atomic_add(&sh[12], 1)] = (int)b;
-                            WB_END_PFOR
-                            nseg = sh[12] * WB_BLK;
-                        }
-                        WB_PFOR(t, nseg)
-                            const int m = in_lds ? hitb[t >> 5] * WB_BLK + ((int)t & (WB_BLK - 1)) : (int)t;
-                            if (m >= N - 1) continue;
-                            const uint32_t pa = pts[m], pb = pts[m + 1];
-                            const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
-                            // first the chords whose box meets the segment's (eight at a time: their LDS reads in flight together),
-                            // then the exact predicate for those few
-                            uint32_t near = 0u, hits = 0u;
-                            const int sx0 = ax < bx ? ax : bx, sx1 = ax < bx ? bx : ax, sy0 = ay < by ? ay : by, sy1 = ay < by ? by : ay;
-                            for (int c0 = 0; c0 < nb; c0 += 8) {
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) {
-                                    const uint32_t pq = hq[(c0 + q) & (WB_F234_BATCH - 1)];
-                                    const int qx = wb_pt_x(pq), qy = wb_pt_y(pq);
-                                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
-                                    if (c0 + q < nb && !(sx1 < cx0 || sx0 > cx1 || sy1 < cy0 || sy0 > cy1)) near |= 1u << (c0 + q);
-                                }
-                            }
-                            while (near) {
-                                const int c = wb_ctz32(near);
-                                near &= near - 1u;
-                                const uint32_t pq = hq[c];
-                                if (wb_chord_hits_segment(px, py, wb_pt_x(pq), wb_pt_y(pq), ax, ay, bx, by, pe0, pe1)) hits |= 1u << c;
-                            }
-                            if (hits) wb_atomic_or(&hitm[0], hits);
-                        WB_END_PFOR
+                        test_batch(nb);
                         WB_STAMP(a.ctl, 6);
                         WB_STAMP_COUNT(11, 1);
                         for (int c = 0; c < nb; ++c) {
                             if (!((hitm[0] >> c) & 1u)) {             // the largest candidate that passes routine 2
-                                jn = csort[b0 + c];
+                                const int jn = csort[b0 + c];
                                 if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
                                 ++nsurv;
                                 M = jn;
@@ -1455,9 +1396,70 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                         else done = true;                              // every candidate of the row failed
                     }
                 }
-                break;
+                cur = row + 1;
+            }
+        } else {
+        // (a contour longer than the LDS holds: row after row in global memory, a search for the next row and a chord test each)
+        int ntest = 0;
+        for (int step = 0;; ++step) {
+            const int fs = 3 + (step & 1);
+            const int win = WB_NT > 64 ? WB_NT : 64;
+            {
+                WB_PFOR(t, win)
+                    const int i = cur + (int)t;
+                    wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
+                WB_END_PFOR
+            }
+            if (sh[fs] == 0x7FFFFFFF) {
+                for (int base = cur + win; base < N; base += win) {
+                    WB_PFOR(t, win)
+                        const int i = base + (int)t;
+                        wb_atomic_min_first(&sh[fs], i < N && rmax[i] > M, i);
+                    WB_END_PFOR
+                    if (sh[fs] != 0x7FFFFFFF) break;
+                }
+            }
+            const int row = sh[fs];
+            if (row == 0x7FFFFFFF) break;
+            int jn = rmax[row];                 // the row's largest candidate first
+            int bound = 0x7FFFFFFF;
+            for (;;) {
+                // routine 2 for this one chord: does the open chord meet the contour's interior? (all lanes, all segments)
+                const int hf = 5 + (ntest & 1);
+                ++ntest;
+                const int px = wb_pt_x(pts[row]), py = wb_pt_y(pts[row]), qx = wb_pt_x(pts[jn]), qy = wb_pt_y(pts[jn]);
+                const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                WB_PFOR(m, N - 1)
+                    if (m == 0) { sh[3 + ((step + 1) & 1)] = 0x7FFFFFFF; sh[5 + (ntest & 1)] = 0; }   // the next step's / test's slots
+                    const uint32_t pa = pts[m], pb = pts[m + 1];
+                    const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
+                    // a segment whose box misses the chord's box cannot meet the chord
+                    if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
+                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) sh[hf] = 1;
+                WB_END_PFOR
+                if (!sh[hf]) {                             // passes routine 2: the row's survivor
+                    if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
+                    ++nsurv;
+                    M = jn;
+                    break;
+                }
+                // the chord meets the contour: the row's largest candidate in (M, jn), one per round
+                bound = jn;
+                WB_SINGLE
+                sh[9] = -1;
+                WB_END_SINGLE
+                WB_PFOR(p, P)
+                    if (alive[p] && (int)(pairs[p] >> 32) == row) {
+                        const int j = (int)(pairs[p] & 0xFFFFFFFFull);
+                        if (j > M && j < bound) wb_atomic_max(&sh[9], j);
+                    }
+                WB_END_PFOR
+                jn = sh[9];
+                WB_SYNC();
+                if (jn < 0) break;                         // every candidate of the row failed
             }
             cur = row + 1;
+        }
         }
         WB_SINGLE
         sh[2] = nsurv;

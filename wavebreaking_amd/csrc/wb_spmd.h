@@ -105,6 +105,15 @@ static inline void wb_block_scan_excl_max(int* a, int n, int init) {
     for (int i = 0; i < n; ++i) { int v = a[i]; a[i] = run; if (v > run) run = v; }
 }
 
+// the RECORDS of a[lo..hi) above `floor`, in ascending order of their index: the i with a[i] > max(floor, a[lo..i)).
+// out[0..cap) <- the first cap of them; returns how many were written (== cap: there may be more behind out[cap - 1])
+static inline int wb_block_records(const int* a, int lo, int hi, int floor, int* out, int cap) {
+    int run = floor, cnt = 0;
+    for (int i = lo; i < hi && cnt < cap; ++i)
+        if (a[i] > run) { run = a[i]; out[cnt++] = i; }
+    return cnt;
+}
+
 // in-place inclusive running sum of a[0..n) (doubles) on top of `carry`; returns the new carry.  (On the GPU the terms are
 // combined as a parallel scan combines them: a running sum that differs from the left-to-right one in its last bits.)
 static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
@@ -358,6 +367,56 @@ __device__ inline void wb_block_scan_excl_max(int* a, int n, int init) {
         }
         __syncthreads();
     }
+}
+// the RECORDS of a[lo..hi) above `floor`, in ascending order of their index: the i with a[i] > max(floor, a[lo..i)).
+// out[0..cap) (LDS) <- the first cap of them; returns how many were written (== cap: there may be more behind out[cap - 1]).
+// All threads of the block call it with the same arguments and get the same result; eight consecutive elements per thread and
+// chunk, running maximum and count across the wave by shuffles and across the waves through LDS: two barriers per chunk of
+// 8 * blockDim.x elements and one behind it (out[] is complete and visible when the call returns).
+__device__ inline int wb_block_records(const int* a, int lo, int hi, int floor, int* out, int cap) {
+    __shared__ int wb_rec_max[16];
+    __shared__ int wb_rec_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    const int none = (int)0x80000000;
+    int runmax = floor, runcnt = 0;                    // the same in every thread
+    for (int base = lo; base < hi && runcnt < cap; base += 8 * (int)blockDim.x) {
+        const int i0 = base + 8 * tid;
+        int v[8], mx = none;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < hi) ? a[i0 + k] : none; mx = v[k] > mx ? v[k] : mx; }
+        int inc = mx;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d && o > inc) inc = o;
+        }
+        int excl = __shfl_up(inc, 1, 64);
+        if (lane == 0) excl = none;
+        if (lane == 63) wb_rec_max[wave] = inc;
+        __syncthreads();
+        int run = runmax;
+        for (int w = 0; w < wave; ++w) run = wb_rec_max[w] > run ? wb_rec_max[w] : run;
+        run = excl > run ? excl : run;
+        int cnt = 0;
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (v[k] > run) { run = v[k]; mask |= 1u << k; ++cnt; }
+        const int cinc = wb_wave_scan_incl(cnt);
+        if (lane == 63) wb_rec_cnt[wave] = cinc;
+        __syncthreads();
+        int off = runcnt + cinc - cnt;
+        for (int w = 0; w < wave; ++w) off += wb_rec_cnt[w];
+        while (mask) {
+            const int k = __ffs((int)mask) - 1;
+            mask &= mask - 1u;
+            if (off < cap) out[off] = i0 + k;
+            ++off;
+        }
+        for (int w = 0; w < nw; ++w) { runmax = wb_rec_max[w] > runmax ? wb_rec_max[w] : runmax; runcnt += wb_rec_cnt[w]; }
+        __syncthreads();
+    }
+    return runcnt < cap ? runcnt : cap;
 }
 // in-place inclusive running sum of a[0..n) (doubles, LDS or global; n <= 8 * blockDim.x) on top of `carry`; all threads of
 // the block call it, every thread gets the new carry.  A thread owns 8 consecutive terms; thread sums are scanned inside
