@@ -43,13 +43,15 @@ def test_streamer_filters_on_contours_longer_than_their_lds(sim, reverse):
     lib.lib.wb_hostsim_set_reverse(reverse)
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(10, 3, lat, lon, eps=0.3)
-    for lpts in (64, 256, 0):
+    for lpts, fused in ((64, 1), (256, 1), (0, 0), (64, 0), (0, 1)):
         ctx.set_option("f234_lpts", lpts)
+        ctx.set_option("f1_fused", fused)      # routine 1 inside wb_k_streamer_f234 / as its own launch
         try:
             got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(3), [-2, 2], intensity=pv)
             assert len(ref["streamers"]) > 5
         finally:
             ctx.set_option("f234_lpts", 0)
+            ctx.set_option("f1_fused", 0)
 
 
 def test_demo_shaped_config0(sim):

@@ -1547,6 +1547,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             st.nalive = (int*)talloc(nsel_b * sizeof(int));
             st.tie_m = (int*)talloc(nsel_b * sizeof(int));
             st.eager = ctx->eager_f2 ? 1 : 0;
+            st.f1_fused = (ctx->f1_fused && !ctx->eager_f2) ? 1 : 0;
             st.rowmax = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
             st.rowaux = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
             st.rowmx = (int*)talloc((size_t)(NPT + 1) * sizeof(int));
@@ -1587,7 +1588,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             boxcom_here(2);
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_pairs_order, 1, WB_LIST_THREADS, st);
-            { long long res = 2LL * wb_num_cus(ctx) - ctx->persist_slack; if (res < 1) res = 1; WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
+            // routine 1: inside wb_k_streamer_f234 (option f1_fused, the default), or its own persistent launch in front of the eager kernels
+            if (!st.f1_fused) { long long res = (2048LL / WB_F1_THREADS) * wb_num_cus(ctx) - ctx->persist_slack; if (res < 1) res = 1; WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
             b->timer.end(ctx);
             if (ctx->eager_f2) {
                 // routine 2 for every candidate pair, then routines 3 + 4 on the survivors (option "eager_f2": the exhaustive
@@ -1604,7 +1606,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                 b->timer.end(ctx);
             } else {
                 b->timer.begin(ctx, "streamer_f234");
-                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 12 + (size_t)(st.f234_cap / WB_BLK + 1) * 16 + 64, st);
+                WB_LAUNCH_LDS(wb_k_streamer_f234, nsel_b, WB_F234_THREADS, (size_t)st.f234_cap * 4 + (size_t)(((st.f234_cap + 1) & ~1) + (st.f234_cap > WB_F234_SCR ? ((st.f234_cap + 1) & ~1) : WB_F234_SCR)) * 4 + (size_t)(st.f234_cap / WB_BLK + 1) * 16 + 64, st);
                 WB_LAUNCH(wb_k_streamer_ties, 1, 64, st);      // one wave: check_groups' exact ties (nearly always none)
                 b->timer.end(ctx);
             }
@@ -2139,6 +2141,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "geometry")) { ctx->geometry = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }
+    if (!strcmp(name, "f1_fused")) { ctx->f1_fused = value ? 1 : 0; return 0; }
     if (!strcmp(name, "f234_lpts")) { ctx->f234_lpts = value >= 64 ? value : 0; return 0; }      // (tests: longer contours take wb_k_streamer_f234's path through global memory)
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }
     if (!strcmp(name, "scan_pad")) { ctx->scan_pad = value >= 0 ? value : 0; return 0; }

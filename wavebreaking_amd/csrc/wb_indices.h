@@ -325,6 +325,7 @@ struct WbStreamerArgs {
     int p2_cap;                // contour points its LDS holds; 0: kernel not used (every contour in the tiled kernel's list)
     int p2_split;              // workgroups per contour
     int f234_cap;              // wb_k_streamer_f234: contour points its dynamic LDS holds (12 bytes each + a bit)
+    int f1_fused;              // 1: wb_k_streamer_f234 runs routine 1 itself (no wb_k_streamer_f1 launch)
     int* order;                // [nsel] the selected contours, those with the most candidate pairs first (wb_k_pairs_order)
     int* recheck;              // [recheck_cap][4] pairs inside a guard band: contour, i, j, 0 (wb_k_streamer_recheck decides them)
     int recheck_cap;
@@ -1130,8 +1131,15 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #define WB_F234_OCC 6               // waves per SIMD the register allocation leaves room for (6: 80 registers, three workgroups per CU)
 #endif
 #define WB_F234_R4 256             // survivors whose routine-4 arrays are held in LDS
-#define WB_F234_CAND 512           // candidates of one row collected after its first chord failed
-#define WB_F234_BATCH 32           // chords tested per sweep over the contour's segments       // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
+#define WB_F234_CH WB_F234_R4       // records listed per round
+#define WB_F234_CC (2 * WB_F234_R4)   // chords tested per round
+#define WB_F234_K 8                // candidates of a failing row tested per round
+#define WB_F234_GROUP 128          // chords whose (chord, block) items are listed together
+#define WB_F234_ITEMS 1024         // ... and how many the list holds
+#define WB_F234_FMAX 8             // failing records whose candidates a round looks at
+#define WB_F234_FSTAGE 128         // candidates in range of one of them held in LDS (more: only the largest is tested)
+#define WB_F234_SCR (10 * WB_F234_R4)   // ints of the sweep's lists / routine 4's arrays (4 R4 ints + 3 R4 64-bit words)
+      // per-contour work is a chain of short phases: many lanes = few dependent round trips per phase
 WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a) {
     if (WB_BLOCK_ID >= a.ctl->nsel) return;
     const int s = a.order[WB_BLOCK_ID];
@@ -1158,39 +1166,57 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     // at most WB_F234_LPTS: with a fixed 4096 the kernel held three workgroups per CU, sized to a 0.25 degree contour four)
     WB_DYN_SHARED_BEGIN
     WB_DYN_SHARED(uint32_t, lpts, a.f234_cap);
-    WB_DYN_SHARED(int, lrmax, a.f234_cap);       // per row: largest ind2 among its alive candidates
-    WB_DYN_SHARED(int, rend, a.f234_cap);        // per row: its alive candidates, then the end of its bucket in bk
+    // lwork: per row the largest ind2 among its alive candidates (lrmax), then per row its alive candidates / the end of its bucket in
+    // bk (rend) -- once the buckets stand (their ends go to global memory) the sweep's lists, then routine 4's arrays; before all
+    // that, as one piece, routine 1's table of the western pairs
+    const int capE = (a.f234_cap + 1) & ~1, scrE = a.f234_cap > WB_F234_SCR ? capE : WB_F234_SCR;
+    WB_DYN_SHARED(int, lwork, capE + scrE);
+    int* const lrmax = lwork;
+    int* const rend = lwork + capE;
     WB_DYN_SHARED(int, lbb, 4 * (a.f234_cap / WB_BLK + 1));   // boxes of the blocks of WB_BLK segments (wb_k_streamer_prep: points 32 b .. 32 b + 32)
-    WB_SHARED(int, chain, WB_F234_BATCH);        // the next records of rmax[] above M: the rows whose largest candidates are tested together
-    WB_SHARED(uint32_t, hp, WB_F234_BATCH);      // near end points of the chords of a batch
-    WB_SHARED(uint32_t, skipm, 1);               // chords of the batch whose result is known already
-    WB_SHARED(uint32_t, tbits, WB_F234_LPTS / 16);   // two bits per row: its largest candidate has been tested / meets the contour
-    WB_SHARED(int, cand, WB_F234_CAND);          // a row's candidates after its largest one failed routine 2; sorted copy
-    WB_SHARED(int, csort, WB_F234_CAND);
-    WB_SHARED(uint32_t, hq, WB_F234_BATCH);     // far end points of the chords of a batch
-    WB_SHARED(uint32_t, hitm, 1);               // ... and which of them met the contour
+    WB_SHARED(uint32_t, tbits, WB_F234_LPTS / 16);   // two bits per row: the chord to its present bound rmax[r] has been tested / meets the contour
+    WB_SHARED(int, items, WB_F234_ITEMS);        // (chord, block) pairs whose boxes meet
+    WB_SHARED(uint32_t, hitw, WB_F234_CC / 32);  // a bit per chord of the round: it meets the contour
+    WB_SHARED(int, fl, 4 * WB_F234_FMAX);        // the failing records of a round: place in the list, floor, candidates in range, the largest of them
+    int* const lr4 = rend;                                                        // [4 R4] the sweep's record list and its bookkeeping, then routine 4's arrays
+    unsigned long long* const lbest = (unsigned long long*)(rend + 4 * WB_F234_R4);   // [3 R4] the sweep's chords, then routine 4's best length / member per group
+    int* const grend = a.rowaux + a.poff[s];     // the buckets' ends, for the sweep
     WB_SHARED(int, sh, 15);              // [2] survivors, [3..4] row found, [5..6] hit flag, [7..8] change flag, [9] next candidate, [10..11] blocks met by a chord, [12] by a batch of chords
                                          // (words alternate between two slots: a slot is rewritten two barriers after its last read)
-    const int stage = a.stage[s];
-    const int nal = a.nalive[s];
     const bool in_lds = N <= a.f234_cap;
     const uint32_t* pts = in_lds ? lpts : gpts;
     const uint32_t pe0 = gpts[0], pe1 = gpts[N - 1];          // the contour's end vertices: its boundary, as a point set (wb_chord_hits_segment)
     int* rmax = in_lds ? lrmax : a.rowmx + a.poff[s];
     WB_STAMP_BEGIN
     const int nblk = (N + WB_BLK - 1) / WB_BLK;
+    if (in_lds) {
+        WB_PFOR(i, N)
+            lpts[i] = gpts[i];
+            if (i < 4 * nblk) lbb[i] = a.bbx[4 * ((a.poff[s] >> 5) + s) + i];
+        WB_END_PFOR
+    }
+    if (a.f1_fused) {
+        // routine 1 (check_duplicates) here, on the contour just loaded: its table of the western pairs lies where the row maxima
+        // and buckets will (they are built from its result), a power of two of 64-bit entries; a contour with more western pairs
+        // than half of that takes the table in global memory, as in wb_k_streamer_f1
+        int lcap = 256;
+        while (2 * lcap <= (capE + scrE) / 2) lcap <<= 1;
+        (void)wb_streamer_f1_body(a, s, job, pts, (unsigned long long*)lwork, lcap, false);
+        WB_SYNC();
+    }
+    const int stage = a.stage[s];
+    const int nal = a.nalive[s];
     WB_PFOR(i, N)
-        if (in_lds) { lpts[i] = gpts[i]; rend[i] = 0; }
+        if (in_lds) rend[i] = 0;
         if (in_lds && i < (N + 15) / 16) tbits[i] = 0u;
         rmax[i] = -1;
-        if (in_lds && i < 4 * nblk) lbb[i] = a.bbx[4 * ((a.poff[s] >> 5) + s) + i];
     WB_END_PFOR
     WB_SINGLE
-    sh[2] = 0;
-    sh[3] = 0x7FFFFFFF; sh[4] = 0x7FFFFFFF;     // search results of even / odd iterations
+    sh[2] = 0; sh[9] = 0;
+    sh[3] = in_lds ? 0 : 0x7FFFFFFF; sh[4] = sh[3];   // (global-memory sweep) search results of even / odd iterations
     sh[5] = 0; sh[6] = 0;                       // hit flags of even / odd chord tests
     sh[10] = 0; sh[11] = 0; sh[12] = 0;         // blocks met by even / odd chord tests, by a batch
-    sh[13] = 0x7FFFFFFF; sh[14] = 0x7FFFFFFF;   // word found by the far search of even / odd iterations
+    sh[13] = 0; sh[14] = 0;
     WB_END_SINGLE
     WB_STAMP(a.ctl, 0);
     if (stage == 1 && nal > 1) {
@@ -1234,169 +1260,198 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                 for (int u = 0; u < 4; ++u)
                     if (al[u]) bk[wb_atomic_add(&rend[(int)(pr[u] >> 32)], 1)] = (int)(pr[u] & 0xFFFFFFFFull);
             WB_END_PFOR
+            WB_PFOR(i, N)
+                grend[i] = rend[i];
+            WB_END_PFOR
         }
         WB_STAMP(a.ctl, 1);
-        // The sweep.  A row contributes the largest of its candidates above M whose chord passes routine 2; whether a chord
-        // passes does not depend on M.  So as long as every row's LARGEST candidate passes, the rows that contribute are the
-        // records of rmax[] above M -- known without a single chord test -- and their chords are tested together, WB_F234_BATCH
-        // records per sweep over the contour's segments.  Only a record whose largest candidate fails makes the sweep look at
-        // that row's other candidates (in descending order, again a batch at a time) and at the records behind it anew.
-        // (Until round 5 the rows were visited one after the other, a search for the next row and a chord test each: 18 rows per
-        // contour of the 0.25 degree bench batch, 4.5 + 1.9 us per row, three quarters of the kernel.)
-        // M, the next row and the survivor count are the same in every lane and live in registers.
-        int M = -1, cur = 0, nsurv = 0;
+        // The sweep (check_overlapping over the pairs that pass check_intersections).  Going through the rows in ascending order
+        // with M = the largest ind2 kept so far, a row contributes the largest of its candidates above M whose chord passes
+        // routine 2.  Whether a chord passes does not depend on M: with F[r] = the largest PASSING candidate of row r, the rows
+        // that contribute are exactly the records of F (F[r] > F[r'] for every r' < r).  rmax[r] starts as the row's largest
+        // candidate, an upper bound of F[r], and is only ever lowered towards it; one round
+        //   * lists the records of rmax (wb_block_records) -- the only rows that can matter under the present bounds,
+        //   * tests the chords of the records not tested yet, and for a record whose chord is known to meet the contour its next
+        //     WB_F234_K candidates (below its bound, above the last passing record in front of it), all in ONE sweep,
+        //   * lowers the failing records' bounds to their first passing candidate (or to the last one tested, or to "none"),
+        // and the rounds end when every record's chord has passed: they are the survivors, in row order.  A chord is tested only
+        // if the row-after-row sweep would test it too (bounds in front of it that are too high can only hide a row), but the
+        // rows' tests are no longer one after the other: a contour takes a handful of rounds of nine barriers, whatever the
+        // number of its rows -- the row-after-row sweep took 18 rows x 6 barriers on the average contour of the 0.25 degree bench
+        // batch and 61 rows, 31 of them failing with a dozen candidates each, on the one that set the kernel's duration.
+        int nsurv = 0;
+        int M = -1, cur = 0;
         if (in_lds) {
-            // hp / hq: the end points of the chords of a batch (skipm: chords not to test).  First the (chord, block of 32 segments)
-            // items whose boxes meet -- a lane per chord and block --, then a lane per item and segment: box, then the exact
-            // predicate.  hitm: the chords that meet the contour.  (Testing the union of the chords' blocks against every chord of
-            // the batch, as the row's candidates were until round 5, is 7 us per sweep when the chords lie all over the contour.)
-            auto test_batch = [&](int nb) WB_LAMBDA_INLINE {
-                const uint32_t skip = skipm[0];
-                WB_PFOR32(t, nb * nblk)
-                    const int c = t / nblk, b = t - c * nblk;
-                    if ((skip >> c) & 1u) continue;
-                    const int px = wb_pt_x(hp[c]), py = wb_pt_y(hp[c]), qx = wb_pt_x(hq[c]), qy = wb_pt_y(hq[c]);
-                    const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
-                    const int* bb = lbb + 4 * b;
-                    if (!(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0)) {
-                        const int slot = wb_atomic_add(&sh[12], 1);
-                        if (slot < WB_F234_CAND) cand[slot] = (c << 16) | b;
+            int* const chain = lr4;                              // [CH] the records of rmax[] above M from row cur on
+            int* const kslot = lr4 + WB_F234_CH;                 // [CH] the record's own chord in this round's list / its place among the failing records
+            int* const kcnt = lr4 + 2 * WB_F234_CH;              // [CH] -1: the record's own chord is tested (not tested before); 1: a failing record that has its candidates tested
+            uint32_t* const cp = (uint32_t*)lbest;               // [CC] the chords of the round: near end,
+            uint32_t* const cq = cp + WB_F234_CC;                // far end,
+            int* const cj = (int*)(cq + WB_F234_CC);             // ind2 (-1: no chord)
+            int* const stage = items;                            // [FMAX][FSTAGE] a failing record's candidates in range (before the items are listed)
+            const uint32_t TB_TESTED = 1u, TB_FAILED = 2u;
+            auto emit = [&](int nc) WB_LAMBDA_INLINE {           // every record's chord has passed: the survivors of rows cur ..
+                WB_PFOR32(c, nc)
+                    mi[nsurv + c] = chain[c];
+                    mj[nsurv + c] = rmax[chain[c]];
+                WB_END_PFOR
+                nsurv += nc;
+            };
+            // counters of a round: sh[9] own chords, sh[10] records not yet passed, sh[12] / sh[13] items of even / odd groups,
+            // sh[3 + par] failing records, sh[5 + par] "a record's own chord met the contour" (par: the round's parity); all zero
+            // at the start of a round -- cleared in the verdict pass of the round before, two barriers after their last use
+            for (int round = 0;; ++round) {
+                const int nfw = 3 + (round & 1), hfw = 5 + (round & 1);
+                const int nc = wb_block_records(rmax, cur, N, M, chain, WB_F234_CH);
+                WB_STAMP(a.ctl, 4);
+                if (nc == 0) break;
+                WB_PFOR32(c, nc)
+                    const int r = chain[c], u = rmax[r];
+                    const uint32_t st = (tbits[r >> 4] >> (2 * (r & 15))) & 3u;
+                    kcnt[c] = 0;
+                    if (c < WB_F234_CC / 32) hitw[c] = 0u;           // (a round of nc records tests at most 8 nc chords)
+                    if (!(st & TB_TESTED)) {
+                        wb_atomic_add(&sh[10], 1);
+                        const int slot = wb_atomic_add(&sh[9], 1);      // (at most CH of them: they always find room)
+                        cp[slot] = pts[r]; cq[slot] = pts[u]; cj[slot] = u; kslot[c] = slot; kcnt[c] = -1;
+                    } else if (st & TB_FAILED) {
+                        wb_atomic_add(&sh[10], 1);
+                        const int f = wb_atomic_add(&sh[nfw], 1);
+                        if (f < WB_F234_FMAX) {
+                            // the last record in front of this one whose chord has passed: its ind2 is final, candidates up to it are moot
+                            int floor = M;
+                            for (int b = (int)c - 1; b >= 0; --b) {
+                                const int rb = chain[b];
+                                const uint32_t sb = (tbits[rb >> 4] >> (2 * (rb & 15))) & 3u;
+                                if (sb == TB_TESTED) { floor = rmax[rb]; break; }
+                            }
+                            kslot[c] = f; kcnt[c] = 1;
+                            fl[f] = (int)c; fl[WB_F234_FMAX + f] = floor; fl[2 * WB_F234_FMAX + f] = 0; fl[3 * WB_F234_FMAX + f] = -1;
+                        }                                            // (more failing records than a round takes: the next round)
                     }
                 WB_END_PFOR
-                const int nit = sh[12];
+                WB_STAMP(a.ctl, 5);
+                if (sh[10] == 0) {
+                    emit(nc);
+                    if (nc < WB_F234_CH) break;
+                    cur = chain[nc - 1] + 1;                       // (more records than the list holds: on behind its last one)
+                    M = rmax[chain[nc - 1]];
+                    if (WB_TID == 0) { sh[7 - nfw] = 0; sh[11 - hfw] = 0; }   // (no verdict pass in this round)
+                    WB_SYNC();
+                    continue;
+                }
+                const int nu = sh[9], nf = sh[nfw] < WB_F234_FMAX ? sh[nfw] : WB_F234_FMAX;
+                if (nf > 0) {
+                    // a failing record's candidates in (floor, bound): 64 lanes go through its bucket, the candidates in range
+                    // meet in LDS; the WB_F234_K largest of them are this round's chords of the row (rank by counting)
+                    WB_PFOR32(t, nf * 64)
+                        const int f = t >> 6, c = fl[f], r = chain[c], u = rmax[r], floor = fl[WB_F234_FMAX + f];
+                        const int lo = r ? grend[r - 1] : 0, hi = grend[r];
+                        for (int e = lo + (t & 63); e < hi; e += 64) {
+                            const int j = bk[e];
+                            if (j > floor && j < u) {
+                                const int slot = wb_atomic_add(&fl[2 * WB_F234_FMAX + f], 1);
+                                if (slot < WB_F234_FSTAGE) stage[f * WB_F234_FSTAGE + slot] = j;
+                                wb_atomic_max(&fl[3 * WB_F234_FMAX + f], j);
+                            }
+                        }
+                    WB_END_PFOR
+                    WB_PFOR32(t, nf * WB_F234_FSTAGE)
+                        const int f = t / WB_F234_FSTAGE, i = t % WB_F234_FSTAGE, all = fl[2 * WB_F234_FMAX + f];
+                        const int r = chain[fl[f]], base = nu + f * WB_F234_K;
+                        if (all > WB_F234_FSTAGE) {
+                            // (more candidates in range than the staging holds: the largest one alone)
+                            if (i == 0) { cp[base] = pts[r]; cq[base] = pts[fl[3 * WB_F234_FMAX + f]]; cj[base] = fl[3 * WB_F234_FMAX + f]; }
+                            else if (i < WB_F234_K) cj[base + i] = -1;
+                        } else {
+                            if (i < all) {
+                                const int j = stage[f * WB_F234_FSTAGE + i];
+                                int rk = 0;
+                                for (int q = 0; q < all; ++q) rk += stage[f * WB_F234_FSTAGE + q] > j ? 1 : 0;
+                                if (rk < WB_F234_K) { cp[base + rk] = pts[r]; cq[base + rk] = pts[j]; cj[base + rk] = j; }
+                            } else if (i < WB_F234_K) cj[base + i] = -1;     // (fewer than K candidates: ranks all .. K - 1 stay empty)
+                        }
+                    WB_END_PFOR
+                }
+                const int nch = nu + nf * WB_F234_K;
+                WB_STAMP_COUNT(9, nch);                            // (development counters of the longest workgroup: chord slots, rounds)
+                WB_STAMP_COUNT(11, 1);
+                // the chords against the contour, WB_F234_GROUP at a time: the (chord, block of 32 segments) items whose boxes meet --
+                // a lane per chord and block --, then a lane per item and segment: box, then the exact predicate.  hitw: a bit per
+                // chord that meets the contour.
                 auto seg_test = [&](int c, int m) WB_LAMBDA_INLINE {
-                    const uint32_t pa = pts[m], pb = pts[m + 1], pp = hp[c], pq = hq[c];
+                    const uint32_t pa = pts[m], pb = pts[m + 1], pp = cp[c], pq = cq[c];
                     const int ax = wb_pt_x(pa), ay = wb_pt_y(pa), bx = wb_pt_x(pb), by = wb_pt_y(pb);
                     const int px = wb_pt_x(pp), py = wb_pt_y(pp), qx = wb_pt_x(pq), qy = wb_pt_y(pq);
                     const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
                     // a segment whose box misses the chord's box cannot meet the chord
                     if (!((ax < cx0 && bx < cx0) || (ax > cx1 && bx > cx1) || (ay < cy0 && by < cy0) || (ay > cy1 && by > cy1)))
-                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) wb_atomic_or(&hitm[0], 1u << c);
+                        if (wb_chord_hits_segment(px, py, qx, qy, ax, ay, bx, by, pe0, pe1)) wb_atomic_or(&hitw[c >> 5], 1u << (c & 31));
                 };
-                if (nit <= WB_F234_CAND) {
-                    WB_PFOR32(t, nit * WB_BLK)
-                        const int it = cand[t >> 5], m = (it & 0xFFFF) * WB_BLK + (t & (WB_BLK - 1));
-                        if (m < N - 1) seg_test(it >> 16, m);
+                for (int g0 = 0; g0 < nch; g0 += WB_F234_GROUP) {
+                    const int ng = nch - g0 < WB_F234_GROUP ? nch - g0 : WB_F234_GROUP;
+                    const int is = 12 + ((g0 / WB_F234_GROUP) & 1);   // (item counters of even / odd groups)
+                    WB_PFOR32(t, ng << 7)                             // (nblk <= 128: a chord's blocks are 128 consecutive t, no division)
+                        if (t == 0) sh[25 - is] = 0;                  // the next group's counter
+                        const int c = g0 + (t >> 7), b = t & 127;
+                        if (b >= nblk || cj[c] < 0) continue;
+                        const int px = wb_pt_x(cp[c]), py = wb_pt_y(cp[c]), qx = wb_pt_x(cq[c]), qy = wb_pt_y(cq[c]);
+                        const int cx0 = px < qx ? px : qx, cx1 = px < qx ? qx : px, cy0 = py < qy ? py : qy, cy1 = py < qy ? qy : py;
+                        const int* bb = lbb + 4 * b;
+                        if (!(bb[0] > cx1 || bb[1] < cx0 || bb[2] > cy1 || bb[3] < cy0)) {
+                            const int slot = wb_atomic_add(&sh[is], 1);
+                            if (slot < WB_F234_ITEMS) items[slot] = (c << 12) | b;
+                        }
                     WB_END_PFOR
-                } else {
-                    // (more items than the list holds: every chord against every segment)
-                    WB_PFOR32(t, nb * (N - 1))
-                        const int c = t / (N - 1), m = t - c * (N - 1);
-                        if (!((skip >> c) & 1u)) seg_test(c, m);
-                    WB_END_PFOR
-                }
-            };
-            for (;;) {
-                if (WB_TID == 0) { hitm[0] = 0u; skipm[0] = 0u; sh[12] = 0; }       // (read last before the barrier that ended the previous round)
-                const int nc = wb_block_records(rmax, cur, N, M, chain, WB_F234_BATCH);
-                WB_STAMP(a.ctl, 4);
-                if (nc == 0) break;
-                // a record whose chord was tested in an earlier round (it stood behind a record that failed) is not tested again:
-                // tbits holds, two bits per row, "largest candidate tested" and "... and it meets the contour"
-                WB_PFOR32(c, nc)
-                    const int r = chain[c];
-                    const uint32_t st = (tbits[r >> 4] >> (2 * (r & 15))) & 3u;
-                    hp[c] = pts[r];
-                    hq[c] = pts[rmax[r]];
-                    if (st & 1u) wb_atomic_or(&skipm[0], 1u << c);
-                    if (st & 2u) wb_atomic_or(&hitm[0], 1u << c);
-                WB_END_PFOR
-                const int ntested = nc - wb_popc32(skipm[0]);
-                if (ntested > 0) {
-                    WB_STAMP_COUNT(9, ntested);                  // (development counters of the longest workgroup: chords of records tested, candidates collected, batched sweeps)
-                    test_batch(nc);
-                    WB_STAMP_COUNT(11, 1);
+                    const int nit = sh[is];
+                    if (nit <= WB_F234_ITEMS) {
+                        WB_PFOR32(t, nit * WB_BLK)
+                            const int it = items[t >> 5], m = (it & 0xFFF) * WB_BLK + (t & (WB_BLK - 1));
+                            if (m < N - 1) seg_test(it >> 12, m);
+                        WB_END_PFOR
+                    } else {
+                        // (more items than the list holds: every chord of the group against every segment)
+                        WB_PFOR32(t, ng * (N - 1))
+                            const int c = g0 + t / (N - 1);
+                            if (cj[c] >= 0) seg_test(c, t % (N - 1));
+                        WB_END_PFOR
+                    }
                 }
                 WB_STAMP(a.ctl, 6);
-                const uint32_t hm = hitm[0];
-                int failed = -1;
-                for (int c = 0; c < nc; ++c) {
-                    const int r = chain[c];
-                    const bool hit = (hm >> c) & 1u;
-                    if (WB_TID == 0) tbits[r >> 4] |= (hit ? 3u : 1u) << (2 * (r & 15));
-                    if (failed >= 0) continue;
-                    if (hit) { failed = c; continue; }
-                    const int u = rmax[r];                          // passes routine 2: the row's survivor
-                    if (WB_TID == 0) { mi[nsurv] = r; mj[nsurv] = u; }
-                    ++nsurv;
-                    M = u;
-                    cur = r + 1;
-                }
-                if (failed < 0 && nc < WB_F234_BATCH) break;       // every record of the contour has been seen
-                const int row = failed >= 0 ? chain[failed] : -1;
-                WB_SYNC();                                         // chain[] and hitm are read by every lane before they are rewritten
-                if (failed < 0) continue;
-                // The record's chord meets the contour.  The row's other candidates in (M, its largest) are collected once, sorted
-                // in descending order and tested WB_F234_BATCH at a time; the first one in that order that passes is the row's
-                // survivor.  Then the records behind the row are looked for again: rows that stood in this record's shadow count now.
-                int bound = rmax[row];
-                bool done = false;
-                while (!done) {
-                    WB_SINGLE
-                    sh[9] = 0;
-                    WB_END_SINGLE
-                    const int lo = row ? rend[row - 1] : 0;
-                    WB_PFOR(q, rend[row] - lo)
-                        const int j = bk[lo + q];
-                        if (j > M && j < bound) {
-                            const int slot = wb_atomic_add(&sh[9], 1);
-                            if (slot < WB_F234_CAND) cand[slot] = j;
+                // the verdicts: a record's own chord is marked; a failing record takes its first candidate that passes as its new
+                // bound (final: every larger candidate of the row meets the contour), or the last one tested, or none
+                WB_PFOR32(c, nc)
+                    if (c == 0) { sh[9] = 0; sh[10] = 0; sh[12] = 0; sh[7 - nfw] = 0; sh[11 - hfw] = 0; }   // the next round's counters
+                    const int r = chain[c], kind = kcnt[c];
+                    if (kind == -1) {
+                        const int s0 = kslot[c];
+                        const bool hit = (hitw[s0 >> 5] >> (s0 & 31)) & 1u;
+                        if (hit) sh[hfw] = 1;
+                        wb_atomic_or(&tbits[r >> 4], (hit ? (TB_TESTED | TB_FAILED) : TB_TESTED) << (2 * (r & 15)));
+                    } else if (kind == 1) {
+                        const int f = kslot[c], s0 = nu + f * WB_F234_K, all = fl[2 * WB_F234_FMAX + f];
+                        const int n = all > WB_F234_FSTAGE ? 1 : (all < WB_F234_K ? all : WB_F234_K);
+                        int found = -1;
+                        for (int q = 0; q < n && found < 0; ++q)
+                            if (!((hitw[(s0 + q) >> 5] >> ((s0 + q) & 31)) & 1u)) found = cj[s0 + q];
+                        if (found >= 0) {
+                            rmax[r] = found;                        // passes: tested, not failed
+                            wb_atomic_and(&tbits[r >> 4], ~(TB_FAILED << (2 * (r & 15))));
+                        } else if (n == all) {
+                            rmax[r] = -1;                           // every candidate in range meets the contour (or there was none)
+                        } else {
+                            rmax[r] = cj[s0 + n - 1];               // (tested, failed: on below it in the next round)
                         }
-                    WB_END_PFOR
-                    WB_STAMP(a.ctl, 5);
-                    const int found = sh[9];
-                    WB_STAMP_COUNT(10, found);
-                    if (found == 0) break;
-                    int K = found < WB_F234_CAND ? found : WB_F234_CAND;
-                    if (found > WB_F234_CAND) {
-                        // more candidates than the list holds: the single largest instead (one chord per round)
-                        WB_SINGLE
-                        sh[9] = -1;
-                        WB_END_SINGLE
-                        WB_PFOR(q, rend[row] - lo)
-                            const int j = bk[lo + q];
-                            if (j > M && j < bound) wb_atomic_max(&sh[9], j);
-                        WB_END_PFOR
-                        K = 1;
-                        WB_SINGLE
-                        csort[0] = sh[9];
-                        WB_END_SINGLE
-                    } else {
-                        WB_PFOR(t, K)                             // rank sort, descending (the ind2 of a row are distinct)
-                            const int v = cand[t];
-                            int rk = 0;
-                            for (int u = 0; u < K; ++u) rk += cand[u] > v ? 1 : 0;
-                            csort[rk] = v;
-                        WB_END_PFOR
                     }
-                    for (int b0 = 0; b0 < K && !done; b0 += WB_F234_BATCH) {
-                        const int nb = K - b0 < WB_F234_BATCH ? K - b0 : WB_F234_BATCH;
-                        WB_PFOR32(c, nb)
-                            hp[c] = pts[row];
-                            hq[c] = pts[csort[b0 + c]];
-                            if (c == 0) { hitm[0] = 0u; skipm[0] = 0u; sh[12] = 0; }
-                        WB_END_PFOR
-                        test_batch(nb);
-                        WB_STAMP(a.ctl, 6);
-                        WB_STAMP_COUNT(11, 1);
-                        for (int c = 0; c < nb; ++c) {
-                            if (!((hitm[0] >> c) & 1u)) {             // the largest candidate that passes routine 2
-                                const int jn = csort[b0 + c];
-                                if (WB_TID == 0) { mi[nsurv] = row; mj[nsurv] = jn; }
-                                ++nsurv;
-                                M = jn;
-                                done = true;
-                                break;
-                            }
-                        }
-                        WB_SYNC();                                 // hitm is read by every lane before the next batch clears it
-                    }
-                    if (!done) {
-                        if (found > WB_F234_CAND) bound = csort[0];   // one chord was tested: the next round looks below it
-                        else done = true;                              // every candidate of the row failed
-                    }
+                WB_END_PFOR
+                if (sh[nfw] == 0 && sh[hfw] == 0) {
+                    // no record failed and none had failed before: the list stands as it is
+                    emit(nc);
+                    if (nc < WB_F234_CH) break;
+                    cur = chain[nc - 1] + 1;
+                    M = rmax[chain[nc - 1]];
+                    WB_SYNC();
                 }
-                cur = row + 1;
             }
         } else {
         // (a contour longer than the LDS holds: row after row in global memory, a search for the next row and a chord test each)
@@ -1558,8 +1613,6 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         if (Gn > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
         WB_END_SINGLE
     };
-    WB_SHARED(int, lr4, 4 * WB_F234_R4);
-    WB_SHARED(unsigned long long, lbest, 3 * WB_F234_R4);
     if (M > 1 && M <= WB_F234_R4) {
         int *lmi = lr4, *lmj = lr4 + WB_F234_R4, *llab = lr4 + 2 * WB_F234_R4, *laux = lr4 + 3 * WB_F234_R4;
         WB_PFOR(m, M)

@@ -51,6 +51,7 @@ struct wb_ctx {
     int geometry = 1;                         // 1: wb_indices also leaves the events' polygons in lon / lat (transform_polygons, index_utils.py:129-184) in pinned host memory, cut and mapped by the device (wb_geom.h); 0: wb_get_event_geometry computes them on the host when asked
     long long geom_seen = 0;                  // vertices of the largest pass's geometry so far (sizes the pinned arrays)
     int trace_fused = 1;                      // 1: the contours of a job by ONE kernel with the job resident in LDS (wb_trace_fused.h); 0: link -> rank -> finish (wb_trace.h), which also take the jobs the fused kernel declines
+    int f1_fused = 0;                         // routine 1 of the streamer index inside wb_k_streamer_f234 (0: wb_k_streamer_f1 in front of it)
     int f234_lpts = 0;                        // wb_k_streamer_f234: contour points its LDS holds at most (0: WB_F234_LPTS)
     int trace_nmax = 0, trace_cmax = 256;     // fused kernel: segments / chains per job its LDS admits (trace_nmax 0: from the grid's width, then from the largest job the context has seen)
     int fused_seen = 0, fused_seen_W = 0;     // largest segment count of a job in the context's batches so far on the grid of that width

@@ -74,6 +74,7 @@ template <class T> static inline T wb_atomic_add(T* p, T v) { T o = *p; *p = o +
 template <class T> static inline T wb_atomic_min(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T wb_atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T wb_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T wb_atomic_and(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <class T> static inline T wb_atomic_cas(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline int wb_popc32(uint32_t v) { return __builtin_popcount(v); }
 static inline int wb_ctz32(uint32_t v) { return __builtin_ctz(v); }
@@ -188,6 +189,7 @@ template <class T> __device__ inline T wb_atomic_add(T* p, T v) { return atomicA
 template <class T> __device__ inline T wb_atomic_min(T* p, T v) { return atomicMin(p, v); }
 template <class T> __device__ inline T wb_atomic_max(T* p, T v) { return atomicMax(p, v); }
 template <class T> __device__ inline T wb_atomic_or(T* p, T v) { return atomicOr(p, v); }
+template <class T> __device__ inline T wb_atomic_and(T* p, T v) { return atomicAnd(p, v); }
 template <class T> __device__ inline T wb_atomic_cas(T* p, T cmp, T v) { return atomicCAS(p, cmp, v); }
 __device__ inline int wb_popc32(uint32_t v) { return __popc(v); }
 __device__ inline int wb_ctz32(uint32_t v) { return __ffs((int)v) - 1; }
