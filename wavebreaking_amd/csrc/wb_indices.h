@@ -1215,6 +1215,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     sh[2] = 0; sh[9] = 0;
     sh[3] = in_lds ? 0 : 0x7FFFFFFF; sh[4] = sh[3];   // (global-memory sweep) search results of even / odd iterations
     sh[5] = 0; sh[6] = 0;                       // hit flags of even / odd chord tests
+    sh[7] = 0; sh[8] = 0;                       // routine 4: change flags of even / odd passes
     sh[10] = 0; sh[11] = 0; sh[12] = 0;         // blocks met by even / odd chord tests, by a batch
     sh[13] = 0; sh[14] = 0;
     WB_END_SINGLE
@@ -1536,16 +1537,15 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     // group scan, best length / member per group, every member's length -- are a dozen barrier-separated phases over M entries
     // each: in the contour's tables in global memory every phase was a round trip to L2 (22 us per contour, 15 % of the
     // kernel); up to WB_F234_R4 survivors they live in LDS and go back to the tables once, for wb_k_streamer_ties.
-    auto groups = [&](const int* mi, const int* mj, int* lab, int* aux, unsigned long long* best) WB_LAMBDA_INLINE {
+    auto groups = [&](const int* mi, const int* mj, int* lab, int* aux, unsigned long long* best) WB_LAMBDA_INLINE -> bool {
         WB_PFOR(m, M)
             lab[m] = (int)m;
         WB_END_PFOR
+        bool apart = false;                                        // no two survivors' chords intersect
         for (int iter = 0; iter < M; ++iter) {
-            const int cf = 7 + (iter & 1);
-            WB_SINGLE
-            sh[cf] = 0;
-            WB_END_SINGLE
+            const int cf = 7 + (iter & 1);                        // (change flags of even / odd passes, both zero at the start)
             WB_PFOR(pair, (int64_t)M * M)
+                if (pair == 0) sh[15 - cf] = 0;                     // the next pass's flag
                 const int m1 = (int)(pair / M), m2 = (int)(pair - (int64_t)m1 * M);
                 if (m1 < m2 && lab[m1] != lab[m2]) {
                     const uint32_t a1 = pts[mi[m1]], b1 = pts[mj[m1]], a2 = pts[mi[m2]], b2 = pts[mj[m2]];
@@ -1560,12 +1560,24 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
                     }
                 }
             WB_END_PFOR
+            if (!sh[cf]) { apart = iter == 0; break; }            // (nothing hooked in this pass: the labels are roots already)
             WB_PFOR(m, M)   // shortcut labels to their root
                 int l = lab[m];
                 while (lab[l] != l) l = lab[l];
                 lab[m] = l;
             WB_END_PFOR
-            if (!sh[cf]) break;
+        }
+        if (apart) {
+            // the usual case: every survivor is a group of its own -- it stays, no length is compared (the passes below would find
+            // just that, in a dozen more barriers)
+            WB_PFOR(m, M)
+                if (m < a.cap_ev) { ev[2 * m + 0] = mi[m]; ev[2 * m + 1] = mj[m]; }
+            WB_END_PFOR
+            WB_SINGLE
+            a.ev_n[s] = M < a.cap_ev ? M : a.cap_ev;
+            if (M > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
+            WB_END_SINGLE
+            return true;
         }
         // per group: max of on[ind1 : ind2+1].sum() -- numpy's pairwise sum of the slice, not a prefix difference: two chords
         // shifted by one point along a lattice contour differ by on[ind1] - on[ind2 + 1], two steps of the same kind whose
@@ -1612,6 +1624,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         a.ev_n[s] = Gn < a.cap_ev ? Gn : a.cap_ev;
         if (Gn > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
         WB_END_SINGLE
+        return false;
     };
     if (M > 1 && M <= WB_F234_R4) {
         int *lmi = lr4, *lmj = lr4 + WB_F234_R4, *llab = lr4 + 2 * WB_F234_R4, *laux = lr4 + 3 * WB_F234_R4;
@@ -1619,7 +1632,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             lmi[m] = mi[m];
             lmj[m] = mj[m];
         WB_END_PFOR
-        groups(lmi, lmj, llab, laux, lbest);
+        if (!groups(lmi, lmj, llab, laux, lbest)) {             // (the tables are read again by wb_k_streamer_ties, for groups only)
         WB_PFOR(m, M)
             lab[m] = llab[m];
             aux[m] = laux[m];
@@ -1627,8 +1640,9 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
             best[M + m] = lbest[M + m];
             best[2 * (size_t)M + m] = lbest[2 * (size_t)M + m];
         WB_END_PFOR
+        }
     } else if (M > 1) {
-        groups(mi, mj, lab, aux, best);
+        (void)groups(mi, mj, lab, aux, best);
     } else {
         WB_SINGLE
         if (M == 1) { ev[0] = mi[0]; ev[1] = mj[0]; }
