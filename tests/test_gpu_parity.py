@@ -239,12 +239,15 @@ def test_link_merge_by_searches_equals_merge_by_row_tables(ctx):
 def test_launch_options_change_no_result(ctx):
     """scan_priority (the field scan on a stream of the highest priority), persist_slack (places the persistent launches leave
     free), boxcom_per_cu / boxcom_after (when the boxes' sums run), CU-masked streams and the patch format of the scan (keys
-    only, values from the field / key + ten values) only move work in time or place: same events, same sums"""
+    only, values from the field / key + ten values), routine 1 of the streamer index inside wb_k_streamer_f234 or as its own
+    launch and the contour length that kernel's LDS holds (longer contours: the row-after-row sweep in global memory) only move
+    work in time or place: same events, same sums"""
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(3, 4, lat, lon, eps=0.2)
     base = None
     for opts in ({}, {"scan_priority": 1}, {"persist_slack": 64, "boxcom_per_cu": 3}, {"boxcom_after": 0}, {"boxcom_after": 2},
-                 {"scan_keys_only": 0}, {"cu_mask": 64}, {"cu_mask": 64128, "scan_keys_only": 0}):
+                 {"scan_keys_only": 0}, {"cu_mask": 64}, {"cu_mask": 64128, "scan_keys_only": 0},
+                 {"f1_fused": 1}, {"f234_lpts": 128}, {"f234_lpts": 64, "f1_fused": 1}):
         for k, v in opts.items():
             ctx.set_option(k, v)
         try:
@@ -255,6 +258,8 @@ def test_launch_options_change_no_result(ctx):
             ctx.set_option("boxcom_per_cu", 12)
             ctx.set_option("boxcom_after", 1)
             ctx.set_option("scan_keys_only", 1)
+            ctx.set_option("f1_fused", 0)
+            ctx.set_option("f234_lpts", 0)
             if "cu_mask" in opts:
                 ctx.set_option("cu_mask", 0)
         counts = tuple(int(got[kind]["step"].size) for kind in ("streamers", "overturnings", "cutoffs"))   # (full_parity has compared every column with the oracle)
