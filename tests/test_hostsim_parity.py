@@ -252,6 +252,26 @@ def test_big_job_paths_without_lds():
     ctx.close()
 
 
+def test_routine1_in_parts_and_with_the_global_table():
+    # check_duplicates (streamer_index.py:160-183): a contour with more western pairs than half the LDS table takes the table in
+    # several parts (keys split by bits of their hash); a build with a 256-entry table sends the 0.25 degree contours there, one
+    # with a 2-entry table (too small to split) to the table in global memory: the same pairs survive
+    import ctypes
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(40, 1, lat, lon, eps=0.3)
+    for variant, defines, path in (("f1parts", ("WB_F1_LTAB=256",), 0), ("nolds", ("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0", "WB_PROPS_LROWS=4", "WB_PROPS_PART=4", "WB_F1_LTAB=2", "WB_TRACE_LTAB=2"), 1)):
+        lib = _hip.Library(helpers.build_hostsim(variant=variant, defines=defines), allow_hostsim=True)
+        lib.lib.wb_hostsim_path_count.restype = ctypes.c_longlong
+        lib.lib.wb_hostsim_path_count(0); lib.lib.wb_hostsim_path_count(1)
+        ctx = _hip.Context(0, lib)
+        try:
+            got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2])
+        finally:
+            ctx.close()
+        assert len(ref["streamers"]) > 3
+        assert lib.lib.wb_hostsim_path_count(path) > 0, variant
+
+
 def test_com_follows_the_reference_arithmetic(sim):
     """calculate_properties truncates x_com / areas (index_utils.py:105-110): overturning boxes with min_lon + max_lon even
     put that quotient ON an integer, so the sums must be pandas' compensated per-cell sums to the last bit."""

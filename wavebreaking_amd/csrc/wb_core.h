@@ -189,6 +189,19 @@ struct WbCtl {
 #define WB_FSTAMP(ctl, k) ((void)0)
 #define WB_FSTAMP_FLUSH(ctl) ((void)0)
 #endif
+#if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 9      // wb_k_streamer_f1 (routine 1)
+#define WB_DSTAMP_BEGIN WB_STAMPX_BEGIN
+#define WB_DSTAMP(ctl, k) WB_STAMPX(ctl, k)
+#define WB_DSTAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
+#define WB_DSTAMP_ARGS , long long* wb_acc_, long long& wb_st_
+#define WB_DSTAMP_PASS , wb_acc_, wb_st_
+#else
+#define WB_DSTAMP_BEGIN
+#define WB_DSTAMP(ctl, k) ((void)0)
+#define WB_DSTAMP_FLUSH(ctl) ((void)0)
+#define WB_DSTAMP_ARGS
+#define WB_DSTAMP_PASS
+#endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 2
 #define WB_PSTAMP_BEGIN WB_STAMPX_BEGIN
 #define WB_PSTAMP(ctl, k) WB_STAMPX(ctl, k)

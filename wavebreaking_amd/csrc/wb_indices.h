@@ -634,7 +634,7 @@ WB_HD inline int wb_bits_for_i(int n) { int b = 0; while ((1 << b) < n) ++b; ret
     WB_END_PFOR
 
 WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, const uint32_t* pts, unsigned long long* ltab,
-                                       int ltab_cap, bool ltab_only) {
+                                       int ltab_cap, bool ltab_only WB_DSTAMP_ARGS) {
     unsigned long long* pairs = a.pairs + (size_t)s * a.cap_pairs;
     int* alive = a.alive + (size_t)s * a.cap_pairs;
     unsigned long long* hkey = a.hkey + (size_t)s * a.hash_size;
@@ -653,83 +653,157 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
         return true;
     }
     const int padd = a.W - a.nlon;
-    WB_SINGLE
-    nwest[0] = 0;
-    cnt[0] = 0;
-    WB_END_SINGLE
-    WB_PAIRS_FOR4(P, pairs, pts)
-        alive[p] = 1;
-        if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) wb_atomic_add(&nwest[0], 1);
-    WB_PAIRS_END4
-    const int bxx = wb_bits_for_i(a.nlon), byy = wb_bits_for_i(a.nlat), pb = wb_bits_for_i(P);
-    int lsize = ltab_cap < 256 ? ltab_cap : 256;
-    while (lsize < 2 * nwest[0] && lsize < ltab_cap) lsize <<= 1;
-    const bool use_ltab = P > 1 && 2 * (bxx + byy) + pb <= 63 && 2 * nwest[0] <= lsize;
-    if (P > 1 && !use_ltab && ltab_only) return false;          // (nothing the stand-alone kernel does not redo has been written)
-    WB_SINGLE
-    wb_atomic_max(&a.ctl->max_pairs, P);
-    wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
-    WB_END_SINGLE
     if (P <= 1) {
         WB_SINGLE
+        if (P == 1) alive[0] = 1;
+        wb_atomic_max(&a.ctl->max_pairs, P);
+        wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
         a.nalive[s] = P;
         a.stage[s] = 0;   // no routine applied: `while len(df_bp.index) > 1`
         WB_END_SINGLE
         return true;
     }
+    const int bxx = wb_bits_for_i(a.nlon), byy = wb_bits_for_i(a.nlat), pb = wb_bits_for_i(P);
     // Usual case: the western pairs (a quarter of all on a full-span contour) fit a table in LDS whose 64-bit entries
     // hold the key (x1 mod nlon, y1, x2 mod nlon, y2) above the pair index -- no table in global memory to clear and probe.
-    if (use_ltab) {
-        const int lmask = lsize - 1;
+    // Two sweeps over the pairs: the western ones are counted and entered (the whole table is cleared in front: 32 KiB, four
+    // stores per thread), the eastern ones look themselves up.  (Until round 5 a first sweep counted the western pairs to size
+    // the table: a third of the routine's time.)
+    bool counted = false;
+    if (2 * (bxx + byy) + pb <= 63) {
+        // One sweep over the pairs (their end points gathered, their keys made) enters the western ones in the table while it is
+        // at most half full and leaves TWO LISTS of (key, pair) words in the contour's scratch: the western and the eastern pairs.
+        // What follows reads those lists only, a quarter of the pairs each and no gathers: the eastern pairs look themselves up;
+        // and when the western pairs were more than half the table (a contour of the 0.25 degree bench batch with more than
+        // 8 000 candidate pairs, 150 of 2 920 -- with the table in global memory, 100-190 us each, they were the kernel's duration)
+        // the keys are split by bits of their hash into as many parts as keep the table a third full, and per part the western
+        // list is entered and the eastern list looked up.
+        WB_SHARED(int, cntp, 3);             // eastern pairs; western pairs of the part; a part that did not fit
+        unsigned long long* const wlist = hkey;          // [P] (the table in global memory below, if it comes to that, starts over)
+        unsigned long long* const elist = hval;          // [P]
+        const int lmask = ltab_cap - 1;
         const unsigned long long pmask = (1ull << pb) - 1ull;
-        WB_PFOR(q, lsize)
+        WB_PFOR(q, ltab_cap)
+            if (q == 0) { nwest[0] = 0; cnt[0] = 0; cntp[0] = 0; cntp[2] = 0; }
             ltab[q] = WB_HEMPTY;
         WB_END_PFOR
+        WB_DSTAMP(a.ctl, 1);
+        auto enter = [&](unsigned long long mine, unsigned long long hk) WB_LAMBDA_INLINE {
+            const unsigned long long key = mine >> pb;
+            uint32_t sl = (uint32_t)hk & (uint32_t)lmask;
+            for (int probe = 0; probe <= lmask; ++probe) {
+                unsigned long long cur = ltab[sl];
+                if (cur == WB_HEMPTY) {
+                    cur = wb_atomic_cas(&ltab[sl], (unsigned long long)WB_HEMPTY, mine);
+                    if (cur == WB_HEMPTY) break;
+                }
+                if ((cur >> pb) == key) { wb_atomic_min(&ltab[sl], mine); break; }
+                sl = (sl + 1) & (uint32_t)lmask;
+            }
+        };
+        auto look_up = [&](unsigned long long mine, unsigned long long hk) WB_LAMBDA_INLINE {
+            const unsigned long long key = mine >> pb;
+            uint32_t sl = (uint32_t)hk & (uint32_t)lmask;
+            for (int probe = 0; probe <= lmask; ++probe) {
+                const unsigned long long cur = ltab[sl];
+                if (cur == WB_HEMPTY) break;
+                if ((cur >> pb) == key) {
+                    const int p = (int)(mine & pmask), pw = (int)(cur & pmask);
+                    alive[pairs[pw] < pairs[p] ? p : pw] = 0;             // the first in (ind1, ind2) order stays
+                    wb_atomic_add(&cnt[0], 1);
+                    break;
+                }
+                sl = (sl + 1) & (uint32_t)lmask;
+            }
+        };
         WB_PAIRS_FOR4(P, pairs, pts)
-            if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) {
+            alive[p] = 1;
+            const bool west = wb_pt_x(pi) < padd && wb_pt_x(pj) < padd;
+            const bool east = !west && wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon;
+            if (west || east) {
                 const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
                                                  (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
                 const unsigned long long mine = (key << pb) | (unsigned long long)p;
-                uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
-                for (int probe = 0; probe <= lmask; ++probe) {
-                    unsigned long long cur = ltab[sl];
-                    if (cur == WB_HEMPTY) {
-                        cur = wb_atomic_cas(&ltab[sl], (unsigned long long)WB_HEMPTY, mine);
-                        if (cur == WB_HEMPTY) break;
-                    }
-                    if ((cur >> pb) == key) { wb_atomic_min(&ltab[sl], mine); break; }
-                    sl = (sl + 1) & (uint32_t)lmask;
+                if (west) {
+                    const int idx = wb_atomic_add(&nwest[0], 1);
+                    wlist[idx] = mine;
+                    if (2 * idx < ltab_cap) enter(mine, wb_mix64(key));
+                } else {
+                    elist[wb_atomic_add(&cntp[0], 1)] = mine;
                 }
             }
         WB_PAIRS_END4
-        WB_PAIRS_FOR4(P, pairs, pts)
-            if (wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon && !(wb_pt_x(pi) < padd && wb_pt_x(pj) < padd)) {
-                const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
-                                                 (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
-                uint32_t sl = (uint32_t)wb_mix64(key) & (uint32_t)lmask;
-                for (int probe = 0; probe <= lmask; ++probe) {
-                    const unsigned long long cur = ltab[sl];
-                    if (cur == WB_HEMPTY) break;
-                    if ((cur >> pb) == key) {
-                        const int pw = (int)(cur & pmask);
-                        alive[pairs[pw] < pr ? p : pw] = 0;             // the first in (ind1, ind2) order stays
-                        wb_atomic_add(&cnt[0], 1);
-                        break;
+        counted = true;
+        WB_DSTAMP(a.ctl, 2);
+        const int nW = nwest[0], nE = cntp[0];
+        bool fits = 2 * nW <= ltab_cap;
+        if (fits) {
+            WB_PFOR(e, nE)
+                const unsigned long long mine = elist[e];
+                look_up(mine, wb_mix64(mine >> pb));
+            WB_END_PFOR
+            WB_DSTAMP(a.ctl, 3);
+        } else if (ltab_cap >= 256) {
+            int npart = 2;                       // parts that are 0.35 full on average (a part may hold half the table; the spread of a part's share is a few per cent)
+            while (7LL * npart * ltab_cap < 20LL * nW && npart < 256) npart <<= 1;
+            fits = true;
+            for (int part = 0; part < npart && fits; ++part) {
+                WB_PFOR(q, ltab_cap)
+                    if (q == 0) cntp[1] = 0;
+                    ltab[q] = WB_HEMPTY;
+                WB_END_PFOR
+                WB_PFOR(e, nW)
+                    const unsigned long long mine = wlist[e], hk = wb_mix64(mine >> pb);
+                    if ((int)((hk >> 40) & (unsigned long long)(npart - 1)) == part) {
+                        if (2 * wb_atomic_add(&cntp[1], 1) < ltab_cap) enter(mine, hk);
+                        else cntp[2] = 1;
                     }
-                    sl = (sl + 1) & (uint32_t)lmask;
-                }
+                WB_END_PFOR
+                if (cntp[2]) { fits = false; break; }               // (a part with more keys than half the table: the table in global memory after all)
+                WB_PFOR(e, nE)
+                    const unsigned long long mine = elist[e], hk = wb_mix64(mine >> pb);
+                    if ((int)((hk >> 40) & (unsigned long long)(npart - 1)) == part) look_up(mine, hk);
+                WB_END_PFOR
             }
-        WB_PAIRS_END4
-        WB_SINGLE
-        a.nalive[s] = P - cnt[0];
-        a.stage[s] = 1;
-        WB_END_SINGLE
-        return true;
+            if (fits) WB_HOSTSIM_PATH(0);
+            WB_DSTAMP(a.ctl, 5);
+        }
+        if (fits) {
+            WB_SINGLE
+            wb_atomic_max(&a.ctl->max_pairs, P);
+            wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
+            a.nalive[s] = P - cnt[0];
+            a.stage[s] = 1;
+            WB_END_SINGLE
+            return true;
+        }
+        if (!ltab_only) {
+            WB_PFOR(p, P)                            // (pairs the parts before have removed are found again below)
+                alive[p] = 1;
+            WB_END_PFOR
+        }
     }
+    if (ltab_only) return false;
+    // (keys wider than the LDS table's entries, a tiny table, or a part that did not fit: the table in global memory)
+    if (!counted) {
+        WB_SINGLE
+        nwest[0] = 0;
+        WB_END_SINGLE
+        WB_PAIRS_FOR4(P, pairs, pts)
+            alive[p] = 1;
+            if (wb_pt_x(pi) < padd && wb_pt_x(pj) < padd) wb_atomic_add(&nwest[0], 1);
+        WB_PAIRS_END4
+    }
+    WB_SINGLE
+    cnt[0] = 0;
+    wb_atomic_max(&a.ctl->max_pairs, P);
+    wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
+    WB_END_SINGLE
     // Two pairs coincide after x mod nlon only if one is the copy of the other one period further east: both end points
     // of the western pair lie in x < W - nlon, both of the eastern one in x >= nlon (a mixed pair would need its copy in
     // the opposite index order).  Only western pairs are entered into the table and only eastern pairs look themselves
     // up -- a quarter of the pairs each on a full-span contour; everything else survives without touching it.
+    WB_HOSTSIM_PATH(1);
     int hsize = 256;                       // table sized to the pairs that go in, the western ones (clearing it is real traffic)
     while (hsize < 2 * nwest[0] && hsize < a.hash_size) hsize <<= 1;
     const int hmask = hsize - 1;
@@ -765,6 +839,7 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
     a.nalive[s] = P - cnt[0];
     a.stage[s] = 1;
     WB_END_SINGLE
+    WB_DSTAMP(a.ctl, 4);                    // (the table in global memory)
     return true;
 }
 
@@ -794,9 +869,9 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
     WB_SHARED(unsigned long long, ltab, WB_F1_LTAB);
     WB_SHARED(int, item, 1);
     const int nsel = a.ctl->nsel;
+    WB_DSTAMP_BEGIN
     for (;;) {
-        WB_SYNC();                                   // (the previous contour's table and counters are done with)
-        WB_SINGLE
+        WB_SINGLE                                    // (the previous contour ended behind a barrier: its table and counters are done with)
         item[0] = wb_atomic_add(&a.ctl->f1_cursor, 1);
         WB_END_SINGLE
         const int it = item[0];
@@ -808,8 +883,10 @@ WB_KERNEL(wb_k_streamer_f1, WbStreamerArgs a) {
 #ifdef WB_WHATIF_BIG
         if (a.npairs[s] > WB_WHATIF_BIG) { if (WB_TID == 0) { a.nalive[s] = 0; a.stage[s] = 4; } continue; }
 #endif
-        (void)wb_streamer_f1_body(a, s, job, pts, ltab, WB_F1_LTAB, false);
+        WB_DSTAMP(a.ctl, 0);
+        (void)wb_streamer_f1_body(a, s, job, pts, ltab, WB_F1_LTAB, false WB_DSTAMP_PASS);
     }
+    WB_DSTAMP_FLUSH(a.ctl);
 }
 
 // routine 2: check_intersections (:185-200): one lane per candidate pair; contour blocks whose bounding box
@@ -1201,7 +1278,12 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         // than half of that takes the table in global memory, as in wb_k_streamer_f1
         int lcap = 256;
         while (2 * lcap <= (capE + scrE) / 2) lcap <<= 1;
-        (void)wb_streamer_f1_body(a, s, job, pts, (unsigned long long*)lwork, lcap, false);
+        {
+#if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 9
+        long long wb_acc_[12] = {0}; long long wb_st_ = 0;
+#endif
+        (void)wb_streamer_f1_body(a, s, job, pts, (unsigned long long*)lwork, lcap, false WB_DSTAMP_PASS);
+        }
         WB_SYNC();
     }
     const int stage = a.stage[s];

@@ -7,6 +7,8 @@
 #if defined(WB_HOSTSIM)
 int wb_hostsim_reverse = 0;
 extern "C" void wb_hostsim_set_reverse(int r) { wb_hostsim_reverse = r; }
+long long wb_hostsim_path[4] = {0, 0, 0, 0};            // which rare paths the simulated kernels took (WB_HOSTSIM_PATH; tests assert they were reached)
+extern "C" long long wb_hostsim_path_count(int k) { const long long v = wb_hostsim_path[k & 3]; wb_hostsim_path[k & 3] = 0; return v; }
 #define WB_LAUNCH(kernel, grid, block, ...)                                       \
     do {                                                                          \
         const int wb_g_ = (int)(grid);                                            \

@@ -30,6 +30,8 @@
 #define WB_NT 1
 #define WB_TID 0
 extern int wb_hostsim_reverse;
+extern long long wb_hostsim_path[4];
+#define WB_HOSTSIM_PATH(k) (++wb_hostsim_path[k])          // 0: routine 1 in parts, 1: routine 1 with the table in global memory
 #define WB_PFOR(i, n)                                                                    \
     for (int64_t wb_k_##i = 0, wb_n_##i = (int64_t)(n); wb_k_##i < wb_n_##i; ++wb_k_##i) { \
         const int64_t i = wb_hostsim_reverse ? (wb_n_##i - 1 - wb_k_##i) : wb_k_##i;
@@ -126,6 +128,7 @@ static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
 // ---------------------------------------------------------------- HIP / gfx950
 #include <hip/hip_runtime.h>
 #define WB_HD __host__ __device__
+#define WB_HOSTSIM_PATH(k) ((void)0)
 #define WB_DEV __device__
 #define WB_NOINLINE __attribute__((noinline))      // rare slow paths: kept out of the hot kernels' register allocation
 #define WB_LAMBDA_INLINE __attribute__((always_inline))
