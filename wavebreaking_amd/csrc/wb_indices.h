@@ -679,12 +679,13 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
         // the keys are split by bits of their hash into as many parts as keep the table a third full, and per part the western
         // list is entered and the eastern list looked up.
         WB_SHARED(int, cntp, 3);             // eastern pairs; western pairs of the part; a part that did not fit
+        WB_SHARED(unsigned long long, kills, 1);        // pairs removed (a thread counts its own, the waves add them up at the end)
         unsigned long long* const wlist = hkey;          // [P] (the table in global memory below, if it comes to that, starts over)
         unsigned long long* const elist = hval;          // [P]
         const int lmask = ltab_cap - 1;
         const unsigned long long pmask = (1ull << pb) - 1ull;
         WB_PFOR(q, ltab_cap)
-            if (q == 0) { nwest[0] = 0; cnt[0] = 0; cntp[0] = 0; cntp[2] = 0; }
+            if (q == 0) { nwest[0] = 0; cnt[0] = 0; cntp[0] = 0; cntp[2] = 0; kills[0] = 0ull; }
             ltab[q] = WB_HEMPTY;
         WB_END_PFOR
         WB_DSTAMP(a.ctl, 1);
@@ -701,6 +702,7 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
                 sl = (sl + 1) & (uint32_t)lmask;
             }
         };
+        unsigned long long mykills = 0ull;                   // (a thread's share; the host simulation's one thread: all of them)
         auto look_up = [&](unsigned long long mine, unsigned long long hk) WB_LAMBDA_INLINE {
             const unsigned long long key = mine >> pb;
             uint32_t sl = (uint32_t)hk & (uint32_t)lmask;
@@ -710,7 +712,7 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
                 if ((cur >> pb) == key) {
                     const int p = (int)(mine & pmask), pw = (int)(cur & pmask);
                     alive[pairs[pw] < pairs[p] ? p : pw] = 0;             // the first in (ind1, ind2) order stays
-                    wb_atomic_add(&cnt[0], 1);
+                    ++mykills;
                     break;
                 }
                 sl = (sl + 1) & (uint32_t)lmask;
@@ -720,16 +722,18 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
             alive[p] = 1;
             const bool west = wb_pt_x(pi) < padd && wb_pt_x(pj) < padd;
             const bool east = !west && wb_pt_x(pi) >= a.nlon && wb_pt_x(pj) >= a.nlon;
+            // (list slots by one atomic per wave: thousands of lanes adding to one LDS word take their turns -- a contour with 16 000
+            //  pairs spent 50 us of its 250 waiting for them)
+            const int widx = wb_append_slot(&nwest[0], west), eidx = wb_append_slot(&cntp[0], east);
             if (west || east) {
                 const unsigned long long key = ((((unsigned long long)(wb_pt_x(pi) % a.nlon) << byy | (unsigned long long)wb_pt_y(pi)) << bxx |
                                                  (unsigned long long)(wb_pt_x(pj) % a.nlon)) << byy) | (unsigned long long)wb_pt_y(pj);
                 const unsigned long long mine = (key << pb) | (unsigned long long)p;
                 if (west) {
-                    const int idx = wb_atomic_add(&nwest[0], 1);
-                    wlist[idx] = mine;
-                    if (2 * idx < ltab_cap) enter(mine, wb_mix64(key));
+                    wlist[widx] = mine;
+                    if (2 * widx < ltab_cap) enter(mine, wb_mix64(key));
                 } else {
-                    elist[wb_atomic_add(&cntp[0], 1)] = mine;
+                    elist[eidx] = mine;
                 }
             }
         WB_PAIRS_END4
@@ -754,8 +758,10 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
                 WB_END_PFOR
                 WB_PFOR(e, nW)
                     const unsigned long long mine = wlist[e], hk = wb_mix64(mine >> pb);
-                    if ((int)((hk >> 40) & (unsigned long long)(npart - 1)) == part) {
-                        if (2 * wb_atomic_add(&cntp[1], 1) < ltab_cap) enter(mine, hk);
+                    const bool mine_now = (int)((hk >> 40) & (unsigned long long)(npart - 1)) == part;
+                    const int slot = wb_append_slot(&cntp[1], mine_now);
+                    if (mine_now) {
+                        if (2 * slot < ltab_cap) enter(mine, hk);
                         else cntp[2] = 1;
                     }
                 WB_END_PFOR
@@ -769,10 +775,11 @@ WB_DEV inline bool wb_streamer_f1_body(const WbStreamerArgs& a, int s, int job, 
             WB_DSTAMP(a.ctl, 5);
         }
         if (fits) {
+            wb_block_add_u64(&kills[0], mykills);
             WB_SINGLE
             wb_atomic_max(&a.ctl->max_pairs, P);
             wb_atomic_add((unsigned long long*)&a.ctl->cand_pairs, (unsigned long long)P);
-            a.nalive[s] = P - cnt[0];
+            a.nalive[s] = P - (int)kills[0];
             a.stage[s] = 1;
             WB_END_SINGLE
             return true;
