@@ -112,6 +112,23 @@ def test_quarter_degree_parity(ctx):
     assert max(len(c["geometry"]) for c in ref["contours"]) > 2000
 
 
+def test_quarter_degree_streamer_filters_by_other_routes(ctx):
+    # the same 0.25 degree contours (thousands of candidate pairs each) with routine 1 inside wb_k_streamer_f234 (its table over the
+    # row buckets' LDS, in parts where the western pairs do not fit) and with a kernel LDS that holds 1024 points only (longer
+    # contours: the row-after-row sweep in global memory)
+    lat, lon = synth.grid(0.25)
+    pv = synth.pv_field(7, 1, lat, lon, eps=0.3)
+    for opts in ({"f1_fused": 1}, {"f234_lpts": 1024}, {"f1_fused": 1, "f234_lpts": 1024}):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [-2, 2])
+        finally:
+            ctx.set_option("f1_fused", 0)
+            ctx.set_option("f234_lpts", 0)
+        assert len(ref["streamers"]) > 3
+
+
 def test_consecutive_launches_on_different_fields(ctx):
     # the streaming scan's workgroups hand each other halo columns through LDS, which keeps its contents from one launch
     # to the next: two rough fields of the same shape one after the other (a stale halo of the first gave the second 6-8
