@@ -1629,6 +1629,9 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
     auto groups = [&](const int* mi, const int* mj, int* lab, int* aux, unsigned long long* best) WB_LAMBDA_INLINE -> bool {
         WB_PFOR(m, M)
             lab[m] = (int)m;
+            best[m] = 0ull;
+            best[M + m] = WB_HEMPTY;
+            aux[m] = 0;
         WB_END_PFOR
         bool apart = false;                                        // no two survivors' chords intersect
         for (int iter = 0; iter < M; ++iter) {
@@ -1673,11 +1676,6 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         // lengths agree to the last bit or the one before, and the reference's argmax (streamer_index.py:241-246) then
         // turns on how the slices were added; ties -> lowest member
         WB_PFOR(m, M)
-            best[m] = 0ull;
-            best[M + m] = WB_HEMPTY;
-            aux[m] = 0;
-        WB_END_PFOR
-        WB_PFOR(m, M)
             wb_atomic_add(&aux[lab[m]], 1);                        // members per group: a group of one needs no length
         WB_END_PFOR
         const double* onp = a.on + a.poff[s];
@@ -1694,21 +1692,39 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         WB_END_PFOR
         // several members with the SAME length (to the last bit): the reference keeps the one that comes first in a CPython
         // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
-        // registers); here the lowest such member stands in and the contour is marked
+        // registers); here the lowest such member stands in and the contour is marked.  Then the group roots, in order of
+        // their lowest member
         WB_PFOR(m, M)
             if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
+            aux[m] = (lab[m] == (int)m) ? 1 : 0;
         WB_END_PFOR
-        WB_PFOR(m, M)
-            aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
-        WB_END_PFOR
-        const int Gn = wb_block_scan_excl(aux, M);
-        WB_PFOR(m, M)
-            if (lab[m] == (int)m && aux[m] < a.cap_ev) {
-                const int w = (int)best[M + m];
-                ev[2 * aux[m] + 0] = mi[w];
-                ev[2 * aux[m] + 1] = mj[w];
-            }
-        WB_END_PFOR
+        int Gn;
+        if (M <= WB_F234_R4) {
+            // (a few dozen survivors in LDS: a root counts the roots in front of it -- a block scan is four barriers)
+            WB_PFOR(m, M)
+                int pos = 0;
+                if (lab[m] == (int)m) {
+                    for (int q = 0; q < (int)m; ++q) pos += aux[q];
+                    if (pos < a.cap_ev) {
+                        const int w = (int)best[M + m];
+                        ev[2 * pos + 0] = mi[w];
+                        ev[2 * pos + 1] = mj[w];
+                    }
+                }
+                items[m] = pos;                                    // (the group's place among the events: wb_k_streamer_ties reads it from the table)
+            WB_END_PFOR
+            Gn = 0;
+            for (int q = 0; q < M; ++q) Gn += aux[q];
+        } else {
+            Gn = wb_block_scan_excl(aux, M);
+            WB_PFOR(m, M)
+                if (lab[m] == (int)m && aux[m] < a.cap_ev) {
+                    const int w = (int)best[M + m];
+                    ev[2 * aux[m] + 0] = mi[w];
+                    ev[2 * aux[m] + 1] = mj[w];
+                }
+            WB_END_PFOR
+        }
         WB_SINGLE
         a.ev_n[s] = Gn < a.cap_ev ? Gn : a.cap_ev;
         if (Gn > a.cap_ev) wb_atomic_or(&a.status[job], (uint32_t)WB_ST_OVERFLOW_PAIRS);
@@ -1724,7 +1740,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         if (!groups(lmi, lmj, llab, laux, lbest)) {             // (the tables are read again by wb_k_streamer_ties, for groups only)
         WB_PFOR(m, M)
             lab[m] = llab[m];
-            aux[m] = laux[m];
+            aux[m] = items[m];
             best[m] = lbest[m];
             best[M + m] = lbest[M + m];
             best[2 * (size_t)M + m] = lbest[2 * (size_t)M + m];
