@@ -252,6 +252,26 @@ def test_big_job_paths_without_lds():
     ctx.close()
 
 
+def test_streamer_sweep_with_a_short_record_list():
+    # wb_k_streamer_f234 lists the records of the rows' bounds 256 at a time and goes on behind the last one when all of a list have
+    # passed; a build that lists 4 at a time does that on every contour with more than four survivors
+    lib = _hip.Library(helpers.build_hostsim(variant="f234ch4", defines=("WB_F234_CH=4",)), allow_hostsim=True)
+    for reverse in (0, 1):
+        lib.lib.wb_hostsim_set_reverse(reverse)
+        ctx = _hip.Context(0, lib)
+        try:
+            lat, lon = synth.grid(1.0)
+            pv = synth.pv_field(10, 3, lat, lon, eps=0.3)
+            got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(3), [-2, 2], intensity=pv)
+            assert len(ref["streamers"]) > 5
+            lat, lon = synth.grid(0.25)
+            pv = synth.pv_field(40, 1, lat, lon, eps=0.3)
+            helpers.full_parity(ctx, pv, lat, lon, synth.times(1), [2])
+        finally:
+            ctx.close()
+    lib.lib.wb_hostsim_set_reverse(0)
+
+
 def test_routine1_in_parts_and_with_the_global_table():
     # check_duplicates (streamer_index.py:160-183): a contour with more western pairs than half the LDS table takes the table in
     # several parts (keys split by bits of their hash); a build with a 256-entry table sends the 0.25 degree contours there, one

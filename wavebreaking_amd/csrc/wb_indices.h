@@ -1215,7 +1215,9 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
 #define WB_F234_OCC 6               // waves per SIMD the register allocation leaves room for (6: 80 registers, three workgroups per CU)
 #endif
 #define WB_F234_R4 256             // survivors whose routine-4 arrays are held in LDS
-#define WB_F234_CH WB_F234_R4       // records listed per round
+#ifndef WB_F234_CH
+#define WB_F234_CH WB_F234_R4       // records listed per round (at most R4: the list lies where routine 4's arrays will); the tests build a 4-record variant
+#endif
 #define WB_F234_CC (2 * WB_F234_R4)   // chords tested per round
 #define WB_F234_K 8                // candidates of a failing row tested per round
 #define WB_F234_GROUP 128          // chords whose (chord, block) items are listed together
