@@ -186,7 +186,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     int* const nuxl = (int*)(T + L.g2_nux);
     int* const sumyl = (int*)(T + L.g2_sumy);
     int* const setsize = (int*)(T + L.g2_setsize);
-    int* const nuxc = (int*)(T + L.g2_nuxc);                  // the same three counters per contour BEFORE the >= 4 points filter (one bucket scan serves the dedupe and them)
+    int* const nuxc = (int*)(T + L.g2_nuxc);                  // per contour BEFORE the >= 4 points filter: the largest x (nuxc) and the smallest (xminc) of its raw points,
+    int* const xminc = kid;                                   // (kid[] is not needed before the extents have been taken: see there) the sum of y over the kept points and the distinct (x mod nlon, y) (one bucket scan serves the dedupe and them)
     int* const sumyc = (int*)(T + L.g2_sumyc);
     int* const setc = (int*)(T + L.g2_setc);
     unsigned char* const dropped = T + L.g2_dropped;
@@ -574,10 +575,12 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     if (ctr[0]) WB_F_DECLINE();
 
     WB_FSTAMP(a.ctl, 7);
-    // ---- F: buckets of the raw points by x mod nlon (1 << WB_F_XSHIFT meridians each).  A point equal to its predecessor in
+    // ---- F: buckets of the raw points by (x mod nlon, y).  A point equal to its predecessor in
     // the same contour can never be a first occurrence (about half of all raw points: neighbouring crossings that round to the
     // same lattice point): it stays out.
-    const int NB = (nlon >> WB_F_XSHIFT) + 1;
+    int NBP = 1;                                                 // buckets: the largest power of two the counters hold
+    while (2 * NBP <= nlon) NBP <<= 1;
+    const int NB = NBP + 1;
     WB_PFOR32(x, NB + 1)
         cnt[x] = 0;
     WB_END_PFOR
@@ -586,15 +589,22 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         dupb[w] = 0u;
     WB_END_PFOR
     WB_PFOR32(c, C + 1)
-        newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0; nuxc[c] = 0; sumyc[c] = 0; setc[c] = 0;
+        newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0; nuxc[c] = -1; xminc[c] = 0x7FFFFFFF; sumyc[c] = 0; setc[c] = 0;
     WB_END_PFOR
 #define WB_F_XM(pw) (((pw) & xmask) >= (uint32_t)nlon ? ((pw) & xmask) - (uint32_t)nlon : ((pw) & xmask))   /* x mod nlon: x < W <= 2 nlon */
-#define WB_F_BUCKET(pw) ((int)WB_F_XM(pw) >> WB_F_XSHIFT)
+#define WB_F_BUCKET(pw) ((int)((WB_F_XM(pw) + (((pw) >> xb) & ymask) * 347u) & (uint32_t)(NBP - 1)))    /* by (x mod nlon, y) only: what the dedupe, the (x mod nlon, y) sets and in_set compare */
     WB_PFOR32(p, R)
         const uint32_t pw = rawpt[p];
         const bool dup = p > 0 && pw == rawpt[p > 0 ? p - 1 : 0];        // (equal words: the same contour and the same lattice point)
         if (dup) wb_atomic_or(&dupb[p >> 5], 1u << (p & 31));
-        else wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);
+        else {
+            wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);
+            // the contour's extent in x: its points form a lattice path (consecutive crossings of the marching squares lie on the
+            // edges of one cell and round to corners of that cell: |dx| <= 1), so its distinct x are the integers xmin .. xmax
+            const int c = (int)(pw >> sh), x = (int)(pw & xmask);
+            if (x > nuxc[c]) wb_atomic_max(&nuxc[c], x);
+            if (x < xminc[c]) wb_atomic_min(&xminc[c], x);
+        }
     WB_END_PFOR
     const int U = wb_block_scan_excl(cnt, NB);                  // cnt[b]: first entry of bucket b
     WB_PFOR32(p, R)
@@ -605,14 +615,17 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 8);
     // first-occurrence dedupe (contour_index.py:110-112: dict.fromkeys over the contour's points) -- and, in the same scan of the
-    // point's bucket, the contour's distinct x (-> exp_lon, :154), distinct (x mod nlon, y) and sum of y over the kept points
-    // (-> mean_lat, :155): an entry counts for x / (x mod nlon, y) when no entry IN FRONT of it in the bucket has them
+    // point's bucket, the contour's distinct (x mod nlon, y) and the sum of y over the kept points (-> mean_lat, :155): an entry
+    // counts for (x mod nlon, y) when no entry IN FRONT of it in the bucket has them.  (The buckets are by a hash of (x mod nlon, y):
+    // one or two entries each.  By x mod nlon alone -- needed while the distinct x were counted here too, -> exp_lon, :154 -- a
+    // bucket held every crossing of a meridian by every contour of the job and its copy one period east, forty entries, and this
+    // scan was a fifth of the kernel.)
     WB_PFOR32(e, U)
         const int p = (int)order[e];
         const uint32_t pw = rawpt[p];
-        const uint32_t c = pw >> sh, x = pw & xmask, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
-        const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
-        bool first = true, firstx = true, firsty = true;
+        const uint32_t c = pw >> sh, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
+        const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
+        bool first = true, firsty = true;
         for (int e2 = b0; e2 < b1; e2 += 4) {                   // (four entries' positions, then their points: two LDS latencies per four)
             int p2[4];
             uint32_t w2[4];
@@ -625,12 +638,10 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
                 if (p2[q] < p && w2[q] == pw) first = false;
                 if (e2 + q < (int)e) {
                     if ((w2[q] >> xb) == cy && WB_F_XM(w2[q]) == xm) firsty = false;
-                    if ((w2[q] >> sh) == c && (w2[q] & xmask) == x) firstx = false;
                 }
             }
         }
         if (first) { wb_atomic_or(&keepb[p >> 5], 1u << (p & 31)); wb_atomic_add(&sumyc[c], (int)((pw >> xb) & ymask)); }
-        if (firstx) wb_atomic_add(&nuxc[c], 1);
         if (firsty) wb_atomic_add(&setc[c], 1);
     WB_END_PFOR
     // compaction: a thread owns a run of consecutive raw points; the kept ones go to the job's output array (the points of
@@ -659,6 +670,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_SINGLE
     // contours with at least four points stay (contour_index.py:113-117)
     WB_PFOR32(c, C)
+        nuxc[c] = nuxc[c] - xminc[c] + 1;                          // distinct x (xminc lies in kid[])
         kid[c] = (newstart[c + 1] - newstart[c]) >= 4 ? 1 : 0;
         fin[c] = kid[c];
     WB_END_PFOR
@@ -677,7 +689,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // first point of i1; the few that pass it are queued and checked by the whole workgroup.
     auto in_set = [&](const uint32_t pw, const int c2) -> bool {
         const uint32_t xm = WB_F_XM(pw), cy = ((uint32_t)c2 << yb) | ((pw >> xb) & ymask);
-        const int bk = (int)xm >> WB_F_XSHIFT, b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
+        const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
         for (int e2 = b0; e2 < b1; ++e2) {
             const uint32_t pw2 = rawpt[order[e2]];
             if ((pw2 >> xb) == cy && WB_F_XM(pw2) == xm) return true;
