@@ -306,3 +306,23 @@ def test_order_dependent_joins_vs_skimage(golden_dir):
             assert np.array_equal(c, pts[off[i]:off[i + 1]]), (name, i)
         nwalk += 1
     assert nraise == 6 and nwalk == 48
+
+
+def test_a_contours_distinct_x_are_its_extent():
+    """wb_k_trace_fused takes exp_lon (contour_index.py:154: the number of distinct x of the contour's points) as xmax - xmin + 1:
+    consecutive crossings of the marching squares lie on the edges of one cell and round to corners of that cell, so the points
+    form a lattice path.  Here: the oracle's contours in index coordinates (len(set(x)) as the reference counts, contour_index.py:154
+    with original_coordinates=False, the index functions' case) on smooth to rough fields of three grids all have exp_lon equal to
+    their extent."""
+    import numpy as np
+    from oracle import contours as oc, synth
+    n = 0
+    for dlon, eps, t0, nt in ((2.5, 0.2, 0, 4), (2.5, 0.8, 100, 4), (1.0, 0.0, 0, 2), (1.0, 0.6, 40, 2), (0.25, 0.3, 7, 1)):
+        lat, lon = synth.grid(dlon)
+        pv = synth.pv_field(t0, nt, lat, lon, eps=eps)
+        frame = oc.calculate_contours(pv, [-2, 2], lat, lon, synth.times(nt), original_coordinates=False)   # (index coordinates: what the index functions select on)
+        for c in frame:
+            x = np.asarray(c["geometry"])[:, 0]
+            assert round(c["exp_lon"] / dlon) == len(set(x.tolist())) == int(x.max() - x.min()) + 1, (dlon, eps, c["exp_lon"])
+            n += 1
+    assert n > 100
