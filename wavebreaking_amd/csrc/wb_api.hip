@@ -1483,9 +1483,11 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         auto boxcom_here = [&](int stage) {
             if (boxcom_grid <= 0 || ctx->boxcom_after != stage) return;
             side_begin(ctx);
+            const bool masked = boxmask_begin(ctx);
             b->timer.begin(ctx, "box_com");
             WB_LAUNCH(wb_k_box_com, boxcom_grid, 64, ba);
             b->timer.end(ctx);
+            if (masked) boxmask_end(ctx);
             side_end(ctx);
             boxcom_grid = 0;
         };
@@ -2156,13 +2158,18 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
         if (!wb_remask_streams(ctx, value / 1000, value % 1000)) return wb_fail(ctx, "wb_set_option: cu_mask: the masked streams could not be made");
         return 0;
     }
+    if (!strcmp(name, "boxcom_cu_mask")) {       // before the first wb_indices of the context (its stream is made on first use)
+        if (ctx->stream4) return wb_fail(ctx, "wb_set_option: boxcom_cu_mask after the box kernel's stream was made");
+        ctx->boxcom_cu_first = value / 1000; ctx->boxcom_cu_count = value % 1000;
+        return 0;
+    }
     if (!strcmp(name, "scan_cu_mask")) {         // before the first wb_contours of the context (its stream is made on first use)
         if (ctx->stream3) return wb_fail(ctx, "wb_set_option: scan_cu_mask after the scan's stream was made");
         ctx->scan_cu_first = value / 1000; ctx->scan_cu_count = value % 1000; ctx->scan_priority = ctx->scan_cu_count > 0 ? 1 : 0;
         return 0;
     }
 #else
-    if (!strcmp(name, "cu_mask") || !strcmp(name, "scan_cu_mask")) return 0;
+    if (!strcmp(name, "cu_mask") || !strcmp(name, "scan_cu_mask") || !strcmp(name, "boxcom_cu_mask")) return 0;
 #endif
     ctx->err = std::string("wb_set_option: unknown option ") + name;
     return 1;

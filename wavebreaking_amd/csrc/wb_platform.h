@@ -48,6 +48,7 @@ struct wb_ctx {
     int persist_slack = 0;                    // workgroup places the persistent 1024-thread launches (all-pairs, routine 1) leave free: a full grid holds EVERY wave slot of the device until its queue is empty, and the other batch's small kernels wait for that
     int scan_priority = 0;                    // 1: the field scan is launched on a stream of its own (stream3): the device's highest priority, or -- option "scan_cu_mask" -- a CU-masked one
     int cu_first = 0, cu_count = 0;           // option "cu_mask": the context's main and side streams own the compute units [cu_first, cu_first + cu_count) only (0: the whole device)
+    int boxcom_cu_first = 0, boxcom_cu_count = 0;   // option "boxcom_cu_mask": wb_k_box_com runs on those compute units only (its single waves otherwise take slots on every CU from the 1024-thread workgroups of the streamer chain beside it)
     int scan_cu_first = 0, scan_cu_count = 0; // option "scan_cu_mask": ... and the field scan's stream those
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int geometry = 1;                         // 1: wb_indices also leaves the events' polygons in lon / lat (transform_polygons, index_utils.py:129-184) in pinned host memory, cut and mapped by the device (wb_geom.h); 0: wb_get_event_geometry computes them on the host when asked
@@ -75,6 +76,8 @@ struct wb_ctx {
     hipStream_t stream2 = nullptr;            // side stream: result transfers that overlap the last kernel
     hipStream_t stream3 = nullptr;            // option scan_priority: a stream of the device's highest priority for the field scan (made on first use)
     hipEvent_t fork3 = nullptr, join3 = nullptr;
+    hipStream_t stream4 = nullptr;            // option boxcom_cu_mask: a CU-masked stream for wb_k_box_com (made on first use)
+    hipEvent_t fork4 = nullptr, join4 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t scan_done = nullptr;           // recorded behind this context's field scan (option scan_exclusive)
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
@@ -396,6 +399,39 @@ static void side_end(wb_ctx* ctx) {
     (void)ctx;
 #endif
 }
+#if !defined(WB_HOSTSIM)
+static bool wb_masked_stream(hipStream_t* out, int first, int count);
+#endif
+// option "boxcom_cu_mask": what is launched between boxmask_begin and boxmask_end (inside side_begin / side_end) goes to a
+// CU-masked stream, in stream order with the side stream before and behind it
+static bool boxmask_begin(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    if (ctx->boxcom_cu_count <= 0) return false;
+    if (!ctx->stream4) {
+        if (!wb_masked_stream(&ctx->stream4, ctx->boxcom_cu_first, ctx->boxcom_cu_count) ||
+            hipEventCreateWithFlags(&ctx->fork4, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->join4, hipEventDisableTiming) != hipSuccess) {
+            ctx->boxcom_cu_count = 0;
+            return false;
+        }
+    }
+    (void)hipEventRecord(ctx->fork4, ctx->stream);
+    (void)hipStreamWaitEvent(ctx->stream4, ctx->fork4, 0);
+    std::swap(ctx->stream, ctx->stream4);
+    return true;
+#else
+    (void)ctx;
+    return false;
+#endif
+}
+static void boxmask_end(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    (void)hipEventRecord(ctx->join4, ctx->stream);
+    std::swap(ctx->stream, ctx->stream4);
+    (void)hipStreamWaitEvent(ctx->stream, ctx->join4, 0);
+#else
+    (void)ctx;
+#endif
+}
 static void side_join(wb_ctx* ctx) {          // the main stream waits for the side stream's last side_end
 #if !defined(WB_HOSTSIM)
     (void)hipStreamWaitEvent(ctx->stream, ctx->join, 0);
@@ -636,6 +672,9 @@ static void wb_platform_destroy(wb_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    if (c->fork4) (void)hipEventDestroy(c->fork4);
+    if (c->join4) (void)hipEventDestroy(c->join4);
     if (c->fork3) (void)hipEventDestroy(c->fork3);
     if (c->join3) (void)hipEventDestroy(c->join3);
     if (c->fork) (void)hipEventDestroy(c->fork);
