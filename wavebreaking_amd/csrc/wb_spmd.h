@@ -299,6 +299,18 @@ __device__ inline int wb_block_scan_excl(int* a, int n) {
     __shared__ int wb_scan_wave[16];
     __shared__ int wb_scan_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    if (n <= (int)blockDim.x) {
+        // at most one element per thread (a per-job table of a few hundred entries): no carry, two barriers instead of five
+        const int v = tid < n ? a[tid] : 0;
+        const int inc = wb_wave_scan_incl(v);
+        if (lane == 63) wb_scan_wave[wave] = inc;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < nw; ++w) { const int t = wb_scan_wave[w]; if (w < wave) woff += t; total += t; }
+        if (tid < n) a[tid] = woff + inc - v;
+        __syncthreads();                               // (a[] stands; wb_scan_wave is free for the next call)
+        return total;
+    }
     if (tid == 0) wb_scan_carry = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 8 * blockDim.x) {
