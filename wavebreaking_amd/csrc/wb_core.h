@@ -105,6 +105,7 @@ struct WbCtl {
     unsigned long long cell_count;
     int props_cursor;            // next event of the property kernel's work queue
     int group_ties;              // check_groups: groups whose maximum length was shared by several members (exact ties)
+    int tie_marks;               // ... some contour of the pass holds such a group (wb_k_streamer_ties has something to do)
     int n_recheck;               // pairs wb_k_streamer_pairs2 left to wb_k_streamer_recheck (inside a guard band)
     int n_boxq, boxq_cursor;     // overturning boxes queued for wb_k_box_com (wb_k_overturn) / the next one its persistent workgroups take
     int p2_cursor;               // next (contour, part) item of wb_k_streamer_pairs2's persistent workgroups

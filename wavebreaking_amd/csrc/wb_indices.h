@@ -1156,7 +1156,7 @@ WB_KERNEL(wb_k_streamer_f34, WbStreamerArgs a) {
         // set's iteration order -- resolved by wb_k_streamer_ties after this kernel (rare; kept out of this kernel's
         // registers); here the lowest such member stands in and the contour is marked
         WB_PFOR(m, M)
-            if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
+            if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) { a.tie_m[s] = M; a.ctl->tie_marks = 1; }
         WB_END_PFOR
         WB_PFOR(m, M)
             aux[m] = (lab[m] == (int)m) ? 1 : 0;   // group roots, in order of their lowest member
@@ -1697,7 +1697,7 @@ WB_KERNEL_LB(wb_k_streamer_f234, WB_F234_THREADS, WB_F234_OCC, WbStreamerArgs a)
         // registers); here the lowest such member stands in and the contour is marked.  Then the group roots, in order of
         // their lowest member
         WB_PFOR(m, M)
-            if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) a.tie_m[s] = M;
+            if (gval[m] == best[lab[m]] && (int)best[M + lab[m]] != (int)m) { a.tie_m[s] = M; a.ctl->tie_marks = 1; }
             aux[m] = (lab[m] == (int)m) ? 1 : 0;
         WB_END_PFOR
         int Gn;
@@ -1798,6 +1798,7 @@ WB_DEV inline void wb_streamer_resolve_ties(const WbStreamerArgs& a, int s) {
 }
 
 WB_KERNEL(wb_k_streamer_ties, WbStreamerArgs a) {
+    if (!a.ctl->tie_marks) return;                  // (nearly always: no contour of the pass was marked -- going through their marks took 17 us)
     const int nsel = a.ctl->nsel;
     for (int s = WB_BLOCK_ID * WB_NT + WB_TID; s < nsel; s += WB_GRID_DIM * WB_NT) wb_streamer_resolve_ties(a, s);
 }
