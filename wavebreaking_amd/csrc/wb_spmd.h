@@ -296,53 +296,45 @@ __device__ inline int wb_wave_scan_incl(int v) {
 // wave scan of the thread sums, running carry): a per-job array of a few thousand entries is two or three chunks, each
 // one memory round trip and three barriers.
 __device__ inline int wb_block_scan_excl(int* a, int n) {
-    __shared__ int wb_scan_wave[16];
-    __shared__ int wb_scan_carry;
+    // The waves' totals of a chunk go through one of two LDS rows in turn and the running carry stays in registers (every thread
+    // adds up the same totals): ONE barrier per chunk and one behind the last -- it was three per chunk and two around them, and the
+    // single-workgroup kernels that lay out a pass's lists (20 000 events: ten chunks) are nothing but these barriers.
+    __shared__ int wb_scan_wave[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (blockDim.x + 63) >> 6;
     if (n <= (int)blockDim.x) {
-        // at most one element per thread (a per-job table of a few hundred entries): no carry, two barriers instead of five
+        // at most one element per thread (a per-job table of a few hundred entries)
         const int v = tid < n ? a[tid] : 0;
         const int inc = wb_wave_scan_incl(v);
-        if (lane == 63) wb_scan_wave[wave] = inc;
+        if (lane == 63) wb_scan_wave[0][wave] = inc;
         __syncthreads();
         int woff = 0, total = 0;
-        for (int w = 0; w < nw; ++w) { const int t = wb_scan_wave[w]; if (w < wave) woff += t; total += t; }
+        for (int w = 0; w < nw; ++w) { const int t = wb_scan_wave[0][w]; if (w < wave) woff += t; total += t; }
         if (tid < n) a[tid] = woff + inc - v;
-        __syncthreads();                               // (a[] stands; wb_scan_wave is free for the next call)
+        __syncthreads();                               // (a[] stands; the rows are free for the next call)
         return total;
     }
-    if (tid == 0) wb_scan_carry = 0;
-    __syncthreads();
+    int carry = 0, row = 0;                            // the same in every thread
     for (int base = 0; base < n; base += 8 * blockDim.x) {
         const int i0 = base + 8 * tid;
         int v[8], sum = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < n) ? a[i0 + k] : 0; sum += v[k]; }
         const int inc = wb_wave_scan_incl(sum);
-        if (lane == 63) wb_scan_wave[wave] = inc;
+        if (lane == 63) wb_scan_wave[row][wave] = inc;
         __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wb_scan_wave[w];
-        const int carry = wb_scan_carry;
+        int woff = 0, total = 0;
+        for (int w = 0; w < nw; ++w) { const int t = wb_scan_wave[row][w]; if (w < wave) woff += t; total += t; }
         int run = carry + woff + inc - sum;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (i0 + k < n) a[i0 + k] = run;
             run += v[k];
         }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < nw; ++w) tot += wb_scan_wave[w];
-            wb_scan_carry = carry + tot;
-        }
-        __syncthreads();
+        carry += total;
+        row ^= 1;                                      // (the row just read is written again two chunks on, behind the next chunk's barrier)
     }
-    // (every thread has the total before anyone may enter the next scan, whose first statement clears the carry: two scans back
-    //  to back handed some threads 0 for the first one's total -- wb_k_geom_offsets, round 5, one pass in a hundred)
-    const int total = wb_scan_carry;
-    __syncthreads();
-    return total;
+    __syncthreads();                                   // (a[] stands; every thread has read its totals before the next call writes row 0)
+    return carry;
 }
 
 // in-place exclusive running maximum of a[0..n): a[i] <- max(init, a[0..i-1]); all threads of the block call it.
