@@ -37,12 +37,25 @@ tt._kernel_overlaps(ctx)
 tt._kernel_tracking(ctx)
 tt._kernel_thresholds(ctx)
 ctx.close()
+# round 5's rarer routes of the streamer filters: routine 1 in parts of the hash space (a 256-entry table), the record list four at a time,
+# routine 1 inside wb_k_streamer_f234, a kernel LDS of 64 points (longer contours: the sweep in global memory)
+lib2 = _hip.Library(helpers.build_hostsim(variant="f1parts_ch4", defines=("WB_F1_LTAB=256", "WB_F234_CH=4"), sanitize=True), allow_hostsim=True)
+ctx2 = _hip.Context(0, lib2)
+lat1, lon1 = synth.grid(1.0)
+pv1 = synth.pv_field(10, 2, lat1, lon1, eps=0.3)
+for opts in ({}, {"f1_fused": 1}, {"f234_lpts": 64}):
+    for k, v in opts.items():
+        ctx2.set_option(k, v)
+    helpers.full_parity(ctx2, pv1, lat1, lon1, synth.times(2), [-2, 2])
+    ctx2.set_option("f1_fused", 0); ctx2.set_option("f234_lpts", 0)
+ctx2.close()
 print("SANITIZED_OK")
 """
 
 
 def test_parity_case_under_asan_ubsan():
     helpers.build_hostsim(sanitize=True)
+    helpers.build_hostsim(variant="f1parts_ch4", defines=("WB_F1_LTAB=256", "WB_F234_CH=4"), sanitize=True)
     libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
     libubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"]).decode().strip()
     env = dict(os.environ, LD_PRELOAD=libasan + ":" + libubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
