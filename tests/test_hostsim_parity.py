@@ -255,7 +255,7 @@ def test_big_job_paths_without_lds():
 def test_streamer_sweep_with_a_short_record_list():
     # wb_k_streamer_f234 lists the records of the rows' bounds 256 at a time and goes on behind the last one when all of a list have
     # passed; a build that lists 4 at a time does that on every contour with more than four survivors
-    lib = _hip.Library(helpers.build_hostsim(variant="f234ch4", defines=("WB_F234_CH=4",)), allow_hostsim=True)
+    lib = _hip.Library(helpers.build_hostsim(variant="f1parts_ch4", defines=("WB_F1_LTAB=256", "WB_F234_CH=4")), allow_hostsim=True)   # (one build for this and the next test)
     for reverse in (0, 1):
         lib.lib.wb_hostsim_set_reverse(reverse)
         ctx = _hip.Context(0, lib)
@@ -279,7 +279,7 @@ def test_routine1_in_parts_and_with_the_global_table():
     import ctypes
     lat, lon = synth.grid(0.25)
     pv = synth.pv_field(40, 1, lat, lon, eps=0.3)
-    for variant, defines, path in (("f1parts", ("WB_F1_LTAB=256",), 0), ("nolds", ("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0", "WB_PROPS_LROWS=4", "WB_PROPS_PART=4", "WB_F1_LTAB=2", "WB_TRACE_LTAB=2"), 1)):
+    for variant, defines, path in (("f1parts_ch4", ("WB_F1_LTAB=256", "WB_F234_CH=4"), 0), ("nolds", ("WB_TRACE_LDS_N=16", "WB_TRACE_PACK=0", "WB_PROPS_LROWS=4", "WB_PROPS_PART=4", "WB_F1_LTAB=2", "WB_TRACE_LTAB=2"), 1)):
         lib = _hip.Library(helpers.build_hostsim(variant=variant, defines=defines), allow_hostsim=True)
         lib.lib.wb_hostsim_path_count.restype = ctypes.c_longlong
         lib.lib.wb_hostsim_path_count(0); lib.lib.wb_hostsim_path_count(1)
