@@ -142,7 +142,6 @@ __device__ inline double wb_readlane_f64(double v, int lane) {
 }
 __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStreamerArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wb_p2_lds[];
-    __shared__ int wb_p2_item;
     WB_PSTAMP_BEGIN
     const int cap = a.p2_cap, nbmax = cap / WB_BLK + 1, ntmax = cap / WB_PAIR_ROWS + 1, nlat = a.nlat, dy_max = a.dy_max;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = WB_P2_THREADS / 64;
@@ -168,19 +167,36 @@ __global__ __launch_bounds__(WB_P2_THREADS, 8) void wb_k_streamer_pairs2(WbStrea
     long long evaluated = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const double hthr = a.hthr, geo_band = a.geo_band, cont_dis = a.cont_dis;
+    // An item's descriptor -- the queue's atomic, then contour -> offset / length: a chain of three dependent loads, 8 us before
+    // the first point could be asked for -- is fetched ONE ITEM AHEAD by a single lane of the last wave, while the workgroup
+    // sweeps the present item; it goes through two LDS rows in turn.
+    __shared__ long long wb_p2_desc[2][4];                               // item, points of the contour, offset of its points, offset of its prefix
+    auto fetch = [&](int row) {
+        const int it = atomicAdd(&a.ctl->p2_cursor, 1);
+        long long nn = 0, off = 0, pp = 0;
+        if (it < nitems) {
+            const int ss = it / a.p2_split;
+            const int jj = a.sel_job[ss], kk = a.sel_cont[ss];
+            const size_t jb2 = (size_t)jj * a.cap_seg;
+            off = (long long)(2 * jb2) + a.c_off[jb2 + kk];
+            nn = a.c_len[jb2 + kk];
+            pp = a.poff[ss];
+        }
+        wb_p2_desc[row][0] = it; wb_p2_desc[row][1] = nn; wb_p2_desc[row][2] = off; wb_p2_desc[row][3] = pp;
+    };
+    if (tid == 0) fetch(0);
+    int row = 0;
     for (;;) {
-    __syncthreads();                                                     // (the previous item's LDS is done with)
-    if (tid == 0) wb_p2_item = atomicAdd(&a.ctl->p2_cursor, 1);
-    __syncthreads();
-    const int item = wb_p2_item;
+    __syncthreads();                                                     // (the previous item's LDS is done with; this item's descriptor stands)
+    const int item = (int)wb_p2_desc[row][0];
     if (item >= nitems) break;
+    const int N = (int)wb_p2_desc[row][1];
+    const uint32_t* gpts = a.cpts + wb_p2_desc[row][2];
+    const long long po = wb_p2_desc[row][3];
+    if (tid == WB_P2_THREADS - 64) fetch(row ^ 1);                       // (the row read before the barrier above; read next behind the next one)
+    row ^= 1;
     const int s = item / a.p2_split, part = item - s * a.p2_split;
-    const int job = a.sel_job[s], k = a.sel_cont[s];
-    const size_t jb = (size_t)job * a.cap_seg;
-    const uint32_t* gpts = a.cpts + 2 * jb + a.c_off[jb + k];
-    const int N = a.c_len[jb + k];
     if (N > a.p2_cap) continue;                                          // the tiled kernel's list holds this contour
-    const long long po = a.poff[s];
     const double* gpre = a.pre + po;
     const int* gbbx = a.bbx + 4 * ((po >> 5) + s);
     const int* gtbx = a.tbx + 4 * ((po >> 4) + s);
