@@ -518,6 +518,37 @@ def test_device_copy_used_on_trust_and_checked_before_the_call_returns(hostsim_e
     assert list(b1["com"]) != list(a1["com"])
 
 
+def test_two_cubes_keyed_on_pool_threads_are_verified_by_the_calling_thread(hostsim_engine, monkeypatch):
+    """data + intensity of 64 MB and more take their keys on two pool threads (engine.resident_inputs); the pending
+    fingerprints those threads leave belong to the CALL: the calling thread compares them before it returns, so an in-place
+    edit of either cube is seen (one more upload, new events), and nothing stays behind in engine._pending_by_head"""
+    monkeypatch.setattr(engine, "SPECULATE", True)
+    monkeypatch.setattr(engine, "PARALLEL_KEYS_BYTES", 1)                       # (the pool path with the tests' small cubes)
+    data, pv, lat, lon, tm = _field()
+    inten_np = synth.pv_field(0, 3, lat, lon, eps=0.0, seed=20241)
+    inten = wb.GridField(inten_np, data.dims, data.coords)
+    ctx = engine.get_context()
+    uploads = []
+    real_up = ctx.to_device
+    monkeypatch.setattr(ctx, "to_device", lambda a: (uploads.append(a.shape), real_up(a))[1])
+    s0 = engine.FINGERPRINT_STATS.get("speculated", 0)
+    a1 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    a2 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    assert len(uploads) == 2 and list(a1["intensity"]) == list(a2["intensity"])
+    assert engine.FINGERPRINT_STATS.get("speculated", 0) - s0 >= 2             # both cubes of the second call went on trust
+    assert not engine._pending_by_head                                          # ... and were compared by the calling thread
+    inten.values[:] = 2.0 * inten.values                                        # the intensity edited in place
+    b1 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    assert len(uploads) == 3 and not engine._pending_by_head
+    assert np.allclose(np.asarray(b1["intensity"], float), 2.0 * np.asarray(a1["intensity"], float), atol=0.011)
+    assert list(b1["intensity"]) != list(a1["intensity"])
+    v = data.values
+    v[1] = v[1][:, ::-1].copy()                                                 # then a time step of the field mirrored in place
+    c1 = wb.calculate_streamers(data=data, contour_levels=[2], intensity=inten)
+    assert len(uploads) == 4 and not engine._pending_by_head
+    assert list(c1["com"]) != list(b1["com"])
+
+
 def test_an_edit_of_one_time_step_between_two_calls_is_seen(hostsim_engine, monkeypatch):
     """the reference rereads its input on every call (index_utils.py:66-75): a region of ONE time step patched in place
     between two calls -- far from any strided sample -- gives the new events, not the cached cube's; cubes registered with

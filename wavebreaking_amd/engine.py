@@ -204,10 +204,14 @@ def _immutable(arr):
     return isinstance(o, bytes)
 
 
-def _array_key(arr, ctx=None):
+def _array_key(arr, ctx=None, owner=None):
     """cache key of a cube: buffer address, shape, dtype and a fingerprint of its bytes -- of ALL of them unless the buffer
-    cannot change (not writeable) or was registered with keep_inputs()"""
+    cannot change (not writeable) or was registered with keep_inputs().  ``owner``: the thread identifier of the CALL the key
+    is made for (resident_inputs makes the keys of a call's two cubes on pool threads: the pending fingerprints belong to the
+    calling thread, which is the one that verifies or discards them); default: this thread"""
     import time
+    if owner is None:
+        owner = threading.get_ident()
     flat = arr.reshape(-1)                      # a view: the array is C-contiguous
     n = flat.size
     head = (arr.__array_interface__["data"][0], arr.shape, arr.dtype.str)
@@ -230,14 +234,14 @@ def _array_key(arr, ctx=None):
         # bytes as they are NOW is taken on other threads; the call checks it before it returns anything (verify_pending) and
         # starts over with a fresh upload if the cube has changed -- the check costs the call nothing unless it fails.
         with _pending_lock:
-            hit = _pending_by_head.get((ctx.device, threading.get_ident(), head))
+            hit = _pending_by_head.get((ctx.device, owner, head))
             if hit is not None:
                 return hit[0]
             resident, _ = _caches(ctx)
             for k in resident:
                 if k[:3] == head and k[3] == "full":
                     fut = _fp_pool().submit(fingerprint)
-                    _pending_by_head[(ctx.device, threading.get_ident(), head)] = (k, fut, ctx)
+                    _pending_by_head[(ctx.device, owner, head)] = (k, fut, ctx)
                     FINGERPRINT_STATS["speculated"] = FINGERPRINT_STATS.get("speculated", 0) + 1
                     return k
     return head + ("full", fingerprint())
@@ -403,6 +407,10 @@ def release_inputs():
             _drop_resident(ctx, key)
 
 
+# a call with two cubes of at least this many bytes takes their keys on two threads (tests lower it)
+PARALLEL_KEYS_BYTES = 64 << 20
+
+
 def _budget():
     return float(os.environ.get("WB_INPUT_CACHE_GB", 48)) * 2.0 ** 30
 
@@ -429,11 +437,13 @@ def resident_inputs(ctx, field, intensity, block):
     _purge_dead(ctx)
     resident, _ = _caches(ctx)
     arrs = [a for a in (field, intensity) if a is not None]
-    if len(arrs) == 2 and arrs[0].nbytes >= (64 << 20):
-        # the two cubes' fingerprints side by side (wb_fingerprint releases the GIL; each uses its own host threads)
+    if len(arrs) == 2 and arrs[0].nbytes >= PARALLEL_KEYS_BYTES:
+        # the two cubes' fingerprints side by side (wb_fingerprint releases the GIL; each uses its own host threads); the
+        # pending entries they leave are the CALLING thread's -- it is the one that runs verify_pending / discard_pending
         from concurrent.futures import ThreadPoolExecutor
+        me = threading.get_ident()
         with ThreadPoolExecutor(2) as pool:
-            keys = list(pool.map(lambda a: _array_key(a, ctx), arrs))
+            keys = list(pool.map(lambda a: _array_key(a, ctx, owner=me), arrs))
     else:
         keys = [_array_key(a, ctx) for a in arrs]
     fresh = [k not in resident for k in keys]
