@@ -220,9 +220,12 @@ int wb_comm_gather_staged(wb_ctx* ctx, int slot, int dst, const double** rows, i
    wb_comm_gather_staged with slot = -1: it still takes part in the exchange of the counts, with -1 for its own, so every
    rank's call for that slot FAILS ("... ranks in place") instead of waiting for a payload that never comes, and the ranks'
    sequences of collectives stay matched.  wb_comm_abort: ncclCommAbort -- peers blocked in a collective with this rank get an
-   error from RCCL; every later exchange of this context fails at once.  wb_comm_reserve: the destination rank's device and
+   error from RCCL; every later exchange of this context fails at once.  It may be called from another host thread than the
+   one that sits in wb_comm_gather_staged (the library looks at an atomic flag before every group of RCCL calls and holds a
+   lock while it enqueues one).  wb_comm_reserve: the destination rank's device and
    pinned buffers for the whole group's catalogue, made before the record's batches are in flight (growing them inside a
-   gather is a hipFree / hipMalloc beside the workers' kernels). */
+   gather is a hipFree / hipMalloc beside the workers' kernels).  The views a gather handed out (*rows, *poly_x, *poly_y) are
+   valid until the context's next gather OR reserve: a buffer that grows is freed. */
 int wb_comm_abort(wb_ctx* ctx);
 int wb_comm_reserve(wb_ctx* ctx, int64_t rows, int64_t polygon_vertices);
 void wb_comm_destroy(wb_ctx* ctx);

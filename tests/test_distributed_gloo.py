@@ -482,3 +482,10 @@ def test_a_rank_whose_worker_raises_or_that_dies_mid_record_ends_the_others_non_
     for mode in ("raise", "kill"):
         outs = _run_failing_record(tmp_path, mode)
         assert all(rc is not None and rc != 0 for rc, _ in outs), (mode, outs)
+        if mode == "raise":
+            # the rank that raised tells the others that it is leaving (one exchange of the counts with -2): they fail with
+            # GatherAborted / GatherPoisoned within seconds, not at the process group's time-out (60 s here)
+            import re
+            for r in (0, 2):
+                assert "Gather" in outs[r][1], outs
+                assert float(re.search(r"failed after ([0-9.]+) s", outs[r][1]).group(1)) < 30.0, outs

@@ -12,61 +12,9 @@ import numpy as np
 import pytest
 
 from oracle import geom
-from tests import helpers, ogc_reference as ogc
+from tests import geos_cases, helpers, ogc_reference as ogc
+from tests.geos_cases import corner_cases as _corner_cases, intersect_cases as _intersect_cases, touches_cases as _touches_cases
 from wavebreaking_amd import _hip
-
-
-def _dedupe(points):
-    """np.round(...).astype(int) + dict.fromkeys: the reference's contour, contour_index.py:110-112"""
-    return np.array(list(dict.fromkeys(map(tuple, points))), dtype=np.int64)
-
-
-def _walk(rng, n, revisit):
-    """a lattice walk of unit and diagonal steps that doubles back on itself every now and then (so that the deduped contour
-    has long steps OVER earlier vertices)"""
-    steps = np.array([(1, 0), (1, 0), (1, 1), (1, -1), (0, 1), (0, -1), (-1, 0), (-1, 1), (-1, -1)])
-    p = np.array([int(rng.randint(20, 40)), int(rng.randint(20, 40))])
-    out = [p.copy()]
-    k = 0
-    while len(out) < n:
-        if rng.rand() < revisit and len(out) > 6:
-            # go back over the last few points (these revisits are dropped by the dedupe and leave a long step behind)
-            m = int(rng.randint(2, 6))
-            back = out[-2:-2 - m:-1]
-            out.extend(q.copy() for q in back)
-            out.extend(q.copy() for q in back[::-1][1:])
-            p = out[-1].copy()
-            # ... and beyond where we came from
-            p = p + steps[int(rng.randint(0, 4))]
-            out.append(p.copy())
-            continue
-        p = p + steps[int(rng.randint(0, len(steps)))]
-        out.append(p.copy())
-        k += 1
-    return np.array(out)
-
-
-def _contours(rng, count):
-    out = []
-    while len(out) < count:
-        c = _dedupe(_walk(rng, int(rng.randint(12, 60)), float(rng.choice([0.0, 0.1, 0.25]))))
-        if len(c) >= 4 and c.min() >= 0:
-            out.append(c)
-    return out
-
-
-def _corner_cases():
-    """hand-made: the contour's FIRST vertex lies on a later long segment, and chords run through it"""
-    cases = []
-    # first vertex (5, 5); the dedupe leaves the long step (4, 5) -> (7, 5)?? no: the line comes back OVER (5, 5), (6, 5)
-    raw = [(5, 5), (6, 5), (7, 6), (7, 7), (6, 8), (4, 8), (3, 7), (3, 6), (4, 5), (5, 5), (6, 5), (7, 5), (8, 4), (6, 2), (5, 3), (5, 4), (5, 6), (5, 7)]
-    c = _dedupe(np.array(raw))
-    cases.append(c)
-    # last vertex on an earlier segment is impossible after the dedupe (it would have been dropped); first vertex on a LATER
-    # vertical long step:
-    raw = [(10, 10), (11, 10), (12, 11), (12, 12), (10, 13), (9, 12), (10, 11), (10, 10), (10, 9), (10, 8), (9, 7), (8, 9), (9, 10), (11, 10), (12, 10)]
-    cases.append(_dedupe(np.array(raw)))
-    return cases
 
 
 def _device_touches(ctx, contour, i1, i2):
@@ -91,26 +39,6 @@ def _device_intersects(ctx, seg8):
     lib.wb_test_segments_intersect.argtypes = [C.c_void_p, C.c_int, p, p]
     assert lib.wb_test_segments_intersect(ctx.h, len(s), s.ctypes.data_as(p), out.ctypes.data_as(p)) == 0, ctx.error()
     return out.astype(bool)
-
-
-def _touches_cases(seed, ncontours, per):
-    rng = np.random.RandomState(seed)
-    cs = _corner_cases() + _contours(rng, ncontours)
-    for c in cs:
-        n = len(c)
-        # every chord through the first / last vertex's location is interesting: add all pairs collinear with them, + random pairs
-        pairs = set()
-        for _ in range(per):
-            i, j = sorted(int(v) for v in rng.randint(0, n, 2))
-            if i != j:
-                pairs.add((i, j))
-        for e in (0, n - 1):
-            for i in range(n):
-                for j in range(i + 1, n):
-                    if i != e and j != e and geom.orient(c[i, 0], c[i, 1], c[j, 0], c[j, 1], c[e, 0], c[e, 1]) == 0 and len(pairs) < 4 * per:
-                        pairs.add((i, j))
-        ij = np.array(sorted(pairs), dtype=np.int64)
-        yield c, ij
 
 
 def _run_touches(ctx, seed, ncontours, per):
@@ -153,19 +81,6 @@ def test_end_vertex_under_a_later_segment_is_boundary_as_a_point():
     assert seg, k
     want = ogc.chord_touches_linestring(c[i], c[j], c)
     assert geom.chord_touches_contour(c[i], c[j], c) == want
-
-
-def _intersect_cases(seed, n):
-    rng = np.random.RandomState(seed)
-    s = rng.randint(0, 9, size=(n, 8))
-    # many degenerate configurations: shared end points, collinear, touching
-    k = n // 4
-    s[:k, 4:6] = s[:k, 0:2]                                                        # shared end point
-    s[k:2 * k, 4:8] = s[k:2 * k, 0:4] + np.repeat(rng.randint(-2, 3, size=(k, 2)), 2, axis=1) * 0 + np.tile(rng.randint(-1, 2, size=(k, 1)), (1, 4)) * np.array([1, 0, 1, 0])   # shifted along x
-    d = s[2 * k:3 * k, 2:4] - s[2 * k:3 * k, 0:2]
-    s[2 * k:3 * k, 4:6] = s[2 * k:3 * k, 0:2] + d * rng.randint(-1, 3, size=(k, 1))     # third point collinear with the first segment
-    keep = (s[:, 0:2] != s[:, 2:4]).any(axis=1) & (s[:, 4:6] != s[:, 6:8]).any(axis=1)  # no zero-length segments (a LineString needs two distinct points)
-    return s[keep]
 
 
 def test_intersects_oracle_host_simulation_and_matplotlib_against_the_independent_statement():

@@ -560,7 +560,7 @@ static int run_phase1(wb_batch* b) {
         }
     }
     if (!fused_all) {
-    if (!chain_scratch()) return 1;
+    if (!chain_scratch()) return wb_fail(ctx, "out of device memory (scratch of the three-kernel trace chain)");
     b->timer.begin(ctx, "trace_link");
     {   // row tables in dynamic LDS when they fit (16-bit entries: a job of the LDS paths has at most 8192 segments)
         const size_t tab = (size_t)(NS + 1) * nlat * sizeof(uint16_t) + 16;
@@ -796,6 +796,9 @@ extern "C" int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_
     if (nlon < 1 || (!index_space && (!lon || !lat || nlat < 1))) return wb_fail(ctx, "wb_transform_polygons_device: lon / lat / nlon missing");
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     const long long NP = n ? poly_offset[n] : 0;
+    if (!index_space)                             // (wb_k_geom_fill looks lat[y] up unguarded: rows outside the grid are the caller's error)
+        for (long long q = 0; q < NP; ++q)
+            if (py[q] < 0 || py[q] >= nlat) return wb_fail(ctx, "wb_transform_polygons_device: a polygon vertex lies outside the grid's rows (0 <= y < nlat)");
     std::vector<void*> tmp;
     auto talloc = [&](size_t bytes) { void* q = dmalloc(ctx, bytes ? bytes : 8); if (q) tmp.push_back(q); return q; };
     auto release = [&]() { for (void* q : tmp) dfree(ctx, q); tmp.clear(); };
@@ -809,13 +812,19 @@ extern "C" int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_
     ga.cnt_r = (int*)talloc((size_t)(n + 2) * 4); ga.cnt_v = (int*)talloc((size_t)(n + 2) * 4); ga.gflag = (int*)talloc((size_t)(n + 2) * 4);
     ga.ring_offset = (long long*)talloc((size_t)(n + 2) * 8); ga.vert_offset = (long long*)talloc((size_t)(ga.cap_r + 2) * 8);
     ga.x = (double*)talloc((size_t)(ga.cap_v + 2) * 8); ga.y = (double*)talloc((size_t)(ga.cap_v + 2) * 8);
-    if (!ga.y || !ga.x || !ga.vert_offset || !ga.ring_offset || !ga.gflag || !d_lat || !d_lon || !d_py) { release(); return wb_fail(ctx, "out of device memory"); }
+    if (!ga.y || !ga.x || !ga.vert_offset || !ga.ring_offset || !ga.gflag || !ga.cnt_v || !ga.cnt_r || !d_lat || !d_lon || !d_py || !d_px || !d_po) {
+        release();
+        return wb_fail(ctx, "out of device memory");
+    }
+    // a copy or launch that fails: the host function is the same statement (the device path is an optimisation of this call)
+    auto host = [&]() { release(); return wb_transform_polygons(ctx, n, poly_offset, px, py, lon, lat, nlon, index_space, o); };
     std::vector<long long> po(poly_offset, poly_offset + n + 1);
     if (n == 0) po.assign(1, 0);
-    h2d(ctx, d_po, po.data(), po.size() * sizeof(long long));
-    if (NP) { h2d(ctx, d_px, px, (size_t)NP * 4); h2d(ctx, d_py, py, (size_t)NP * 4); }
-    if (lon) h2d(ctx, d_lon, lon, (size_t)nlon * 8);
-    if (lat) h2d(ctx, d_lat, lat, (size_t)nlat * 8);
+    int rc = h2d(ctx, d_po, po.data(), po.size() * sizeof(long long));
+    if (!rc && NP) { rc = h2d(ctx, d_px, px, (size_t)NP * 4); if (!rc) rc = h2d(ctx, d_py, py, (size_t)NP * 4); }
+    if (!rc && lon) rc = h2d(ctx, d_lon, lon, (size_t)nlon * 8);
+    if (!rc && lat) rc = h2d(ctx, d_lat, lat, (size_t)nlat * 8);
+    if (rc) return host();
     ga.poly_offset = d_po; ga.px = d_px; ga.py = d_py; ga.lon = d_lon; ga.lat = d_lat;
     WbOpTimer tm(ctx);
     WB_LAUNCH(wb_k_geom_count, n < 4096 ? (n > 0 ? n : 1) : 4096, WB_GEOM_THREADS, ga);
@@ -824,22 +833,22 @@ extern "C" int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_
     tm.stop();
     std::vector<int> cr((size_t)n + 1), fl((size_t)n + 1, 0);
     std::vector<int> cv((size_t)n + 1);
-    d2h(ctx, cr.data(), ga.cnt_r, (size_t)(n + 1) * 4);
-    d2h(ctx, cv.data(), ga.cnt_v, (size_t)(n + 1) * 4);
-    if (n) d2h(ctx, fl.data(), ga.gflag, (size_t)n * 4);
+    rc = dsync(ctx);
+    if (!rc) rc = d2h(ctx, cr.data(), ga.cnt_r, (size_t)(n + 1) * 4);
+    if (!rc) rc = d2h(ctx, cv.data(), ga.cnt_v, (size_t)(n + 1) * 4);
+    if (!rc && n) rc = d2h(ctx, fl.data(), ga.gflag, (size_t)n * 4);
+    if (rc) return host();
     bool flagged = false;
     for (int64_t k = 0; k < n; ++k) flagged |= fl[(size_t)k] != 0;
     const long long NR = cr[(size_t)n], NV = cv[(size_t)n];
-    if (flagged || NR > ga.cap_r || NV > ga.cap_v) {
-        release();
-        return wb_transform_polygons(ctx, n, poly_offset, px, py, lon, lat, nlon, index_space, o);
-    }
+    if (flagged || NR < 0 || NV < 0 || NR > ga.cap_r || NV > ga.cap_v) return host();
     WbRingSink& g = ctx->geo;
     g = WbRingSink();
     g.ring_offset.resize((size_t)n + 1); g.vert_offset.resize((size_t)NR + 1); g.x.resize((size_t)NV); g.y.resize((size_t)NV);
-    d2h(ctx, g.ring_offset.data(), ga.ring_offset, (size_t)(n + 1) * 8);
-    d2h(ctx, g.vert_offset.data(), ga.vert_offset, (size_t)(NR + 1) * 8);
-    if (NV) { d2h(ctx, g.x.data(), ga.x, (size_t)NV * 8); d2h(ctx, g.y.data(), ga.y, (size_t)NV * 8); }
+    rc = d2h(ctx, g.ring_offset.data(), ga.ring_offset, (size_t)(n + 1) * 8);
+    if (!rc) rc = d2h(ctx, g.vert_offset.data(), ga.vert_offset, (size_t)(NR + 1) * 8);
+    if (!rc && NV) { rc = d2h(ctx, g.x.data(), ga.x, (size_t)NV * 8); if (!rc) rc = d2h(ctx, g.y.data(), ga.y, (size_t)NV * 8); }
+    if (rc) return host();
     release();
     o->n = n;
     o->ring_offset = g.ring_offset.data();
@@ -2649,7 +2658,7 @@ static void wb_comm_release(wb_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (cm.stream) (void)hipStreamSynchronize(cm.stream);
     if (cm.copy_stream) (void)hipStreamSynchronize(cm.copy_stream);
-    if (cm.comm && cm.CommDestroy) (void)cm.CommDestroy(cm.comm);
+    if (cm.comm && !cm.aborted && cm.CommDestroy) (void)cm.CommDestroy(cm.comm);     // (an aborted communicator is gone already)
     void* dev[] = {cm.d_counts, cm.d_scalar, cm.d_rows, cm.d_px, cm.d_py};
     for (void* q : dev) if (q) (void)hipFree(q);
     for (auto& sl : cm.slot) { if (sl.rows) (void)hipFree(sl.rows); if (sl.px) (void)hipFree(sl.px); if (sl.py) (void)hipFree(sl.py); }
@@ -2695,20 +2704,62 @@ extern "C" void wb_comm_destroy(wb_ctx* ctx) { wb_comm_release(ctx); }
 
 extern "C" int wb_comm_allreduce_max(wb_ctx* ctx, int* value) {
     if (!ctx || !value) return 1;
+    if (ctx->comm && ctx->comm->aborted) return wb_fail(ctx, "wb_comm_allreduce_max: the communicator was aborted (wb_comm_abort)");
     if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_allreduce_max: wb_comm_init first");
     wb_use(ctx);
     WbComm& cm = *ctx->comm;
-    cm.h_scalar[0] = *value;
-    WB_HIPC(hipMemcpyAsync(cm.d_scalar, cm.h_scalar, sizeof(int), hipMemcpyHostToDevice, cm.stream));
-    WB_NCCL(cm.AllReduce(cm.d_scalar, cm.d_scalar + 1, 1, ncclInt32, ncclMax, cm.comm, cm.stream));
-    WB_HIPC(hipMemcpyAsync(cm.h_scalar + 1, cm.d_scalar + 1, sizeof(int), hipMemcpyDeviceToHost, cm.stream));
+    {
+        std::unique_lock<std::timed_mutex> lk(cm.issue);
+        if (cm.aborted) return wb_fail(ctx, "wb_comm_allreduce_max: the communicator was aborted (wb_comm_abort)");
+        cm.h_scalar[0] = *value;
+        WB_HIPC(hipMemcpyAsync(cm.d_scalar, cm.h_scalar, sizeof(int), hipMemcpyHostToDevice, cm.stream));
+        WB_NCCL(cm.AllReduce(cm.d_scalar, cm.d_scalar + 1, 1, ncclInt32, ncclMax, cm.comm, cm.stream));
+        WB_HIPC(hipMemcpyAsync(cm.h_scalar + 1, cm.d_scalar + 1, sizeof(int), hipMemcpyDeviceToHost, cm.stream));
+    }
     WB_HIPC(hipStreamSynchronize(cm.stream));
+    if (cm.aborted) return wb_fail(ctx, "wb_comm_allreduce_max: the communicator was aborted (wb_comm_abort)");
     *value = cm.h_scalar[1];
     return 0;
 }
 
 // inside an open ncclGroupStart: a failing call closes the group before the error is reported
 #define WB_NCCL_G(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (void)cm.GroupEnd(); return wb_fail(ctx, std::string(#call) + ": " + cm.GetErrorString(r_)); } } while (0)
+
+// room for `rows` event rows and `verts` polygon vertices of the whole group's catalogue (0: leave as it is), device and pinned
+// host.  A capacity is raised only when its allocation has succeeded (a failed one leaves pointer and capacity at zero: the
+// next gather tries again instead of writing through a null pointer).  Views handed out by an earlier gather (*rows, *poly_x,
+// *poly_y of wb_comm_gather_*) die here when a buffer grows.
+static int wb_comm_room(wb_ctx* ctx, WbComm& cm, size_t rows, size_t verts) {
+    if (rows > cm.cap_rows) {
+        if (cm.d_rows) (void)hipFree(cm.d_rows);
+        cm.d_rows = nullptr; cm.cap_rows = 0;
+        WB_HIPC(hipMalloc((void**)&cm.d_rows, rows * WB_ROW_WIDTH * sizeof(double)));
+        cm.cap_rows = rows;
+    }
+    if (verts > cm.cap_v) {
+        if (cm.d_px) (void)hipFree(cm.d_px);
+        if (cm.d_py) (void)hipFree(cm.d_py);
+        cm.d_px = cm.d_py = nullptr; cm.cap_v = 0;
+        WB_HIPC(hipMalloc((void**)&cm.d_px, verts * sizeof(int32_t)));
+        WB_HIPC(hipMalloc((void**)&cm.d_py, verts * sizeof(int32_t)));
+        cm.cap_v = verts;
+    }
+    if (rows > cm.hcap_rows) {
+        if (cm.h_rows) (void)hipHostFree(cm.h_rows);
+        cm.h_rows = nullptr; cm.hcap_rows = 0;
+        WB_HIPC(hipHostMalloc((void**)&cm.h_rows, rows * WB_ROW_WIDTH * sizeof(double), hipHostMallocDefault));
+        cm.hcap_rows = rows;
+    }
+    if (verts > cm.hcap_v) {
+        if (cm.h_px) (void)hipHostFree(cm.h_px);
+        if (cm.h_py) (void)hipHostFree(cm.h_py);
+        cm.h_px = cm.h_py = nullptr; cm.hcap_v = 0;
+        WB_HIPC(hipHostMalloc((void**)&cm.h_px, verts * sizeof(int32_t), hipHostMallocDefault));
+        WB_HIPC(hipHostMalloc((void**)&cm.h_py, verts * sizeof(int32_t), hipHostMallocDefault));
+        cm.hcap_v = verts;
+    }
+    return 0;
+}
 
 // exchange (2) for tables that lie in device memory at src_*: counts, payload, the one copy to the host on dst
 static int wb_comm_gather_core(wb_ctx* ctx, WbComm& cm, const double* src_rows, const int32_t* src_px, const int32_t* src_py, long long ne,
@@ -2717,13 +2768,21 @@ static int wb_comm_gather_core(wb_ctx* ctx, WbComm& cm, const double* src_rows, 
     const int W = cm.world;
     // (1) counts: one all-gather of (rank + 1, events, vertices); the landing area is poisoned first, so a rank whose triple
     //     did not arrive -- or arrived in another rank's place -- is seen
-    for (int q = 0; q < 3 * W; ++q) cm.h_counts[q] = -1;
-    cm.h_counts[3 * W] = cm.rank + 1; cm.h_counts[3 * W + 1] = ne; cm.h_counts[3 * W + 2] = nv;
-    WB_HIPC(hipMemcpyAsync(cm.d_counts + 3, cm.h_counts, (size_t)3 * W * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
-    WB_HIPC(hipMemcpyAsync(cm.d_counts, cm.h_counts + 3 * W, 3 * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
-    WB_NCCL(cm.AllGather(cm.d_counts, cm.d_counts + 3, 3, ncclInt64, cm.comm, cm.stream));
-    WB_HIPC(hipMemcpyAsync(cm.h_counts, cm.d_counts + 3, (size_t)3 * W * sizeof(long long), hipMemcpyDeviceToHost, cm.stream));
+    //     (every group of RCCL calls is enqueued under cm.issue and behind a look at cm.aborted: wb_comm_abort may come from
+    //     another thread, WbComm in wb_comm.h)
+    const char* gone = "wb_comm_gather_tables: the communicator was aborted (wb_comm_abort)";
+    {
+        std::unique_lock<std::timed_mutex> lk(cm.issue);
+        if (cm.aborted) return wb_fail(ctx, gone);
+        for (int q = 0; q < 3 * W; ++q) cm.h_counts[q] = -1;
+        cm.h_counts[3 * W] = cm.rank + 1; cm.h_counts[3 * W + 1] = ne; cm.h_counts[3 * W + 2] = nv;
+        WB_HIPC(hipMemcpyAsync(cm.d_counts + 3, cm.h_counts, (size_t)3 * W * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
+        WB_HIPC(hipMemcpyAsync(cm.d_counts, cm.h_counts + 3 * W, 3 * sizeof(long long), hipMemcpyHostToDevice, cm.stream));
+        WB_NCCL(cm.AllGather(cm.d_counts, cm.d_counts + 3, 3, ncclInt64, cm.comm, cm.stream));
+        WB_HIPC(hipMemcpyAsync(cm.h_counts, cm.d_counts + 3, (size_t)3 * W * sizeof(long long), hipMemcpyDeviceToHost, cm.stream));
+    }
     WB_HIPC(hipStreamSynchronize(cm.stream));
+    if (cm.aborted) return wb_fail(ctx, gone);
     long long tot_e = 0, tot_v = 0;
     int seen = 0;
     for (int r = 0; r < W; ++r) {
@@ -2736,36 +2795,13 @@ static int wb_comm_gather_core(wb_ctx* ctx, WbComm& cm, const double* src_rows, 
     *rows = nullptr; *poly_x = *poly_y = nullptr; *nrows = 0; *nverts = 0;
     if (cm.rank == dst) {
         // room for the whole catalogue, on the device and in pinned host memory: grown when needed, kept between passes
-        if ((size_t)tot_e > cm.cap_rows) {
-            if (cm.d_rows) (void)hipFree(cm.d_rows);
-            cm.d_rows = nullptr;
-            cm.cap_rows = (size_t)tot_e + (size_t)tot_e / 4 + 1024;
-            WB_HIPC(hipMalloc((void**)&cm.d_rows, cm.cap_rows * WB_ROW_WIDTH * sizeof(double)));
-        }
-        if ((size_t)tot_v > cm.cap_v) {
-            if (cm.d_px) (void)hipFree(cm.d_px);
-            if (cm.d_py) (void)hipFree(cm.d_py);
-            cm.d_px = cm.d_py = nullptr;
-            cm.cap_v = (size_t)tot_v + (size_t)tot_v / 4 + 4096;
-            WB_HIPC(hipMalloc((void**)&cm.d_px, cm.cap_v * sizeof(int32_t)));
-            WB_HIPC(hipMalloc((void**)&cm.d_py, cm.cap_v * sizeof(int32_t)));
-        }
-        if ((size_t)tot_e > cm.hcap_rows) {
-            if (cm.h_rows) (void)hipHostFree(cm.h_rows);
-            cm.h_rows = nullptr;
-            cm.hcap_rows = (size_t)tot_e + (size_t)tot_e / 4 + 1024;
-            WB_HIPC(hipHostMalloc((void**)&cm.h_rows, cm.hcap_rows * WB_ROW_WIDTH * sizeof(double), hipHostMallocDefault));
-        }
-        if ((size_t)tot_v > cm.hcap_v) {
-            if (cm.h_px) (void)hipHostFree(cm.h_px);
-            if (cm.h_py) (void)hipHostFree(cm.h_py);
-            cm.h_px = cm.h_py = nullptr;
-            cm.hcap_v = (size_t)tot_v + (size_t)tot_v / 4 + 4096;
-            WB_HIPC(hipHostMalloc((void**)&cm.h_px, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
-            WB_HIPC(hipHostMalloc((void**)&cm.h_py, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
-        }
+        if (wb_comm_room(ctx, cm, (size_t)tot_e > cm.cap_rows || (size_t)tot_e > cm.hcap_rows ? (size_t)tot_e + (size_t)tot_e / 4 + 1024 : 0,
+                         (size_t)tot_v > cm.cap_v || (size_t)tot_v > cm.hcap_v ? (size_t)tot_v + (size_t)tot_v / 4 + 4096 : 0)) return 1;
     }
     // (2) payload: exact sizes, rank order = time order
+    {
+    std::unique_lock<std::timed_mutex> lk(cm.issue);
+    if (cm.aborted) return wb_fail(ctx, gone);
     WB_NCCL(cm.GroupStart());
     if (cm.rank == dst) {
         long long oe = 0, ov = 0;
@@ -2797,7 +2833,9 @@ static int wb_comm_gather_core(wb_ctx* ctx, WbComm& cm, const double* src_rows, 
             WB_HIPC(hipMemcpyAsync(cm.h_py, cm.d_py, (size_t)tot_v * sizeof(int32_t), hipMemcpyDeviceToHost, cm.stream));
         }
     }
+    }
     WB_HIPC(hipStreamSynchronize(cm.stream));
+    if (cm.aborted) return wb_fail(ctx, gone);
     if (cm.rank == dst) { *rows = cm.h_rows; *poly_x = cm.h_px; *poly_y = cm.h_py; *nrows = tot_e; *nverts = tot_v; }
     return 0;
 }
@@ -2882,10 +2920,14 @@ extern "C" int wb_comm_abort(wb_ctx* ctx) {
     if (!ctx) return 1;
     if (!ctx->comm || !ctx->comm->comm) return 0;
     WbComm& cm = *ctx->comm;
+    if (cm.aborted.exchange(true)) return 0;
     (void)hipSetDevice(ctx->device);
-    cm.aborted = true;
+    // no thread starts another group of RCCL calls from here on.  One that is ENQUEUEING a group right now holds cm.issue: wait for
+    // it, but not for ever -- a thread that sits inside an RCCL call (a group end that sets up connections to a peer that is
+    // gone) is exactly what ncclCommAbort is for, and it sees `aborted` before it touches the communicator again
+    std::unique_lock<std::timed_mutex> lk(cm.issue, std::chrono::seconds(2));
     if (cm.CommAbort) (void)cm.CommAbort(cm.comm);
-    cm.comm = nullptr;
+    if (lk.owns_lock()) cm.comm = nullptr;         // (else the handle's VALUE stays for the thread inside RCCL; nobody passes it on)
     return 0;
 }
 // room for `rows` event rows and `verts` polygon vertices of the WHOLE group's catalogue on this rank (the destination of the
@@ -2896,31 +2938,8 @@ extern "C" int wb_comm_reserve(wb_ctx* ctx, int64_t rows, int64_t verts) {
     if (!ctx->comm || !ctx->comm->comm) return wb_fail(ctx, "wb_comm_reserve: wb_comm_init first");
     WbComm& cm = *ctx->comm;
     (void)hipSetDevice(ctx->device);
-    if ((size_t)rows > cm.cap_rows) {
-        if (cm.d_rows) (void)hipFree(cm.d_rows);
-        cm.d_rows = nullptr; cm.cap_rows = (size_t)rows;
-        WB_HIPC(hipMalloc((void**)&cm.d_rows, cm.cap_rows * WB_ROW_WIDTH * sizeof(double)));
-    }
-    if ((size_t)verts > cm.cap_v) {
-        if (cm.d_px) (void)hipFree(cm.d_px);
-        if (cm.d_py) (void)hipFree(cm.d_py);
-        cm.d_px = cm.d_py = nullptr; cm.cap_v = (size_t)verts;
-        WB_HIPC(hipMalloc((void**)&cm.d_px, cm.cap_v * sizeof(int32_t)));
-        WB_HIPC(hipMalloc((void**)&cm.d_py, cm.cap_v * sizeof(int32_t)));
-    }
-    if ((size_t)rows > cm.hcap_rows) {
-        if (cm.h_rows) (void)hipHostFree(cm.h_rows);
-        cm.h_rows = nullptr; cm.hcap_rows = (size_t)rows;
-        WB_HIPC(hipHostMalloc((void**)&cm.h_rows, cm.hcap_rows * WB_ROW_WIDTH * sizeof(double), hipHostMallocDefault));
-    }
-    if ((size_t)verts > cm.hcap_v) {
-        if (cm.h_px) (void)hipHostFree(cm.h_px);
-        if (cm.h_py) (void)hipHostFree(cm.h_py);
-        cm.h_px = cm.h_py = nullptr; cm.hcap_v = (size_t)verts;
-        WB_HIPC(hipHostMalloc((void**)&cm.h_px, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
-        WB_HIPC(hipHostMalloc((void**)&cm.h_py, cm.hcap_v * sizeof(int32_t), hipHostMallocDefault));
-    }
-    return 0;
+    if (cm.aborted) return wb_fail(ctx, "wb_comm_reserve: the communicator was aborted (wb_comm_abort)");
+    return wb_comm_room(ctx, cm, (size_t)rows, (size_t)verts);
 }
 #undef WB_NCCL_G
 #undef WB_NCCL

@@ -19,6 +19,9 @@
 #if !defined(WB_HOSTSIM)
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
+#include <mutex>
 
 struct WbComm {
     void* lib = nullptr;
@@ -30,7 +33,12 @@ struct WbComm {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
-    bool aborted = false;                 // wb_comm_abort: every later exchange fails at once
+    // wb_comm_abort may come from another host thread than the one inside a gather: `aborted` is checked before every group of
+    // RCCL calls, and `issue` is held while such a group is ENQUEUED (never across a stream wait), so the communicator is not
+    // torn down between two calls that use it; the abort itself waits for `issue` for a bounded time only -- a thread that sits
+    // INSIDE an RCCL call is what ncclCommAbort exists for
+    std::atomic<bool> aborted{false};     // wb_comm_abort: every later exchange fails at once
+    std::timed_mutex issue;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;

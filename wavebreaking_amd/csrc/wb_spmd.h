@@ -292,7 +292,10 @@ __device__ inline int wb_wave_scan_incl(int v) {
 }
 
 // in-place exclusive scan of a[0..n) (global or LDS), all threads of the block call it;
-// returns the total to every thread.  A thread owns 8 consecutive elements of a chunk of 8 * blockDim.x (local prefix,
+// returns the total to every thread.  PRECONDITIONS (the function does not start with a barrier of its own): (1) a[0..n) as the
+// block wrote it is visible to the whole block -- the caller ends a WB_PFOR / WB_SYNC behind its last write to a[] (every caller
+// does); (2) blockDim.x is a multiple of 64: a wave's total is written by its lane 63, a partial last wave would leave its row
+// entry unwritten (every launch that reaches this uses 256, 512 or 1024 threads).  A thread owns 8 consecutive elements of a chunk of 8 * blockDim.x (local prefix,
 // wave scan of the thread sums, running carry): a per-job array of a few thousand entries is two or three chunks, each
 // one memory round trip and three barriers.
 __device__ inline int wb_block_scan_excl(int* a, int n) {

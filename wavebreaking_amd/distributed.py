@@ -233,19 +233,28 @@ class GatherPoisoned(RuntimeError):
     every rank's call for the slot raises this BEFORE the payload is exchanged, so no rank waits for data that never comes"""
 
 
-def _gather_tensors(rows, vx, vy, dist, dst, dev, poison=False):
+class GatherAborted(GatherPoisoned):
+    """some rank took part in the exchange of the counts with -2: it is LEAVING the group (its record failed) and issues no
+    collective after this one.  Every rank sees that in the same exchange and stops issuing collectives as well, so nobody
+    waits for a partner that is gone"""
+
+
+def _gather_tensors(rows, vx, vy, dist, dst, dev, poison=False, leaving=False):
     """the collective part of gather_device_tables on tensors that already exist (inside an _exchange_stream block);
     (rows, vx, vy) numpy arrays on ``dst``, None elsewhere.  ``poison``: this rank has nothing to deliver for the slot
-    (rows / vx / vy may be None): it sends -1 for its counts, and every rank raises GatherPoisoned."""
+    (rows / vx / vy may be None): it sends -1 for its counts, and every rank raises GatherPoisoned.  ``leaving`` (with
+    ``poison``): -2, the rank's last collective -- every rank raises GatherAborted."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    ne, nv = (-1, -1) if poison else (int(rows.shape[0]), int(vx.shape[0]))
+    ne, nv = ((-2, -2) if leaving else (-1, -1)) if poison else (int(rows.shape[0]), int(vx.shape[0]))
     if not poison and dev.type != "cuda":               # dry runs of the N > 1 logic over gloo: CPU tensors
         rows, vx, vy = rows.cpu(), vx.cpu(), vy.cpu()
     counts = torch.tensor([ne, nv], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(allc, counts)
     allc = torch.stack(allc).cpu().numpy()
+    if (allc == -2).any():
+        raise GatherAborted("rank(s) %s left the gather group" % [int(r) for r in np.nonzero((allc == -2).any(axis=1))[0]])
     if (allc < 0).any():
         raise GatherPoisoned("rank(s) %s reported a failure for this slot of the gather" % [int(r) for r in np.nonzero((allc < 0).any(axis=1))[0]])
     me, mv = int(allc[:, 0].max()), int(allc[:, 1].max())
@@ -306,7 +315,7 @@ class TableGatherer:
         self.free = threading.Semaphore(self.nslots)
         self.q = queue.Queue()
         self.results, self.error, self.next_slot = {}, None, 0
-        self.reserved, self.aborted = False, False
+        self.reserved, self.aborted, self.leaving = False, False, False
         self.dev = _device(dist) if comm is None else None
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
@@ -331,7 +340,7 @@ class TableGatherer:
                 item = tuple(t.clone() for t in _batch_tensors(batch, self.dist, False))
         self.q.put((k, item))
 
-    def _gather(self, item, poison):
+    def _gather(self, item, poison, leaving=False):
         if self.comm is not None:
             rows, px, py, seen = self.comm.ctx.comm_gather_staged(-1 if poison else item, self.dst)
             if seen != self.comm.world:
@@ -339,13 +348,22 @@ class TableGatherer:
             return (rows, px, py) if self.comm.rank == self.dst else None
         with _exchange_stream(self.dev):
             if poison:
-                return _gather_tensors(None, None, None, self.dist, self.dst, self.dev, poison=True)
+                return _gather_tensors(None, None, None, self.dist, self.dst, self.dev, poison=True, leaving=leaving)
             return _gather_tensors(item[0], item[1], item[2], self.dist, self.dst, self.dev)
 
     def _run(self):
         while True:
             job = self.q.get()
             if job is None:
+                if self.leaving and not self.aborted:
+                    # abort() on the torch.distributed path (there is no ncclCommAbort to wake the peers): ONE last exchange of
+                    # the counts with -2 behind the slots this rank still owed; the peers' next gather -- whichever slot they
+                    # are at -- raises GatherAborted on all of them at once, and nobody issues a collective after it
+                    try:
+                        self._gather(None, True, leaving=True)
+                    except BaseException:
+                        pass
+                    self.aborted = True
                 return
             k, item = job
             try:
@@ -358,26 +376,36 @@ class TableGatherer:
                     # then waited in ncclAllGather for ever)
                     try:
                         self._gather(item, True)
+                    except GatherAborted:
+                        self.aborted = True                  # a peer has left: no collective after this one
                     except BaseException:
                         pass
+            except GatherAborted as e:
+                self.error, self.aborted = e, True
             except BaseException as e:                       # kept for the caller
                 self.error = e
             finally:
                 self.free.release()
 
     def abort(self, why=None):
-        """the record cannot be finished on this rank (a worker raised): no further collective is issued, the library's
-        communicator is aborted (ncclCommAbort: peers blocked in a collective with this rank get an error instead of
-        waiting for ever), the gather thread is stopped.  The process should end non-zero; a gather group cannot be
-        restarted in place."""
-        self.aborted = True
+        """the record cannot be finished on this rank (a worker raised).  With the library's communicator: no further
+        collective is issued and the communicator is aborted (ncclCommAbort: peers blocked in a collective with this rank get
+        an error instead of waiting for ever; wb_comm_abort is safe beside a gather that is running on the gather thread --
+        the library looks at its `aborted` flag before every group of RCCL calls).  On the torch.distributed path nothing can
+        wake a peer that waits inside a collective, so this rank stays in step instead: the slots it still owes are exchanged
+        as poisoned (-1), then ONE exchange with -2 tells every rank that it is leaving (GatherAborted there; nobody issues a
+        collective after it).  The gather thread is stopped either way.  The process should end non-zero; a gather group
+        cannot be restarted in place."""
         if self.error is None:
             self.error = why if isinstance(why, BaseException) else RuntimeError("TableGatherer aborted: %s" % (why,))
         if self.comm is not None:
+            self.aborted = True
             try:
                 self.comm.ctx.comm_abort()
             except Exception:
                 pass
+        else:
+            self.leaving = True
         self.q.put(None)
         self.thread.join(timeout=30)
 

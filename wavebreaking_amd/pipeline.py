@@ -55,7 +55,7 @@ class BatchPipeline:
         # stagger (set_stagger): which of the two phases of the ABI are entered by one batch at a time.  Default 2: phase 1 (the HBM-bound scan + the trace kernels) is entered by one batch at a time.  Left free, two batches
         # that happen to fall into step -- the same kernel of both at the same time, each on half the device -- stay in step
         # (one run in ten, more often the longer the record: 300-320 k timesteps/s instead of 335-345 k on the bench batch); with
-        # phase 1 exclusive they cannot: 338-345 k in every run (tools/r04_session_s2.sh).  Phase 2 exclusive, or both, cost 5-8 %.
+        # phase 1 exclusive they cannot: 338-345 k in every run (profiles/r04_two_batches_in_step.txt).  Phase 2 exclusive, or both, cost 5-8 %.
         if stagger is None:
             stagger = int(os.environ.get("WB_PIPE_STAGGER", "2"))
         self.default_stagger = int(stagger)
