@@ -7,14 +7,15 @@ overturning and cutoff indices + event tables back in host memory) over ONE resi
 configs[1], 1.0 degree, level [2], the streamer index).  Inputs are generated on the device and are resident in
 HBM when the timed region starts.
 
-WHAT `value` IS: device-resident float32 field batch -> INDEX-SPACE event tables in host memory -- per event its
-step / level / contour, end points or box, orientation, the five area-weighted sums of calculate_properties
-(index_utils.py:66-102), cell count, flags, and the polygon vertices in grid indices (the figure of the earlier rounds).
-`value_with_geometry` (since round 5, timed right behind it): the same passes with the library's default, which also leaves
-the polygons in lon / lat -- transform_polygons with the seam split (index_utils.py:129-184), cut, truncated and mapped by
-the device into pinned host memory (csrc/wb_geom.h).  NOT in either: the upload of the fields over PCIe (`end_to_end`
-measures the drop-in calls from a host cube, upload included), the last few flops of the property columns (:104-120;
-`stage_ms.geometry_host`) and the construction of the (Geo)DataFrame.
+WHAT `value` IS (since round 6): the library's DEFAULT options -- device-resident float32 field batch -> event tables in host
+memory: per event its step / level / contour, end points or box, orientation, the five area-weighted sums of
+calculate_properties (index_utils.py:66-102), cell count, flags and the polygons in lon / lat -- transform_polygons with the
+seam split (index_utils.py:129-184), cut, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h).  The
+polygon vertices in GRID INDICES, which rounds 1-5 also copied to the host in every pass, stay on the device since round 6
+(the reference's frames do not carry them; wb_get_events packs them when asked: context option index_polygons).  `value_without_geometry` (timed right behind it): the same passes with the context
+option geometry = 0, the index-space figure that rounds 1-5 reported as `value`.  NOT in either: the upload of the fields over
+PCIe (`end_to_end` measures the drop-in calls from a host cube, upload included) and the construction of the (Geo)DataFrame;
+`stage_ms.geometry_host` is what the frame's property columns (:104-120) cost on the host per pass.
 
 `--streams` passes (default 2) are in flight per GPU at any time, each on its own context = HIP stream +
 host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.  The K passes are ONE
@@ -172,9 +173,9 @@ def main():
     stage_ms = {}
     counts = {}
     wall = {}
-    # `value` is the index-space figure of the earlier rounds (context option geometry = 0 in the timed region); the same passes WITH
-    # transform_polygons on the device -- the product's default -- are timed right behind it: `value_with_geometry`
-    geometry_on = [os.environ.get("WB_BENCH_GEOMETRY", "0") == "1"]        # (WB_BENCH_GEOMETRY=1: development, the timed region itself with geometry -- profiles of the geometry kernels)
+    # `value` is measured with the library's defaults: transform_polygons on the device included (context option geometry = 1).  The
+    # index-space figure of rounds 1-5 (geometry = 0) is timed right behind it: `value_without_geometry`
+    geometry_on = [os.environ.get("WB_BENCH_GEOMETRY", "1") == "1"]        # (WB_BENCH_GEOMETRY=0: development, the timed region itself without the geometry kernels)
     for c in pipe.contexts:
         c.set_option("geometry", 1 if geometry_on[0] else 0)
 
@@ -193,15 +194,24 @@ def main():
         return wd.global_max_nux(m, dist if multi else None)
 
     def phase2(c, k, b, g, copy=False):
+        """on the worker thread of the pass's context: the index kernels, nothing else (the next pass follows at once)"""
         w1 = time.perf_counter()
         b.set_step_offset(t0)
         b.indices(g, **which)
+        return dict(batch=b, copy=copy, wall=dict(contours_call=b._wall1, indices_call=1e3 * (time.perf_counter() - w1)))
+
+    def read_tables(res):
+        """on the collecting thread, while the workers are in their next passes: the pass's tables -- rows, sums and (library default)
+        the polygons in lon / lat, for which this waits: wb_indices does not (context option geometry_async); the polygon vertices
+        in grid indices only for the comparison with the oracle (copy: wb_get_events packs them then, they stay on the device
+        otherwise) -- its counters and stage times"""
+        b, copy = res["batch"], res["copy"]
         w2 = time.perf_counter()
-        ev = [b.events(i, copy=copy) for i in (0, 1, 2)]          # self-contained: rows, sums, polygon vertices
+        ev = [b.events(i, copy=copy, polygons=copy) for i in (0, 1, 2)]
         geo = [b.event_geometry(i, copy=copy) for i in (0, 1, 2)] if geometry_on[0] else None   # lon / lat rings (transform_polygons), cut and mapped by the device
         w3 = time.perf_counter()
-        res = dict(timings=b.timings(),
-                   counts=dict(polygon_vertices=int(sum(e["poly_x"].size for e in ev)), streamers=int(ev[0]["step"].size),
+        res.update(timings=b.timings(),
+                   counts=dict(polygon_vertices=int(sum(int(e["poly_offset"][-1]) for e in ev if e["poly_offset"].size)), streamers=int(ev[0]["step"].size),
                                overturnings=int(ev[1]["step"].size), cutoffs=int(ev[2]["step"].size),
                                band_hits=b.band_hits(), pair_stats=b.pair_stats(), evaluated_pairs=b.evaluated_pairs(),
                                com_rechecks=b.com_rechecks(), group_ties=b.group_ties(),
@@ -209,31 +219,36 @@ def main():
                                status_or=int(np.bitwise_or.reduce(b.status())) if nt else 0,
                                geometry_rings=int(sum(g[1].size - 1 for g in geo)) if geo else 0,
                                geometry_vertices=int(sum(g[2].size for g in geo)) if geo else 0),
-                   batch=b if multi else None,
                    events=ev if copy else None)
-        if not multi:
-            b.close()
-        res["wall"] = dict(contours_call=b._wall1, indices_call=1e3 * (w2 - w1), tables_call=1e3 * (w3 - w2),
-                           free=1e3 * (time.perf_counter() - w3))
+        res["wall"]["tables_call"] = 1e3 * (w3 - w2)
+        return res
+
+    def finish(res, gatherer=None, k=0):
+        """tables read, batch handed to the gather (N > 1) and freed -- all on the collecting thread (a context's allocators have
+        their own lock: wb_free_batch does not wait for the pass the context's worker is in)"""
+        read_tables(res)
+        w = time.perf_counter()
+        if gatherer is not None:
+            # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there).
+            # Off the critical path: the batch's tables are STAGED (a device-to-device copy of a few MB), the batch is
+            # released, and the gather thread runs the collective while the next batches are computed
+            gatherer.submit(k, res["batch"])
+        res["wall"]["gather"] = 1e3 * (time.perf_counter() - w)
+        w = time.perf_counter()
+        res["batch"].close()
+        res["batch"] = None
+        res["wall"]["free"] = 1e3 * (time.perf_counter() - w)
         return res
 
     def collect_pass(keep, gatherer=None):
         def collect(k, res):
-            w = time.perf_counter()
-            if multi:
-                # exchange (2): packed event rows and polygon vertices, device to device, to rank 0 (complete catalogue there).
-                # Off the critical path: the batch's tables are STAGED (a device-to-device copy of a few MB), the batch is
-                # released, and the gather thread runs the collective while the next batches are computed
-                gatherer.submit(k, res["batch"])
-                pipe.close_batch(k, res["batch"])          # a context is single-threaded: its own worker frees the batch
-                res["batch"] = None
+            finish(res, gatherer, k)
             if keep:
                 for name, ms in res["timings"]:
                     stage_ms.setdefault(name, []).append(ms)
                 counts.update(res["counts"])
                 for kk, v in res["wall"].items():
                     wall.setdefault(kk, []).append(v)
-                wall.setdefault("gather", []).append(1e3 * (time.perf_counter() - w))
             return res
         return collect
 
@@ -265,11 +280,8 @@ def main():
         """a single pass alone on the device"""
         b = phase1(c, 0)
         gmax = reduce_max(b.max_nux())
-        res = phase2(c, 0, b, gmax, copy=copy)
+        res = finish(phase2(c, 0, b, gmax, copy=copy))
         res["gmax"] = gmax
-        if res.get("batch") is not None:                       # N > 1: phase2 leaves the batch open for the gather
-            res["batch"].close()
-            res["batch"] = None
         return res
 
     def one_pass(copy=False):
@@ -301,9 +313,9 @@ def main():
         st_ms = []
 
         def collect_scan(k, res):
-            st_ms.append(dict(res["timings"]).get("scan", float("nan")))
+            st_ms.append(dict(finish(res)["timings"]).get("scan", float("nan")))
             return res
-        pipe.run(3, phase1, reduce_max, phase2, lambda k, res: res, full_width=full_w)
+        pipe.run(3, phase1, reduce_max, phase2, lambda k, res: finish(res), full_width=full_w)
         torch.cuda.synchronize()
         tic_s = time.perf_counter()
         pipe.run(a.stagger_steps, phase1, reduce_max, phase2, collect_scan, full_width=full_w)
@@ -314,30 +326,36 @@ def main():
         staggered = {"value": nt * a.stagger_steps / dt_s, "ms_per_step": 1e3 * dt_s / a.stagger_steps, "steps": a.stagger_steps,
                      "scan_launch_ms": sc, "roofline_frac": nt * nlat * nlon * 4 / (sc * 1e-3) / HBM_PEAK,
                      "what": "BatchPipeline.set_stagger(1): each ABI phase entered by one batch at a time"}
-    # the same passes WITH transform_polygons on the device (context option geometry = 1, the product's default): the events' polygons
-    # in lon / lat, cut at the last meridian, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h)
-    with_geometry = None
+    # the same passes WITHOUT transform_polygons (context option geometry = 0): the index-space tables alone, the figure rounds 1-5
+    # reported as `value`
+    other_geometry = None
+    main_geometry = geometry_on[0]
     if not multi and a.stagger_steps > 0:
-        geometry_on[0] = True
+        geometry_on[0] = not main_geometry
         for c in pipe.contexts:
-            c.set_option("geometry", 1)
+            c.set_option("geometry", 1 if geometry_on[0] else 0)
         run_record(3, False)
         torch.cuda.synchronize()
         main_stage = {k: list(v) for k, v in stage_ms.items()}      # (the timed region's stage times stay what they are)
         main_wall = {k: list(v) for k, v in wall.items()}
         stage_ms.clear()
         tic_g = time.perf_counter()
-        run_record(a.stagger_steps, True)             # (kept: its stage times carry the geometry kernels, its counts the rings)
+        main_counts = dict(counts)
+        run_record(a.stagger_steps, True)
         torch.cuda.synchronize()
         dt_g = time.perf_counter() - tic_g
         geo_stage = {k: float(np.mean(v)) for k, v in stage_ms.items()}
         stage_ms.clear(); stage_ms.update(main_stage)
         wall.clear(); wall.update(main_wall)
-        with_geometry = {"value": nt * a.stagger_steps / dt_g, "ms_per_step": 1e3 * dt_g / a.stagger_steps, "steps": a.stagger_steps,
-                         "rings": counts.get("geometry_rings"), "vertices": counts.get("geometry_vertices"),
-                         "stage_ms": {k: geo_stage.get(k) for k in ("polygons", "geometry", "props", "results") if k in geo_stage},
-                         "what": "context option geometry = 1 (the library's default): wb_indices also leaves the events' lon / lat rings "
-                                 "(transform_polygons, index_utils.py:129-184) in pinned host memory"}
+        counts.clear(); counts.update(main_counts)
+        other_geometry = {"value": nt * a.stagger_steps / dt_g, "ms_per_step": 1e3 * dt_g / a.stagger_steps, "steps": a.stagger_steps,
+                          "geometry": int(geometry_on[0]),
+                          "stage_ms": {k: geo_stage.get(k) for k in ("polygons", "geometry", "props", "results") if k in geo_stage},
+                          "what": "the same passes with the context option geometry = %d%s" % (int(geometry_on[0]),
+                                  "" if geometry_on[0] else ": index-space event tables only, no lon / lat rings (what rounds 1-5 reported as `value`)")}
+        geometry_on[0] = main_geometry
+        for c in pipe.contexts:
+            c.set_option("geometry", 1 if main_geometry else 0)
     # outside `value`, for the record: what transform_polygons (index_utils.py:129-184) and the frame's property columns
     # (:104-120) cost per pass on the host -- one wb_get_event_geometry per index (the library's C++ seam split over the whole
     # table) + properties_from_sums, timed on this thread after the timed region
@@ -349,7 +367,7 @@ def main():
         tic_g = time.perf_counter()
         nrings = 0
         for kind in (0, 1, 2):
-            ev_k = b.events(kind, copy=False)
+            ev_k = b.events(kind, copy=False, polygons=False)
             if ev_k["step"].size:
                 ring_off, vert_off, gx, gy = b.event_geometry(kind, copy=False)
                 nrings += int(vert_off.size) - 1
@@ -422,18 +440,20 @@ def main():
         if geometry_host is not None:
             out["stage_ms"]["geometry_host"] = geometry_host["ms"]
             out["geometry_host"] = geometry_host
-        if with_geometry is not None:
-            out["value_with_geometry"] = with_geometry["value"]
-            out["with_geometry"] = with_geometry
-            out["geometry_adds_ms_per_step"] = with_geometry["ms_per_step"] - out["ms_per_step"]
-        out["value_is"] = ("device-resident f32 field batch -> index-space event tables of all requested indices in host memory (rows: step, "
-                           "level, contour, end points or box, orientation; the five area-weighted sums; cell counts; flags; polygon vertices "
-                           "in grid indices) -- the figure of the earlier rounds.  `value_with_geometry`: the same passes with the library's "
-                           "default (context option geometry = 1): additionally the events' polygons in lon / lat -- transform_polygons, "
-                           "index_utils.py:129-184: cut at the last meridian, truncated and mapped by the device into pinned host memory "
-                           "(csrc/wb_geom.h).  NOT included in either: the upload of the fields (end_to_end has it), the last flops of the "
-                           "frame's property columns (stage_ms.geometry_host: the views of the rings + properties_from_sums, host) and "
-                           "frame construction")
+        out["geometry"] = int(main_geometry)
+        if other_geometry is not None:
+            key = "value_without_geometry" if main_geometry else "value_with_geometry"
+            out[key] = other_geometry["value"]
+            out[key.replace("value_", "")] = other_geometry
+            out["geometry_adds_ms_per_step"] = (out["ms_per_step"] - other_geometry["ms_per_step"]) if main_geometry else (other_geometry["ms_per_step"] - out["ms_per_step"])
+        out["value_is"] = ("the library's defaults (context option geometry = %d): device-resident f32 field batch -> event tables of all requested "
+                           "indices in host memory (rows: step, level, contour, end points or box, orientation; the five area-weighted sums; cell "
+                           "counts; flags; the polygon vertices in grid indices stay on the device -- context option index_polygons = 0 -- and are packed "
+                           "when wb_get_events asks)%s.  NOT included: the upload of the fields (end_to_end has it) and "
+                           "frame construction; stage_ms.geometry_host is the host's part of the frame's property columns per pass"
+                           % (int(main_geometry), " AND the events' polygons in lon / lat -- transform_polygons, index_utils.py:129-184: cut at the last "
+                              "meridian, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h); `value_without_geometry`: the "
+                              "same passes with geometry = 0, the figure rounds 1-5 reported as `value`" if main_geometry else ""))
         if world == 1 and a.e2e_steps > 0 and a.config == 2:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:

@@ -136,7 +136,10 @@ int wb_indices(wb_batch* b, int global_max_nux, int which);
    (lon[x % nlon], lat[y]); an event that reaches the periodic columns is cut at the last meridian into several rings
    (:148-173).  Event k owns rings ring_offset[k] .. ring_offset[k+1] (none: empty polygon, one: Polygon, several:
    MultiPolygon), ring q the vertices vert_offset[q] .. vert_offset[q+1] (not repeated at the end).  Same layout as the
-   input of wb_flag_events. */
+   input of wb_flag_events.  With the context options "geometry" and "geometry_async" (both 1 by default) the device cuts and maps
+   the rings during wb_indices into pinned host memory, and wb_indices does NOT wait for those kernels -- they are PCIe-bound
+   (27 MB of doubles per year of 0.25 degree) and finish beside the next pass's field scan: wb_get_event_geometry waits for them
+   (so do wb_free_batch and the batch's next wb_indices). */
 typedef struct wb_geometry {
     int64_t n;
     const int64_t* ring_offset;
@@ -159,7 +162,18 @@ int wb_transform_polygons(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, co
 int wb_transform_polygons_device(wb_ctx* ctx, int64_t n, const int64_t* poly_offset, const int32_t* px, const int32_t* py,
                                  const double* lon, const double* lat, int nlon, int nlat, int index_space, wb_geometry* out);
 int wb_get_contours(wb_batch* b, wb_contour_table* out);
+/* The event table of one index.  wb_get_events: complete, including the polygons in grid indices (poly_x / poly_y).  Since round 6
+   wb_indices leaves those on the device as descriptors + contours (context option "index_polygons" 0, the default; 1: it packs
+   them into pinned host memory itself, 13.5 MB per year of 0.25 degree over PCIe): the first wb_get_events of a pass then packs them
+   -- it launches a kernel and waits, so it belongs to the thread that drives the context.  wb_get_event_rows: everything but the
+   vertices (poly_x = poly_y = NULL; poly_offset still holds the vertex counts) -- what a caller needs who takes the polygons in
+   lon / lat from wb_get_event_geometry, as the drop-in functions do (the reference's frames carry no index polygons,
+   index_utils.py:129-184); it launches nothing and may be called from any thread.
+   Threads: a context is DRIVEN by one thread (wb_contours, wb_indices, pass after pass).  A second thread may, at the same time,
+   read a finished batch (wb_get_event_rows, wb_get_event_geometry, wb_get_status, the counters) and free it (wb_free_batch) while
+   the driving thread is already in the next pass: the calls that launch take the context's lock, the allocators have their own. */
 int wb_get_events(wb_batch* b, int kind, wb_event_table* out);
+int wb_get_event_rows(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */
 int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont);            /* threshold guard-band re-evaluations */
 /* calculate_properties truncates x_com / areas and y_com / areas (index_utils.py:105-110); events whose quotient lies

@@ -7,6 +7,7 @@ import numpy as np
 
 from oracle import api as oapi
 from oracle import contours as ocont
+from oracle import synth
 from wavebreaking_amd import _hip
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -429,3 +430,45 @@ def reference_rules_case(ctx, golden_dir):
         assert cut["contour"].tolist() == g[key + "__cutoffs"].tolist(), key
         nframes += 1
     return ncont, nbox, nframes
+
+
+def check_deferred_results(ctx, nt=6, dlon=1.0):
+    """What wb_indices leaves unfinished on purpose since round 6: the geometry kernels are not waited for (context option
+    geometry_async: wb_get_event_geometry waits) and the polygons in grid indices stay on the device (index_polygons = 0:
+    wb_get_events packs them, wb_get_event_rows never does).  Every combination of the two options gives the same tables, rings
+    and polygons; the rows-only table differs from the full one in the vertices alone; a batch freed with its geometry still in
+    flight and a second wb_indices on a batch whose first geometry nobody asked for are safe."""
+    lat, lon = synth.grid(dlon)
+    pv = synth.pv_field(30, nt, lat, lon, eps=0.2)
+    out = {}
+    try:
+        for ga, ip in ((1, 0), (0, 0), (1, 1), (0, 1)):
+            ctx.set_option("geometry_async", ga)
+            ctx.set_option("index_polygons", ip)
+            b = ctx.contours(pv, lat, lon, [-2.0, 2.0], dlon, dlon, periodic_add=120.0, intensity=pv)
+            b.indices()
+            rows = [b.events(k, polygons=False) for k in (0, 1, 2)]                # first: nothing packed yet when ip == 0
+            geo = [b.event_geometry(k) for k in (0, 1, 2)]
+            full = [b.events(k) for k in (0, 1, 2)]
+            out[(ga, ip)] = (rows, geo, full)
+            b.indices(cutoffs=False)                                               # again on the same batch: the first call's leftovers are settled
+            again = [b.events(k) for k in (0, 1, 2)]
+            assert again[2]["step"].size == 0 and np.array_equal(again[0]["poly_x"], full[0]["poly_x"])
+            b.indices()                                                            # geometry in flight, nobody asks: close() waits
+            b.close()
+    finally:
+        ctx.set_option("geometry_async", 1)
+        ctx.set_option("index_polygons", 0)
+    ref_rows, ref_geo, ref_full = out[(0, 1)]
+    assert sum(r["step"].size for r in ref_rows) > 10
+    for key, (rows, geo, full) in out.items():
+        for k in (0, 1, 2):
+            for col in ref_full[k]:
+                assert np.array_equal(full[k][col], ref_full[k][col]), (key, k, col)
+                if col in ("poly_x", "poly_y"):
+                    assert rows[k][col].size == 0
+                else:
+                    assert np.array_equal(rows[k][col], ref_full[k][col]), (key, k, col)
+            for a, c in zip(geo[k], ref_geo[k]):
+                assert np.array_equal(a, c), (key, k)
+    return out

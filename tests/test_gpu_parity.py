@@ -376,3 +376,9 @@ def test_device_geometry_equals_host_geometry(ctx):
         ro = np.asarray(rings[1][kind][0])
         nsplit += int((np.diff(ro) != 1).sum())
     assert sum(len(np.asarray(r[0])) for r in rings[1]) > 60 and nsplit > 0
+
+
+def test_rows_without_vertices_lazy_polygons_and_deferred_geometry(ctx):
+    """the same on the device, where the geometry kernels really are in flight when wb_indices returns"""
+    helpers.check_deferred_results(ctx, nt=8)
+    helpers.check_deferred_results(ctx, nt=4, dlon=0.25)

@@ -523,3 +523,9 @@ def test_two_kernel_scan_simulation_equals_the_single_scan(sim, bands):
     assert np.array_equal(sa, sb) and ta["step"].size > 6
     for key in ta:
         assert np.array_equal(ta[key], tb[key]), key
+
+
+def test_rows_without_vertices_lazy_polygons_and_deferred_geometry(sim):
+    lib, ctx = sim
+    lib.lib.wb_hostsim_set_reverse(0)
+    helpers.check_deferred_results(ctx, nt=3)

@@ -95,6 +95,7 @@ class Library:
         lib.wb_indices.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.wb_get_contours.argtypes = [C.c_void_p, C.POINTER(WbContourTable)]
         lib.wb_get_events.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbEventTable)]
+        lib.wb_get_event_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbEventTable)]
         lib.wb_get_event_geometry.argtypes = [C.c_void_p, C.c_int, C.POINTER(WbGeometry)]
         lib.wb_transform_polygons.argtypes = [C.c_void_p, C.c_int64, i64p, i32p, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                               C.c_int, C.c_int, C.POINTER(WbGeometry)]
@@ -682,11 +683,15 @@ class Batch:
                     sum_y=_arr(t.sum_y, n, np.int64), npts=_arr(t.npts, n, np.int32), offset=_arr(t.offset, n, np.int64),
                     x=_arr(t.x, m, np.int32), y=_arr(t.y, m, np.int32))
 
-    def events(self, kind, copy=True):
+    def events(self, kind, copy=True, polygons=True):
         """Event table of one index.  ``copy=False`` hands out views of the library's host tables (valid until the
-        batch is closed or ``indices`` runs again) instead of private copies."""
+        batch is closed or ``indices`` runs again) instead of private copies.  ``polygons=False``: without the polygon
+        vertices in grid indices (``poly_x`` / ``poly_y`` empty, ``poly_offset`` still the vertex counts) -- what a caller
+        wants who takes the polygons in lon / lat from ``event_geometry``: ``indices`` leaves the index polygons on the device,
+        and asking for them (the default here) packs them into host memory first (wb_get_events / wb_get_event_rows)."""
         t = WbEventTable()
-        if self.ctx.L.lib.wb_get_events(self.h, int(kind), C.byref(t)) != 0:
+        get = self.ctx.L.lib.wb_get_events if polygons else self.ctx.L.lib.wb_get_event_rows
+        if get(self.h, int(kind), C.byref(t)) != 0:
             raise RuntimeError("wb_get_events failed: " + self.ctx.error())
         n = t.n
         A = lambda p, m, dt: _arr(p, m, dt, copy)
@@ -697,8 +702,8 @@ class Batch:
                    flags=A(t.flags, n, np.int32))
         poff = A(t.poly_offset, n + 1, np.int64)
         out["poly_offset"] = poff
-        out["poly_x"] = A(t.poly_x, poff[-1] if n else 0, np.int32)
-        out["poly_y"] = A(t.poly_y, poff[-1] if n else 0, np.int32)
+        out["poly_x"] = A(t.poly_x, poff[-1] if (n and polygons) else 0, np.int32)
+        out["poly_y"] = A(t.poly_y, poff[-1] if (n and polygons) else 0, np.int32)
         if self.want_cells and t.cell_offset:
             off = A(t.cell_offset, n + 1, np.int64)
             out["cell_offset"] = off

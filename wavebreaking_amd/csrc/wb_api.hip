@@ -87,12 +87,27 @@ struct wb_batch {
     std::vector<std::pair<void*, size_t>> gres;
     long long* g_ring_offset = nullptr; long long* g_vert_offset = nullptr; double* g_x = nullptr; double* g_y = nullptr;
     long long g_rings = -1, g_verts = 0;            // -1: not there (option off, or an event the kernel flagged: host function)
+    // the last wb_indices' event descriptors and polygon offsets stay on the device: index polygons are packed when wb_get_events
+    // first asks for them (context option index_polygons = 0), the geometry kernels may still be reading them (geometry_async)
+    int* d_ev = nullptr; long long* d_poff = nullptr;
+    int d_ev_cap_seg = 0;
+    // geometry kernels wb_indices did not wait for: their event, their totals in pinned memory, their scratch
+    bool g_pending = false;
+    long long* g_tot = nullptr;                     // [4] rings, vertices, overflow, flagged (inside the ring_offset block)
+    long long g_cap_r = 0, g_cap_v = 0;
+    int *g_cnt_r = nullptr, *g_cnt_v = nullptr, *g_flag = nullptr;
+#if !defined(WB_HOSTSIM)
+    hipEvent_t g_event = nullptr;
+#endif
     int32_t *poly_x = nullptr, *poly_y = nullptr;   // polygon vertices of all events (streamers, overturnings, cutoffs)
     size_t poly_n = 0, poly_bytes = 0;
     WbTimer timer;
     size_t timer_phase1 = 0;                // stages recorded by wb_contours
     std::string timer_names;
 };
+
+static int wb_geom_settle(wb_batch* b);        // (defined in front of wb_indices)
+static int wb_pack_polys_now(wb_batch* b);
 
 #ifndef WB_LIST_THREADS
 #define WB_LIST_THREADS 256          // single-workgroup list / offset kernels
@@ -256,6 +271,12 @@ void wb_free_batch(wb_batch* b) {
     if (!b) return;
     wb_use(b->ctx);
     double wb_t0_ = wb_now_ms();
+#if !defined(WB_HOSTSIM)
+    // (may be called by another thread than the one that drives the context: it takes the allocators' lock only.  Geometry
+    // kernels that nobody has waited for yet still read the batch's contours and write its pinned arrays)
+    if (b->g_event) { if (b->g_pending) (void)hipEventSynchronize(b->g_event); (void)hipEventDestroy(b->g_event); b->g_event = nullptr; }
+#endif
+    b->g_pending = false;
     for (void* p : b->owned) dfree(b->ctx, p);
     hfree(b->ctx, b->poly_x, b->poly_bytes);
     hfree(b->ctx, b->poly_y, b->poly_bytes);
@@ -607,6 +628,7 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
     if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
     const int W = p.nlon + padd;
     if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large: nlon + periodic columns <= 4096, nlat <= 32767");
+    std::lock_guard<std::recursive_mutex> wb_lk_(ctx->mu);
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     wb_batch* b = new wb_batch();
     b->ctx = ctx;
@@ -731,6 +753,8 @@ extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* can
 }
 extern "C" int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* o) {
     if (!b || !o || kind < 0 || kind > 2) return 1;
+    wb_use(b->ctx);
+    if (wb_geom_settle(b)) return 1;              // geometry kernels wb_indices did not wait for (context option geometry_async)
     wb_batch::Ev& t = b->ev[kind];
     WbRingSink& g = b->geo[kind];
     g = WbRingSink();
@@ -755,6 +779,9 @@ extern "C" int wb_get_event_geometry(wb_batch* b, int kind, wb_geometry* o) {
         o->y = b->g_y + v0;
         return 0;
     }
+    // the host function (option "geometry" off, or a pass the device's arrays did not hold / an event its kernel flagged): from the
+    // polygons in grid indices
+    if (n > 0 && !b->poly_x && b->poly_n > 0 && wb_pack_polys_now(b)) return 1;
     g.ring_offset.push_back(0);
     g.vert_offset.push_back(0);
     for (int64_t k = 0; k < n; ++k) {
@@ -1180,12 +1207,11 @@ WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const l
         const size_t jb = (size_t)d[1] * cap_seg;
         const uint32_t* pts = cpts + 2 * jb + c_off[jb + d[2]];
         const int n = (int)(poff[e + 1] - poff[e]);
-        int* dx = out_x + poff[e];
-        int* dy = out_y + poff[e];
+        int* dx = out_x ? out_x + poff[e] : nullptr;          // (NULL: the device copies only -- a gather's)
+        int* dy = out_x ? out_y + poff[e] : nullptr;
         WB_PFOR(k, n)
             const uint32_t v = wb_event_vertex(d, pts, (int)k);
-            dx[k] = wb_pt_x(v);
-            dy[k] = wb_pt_y(v);
+            if (dx) { dx[k] = wb_pt_x(v); dy[k] = wb_pt_y(v); }
             if (dev_x) { dev_x[poff[e] + k] = wb_pt_x(v); dev_y[poff[e] + k] = wb_pt_y(v); }
         WB_END_PFOR
     }
@@ -1364,12 +1390,59 @@ static wb_ctx::Tables* make_tables(wb_batch* b) {
 // allocations come from the phase-1 bounds, capacities that turn out too small are reported through the control block
 // and the whole phase is repeated with room to spare (rare).  The host waits twice: for the first control-block snapshot
 // (event and vertex counts -> sizes of the result copies) while the property kernel is still running, and for the end.
+
+// ---- what the last wb_indices left unfinished on purpose
+// the geometry kernels nobody has waited for yet (context option geometry_async): wait, judge the pass from the totals they left in
+// pinned memory, free their scratch.  An overflow of the pinned arrays -- they are sized from the largest pass the context has
+// seen -- or an event with more cut edges than the kernel holds leaves g_rings = -1: wb_get_event_geometry then runs the host
+// function (wb_geometry.h), as it does with the option "geometry" off.
+static int wb_geom_settle(wb_batch* b) {
+    if (!b->g_pending) return 0;
+    wb_ctx* ctx = b->ctx;
+    b->g_pending = false;
+#if !defined(WB_HOSTSIM)
+    if (b->g_event && hipEventSynchronize(b->g_event) != hipSuccess) return wb_fail(ctx, "wb_indices: the geometry kernels failed");
+#endif
+    bfree_one(b, b->g_cnt_r); bfree_one(b, b->g_cnt_v); bfree_one(b, b->g_flag);
+    b->g_cnt_r = b->g_cnt_v = b->g_flag = nullptr;
+    const long long NR = b->g_tot[0], NV = b->g_tot[1], over = b->g_tot[2], flagged = b->g_tot[3];
+    if (NR < 0 || NV < 0) return wb_fail(ctx, "wb_indices: the geometry kernels left no totals");
+    if (NV > ctx->geom_seen) ctx->geom_seen = NV;
+    if (NR > ctx->geom_rings_seen) ctx->geom_rings_seen = NR;
+    if (over || flagged || NR > b->g_cap_r || NV > b->g_cap_v) {
+        b->g_rings = -1;                                  // the host function, on demand
+        for (auto& hb : b->gres) hfree(ctx, hb.first, hb.second);
+        b->gres.clear();
+        b->g_ring_offset = b->g_vert_offset = nullptr; b->g_x = b->g_y = nullptr; b->g_tot = nullptr;
+        return 0;
+    }
+    b->g_rings = NR; b->g_verts = NV;
+    return 0;
+}
+// the events' polygons in grid indices, packed into pinned host memory now (context option index_polygons = 0: wb_indices left
+// them on the device as descriptors + contours).  Launches on the context's stream and waits: the context's lock is taken.
+static int wb_pack_polys_now(wb_batch* b) {
+    if (b->poly_x || !b->d_ev || !b->d_poff) return 0;
+    wb_ctx* ctx = b->ctx;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
+    b->poly_x = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
+    b->poly_y = (int32_t*)hmalloc(ctx, (b->poly_n + 1) * sizeof(int32_t), &b->poly_bytes);
+    if (!b->poly_x || !b->poly_y) return wb_fail(ctx, "out of host memory");
+    WB_LAUNCH(wb_k_pack_polys, ctx->polys_grid, 256, b->d_ctl, b->d_ev_cap_seg, b->d_ev, b->d_poff, b->c_off, b->cpts, b->poly_x, b->poly_y, (int*)nullptr, (int*)nullptr);
+    return dsync(ctx);
+}
+
 extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     if (!b) return 1;
     wb_ctx* ctx = b->ctx;
     const wb_params& p = b->p;
     const int J = b->njobs, cap = b->cap_seg;
+    std::lock_guard<std::recursive_mutex> wb_lk_(ctx->mu);
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
+    // what an earlier call on this batch left behind: geometry kernels still in flight, descriptors kept for them / for the polygons
+    if (wb_geom_settle(b)) return 1;
+    if (b->d_ev) { bfree_one(b, b->d_ev); bfree_one(b, b->d_poff); b->d_ev = nullptr; b->d_poff = nullptr; }
     wb_ctx::Tables* T = make_tables(b);
     if (!T) return wb_fail(ctx, "out of memory (tables)");
     const WbCtl& h1 = b->h_ctl;                 // phase-1 summary
@@ -1400,7 +1473,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     b->gres.clear();
     b->g_rings = -1;
     long long cap_gv = std::min<long long>(cap_poly + cap_poly / 8 + 1024, std::max<long long>(ctx->geom_seen + ctx->geom_seen / 4 + 4096, 1LL << 21));
-    long long cap_gr = (long long)cap_ne + cap_ne / 4 + 1024;
+    long long cap_gr = std::max<long long>((long long)cap_ne + cap_ne / 4 + 1024, ctx->geom_rings_seen + ctx->geom_rings_seen / 4 + 1024);
 
     WbCtl fin;
     memset(&fin, 0, sizeof(fin));
@@ -1680,11 +1753,16 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         // sized for the capacity -- the counts are only known on the device), properties on the main one; then ONE kernel
         // writes the control block and the event tables into a pinned host block, and the host waits ONCE
         size_t got = 0;
-        b->poly_x = (int32_t*)hmalloc(ctx, (size_t)(cap_poly + 1) * sizeof(int32_t), &b->poly_bytes);
-        b->poly_y = (int32_t*)hmalloc(ctx, (size_t)(cap_poly + 1) * sizeof(int32_t), &b->poly_bytes);
+        // index polygons: packed now into pinned host memory (context option index_polygons = 1, or the device copies a gather
+        // wants), or left as descriptors + contours on the device until wb_get_events asks for them (the default)
+        const bool polys_now = ctx->index_polygons != 0;
+        if (polys_now) {
+            b->poly_x = (int32_t*)hmalloc(ctx, (size_t)(cap_poly + 1) * sizeof(int32_t), &b->poly_bytes);
+            b->poly_y = (int32_t*)hmalloc(ctx, (size_t)(cap_poly + 1) * sizeof(int32_t), &b->poly_bytes);
+        }
         void* hblock = hmalloc(ctx, wb_result_block_bytes((size_t)cap_ne, p.want_cells != 0), &got);
         if (hblock) b->hres.push_back({hblock, got});
-        if (!hblock || !b->poly_x || !b->poly_y) { release(); return wb_fail(ctx, "out of host memory"); }
+        if (!hblock || (polys_now && (!b->poly_x || !b->poly_y))) { release(); return wb_fail(ctx, "out of host memory"); }
         const WbResultBlock rb = wb_result_block(hblock, (size_t)cap_ne, p.want_cells != 0);
         int *d_px = nullptr, *d_py = nullptr;
         if (ctx->keep_device) {                                // device copies of the vertices for the gather
@@ -1697,6 +1775,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         WbGeomArgs ga;
         memset(&ga, 0, sizeof(ga));
         const bool do_geom = ctx->geometry != 0;
+        const bool geom_async = do_geom && ctx->geometry_async != 0;
         if (do_geom) {
             if (cap_gr < (long long)cap_ne + 16) cap_gr = (long long)cap_ne + cap_ne / 4 + 1024;
             ga.nev = -1; ga.ctl = ctl; ga.ctl_out = ctl; ga.cap_seg = cap; ga.nlon = p.nlon; ga.index_space = 0;
@@ -1707,28 +1786,46 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             ga.cap_r = cap_gr; ga.cap_v = cap_gv;
             size_t gg = 0;
             auto gbuf = [&](size_t bytes) -> void* { void* q = hmalloc(ctx, bytes ? bytes : 8, &gg); if (q) b->gres.push_back({q, gg}); return q; };
-            ga.ring_offset = (long long*)gbuf((size_t)(cap_ne + 2) * sizeof(long long));
+            ga.ring_offset = (long long*)gbuf((size_t)(cap_ne + 2 + 8) * sizeof(long long));      // (+ the pass's four totals behind the offsets)
             ga.vert_offset = (long long*)gbuf((size_t)(cap_gr + 2) * sizeof(long long));
             ga.x = (double*)gbuf((size_t)(cap_gv + 2) * sizeof(double));
             ga.y = (double*)gbuf((size_t)(cap_gv + 2) * sizeof(double));
             if (!ga.gflag || !ga.cnt_v || !ga.y || !ga.x || !ga.vert_offset || !ga.ring_offset) { release(); return wb_fail(ctx, "out of memory (event geometry)"); }
+            ga.tot_out = ga.ring_offset + (cap_ne + 2) + 2;
+            for (int q = 0; q < 4; ++q) ga.tot_out[q] = -1;
         }
-        side_begin(ctx);
-        b->timer.begin(ctx, "polygons");
-        WB_LAUNCH(wb_k_pack_polys, ctx->polys_grid, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, b->poly_x, b->poly_y, d_px, d_py);
-        b->timer.end(ctx);
-        if (do_geom) {
+        auto launch_geometry = [&]() {
             b->timer.begin(ctx, "geometry");
             WB_LAUNCH(wb_k_geom_count, ctx->polys_grid, WB_GEOM_THREADS, ga);
             WB_LAUNCH(wb_k_geom_offsets, 1, WB_LIST_THREADS, ga);
             WB_LAUNCH(wb_k_geom_fill, ctx->polys_grid, WB_GEOM_THREADS, ga);
             b->timer.end(ctx);
+        };
+        side_begin(ctx);
+        if (polys_now || d_px) {
+            b->timer.begin(ctx, "polygons");
+            WB_LAUNCH(wb_k_pack_polys, ctx->polys_grid, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, b->poly_x, b->poly_y, d_px, d_py);
+            b->timer.end(ctx);
         }
+        if (do_geom && !geom_async) launch_geometry();
         side_end(ctx);
+        if (geom_async) {
+            // the geometry kernels write 27 MB of doubles per year of 0.25 degree over PCIe (0.5 ms) and nothing on the device reads
+            // them: nobody waits for them here -- neither the main stream nor the host.  They finish beside whatever the device runs
+            // next (the next pass's HBM-bound field scan), and wb_get_event_geometry / wb_free_batch / the batch's next wb_indices wait
+            // for the event recorded behind them (wb_geom_settle)
+            side_begin(ctx);
+            launch_geometry();
+#if !defined(WB_HOSTSIM)
+            if (!b->g_event) (void)hipEventCreateWithFlags(&b->g_event, hipEventDisableTiming);
+            if (b->g_event) (void)hipEventRecord(b->g_event, ctx->stream);
+#endif
+            side_leave(ctx);
+        }
         b->timer.begin(ctx, "props");
         WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
         b->timer.end(ctx);
-        side_join(ctx);                                        // (the control block carries the geometry's totals)
+        side_join(ctx);                                        // (the vertices; synchronous geometry: the control block carries its totals)
         b->timer.begin(ctx, "results");
         WB_LAUNCH(wb_k_pack_results, cap_ne < 64 * 256 ? (cap_ne + 255) / 256 + 1 : 64, 256, ctl, fa.ev, fa.poff, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
                   pa.ev_cell_off, rb);
@@ -1743,17 +1840,20 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
                       fa.poff, b->d_job_step, b->d_job_level, p.nlevels, b->step_offset, b->dev_rows);
         }
         side_join(ctx);
-        if (dsync(ctx) || side_sync(ctx)) { release(); return 1; }
+        if (dsync(ctx) || (!geom_async && side_sync(ctx))) { release(); return 1; }
         fin = *rb.ctl;
         bool again = false;
         if (do_st && fin.max_pairs > cap_pairs) { cap_pairs = next_pow2((long long)fin.max_pairs + fin.max_pairs / 8); again = true; }
         if (do_st && fin.n_recheck > 65536) { p2_off = true; again = true; }    // more guard-band pairs than the recheck list holds: tiled kernel
         if (fin.overflow & 1) { cap_ne = next_pow2((long long)fin.ne_demand + fin.ne_demand / 4); again = true; }
         if (fin.overflow & 2) { cap_poly = fin.poly_total + fin.poly_total / 8 + 1024; again = true; }
-        if (do_geom && (fin.overflow & 4)) { cap_gv = (long long)fin.geom_verts + fin.geom_verts / 8 + 1024; cap_gr = (long long)fin.geom_rings + fin.geom_rings / 8 + 1024; again = true; }
+        if (do_geom && !geom_async && (fin.overflow & 4)) { cap_gv = (long long)fin.geom_verts + fin.geom_verts / 8 + 1024; cap_gr = (long long)fin.geom_rings + fin.geom_rings / 8 + 1024; again = true; }
         const bool other = again;
         if (p.want_cells && !again && fin.cell_count > cell_cap) { cell_cap = fin.cell_count + 1024; again = true; }   // cell pool too small: again with the exact size
         if (again) {
+#if !defined(WB_HOSTSIM)
+            if (geom_async && b->g_event) (void)hipEventSynchronize(b->g_event);      // (they read this attempt's descriptors and write its arrays)
+#endif
             hfree(ctx, b->poly_x, b->poly_bytes);
             hfree(ctx, b->poly_y, b->poly_bytes);
             b->poly_x = b->poly_y = nullptr;
@@ -1770,11 +1870,24 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const int NE = fin.NE;
         const long long NV = fin.poly_total;
         b->poly_n = (size_t)NV;
-        if (do_geom && fin.geom_flagged == 0) {
+        auto keep = [&](void* q) { for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == q) { tmp.erase(tmp.begin() + i); break; } };
+        if (do_geom && !geom_async && fin.geom_flagged == 0) {
             b->g_ring_offset = ga.ring_offset; b->g_vert_offset = ga.vert_offset; b->g_x = ga.x; b->g_y = ga.y;
             b->g_rings = fin.geom_rings; b->g_verts = fin.geom_verts;
             if (fin.geom_verts > ctx->geom_seen) ctx->geom_seen = fin.geom_verts;
+            if (fin.geom_rings > ctx->geom_rings_seen) ctx->geom_rings_seen = fin.geom_rings;
         }
+        if (geom_async) {
+            // still running, perhaps: judged when somebody asks (wb_geom_settle); the arrays they use leave this attempt's scratch
+            b->g_pending = true;
+            b->g_ring_offset = ga.ring_offset; b->g_vert_offset = ga.vert_offset; b->g_x = ga.x; b->g_y = ga.y; b->g_tot = ga.tot_out;
+            b->g_cap_r = cap_gr; b->g_cap_v = cap_gv;
+            b->g_cnt_r = ga.cnt_r; b->g_cnt_v = ga.cnt_v; b->g_flag = ga.gflag;
+            keep(ga.cnt_r); keep(ga.cnt_v); keep(ga.gflag);
+        }
+        // the descriptors and polygon offsets stay on the device (lazy index polygons, the geometry kernels)
+        b->d_ev = fa.ev; b->d_poff = fa.poff; b->d_ev_cap_seg = cap;
+        keep(fa.ev); keep(fa.poff);
         h_ev = rb.ev; h_poff = rb.poff; h_sums = rb.sums; h_nc = rb.ncells; h_fl = rb.flags; h_coff = rb.cell_off;
         if (ctx->keep_device) {
             b->dev_px = d_px; b->dev_py = d_py;
@@ -1860,12 +1973,13 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     // the small pinned result blocks go back to the context's pool
     for (auto& hb : b->hres) hfree(ctx, hb.first, hb.second);
     b->hres.clear();
-    b->timer.collect();
+    b->timer.collect(!b->g_pending);          // (geometry kernels nobody waits for: their stage is collected by wb_get_timings)
     return 0;
 }
 
-extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
+static int wb_event_rows(wb_batch* b, int kind, wb_event_table* o, bool polygons) {
     if (!b || !o || kind < 0 || kind > 2) return 1;
+    if (polygons && !b->poly_x && b->poly_n > 0 && wb_pack_polys_now(b)) return 1;
     wb_batch::Ev& t = b->ev[kind];
     o->n = (int64_t)t.step.size();
     o->step = t.step.data(); o->level_idx = t.level.data(); o->contour = t.contour.data();
@@ -1874,9 +1988,17 @@ extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) {
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
     if (t.polyoff.empty()) t.polyoff.push_back(0);
-    o->poly_offset = t.polyoff.data(); o->poly_x = b->poly_x ? b->poly_x + t.pbase : nullptr; o->poly_y = b->poly_y ? b->poly_y + t.pbase : nullptr;
+    o->poly_offset = t.polyoff.data();
+    o->poly_x = (polygons && b->poly_x) ? b->poly_x + t.pbase : nullptr; o->poly_y = (polygons && b->poly_y) ? b->poly_y + t.pbase : nullptr;
     return 0;
 }
+// the event table of one index.  wb_get_events: with the polygons in grid indices -- packed into pinned host memory by this call if
+// wb_indices left them on the device (context option index_polygons = 0, the default: it then launches a kernel and waits, so it
+// belongs to the thread that drives the context or to a moment when no pass runs on it).  wb_get_event_rows: everything but
+// the vertices (poly_x = poly_y = NULL, poly_offset still holds the vertex counts): what a caller needs who takes the
+// polygons in lon / lat from wb_get_event_geometry -- never launches, any thread.
+extern "C" int wb_get_events(wb_batch* b, int kind, wb_event_table* o) { return wb_event_rows(b, kind, o, true); }
+extern "C" int wb_get_event_rows(wb_batch* b, int kind, wb_event_table* o) { return wb_event_rows(b, kind, o, false); }
 
 // ------------------------------------------------------------------------------------------------ user-supplied contours
 // decorator_contour_calculation (contour_index.py:197-249): the index functions also accept a contour frame
@@ -1891,6 +2013,7 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
     if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
     const int W = p.nlon + padd;
     if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large");
+    std::lock_guard<std::recursive_mutex> wb_lk_(ctx->mu);
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     int maxn = 1;
     for (int64_t k = 0; k < n; ++k) {
@@ -2150,6 +2273,8 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "link_rows")) { ctx->link_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_fused")) { ctx->trace_fused = value ? 1 : 0; return 0; }
     if (!strcmp(name, "geometry")) { ctx->geometry = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "geometry_async")) { ctx->geometry_async = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "index_polygons")) { ctx->index_polygons = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }
     if (!strcmp(name, "f1_fused")) { ctx->f1_fused = value ? 1 : 0; return 0; }

@@ -47,6 +47,8 @@ struct WbGeomArgs {
     long long* ring_offset;             // [nev + 1]   pinned host (or device, wb_transform_polygons_device)
     long long* vert_offset;             // [rings + 1]
     double* x; double* y;               // [vertices]
+    long long* tot_out;                 // NULL, or [4] in pinned host memory <- rings, vertices, 1 if they do not fit cap_r / cap_v, flagged events: a
+                                        // pass whose geometry kernels wb_indices does not wait for (option geometry_async) is judged from these
 };
 
 // one event by one single-wave workgroup; fill = false: counts only
@@ -274,6 +276,10 @@ WB_KERNEL(wb_k_geom_offsets, WbGeomArgs a) {
     if (a.ctl_out) {
         a.ctl_out->geom_rings = NR; a.ctl_out->geom_verts = NV;
         if (!fits) wb_atomic_or(&a.ctl_out->overflow, 4);
+    }
+    if (a.tot_out) {
+        a.tot_out[1] = NV; a.tot_out[2] = fits ? 0 : 1; a.tot_out[3] = a.ctl_out ? (long long)a.ctl_out->geom_flagged : 0;
+        a.tot_out[0] = NR;
     }
     WB_END_SINGLE
 }

@@ -27,9 +27,16 @@ extern "C" long long wb_hostsim_path_count(int k) { const long long v = wb_hosts
 #endif
 
 // ------------------------------------------------------------------------------------------------ context
+#include <mutex>
 struct wb_ctx {
     int device = 0;
     std::string err;
+    // Two host threads may meet on a context since round 6: the one that DRIVES it (wb_contours / wb_indices, pass after pass) and
+    // one that reads a finished batch's tables and frees it while the next pass is already running (wavebreaking_amd/pipeline.py).
+    // `mu` is held by every call that launches on the context's streams (recursive: such calls nest); `alloc_mu` guards the two
+    // allocators (device blocks, pinned host blocks) and nothing else, so wb_free_batch never waits for a running pass.
+    std::recursive_mutex mu;
+    std::mutex alloc_mu;
     // host buffers of the big result arrays are recycled between batches: a fresh 10 MB vector costs ~1 ms of page
     // faults and zero-fill per pass
     std::multimap<size_t, void*> hpool;
@@ -51,8 +58,11 @@ struct wb_ctx {
     int boxcom_cu_first = 0, boxcom_cu_count = 0;   // option "boxcom_cu_mask": wb_k_box_com runs on those compute units only (its single waves otherwise take slots on every CU from the 1024-thread workgroups of the streamer chain beside it)
     int scan_cu_first = 0, scan_cu_count = 0; // option "scan_cu_mask": ... and the field scan's stream those
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
+    int index_polygons = 0;                   // 1: wb_indices packs the events' polygons in grid indices into pinned host memory (13.5 MB per year of 0.25 degree over PCIe); 0 (default since round 6): wb_get_events packs them when it is first asked for them -- the drop-in functions build their frames from the lon / lat rings and never ask
+    int geometry_async = 1;                   // 1: the geometry kernels of wb_indices (PCIe-bound: 27 MB of doubles per year of 0.25 degree) are not waited for by wb_indices -- they finish beside the next pass's field scan, wb_get_event_geometry waits for them; 0: wb_indices returns when they are done
     int geometry = 1;                         // 1: wb_indices also leaves the events' polygons in lon / lat (transform_polygons, index_utils.py:129-184) in pinned host memory, cut and mapped by the device (wb_geom.h); 0: wb_get_event_geometry computes them on the host when asked
     long long geom_seen = 0;                  // vertices of the largest pass's geometry so far (sizes the pinned arrays)
+    long long geom_rings_seen = 0;            // ... and its rings
     int trace_fused = 1;                      // 1: the contours of a job by ONE kernel with the job resident in LDS (wb_trace_fused.h); 0: link -> rank -> finish (wb_trace.h), which also take the jobs the fused kernel declines
     int f1_fused = 0;                         // routine 1 of the streamer index inside wb_k_streamer_f234 (0: wb_k_streamer_f1 in front of it)
     int f234_lpts = 0;                        // wb_k_streamer_f234: contour points its LDS holds at most (0: WB_F234_LPTS)
@@ -138,6 +148,7 @@ static void* hmalloc(wb_ctx* c, size_t bytes, size_t* got) {
     size_t want = (size_t)1 << 20;
     while (want < bytes) want <<= 1;
     *got = want;
+    std::lock_guard<std::mutex> lk(c->alloc_mu);
     auto it = c->hpool.find(want);
     if (it != c->hpool.end()) {
         void* p = it->second;
@@ -161,6 +172,7 @@ static void hrelease(void* p) {
 }
 static void hfree(wb_ctx* c, void* p, size_t bytes) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(c->alloc_mu);
     if (c->hpool.size() < 24) c->hpool.insert({bytes, p}); else hrelease(p);      // (24: the three index calls on a contour frame use three size classes of vertex arrays each; pinning a fresh 16-64 MB block costs tens of ms)
 }
 
@@ -193,6 +205,7 @@ static int dsync(wb_ctx*) { return 0; }
 static void* dmalloc(wb_ctx* c, size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
+    std::lock_guard<std::mutex> lk(c->alloc_mu);
     auto it = c->pool.lower_bound(bytes);
     if (it != c->pool.end() && it->first <= bytes + bytes / 4 + 4096) {   // close enough: reuse
         void* p = it->second;
@@ -215,6 +228,7 @@ static void* dmalloc(wb_ctx* c, size_t bytes) {
 }
 static void dfree(wb_ctx* c, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(c->alloc_mu);
     auto it = c->live.find(p);
     if (it == c->live.end()) { (void)hipFree(p); return; }
     c->pool.insert({it->second, p});
@@ -394,6 +408,15 @@ static void side_begin(wb_ctx* ctx) {
 static void side_end(wb_ctx* ctx) {
 #if !defined(WB_HOSTSIM)
     (void)hipEventRecord(ctx->join, ctx->stream);
+    std::swap(ctx->stream, ctx->stream2);
+#else
+    (void)ctx;
+#endif
+}
+// ... back to the main stream WITHOUT moving the join event: what was launched on the side stream since the last side_begin is
+// waited for by nobody on the device (the caller has recorded an event of its own behind it: the deferred geometry kernels)
+static void side_leave(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
     std::swap(ctx->stream, ctx->stream2);
 #else
     (void)ctx;
@@ -582,10 +605,13 @@ struct WbTimer {
         names.pop_back();
         ms.pop_back();
     }
-    void collect() {
+    // wait = false: stages whose end event has not been reached yet (kernels nobody waited for: the deferred geometry) keep
+    // their events and are collected by a later call
+    void collect(bool wait = true) {
 #if !defined(WB_HOSTSIM)
         for (size_t i = 0; i < ev0.size(); ++i) {
             if (!ev0[i]) continue;
+            if (!wait && hipEventQuery(ev1[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
             (void)hipEventSynchronize(ev1[i]);
             float t = 0.f;
             (void)hipEventElapsedTime(&t, ev0[i], ev1[i]);

@@ -60,7 +60,7 @@ def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, pa
             try:
                 b.indices(g, **which)
                 engine.check_batch(b, "indices", prep.times, levels, pos, t0)
-                ev = b.events(kind)
+                ev = b.events(kind, polygons=False)          # (the frames are built from the lon / lat rings)
                 n = ev["step"].size
                 if n:
                     ring_off, vert_off, gx, gy = b.event_geometry(kind)

@@ -80,8 +80,9 @@ class BatchPipeline:
             c.close()
 
     def close_batch(self, k, batch):
-        """free batch k on the worker thread of its context (a context, including its allocator, belongs to one thread)"""
-        return self._workers[k % self.depth].submit(batch.close)
+        """free batch k, on the calling thread: a context's allocators have a lock of their own since round 6 (wb_free_batch may
+        come from another thread than the one that drives the context), so the worker of context k % depth is not interrupted"""
+        batch.close()
 
     def run_record(self, n, contours, reduce_max, indices, collect, full_width, before_reduce=None):
         """``n`` batches of ONE record, selected against ``full_width`` WITHOUT waiting for an exchange: no contour can exceed
@@ -94,12 +95,23 @@ class BatchPipeline:
         called after the last ``collect`` and before the exchange: a run whose gathers are issued by another thread
         (distributed.TableGatherer) waits for them there -- every rank must issue its collectives in ONE order, all gathers of
         the record, then the all-reduce."""
+        import queue
         d = self.depth
 
-        # the workers run free of each other; the FIRST batch of worker j waits until worker j - 1 has finished phase 1 of its
-        # first batch, so that the contexts start out of step -- one batch's HBM-bound scan beside the other's index kernels
-        # rather than beside its twin -- and, taking equally long per batch, stay so (option offset_start, default on)
+        # The workers schedule THEMSELVES: worker j runs batches j, j + d, j + 2 d, ... one after the other -- phase 1, phase 2, the
+        # next batch's phase 1 -- and hands every finished batch to this thread through a queue; nothing this thread does (reading
+        # a batch's tables, waiting for its geometry, freeing it: `collect`) stands between two passes of a worker.  (Until round 6
+        # this thread submitted batch k + d to the worker when it had received batch k, and the worker read the tables and freed
+        # the batch before it returned: 0.47 ms of host work between a pass's last kernel and the next pass's first.)  A worker
+        # runs at most `ahead` batches in front of what has been collected (their device scratch is alive until then).
+        # The FIRST batch of worker j waits until worker j - 1 has finished phase 1 of its first batch, so that the contexts start
+        # out of step -- one batch's HBM-bound scan beside the other's index kernels rather than beside its twin -- and, taking
+        # equally long per batch, stay so (option offset_start, default on)
         started = [threading.Event() for _ in range(d)]
+        stop = threading.Event()
+        ahead = max(1, int(os.environ.get("WB_PIPE_AHEAD", "2")))
+        room = [threading.Semaphore(ahead) for _ in range(d)]
+        done = [queue.Queue() for _ in range(d)]
 
         l1, l2 = self._locks if self._locks is not None else (None, None)
 
@@ -120,15 +132,39 @@ class BatchPipeline:
                 with l2:
                     return b.max_nux(), indices(ctx, k, b, full_width)
             return b.max_nux(), indices(ctx, k, b, full_width)
-        fut, out, local = {}, [], 0
-        for k in range(min(d, n)):
-            fut[k] = self._workers[k % d].submit(both, self.contexts[k % d], k)
-        for k in range(n):
-            m, r = _result(fut.pop(k), "batch %d" % k)
-            local = max(local, int(m))
-            if k + d < n:
-                fut[k + d] = self._workers[k % d].submit(both, self.contexts[k % d], k + d)
-            out.append(collect(k, r))
+
+        def loop(j):
+            for k in range(j, n, d):
+                room[j].acquire()
+                if stop.is_set():
+                    return
+                try:
+                    done[j].put((k, both(self.contexts[j], k), None))
+                except BaseException as e:          # handed to the caller's thread, which raises it in batch order
+                    done[j].put((k, None, e))
+                    return
+        futs = [self._workers[j].submit(loop, j) for j in range(min(d, n))]
+        out, local = [], 0
+        try:
+            for k in range(n):
+                try:
+                    kk, mr, err = done[k % d].get(timeout=_timeout())
+                except queue.Empty:
+                    raise PipelineTimeout("BatchPipeline: batch %d did not finish within %s s (WB_PIPE_TIMEOUT)" % (k, os.environ.get("WB_PIPE_TIMEOUT", "600")))
+                if err is not None:
+                    raise err
+                assert kk == k
+                m, r = mr
+                local = max(local, int(m))
+                out.append(collect(k, r))
+                room[k % d].release()
+        except BaseException:
+            stop.set()                              # the workers end behind the batch they are in
+            for sem in room:
+                sem.release()
+            raise
+        for f in futs:
+            _result(f, "a worker of the record")
         if before_reduce is not None:
             before_reduce()
         g = reduce_max(local)
