@@ -89,6 +89,9 @@ typedef struct wb_event_table {
     const int32_t* poly_y;      /*  is self-contained and the contour table need not be fetched                 */
     const int32_t* flags;       /* bit 0 (WB_EVENT_NOT_SIMPLE): the event's polygon crosses itself -- its cells follow the non-zero
                                    winding rule; the reference relies on GEOS' make_valid there (index_utils.py:164), unpinned */
+    const double* props;        /* [n][5] the frame's property columns, computed by the device from the sums exactly as
+                                   index_utils.py:104-120 does: com longitude, com latitude (lon[int(x_com / areas) % nlon],
+                                   lat[int(y_com / areas)]), mean_var, intensity, event_area (each .round(2)) */
 } wb_event_table;
 #define WB_EVENT_NOT_SIMPLE 1
 

@@ -22,6 +22,11 @@ double wb_probe_streams_ms(wb_ctx* ctx, const void* dev, uint64_t bytes, uint64_
 int wb_test_chord_touches(wb_ctx* ctx, int n, const int32_t* x, const int32_t* y, int nchords, const int32_t* i1, const int32_t* i2,
                           int32_t* touches);
 int wb_test_segments_intersect(wb_ctx* ctx, int npairs, const int32_t* seg8, int32_t* intersects);
+/* The frame's property columns (index_utils.py:104-120: the truncated centre of mass, the three .round(2)) evaluated ON THE DEVICE
+   by the function wb_k_pack_results calls for every event (csrc/wb_props.h:wb_props_columns): sums[n][5] (areas, mean_var,
+   intensity, x_com, y_com) -> out[n][5] (com longitude, com latitude, mean_var, intensity, event_area).  For the test against
+   the reference's own statements (tests/golden/reference_rules.npz). */
+int wb_test_props_columns(wb_ctx* ctx, int64_t n, const double* sums, const double* lon, int nlon, const double* lat, int nlat, double* out);
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,17 @@ def test_spatial_resolution_against_the_reference(ref):
     assert raised >= 4
 
 
+_sim = []
+
+
+def _sim_context():
+    if not _sim:
+        from tests import helpers
+        from wavebreaking_amd import _hip
+        _sim.append(_hip.Context(0, helpers.hostsim_library()))
+    return _sim[0]
+
+
 def test_property_sums_and_columns_against_the_reference(ref):
     # index_utils.py:54-63, 91-120 (pandas' groupby sum, com truncation, rounding) on the oracle's cell lists
     from wavebreaking_amd.utils.index_utils import properties_from_sums
@@ -192,6 +203,10 @@ def test_property_sums_and_columns_against_the_reference(ref):
             assert np.array_equal(np.asarray(got), want[e]), (key, e)
             events += 1
         com, mean_var, intensity, area = properties_from_sums(want, lon, lat, len(lon))
+        # ... and the device function wb_indices runs for every event (csrc/wb_props.h:wb_props_columns), here in the host simulation
+        dev = _sim_context().props_columns(want, lon, lat)
+        assert np.array_equal(dev[:, :2], ref[key + "__com"]) and np.array_equal(dev[:, 2], ref[key + "__mean_var"])
+        assert np.array_equal(dev[:, 3], ref[key + "__intensity"]) and np.array_equal(dev[:, 4], ref[key + "__event_area"])
         assert np.array_equal(np.asarray(com), ref[key + "__com"])
         assert np.array_equal(mean_var, ref[key + "__mean_var"]) and np.array_equal(intensity, ref[key + "__intensity"])
         assert np.array_equal(area, ref[key + "__event_area"])

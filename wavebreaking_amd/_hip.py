@@ -43,7 +43,7 @@ class WbEventTable(C.Structure):
         ("ncells", C.POINTER(C.c_int32)), ("cell_offset", C.POINTER(C.c_int64)),
         ("cell_x", C.POINTER(C.c_int32)), ("cell_y", C.POINTER(C.c_int32)),
         ("poly_offset", C.POINTER(C.c_int64)), ("poly_x", C.POINTER(C.c_int32)), ("poly_y", C.POINTER(C.c_int32)),
-        ("flags", C.POINTER(C.c_int32)),
+        ("flags", C.POINTER(C.c_int32)), ("props", C.POINTER(C.c_double)),
     ]
 
 
@@ -527,6 +527,20 @@ class Context:
         if self.h:
             self.L.lib.wb_comm_destroy(self.h)
 
+    def props_columns(self, sums, lon, lat):
+        """the frame's property columns from the five per-event sums, by the device function wb_indices runs for every event
+        (index_utils.py:104-120): (n, 5) float64 -- com longitude, com latitude, mean_var, intensity, event_area"""
+        sums = np.ascontiguousarray(sums, dtype=np.float64).reshape(-1, 5)
+        lon = np.ascontiguousarray(lon, dtype=np.float64)
+        lat = np.ascontiguousarray(lat, dtype=np.float64)
+        out = np.zeros_like(sums)
+        dp = C.POINTER(C.c_double)
+        f = self.L.lib.wb_test_props_columns
+        f.argtypes = [C.c_void_p, C.c_int64, dp, dp, C.c_int, dp, C.c_int, dp]
+        if f(self.h, len(sums), sums.ctypes.data_as(dp), lon.ctypes.data_as(dp), int(lon.size), lat.ctypes.data_as(dp), int(lat.size), out.ctypes.data_as(dp)) != 0:
+            raise RuntimeError("wb_test_props_columns failed: " + self.error())
+        return out
+
     def transform_polygons(self, polygons, lon, lat, nlon, index_space=False, device=False):
         """wb_transform_polygons: index-lattice polygons (list of (n, 2) integer arrays) -> per polygon the list of its rings
         ((m, 2) float64 arrays) in (lon, lat) -- or, with ``index_space``, in index coordinates as they are cut at the seam.
@@ -699,7 +713,9 @@ class Batch:
                    contour=A(t.contour, n, np.int64), ind1=A(t.ind1, n, np.int32), ind2=A(t.ind2, n, np.int32),
                    box=A(t.box, 4 * n, np.int32).reshape(-1, 4), orientation=A(t.orientation, n, np.int32),
                    sums=A(t.sums, 5 * n, np.float64).reshape(-1, 5), ncells=A(t.ncells, n, np.int32),
-                   flags=A(t.flags, n, np.int32))
+                   flags=A(t.flags, n, np.int32),
+                   # the frame's property columns from the device (index_utils.py:104-120): com lon, com lat, mean_var, intensity, event_area
+                   props=A(t.props, 5 * n, np.float64).reshape(-1, 5))
         poff = A(t.poly_offset, n + 1, np.int64)
         out["poly_offset"] = poff
         out["poly_x"] = A(t.poly_x, poff[-1] if (n and polygons) else 0, np.int32)

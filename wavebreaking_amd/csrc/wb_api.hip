@@ -80,7 +80,7 @@ struct wb_batch {
         std::vector<int32_t> step, level, ind1, ind2, box, orient, ncells, flags, cx, cy;
         std::vector<int64_t> contour, celloff, polyoff;
         size_t pbase = 0;              // first polygon vertex of this table in wb_batch::poly_x / poly_y
-        std::vector<double> sums;
+        std::vector<double> sums, props;
     } ev[3];
     WbRingSink geo[3];                              // event geometry in lon / lat (wb_get_event_geometry), built on demand
     // ... or cut and mapped by the device during wb_indices (context option "geometry"): pinned host arrays over ALL events
@@ -927,6 +927,32 @@ extern "C" int wb_test_chord_touches(wb_ctx* ctx, int n, const int32_t* x, const
     dfree(ctx, d);
     return rc;
 }
+WB_KERNEL(wb_k_test_props_columns, int n, const double* sums, const double* lon, const double* lat, int nlon, int nlat, double* out) {
+    for (int b0 = WB_BLOCK_ID * 256; b0 < n; b0 += WB_GRID_DIM * 256) {
+        WB_PFOR(t, 256)
+            const int k = b0 + (int)t;
+            if (k < n) wb_props_columns(sums + (size_t)k * 5, lon, lat, nlon, nlat, out + (size_t)k * 5);
+        WB_END_PFOR
+    }
+}
+extern "C" int wb_test_props_columns(wb_ctx* ctx, int64_t n, const double* sums, const double* lon, int nlon, const double* lat, int nlat, double* out) {
+    if (!ctx || n < 0 || nlon < 1 || nlat < 1 || !lon || !lat || (n && (!sums || !out))) return 1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
+    double* d = (double*)dmalloc(ctx, ((size_t)10 * n + nlon + nlat + 4) * sizeof(double));
+    if (!d) return wb_fail(ctx, "out of device memory");
+    double *ds = d, *dout = d + 5 * n, *dlon = dout + 5 * n, *dlat = dlon + nlon;
+    int rc = n ? h2d(ctx, ds, sums, (size_t)n * 5 * 8) : 0;
+    if (!rc) rc = h2d(ctx, dlon, lon, (size_t)nlon * 8);
+    if (!rc) rc = h2d(ctx, dlat, lat, (size_t)nlat * 8);
+    if (!rc) {
+        WB_LAUNCH(wb_k_test_props_columns, (n + 255) / 256 > 0 ? ((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024) : 1, 256, (int)n, ds, dlon, dlat, nlon, nlat, dout);
+        rc = dsync(ctx);
+    }
+    if (!rc && n) rc = d2h(ctx, out, dout, (size_t)n * 5 * 8);
+    dfree(ctx, d);
+    return rc;
+}
 extern "C" int wb_test_segments_intersect(wb_ctx* ctx, int npairs, const int32_t* seg8, int32_t* intersects) {
     if (!ctx || npairs < 0 || (npairs && (!seg8 || !intersects))) return 1;
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
@@ -1222,10 +1248,11 @@ WB_KERNEL(wb_k_pack_polys, const WbCtl* ctl, int cap_seg, const int* ev, const l
 // launch where seven copy operations used to follow two read-backs of the control block.
 struct WbResultBlock {
     WbCtl* ctl; int* ev; long long* poff; double* sums; int* ncells; int* flags; long long* cell_off;
+    double* props;                     // [n][5] the frame's property columns (index_utils.py:104-120): com_lon, com_lat, mean_var, intensity, event_area
 };
 static size_t wb_result_block_bytes(size_t cap_ne, bool cells) {
     const size_t n = cap_ne + 1;
-    return 512 + n * (8 * sizeof(int) + sizeof(long long) + 5 * sizeof(double) + 2 * sizeof(int) + (cells ? sizeof(long long) : 0)) + 64;
+    return 512 + n * (8 * sizeof(int) + sizeof(long long) + 10 * sizeof(double) + 2 * sizeof(int) + (cells ? sizeof(long long) : 0)) + 64;
 }
 static WbResultBlock wb_result_block(void* base, size_t cap_ne, bool cells) {
     const size_t n = cap_ne + 1;
@@ -1233,6 +1260,7 @@ static WbResultBlock wb_result_block(void* base, size_t cap_ne, bool cells) {
     char* q = (char*)base;
     r.ctl = (WbCtl*)q; q += 512;                      // (sizeof(WbCtl) <= 512, checked below)
     r.sums = (double*)q; q += n * 5 * sizeof(double);
+    r.props = (double*)q; q += n * 5 * sizeof(double);
     r.poff = (long long*)q; q += n * sizeof(long long);
     r.cell_off = cells ? (long long*)q : nullptr; q += cells ? n * sizeof(long long) : 0;
     r.ev = (int*)q; q += n * 8 * sizeof(int);
@@ -1242,7 +1270,7 @@ static WbResultBlock wb_result_block(void* base, size_t cap_ne, bool cells) {
 }
 static_assert(sizeof(WbCtl) <= 512, "the result block reserves 512 bytes for the control block");
 WB_KERNEL(wb_k_pack_results, const WbCtl* ctl, const int* ev, const long long* poff, const double* sums, const int* ncells,
-          const int* flags, const long long* cell_off, WbResultBlock out) {
+          const int* flags, const long long* cell_off, WbResultBlock out, const double* lon, const double* lat, int nlon, int nlat) {
     const int nev = (ctl->overflow & 1) ? 0 : ctl->NE;
     if (WB_BLOCK_ID == 0) {
         WB_PFOR(w, sizeof(WbCtl) / 4)
@@ -1255,7 +1283,10 @@ WB_KERNEL(wb_k_pack_results, const WbCtl* ctl, const int* ev, const long long* p
             if (e <= nev) out.poff[e] = poff[e];
             if (e < nev) {
                 for (int q = 0; q < 8; ++q) out.ev[(size_t)e * 8 + q] = ev[(size_t)e * 8 + q];
-                for (int q = 0; q < 5; ++q) out.sums[(size_t)e * 5 + q] = sums[(size_t)e * 5 + q];
+                double sv[5], pc[5];
+                for (int q = 0; q < 5; ++q) { sv[q] = sums[(size_t)e * 5 + q]; out.sums[(size_t)e * 5 + q] = sv[q]; }
+                wb_props_columns(sv, lon, lat, nlon, nlat, pc);          // the last flops of calculate_properties (index_utils.py:104-120)
+                for (int q = 0; q < 5; ++q) out.props[(size_t)e * 5 + q] = pc[q];
                 out.ncells[e] = ncells[e];
                 out.flags[e] = flags[e];
                 if (out.cell_off) out.cell_off[e] = cell_off[e];
@@ -1478,6 +1509,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     WbCtl fin;
     memset(&fin, 0, sizeof(fin));
     bool p2_off = false;
+    double* h_props = nullptr;
     int* h_ev = nullptr; double* h_sums = nullptr; int* h_nc = nullptr; int* h_fl = nullptr; long long* h_poff = nullptr; long long* h_coff = nullptr;
     uint32_t* h_cells = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -1828,7 +1860,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         side_join(ctx);                                        // (the vertices; synchronous geometry: the control block carries its totals)
         b->timer.begin(ctx, "results");
         WB_LAUNCH(wb_k_pack_results, cap_ne < 64 * 256 ? (cap_ne + 255) / 256 + 1 : 64, 256, ctl, fa.ev, fa.poff, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
-                  pa.ev_cell_off, rb);
+                  pa.ev_cell_off, rb, T->base + T->o_lonval, T->base + T->o_lat, p.nlon, p.nlat);
         b->timer.end(ctx);
         if (ctx->keep_device) {
             // device rows for the gather, packed here; the vertex arrays are taken out of this attempt's scratch
@@ -1888,6 +1920,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         // the descriptors and polygon offsets stay on the device (lazy index polygons, the geometry kernels)
         b->d_ev = fa.ev; b->d_poff = fa.poff; b->d_ev_cap_seg = cap;
         keep(fa.ev); keep(fa.poff);
+        h_props = rb.props;
         h_ev = rb.ev; h_poff = rb.poff; h_sums = rb.sums; h_nc = rb.ncells; h_fl = rb.flags; h_coff = rb.cell_off;
         if (ctx->keep_device) {
             b->dev_px = d_px; b->dev_py = d_py;
@@ -1930,7 +1963,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const size_t m = (size_t)(hi - lo);
         const long long pbase = NE ? h_poff[lo] : 0, pn = NE ? h_poff[hi] - h_poff[lo] : 0;
         t.step.resize(m); t.level.resize(m); t.contour.resize(m); t.ind1.resize(m); t.ind2.resize(m);
-        t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.ncells.resize(m); t.flags.resize(m);
+        t.box.assign(4 * m, 0); t.orient.assign(m, 0); t.sums.resize(5 * m); t.props.resize(5 * m); t.ncells.resize(m); t.flags.resize(m);
         t.polyoff.resize(m + 1); t.pbase = (size_t)pbase;
         for (size_t k = 0; k < m; ++k) {
             const int e = lo + (int)k;
@@ -1946,7 +1979,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             } else {
                 t.ind1[k] = d[3]; t.ind2[k] = d[4];
             }
-            for (int q = 0; q < 5; ++q) t.sums[5 * k + q] = h_sums[(size_t)e * 5 + q];
+            for (int q = 0; q < 5; ++q) { t.sums[5 * k + q] = h_sums[(size_t)e * 5 + q]; t.props[5 * k + q] = h_props[(size_t)e * 5 + q]; }
             t.polyoff[k] = h_poff[e] - pbase;
             t.ncells[k] = h_nc[e];
             t.flags[k] = h_fl[e];
@@ -1984,7 +2017,7 @@ static int wb_event_rows(wb_batch* b, int kind, wb_event_table* o, bool polygons
     o->n = (int64_t)t.step.size();
     o->step = t.step.data(); o->level_idx = t.level.data(); o->contour = t.contour.data();
     o->ind1 = t.ind1.data(); o->ind2 = t.ind2.data(); o->box = t.box.data(); o->orientation = t.orient.data();
-    o->sums = t.sums.data(); o->ncells = t.ncells.data(); o->flags = t.flags.data();
+    o->sums = t.sums.data(); o->ncells = t.ncells.data(); o->flags = t.flags.data(); o->props = t.props.data();
     o->cell_offset = b->p.want_cells ? t.celloff.data() : nullptr;
     o->cell_x = t.cx.data(); o->cell_y = t.cy.data();
     if (t.polyoff.empty()) t.polyoff.push_back(0);

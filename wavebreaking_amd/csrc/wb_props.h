@@ -56,6 +56,27 @@ struct WbPropsArgs {
     long long* ev_cell_off;     // [nev]
 };
 
+// The frame's property columns of one event from its five sums (index_utils.py:104-120), exactly as numpy / pandas compute them
+// there: com = (lon[int(x_com / areas) % nlon], lat[int(y_com / areas)]) -- .astype("int") truncates, % takes the divisor's sign --
+// and .round(2) = rint(v * 100) / 100 (numpy's round: multiply, round half to even, divide; the quotient v / areas is rounded to
+// double first).  out[5]: com_lon, com_lat, mean_var, intensity, event_area.  The build runs with -ffp-contract=off: no product
+// is fused into the division's fix-up.  Pinned by tests/golden/reference_rules.npz (the reference's own statements on the oracle's
+// sums) through wb_test_props_columns.
+WB_HD inline void wb_props_columns(const double* s, const double* lon, const double* lat, int nlon, int nlat, double* out) {
+    const double a = s[0];
+    const double qx = s[3] / a, qy = s[4] / a;
+    long long ix = (qx == qx && fabs(qx) < 9.0e18) ? (long long)qx : 0, iy = (qy == qy && fabs(qy) < 9.0e18) ? (long long)qy : 0;
+    ix %= (long long)nlon;
+    if (ix < 0) ix += nlon;
+    if (iy < 0) iy += nlat;                          // (numpy counts a negative index from the end)
+    iy = iy < 0 ? 0 : (iy >= nlat ? nlat - 1 : iy);  // (beyond the axis numpy raises; an event's centre of mass lies inside its rows)
+    out[0] = lon[ix];
+    out[1] = lat[iy];
+    out[2] = rint((s[1] / a) * 100.0) / 100.0;
+    out[3] = rint((s[2] / a) * 100.0) / 100.0;
+    out[4] = rint(a * 100.0) / 100.0;
+}
+
 WB_HD inline double wb_load_field(const void* p, size_t idx, int dtype) {
     return dtype == 0 ? (double)((const float*)p)[idx] : ((const double*)p)[idx];
 }

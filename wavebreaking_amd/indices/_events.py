@@ -4,7 +4,6 @@ import numpy as np
 
 from wavebreaking_amd import _hip, engine
 from wavebreaking_amd import gridfield as _gf
-from wavebreaking_amd.utils import index_utils as iu
 
 DIM_KEYS = ("time_name", "lon_name", "lat_name", "ntime", "nlon", "nlat", "dlon", "dlat")
 
@@ -70,7 +69,7 @@ def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, pa
                     else:                       # a frame handed in: one job per contour row, rows keep the frame's order
                         step = ev["step"].astype(np.int64)
                         lpos = ev["level_idx"].astype(np.int64)
-                    parts.append(dict(step=step, lpos=lpos, sums=ev["sums"], orientation=ev["orientation"],
+                    parts.append(dict(step=step, lpos=lpos, props=ev["props"], orientation=ev["orientation"],
                                       ring_off=ring_off, vert_off=vert_off, gx=gx, gy=gy, n=n))
             except Exception:
                 for ob, *_ in pending:
@@ -125,7 +124,7 @@ def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, pa
         return _gf.empty_frame()                                          # streamer_index.py:278-279
     step = np.concatenate([p["step"] for p in parts])
     lpos = np.concatenate([p["lpos"] for p in parts])
-    sums = np.concatenate([p["sums"] for p in parts])
+    props = np.concatenate([p["props"] for p in parts])
     orient_code = np.concatenate([p["orientation"] for p in parts])
     # geometry objects, batch after batch (the three cases of index_utils.py:167-173 in make_polygon)
     geoms = []
@@ -137,13 +136,15 @@ def _run_index(kind, data, contour_levels, contours, intensity, periodic_add, pa
     if len(parts) > 1 and several:
         # several batches (time blocks, level groups): time-major, level-minor, event order inside a (step, level) kept
         order = np.lexsort((np.arange(step.size), lpos, step))
-        step, lpos, sums, orient_code = step[order], lpos[order], sums[order], orient_code[order]
+        step, lpos, props, orient_code = step[order], lpos[order], props[order], orient_code[order]
         geoms = [geoms[i] for i in order]
     level_values = np.empty(len(levels), dtype=object)
     level_values[:] = list(levels)
     cols = dict(date=np.asarray(prep.times)[step], level=list(level_values[lpos]))
-    com, mean_var, inten, area = iu.properties_from_sums(sums, prep.lon, prep.lat, prep.nlon)
-    cols.update(com=com, mean_var=mean_var, intensity=inten, event_area=area)   # index_utils.py:113-120
+    # index_utils.py:104-120: the truncated centre of mass and the three rounded columns come from the device with the sums
+    # (wb_k_pack_results; utils.index_utils.properties_from_sums is the same statement in numpy)
+    cols.update(com=list(zip(props[:, 0].tolist(), props[:, 1].tolist())), mean_var=props[:, 2].copy(), intensity=props[:, 3].copy(),
+                event_area=props[:, 4].copy())
     if kind == _hip.OVERTURNINGS:
         names = np.array(["cyclonic", "anticyclonic"], dtype=object)
         cols["orientation"] = list(names[orient_code])
