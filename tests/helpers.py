@@ -465,15 +465,16 @@ def check_deferred_results(ctx, nt=6, dlon=1.0):
     pv = synth.pv_field(30, nt, lat, lon, eps=0.2)
     out = {}
     try:
-        for ga, ip in ((1, 0), (0, 0), (1, 1), (0, 1)):
+        for ga, ip, dma in ((1, 0, 1), (0, 0, 1), (1, 1, 0), (0, 1, 0), (1, 0, 0)):
             ctx.set_option("geometry_async", ga)
             ctx.set_option("index_polygons", ip)
+            ctx.set_option("geometry_dma", dma)         # (the kernels write device arrays, a DMA copy moves the rings / they store into pinned memory)
             b = ctx.contours(pv, lat, lon, [-2.0, 2.0], dlon, dlon, periodic_add=120.0, intensity=pv)
             b.indices()
             rows = [b.events(k, polygons=False) for k in (0, 1, 2)]                # first: nothing packed yet when ip == 0
             geo = [b.event_geometry(k) for k in (0, 1, 2)]
             full = [b.events(k) for k in (0, 1, 2)]
-            out[(ga, ip)] = (rows, geo, full)
+            out[(ga, ip, dma)] = (rows, geo, full)
             b.indices(cutoffs=False)                                               # again on the same batch: the first call's leftovers are settled
             again = [b.events(k) for k in (0, 1, 2)]
             assert again[2]["step"].size == 0 and np.array_equal(again[0]["poly_x"], full[0]["poly_x"])
@@ -482,7 +483,8 @@ def check_deferred_results(ctx, nt=6, dlon=1.0):
     finally:
         ctx.set_option("geometry_async", 1)
         ctx.set_option("index_polygons", 0)
-    ref_rows, ref_geo, ref_full = out[(0, 1)]
+        ctx.set_option("geometry_dma", 1)
+    ref_rows, ref_geo, ref_full = out[(0, 1, 0)]
     assert sum(r["step"].size for r in ref_rows) > 10
     for key, (rows, geo, full) in out.items():
         for k in (0, 1, 2):

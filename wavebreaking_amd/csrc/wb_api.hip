@@ -96,6 +96,11 @@ struct wb_batch {
     long long* g_tot = nullptr;                     // [4] rings, vertices, overflow, flagged (inside the ring_offset block)
     long long g_cap_r = 0, g_cap_v = 0;
     int *g_cnt_r = nullptr, *g_cnt_v = nullptr, *g_flag = nullptr;
+    // context option geometry_dma: the kernels' device arrays (x, y: what the copy behind the kernels left out is fetched by
+    // wb_geom_settle) and how many vertices that copy covered
+    double *g_dx = nullptr, *g_dy = nullptr;
+    long long* g_dro = nullptr; long long* g_dvo = nullptr;
+    long long g_copied = 0;
 #if !defined(WB_HOSTSIM)
     hipEvent_t g_event = nullptr;
 #endif
@@ -1437,6 +1442,20 @@ static int wb_geom_settle(wb_batch* b) {
     bfree_one(b, b->g_cnt_r); bfree_one(b, b->g_cnt_v); bfree_one(b, b->g_flag);
     b->g_cnt_r = b->g_cnt_v = b->g_flag = nullptr;
     const long long NR = b->g_tot[0], NV = b->g_tot[1], over = b->g_tot[2], flagged = b->g_tot[3];
+    int tail_rc = 0;
+#if !defined(WB_HOSTSIM)
+    if (b->g_dx && NV > b->g_copied && !over && !flagged && NV <= b->g_cap_v) {
+        // the DMA copy behind the kernels covered as many vertices as the context's largest pass so far held: the rest now
+        std::lock_guard<std::mutex> lk(ctx->settle_mu);
+        if (!ctx->settle_stream && hipStreamCreateWithFlags(&ctx->settle_stream, hipStreamNonBlocking) != hipSuccess) { ctx->settle_stream = nullptr; tail_rc = 1; }
+        const size_t o = (size_t)b->g_copied, m = (size_t)(NV - b->g_copied) * sizeof(double);
+        if (!tail_rc) tail_rc = hipMemcpyAsync(b->g_x + o, b->g_dx + o, m, hipMemcpyDeviceToHost, ctx->settle_stream) != hipSuccess ||
+                                hipMemcpyAsync(b->g_y + o, b->g_dy + o, m, hipMemcpyDeviceToHost, ctx->settle_stream) != hipSuccess ||
+                                hipStreamSynchronize(ctx->settle_stream) != hipSuccess;
+    }
+#endif
+    if (b->g_dx) { bfree_one(b, b->g_dx); bfree_one(b, b->g_dy); bfree_one(b, b->g_dro); bfree_one(b, b->g_dvo); b->g_dx = b->g_dy = nullptr; b->g_dro = b->g_dvo = nullptr; }
+    if (tail_rc) return wb_fail(ctx, "wb_indices: the copy of the geometry's tail failed");
     if (NR < 0 || NV < 0) return wb_fail(ctx, "wb_indices: the geometry kernels left no totals");
     if (NV > ctx->geom_seen) ctx->geom_seen = NV;
     if (NR > ctx->geom_rings_seen) ctx->geom_rings_seen = NR;
@@ -1826,12 +1845,42 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             ga.tot_out = ga.ring_offset + (cap_ne + 2) + 2;
             for (int q = 0; q < 4; ++q) ga.tot_out[q] = -1;
         }
+        // context option geometry_dma: the kernels write device arrays of the same layout, a DMA copy behind them fills the pinned ones
+        long long *h_ro = ga.ring_offset, *h_vo = ga.vert_offset;
+        double *h_gx = ga.x, *h_gy = ga.y;
+        long long* h_tot = ga.tot_out;
+        bool geom_dma = false;
+        long long n_copy = 0;
+#if !defined(WB_HOSTSIM)
+        if (do_geom && ctx->geometry_dma) {
+            long long* d_ro = (long long*)talloc((size_t)(cap_ne + 2 + 8) * sizeof(long long));
+            long long* d_vo = (long long*)talloc((size_t)(cap_gr + 2) * sizeof(long long));
+            double* d_gx = (double*)talloc((size_t)(cap_gv + 2) * sizeof(double));
+            double* d_gy = (double*)talloc((size_t)(cap_gv + 2) * sizeof(double));
+            if (!d_ro || !d_vo || !d_gx || !d_gy) { release(); return wb_fail(ctx, "out of device memory (event geometry)"); }
+            ga.ring_offset = d_ro; ga.vert_offset = d_vo; ga.x = d_gx; ga.y = d_gy; ga.tot_out = d_ro + (cap_ne + 2) + 2;
+            geom_dma = true;
+            n_copy = std::min<long long>(cap_gv, ctx->geom_seen > 0 ? ctx->geom_seen + ctx->geom_seen / 16 + 4096 : 0);
+        }
+#endif
         auto launch_geometry = [&]() {
             b->timer.begin(ctx, "geometry");
             WB_LAUNCH(wb_k_geom_count, ctx->polys_grid, WB_GEOM_THREADS, ga);
             WB_LAUNCH(wb_k_geom_offsets, 1, WB_LIST_THREADS, ga);
             WB_LAUNCH(wb_k_geom_fill, ctx->polys_grid, WB_GEOM_THREADS, ga);
             b->timer.end(ctx);
+#if !defined(WB_HOSTSIM)
+            if (geom_dma) {
+                // (on the stream the kernels went to; the event tables' ring offsets with the pass's totals behind them, the rings'
+                //  vertex offsets, and the first n_copy vertices -- all of them, unless this pass holds more than any before it)
+                (void)hipMemcpyAsync(h_ro, ga.ring_offset, (size_t)(cap_ne + 2 + 8) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+                (void)hipMemcpyAsync(h_vo, ga.vert_offset, (size_t)(cap_gr + 2) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+                if (n_copy > 0) {
+                    (void)hipMemcpyAsync(h_gx, ga.x, (size_t)n_copy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+                    (void)hipMemcpyAsync(h_gy, ga.y, (size_t)n_copy * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+                }
+            }
+#endif
         };
         side_begin(ctx);
         if (polys_now || d_px) {
@@ -1903,19 +1952,17 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         const long long NV = fin.poly_total;
         b->poly_n = (size_t)NV;
         auto keep = [&](void* q) { for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == q) { tmp.erase(tmp.begin() + i); break; } };
-        if (do_geom && !geom_async && fin.geom_flagged == 0) {
-            b->g_ring_offset = ga.ring_offset; b->g_vert_offset = ga.vert_offset; b->g_x = ga.x; b->g_y = ga.y;
-            b->g_rings = fin.geom_rings; b->g_verts = fin.geom_verts;
-            if (fin.geom_verts > ctx->geom_seen) ctx->geom_seen = fin.geom_verts;
-            if (fin.geom_rings > ctx->geom_rings_seen) ctx->geom_rings_seen = fin.geom_rings;
-        }
-        if (geom_async) {
-            // still running, perhaps: judged when somebody asks (wb_geom_settle); the arrays they use leave this attempt's scratch
+        if (do_geom) {
+            // judged by wb_geom_settle from the totals the kernels left: at once when this call waited for them (geometry_async = 0),
+            // when somebody asks otherwise -- they may still be running; the arrays they use leave this attempt's scratch
             b->g_pending = true;
-            b->g_ring_offset = ga.ring_offset; b->g_vert_offset = ga.vert_offset; b->g_x = ga.x; b->g_y = ga.y; b->g_tot = ga.tot_out;
+            b->g_ring_offset = h_ro; b->g_vert_offset = h_vo; b->g_x = h_gx; b->g_y = h_gy; b->g_tot = h_tot;
             b->g_cap_r = cap_gr; b->g_cap_v = cap_gv;
             b->g_cnt_r = ga.cnt_r; b->g_cnt_v = ga.cnt_v; b->g_flag = ga.gflag;
             keep(ga.cnt_r); keep(ga.cnt_v); keep(ga.gflag);
+            b->g_copied = geom_dma ? n_copy : cap_gv;
+            if (geom_dma) { b->g_dx = ga.x; b->g_dy = ga.y; b->g_dro = ga.ring_offset; b->g_dvo = ga.vert_offset; keep(ga.x); keep(ga.y); keep(ga.ring_offset); keep(ga.vert_offset); }
+            if (!geom_async && wb_geom_settle(b)) { release(); return 1; }
         }
         // the descriptors and polygon offsets stay on the device (lazy index polygons, the geometry kernels)
         b->d_ev = fa.ev; b->d_poff = fa.poff; b->d_ev_cap_seg = cap;
@@ -2307,6 +2354,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "trace_fused")) { ctx->trace_fused = value ? 1 : 0; return 0; }
     if (!strcmp(name, "geometry")) { ctx->geometry = value ? 1 : 0; return 0; }
     if (!strcmp(name, "geometry_async")) { ctx->geometry_async = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "geometry_dma")) { ctx->geometry_dma = value ? 1 : 0; return 0; }
     if (!strcmp(name, "index_polygons")) { ctx->index_polygons = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }

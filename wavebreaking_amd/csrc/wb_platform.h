@@ -60,6 +60,7 @@ struct wb_ctx {
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int index_polygons = 0;                   // 1: wb_indices packs the events' polygons in grid indices into pinned host memory (13.5 MB per year of 0.25 degree over PCIe); 0 (default since round 6): wb_get_events packs them when it is first asked for them -- the drop-in functions build their frames from the lon / lat rings and never ask
     int geometry_async = 1;                   // 1: the geometry kernels of wb_indices (PCIe-bound: 27 MB of doubles per year of 0.25 degree) are not waited for by wb_indices -- they finish beside the next pass's field scan, wb_get_event_geometry waits for them; 0: wb_indices returns when they are done
+    int geometry_dma = 1;                     // 1: the geometry kernels write DEVICE arrays and a DMA copy behind them moves the rings to pinned host memory (the copy engine, not the compute units, waits for PCIe; as many vertices as the context's largest pass so far held, the rest -- if any -- when the geometry is asked for); 0: the kernels store into pinned host memory themselves (round 5: while 2048 waves trickle 27 MB through PCIe every kernel beside them slows down -- wb_k_props 0.55 -> 0.9 ms)
     int geometry = 1;                         // 1: wb_indices also leaves the events' polygons in lon / lat (transform_polygons, index_utils.py:129-184) in pinned host memory, cut and mapped by the device (wb_geom.h); 0: wb_get_event_geometry computes them on the host when asked
     long long geom_seen = 0;                  // vertices of the largest pass's geometry so far (sizes the pinned arrays)
     long long geom_rings_seen = 0;            // ... and its rings
@@ -90,6 +91,8 @@ struct wb_ctx {
     hipEvent_t fork4 = nullptr, join4 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t scan_done = nullptr;           // recorded behind this context's field scan (option scan_exclusive)
+    hipStream_t settle_stream = nullptr;      // wb_geom_settle: the tail of a pass's geometry that the DMA copy behind its kernels did not cover (made on first use)
+    std::mutex settle_mu;
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
     // (measured: 0.7 ms for the first pass's ~40 allocations, 350 ms for every later pass), so blocks are
     // kept for the life of the context and handed out again by size
@@ -699,6 +702,7 @@ static void wb_platform_destroy(wb_ctx* c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
+    if (c->settle_stream) (void)hipStreamDestroy(c->settle_stream);
     if (c->fork4) (void)hipEventDestroy(c->fork4);
     if (c->join4) (void)hipEventDestroy(c->join4);
     if (c->fork3) (void)hipEventDestroy(c->fork3);
