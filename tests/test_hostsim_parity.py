@@ -420,7 +420,7 @@ def test_cells_equal_to_the_level_full_path(sim, seed):
 def test_box_com_one_lane_walk():
     # a build whose row-parallel box evaluation never applies: every box in the guard band is walked cell by cell by one
     # lane -- same sums
-    lib = _hip.Library(helpers.build_hostsim(variant="boxlane", defines=("WB_BOXCOM_FORCE_WALK=1", "WB_BOXCOM_ROWS=3")), allow_hostsim=True)
+    lib = _hip.Library(helpers.build_hostsim(variant="boxlane", defines=("WB_BOXCOM_FORCE_WALK=1", "WB_BOXCOM_ROWS=3", "WB_BOXCOM_BOUND=0")), allow_hostsim=True)
     ctx = _hip.Context(0, lib)
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(0, 6, lat, lon, eps=0.3)
@@ -432,13 +432,36 @@ def test_box_com_one_lane_walk():
 def test_box_com_in_chunks_of_two_rows():
     # the row-parallel evaluation with chunks of two rows and a single segment per row: state handed from chunk to chunk, wide
     # rows walked chunk-wise by one lane and the prediction taken up again after them -- same sums
-    lib = _hip.Library(helpers.build_hostsim(variant="boxchunk", defines=("WB_BOXCOM_ROWS=2", "WB_BOXCOM_SEGS=1")), allow_hostsim=True)
+    lib = _hip.Library(helpers.build_hostsim(variant="boxchunk", defines=("WB_BOXCOM_ROWS=2", "WB_BOXCOM_SEGS=1", "WB_BOXCOM_BOUND=0")), allow_hostsim=True)
     ctx = _hip.Context(0, lib)
     lat, lon = synth.grid(1.0)
     pv = synth.pv_field(0, 6, lat, lon, eps=0.3)
     got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(6), [-2, 2], intensity=pv)
     assert got["com_rechecks"][1] >= 8 and 0 < got["com_rechecks"][2] < got["com_rechecks"][1]
     ctx.close()
+
+
+def test_box_sums_from_exact_totals_equal_the_chained_evaluation():
+    """wb_k_box_com settles most queued boxes from the EXACT totals of their terms (no rounding boundary within the compensated
+    sum's error bound: csrc/wb_props.h); a build with -DWB_BOXCOM_BOUND=2 evaluates every such box BOTH ways and counts the
+    boxes on which the two differ in a single bit: none, on every grid of the suite; and the default build settles most boxes
+    that way while the full parity (sums to the last bit where the centre of mass sits next to an integer) holds"""
+    lib = _hip.Library(helpers.build_hostsim(variant="boxbound2", defines=("WB_BOXCOM_BOUND=2",)), allow_hostsim=True)
+    ctx = _hip.Context(0, lib)
+    settled = queued = 0
+    try:
+        for dlon, t0, nt, eps in ((1.0, 0, 12, 0.3), (1.0, 100, 12, 0.0), (2.5, 7, 16, 0.2), (0.5, 40, 4, 0.1), (0.25, 3, 1, 0.0)):
+            lat, lon = synth.grid(dlon)
+            pv = synth.pv_field(t0, nt, lat, lon, eps=eps)
+            b = ctx.contours(pv, lat, lon, [-2.0, 2.0], dlon, dlon, periodic_add=120.0, want_cells=False)
+            b.indices(streamers=False, cutoffs=False)
+            assert b.counter("box_bound_mismatch") == 0, (dlon, t0)
+            settled += b.counter("box_bound")
+            queued += b.com_rechecks()[1]
+            b.close()
+    finally:
+        ctx.close()
+    assert queued >= 50 and settled >= 0.8 * queued, (settled, queued)
 
 
 def test_polygon_that_crosses_itself_is_flagged(sim):

@@ -762,6 +762,15 @@ class Batch:
         self.ctx.L.lib.wb_get_com_rechecks(self.h, C.byref(a), C.byref(c), C.byref(o))
         return int(a.value), int(c.value), int(o.value)
 
+    def counter(self, name):
+        """a named counter of the last indices() call (wb_get_counter): "box_bound", "box_bound_mismatch" """
+        v = C.c_int64()
+        f = self.ctx.L.lib.wb_get_counter
+        f.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        if f(self.h, name.encode(), C.byref(v)) != 0:
+            raise RuntimeError("wb_get_counter failed: " + self.ctx.error())
+        return int(v.value)
+
     def pair_stats(self):
         """(base-point pairs covered by the all-pairs test, candidate pairs found) of the last indices() call."""
         a, c = C.c_int64(), C.c_int64()

@@ -68,6 +68,7 @@ struct wb_batch {
     int *dev_px = nullptr, *dev_py = nullptr, *d_job_level = nullptr;
     long long dev_n[3] = {0, 0, 0}, dev_nv = 0, step_offset = 0;
     long long com_rechecks[3] = {0, 0, 0};     // events / boxes whose centre-of-mass sums were re-evaluated in the reference's order
+    long long box_bound = 0, box_bound_mismatch = 0;   // queued boxes settled from the exact totals of their terms (wb_k_box_com) / test build WB_BOXCOM_BOUND = 2: boxes the two paths disagree on
     long long group_ties = 0;                  // check_groups: groups whose largest length was shared by several members
     // batches built from a user-supplied contour frame: one job per contour row
     std::vector<int> job_step, job_level;
@@ -750,6 +751,15 @@ extern "C" int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes,
     return 0;
 }
 
+// counters of the last wb_indices by name: "box_bound" (queued overturning boxes whose centre-of-mass sums followed from the exact
+// totals of their terms, no chain), "box_bound_mismatch" (test builds with -DWB_BOXCOM_BOUND=2 only: boxes on which that and the
+// chained evaluation disagree -- must be 0)
+extern "C" int wb_get_counter(wb_batch* b, const char* name, int64_t* value) {
+    if (!b || !name || !value) return 1;
+    if (!strcmp(name, "box_bound")) { *value = b->box_bound; return 0; }
+    if (!strcmp(name, "box_bound_mismatch")) { *value = b->box_bound_mismatch; return 0; }
+    return wb_fail(b->ctx, std::string("wb_get_counter: unknown counter ") + name);
+}
 extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs) {
     if (!b) return 1;
     *point_pairs = b->pair_stats[0];
@@ -1996,6 +2006,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     b->band[0] = fin.band[0]; b->band[1] = fin.band[1];
     b->pair_stats[0] = fin.point_pairs; b->pair_stats[1] = fin.cand_pairs; b->pair_stats[2] = fin.evaluated_pairs;
     for (int q = 0; q < 3; ++q) b->com_rechecks[q] = fin.com_rechecks[q];
+    b->box_bound = fin.box_bound; b->box_bound_mismatch = fin.dbg[23];
     b->group_ties = fin.group_ties;
     const int NS = fin.NS, NO = fin.NO, NE = fin.NE;
     if (NS < 0 || NO < 0 || NE < NS + NO)

@@ -112,6 +112,7 @@ struct WbCtl {
     int f1_cursor;               // next contour (in wb_k_pairs_order's order) of wb_k_streamer_f1's persistent workgroups
     int geom_rings, geom_verts;  // transform_polygons on the device (wb_geom.h): rings and vertices of the pass's events in lon / lat
     int geom_flagged;            // events with more cut edges than its kernel holds (the host function does the pass's geometry then)
+    int box_bound;               // queued boxes wb_k_box_com settled from the exact totals of their terms alone (no rounding boundary within the steps' error bound)
     long long dbg[24];           // development: per-phase clock sums of an instrumented kernel (WB_STAMP)
 };
 // development aid: clock ticks (100 MHz wall clock) spent between two stamps of thread 0, summed over the workgroups.
