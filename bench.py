@@ -454,6 +454,8 @@ def main():
                            % (int(main_geometry), " AND the events' polygons in lon / lat -- transform_polygons, index_utils.py:129-184: cut at the last "
                               "meridian, truncated and mapped by the device into pinned host memory (csrc/wb_geom.h); `value_without_geometry`: the "
                               "same passes with geometry = 0, the figure rounds 1-5 reported as `value`" if main_geometry else ""))
+        if world == 1 and a.config == 2 and a.stagger_steps > 0:
+            out["float64_field"] = float64_scan(ctx, lat, lon, levels, nt, par, a.eps, bytes_per_ts)
         if world == 1 and a.e2e_steps > 0 and a.config == 2:
             out["end_to_end"] = end_to_end(ctx, d_pv, d_int, lat, lon, levels, min(nt, a.e2e_steps))
         if world == 1 and a.cpu_sample > 0:
@@ -471,6 +473,38 @@ def main():
         # the process winds down, i.e. BEHIND the result line: whatever a rank still sends to its standard output is dropped
         sys.stdout.flush()
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
+
+def float64_scan(ctx, lat, lon, levels, nt, par, eps, bytes_per_ts_f32):
+    """The same record as a float64 cube -- what calculate_smoothed_field hands on (numpy promotes the float32 data with its
+    float64 weights, spatial.py:98-109) -- through phase 1 alone on the device: the streaming scan's float64 instance (LDS halo
+    exchange, patches as keys only since round 6: context option scan_f64_fast) reads 8 bytes per cell; reported beside the
+    float32 roofline, never as `value`."""
+    from wavebreaking_amd import synthetic as synth
+    nlat, nlon = lat.size, lon.size
+    d = ctx.alloc(nt * nlat * nlon * 8)
+    try:
+        ctx.synth_fill(d, np.float64, 0, nt, lat, lon, par, eps, synth.SEED)
+        out = {}
+        for fast in (1, 0):
+            ctx.set_option("scan_f64_fast", fast)
+            ms = []
+            for rep in range(4):
+                b = ctx.contours(d, lat, lon, levels, float(lon[1] - lon[0]), float(lat[1] - lat[0]), device_shape=(nt, nlat, nlon), device_dtype=np.float64, want_cells=False)
+                t = dict(b.timings())
+                b.close()
+                if rep:
+                    ms.append((t.get("scan", float("nan")), t.get("scan_build", float("nan")), t.get("trace_fused", float("nan"))))
+            scan, build, fused = (float(np.median([m[k] for m in ms])) for k in range(3))
+            out["fast" if fast else "rounds_2_to_5"] = {"scan_ms": scan, "scan_build_ms": build, "trace_fused_ms": fused,
+                                                       "GBps": 2 * nt * bytes_per_ts_f32 / (scan * 1e-3) / 1e9, "frac": 2 * nt * bytes_per_ts_f32 / (scan * 1e-3) / HBM_PEAK}
+        ctx.set_option("scan_f64_fast", 1)
+        out["what"] = ("%d steps of the record as float64 (8 B per cell: %d algorithmic bytes per launch), one batch alone: the streaming scan's HIP-event duration, "
+                       "median of 3 launches; fast = LDS halo exchange + patches as keys only (context option scan_f64_fast = 1, the default)" % (nt, 2 * nt * bytes_per_ts_f32))
+        return out
+    finally:
+        ctx.set_option("scan_f64_fast", 1)
+        ctx.free(d)
 
 
 def pmc_traffic(nt):

@@ -382,3 +382,33 @@ def test_rows_without_vertices_lazy_polygons_and_deferred_geometry(ctx):
     """the same on the device, where the geometry kernels really are in flight when wb_indices returns"""
     helpers.check_deferred_results(ctx, nt=8)
     helpers.check_deferred_results(ctx, nt=4, dlon=0.25)
+
+
+def test_float64_fields_take_the_fast_streaming_scan(ctx):
+    """float64 fields -- what calculate_smoothed_field returns (numpy promotes) -- through the streaming scan's LDS halo exchange with
+    patches as keys only (context option scan_f64_fast, round 6) and through the scalar-halo kernel of rounds 2-5: the same contour
+    tables and status words, and full parity with the oracle, on grids of one, two and six strips, with NaN rows (the rows the
+    smoothing leaves, spatial.py:106-107) and three levels"""
+    cases = []
+    for dlon, t0, nt, eps in ((0.25, 40, 2, 0.3), (1.0, 3, 4, 0.2), (0.5, 11, 2, 0.1), (2.5, 0, 3, 0.2)):
+        lat, lon = synth.grid(dlon)
+        pv = synth.pv_field(t0, nt, lat, lon, eps=eps).astype(np.float64)
+        cases.append((pv, lat, lon, dlon, nt))
+    lat, lon = synth.grid(1.0)
+    pv = synth.pv_field(3, 3, lat, lon, eps=0.2).astype(np.float64)
+    pv[:, :2] = np.nan; pv[:, -2:] = np.nan
+    cases.append((pv, lat, lon, 1.0, 3))
+    for pv, lat, lon, dlon, nt in cases:
+        tabs = {}
+        for fast in (1, 0):
+            ctx.set_option("scan_f64_fast", fast)
+            try:
+                b = ctx.contours(pv, lat, lon, [-2.0, 1.5, 2.0], dlon, dlon, periodic_add=120.0)
+                tabs[fast] = (b.contour_table(), b.status().copy(), dict(b.timings()))
+                b.close()
+            finally:
+                ctx.set_option("scan_f64_fast", 1)
+        for key in tabs[1][0]:
+            assert np.array_equal(tabs[1][0][key], tabs[0][0][key]), (dlon, key)
+        assert np.array_equal(tabs[1][1], tabs[0][1]) and tabs[1][0]["step"].size > 0
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(nt), [-2, 2])

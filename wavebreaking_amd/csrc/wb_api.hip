@@ -424,8 +424,11 @@ static int run_phase1(wb_batch* b) {
         size_t lds_limit = 64 << 10;
         int threads_limit = 1024;
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) { lds_limit = prop.sharedMemPerBlock; threads_limit = prop.maxThreadsPerBlock; } }
-        const size_t stream_lds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (4 + 10 * esz) + (size_t)b->nwork_strips * 257 * (esz + 4) + 64;
+        // (float fields and, with the option scan_f64_fast, float64 fields that load as vectors store their patches as keys only)
+        const bool ko_likely = ctx->scan_keys_only && vec && ctx->scan_halo_lds && (p.dtype == 0 ? ctx->scan_variant == 2 : ctx->scan_f64_fast != 0);
+        const size_t stream_lds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (ko_likely ? 4 : 4 + 10 * esz) + (size_t)b->nwork_strips * 257 * (esz + 4) + 64;
         const bool stream_fits = stream_lds <= lds_limit && 64 * b->nwork_strips <= threads_limit;
+        bool streamed = false;
         if (ctx->scan_split && nlat < 65536 && b->W <= 65536 && stream_fits) {
             // two kernels (wb_scan.h): the streaming kernel captures the patches that hold a crossing, the build
             // kernel turns them into the per-level segment lists
@@ -446,7 +449,7 @@ static int run_phase1(wb_batch* b) {
             if (ctx->scan_bands > 0) nbands = ctx->scan_bands;             // (option "scan_bands": development override)
             {   // bands short enough for the LDS halo exchange of the streaming kernel (wb_k_scan_build handles up to 16)
                 const int minb = (nlat - 1 + 254) / 255;
-                if (vec && p.dtype == 0 && ctx->scan_halo_lds && nbands < minb && minb <= 16) nbands = minb;
+                if (vec && ctx->scan_halo_lds && nbands < minb && minb <= 16) nbands = minb;
             }
             if (nbands > nlat - 1) nbands = nlat - 1;
             sa.band_rows = (nlat - 1 + nbands - 1) / nbands;
@@ -457,10 +460,14 @@ static int run_phase1(wb_batch* b) {
             sa.debug = ctx->scan_debug;
             const long long lists = items * sa.nbands;
             // the strips of a workgroup hand each other the halo column through LDS when a band's rows fit (vector loads only)
-            sa.halo_rows = (vec && p.dtype == 0 && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
+            // (float64 since round 6: option "scan_f64_fast", default 1 -- until then float64 fields, what calculate_smoothed_field
+            //  returns, took the scalar-halo kernel with a 6-deep ring and 84-byte patches)
+            const bool f64_fast = p.dtype != 0 && ctx->scan_f64_fast && ctx->scan_keys_only;
+            sa.halo_rows = (vec && (p.dtype == 0 || f64_fast) && ctx->scan_halo_lds && sa.band_rows + 1 <= 256) ? sa.band_rows + 1 : 0;
             // keys only (option "scan_keys_only", the default where the 13 x 4 streaming kernel runs): a patch is stored as its
             // key, wb_k_scan_build reads the values from the field
-            sa.keys_only = (ctx->scan_keys_only && p.dtype == 0 && vec && sa.halo_rows && variant == 2) ? 1 : 0;
+            sa.keys_only = (ctx->scan_keys_only && vec && sa.halo_rows && (p.dtype == 0 ? variant == 2 : f64_fast)) ? 1 : 0;
+            if (p.dtype != 0 && !sa.keys_only) sa.halo_rows = 0;
             sa.cap_k = balloc<uint32_t>(b, (size_t)lists * sa.cap_vs);
             sa.cap_v = balloc<unsigned char>(b, sa.keys_only ? 256 : (size_t)lists * sa.cap_vs * 10 * esz);
             sa.cap_n = balloc<int>(b, (size_t)lists);
@@ -473,6 +480,8 @@ static int run_phase1(wb_batch* b) {
             b->phase1_scratch.push_back(spare);
             const size_t slds = (size_t)b->nwork_strips * WB_STREAM_LBUF * (sa.keys_only ? 4 : 4 + 10 * esz)    // a patch buffer per wave
                                 + (size_t)b->nwork_strips * sa.halo_rows * (esz + 4);
+            if (slds <= lds_limit) {                       // (else -- a field whose bands do not admit the mode the estimate above assumed -- the single-kernel scan)
+            streamed = true;
             sa.cursor = ctx->scan_dynamic ? &b->d_ctl->scan_cursor : nullptr;       // (the control block was zeroed above)
             long long mwg = slots * (ctx->scan_grid_mult > 0 ? ctx->scan_grid_mult : 1);
             if (mwg > (long long)p.nt * sa.nbands) mwg = (long long)p.nt * sa.nbands;
@@ -494,7 +503,9 @@ static int run_phase1(wb_batch* b) {
                 case 5: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 5, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
                 default: hipLaunchKernelGGL((wb_k_scan_stream<float, true, N, 8, 6, true>), mgrid, sblock, slds, ctx->stream, sa); break; \
             }
-#define WB_STREAM_ANY(T, V, N) hipLaunchKernelGGL((wb_k_scan_stream<T, V, N, 6, 4, false>), mgrid, sblock, slds, ctx->stream, sa)
+#define WB_STREAM_ANY(T, V, N) \
+            if (sizeof(T) == 8 && V && sa.halo_rows && sa.keys_only) hipLaunchKernelGGL((wb_k_scan_stream<double, true, N, 8, 4, true, true>), mgrid, sblock, slds, ctx->stream, sa); \
+            else hipLaunchKernelGGL((wb_k_scan_stream<T, V, N, 6, 4, false>), mgrid, sblock, slds, ctx->stream, sa)
 #define WB_SCAN_N(T, V) \
             switch (p.nlevels) { case 1: WB_STREAM_ANY(T, V, 1); break; case 2: WB_STREAM_ANY(T, V, 2); break; \
                                  case 3: WB_STREAM_ANY(T, V, 3); break; default: WB_STREAM_ANY(T, V, 4); break; }
@@ -518,7 +529,9 @@ static int run_phase1(wb_batch* b) {
             if (p.dtype == 0) { WB_BUILD_N(float) } else { WB_BUILD_N(double) }
 #undef WB_BUILD_N
 #undef WB_BUILD_LAUNCH
-        } else {
+            }
+        }
+        if (!streamed) {
         dzero_flush(ctx);
         const dim3 grid((unsigned)nwg);
 #define WB_SCAN_LAUNCH(T, V, N) hipLaunchKernelGGL((wb_k_scan<T, V, N>), grid, block, 0, ctx->stream, sa)
@@ -2350,6 +2363,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "keep_device")) { ctx->keep_device = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
     if (!strcmp(name, "scan_keys_only")) { ctx->scan_keys_only = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "scan_f64_fast")) { ctx->scan_f64_fast = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     if (!strcmp(name, "scan_grid_mult")) { ctx->scan_grid_mult = value; return 0; }
     if (!strcmp(name, "scan_dynamic")) { ctx->scan_dynamic = value ? 1 : 0; return 0; }

@@ -49,6 +49,7 @@ struct wb_ctx {
     int scan_grid_mult = 1;                   // workgroups of the streaming scan = resident slots x this (capped at the work items)
     int scan_dynamic = 1;                     // streaming scan: a workgroup takes the next work item when it is free (0: items dealt out by workgroup number)
     int scan_keys_only = 1;                   // streaming scan (13 x 4 float kernel): a captured patch is stored as its key alone, the build kernel reads the values from the field (0: key + ten values, 44 B)
+    int scan_f64_fast = 1;                    // streaming scan, float64 fields: 8 x 4 kernel with the LDS halo exchange and patches as keys only (0: the scalar-halo 6 x 4 kernel with key + ten values, rounds 2-5)
     int scan_variant = 2;                     // streaming scan, float fields: ring depth x waves per SIMD -- 0: 8 x 6, 1: 10 x 5, 2: 13 x 4 (default), 3: 6 x 8, 4: 9 x 5, 5: 8 x 5
     int boxcom_per_cu = 12;                   // persistent grid of wb_k_box_com: single-wave workgroups per CU (what its LDS admits)
     int boxcom_after = 1;                     // when wb_k_box_com runs on the side stream: 0 right behind wb_k_overturn (beside wb_k_streamer_prep), 1 behind wb_k_streamer_prep, 2 behind wb_k_streamer_pairs2 of the main stream

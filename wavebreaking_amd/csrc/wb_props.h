@@ -818,19 +818,27 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
                     if (dt < (wb_u128)top) top = (unsigned long long)dt;
                 }
                 wb_dbl_split((double)x1 * wp, &mp, &ep);
-                int eprev = (r > 0 && mp) ? ep : (r > 0 ? -100000 : 100000);
+                // the row's terms x * w: mantissas of a run of equal exponent are added in 64 bits (at most 2047 of them), the run goes
+                // into the 128-bit total when the exponent changes; `edge` is kept in the term's OWN units (never more than its
+                // distance in units of 2^ue: the comparison below stays on the safe side)
+                int ecur = (r > 0 && mp) ? ep : (r > 0 ? -100000 : 100000);      // exponent of the term in front (the sequence's, across the rows)
+                unsigned long long acc = 0ull;
+                int cnt = 0;
                 for (int x = x0; x <= x1; ++x) {
                     const double p = (double)x * w;
                     wb_dbl_split(p, &m, &e);
-                    if (!m) { eprev = -100000; continue; }
-                    Tx += (wb_u128)m << (e - ue);
-                    if (e > eprev) Bx += 1ull << (e - ue);
-                    wb_u128 dt = (wb_u128)((1ull << 53) - m) << (e - ue);
-                    const wb_u128 db = (wb_u128)(m - (1ull << 52)) << (e - ue);
-                    if (db < dt) dt = db;
-                    if (dt < (wb_u128)top) top = (unsigned long long)dt;
-                    eprev = e;
+                    if (!m) continue;
+                    if (e != ecur || cnt == 2047) {
+                        if (cnt) Tx += (wb_u128)acc << (ecur - ue);
+                        if (e > ecur) Bx += 1ull << (e - ue);
+                        acc = 0ull; cnt = 0; ecur = e;
+                    }
+                    acc += m; ++cnt;
+                    const unsigned long long dtop = (1ull << 53) - m, dbot = m - (1ull << 52);
+                    const unsigned long long dd = dtop < dbot ? dtop : dbot;
+                    if (dd < top) top = dd;
                 }
+                if (cnt) Tx += (wb_u128)acc << (ecur - ue);
             }
         }
         // (the chained passes' segment arrays are free here: 12 words per lane)

@@ -502,10 +502,11 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
     // one 16 KB pool: key + values: cb[1024] + lcase[1024]; keys only: cb[256] + lcase[256] + the patches' ten values (10 KB) -- the
     // kernel's LDS decides how many of its 8 760 workgroups a CU holds beside the other batch's kernels
     __shared__ unsigned long long wb_build_pool[2 * WB_BUILD_CHUNK];
-    const int CH = a.keys_only ? WB_BUILD_KO_CHUNK : WB_BUILD_CHUNK;
+    constexpr int KOCH = sizeof(T) == 4 ? WB_BUILD_KO_CHUNK : WB_BUILD_KO_CHUNK / 2;    // keys only: patches per chunk (float64: 128 -- ten values of 8 bytes each, 10 KB as well)
+    const int CH = a.keys_only ? KOCH : WB_BUILD_CHUNK;
     unsigned long long* const cb = wb_build_pool;              // per patch: segments for the base list | periodic-copy list << 32 -> scan
     unsigned long long* const lcase = wb_build_pool + CH;
-    float* const lvf = (float*)(wb_build_pool + 2 * CH);      // (keys only: 2 * 256 words in front, 10 * 256 floats = 10 KB behind them: inside the pool)
+    T* const lvf = (T*)(wb_build_pool + 2 * CH);              // (keys only: 2 * KOCH words in front, 10 * KOCH values = 10 KB behind them: inside the pool)
     __shared__ int boff[17];                                   // first patch of a band in the concatenation of the bands' lists
     const int g = blockIdx.x;
     const int NS = a.nstrips, NSB = a.nwork;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                     v[5 + k] = f0[nlon + cc];
                 }
 #pragma unroll
-                for (int k = 0; k < 10; ++k) lvf[k * WB_BUILD_KO_CHUNK + i] = (float)v[k];     // (keys only runs on float fields)
+                for (int k = 0; k < 10; ++k) lvf[k * KOCH + i] = v[k];
             } else {
                 const T* d = (const T*)a.cap_v + gl * cs * 10 + li;
 #pragma unroll
@@ -627,8 +628,8 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                     if (ns) {
                         T ul, ur, ll, lr;
                         if (a.keys_only) {
-                            ul = (T)lvf[k * WB_BUILD_KO_CHUNK + i]; ur = (T)lvf[(k + 1) * WB_BUILD_KO_CHUNK + i];
-                            ll = (T)lvf[(5 + k) * WB_BUILD_KO_CHUNK + i]; lr = (T)lvf[(6 + k) * WB_BUILD_KO_CHUNK + i];
+                            ul = lvf[k * KOCH + i]; ur = lvf[(k + 1) * KOCH + i];
+                            ll = lvf[(5 + k) * KOCH + i]; lr = lvf[(6 + k) * KOCH + i];
                         } else { ul = d[k * cs]; ur = d[(k + 1) * cs]; ll = d[(5 + k) * cs]; lr = d[(6 + k) * cs]; }
                         wb_store_square<T>(a.stg_k + base, (T*)a.stg_v + base * 4, a.cap_strip, W, r, c0 + k, cs2, ns, ul, ur, ll, lr, mine);
                         if (has_copy && c0 + k < a.padd - 1)

@@ -66,6 +66,30 @@ __device__ inline float wb_lds_wait_eq(uint32_t addr_tag, uint32_t tag, uint32_t
         : "=&v"(tmp), "=&v"(val), "+s"(budget) : "v"(addr_tag), "s"(tag), "v"(addr_val) : "vcc", "scc", "memory");
     return val;
 }
+// ... the same for a 64-bit value (float64 fields, round 6)
+__device__ inline double wb_lds_wait_eq64(uint32_t addr_tag, uint32_t tag, uint32_t addr_val, uint32_t& budget) {
+    uint32_t tmp;
+    double val;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %3\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, %0, %4\n\t"
+        "s_cbranch_vccnz 2f\n\t"
+        "s_cmp_eq_u32 %2, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_u32 %2, %2, 1\n\t"
+        "s_sleep 1\n\t"
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "ds_read_b64 %1, %5\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : "=&v"(tmp), "=&v"(val), "+s"(budget) : "v"(addr_tag), "s"(tag), "v"(addr_val) : "vcc", "scc", "memory");
+    return val;
+}
+template <typename T> __device__ inline T wb_lds_wait_val(uint32_t addr_tag, uint32_t tag, uint32_t addr_val, uint32_t& budget);
+template <> __device__ inline float wb_lds_wait_val<float>(uint32_t addr_tag, uint32_t tag, uint32_t addr_val, uint32_t& budget) { return wb_lds_wait_eq(addr_tag, tag, addr_val, budget); }
+template <> __device__ inline double wb_lds_wait_val<double>(uint32_t addr_tag, uint32_t tag, uint32_t addr_val, uint32_t& budget) { return wb_lds_wait_eq64(addr_tag, tag, addr_val, budget); }
 #ifndef WB_STREAM_SPIN_BUDGET
 #define WB_STREAM_SPIN_BUDGET (1u << 22)     // sleeps of ~64 clocks + an LDS read each: a few tenths of a second per wave and launch
 #endif
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(1024, WPS) void wb_k_scan_stream(WbScanArgs a) {
             pubv[r] = x0;
             pubt[r] = tag;
             if (hsrc < 0) return hh;
-            return (T)wb_lds_wait_eq((uint32_t)(uintptr_t)(srct + r), tag, (uint32_t)(uintptr_t)(srcv + r), spin_budget);
+            return wb_lds_wait_val<T>((uint32_t)(uintptr_t)(srct + r), tag, (uint32_t)(uintptr_t)(srcv + r), spin_budget);
         };
         T p4, pmn, pmx;                                       // previous row, completed: its halo, minimum and maximum
         auto finish = [&](const V4& qq, T hh, T& v4, T& mn, T& mx) {

@@ -204,6 +204,19 @@ def _immutable(arr):
     return isinstance(o, bytes)
 
 
+def _head(arr):
+    return (arr.__array_interface__["data"][0], arr.shape, arr.dtype.str)
+
+
+def _timed_fingerprint(lib, arr):
+    import time
+    tic = time.perf_counter()
+    fp = lib.fingerprint(arr)                    # (releases the GIL; several host threads of its own)
+    FINGERPRINT_STATS["full"] += 1
+    FINGERPRINT_STATS["seconds"] += time.perf_counter() - tic
+    return fp
+
+
 def _array_key(arr, ctx=None, owner=None):
     """cache key of a cube: buffer address, shape, dtype and a fingerprint of its bytes -- of ALL of them unless the buffer
     cannot change (not writeable) or was registered with keep_inputs().  ``owner``: the thread identifier of the CALL the key
@@ -407,6 +420,8 @@ def release_inputs():
             _drop_resident(ctx, key)
 
 
+# the fingerprint of a cube that is certainly not on the device is taken BESIDE its upload (WB_FINGERPRINT_BESIDE_UPLOAD=0: first)
+FINGERPRINT_BESIDE_UPLOAD = os.environ.get("WB_FINGERPRINT_BESIDE_UPLOAD", "1") != "0"
 # a call with two cubes of at least this many bytes takes their keys on two threads (tests lower it)
 PARALLEL_KEYS_BYTES = 64 << 20
 
@@ -437,6 +452,40 @@ def resident_inputs(ctx, field, intensity, block):
     _purge_dead(ctx)
     resident, _ = _caches(ctx)
     arrs = [a for a in (field, intensity) if a is not None]
+    nt = field.shape[0]
+    # Cubes that are CERTAINLY not on the device (no entry of this address, shape and dtype): their upload starts at once and the
+    # fingerprint that becomes part of their cache key is taken beside it, on a pool thread (both read the cube once: 1.5 GB at
+    # 55 GB/s over PCIe against 200-300 GB/s of hashing) -- until round 6 the call hashed first (10-15 ms for a year's two
+    # cubes) and uploaded then.
+    if FINGERPRINT_BESIDE_UPLOAD and not (PIPELINED_UPLOAD and block < nt):
+        plan = []
+        for a in arrs:
+            head = _head(a)
+            if not (_immutable(a) or _is_promised(a)) and not any(k[:3] == head for k in resident):
+                plan.append((a, head, _fp_pool().submit(_timed_fingerprint, ctx.L, a)))
+            else:
+                plan.append((a, None, None))
+        if any(f is not None for _, _, f in plan):
+            keys = [None if f is not None else _array_key(a, ctx) for a, _, f in plan]
+            ents = []
+            for i, (a, head, fut) in enumerate(plan):
+                mine = [k for k in keys if k is not None]
+                if fut is None:
+                    ents.append(resident_input(ctx, a, keys[i], protect=mine))
+                    continue
+                fits = _make_room(ctx, a.nbytes, set(mine))
+                _tick[0] += 1
+                ptr = ctx.to_device(a)
+                key = head + ("full", fut.result())
+                ent = dict(ptr=ptr, nbytes=a.nbytes, key=key, tick=_tick[0])
+                if fits and key not in resident:
+                    resident[key] = ent
+                    _watch(ctx, a, key)
+                else:
+                    ent["transient"] = True
+                keys[i] = key
+                ents.append(ent)
+            return ents[0], (ents[1] if intensity is not None else None)
     if len(arrs) == 2 and arrs[0].nbytes >= PARALLEL_KEYS_BYTES:
         # the two cubes' fingerprints side by side (wb_fingerprint releases the GIL; each uses its own host threads); the
         # pending entries they leave are the CALLING thread's -- it is the one that runs verify_pending / discard_pending
@@ -447,7 +496,6 @@ def resident_inputs(ctx, field, intensity, block):
     else:
         keys = [_array_key(a, ctx) for a in arrs]
     fresh = [k not in resident for k in keys]
-    nt = field.shape[0]
     if not any(fresh) or not PIPELINED_UPLOAD or block >= nt:
         ents = [resident_input(ctx, a, k, protect=keys) for a, k in zip(arrs, keys)]
         return ents[0], (ents[1] if intensity is not None else None)
