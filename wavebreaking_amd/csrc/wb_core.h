@@ -457,6 +457,115 @@ WB_HD inline void wb_dbl_split(double v, unsigned long long* m, int* e) {
     if (ef == 0) { *m = fr; *e = -1074; } else { *m = fr | (1ull << 52); *e = ef - 1075; }
 }
 
+
+#ifndef WB_BOXCOM_BOUND
+#define WB_BOXCOM_BOUND 1            // 1: wb_k_overturn settles a box whose three sums are decided by the exact totals of their terms and queues the others for
+                                     // wb_k_box_com's chained passes; 0 (a test build): every such box is queued; 2 (a test build): every box is queued and
+                                     // wb_k_box_com evaluates it both ways -- a box on which the two differ is counted in dbg[23] (must be 0)
+#endif
+// ---- the overturning boxes' centre-of-mass sums from the EXACT totals of their terms (wb_k_overturn, wb_k_box_com; the argument
+// is in wb_props.h in front of wb_k_box_com): 128-bit fixed point in units of 2^ue
+typedef unsigned __int128 wb_u128;
+WB_HD inline wb_u128 wb_fix128(double v, int ue) {
+    unsigned long long m; int e;
+    wb_dbl_split(v, &m, &e);
+    if (!m) return (wb_u128)0;
+    if (e >= ue) return (wb_u128)m << (e - ue);
+    // a small multiple of 2^ue (a compensation term): its 53-bit mantissa ends in zeros
+    return ue - e > 63 ? (wb_u128)0 : (wb_u128)(m >> (ue - e));
+}
+// state (s, c) of the compensated sum whose exact running total is E * 2^ue, every step having been exact: s = RN(E),
+// c = s - E.  false: c does not fit a double (such a state cannot have been reached by exact steps)
+WB_HD inline bool wb_state_from_exact(wb_u128 E, int ue, double* s, double* c) {
+    if (E == 0) { *s = 0.0; *c = 0.0; return true; }
+    const unsigned long long hi = (unsigned long long)(E >> 64), lo = (unsigned long long)E;
+    const int msb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
+    if (msb <= 52) { *s = ldexp((double)lo, ue); *c = 0.0; return true; }
+    const int sh = msb - 52;
+    if (sh > 53) return false;
+    unsigned long long q = (unsigned long long)(E >> sh);
+    const wb_u128 rem = E - ((wb_u128)q << sh), half = (wb_u128)1 << (sh - 1);
+    const bool up = rem > half || (rem == half && (q & 1ull));
+    if (up) q += 1;
+    *s = ldexp((double)q, sh + ue);
+    if (up) *c = ldexp((double)(unsigned long long)(((wb_u128)q << sh) - E), ue);
+    else *c = rem ? -ldexp((double)(unsigned long long)rem, ue) : 0.0;
+    return true;
+}
+
+
+// totals of a set of rows of a box: T[3] exact totals of the terms of the three sums (areas: w, x_com: x * w, y_com: y * w, each
+// rounded once as the reference rounds it), B[3] the bound on what the compensated sums' inexact steps can add, edge the smallest
+// distance of a term to the top or the bottom of its binade (in the term's own units: never more than in units of 2^ue)
+struct WbBoxRows { wb_u128 T[3]; unsigned long long B[3]; unsigned long long edge; };
+WB_HD inline void wb_box_rows_clear(WbBoxRows* o) { o->T[0] = o->T[1] = o->T[2] = 0; o->B[0] = o->B[1] = o->B[2] = 0; o->edge = ~0ull; }
+// row y of the box [x0, x1] x [.., ..] added to o.  first: the box's first row (its sums start from s = c = 0: that step is exact)
+WB_HD inline void wb_box_row_terms(const double* wlat, int y, bool first, int x0, int x1, int ue, WbBoxRows* o) {
+    const int cols = x1 - x0 + 1;
+    const double w = wlat[y], yw = (double)y * w;
+    // the term in front of this row's first, in each of the three sequences
+    const double wp = first ? 0.0 : wlat[y - 1];
+    unsigned long long m, mp; int e, ep;
+    // a step whose y = v - c is rounded costs at most ulp(v): y is rounded to half a unit of its own binade, which is v's or -- c < 0
+    // -- the next one up.  It can be rounded only where v's unit is coarser than the unit c is a multiple of: the unit of the
+    // PREVIOUS term's y -- that term's own unit, unless its y fell into the binade below (the term within |c| of the bottom of its
+    // binade) -- or where v - c leaves v's binade upwards (v within |c| of the top): `edge`
+    wb_dbl_split(w, &m, &e);
+    wb_dbl_split(wp, &mp, &ep);
+    if (m) {
+        o->T[0] += ((wb_u128)m * (unsigned)cols) << (e - ue);
+        if (!first && (!mp || e > ep)) o->B[0] += 1ull << (e - ue);
+        const unsigned long long dtop = (1ull << 53) - m, dbot = m - (1ull << 52);
+        const unsigned long long dd = dtop < dbot ? dtop : dbot;
+        if (dd < o->edge) o->edge = dd;
+    }
+    wb_dbl_split(yw, &m, &e);
+    wb_dbl_split((double)(y - 1) * wp, &mp, &ep);
+    if (m) {
+        o->T[2] += ((wb_u128)m * (unsigned)cols) << (e - ue);
+        if (!first && (!mp || e > ep)) o->B[2] += 1ull << (e - ue);
+        const unsigned long long dtop = (1ull << 53) - m, dbot = m - (1ull << 52);
+        const unsigned long long dd = dtop < dbot ? dtop : dbot;
+        if (dd < o->edge) o->edge = dd;
+    }
+    wb_dbl_split((double)x1 * wp, &mp, &ep);
+    // the row's terms x * w: mantissas of a run of equal exponent are added in 64 bits (at most 2047 of them), the run goes into
+    // the 128-bit total when the exponent changes
+    int ecur = (!first && mp) ? ep : (!first ? -100000 : 100000);      // exponent of the term in front (the sequence's, across the rows)
+    unsigned long long acc = 0ull;
+    int cnt = 0;
+    for (int x = x0; x <= x1; ++x) {
+        const double p = (double)x * w;
+        wb_dbl_split(p, &m, &e);
+        if (!m) continue;
+        if (e != ecur || cnt == 2047) {
+            if (cnt) o->T[1] += (wb_u128)acc << (ecur - ue);
+            if (e > ecur) o->B[1] += 1ull << (e - ue);
+            acc = 0ull; cnt = 0; ecur = e;
+        }
+        acc += m; ++cnt;
+        const unsigned long long dtop = (1ull << 53) - m, dbot = m - (1ull << 52);
+        const unsigned long long dd = dtop < dbot ? dtop : dbot;
+        if (dd < o->edge) o->edge = dd;
+    }
+    if (cnt) o->T[1] += (wb_u128)acc << (ecur - ue);
+}
+// the three sums, if the totals decide them: S = RN(T + d) with |d| <= B, and no term so close to an edge of its binade that a
+// step outside the bound's accounting could have been rounded (|c| <= ulp(S) / 2 = 2^(msb - 53) units; four times that is asked for)
+WB_HD inline bool wb_box_decide(const wb_u128* T, const wb_u128* Bin, unsigned long long edge, int ue, double* sv) {
+    for (int q = 0; q < 3; ++q) {
+        const wb_u128 B = Bin[q] + 1;                                 // (never an empty interval)
+        if (T[q] <= B) return false;
+        double s0, s1, c0, c1;
+        if (!(wb_state_from_exact(T[q] - B, ue, &s0, &c0) && wb_state_from_exact(T[q] + B, ue, &s1, &c1) && s0 == s1)) return false;
+        sv[q] = s0;
+        const unsigned long long hi = (unsigned long long)(T[q] >> 64), lo = (unsigned long long)T[q];
+        const int msb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo | 1ull);
+        if (msb > 52 && (msb - 52 >= 63 || edge <= (2ull << (msb - 52)))) return false;
+    }
+    return true;
+}
+
 WB_HD inline uint64_t wb_mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

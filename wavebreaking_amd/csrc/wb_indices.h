@@ -139,6 +139,9 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
     WB_SHARED(int, ifirst, WB_OT_CAP);
     WB_SHARED(int, ilast, WB_OT_CAP);
     WB_SHARED(int, gcount, 2);
+    WB_SHARED(int, need, WB_OT_CAP);             // boxes whose truncated centre of mass turns on the last bits of the reference's sums
+    WB_SHARED(int, elim, 2);                     // exponent range of a box's row weights
+    WB_SHARED(unsigned long long, bacc, 16);     // a box's exact totals: 3 x 4 limbs of 32 bits (added up as 64-bit words), 3 bounds, the edge distance
     int* box = a.ot_box + (size_t)s * WB_OT_CAP * 4;
     int* orient = a.ot_orient + (size_t)s * WB_OT_CAP;
 
@@ -252,8 +255,13 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
             }
             const double ulps = wb_com_ulps(rows);
             double* out = a.ot_sums + ((size_t)s * WB_OT_CAP + g) * 3;
+            need[g] = 0;
             if (cols > 0 && rows > 0 && (wb_trunc_unsafe(xc, areas, ulps) || wb_trunc_unsafe(yc, areas, ulps))) {
+#if WB_BOXCOM_BOUND >= 1
+                need[g] = 1;                                    // settled below from the exact totals of its terms, or queued
+#else
                 a.boxq[wb_atomic_add(&a.ctl->n_boxq, 1)] = s * WB_OT_CAP + (int)g;
+#endif
                 wb_atomic_add(&a.ctl->com_rechecks[1], 1);
             } else {
                 out[0] = areas;
@@ -262,6 +270,76 @@ WB_KERNEL(wb_k_overturn, WbOverturnArgs a) {
             }
         }
     WB_END_PFOR
+#if WB_BOXCOM_BOUND >= 1
+    // The reference's sums of such a box are decided by the EXACT totals of their terms unless a rounding boundary lies within
+    // the compensated summation's error bound of a total (the argument: wb_props.h in front of wb_k_box_com; the pieces:
+    // wb_core.h): a thread per row adds the row's terms up in 128-bit fixed point, the workgroup's totals go through LDS as 32-bit
+    // limbs, one thread decides.  98 % of the boxes of a 0.25 degree year end here; the rest -- a few dozen per pass -- are queued
+    // for wb_k_box_com's chained evaluation (until round 6 ALL of them were: 3 193 single-wave chains of ~10^5 instructions each
+    // beside the streamer kernels).
+    if (a.wlat) {
+    for (int g = 0; g < G; ++g) {
+        if (!need[g]) continue;                                 // (workgroup-uniform: LDS)
+        int x0 = gmin[g], y0 = ylo[g], x1 = gmax[g], y1 = yhi[g];
+        if (x0 < 0) x0 = 0;
+        if (y0 < 0) y0 = 0;
+        if (x1 > a.W - 1) x1 = a.W - 1;
+        if (y1 > a.nlat - 1) y1 = a.nlat - 1;
+        const int rows = y1 - y0 + 1;
+        WB_SINGLE
+        elim[0] = 4096; elim[1] = -4096;
+        for (int q = 0; q < 15; ++q) bacc[q] = 0ull;
+        bacc[15] = ~0ull;
+        WB_END_SINGLE
+        WB_PFOR(r, rows)
+            unsigned long long m; int ex;
+            wb_dbl_split(a.wlat[y0 + (int)r], &m, &ex);
+            if (m) { wb_atomic_min(&elim[0], ex); wb_atomic_max(&elim[1], ex); }
+        WB_END_PFOR
+        const int emin = elim[0], emax = elim[1];
+        // every term is below max(x1, y1) * w_max < 2^(emax + 53 + 16); the total of < 2^32 cells must stay below 2^127
+        const bool range_ok = !(emin > emax || (emax - emin) + 53 + 16 + 32 > 126);
+        if (range_ok) {
+            WB_PFOR(r, rows)
+                WbBoxRows o;
+                wb_box_rows_clear(&o);
+                wb_box_row_terms(a.wlat, y0 + (int)r, r == 0, x0, x1, emin, &o);
+                for (int q = 0; q < 3; ++q) {
+                    for (int limb = 0; limb < 4; ++limb) {
+                        const unsigned long long part = (unsigned long long)(o.T[q] >> (32 * limb)) & 0xFFFFFFFFull;
+                        if (part) wb_atomic_add(&bacc[4 * q + limb], part);
+                    }
+                    if (o.B[q]) wb_atomic_add(&bacc[12 + q], o.B[q]);
+                }
+                wb_atomic_min(&bacc[15], o.edge);
+            WB_END_PFOR
+        }
+        WB_SINGLE
+        bool sure = false;
+        double sv[3] = {0.0, 0.0, 0.0};
+        if (range_ok) {
+            wb_u128 T[3], B[3];
+            for (int q = 0; q < 3; ++q) {
+                T[q] = 0;
+                for (int limb = 0; limb < 4; ++limb) T[q] += (wb_u128)bacc[4 * q + limb] << (32 * limb);
+                B[q] = bacc[12 + q];
+            }
+            sure = wb_box_decide(T, B, bacc[15], emin, sv);
+        }
+        if (sure) {
+            double* out = a.ot_sums + ((size_t)s * WB_OT_CAP + g) * 3;
+            out[0] = sv[0]; out[1] = sv[1]; out[2] = sv[2];
+            wb_atomic_add(&a.ctl->box_bound, 1);
+#if WB_BOXCOM_BOUND == 2
+            a.boxq[wb_atomic_add(&a.ctl->n_boxq, 1)] = (s * WB_OT_CAP + g) | 0x40000000;     // (test build: the chained passes all the same, and the two compared)
+#endif
+        } else {
+            a.boxq[wb_atomic_add(&a.ctl->n_boxq, 1)] = s * WB_OT_CAP + g;
+        }
+        WB_END_SINGLE
+    }
+    }
+#endif
     WB_SINGLE
     a.ot_n[s] = G;
     WB_END_SINGLE

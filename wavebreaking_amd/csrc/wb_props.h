@@ -662,15 +662,10 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
 #ifndef WB_BOXCOM_FORCE_WALK
 #define WB_BOXCOM_FORCE_WALK 0       // 1 (a test build): no chunk is predicted, one lane walks them all
 #endif
-#ifndef WB_BOXCOM_BOUND
-#define WB_BOXCOM_BOUND 1            // 1: a box whose three sums are decided by the exact totals of their terms (below) skips the chained passes; 0 (a test
-                                     // build): every queued box takes them; 2 (a test build): both, and a box the two disagree on is counted in dbg[23]
-#endif
 #ifndef WB_BOXCOM_SEGS
 #define WB_BOXCOM_SEGS 6             // binade steps of x * w along a row the prediction follows (x < 4096 admits 12: a row with more is walked;
                                      // 6 halve the kernel's LDS -- 13 KB a wave -- and what it takes from the all-pairs kernel it runs beside)
 #endif
-typedef unsigned __int128 wb_u128;
 struct WbBoxComArgs {
     int nlat, W;
     WbCtl* ctl;                   // n_boxq queued boxes, boxq_cursor; com_rechecks[2]: boxes with a chunk walked by one lane
@@ -679,33 +674,6 @@ struct WbBoxComArgs {
     const double* wlat;
     double* ot_sums;              // [nsel][WB_OT_CAP][3] areas, x_com, y_com
 };
-WB_HD inline wb_u128 wb_fix128(double v, int ue) {
-    unsigned long long m; int e;
-    wb_dbl_split(v, &m, &e);
-    if (!m) return (wb_u128)0;
-    if (e >= ue) return (wb_u128)m << (e - ue);
-    // a small multiple of 2^ue (a compensation term): its 53-bit mantissa ends in zeros
-    return ue - e > 63 ? (wb_u128)0 : (wb_u128)(m >> (ue - e));
-}
-// state (s, c) of the compensated sum whose exact running total is E * 2^ue, every step having been exact: s = RN(E),
-// c = s - E.  false: c does not fit a double (such a state cannot have been reached by exact steps)
-WB_HD inline bool wb_state_from_exact(wb_u128 E, int ue, double* s, double* c) {
-    if (E == 0) { *s = 0.0; *c = 0.0; return true; }
-    const unsigned long long hi = (unsigned long long)(E >> 64), lo = (unsigned long long)E;
-    const int msb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo);
-    if (msb <= 52) { *s = ldexp((double)lo, ue); *c = 0.0; return true; }
-    const int sh = msb - 52;
-    if (sh > 53) return false;
-    unsigned long long q = (unsigned long long)(E >> sh);
-    const wb_u128 rem = E - ((wb_u128)q << sh), half = (wb_u128)1 << (sh - 1);
-    const bool up = rem > half || (rem == half && (q & 1ull));
-    if (up) q += 1;
-    *s = ldexp((double)q, sh + ue);
-    if (up) *c = ldexp((double)(unsigned long long)(((wb_u128)q << sh) - E), ue);
-    else *c = rem ? -ldexp((double)(unsigned long long)rem, ue) : 0.0;
-    return true;
-}
-
 WB_DEV inline int wb_dbl_exp(double v) { unsigned long long m; int e; wb_dbl_split(v, &m, &e); return m ? e : -100000; }
 
 // WB_BOXCOM_G boxes at a time per workgroup (one wave), WB_BOXCOM_ROWS rows of each per chunk: passes 1 and 3 have a lane per
@@ -722,10 +690,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     WB_SHARED(double, st, 6 * WB_BOXCOM_G * (WB_BOXCOM_ROWS + 1));   // per chain and box: state s, c at the start of every row of the chunk (+ after its last)
     WB_SHARED(int, bx, 12 * WB_BOXCOM_G);                         // per box: x0, y0, x1, y1, rows, first row of the chunk, rows of the chunk, unit exponent, largest exponent, whole box by one lane, this chunk by one lane, a chunk was walked
     WB_SHARED(int, ctl, 2);                                      // [0] the first queue entry taken, [1] some box has a chunk left
-#if WB_BOXCOM_BOUND == 2
-    WB_SHARED(double, bsv, 3 * WB_BOXCOM_G);                     // (test build) the three sums as the bound gave them
-    WB_SHARED(int, bset, WB_BOXCOM_G);
-#endif
+
     WB_BSTAMP_BEGIN                                              // development stamps: 0 closed forms, 1 .. 3 the passes, 4 the one-lane walks / output
     // persistent: a workgroup (one wave) takes the next WB_BOXCOM_G queued boxes until the queue is empty -- only the boxes that
     // need the reference-order sums are here (wb_k_overturn queued them), whatever contour they belong to
@@ -739,7 +704,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
         int* b = bx + 12 * g;
         int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
         if (q0 + (int)g < nq) {
-            const int* d = a.ot_box + (size_t)a.boxq[q0 + (int)g] * 4;
+            const int* d = a.ot_box + (size_t)(a.boxq[q0 + (int)g] & 0x3FFFFFFF) * 4;
             x0 = d[0]; y0 = d[1]; x1 = d[2]; y1 = d[3];
             if (x0 < 0) x0 = 0;
             if (y0 < 0) y0 = 0;
@@ -767,130 +732,18 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
         for (int q = 0; q < 6; ++q) WB_BOXCOM_ST(q, g, 0) = 0.0;            // the sums start at s = c = 0: certain
     WB_END_PFOR
     WB_BSTAMP(a.ctl, 0);
-#if WB_BOXCOM_BOUND
-    // Most boxes need no chain at all.  The value pandas returns is s after the last step, and s = RN(E) with E the running total
-    // as the compensated sum carries it: E grows by exactly the term v at every step except where y = v - c is rounded, and then
-    // by v + e1 with |e1| <= ulp(y) / 2 (t - s and (t - s) - y are exact: c is the exact error of s + y).  y = v - c can need
-    // rounding only (i) where v's unit is coarser than c's -- c is a multiple of the finest unit among the terms since the last
-    // such step, so: at a row's first term (the weight changes) and where the terms x * w of a row step up into a higher binade
-    // -- or (ii) where v - c leaves v's binade upwards: v within |c| <= ulp(S) / 2 of the next power of two.  So
-    //     S = RN(T + d),   T = the EXACT total of the (rounded) terms,   |d| <= B = sum over the steps of kind (i) of ulp(v)
-    // (twice the bound, for slack), and T, B and "no term of kind (ii)" are sums / minima over the cells -- a lane per row, no
-    // chain.  Where RN(T - B) == RN(T + B) for each of the three sums that IS the reference's value, bit for bit; the boxes for
-    // which it is not (a rounding boundary within B of T: a few per cent, B / ulp(S) ~ 2 / columns) take the chained passes below.
-    // (WB_BOXCOM_BOUND = 2, a test build: every box takes both and a disagreement is counted.)
-    WB_PFOR(l, WB_BOXCOM_NL)
-        const int g = (int)l / WB_BOXCOM_ROWS, r0 = (int)l % WB_BOXCOM_ROWS;
-        const int* b = bx + 12 * g;
-        wb_u128 Ta = 0, Tx = 0, Ty = 0;
-        unsigned long long Ba = 0, Bx = 0, By = 0;
-        unsigned long long top = ~0ull;                                    // `edge`: smallest distance of a term to the top or the bottom of its binade, in units of 2^ue (saturated)
-        if (!b[9]) {
-            const int x0 = b[0], x1 = b[2], ue = b[7], cols = x1 - x0 + 1;
-            for (int r = r0; r < b[4]; r += WB_BOXCOM_ROWS) {
-                const int y = b[1] + r;
-                const double w = a.wlat[y], yw = (double)y * w;
-                // the term in front of this row's first, in each of the three sequences (none in front of the box's first row: the
-                // sums start from s = c = 0, that step is exact)
-                const double wp = r > 0 ? a.wlat[y - 1] : 0.0;
-                unsigned long long m, mp; int e, ep;
-                // a step of kind (i) costs at most ulp(v): y = v - c is rounded to half a unit of its own binade, which is v's or
-                // -- c < 0 -- the next one up.  The unit c is a multiple of is the unit of the PREVIOUS term's y: that term's own
-                // unit, unless its y fell into the binade below (the term within |c| of the bottom of its binade: `edge` below)
-                wb_dbl_split(w, &m, &e);
-                wb_dbl_split(wp, &mp, &ep);
-                if (m) {
-                    Ta += ((wb_u128)m * (unsigned)cols) << (e - ue);
-                    if (r > 0 && (!mp || e > ep)) Ba += 1ull << (e - ue);
-                    wb_u128 dt = (wb_u128)((1ull << 53) - m) << (e - ue);
-                    const wb_u128 db = (wb_u128)(m - (1ull << 52)) << (e - ue);
-                    if (db < dt) dt = db;
-                    if (dt < (wb_u128)top) top = (unsigned long long)dt;
-                }
-                wb_dbl_split(yw, &m, &e);
-                wb_dbl_split((double)(y - 1) * wp, &mp, &ep);
-                if (m) {
-                    Ty += ((wb_u128)m * (unsigned)cols) << (e - ue);
-                    if (r > 0 && (!mp || e > ep)) By += 1ull << (e - ue);
-                    wb_u128 dt = (wb_u128)((1ull << 53) - m) << (e - ue);
-                    const wb_u128 db = (wb_u128)(m - (1ull << 52)) << (e - ue);
-                    if (db < dt) dt = db;
-                    if (dt < (wb_u128)top) top = (unsigned long long)dt;
-                }
-                wb_dbl_split((double)x1 * wp, &mp, &ep);
-                // the row's terms x * w: mantissas of a run of equal exponent are added in 64 bits (at most 2047 of them), the run goes
-                // into the 128-bit total when the exponent changes; `edge` is kept in the term's OWN units (never more than its
-                // distance in units of 2^ue: the comparison below stays on the safe side)
-                int ecur = (r > 0 && mp) ? ep : (r > 0 ? -100000 : 100000);      // exponent of the term in front (the sequence's, across the rows)
-                unsigned long long acc = 0ull;
-                int cnt = 0;
-                for (int x = x0; x <= x1; ++x) {
-                    const double p = (double)x * w;
-                    wb_dbl_split(p, &m, &e);
-                    if (!m) continue;
-                    if (e != ecur || cnt == 2047) {
-                        if (cnt) Tx += (wb_u128)acc << (ecur - ue);
-                        if (e > ecur) Bx += 1ull << (e - ue);
-                        acc = 0ull; cnt = 0; ecur = e;
-                    }
-                    acc += m; ++cnt;
-                    const unsigned long long dtop = (1ull << 53) - m, dbot = m - (1ull << 52);
-                    const unsigned long long dd = dtop < dbot ? dtop : dbot;
-                    if (dd < top) top = dd;
-                }
-                if (cnt) Tx += (wb_u128)acc << (ecur - ue);
-            }
-        }
-        // (the chained passes' segment arrays are free here: 12 words per lane)
-        seglo[0 * WB_BOXCOM_NL + l] = (unsigned long long)Ta; seghi[0 * WB_BOXCOM_NL + l] = (unsigned long long)(Ta >> 64);
-        seglo[1 * WB_BOXCOM_NL + l] = (unsigned long long)Tx; seghi[1 * WB_BOXCOM_NL + l] = (unsigned long long)(Tx >> 64);
-        seglo[2 * WB_BOXCOM_NL + l] = (unsigned long long)Ty; seghi[2 * WB_BOXCOM_NL + l] = (unsigned long long)(Ty >> 64);
-        seglo[3 * WB_BOXCOM_NL + l] = Ba; seghi[3 * WB_BOXCOM_NL + l] = Bx;
-        seglo[4 * WB_BOXCOM_NL + l] = By; seghi[4 * WB_BOXCOM_NL + l] = top;
-    WB_END_PFOR
-    WB_PFOR(g, WB_BOXCOM_G)
-        int* b = bx + 12 * g;
-#if WB_BOXCOM_BOUND == 2
-        bset[g] = 0;
-#endif
-        if (!b[9] && b[4] > 0 && !WB_BOXCOM_FORCE_WALK) {
-            wb_u128 T[3] = {0, 0, 0};
-            wb_u128 B[3] = {0, 0, 0};
-            unsigned long long top = ~0ull;
-            for (int r = 0; r < WB_BOXCOM_ROWS; ++r) {
-                const int l = (int)g * WB_BOXCOM_ROWS + r;
-                for (int q = 0; q < 3; ++q) T[q] += ((wb_u128)seghi[q * WB_BOXCOM_NL + l] << 64) | seglo[q * WB_BOXCOM_NL + l];
-                B[0] += seglo[3 * WB_BOXCOM_NL + l]; B[1] += seghi[3 * WB_BOXCOM_NL + l]; B[2] += seglo[4 * WB_BOXCOM_NL + l];
-                if (seghi[4 * WB_BOXCOM_NL + l] < top) top = seghi[4 * WB_BOXCOM_NL + l];
-            }
-            bool sure = true;
-            double sv[3] = {0.0, 0.0, 0.0};
-            for (int q = 0; q < 3 && sure; ++q) {
-                double s0, s1, c0, c1;
-                B[q] += 1;                                                 // (never an empty interval)
-                if (T[q] <= B[q]) { sure = false; break; }
-                sure = wb_state_from_exact(T[q] - B[q], b[7], &s0, &c0) && wb_state_from_exact(T[q] + B[q], b[7], &s1, &c1) && s0 == s1;
-                sv[q] = s0;
-                // (ii): |c| <= ulp(S) / 2 = 2^(msb - 53) units when S needs rounding at all; no term may come that close to its binade's top
-                const unsigned long long hi = (unsigned long long)(T[q] >> 64), lo = (unsigned long long)T[q];
-                const int msb = hi ? 127 - __builtin_clzll(hi) : 63 - __builtin_clzll(lo | 1ull);
-                if (msb > 52 && (msb - 52 >= 63 || top <= (2ull << (msb - 52)))) sure = false;
-            }
-            if (sure) {
-#if WB_BOXCOM_BOUND == 2
-                // test build: remembered, the chained passes run all the same and the end compares
-                bsv[3 * g] = sv[0]; bsv[3 * g + 1] = sv[1]; bsv[3 * g + 2] = sv[2];
-                bset[g] = 1;
-#else
-                WB_BOXCOM_ST(0, g, 0) = sv[0]; WB_BOXCOM_ST(2, g, 0) = sv[1]; WB_BOXCOM_ST(4, g, 0) = sv[2];
-                b[5] = b[4];                                               // no rows left for the chunks below
-#endif
-                wb_atomic_add(&a.ctl->box_bound, 1);
-            }
-        }
-    WB_END_PFOR
-    WB_BSTAMP(a.ctl, 5);
-#endif
+    // (Most boxes never come here: wb_k_overturn settles a box whose three sums are decided by the EXACT totals of their terms --
+    //  the value pandas returns is s after the last step, and s = RN(E) with E the running total as the compensated sum carries it:
+    //  E grows by exactly the term v at every step except where y = v - c is rounded, and then by v + e1 with |e1| <= ulp(y) / 2
+    //  (t - s and (t - s) - y are exact: c is the exact error of s + y).  y = v - c can need rounding only (i) where v's unit is
+    //  coarser than c's -- c is a multiple of the unit of the previous term's y, so: where the sequence of terms steps up into a
+    //  higher binade -- or (ii) where v - c leaves v's binade (v within |c| <= ulp(S) / 2 of an edge of it).  So S = RN(T + d), T the
+    //  exact total of the rounded terms, |d| <= B = the sum of ulp(v) over the steps of kind (i), and T, B and "no term of kind
+    //  (ii)" are sums / minima over the cells: no chain.  Where RN(T - B) == RN(T + B) for each of the three sums that IS the
+    //  reference's value, bit for bit (wb_core.h: wb_box_row_terms, wb_box_decide); the boxes for which it is not -- a rounding
+    //  boundary within B of T: 1.5 % of them at 0.25 degree, 6 % at 1 degree -- are queued for the chained passes below.  A build
+    //  with -DWB_BOXCOM_BOUND=2 queues EVERY box, marked with what the totals said, and counts the boxes on which the chained
+    //  evaluation differs in a single bit: none of 23 217 on the grids of profiles/r06_boxbound_check.txt.)
     // The boxes in chunks of WB_BOXCOM_ROWS rows.  A chunk starts from the TRUE state of the three sums (verified by the
     // previous chunk, or walked) in st[..][0]; if it verifies, its end state is true as well and becomes the next start; if
     // not (a rounding tie, an inexact step the prediction missed, more binade steps in a row than WB_BOXCOM_SEGS), one lane
@@ -1042,7 +895,7 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
     WB_PFOR(g, WB_BOXCOM_G)
         const int* b = bx + 12 * g;
         if (q0 + (int)g < nq) {
-            double* out = a.ot_sums + (size_t)a.boxq[q0 + (int)g] * 3;
+            double* out = a.ot_sums + (size_t)(a.boxq[q0 + (int)g] & 0x3FFFFFFF) * 3;
             double sa, sx, sy;
             if (b[9]) {                                              // exponents out of the fixed-point range: one lane walks every cell
                 double ca = 0.0, cx = 0.0, cy = 0.0;
@@ -1064,7 +917,8 @@ WB_KERNEL(wb_k_box_com, WbBoxComArgs a) {
             }
             if (b[9] || b[11]) wb_atomic_add(&a.ctl->com_rechecks[2], 1);
 #if WB_BOXCOM_BOUND == 2
-            if (bset[g] && !(bsv[3 * g] == sa && bsv[3 * g + 1] == sx && bsv[3 * g + 2] == sy)) wb_atomic_add((unsigned long long*)&a.ctl->dbg[23], 1ull);
+            // test build: bit 30 of the queue entry marks a box wb_k_overturn settled from the exact totals (its sums stand in out[])
+            if ((a.boxq[q0 + (int)g] & 0x40000000) && !(out[0] == sa && out[1] == sx && out[2] == sy)) wb_atomic_add((unsigned long long*)&a.ctl->dbg[23], 1ull);
 #endif
             out[0] = sa;
             out[1] = sx;
