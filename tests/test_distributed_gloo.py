@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from oracle import synth
 from tests import helpers
@@ -18,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
 import os, sys
 import numpy as np
+import pytest
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 from oracle import synth
@@ -103,6 +105,7 @@ def test_shard_covers_everything():
 WORKER_FRAMES = r'''
 import os, sys, pickle
 import numpy as np
+import pytest
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 import wavebreaking_amd as wb
@@ -195,6 +198,7 @@ def test_sharded_calls_return_the_single_process_frames(tmp_path, monkeypatch):
 WORKER3 = r'''
 import os, sys
 import numpy as np
+import pytest
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 from oracle import synth
@@ -262,6 +266,7 @@ def test_three_ranks_one_without_steps_gather_complete_catalogue(tmp_path):
 WORKER_RECORD = r'''
 import os, sys
 import numpy as np
+import pytest
 sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 from oracle import synth
@@ -394,6 +399,7 @@ def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_
 FAIL_WORKER = r'''
 import os, sys, time
 import numpy as np
+import pytest
 sys.path.insert(0, sys.argv[1])
 import datetime
 import torch.distributed as dist
@@ -489,3 +495,82 @@ def test_a_rank_whose_worker_raises_or_that_dies_mid_record_ends_the_others_non_
             for r in (0, 2):
                 assert "Gather" in outs[r][1], outs
                 assert float(re.search(r"failed after ([0-9.]+) s", outs[r][1]).group(1)) < 30.0, outs
+
+
+WORKER_TRACK = r'''
+import os, sys, pickle
+import numpy as np
+import pytest
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import wavebreaking_amd as wb
+from tests import helpers, test_tracking as tt
+from wavebreaking_amd import _hip, engine
+from wavebreaking_amd import distributed as wd
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+engine._contexts[0] = _hip.Context(0, helpers.hostsim_library())
+out = {}
+for case, (seed, n, steps, tr) in enumerate(((9, 60, 9, None), (21, 48, 7, 12.0), (33, 30, 12, None))):
+    dates, polys, com = tt._tracking_case(seed, n, steps, shuffle=False)          # rows in time order, as calculate_* returns them
+    lonlat = [[np.c_[-180 + 0.25 * r[:, 0], -90 + 0.25 * r[:, 1]] for r in rs] for rs in polys]
+    # time-sharded: contiguous blocks of DATES (a date is never split between two ranks)
+    ud = np.unique(dates)
+    first, count = wd.shard(len(ud), rank, world)
+    mine = np.isin(dates, ud[first:first + count])
+    events = tt._frame(dates[mine], [p for p, m in zip(lonlat, mine) if m], com[mine])
+    events.attrs["wavebreaking_grid"] = dict(lon=(-180.0, 0.25), lat=(-90.0, 0.25))
+    for method, kw in (("by_overlap", dict(overlap=0.02)), ("by_distance", dict(distance=5000))):
+        got = wd.track_events_sharded(events, dist, time_range=tr, method=method, **kw)
+        if rank == 0:
+            out[(case, method)] = (got["label"].tolist(), [str(d) for d in got["date"].values], [tuple(c) for c in got["com"]])
+        else:
+            assert got is None
+if rank == 0:
+    pickle.dump(out, open(sys.argv[2], "wb"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_track_events_on_time_shards_equals_the_single_process_labels(tmp_path, monkeypatch, world):
+    """track_events (events.py:113-241) on a time-sharded catalogue: every rank tracks its own block of dates plus a halo of the
+    rows within time_range in front of it, the local labels are unified through the rows two ranks share -- the labels and the
+    row order of the whole record are those of the single-process call, for both methods, with time_range given or taken from
+    the smallest gap of the WHOLE record, with more dates than ranks and fewer rows than that"""
+    import pickle
+
+    import wavebreaking_amd as wb
+    from tests import test_tracking as tt
+    from wavebreaking_amd import engine
+    helpers.build_hostsim()
+    script = tmp_path / "worker_track.py"
+    script.write_text(WORKER_TRACK)
+    out = tmp_path / "track.pkl"
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = pickle.load(open(out, "rb"))
+    ctx = _hip.Context(0, helpers.hostsim_library())
+    monkeypatch.setitem(engine._contexts, 0, ctx)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    linked = 0
+    for case, (seed, n, steps, tr) in enumerate(((9, 60, 9, None), (21, 48, 7, 12.0), (33, 30, 12, None))):
+        dates, polys, com = tt._tracking_case(seed, n, steps, shuffle=False)
+        lonlat = [[np.c_[-180 + 0.25 * r[:, 0], -90 + 0.25 * r[:, 1]] for r in rs] for rs in polys]
+        events = tt._frame(dates, lonlat, com)
+        events.attrs["wavebreaking_grid"] = dict(lon=(-180.0, 0.25), lat=(-90.0, 0.25))
+        for method, kw in (("by_overlap", dict(overlap=0.02)), ("by_distance", dict(distance=5000))):
+            want = wb.track_events(events, time_range=tr, method=method, **kw)
+            labels, dts, coms = got[(case, method)]
+            assert labels == want["label"].tolist(), (case, method)
+            assert dts == [str(d) for d in want["date"].values] and coms == [tuple(c) for c in want["com"]], (case, method)
+            linked += len(labels) - len(set(labels))
+    assert linked > 20
+    ctx.close()

@@ -564,3 +564,129 @@ def _any_rank_failed(mine, dist):
         t = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(int(t.item()))
+
+
+# ------------------------------------------------------------------------------------------------ tracking on shards
+def track_events_sharded(events, dist=None, dst=0, time_range=None, **kwargs):
+    """``track_events`` (processing/events.py:113-241) on a time-sharded catalogue WITHOUT moving it to one rank first
+    ("a one-step halo of event polygons at shard boundaries"): every rank holds the frame of its own contiguous
+    block of dates (what ``calculate_*`` returned for its shard, rows in time order) and
+
+    1. the ranks exchange their TAILS -- the rows of each rank's last ``time_range`` hours, a step's worth of events -- and every
+       rank puts in front of its rows those rows of the ranks before it that lie within ``time_range`` of its first date (its halo):
+       every pair 0 < dt <= time_range (events.py:163-181) then has both members on the rank that owns the later one;
+    2. every rank runs ``track_events`` on halo + own rows (the pair tests -- exact overlap areas or haversines -- on its own GPU);
+    3. the local labels are unified: a halo row carries a label on the rank that owns it AND on the rank that borrowed it, so the
+       (rank, label) classes that share a row are one component (union-find over a few dozen nodes per boundary on ``dst``);
+       components are named after their smallest row of the whole record and renumbered 0, 1, 2, ... (events.py:224-238), the
+       frame is sorted by label and date (:241).
+
+    Returns on ``dst`` the tracked frame of the whole record -- row for row what ``track_events`` returns for the
+    concatenated catalogue --, None elsewhere.  ``time_range`` None: the smallest positive gap between two rows' dates over ALL
+    ranks (events.py:151-153)."""
+    import pandas as pd
+    from wavebreaking_amd.processing import events as pe
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return pe.track_events(events, time_range=time_range, **kwargs)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    events = events.reset_index(drop=True) if len(events) else events
+    n_own = len(events)
+    dates = np.asarray(events["date"].values) if n_own else np.zeros(0, dtype="datetime64[ns]")
+    is_time = n_own == 0 or np.issubdtype(dates.dtype, np.datetime64)
+    key = (dates.astype("datetime64[ns]").astype(np.int64) if is_time else dates.astype(np.float64)) if n_own else np.zeros(0)
+    unit = 1e9 * 3600.0 if is_time else 1.0
+    # what the ranks tell each other: first / last date and row count; the smallest positive gap needs the neighbours' edges too
+    info = [None] * world
+    dist.all_gather_object(info, dict(n=n_own, first=(key.min() if n_own else None), last=(key.max() if n_own else None),
+                                      uniq=np.unique(key) if n_own else np.zeros(0)))
+    if time_range is None:
+        allk = np.unique(np.concatenate([i["uniq"] for i in info])) if any(i["n"] for i in info) else np.zeros(0)
+        gaps = np.diff(allk)
+        gaps = gaps[gaps > 0]
+        if gaps.size == 0:
+            raise ValueError("No events detected in the time range: {}".format(np.nan))
+        time_range = float(gaps.min() / unit)
+    reach = time_range * unit
+    # 1. tails: the rows of my last time_range (they can be somebody's halo)
+    tail = events[key >= key.max() - reach] if n_own else events
+    tail_rows = np.nonzero(key >= key.max() - reach)[0] if n_own else np.zeros(0, dtype=np.int64)
+    tails = [None] * world
+    dist.all_gather_object(tails, (tail, tail_rows))
+    halo_frames, halo_ids = [], []                       # rows borrowed from the ranks before me, (owner rank, owner row) each
+    if n_own:
+        for q in range(rank):
+            fq, rq = tails[q]
+            if fq is None or not len(fq):
+                continue
+            kq = np.asarray(fq["date"].values)
+            kq = kq.astype("datetime64[ns]").astype(np.int64) if is_time else kq.astype(np.float64)
+            m = (kq >= key.min() - reach) & (kq < key.min())
+            if m.any():
+                halo_frames.append(fq[m])
+                halo_ids.extend((q, int(r)) for r in np.asarray(rq)[m])
+    # 2. local labels on halo + own rows
+    error, local = None, np.zeros(0, dtype=np.int64)
+    try:
+        if n_own:
+            both = pd.concat(halo_frames + [events]).reset_index(drop=True) if halo_frames else events
+            both.attrs.update(events.attrs)
+            if len(both) > 1 and np.unique(np.asarray(both["date"].values)).size > 1:
+                try:
+                    tr = pe.track_events(both, time_range=time_range, **kwargs)
+                    local = np.empty(len(both), dtype=np.int64)
+                    local[tr.index.to_numpy()] = np.asarray(tr["label"], dtype=np.int64)
+                except ValueError as e:                       # "No events detected in the time range": no pair on this rank
+                    if "No events detected" not in str(e):
+                        raise
+                    local = np.arange(len(both), dtype=np.int64)
+            else:
+                local = np.arange(len(both), dtype=np.int64)
+    except Exception as e:
+        error = e
+    failed = _any_rank_failed(error is not None, dist)
+    if error is not None:
+        raise error
+    if failed:
+        raise RuntimeError("track_events_sharded: the call failed on another rank")
+    nh = len(halo_ids)
+    report = dict(own=local[nh:], halo=[(q, r, int(local[k])) for k, (q, r) in enumerate(halo_ids)])
+    reports = [None] * world if rank == dst else None
+    dist.gather_object(report, reports, dst=dst)
+    frames = gather_frames(events, dist, dst)
+    if rank != dst:
+        return None
+    # 3. one component per class of (rank, label) nodes that share a row
+    parent = {}
+
+    def find(a):
+        while parent.setdefault(a, a) != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for r, rep in enumerate(reports):
+        for q, row, lab in rep["halo"]:
+            a, b = find((r, lab)), find((q, int(reports[q]["own"][row])))
+            if a != b:
+                parent[a] = b
+    base = np.concatenate([[0], np.cumsum([i["n"] for i in info])])
+    total = int(base[-1])
+    if total == 0:
+        return events
+    if not any(len(rep["own"]) > 1 or rep["halo"] for rep in reports) and total < 2:
+        raise ValueError("No events detected in the time range: {}".format(time_range))
+    comp = np.empty(total, dtype=object)
+    for r, rep in enumerate(reports):
+        for i, lab in enumerate(rep["own"]):
+            comp[base[r] + i] = find((r, int(lab)))
+    first_row, label = {}, np.empty(total, dtype=np.int64)
+    for g in range(total):                                 # components named after their smallest row, renumbered in that order
+        label[g] = first_row.setdefault(comp[g], len(first_row))
+    whole = pd.concat([f for f in frames if f is not None and len(f)]).reset_index(drop=True)
+    wk = np.asarray(whole["date"].values)
+    wk = wk.astype("datetime64[ns]").astype(np.int64) if is_time else wk.astype(np.float64)
+    gaps = np.diff(np.unique(wk)) / unit
+    if gaps.size == 0 or not (gaps.min() <= time_range):
+        raise ValueError("No events detected in the time range: {}".format(time_range))      # events.py:179-181
+    whole["label"] = label
+    out = whole.iloc[np.lexsort((wk, label))]                                                # events.py:241
+    return out
