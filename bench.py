@@ -361,9 +361,9 @@ def main():
     # table) + properties_from_sums, timed on this thread after the timed region
     geometry_host = None
     if not multi:
-        from wavebreaking_amd.utils import index_utils as iu
         b = phase1(ctx, 0)
         b.indices(reduce_max(b.max_nux()), **which)
+        b.event_geometry(0, copy=False)                               # (the wait for the geometry kernels is the device's, not the host's)
         tic_g = time.perf_counter()
         nrings = 0
         for kind in (0, 1, 2):
@@ -371,10 +371,12 @@ def main():
             if ev_k["step"].size:
                 ring_off, vert_off, gx, gy = b.event_geometry(kind, copy=False)
                 nrings += int(vert_off.size) - 1
-                iu.properties_from_sums(ev_k["sums"], lon, lat, nlon)
+                pr = ev_k["props"]                                   # com, mean_var, intensity, event_area from the device (index_utils.py:104-120)
+                com = list(zip(pr[:, 0].tolist(), pr[:, 1].tolist()))
         geometry_host = {"ms": 1e3 * (time.perf_counter() - tic_g), "rings": nrings,
-                         "what": "wb_get_event_geometry (since round 5: views of the rings the device wrote during wb_indices) + "
-                                 "properties_from_sums (index_utils.py:104-120) for the three event tables of one pass, host only"}
+                         "what": "what the host still does per pass for the frames' geometry and property columns: views of the rings and of the "
+                                 "property columns the device wrote (wb_get_event_geometry, wb_get_event_rows) + the `com` column as a list of tuples "
+                                 "(index_utils.py:111); until round 6 properties_from_sums in numpy: 6-7 ms"}
         b.close()
     verify = None
     if multi:
