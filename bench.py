@@ -257,13 +257,17 @@ def main():
         if cat is None:
             return None
         assert int(cat[0][:, 18].sum()) == cat[1].size == cat[2].size
-        return int(cat[0].shape[0]), int(cat[1].size)
+        if len(cat) > 3:                                   # the rings in lon / lat travelled too (geometry of every rank's own device)
+            ring_off, vert_off, gx, gy = cat[3]
+            assert ring_off.size == cat[0].shape[0] + 1 and vert_off.size == ring_off[-1] + 1 and gx.size == gy.size == vert_off[-1]
+            return int(cat[0].shape[0]), int(cat[1].size), int(ring_off[-1]), int(gx.size)
+        return int(cat[0].shape[0]), int(cat[1].size), 0, 0
 
     def run_record(n, keep):
         """n passes as ONE record: every batch selected against the full width of the extended grid at once, the ONE
         all-reduce(max) that verifies it after the last batch (streamer_index.py:106: the maximum over the whole frame), the
         gathers of a multi-GPU run on their own thread"""
-        gatherer = wd.TableGatherer(dist, comm=libcomm, dst=0, on_result=gathered) if multi else None
+        gatherer = wd.TableGatherer(dist, comm=libcomm, dst=0, on_result=gathered, geometry=geometry_on[0]) if multi else None
         got = []
         # (one order of collectives on every rank: the record's gathers -- the gather thread's -- and then its all-reduce)
         try:
@@ -274,7 +278,7 @@ def main():
                 gatherer.abort(e)
             raise
         if keep and multi and rank == 0 and got:
-            counts["gathered_events"], counts["gathered_polygon_vertices"] = got[-1]
+            counts["gathered_events"], counts["gathered_polygon_vertices"], counts["gathered_rings"], counts["gathered_ring_vertices"] = got[-1]
 
     def solo_pass(c, copy=False):
         """a single pass alone on the device"""
@@ -388,17 +392,22 @@ def main():
         # LAST timed pass -- the ranks the collective saw must be WORLD_SIZE, and what rank 0 gathered in that pass must be
         # the sum over the ranks
         mine = torch.tensor([1, counts.get("streamers", 0) + counts.get("overturnings", 0) + counts.get("cutoffs", 0),
-                             counts.get("polygon_vertices", 0)], dtype=torch.int64, device=cdev)
+                             counts.get("polygon_vertices", 0), counts.get("geometry_rings", 0), counts.get("geometry_vertices", 0)], dtype=torch.int64, device=cdev)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-        seen, ev_sum, vert_sum = (int(v) for v in mine.cpu().tolist())
+        seen, ev_sum, vert_sum, ring_sum, gvert_sum = (int(v) for v in mine.cpu().tolist())
         verify = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "gather_path": gather_path, "ranks_seen_by_allreduce": seen,
-                  "events_sum_over_ranks": ev_sum, "polygon_vertices_sum_over_ranks": vert_sum}
+                  "events_sum_over_ranks": ev_sum, "polygon_vertices_sum_over_ranks": vert_sum,
+                  "rings_sum_over_ranks": ring_sum, "ring_vertices_sum_over_ranks": gvert_sum,
+                  "geometry_gather": "every rank's lon / lat rings (transform_polygons on its own device) to rank 0 beside the tables: torch.distributed gathers of the arrays the geometry kernels wrote" if main_geometry else "off"}
         if rank == 0:
             if seen != world or dist.get_world_size() != world:
                 raise SystemExit("bench.py: the collective saw %d ranks, WORLD_SIZE is %d" % (seen, world))
             if counts.get("gathered_events") != ev_sum or counts.get("gathered_polygon_vertices") != vert_sum:
                 raise SystemExit("bench.py: rank 0 gathered %s events / %s vertices, the ranks hold %d / %d"
                                  % (counts.get("gathered_events"), counts.get("gathered_polygon_vertices"), ev_sum, vert_sum))
+            if main_geometry and (counts.get("gathered_rings") != ring_sum or counts.get("gathered_ring_vertices") != gvert_sum):
+                raise SystemExit("bench.py: rank 0 gathered %s rings / %s ring vertices, the ranks hold %d / %d"
+                                 % (counts.get("gathered_rings"), counts.get("gathered_ring_vertices"), ring_sum, gvert_sum))
             verify["gather_verified"] = True
     out = None
 

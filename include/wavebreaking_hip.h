@@ -210,6 +210,13 @@ int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);
 int wb_set_step_offset(wb_batch* b, int64_t first_step);
 int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[3], const int32_t** poly_x, const int32_t** poly_y,
                          int64_t* nverts);
+/* ... and the pass's rings in lon / lat (context option "geometry") where the kernels wrote them -- device arrays with the options
+   geometry_dma and keep_device, else the pinned host arrays (*on_device says which): ring_offset[nev + 1] over the events in
+   table order (streamers, overturnings, cutoffs), vert_offset[nrings + 1], x / y[nverts] degrees.  A time-sharded run gathers
+   them beside the tables (wavebreaking_amd.distributed), so that rank dst holds the catalogue WITH its geometry and no rank
+   transforms another rank's polygons (index_utils.py:129-184).  Waits for the geometry kernels. */
+int wb_get_device_geometry(wb_batch* b, const int64_t** ring_offset, int64_t* nev, const int64_t** vert_offset, int64_t* nrings,
+                           const double** x, const double** y, int64_t* nverts, int* on_device);
 void wb_free_batch(wb_batch* b);
 
 /* ---- the two exchanges of a time-sharded run (one process per GPU), on RCCL inside the library -------------------------

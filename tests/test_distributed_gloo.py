@@ -305,11 +305,11 @@ def reduce_max(m):
 cats = {}
 def gathered(k, cat):
     if cat is not None:
-        cats[k] = tuple(np.array(a) for a in cat)       # (the buffers are reused by the next gather)
+        cats[k] = tuple(np.array(a) for a in cat[:3]) + (tuple(np.array(a) for a in cat[3]),)       # (the buffers are reused by the next gather)
     return k
 
 def record(field_ok):
-    g = wd.TableGatherer(dist, comm=None, dst=0, on_result=gathered)
+    g = wd.TableGatherer(dist, comm=None, dst=0, on_result=gathered, geometry=True)
     done = []
     def collect(k, b):
         g.submit(k, b)
@@ -330,7 +330,12 @@ if rank == 0:
     rows = np.concatenate([cats[k][0] for k in (0, 1)])
     px = np.concatenate([cats[k][1] for k in (0, 1)])
     py = np.concatenate([cats[k][2] for k in (0, 1)])
-    np.savez(sys.argv[2], rows=rows, px=px, py=py)
+    # the rings in lon / lat: batch after batch, offsets rebased
+    ring_count = np.concatenate([np.diff(cats[k][3][0]) for k in (0, 1)])
+    vert_count = np.concatenate([np.diff(cats[k][3][1]) for k in (0, 1)])
+    gx = np.concatenate([cats[k][3][2] for k in (0, 1)])
+    gy = np.concatenate([cats[k][3][3] for k in (0, 1)])
+    np.savez(sys.argv[2], rows=rows, px=px, py=py, ring_count=ring_count, vert_count=vert_count, gx=gx, gy=gy)
 # a record in which NO contour spans the extended grid: every rank learns so from the one exchange
 pv[:, :, :12] = 0.0
 try:
@@ -378,6 +383,13 @@ def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_
     rows, px, py = got["rows"], got["px"], got["py"]
     npoly = rows[:, 18].astype(np.int64)
     start = np.cumsum(npoly) - npoly
+    # ... and with them the rings in lon / lat, cut and mapped by every rank's own device (transform_polygons,
+    # index_utils.py:129-184): row k of the gathered catalogue owns the next ring_count[k] rings
+    ring_count, vert_count, ggx, ggy = got["ring_count"], got["vert_count"], got["gx"], got["gy"]
+    assert ring_count.size == rows.shape[0] and vert_count.size == ring_count.sum() and ggx.size == vert_count.sum() == ggy.size
+    ring_start = np.cumsum(ring_count) - ring_count
+    vert_start = np.cumsum(vert_count) - vert_count
+    nrings_checked = 0
     total = 0
     for kind in (0, 1, 2):
         ev = b.events(kind)
@@ -390,8 +402,16 @@ def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_
         gx = np.concatenate([px[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
         gy = np.concatenate([py[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
         assert np.array_equal(gx, ev["poly_x"]) and np.array_equal(gy, ev["poly_y"])
+        ro, vo, wx, wy = b.event_geometry(kind)
+        for q, i in enumerate(m):
+            assert ring_count[i] == ro[q + 1] - ro[q], (kind, q)
+            for j in range(int(ring_count[i])):
+                a0 = vert_start[ring_start[i] + j]; a1 = a0 + vert_count[ring_start[i] + j]
+                w0, w1 = vo[ro[q] + j], vo[ro[q] + j + 1]
+                assert np.array_equal(ggx[a0:a1], wx[w0:w1]) and np.array_equal(ggy[a0:a1], wy[w0:w1]), (kind, q, j)
+                nrings_checked += 1
         total += m.size
-    assert total == rows.shape[0] > 20
+    assert total == rows.shape[0] > 20 and nrings_checked >= total
     b.close()
     ctx.close()
 

@@ -781,6 +781,17 @@ class Batch:
         """first time step of this batch in the whole record (added to the step column of the device rows)"""
         self.ctx.L.lib.wb_set_step_offset(self.h, int(first_step))
 
+    def device_geometry(self):
+        """(ring_offset pointer, events, vert_offset pointer, rings, x pointer, y pointer, vertices, on_device): the rings of the
+        last indices() where the kernels wrote them (wb_get_device_geometry)"""
+        ro, vo, x, y = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ne, nr, nv, dev = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        f = self.ctx.L.lib.wb_get_device_geometry
+        f.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p), C.POINTER(C.c_int64)] * 2 + [C.POINTER(C.c_void_p)] * 2 + [C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        if f(self.h, C.byref(ro), C.byref(ne), C.byref(vo), C.byref(nr), C.byref(x), C.byref(y), C.byref(nv), C.byref(dev)) != 0:
+            raise RuntimeError("wb_get_device_geometry failed: " + self.ctx.error())
+        return ro.value or 0, int(ne.value), vo.value or 0, int(nr.value), x.value or 0, y.value or 0, int(nv.value), bool(dev.value)
+
     def device_tables(self):
         """(rows pointer, (n streamers, n overturnings, n cutoffs), poly_x pointer, poly_y pointer, vertices): the result
         of the last indices() as DEVICE buffers (context option "keep_device")"""

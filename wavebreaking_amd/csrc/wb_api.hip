@@ -1011,6 +1011,25 @@ extern "C" int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[
     *nverts = b->dev_nv;
     return 0;
 }
+// the rings of the last wb_indices (context option "geometry") as they lie where the kernels wrote them: DEVICE arrays with the
+// options geometry_dma and keep_device (a time-sharded run gathers them device to device beside the tables of
+// wb_get_device_tables), else the pinned host arrays.  ring_offset[nev + 1] (events in table order: streamers, overturnings,
+// cutoffs), vert_offset[nrings + 1], x / y[nverts] degrees.  Waits for the geometry kernels.
+extern "C" int wb_get_device_geometry(wb_batch* b, const int64_t** ring_offset, int64_t* nev, const int64_t** vert_offset, int64_t* nrings,
+                                      const double** x, const double** y, int64_t* nverts, int* on_device) {
+    if (!b || !ring_offset || !nev || !vert_offset || !nrings || !x || !y || !nverts || !on_device) return 1;
+    wb_use(b->ctx);
+    if (wb_geom_settle(b)) return 1;
+    if (b->g_rings < 0) return wb_fail(b->ctx, "wb_get_device_geometry: the pass has no device geometry (context option geometry off, or a pass its arrays did not hold)");
+    *nev = b->dev_n[0] + b->dev_n[1] + b->dev_n[2]; *nrings = b->g_rings; *nverts = b->g_verts;
+    const bool dev = b->g_dx != nullptr;
+    *on_device = dev ? 1 : 0;
+    *ring_offset = (const int64_t*)(dev ? b->g_dro : b->g_ring_offset);
+    *vert_offset = (const int64_t*)(dev ? b->g_dvo : b->g_vert_offset);
+    *x = dev ? b->g_dx : b->g_x;
+    *y = dev ? b->g_dy : b->g_y;
+    return 0;
+}
 extern "C" int wb_get_group_ties(wb_batch* b, int64_t* ties) {
     if (!b) return 1;
     *ties = b->group_ties;
@@ -1480,7 +1499,8 @@ static int wb_geom_settle(wb_batch* b) {
                                 hipStreamSynchronize(ctx->settle_stream) != hipSuccess;
     }
 #endif
-    if (b->g_dx) { bfree_one(b, b->g_dx); bfree_one(b, b->g_dy); bfree_one(b, b->g_dro); bfree_one(b, b->g_dvo); b->g_dx = b->g_dy = nullptr; b->g_dro = b->g_dvo = nullptr; }
+    // (a time-sharded run gathers the rings device to device: with keep_device they stay until the batch's next wb_indices / its end)
+    if (b->g_dx && !ctx->keep_device) { bfree_one(b, b->g_dx); bfree_one(b, b->g_dy); bfree_one(b, b->g_dro); bfree_one(b, b->g_dvo); b->g_dx = b->g_dy = nullptr; b->g_dro = b->g_dvo = nullptr; }
     if (tail_rc) return wb_fail(ctx, "wb_indices: the copy of the geometry's tail failed");
     if (NR < 0 || NV < 0) return wb_fail(ctx, "wb_indices: the geometry kernels left no totals");
     if (NV > ctx->geom_seen) ctx->geom_seen = NV;
@@ -1519,6 +1539,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
     // what an earlier call on this batch left behind: geometry kernels still in flight, descriptors kept for them / for the polygons
     if (wb_geom_settle(b)) return 1;
     if (b->d_ev) { bfree_one(b, b->d_ev); bfree_one(b, b->d_poff); b->d_ev = nullptr; b->d_poff = nullptr; }
+    if (b->g_dx) { bfree_one(b, b->g_dx); bfree_one(b, b->g_dy); bfree_one(b, b->g_dro); bfree_one(b, b->g_dvo); b->g_dx = b->g_dy = nullptr; b->g_dro = b->g_dvo = nullptr; }
     wb_ctx::Tables* T = make_tables(b);
     if (!T) return wb_fail(ctx, "out of memory (tables)");
     const WbCtl& h1 = b->h_ctl;                 // phase-1 summary

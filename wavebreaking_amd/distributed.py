@@ -295,6 +295,80 @@ def _gather_tensors(rows, vx, vy, dist, dst, dev, poison=False, leaving=False):
     return hr[:tot_e].numpy(), hx[:tot_v].numpy(), hy[:tot_v].numpy()
 
 
+def _geometry_tensors(batch, dist):
+    """the rings of a batch's last indices() as torch tensors over the arrays the kernels wrote (device memory of the HIP build
+    with the options keep_device / geometry_dma, no copy): (rings per event int64[ne], vertices per ring int64[nr], x float64[nv],
+    y float64[nv]); a rank without a batch contributes empty ones"""
+    import torch
+    if batch is None:
+        on_gpu = dist.get_backend() == "nccl"
+        z = lambda dt: torch.zeros(0, dtype=dt, device="cuda" if on_gpu else "cpu")
+        return z(torch.int64), z(torch.int64), z(torch.float64), z(torch.float64)
+    ro, ne, vo, nr, x, y, nv, on_dev = batch.device_geometry()
+    gpu = on_dev and batch.ctx.L.backend == "hip"
+    if dist.get_backend() == "nccl" and not gpu:
+        # (pinned host arrays -- the options were off: up to the device for the collective)
+        dev = _device(dist)
+        t = lambda p, n, dt: _wrap(p, (n,), dt, False).to(dev)
+    else:
+        t = lambda p, n, dt: _wrap(p, (n,), dt, gpu)
+    ring_off, vert_off = t(ro, ne + 1, np.int64), t(vo, nr + 1, np.int64)
+    return ring_off[1:] - ring_off[:-1], vert_off[1:] - vert_off[:-1], t(x, nv, np.float64), t(y, nv, np.float64)
+
+
+def _gather_geometry(parts, dist, dst, dev):
+    """the collective behind the geometry of a gathered catalogue: every rank's (rings per event, vertices per ring, x, y) to
+    ``dst`` in rank (= time) order -- counts first, the payload padded to the largest rank's.  On ``dst``: (ring_offset
+    int64[events + 1], vert_offset int64[rings + 1], x, y) of the whole catalogue, numpy; None elsewhere."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    rc, vc, x, y = parts
+    if dev.type != "cuda":
+        rc, vc, x, y = rc.cpu(), vc.cpu(), x.cpu(), y.cpu()
+    counts = torch.tensor([int(rc.shape[0]), int(vc.shape[0]), int(x.shape[0])], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts)
+    allc = torch.stack(allc).cpu().numpy()
+    me, mr, mv = (max(int(allc[:, k].max()), 1) for k in range(3))
+    ibuf = torch.zeros(me + mr, dtype=torch.int64, device=dev)
+    ibuf[: rc.shape[0]] = rc
+    ibuf[me: me + vc.shape[0]] = vc
+    fbuf = torch.zeros((2, mv), dtype=torch.float64, device=dev)
+    fbuf[0, : x.shape[0]] = x
+    fbuf[1, : y.shape[0]] = y
+    iout = [torch.zeros_like(ibuf) for _ in range(world)] if rank == dst else None
+    fout = [torch.zeros_like(fbuf) for _ in range(world)] if rank == dst else None
+    dist.gather(ibuf, iout, dst=dst)
+    dist.gather(fbuf, fout, dst=dst)
+    if rank != dst:
+        return None
+    rcs = torch.cat([iout[r][: int(allc[r, 0])] for r in range(world)]).cpu().numpy()
+    vcs = torch.cat([iout[r][me: me + int(allc[r, 1])] for r in range(world)]).cpu().numpy()
+    xs = torch.cat([fout[r][0, : int(allc[r, 2])] for r in range(world)]).cpu().numpy()
+    ys = torch.cat([fout[r][1, : int(allc[r, 2])] for r in range(world)]).cpu().numpy()
+    return (np.concatenate([[0], np.cumsum(rcs)]).astype(np.int64), np.concatenate([[0], np.cumsum(vcs)]).astype(np.int64), xs, ys)
+
+
+def gather_device_geometry(batch, dist, dst=0):
+    """the lon / lat rings of every rank's batch (transform_polygons done by each rank's own device, index_utils.py:129-184) to
+    rank ``dst``, in rank (= time) order and in the row order of ``gather_device_tables(..., as_rows=True)``: rank ``dst`` holds the
+    catalogue WITH its geometry and transforms nobody's polygons.  (ring_offset, vert_offset, x, y) there, None elsewhere."""
+    if dist is None or not dist.is_initialized():
+        ro, ne, vo, nr, x, y, nv, on_dev = batch.device_geometry()
+        t = _geometry_tensors(batch, _Single())
+        return (np.concatenate([[0], np.cumsum(t[0].cpu().numpy())]).astype(np.int64), np.concatenate([[0], np.cumsum(t[1].cpu().numpy())]).astype(np.int64),
+                t[2].cpu().numpy(), t[3].cpu().numpy())
+    dev = _device(dist)
+    with _exchange_stream(dev):
+        return _gather_geometry(_geometry_tensors(batch, dist), dist, dst, dev)
+
+
+class _Single:
+    @staticmethod
+    def get_backend():
+        return "none"
+
+
 class TableGatherer:
     """Exchange (2) off the critical path.  ``submit(k, batch)`` -- on the caller's thread, in batch order -- STAGES the
     batch's device tables (a device-to-device copy of a few MB into a slot that outlives the batch: the batch can be closed
@@ -305,11 +379,16 @@ class TableGatherer:
     None for torch.distributed (``dist``).  ``on_result(k, (rows, poly_x, poly_y) or None)`` runs on the gather thread as
     soon as batch k's catalogue stands in rank ``dst``'s pinned host buffers (views, valid until the next gather)."""
 
-    def __init__(self, dist, comm=None, dst=0, on_result=None, slots=None):
+    def __init__(self, dist, comm=None, dst=0, on_result=None, slots=None, geometry=False):
         import queue
         import threading
         from wavebreaking_amd import _hip
         self.dist, self.comm, self.dst = dist, comm, dst
+        # geometry: the batches' lon / lat rings travel too (a second pair of gathers per slot, through torch.distributed on
+        # either path: clones of the arrays the geometry kernels wrote); ``on_result`` then gets (rows, poly_x, poly_y, (ring_offset,
+        # vert_offset, x, y))
+        self.geometry = bool(geometry)
+        self.gdev = _device(dist) if geometry else None
         self.on_result = on_result or (lambda k, cat: None)
         self.nslots = int(slots or _hip.COMM_SLOTS)
         self.free = threading.Semaphore(self.nslots)
@@ -332,13 +411,17 @@ class TableGatherer:
         self.free.acquire()                                  # a slot the gather thread is done with (it may lag by nslots batches)
         slot = self.next_slot
         self.next_slot = (slot + 1) % self.nslots
+        geo = None
+        if self.geometry:
+            with _exchange_stream(self.gdev):                # (clones: the batch is released right after this call)
+                geo = tuple(t.clone() for t in _geometry_tensors(batch, self.dist))
         if self.comm is not None:
             self.comm.ctx.comm_stage_tables(batch, slot)
             item = slot
         else:
             with _exchange_stream(self.dev):                 # clones outlive the batch (leaving the block waits for the copies)
                 item = tuple(t.clone() for t in _batch_tensors(batch, self.dist, False))
-        self.q.put((k, item))
+        self.q.put((k, (item, geo)))
 
     def _gather(self, item, poison, leaving=False):
         if self.comm is not None:
@@ -365,10 +448,16 @@ class TableGatherer:
                         pass
                     self.aborted = True
                 return
-            k, item = job
+            k, (item, geo) = job
             try:
                 if self.error is None:
-                    self.results[k] = self.on_result(k, self._gather(item, False))
+                    cat = self._gather(item, False)
+                    if self.geometry:
+                        # (the same order on every rank's gather thread: the slot's tables, then its rings)
+                        with _exchange_stream(self.gdev):
+                            g = _gather_geometry(geo, self.dist, self.dst, self.gdev)
+                        cat = None if cat is None else tuple(cat) + (g,)
+                    self.results[k] = self.on_result(k, cat)
                 elif not self.aborted:
                     # A failure here must not leave the peers inside a collective: this rank still takes part in the exchange of
                     # the counts of every slot it owes, with -1 for its own, so every rank's gather for the slot raises and the
