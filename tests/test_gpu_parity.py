@@ -412,3 +412,27 @@ def test_float64_fields_take_the_fast_streaming_scan(ctx):
             assert np.array_equal(tabs[1][0][key], tabs[0][0][key]), (dlon, key)
         assert np.array_equal(tabs[1][1], tabs[0][1]) and tabs[1][0]["step"].size > 0
         helpers.full_parity(ctx, pv, lat, lon, synth.times(nt), [-2, 2])
+
+
+def test_grids_wider_than_4096_columns(ctx):
+    """nlon + periodic columns up to 16384 (until round 6: 4096): a 1/16 degree grid -- 5760 + 1920 columns -- whose 23 strips the
+    streaming scan's workgroup does not hold (the single-kernel scan takes over) and whose jobs the fused trace may decline (the
+    three-kernel chain): full parity with the oracle on a latitude band, float32 and float64, and the contour table of a global
+    field of 2881 rows"""
+    dl = 0.0625
+    lon = -180.0 + dl * np.arange(5760)
+    lat = 25.0 + dl * np.arange(641)
+    pv = synth.pv_field(5, 2, lat, lon, eps=0.0)
+    got, ref = helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2.0], intensity=pv, want_cells=False)
+    assert len(ref["contours"]) >= 4 and len(ref["overturnings"]) >= 2
+    helpers.full_parity(ctx, pv[:1].astype(np.float64), lat, lon, synth.times(1), [2.0], want_cells=False)
+    # the whole globe at that resolution: contours of both levels against the oracle's (a step of 16.6 M cells)
+    from oracle import contours as ocont
+    latg = -90.0 + dl * np.arange(2881)
+    pvg = synth.pv_field(9, 1, latg, lon, eps=0.0)
+    b = ctx.contours(pvg, latg, lon, [-2.0, 2.0], dl, dl, periodic_add=120.0)
+    tab = b.contour_table()
+    b.close()
+    want = ocont.calculate_contours(pvg, [-2.0, 2.0], latg, lon, synth.times(1), periodic_add=120, original_coordinates=False)
+    helpers.compare_contours(tab, want, [-2.0, 2.0], dl)
+    assert len(want) >= 2 and tab["nux"].max() == 5760 + 1920

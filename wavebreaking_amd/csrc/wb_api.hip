@@ -112,6 +112,10 @@ struct wb_batch {
     std::string timer_names;
 };
 
+// widest periodically extended grid: a lattice point is 16 + 16 bits (wb_core.h), a segment key holds nlat * W < 2^26 squares;
+// beyond the widths the fast kernels hold (16 strips of 256 columns in the streaming scan, 8190 segments per job in the fused
+// trace) the single-kernel scan and the three-kernel trace chain take over
+#define WB_MAX_W 16384
 static int wb_geom_settle(wb_batch* b);        // (defined in front of wb_indices)
 static int wb_pack_polys_now(wb_batch* b);
 
@@ -649,7 +653,7 @@ extern "C" int wb_contours(wb_ctx* ctx, const wb_params* pp, wb_batch** out) {
     const int padd = (int)(p.periodic_add / p.dlon);     // contour_index.py:97
     if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
     const int W = p.nlon + padd;
-    if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large: nlon + periodic columns <= 4096, nlat <= 32767");
+    if (W > WB_MAX_W || p.nlat > 32767) return wb_fail(ctx, "grid too large: nlon + periodic columns <= 16384, nlat <= 32767");
     std::lock_guard<std::recursive_mutex> wb_lk_(ctx->mu);
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     wb_batch* b = new wb_batch();
@@ -2140,7 +2144,7 @@ extern "C" int wb_batch_from_contours(wb_ctx* ctx, const wb_params* pp, int64_t 
     const int padd = (int)(p.periodic_add / p.dlon);
     if (padd < 0 || padd > p.nlon) return wb_fail(ctx, "periodic_add must be between 0 and 360 degrees");
     const int W = p.nlon + padd;
-    if (W > 4096 || p.nlat > 32767) return wb_fail(ctx, "grid too large");
+    if (W > WB_MAX_W || p.nlat > 32767) return wb_fail(ctx, "grid too large: nlon + periodic columns <= 16384, nlat <= 32767");
     std::lock_guard<std::recursive_mutex> wb_lk_(ctx->mu);
     if (!wb_select_device(ctx)) return wb_fail(ctx, "hipSetDevice failed");
     int maxn = 1;
