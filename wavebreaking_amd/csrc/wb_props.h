@@ -174,60 +174,6 @@ WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x
         else wb_props_field_sums_t<double, false>(a, tbase, x0, y0, rows, cols, bm, wb, out);
     }
 }
-// ... over the MEMBER SPANS of the rows instead of the whole bounding box (round 6): row r's members lie in the columns
-// [first, first + len) -- packed first | len << 16 in sp[r] --, pre[r] is the number of span cells in the rows above it and total
-// their number in all rows.  A streamer is a filament: its spans hold a fifth of its box's cells, and the box loads -- 0.9 GB per
-// pass for events whose cells add up to less than 0.1 GB -- were most of the property kernel's traffic.  A cell's row is found by
-// a branch-free binary search in pre[] (eight steps: an event of the LDS raster has at most WB_PROPS_LROWS <= 256 rows); the
-// loads stay unconditional and eight to a lane, as in the box version.
-template <class T>
-WB_DEV inline void wb_props_span_sums_t(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, const uint32_t* bm, int wb,
-                                        const int* pre, const uint32_t* sp, int total, double* out) {
-    const T* data = (const T*)a.data + tbase;
-    const bool has_i = a.intensity != nullptr;
-    const T* inten = has_i ? (const T*)a.intensity + tbase : data;
-    double accv = 0.0, acci = 0.0;
-    for (int i0 = WB_TID; i0 < total; i0 += 8 * WB_NT) {
-        T dv[8], di[8];
-        double wq[8];
-        unsigned member = 0u;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int i = i0 + q * WB_NT;
-            const bool live = i < total;
-            const int ii = live ? i : 0;
-            int lo = 0;                                      // the last row whose prefix is <= ii
-#pragma unroll
-            for (int st = 128; st >= 1; st >>= 1) {
-                const int mid = lo + st;
-                lo = (mid < rows && pre[mid] <= ii) ? mid : lo;
-            }
-            const uint32_t spv = sp[lo];
-            int xq = (int)(spv & 0xFFFFu) + (ii - pre[lo]);
-            const int len = (int)(spv >> 16);
-            xq = xq < (int)(spv & 0xFFFFu) + (len > 0 ? len - 1 : 0) ? xq : (int)(spv & 0xFFFFu) + (len > 0 ? len - 1 : 0);   // (rows without members have no cells: ii never lands there; the clamp keeps the address inside the box)
-            const bool in = live && ((bm[lo * wb + (xq >> 5)] >> (xq & 31)) & 1u);
-            int gx = x0 + xq;
-            gx = gx < a.W ? gx : a.W - 1;
-            const int col = gx >= a.nlon ? gx - a.nlon : gx;
-            const int y = y0 + lo;
-            const size_t idx = (size_t)y * a.nlon + (size_t)col;
-            dv[q] = data[idx];
-            di[q] = inten[idx];
-            wq[q] = a.wlat[y];
-            member |= (in ? 1u : 0u) << q;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double pv = wq[q] * (double)dv[q], pi = wq[q] * (double)di[q];
-            accv += ((member >> q) & 1u) ? pv : 0.0;
-            acci += (((member >> q) & 1u) && has_i) ? pi : 0.0;
-        }
-    }
-    out[2 * WB_TID] = accv;
-    out[2 * WB_TID + 1] = acci;
-    WB_SYNC();
-}
 // The raster of an event in LDS: per row of its bounding box a short list of signed scanline crossings (sorted by the
 // row's lane, swept into winding numbers) and one bit per cell.  Events taller than WB_PROPS_LROWS rows, with more cells
 // than the bitmap holds or with a row crossed more than WB_PROPS_K times keep the raster in global memory (one int per
@@ -237,9 +183,6 @@ WB_DEV inline void wb_props_span_sums_t(const WbPropsArgs& a, size_t tbase, int 
 #endif
 #ifndef WB_PROPS_CHUNK
 #define WB_PROPS_CHUNK 4             // events a slot takes from the queue at a time
-#endif
-#ifndef WB_PROPS_SPANS
-#define WB_PROPS_SPANS 1             // 1: field sums over the rows' member spans where those are a third of the box or less (0, a test build: always the box)
 #endif
 #ifndef WB_PROPS_BM
 #define WB_PROPS_BM 768              // bitmap words (24 576 cells)
@@ -555,28 +498,11 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 WB_ACC(0, y0 + (int)rr) = (double)cnt;
                 WB_ACC(1, y0 + (int)rr) = (double)sx;
             WB_END_PFOR
-            // ... and the field sums with the lanes along the rows: over the rows' member spans when those hold less than a third
-            // of the box (filaments: the streamers), over the box otherwise (compact events: the search costs more than it saves)
-            int* const spre = xcnt;                                   // (both free since the sweep)
-            uint32_t* const spk = (uint32_t*)xlist8;
-            WB_PFOR(rr, rows)
-                const uint32_t* row = bm + (int)rr * wb;
-                int first = -1, last = -1;
-                for (int w = 0; w < wb; ++w) {
-                    const uint32_t v = row[w];
-                    if (v) {
-                        if (first < 0) first = 32 * w + wb_ctz32(v);
-                        last = 32 * w + 31 - wb_clz32(v);
-                    }
-                }
-                spk[rr] = first < 0 ? 0u : ((uint32_t)first | ((uint32_t)(last - first + 1) << 16));
-                spre[rr] = first < 0 ? 0 : last - first + 1;
-            WB_END_PFOR
-            const int span_total = wb_block_scan_excl(spre, rows);
-            if (WB_PROPS_SPANS && 3 * span_total < rows * cols && rows <= 256) {
-                if (a.dtype == 0) wb_props_span_sums_t<float>(a, tbase, x0, y0, rows, bm, wb, spre, spk, span_total, lred);
-                else wb_props_span_sums_t<double>(a, tbase, x0, y0, rows, bm, wb, spre, spk, span_total, lred);
-            } else wb_props_field_sums(a, tbase, x0, y0, rows, cols, bm, wb, lred);
+            // ... and the field sums with the lanes along the rows.  (Over the box: its cells are read whether they are members or not.
+            // Round 6 measured what that wastes -- the members are 50 % of a streamer's box, 65 % of a cutoff's, all of an overturning
+            // box: 62 M member cells of 78 M box cells per 0.25 degree year -- and tried sums over the rows' member spans instead:
+            // they never held less than half a box, and the search for a cell's row cost more than the loads it saved.)
+            wb_props_field_sums(a, tbase, x0, y0, rows, cols, bm, wb, lred);
         } else {
         // D: per-row counts and sums
         WB_PFOR(rr, rows)

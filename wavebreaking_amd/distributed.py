@@ -342,10 +342,31 @@ def _gather_geometry(parts, dist, dst, dev):
     dist.gather(fbuf, fout, dst=dst)
     if rank != dst:
         return None
-    rcs = torch.cat([iout[r][: int(allc[r, 0])] for r in range(world)]).cpu().numpy()
-    vcs = torch.cat([iout[r][me: me + int(allc[r, 1])] for r in range(world)]).cpu().numpy()
-    xs = torch.cat([fout[r][0, : int(allc[r, 2])] for r in range(world)]).cpu().numpy()
-    ys = torch.cat([fout[r][1, : int(allc[r, 2])] for r in range(world)]).cpu().numpy()
+    if dev.type != "cuda":
+        rcs = torch.cat([iout[r][: int(allc[r, 0])] for r in range(world)]).numpy()
+        vcs = torch.cat([iout[r][me: me + int(allc[r, 1])] for r in range(world)]).numpy()
+        xs = torch.cat([fout[r][0, : int(allc[r, 2])] for r in range(world)]).numpy()
+        ys = torch.cat([fout[r][1, : int(allc[r, 2])] for r in range(world)]).numpy()
+    else:
+        # the one copy to the host: every rank's valid part straight into pinned memory (views, valid until the next gather)
+        te, tr, tv = (int(allc[:, k].sum()) for k in range(3))
+        hrc = _pinned_host("g_rc", (max(te, 1),), torch.int64)
+        hvc = _pinned_host("g_vc", (max(tr, 1),), torch.int64)
+        hx = _pinned_host("g_x", (max(tv, 1),), torch.float64)
+        hy = _pinned_host("g_y", (max(tv, 1),), torch.float64)
+        oe = orr = ov = 0
+        for r in range(world):
+            ke, kr, kv = (int(allc[r, k]) for k in range(3))
+            if ke:
+                hrc[oe:oe + ke].copy_(iout[r][:ke], non_blocking=True)
+            if kr:
+                hvc[orr:orr + kr].copy_(iout[r][me:me + kr], non_blocking=True)
+            if kv:
+                hx[ov:ov + kv].copy_(fout[r][0, :kv], non_blocking=True)
+                hy[ov:ov + kv].copy_(fout[r][1, :kv], non_blocking=True)
+            oe += ke; orr += kr; ov += kv
+        torch.cuda.current_stream().synchronize()
+        rcs, vcs, xs, ys = hrc[:te].numpy(), hvc[:tr].numpy(), hx[:tv].numpy(), hy[:tv].numpy()
     return (np.concatenate([[0], np.cumsum(rcs)]).astype(np.int64), np.concatenate([[0], np.cumsum(vcs)]).astype(np.int64), xs, ys)
 
 
