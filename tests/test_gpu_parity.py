@@ -436,3 +436,34 @@ def test_grids_wider_than_4096_columns(ctx):
     want = ocont.calculate_contours(pvg, [-2.0, 2.0], latg, lon, synth.times(1), periodic_add=120, original_coordinates=False)
     helpers.compare_contours(tab, want, [-2.0, 2.0], dl)
     assert len(want) >= 2 and tab["nux"].max() == 5760 + 1920
+
+
+def test_property_columns_on_the_device_against_the_reference_own_lines(ctx, golden_dir):
+    """index_utils.py:104-120 (the truncated centre of mass, the three .round(2)) as the DEVICE computes them for every event
+    (wb_k_pack_results -> csrc/wb_props.h:wb_props_columns), on the sums of tests/golden/reference_rules.npz against the columns the
+    reference's own statements gave for them -- bit for bit -- and on awkward quotients against numpy's statement of the same lines"""
+    from wavebreaking_amd.utils.index_utils import properties_from_sums
+    ref = np.load(golden_dir + "/reference_rules.npz")
+    events = 0
+    for k in range(int(ref["props__count"])):
+        key = "props__p%02d" % k
+        dlon = float(ref[key + "__field"][0])
+        lat, lon = synth.grid(dlon)
+        want = ref[key + "__sums"]
+        dev = ctx.props_columns(want, lon, lat)
+        assert np.array_equal(dev[:, :2], ref[key + "__com"]) and np.array_equal(dev[:, 2], ref[key + "__mean_var"])
+        assert np.array_equal(dev[:, 3], ref[key + "__intensity"]) and np.array_equal(dev[:, 4], ref[key + "__event_area"])
+        events += len(want)
+    assert events > 100
+    # quotients on and next to integers, halves at the second decimal (round half to even), negative means
+    rng = np.random.RandomState(5)
+    lat, lon = synth.grid(0.25)
+    n = 20000
+    a = rng.uniform(1e3, 1e9, n)
+    s = np.c_[a, a * rng.uniform(-40, 40, n), a * rng.uniform(-5, 5, n), a * rng.uniform(0, lon.size + 400, n), a * rng.uniform(0, lat.size - 1, n)]
+    s[:2000, 3] = a[:2000] * rng.randint(0, lon.size + 400, 2000)                      # x_com / areas an integer, up to the product's rounding
+    s[2000:4000, 1] = a[2000:4000] * (rng.randint(-4000, 4000, 2000) + 0.5) / 100.0    # mean_var at a tie of the second decimal
+    com, mean_var, inten, area = properties_from_sums(s, lon, lat, lon.size)
+    dev = ctx.props_columns(s, lon, lat)
+    assert np.array_equal(dev[:, :2], np.asarray(com)) and np.array_equal(dev[:, 2], mean_var)
+    assert np.array_equal(dev[:, 3], inten) and np.array_equal(dev[:, 4], area)
