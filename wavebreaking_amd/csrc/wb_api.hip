@@ -528,7 +528,6 @@ static int run_phase1(wb_batch* b) {
             b->timer.end(ctx);
             prio_end(ctx);
             wb_scan_gate_leave(ctx);
-            wb_scan_mark(ctx);
             b->timer.begin(ctx, "scan_build");
 #define WB_BUILD_LAUNCH(T, N) hipLaunchKernelGGL((wb_k_scan_build<T, N>), bgrid, block, 0, ctx->stream, sa)
 #define WB_BUILD_N(T) \
@@ -1923,7 +1922,6 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.end(ctx);
 #if !defined(WB_HOSTSIM)
             if (geom_dma) {
-                wb_scan_mark_wait(ctx, ctx->stream);
                 // (on the stream the kernels went to; the event tables' ring offsets with the pass's totals behind them, the rings'
                 //  vertex offsets, and the first n_copy vertices -- all of them, unless this pass holds more than any before it)
                 (void)hipMemcpyAsync(h_ro, ga.ring_offset, (size_t)(cap_ne + 2 + 8) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
@@ -2410,7 +2408,6 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "geometry")) { ctx->geometry = value ? 1 : 0; return 0; }
     if (!strcmp(name, "geometry_async")) { ctx->geometry_async = value ? 1 : 0; return 0; }
     if (!strcmp(name, "geometry_dma")) { ctx->geometry_dma = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "copies_after_scan")) { ctx->copies_after_scan = value ? 1 : 0; return 0; }
     if (!strcmp(name, "index_polygons")) { ctx->index_polygons = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }

@@ -61,7 +61,6 @@ struct wb_ctx {
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int index_polygons = 0;                   // 1: wb_indices packs the events' polygons in grid indices into pinned host memory (13.5 MB per year of 0.25 degree over PCIe); 0 (default since round 6): wb_get_events packs them when it is first asked for them -- the drop-in functions build their frames from the lon / lat rings and never ask
     int geometry_async = 1;                   // 1: the geometry kernels of wb_indices (PCIe-bound: 27 MB of doubles per year of 0.25 degree) are not waited for by wb_indices -- they finish beside the next pass's field scan, wb_get_event_geometry waits for them; 0: wb_indices returns when they are done
-    int copies_after_scan = 1;                // 1: the copies that move a pass's rings to the host wait (on the device) for the field scan that is running when they are queued
     int geometry_dma = 1;                     // 1: the geometry kernels write DEVICE arrays and a DMA copy behind them moves the rings to pinned host memory (the copy engine, not the compute units, waits for PCIe; as many vertices as the context's largest pass so far held, the rest -- if any -- when the geometry is asked for); 0: the kernels store into pinned host memory themselves (round 5: while 2048 waves trickle 27 MB through PCIe every kernel beside them slows down -- wb_k_props 0.55 -> 0.9 ms)
     int geometry = 1;                         // 1: wb_indices also leaves the events' polygons in lon / lat (transform_polygons, index_utils.py:129-184) in pinned host memory, cut and mapped by the device (wb_geom.h); 0: wb_get_event_geometry computes them on the host when asked
     long long geom_seen = 0;                  // vertices of the largest pass's geometry so far (sizes the pinned arrays)
@@ -93,7 +92,6 @@ struct wb_ctx {
     hipEvent_t fork4 = nullptr, join4 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t scan_done = nullptr;           // recorded behind this context's field scan (option scan_exclusive)
-    hipEvent_t scan_mark = nullptr;           // ... (option copies_after_scan)
     hipStream_t settle_stream = nullptr;      // wb_geom_settle: the tail of a pass's geometry that the DMA copy behind its kernels did not cover (made on first use)
     std::mutex settle_mu;
     // caching device allocator: hipMalloc after hipFree of GB-sized blocks costs 100s of ms on this stack
@@ -558,28 +556,9 @@ static void wb_scan_gate_leave(wb_ctx* c) {
     (void)hipEventRecord(c->scan_done, c->stream);
     wb_scan_gate_last[c->device] = c->scan_done;
 }
-// The newest field scan launched on the device, whoever's (option copies_after_scan): the copies that move a pass's rings to the
-// host are blit kernels that read 27 MB from HBM and trickle them through PCIe -- beside the HBM-bound scan they take 1.2 ms
-// instead of 0.26 and cost it 10 %.  They wait, ON THE DEVICE, for the scan that is running when they are queued, and run beside the
-// latency-bound kernels behind it.
-static hipEvent_t wb_scan_mark_last[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-static void wb_scan_mark(wb_ctx* c) {
-    if (!c->copies_after_scan || c->device < 0 || c->device >= 16) return;
-    std::lock_guard<std::mutex> g(wb_scan_gate_mutex);
-    if (!c->scan_mark && hipEventCreateWithFlags(&c->scan_mark, hipEventDisableTiming) != hipSuccess) { c->scan_mark = nullptr; return; }
-    (void)hipEventRecord(c->scan_mark, c->stream);
-    wb_scan_mark_last[c->device] = c->scan_mark;
-}
-static void wb_scan_mark_wait(wb_ctx* c, hipStream_t on) {
-    if (!c->copies_after_scan || c->device < 0 || c->device >= 16) return;
-    std::lock_guard<std::mutex> g(wb_scan_gate_mutex);
-    if (wb_scan_mark_last[c->device]) (void)hipStreamWaitEvent(on, wb_scan_mark_last[c->device], 0);
-}
 static void wb_scan_gate_forget(wb_ctx* c) {
     std::lock_guard<std::mutex> g(wb_scan_gate_mutex);
-    if (c->device >= 0 && c->device < 16 && wb_scan_mark_last[c->device] == c->scan_mark) wb_scan_mark_last[c->device] = nullptr;
-    if (c->scan_mark) (void)hipEventDestroy(c->scan_mark);
-    c->scan_mark = nullptr;
+
     if (c->device >= 0 && c->device < 16 && wb_scan_gate_last[c->device] == c->scan_done) wb_scan_gate_last[c->device] = nullptr;
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     c->scan_done = nullptr;
@@ -588,7 +567,6 @@ static void wb_scan_gate_forget(wb_ctx* c) {
 static void wb_scan_gate_enter(wb_ctx*) {}
 static void wb_scan_gate_leave(wb_ctx*) {}
 static void wb_scan_gate_forget(wb_ctx*) {}
-static void wb_scan_mark(wb_ctx*) {}
 #endif
 
 // stage timer: HIP events on the context's stream (host simulation: zeros)
