@@ -287,6 +287,7 @@ void wb_free_batch(wb_batch* b) {
     if (b->g_event) { if (b->g_pending) (void)hipEventSynchronize(b->g_event); (void)hipEventDestroy(b->g_event); b->g_event = nullptr; }
 #endif
     b->g_pending = false;
+    b->timer.collect();                         // (the events of a stage nobody collected: the geometry kernels' when no timings were asked for)
     for (void* p : b->owned) dfree(b->ctx, p);
     hfree(b->ctx, b->poly_x, b->poly_bytes);
     hfree(b->ctx, b->poly_y, b->poly_bytes);
