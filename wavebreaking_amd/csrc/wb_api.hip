@@ -530,7 +530,9 @@ static int run_phase1(wb_batch* b) {
             prio_end(ctx);
             wb_scan_gate_leave(ctx);
             b->timer.begin(ctx, "scan_build");
-#define WB_BUILD_LAUNCH(T, N) hipLaunchKernelGGL((wb_k_scan_build<T, N>), bgrid, block, 0, ctx->stream, sa)
+#define WB_BUILD_LAUNCH(T, N) \
+            if (sa.keys_only) hipLaunchKernelGGL((wb_k_scan_build<T, N, true>), bgrid, dim3(WB_BUILD_KO_THREADS), 0, ctx->stream, sa); \
+            else hipLaunchKernelGGL((wb_k_scan_build<T, N, false>), bgrid, block, 0, ctx->stream, sa)
 #define WB_BUILD_N(T) \
             switch (p.nlevels) { case 1: WB_BUILD_LAUNCH(T, 1); break; case 2: WB_BUILD_LAUNCH(T, 2); break; \
                                  case 3: WB_BUILD_LAUNCH(T, 3); break; default: WB_BUILD_LAUNCH(T, 4); break; }

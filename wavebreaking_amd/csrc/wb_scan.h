@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256) void wb_k_scan(WbScanArgs a) {
 // copies) -- the staging format the trace kernels read.  It touches the captured patches only (a few % of the field).
 // Patch layout: value k (0..4 upper row, 5..9 lower row) of patch i of a list at cap_v[list][k * cap_rec + i].
 #define WB_BUILD_CHUNK 1024
-#define WB_BUILD_KO_CHUNK 256
+#ifndef WB_BUILD_KO_CHUNK
+#define WB_BUILD_KO_CHUNK 128
+#endif
 // in-place exclusive scan of 64-bit values in LDS (two 32-bit counters per word, no carry between them as long as each
 // stays below 2^32); every thread of the block calls it; returns the total
 __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* a, int n) {
@@ -497,13 +499,19 @@ __device__ inline unsigned long long wb_block_scan_excl_u64(unsigned long long* 
     return total;
 }
 
-template <typename T, int NLEV>
+// KO (a.keys_only, round 6 a template parameter): the pool is then cb[KOCH] + lcase[KOCH] + the patches' ten values -- 7 KB for KOCH =
+// WB_BUILD_KO_CHUNK patches (float; float64: half as many) -- and the launch has WB_BUILD_KO_THREADS threads: the kernel is a chain
+// of latency-bound phases per workgroup (patch keys, ten gathers from the field, two block scans and the segment stores per
+// level), and what hides them is workgroups per CU -- 16 of two waves instead of 8 of four (16 KB of LDS each)
+#ifndef WB_BUILD_KO_THREADS
+#define WB_BUILD_KO_THREADS 128
+#endif
+template <typename T, int NLEV, bool KO>
 __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
-    // one 16 KB pool: key + values: cb[1024] + lcase[1024]; keys only: cb[256] + lcase[256] + the patches' ten values (10 KB) -- the
-    // kernel's LDS decides how many of its 8 760 workgroups a CU holds beside the other batch's kernels
-    __shared__ unsigned long long wb_build_pool[2 * WB_BUILD_CHUNK];
-    constexpr int KOCH = sizeof(T) == 4 ? WB_BUILD_KO_CHUNK : WB_BUILD_KO_CHUNK / 2;    // keys only: patches per chunk (float64: 128 -- ten values of 8 bytes each, 10 KB as well)
-    const int CH = a.keys_only ? KOCH : WB_BUILD_CHUNK;
+    // key + values: one 16 KB pool, cb[1024] + lcase[1024]; keys only: see above
+    constexpr int KOCH = sizeof(T) == 4 ? WB_BUILD_KO_CHUNK : WB_BUILD_KO_CHUNK / 2;    // keys only: patches per chunk
+    __shared__ unsigned long long wb_build_pool[KO ? (2 * KOCH + (10 * KOCH * sizeof(T) + 7) / 8) : 2 * WB_BUILD_CHUNK];
+    const int CH = KO ? KOCH : WB_BUILD_CHUNK;
     unsigned long long* const cb = wb_build_pool;              // per patch: segments for the base list | periodic-copy list << 32 -> scan
     unsigned long long* const lcase = wb_build_pool + CH;
     T* const lvf = (T*)(wb_build_pool + 2 * CH);              // (keys only: 2 * KOCH words in front, 10 * KOCH values = 10 KB behind them: inside the pool)
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
             const uint32_t key = a.cap_k[gl * cs + li];
             const int c0 = (int)(key & 0xFFFFu);
             T v[10];
-            if (a.keys_only) {
+            if (KO) {
                 // the patch's 2 x 5 values from the field: columns c0 .. c0 + 4 (mod nlon) of rows r and r + 1, as the streaming
                 // kernel saw them (a lane's four columns + its right neighbour's first / column 0 behind the row's end)
                 const T* f0 = (const T*)a.field + ((size_t)t * a.nlat + (key >> 16)) * nlon;
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                 locate(q0 + i, gl, li);
                 const uint32_t key = a.cap_k[gl * cs + li];
                 const int r = (int)(key >> 16), c0 = (int)(key & 0xFFFFu);
-                const T* d = a.keys_only ? nullptr : (const T*)a.cap_v + gl * cs * 10 + li;
+                const T* d = KO ? nullptr : (const T*)a.cap_v + gl * cs * 10 + li;
                 const unsigned long long at = cur[l] + cb[i];
                 int mine = (int)(at & 0xFFFFFFFFull), cmine = (int)(at >> 32);
 #pragma unroll
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(256) void wb_k_scan_build(WbScanArgs a) {
                     const int ns = wb_case_nseg(cs2);
                     if (ns) {
                         T ul, ur, ll, lr;
-                        if (a.keys_only) {
+                        if (KO) {
                             ul = lvf[k * KOCH + i]; ur = lvf[(k + 1) * KOCH + i];
                             ll = lvf[(5 + k) * KOCH + i]; lr = lvf[(6 + k) * KOCH + i];
                         } else { ul = d[k * cs]; ur = d[(k + 1) * cs]; ll = d[(5 + k) * cs]; lr = d[(6 + k) * cs]; }
