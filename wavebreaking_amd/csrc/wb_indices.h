@@ -421,7 +421,10 @@ WB_HD inline double wb_haversine(double la1, double lo1, double la2, double lo2)
 #define WB_CONT_BAND 1e-6     // absolute guard band (km) on the along-contour distance
 
 // per selected contour: on[] and its prefix (streamer_index.py:133), per-point trigonometric table, block boxes
-WB_KERNEL(wb_k_streamer_prep, WbStreamerArgs a) {
+#ifndef WB_PREP_OCC
+#define WB_PREP_OCC 4              // waves per SIMD the register allocation leaves room for (4: 128 registers; the kernel is launched with 256 threads)
+#endif
+WB_KERNEL_LB(wb_k_streamer_prep, 256, WB_PREP_OCC, WbStreamerArgs a) {
     const int s = WB_BLOCK_ID;
     if (s >= a.ctl->nsel) return;
     const int job = a.sel_job[s], k = a.sel_cont[s];
