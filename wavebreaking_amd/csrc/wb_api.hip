@@ -568,21 +568,37 @@ static int run_phase1(wb_batch* b) {
     // the phase's summary -- goes through the three kernels below, which then leave the finished jobs alone.
     bool fused_all = false;
     if (ctx->trace_fused && b->W <= 16384) {
-        if (ctx->fused_seen_W != b->W) { ctx->fused_seen_W = b->W; ctx->fused_seen = 0; }
-        int nmax = ctx->trace_nmax > 0 ? ctx->trace_nmax : (ctx->fused_seen > 0 ? ctx->fused_seen + ctx->fused_seen / 16 + 64 : 3 * b->W);
-        nmax = (nmax + 255) & ~255;
-        if (nmax < 512) nmax = 512;
-        if (nmax > 8184) nmax = 8184;
+        if (ctx->fused_seen_W != b->W) { ctx->fused_seen_W = b->W; ctx->fused_seen = 0; ctx->fused_seen_c = 0; ctx->fused_seen_s = 0; }
+        // What the launch's LDS admits follows what the context's batches on this grid have asked for -- segments, chains and ranking
+        // splitters of the largest job so far, with a margin; a job that asks for more is declined and taken by the three-kernel chain,
+        // and the next launch has grown.  The LDS of a job decides how many jobs a CU holds, and the kernel's rate is that number
+        // (160 KB: three jobs at 52 KB, four at <= 40 KB): of the two margins the smaller one is taken when it admits another job per CU.
         WbFusedArgs fa;
         memset(&fa, 0, sizeof(fa));
-        fa.nmax = nmax; fa.smax = nmax / 16 + 128; fa.cmax = ctx->trace_cmax > 0 ? ctx->trace_cmax : 256; fa.nwork = b->nwork_strips;
+        fa.nwork = b->nwork_strips;
         size_t lds_block = 0, lds_cu = 0;
         wb_lds_limits(ctx, &lds_block, &lds_cu);
-        WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
-        while (L.total > lds_cu / 2 && fa.nmax > 1024) {        // never more than half a CU's LDS: smaller jobs only
-            fa.nmax -= 256; fa.smax = fa.nmax / 16 + 128;
+        WbFusedLayout L;
+        auto plan = [&](int tight) {
+            const int seen = ctx->fused_seen, seen_c = ctx->fused_seen_c, seen_s = ctx->fused_seen_s;
+            int nmax = ctx->trace_nmax > 0 ? ctx->trace_nmax : (seen > 0 ? (tight ? seen + seen / 32 + 32 : seen + seen / 16 + 64) : 3 * b->W);
+            nmax = (nmax + 63) & ~63;
+            if (nmax < 512) nmax = 512;
+            if (nmax > 8184) nmax = 8184;
+            int cmax = ctx->trace_cmax > 0 ? ctx->trace_cmax : (seen_c > 0 ? ((seen_c + seen_c / 4 + 16 + 31) & ~31) : 256);
+            if (cmax > 256 && ctx->trace_cmax <= 0) cmax = 256;
+            fa.nmax = nmax; fa.cmax = cmax;
+            const int s_grid = nmax / 16 + 128, s_seen = (seen_s + seen_s / (tight ? 16 : 8) + 16 + 7) & ~7;
+            fa.smax = (ctx->trace_nmax > 0 || seen_s <= 0 || s_seen > s_grid) ? s_grid : s_seen;
             L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
-        }
+            while (L.total > lds_cu / 2 && fa.nmax > 1024) {        // never more than half a CU's LDS: smaller jobs only
+                fa.nmax -= 256; fa.smax = fa.nmax / 16 + 128;
+                L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
+            }
+            return (int)(lds_cu / (L.total + 512));                // jobs per CU (512: the kernel's static LDS, rounded up)
+        };
+        const int per_cu_wide = plan(0);
+        if (ctx->trace_nmax <= 0 && plan(1) <= per_cu_wide) (void)plan(0);
         bool ok = L.total <= lds_cu / 2;
 #if !defined(WB_HOSTSIM)
         if (ok && L.total > lds_block && hipFuncSetAttribute((const void*)wb_k_trace_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total) != hipSuccess) {
@@ -600,7 +616,9 @@ static int run_phase1(wb_batch* b) {
             b->timer.end(ctx);
             if (phase1_summary(b)) return 1;
             if (b->h_ctl.max_nseg > ctx->fused_seen) ctx->fused_seen = b->h_ctl.max_nseg;
-            if (wb_debug()) fprintf(stderr, "[wb] fused trace: nmax %d smax %d cmax %d, %zu B of LDS, %d of %d jobs declined, largest job %d\n", fa.nmax, fa.smax, fa.cmax, L.total, b->h_ctl.n_unfused, J, b->h_ctl.max_nseg);
+            if (b->h_ctl.max_chains > ctx->fused_seen_c) ctx->fused_seen_c = b->h_ctl.max_chains;
+            if (b->h_ctl.max_splitters > ctx->fused_seen_s) ctx->fused_seen_s = b->h_ctl.max_splitters;
+            if (wb_debug()) fprintf(stderr, "[wb] fused trace: nmax %d smax %d cmax %d, %zu B of LDS (%d jobs per CU), %d of %d jobs declined, largest job %d segments, %d chains, %d splitters\n", fa.nmax, fa.smax, fa.cmax, L.total, (int)(lds_cu / (L.total + 512)), b->h_ctl.n_unfused, J, b->h_ctl.max_nseg, b->h_ctl.max_chains, b->h_ctl.max_splitters);
             if (b->h_ctl.n_unfused == 0) fused_all = true;
             else {
                 ta.fdone = fdone;
@@ -2413,7 +2431,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "geometry_dma")) { ctx->geometry_dma = value ? 1 : 0; return 0; }
     if (!strcmp(name, "index_polygons")) { ctx->index_polygons = value ? 1 : 0; return 0; }
     if (!strcmp(name, "trace_nmax")) { ctx->trace_nmax = value > 0 ? value : 0; return 0; }
-    if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 256; return 0; }
+    if (!strcmp(name, "trace_cmax")) { ctx->trace_cmax = value > 0 ? value : 0; return 0; }
     if (!strcmp(name, "f1_fused")) { ctx->f1_fused = value ? 1 : 0; return 0; }
     if (!strcmp(name, "f234_lpts")) { ctx->f234_lpts = value >= 64 ? value : 0; return 0; }      // (tests: longer contours take wb_k_streamer_f234's path through global memory)
     if (!strcmp(name, "scan_bands")) { ctx->scan_bands = value; return 0; }

@@ -88,6 +88,7 @@ struct WbCtl {
     int n_slow;                  // jobs the second trace pass redoes: more segments than the LDS paths hold, or an order-dependent join (cells equal to the level)
     int n_unfused;               // jobs wb_k_trace_fused declined (cells equal to the level, more segments / chains than its LDS holds): the three-kernel chain takes them
     int max_nseg;                // largest segment count of a job (sizes the fused kernel's LDS for the context's next batch)
+    int max_chains, max_splitters;   // ... largest number of chains (raw contours) / of ranking splitters of a job the fused kernel finished
     // phase 2 (wb_indices)
     int nsel, ncut;              // selected contours / cutoff contours
     long long npt_sel;

@@ -68,8 +68,9 @@ struct wb_ctx {
     int trace_fused = 1;                      // 1: the contours of a job by ONE kernel with the job resident in LDS (wb_trace_fused.h); 0: link -> rank -> finish (wb_trace.h), which also take the jobs the fused kernel declines
     int f1_fused = 0;                         // routine 1 of the streamer index inside wb_k_streamer_f234 (0: wb_k_streamer_f1 in front of it)
     int f234_lpts = 0;                        // wb_k_streamer_f234: contour points its LDS holds at most (0: WB_F234_LPTS)
-    int trace_nmax = 0, trace_cmax = 256;     // fused kernel: segments / chains per job its LDS admits (trace_nmax 0: from the grid's width, then from the largest job the context has seen)
+    int trace_nmax = 0, trace_cmax = 0;       // fused kernel: segments / chains per job its LDS admits (0: from the grid's width / 256 chains, then from the largest job the context has seen)
     int fused_seen = 0, fused_seen_W = 0;     // largest segment count of a job in the context's batches so far on the grid of that width
+    int fused_seen_c = 0, fused_seen_s = 0;   // ... largest number of chains / of ranking splitters
     int link_rows = 1;                        // wb_k_trace_link: merge by row tables in LDS (0: by binary searches, the path of jobs / grids the tables do not hold)
     int scan_band_rows = 0;                   // streaming scan: rows of squares per band (0: the rows divided evenly over the bands)
     int scan_pad = 0;                         // streaming scan: elements added to the stride of the patch lists' arrays (WbScanArgs.cap_vs)

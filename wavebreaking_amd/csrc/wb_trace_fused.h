@@ -31,16 +31,23 @@
 #ifndef WB_FUSED_THREADS
 #define WB_FUSED_THREADS 256
 #endif
+#ifndef WB_FUSED_OCC
+#define WB_FUSED_OCC 2              // waves per SIMD the register allocation leaves room for
+#endif
 #define WB_F_SPLIT 16                // every WB_F_SPLIT-th segment is a splitter
 #define WB_F_NIL 0x1FFFu             // 13-bit links: a job of the fused path has at most 8190 segments
 #define WB_F_HEAD 0x8000u            // flags in the upper bits of a link word
 #define WB_F_SPLITTER 0x4000u
 #define WB_F_NONE 0xFFFFFFFFu
 #define WB_F_NCAND 128
+#if defined(WB_HOSTSIM)
+#define WB_F_QREG 1024               // splitters whose ranking word one thread carries across a barrier (the host simulation's single thread: all)
+#else
+#define WB_F_QREG ((1023 + WB_FUSED_THREADS) / WB_FUSED_THREADS)
+#endif
 #define WB_F_WALK 32                 // a walk hands over to a new splitter after this many segments (the longest walk sets the phase's duration)
 
 // LDS layout (bytes) for a launch that admits jobs of up to nmax segments, smax splitters, cmax chains
-#define WB_F_XSHIFT 0                // a bucket holds the raw points of 1 << WB_F_XSHIFT neighbouring meridians (x mod nlon)
 struct WbFusedLayout {
     // region A: keys (link) -> owner / local position (ranking) -> raw points, packed contour | y | x
     // region B: links + flags (link, ranking) -> destination of a segment's point -> bucket order
@@ -48,10 +55,16 @@ struct WbFusedLayout {
     size_t oA, oB, oT, total;
     size_t t_rawbase, t_closed;      // per contour, from the numbering to the end
     // group 1 (link + ranking) and group 2 (finish) share what follows
-    size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_q1, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
+    size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
     size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_nuxc, g2_sumyc, g2_setc, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
 };
 WB_HD inline size_t wb_f_al(size_t v) { return (v + 7) & ~(size_t)7; }
+// buckets of the raw points: the largest power of two <= nlon (+ 1: see phase F)
+WB_HD inline int wb_f_nbuckets(int nlon) {
+    int nb = 1;
+    while (2 * nb <= nlon) nb <<= 1;
+    return nb;
+}
 WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlon, int nthreads) {
     WbFusedLayout L;
     const size_t R = (size_t)nmax + cmax + 2;
@@ -73,7 +86,6 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     L.g1_nnext = g1; g1 += wb_f_al(2 * S1);
     L.g1_cix = g1; g1 += wb_f_al(4 * S1);
     L.g1_q0 = g1; g1 += wb_f_al(8 * S1);
-    L.g1_q1 = g1; g1 += wb_f_al(8 * S1);
     L.g1_cmin = g1; g1 += wb_f_al(4 * C1);
     L.g1_cmaxk = g1; g1 += wb_f_al(4 * C1);
     L.g1_lnode = g1; g1 += wb_f_al(2 * C1);
@@ -82,7 +94,7 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     L.g1_cloop = g1; g1 += wb_f_al(C1);
     L.g1_cnum = g1; g1 += wb_f_al(2 * C1);
     size_t g2 = t;
-    L.g2_cnt = g2; g2 += wb_f_al(4 * (((size_t)nlon >> WB_F_XSHIFT) + 3));
+    L.g2_cnt = g2; g2 += wb_f_al(4 * ((size_t)wb_f_nbuckets(nlon) + 3));
     L.g2_keep = g2; g2 += wb_f_al(4 * ((R + 31) / 32 + 1));
     L.g2_dup = g2; g2 += wb_f_al(4 * ((R + 31) / 32 + 1));
     L.g2_blk = g2; g2 += wb_f_al(2 * ((R + 31) / 32 + 2));
@@ -134,7 +146,7 @@ struct WbFusedArgs {
     unsigned char* fdone;            // [njobs] 1: this kernel finished the job, 0: the three-kernel chain must
 };
 
-WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
+WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     const WbTraceArgs& a = fa.t;
     const int job = WB_BLOCK_ID;
     if (job >= a.njobs) return;
@@ -168,8 +180,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     uint16_t* const nnext = (uint16_t*)(T + L.g1_nnext);
     uint16_t* const ndend = nnext;                             // (the sub-list's end, until it has become the next splitter's ordinal)
     int* const cix = (int*)(T + L.g1_cix);
-    unsigned long long* const Q0 = (unsigned long long*)(T + L.g1_q0);
-    unsigned long long* const Q1 = (unsigned long long*)(T + L.g1_q1);
+    unsigned long long* const Q = (unsigned long long*)(T + L.g1_q0);
     uint32_t* const cmin = (uint32_t*)(T + L.g1_cmin);
     uint32_t* const cmaxk = (uint32_t*)(T + L.g1_cmaxk);
     uint16_t* const lnode = (uint16_t*)(T + L.g1_lnode);
@@ -260,8 +271,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // that there is none, for nearly every segment (the entries between two rows of a strip are few).  What they leave open --
     // the target square lies in another strip's list, or further away -- goes to a short queue that is searched afterwards.
     const float invW = 1.0f / (float)W;
-    uint16_t* const queue = (uint16_t*)(K + n);                 // (behind the keys: region A has room for cmax + 2 more words)
-    const int QMAX = 2 * fa.cmax;
+    uint16_t* const queue = (uint16_t*)Q;                       // (the splitters' ranking words are not in use yet: four entries per splitter)
+    const int QMAX = 4 * fa.smax;
     // square and side a segment leads to -> the list that holds the square, or -1 (off the grid: the contour ends there)
     auto aim = [&](const uint32_t k, int* target, int* want) -> int {
         const int sq = wb_key_sq(k), cs = wb_key_case(k), sub = wb_key_sub(k);
@@ -354,7 +365,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         wpre[w] = wb_popc32(f);
     WB_END_PFOR
     const int S1 = wb_block_scan_excl(wpre, nwords);
-    if (S1 > fa.smax || fa.smax > 1023) WB_F_DECLINE();
+    // (what a job asked for sizes the context's next launch -- also when this one declines it)
+#define WB_F_NOTE(field, v) do { if (WB_TID == 0) wb_atomic_max(&a.ctl->field, (int)(v)); } while (0)
+    if (S1 > fa.smax || fa.smax > 1023) { WB_F_NOTE(max_splitters, S1 + S1 / 8); WB_F_DECLINE(); }
     WB_PFOR32(w, nwords)
         uint32_t f = spb[w];
         int o = wpre[w];
@@ -400,7 +413,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     WB_END_PFOR
     // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
     const int S2 = ctr[1];
-    if (ctr[0] || S2 > fa.smax) WB_F_DECLINE();
+    if (ctr[0] || S2 > fa.smax) { WB_F_NOTE(max_splitters, S2 + fa.smax / 8); WB_F_DECLINE(); }
     WB_PFOR32(g, n)
         bool want = false;
         const uint32_t w = S[g];
@@ -412,12 +425,12 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         if (want && slot < fa.smax) { ndseg[slot] = (uint16_t)g; wb_atomic_or(&spb[g >> 5], 1u << (g & 31)); }
     WB_END_PFOR
     const int S3 = ctr[1];
-    if (S3 > fa.smax) WB_F_DECLINE();
+    if (S3 > fa.smax) { WB_F_NOTE(max_splitters, S3); WB_F_DECLINE(); }
     WB_PFOR32(o, S3 - S2)
         walk(S2 + (int)o);
     WB_END_PFOR
     const int NSP = ctr[1];
-    if (ctr[0] || NSP > fa.smax) WB_F_DECLINE();
+    if (ctr[0] || NSP > fa.smax) { WB_F_NOTE(max_splitters, NSP + fa.smax / 8); WB_F_DECLINE(); }
     // C4: the splitters' own list: next splitter, previous splitter
     const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
     WB_PFOR32(o, NSP)
@@ -434,29 +447,40 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
 #define WB_FQ(j, d, h, m) ((unsigned long long)(uint16_t)(j) | (unsigned long long)(uint16_t)(d) << 16 | (unsigned long long)(uint16_t)(h) << 32 | (unsigned long long)(uint16_t)(m) << 48)
     int rounds = 0;
     while ((1 << rounds) < NSP) ++rounds;
-    auto rank_nodes = [&]() -> unsigned long long* {
+    // In place: a thread holds the new words of its nodes (at most WB_F_QREG: smax <= 1023) across a barrier -- a second array of
+    // words was 3 KB of the job's LDS, and the LDS decides how many jobs a CU holds.
+    auto rank_nodes = [&]() {
         WB_PFOR32(o, NSP)
             const uint16_t p = ncp[o];
-            Q0[o] = WB_FQ(p, p != NN ? nlen[p] : 0, o, o);
+            Q[o] = WB_FQ(p, p != NN ? nlen[p] : 0, o, o);
         WB_END_PFOR
-        unsigned long long *qi = Q0, *qo = Q1;
         for (int it = 0; it < rounds; ++it) {
-            WB_PFOR32(o, NSP)
-                const unsigned long long w = qi[o];
+            unsigned long long nwq[WB_F_QREG];
+#pragma unroll
+            for (int u = 0; u < WB_F_QREG; ++u) {
+                const int o = WB_TID + u * WB_NT;
+                if (o >= NSP) break;
+                const unsigned long long w = Q[o];
                 const uint16_t j = (uint16_t)w;
                 unsigned long long nw = w;
                 if (j != NN) {
-                    const unsigned long long wj = qi[j];
+                    const unsigned long long wj = Q[j];
                     const uint16_t m1 = (uint16_t)(w >> 48), m2 = (uint16_t)(wj >> 48);
                     nw = WB_FQ((uint16_t)wj, (uint16_t)(w >> 16) + (uint16_t)(wj >> 16), (uint16_t)(wj >> 32), m1 < m2 ? m1 : m2);
                 }
-                qo[o] = nw;
-            WB_END_PFOR
-            unsigned long long* t = qi; qi = qo; qo = t;
+                nwq[u] = nw;
+            }
+            WB_SYNC();
+#pragma unroll
+            for (int u = 0; u < WB_F_QREG; ++u) {
+                const int o = WB_TID + u * WB_NT;
+                if (o >= NSP) break;
+                Q[o] = nwq[u];
+            }
+            WB_SYNC();
         }
-        return qi;
     };
-    unsigned long long* Q = rank_nodes();
+    rank_nodes();
     // chains: an open chain is named by its first node, a loop (jump pointer still alive) by its smallest ordinal
     WB_PFOR32(o, NSP)
         const unsigned long long w = Q[o];
@@ -466,7 +490,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         if (loop) ctr[3] = 1;
     WB_END_PFOR
     const int C = wb_block_scan_excl(cix, NSP);               // cix[o] (for a naming node): the chain's index
-    if (C > cmax) WB_F_DECLINE();
+    if (C > cmax) { WB_F_NOTE(max_chains, C); WB_F_DECLINE(); }
     const bool any_loop = ctr[3] != 0;
     // every node learns its chain's index (the naming node's entry is read before anything overwrites it: two steps)
     WB_PFOR32(o, NSP)
@@ -497,7 +521,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
         WB_PFOR32(ch, C)
             if (cloop[ch]) ncp[lnode[ch]] = NN;
         WB_END_PFOR
-        Q = rank_nodes();
+        rank_nodes();
     }
     // chain lengths
     WB_PFOR32(o, NSP)
@@ -578,8 +602,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     // ---- F: buckets of the raw points by (x mod nlon, y).  A point equal to its predecessor in
     // the same contour can never be a first occurrence (about half of all raw points: neighbouring crossings that round to the
     // same lattice point): it stays out.
-    int NBP = 1;                                                 // buckets: the largest power of two the counters hold
-    while (2 * NBP <= nlon) NBP <<= 1;
+    const int NBP = wb_f_nbuckets(nlon);                         // buckets: the largest power of two the counters hold
     const int NB = NBP + 1;
     WB_PFOR32(x, NB + 1)
         cnt[x] = 0;
@@ -756,8 +779,11 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, 2, WbFusedArgs fa) {
     a.ncont[job] = Cf;
     a.nseg[job] = n;
     fa.fdone[job] = 1;
+    wb_atomic_max(&a.ctl->max_chains, C);                       // (size the next batch's launch: wb_fused_layout)
+    wb_atomic_max(&a.ctl->max_splitters, NSP);
     WB_END_SINGLE
 #undef WB_F_DECLINE
+#undef WB_F_NOTE
 #undef WB_FQ
 #undef WB_F_OWN
 #undef WB_F_LP
