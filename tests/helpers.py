@@ -338,6 +338,33 @@ def level_hit_field(seed, dlon=1.0, eps=0.3, nhits=4, level=2.0, seam=True):
     return pv, lat, lon
 
 
+def half_way_crossing_field(seed, dlon=2.5, dtype=np.float32, level=2.0):
+    """synthetic PV whose cells next to the `level` contour sit at distances from the level that put the crossings AT one half of
+    their edges (exact ties of np.round: half to even), a few float32 / float64 ulps beside it, and a few 1e-4 .. 1e-2 beside it --
+    the band in which wb_k_trace_fused leaves its float32 pre-decision for the reference's float64 quotient.  No cell equals the level."""
+    from oracle import synth
+    lat, lon = synth.grid(dlon)
+    rng = np.random.RandomState(5000 + seed)
+    pv = synth.pv_field(seed, 2, lat, lon, eps=0.25).astype(np.float64)
+    for a in pv:
+        hi = a > level
+        m = np.zeros_like(hi)
+        m[:-1] |= hi[:-1] != hi[1:]
+        m[1:] |= hi[:-1] != hi[1:]
+        m[:, :-1] |= hi[:, :-1] != hi[:, 1:]
+        m[:, 1:] |= hi[:, :-1] != hi[:, 1:]
+        dist = rng.choice([0.5, 1.0, 1.5, 3.0], size=a.shape)      # |value - level| of the cells at the contour: equal distances on both sides = ties
+        kind = rng.randint(0, 4, size=a.shape)
+        eps_t = np.finfo(dtype).eps
+        off = np.where(kind == 0, 0.0, np.where(kind == 1, rng.randint(-3, 4, size=a.shape) * eps_t,
+                       np.where(kind == 2, rng.uniform(-4e-3, 4e-3, size=a.shape), rng.uniform(-4e-2, 4e-2, size=a.shape))))
+        q = level + np.where(hi, 1.0, -1.0) * dist * (1.0 + off)
+        a[m] = q[m]
+    pv = pv.astype(dtype)
+    assert not np.any(pv == level)
+    return pv, lat, lon
+
+
 def not_simple_polygon_case(ctx):
     """A cutoff whose polygon crosses itself (a bow tie handed in as a closed contour) next to a simple one: the event
     table flags the first, the oracle's winding numbers agree, cells follow the non-zero winding rule."""

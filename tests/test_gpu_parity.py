@@ -314,7 +314,7 @@ def _contour_tables_gpu(ctx, pv, lat, lon, levels, d, padd, **opts):
         st = np.array(b.status())
         b.close()
     finally:
-        for k, v in dict(trace_fused=1, trace_nmax=0, trace_cmax=256).items():
+        for k, v in dict(trace_fused=1, trace_nmax=0, trace_cmax=0).items():
             ctx.set_option(k, v)
     return tab, st
 
@@ -345,6 +345,25 @@ def test_fused_trace_kernel_equals_the_three_kernel_chain(ctx):
                     assert np.array_equal(ref[key], got[key]), (d, padd, opts, key)
                 assert np.array_equal(st0, st1), (d, padd, opts)
     assert total > 400
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_crossings_at_one_half_of_their_edges(ctx, dtype):
+    """crossing fractions of exactly one half (np.round: half to even, contour_index.py:111), a few ulps beside it and a few 1e-3
+    beside it: wb_k_trace_fused decides most lattice points from a float32 quotient (v_rcp_f32) and these from the reference's
+    float64 one -- same tables as the three-kernel chain, which evaluates every crossing in float64, and as the oracle"""
+    total = 0
+    for seed in range(6):
+        pv, lat, lon = helpers.half_way_crossing_field(seed, dlon=2.5 if seed < 4 else 1.0, dtype=dtype)
+        d = 2.5 if seed < 4 else 1.0
+        ref, st0 = _contour_tables_gpu(ctx, pv, lat, lon, [2.0], d, 120.0, trace_fused=0)
+        got, st1 = _contour_tables_gpu(ctx, pv, lat, lon, [2.0], d, 120.0, trace_fused=1)
+        for key in ref:
+            assert np.array_equal(ref[key], got[key]), (seed, key)
+        assert np.array_equal(st0, st1)
+        total += ref["step"].size
+        helpers.full_parity(ctx, pv, lat, lon, synth.times(2), [2.0])
+    assert total > 30
 
 
 def test_device_geometry_equals_host_geometry(ctx):

@@ -17,15 +17,14 @@ enum { WB_TOP = 0, WB_RIGHT = 1, WB_BOTTOM = 2, WB_LEFT = 3 };
 // entry = from0 | to0<<2 | from1<<4 | to1<<6 ; number of segments in WB_NSEG.
 //  1:(T->L) 2:(R->T) 3:(R->L) 4:(L->B) 5:(T->B) 6:(R->T),(L->B) 7:(R->B)
 //  8:(B->R) 9:(T->L),(B->R) 10:(B->T) 11:(B->L) 12:(L->R) 13:(T->R) 14:(L->T)
-WB_HD inline int wb_case_nseg(int c) { return (c == 0 || c == 15) ? 0 : ((c == 6 || c == 9) ? 2 : 1); }
-// sides T=0 R=1 B=2 L=3, two bits per case (packed so that no constant array lands in scratch)
+// (tables packed into constants, two bits per case: no constant array lands in scratch, no branch on the case)
+WB_HD inline int wb_case_nseg(int c) { return (int)((0x15596554u >> (2 * c)) & 3u); }     // 0 / 15: none, 6 / 9: two, else one
+// sides T=0 R=1 B=2 L=3; the second segment of a saddle: 6:(L->B)  9:(B->R)
 WB_HD inline int wb_seg_from(int c, int sub) {
-    if (sub) return c == 6 ? WB_LEFT : WB_BOTTOM;     // 6:(L->B)  9:(B->R)
-    return (int)((0x33a25350u >> (2 * c)) & 3u);
+    return (int)(((sub ? 0xAAAABAAAu : 0x33a25350u) >> (2 * c)) & 3u);
 }
 WB_HD inline int wb_seg_to(int c, int sub) {
-    if (sub) return c == 6 ? WB_BOTTOM : WB_RIGHT;
-    return (int)((0x05cd8accu >> (2 * c)) & 3u);
+    return (int)(((sub ? 0x55556555u : 0x05cd8accu) >> (2 * c)) & 3u);
 }
 
 // crossing fraction, exactly skimage's _get_fraction (float64)
@@ -120,12 +119,19 @@ struct WbCtl {
 // -DWB_STAMPS=1 instruments wb_k_streamer_f234 (WB_STAMP), =2 wb_k_streamer_pairs (WB_PSTAMP), =3 wb_k_props (WB_RSTAMP), =4 wb_k_trace_finish (WB_TSTAMP), =5 wb_k_box_com (WB_BSTAMP), =6 wb_k_trace_link (WB_LSTAMP), =7 wb_k_trace_rank (WB_KSTAMP), =8 wb_k_trace_fused (WB_FSTAMP); WB_DEBUG_STAMPS=1 prints.
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS)
 // sums kept in registers of thread 0, one global atomic per phase and workgroup at the end (..._FLUSH)
+#if defined(WB_STAMPS_FINE)
+// -DWB_STAMPS_FINE: twenty sums (a kernel's WB_xSTAMP_FINE stamps cut its phases further), no statistics of the longest workgroup
+#define WB_STAMPX_BEGIN long long wb_acc_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
+#define WB_STAMPX(ctl, k) do { if (threadIdx.x == 0) { const long long wb_n_ = (long long)wall_clock64(); wb_acc_[k] += wb_n_ - wb_st_; wb_st_ = wb_n_; } } while (0)
+#define WB_STAMPX_FLUSH(ctl) do { if (threadIdx.x == 0) { for (int wb_q_ = 0; wb_q_ < 20; ++wb_q_) if (wb_acc_[wb_q_]) atomicAdd((unsigned long long*)&(ctl)->dbg[wb_q_], (unsigned long long)wb_acc_[wb_q_]); } } while (0)
+#else
 #define WB_STAMPX_BEGIN long long wb_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wb_st_ = (threadIdx.x == 0) ? (long long)wall_clock64() : 0;
 #define WB_STAMPX(ctl, k) do { if (threadIdx.x == 0) { const long long wb_n_ = (long long)wall_clock64(); wb_acc_[k] += wb_n_ - wb_st_; wb_st_ = wb_n_; } } while (0)
 // (dbg[20]: the longest workgroup; dbg[21..23]: workgroups that took more than 200 / 400 / 800 us, printed as count * 1e-5)
 #define WB_STAMPX_FLUSH(ctl) do { if (threadIdx.x == 0) { long long wb_t_ = 0; for (int wb_q_ = 0; wb_q_ < 12; ++wb_q_) if (wb_acc_[wb_q_]) { wb_t_ += wb_acc_[wb_q_]; atomicAdd((unsigned long long*)&(ctl)->dbg[wb_q_], (unsigned long long)wb_acc_[wb_q_]); } \
     if (atomicMax((unsigned long long*)&(ctl)->dbg[20], (unsigned long long)wb_t_) < (unsigned long long)wb_t_) for (int wb_q_ = 0; wb_q_ < 8; ++wb_q_) (ctl)->dbg[12 + wb_q_] = wb_acc_[wb_q_ < 3 ? 4 + wb_q_ : wb_q_ + 5];   /* the longest workgroup's own stamps 4, 5, 6 and 8 .. 11 (slots 12 ..) */ \
     for (int wb_q_ = 0; wb_q_ < 3; ++wb_q_) if (wb_t_ > (20000ll << wb_q_)) atomicAdd((unsigned long long*)&(ctl)->dbg[21 + wb_q_], 1ull); } } while (0)
+#endif
 #endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 1
 #define WB_STAMP_BEGIN WB_STAMPX_BEGIN
@@ -187,9 +193,15 @@ struct WbCtl {
 #define WB_FSTAMP_BEGIN WB_STAMPX_BEGIN
 #define WB_FSTAMP(ctl, k) WB_STAMPX(ctl, k)
 #define WB_FSTAMP_FLUSH(ctl) WB_STAMPX_FLUSH(ctl)
+#if defined(WB_STAMPS_FINE)
+#define WB_FSTAMP_FINE(ctl, k) WB_STAMPX(ctl, k)
+#else
+#define WB_FSTAMP_FINE(ctl, k) ((void)0)
+#endif
 #else
 #define WB_FSTAMP_BEGIN
 #define WB_FSTAMP(ctl, k) ((void)0)
+#define WB_FSTAMP_FINE(ctl, k) ((void)0)
 #define WB_FSTAMP_FLUSH(ctl) ((void)0)
 #endif
 #if !defined(WB_HOSTSIM) && defined(WB_STAMPS) && WB_STAMPS == 9      // wb_k_streamer_f1 (routine 1)

@@ -92,6 +92,8 @@ static inline double wb_block_sum_f64(double v, double* lw) { (void)lw; return v
 static inline void wb_block_add_u64(unsigned long long* acc, unsigned long long v) { *acc += v; }
 // slot of an append to a list whose length counter all calling lanes share (-1 for lanes with want == false)
 static inline int wb_append_slot(int* counter, bool want) { return want ? (*counter)++ : -1; }
+// approximate reciprocal (the device's v_rcp_f32: 1 ulp); for decisions that carry their own margin only
+static inline float wb_rcp_f32(float v) { return 1.0f / v; }
 // first slot of n (0 <= n < 32) consecutive entries appended by the calling lane
 static inline int wb_append_slots(int* counter, int n) { const int b = *counter; *counter += n; return b; }
 
@@ -249,6 +251,7 @@ __device__ inline void wb_atomic_add_agg(int* base, int idx, int val) {
 // slot of an append to a list whose length counter ALL calling lanes share (-1 for lanes with want == false): one atomic
 // per wave instead of one per appending lane (same-address atomics serialise).  Call from code every lane of interest
 // reaches together; lanes that left the enclosing loop are simply not in the ballot.
+__device__ inline float wb_rcp_f32(float v) { return __builtin_amdgcn_rcpf(v); }
 __device__ inline int wb_append_slot(int* counter, bool want) {
     const unsigned long long m = __ballot(want);
     if (!m) return -1;

@@ -55,7 +55,7 @@ struct WbFusedLayout {
     size_t oA, oB, oT, total;
     size_t t_rawbase, t_closed;      // per contour, from the numbering to the end
     // group 1 (link + ranking) and group 2 (finish) share what follows
-    size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_cmin, g1_cmaxk, g1_lnode, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
+    size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_cmin, g1_cmaxk, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
     size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_nuxc, g2_sumyc, g2_setc, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
 };
 WB_HD inline size_t wb_f_al(size_t v) { return (v + 7) & ~(size_t)7; }
@@ -87,8 +87,7 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     L.g1_cix = g1; g1 += wb_f_al(4 * S1);
     L.g1_q0 = g1; g1 += wb_f_al(8 * S1);
     L.g1_cmin = g1; g1 += wb_f_al(4 * C1);
-    L.g1_cmaxk = g1; g1 += wb_f_al(4 * C1);
-    L.g1_lnode = g1; g1 += wb_f_al(2 * C1);
+    L.g1_cmaxk = g1; g1 += wb_f_al(8 * C1);
     L.g1_lpos = g1; g1 += wb_f_al(2 * C1);
     L.g1_ctot = g1; g1 += wb_f_al(4 * C1);
     L.g1_cloop = g1; g1 += wb_f_al(C1);
@@ -109,10 +108,16 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     L.g2_dropped = g2; g2 += wb_f_al(C1);
     L.g2_ckept = g2; g2 += wb_f_al(2 * C1);
     L.g2_fin = g2; g2 += wb_f_al(4 * C1);
-    L.g2_tcount = g2; g2 += wb_f_al(4 * ((size_t)nthreads + 2));
+    L.g2_tcount = g2; g2 += wb_f_al(4 * ((size_t)(nthreads > cmax ? nthreads : cmax) + 2));
     L.g2_cand = g2; g2 += wb_f_al(4 * 2 * WB_F_NCAND);
     L.total = L.oT + (g1 > g2 ? g1 : g2);
     return L;
+}
+
+// the reference's arithmetic for a crossing's coordinate along its edge (wb_crossing_point): kept out of line, the fused kernel
+// needs it for one crossing in a few hundred
+WB_DEV WB_NOINLINE int wb_f_along_exact(int base, double va, double vb, double level) {
+    return wb_rint((double)base + wb_fraction(va, vb, level));
 }
 
 // position g in the concatenation of a job's lists -> (list, index inside it)
@@ -153,7 +158,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     const int NS = a.nstrips, W = a.W, nlon = a.nlon, nlat = a.nlat;
     const size_t jb = (size_t)job * a.cap_seg;
     WB_SHARED(int, sbase, WB_MAX_LISTS + 2);
-    WB_SHARED(int, ctr, 8);          // [0] bail flag, [1] splitters, [2] chains, [3] any loop, [4] queued pairs, [5] pair failure flag, [6] points in buckets
+    WB_SHARED(int, ctr, 8);          // [0] bail flag, [1] splitters, [4] queued pairs, [5] pair failure flag, [6] queued successor searches, [7] contours' first segments
     WB_DYN_SHARED_BEGIN
     const WbFusedLayout L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, nlon, WB_FUSED_THREADS);
     WB_DYN_SHARED(unsigned char, lds, L.total);
@@ -182,8 +187,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     int* const cix = (int*)(T + L.g1_cix);
     unsigned long long* const Q = (unsigned long long*)(T + L.g1_q0);
     uint32_t* const cmin = (uint32_t*)(T + L.g1_cmin);
-    uint32_t* const cmaxk = (uint32_t*)(T + L.g1_cmaxk);
-    uint16_t* const lnode = (uint16_t*)(T + L.g1_lnode);
+    unsigned long long* const cmaxk = (unsigned long long*)(T + L.g1_cmaxk);      // a loop's largest key << 16 | the segment that has it
     uint16_t* const lpos = (uint16_t*)(T + L.g1_lpos);
     int* const ctot = (int*)(T + L.g1_ctot);
     unsigned char* const cloop = T + L.g1_cloop;
@@ -297,35 +301,49 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         if (wb_case_nseg(cs2) == 2 && wb_seg_from(cs2, 1) == want) return (uint32_t)f + 1u;
         return WB_F_NIL;
     };
-    int lrun = 0;
+    // (The main loop knows nothing of the lists' ends: a square lives in ONE list, so an entry of the window that belongs to a
+    // neighbouring list can never equal the target, and "at or beyond the target" read off such an entry is either right -- the
+    // window has left the segment's own list without meeting the target: there is no such square -- or leaves the segment to the
+    // queue.  The segment's own list and the target's are told apart by their columns.)
+    // Written as data flow -- flags combined with & and |, values chosen by flags, every load unconditional from a clamped position:
+    // the compiler turns `if`s and short-circuit conditions around LDS loads into exec-mask branches, a dozen of them per segment.
+    static_assert(WB_STRIP == 256, "the strip of a column is taken by a shift");
     WB_PFOR32(g, n)
         const uint32_t k = K[g];
-        int target, want;
-        const int tl = aim(k, &target, &want);
-        (void)wb_f_locate_run(sbase, (int)g, &lrun);              // the segment's own list
-        const int lo = sbase[lrun], hi = sbase[lrun + 1];
-        const int cs = wb_key_case(k), sub = wb_key_sub(k);
-        const bool fwd = (want ^ 2) == WB_RIGHT || (want ^ 2) == WB_BOTTOM;
+        const int sq = wb_key_sq(k), cs = wb_key_case(k), sub = wb_key_sub(k);
+        int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;     // sq / W without the integer division (sq < 2^24: exact up to the fix-up)
+        const int adj = (c >= W ? 1 : 0) - (c < 0 ? 1 : 0);
+        r += adj; c -= adj * W;
+        const int ts = wb_seg_to(cs, sub), want = ts ^ 2;
+        const int fwd = (ts == WB_RIGHT ? 1 : 0) | (ts == WB_BOTTOM ? 1 : 0), step = 2 * fwd - 1;
+        const int rr = r + (ts == WB_BOTTOM ? 1 : 0) - (ts == WB_TOP ? 1 : 0), cc = c + (ts == WB_RIGHT ? 1 : 0) - (ts == WB_LEFT ? 1 : 0);
+        const int target = rr * W + cc;
+        const int tl = cc < nlon ? (cc >> 8) : NSB + ((cc - nlon) >> 8);
+        const int ls = c < nlon ? (c >> 8) : NSB + ((c - nlon) >> 8);
+        const int there = (rr >= 0 ? 1 : 0) & (rr < nlat - 1 ? 1 : 0) & (cc >= 0 ? 1 : 0) & (cc < W - 1 ? 1 : 0) & (tl < NS ? 1 : 0);      // (0: off the grid, the contour ends)
         const int b = fwd ? (int)g - sub + wb_case_nseg(cs) : (int)g - sub - 1;
         uint32_t kw[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int at = fwd ? b + q : b - q;
-            kw[q] = (at >= lo && at < hi) ? K[at] : (fwd ? 0x07FFFFFFu : 0u);      // (past the list's end: beyond every target / in front of every target)
+            int at = b + q * step;
+            at = at < 0 ? 0 : at;
+            kw[q] = K[at > n - 1 ? n - 1 : at];
         }
-        uint32_t sc = WB_F_NIL;
-        bool open = false;
-        if (tl == lrun) {
-            open = true;
-            int hit = -1;
+        int undecided = there & (tl == ls ? 1 : 0), hit = -1, hcs = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int at = fwd ? b + q : b - q;
-                const int sq2 = (at >= lo && at < hi) ? wb_key_sq(kw[q]) : (fwd ? 0x7FFFFFFF : -1);
-                if (open && (fwd ? sq2 >= target : sq2 <= target)) { open = false; if (sq2 == target) hit = at - (fwd ? 0 : wb_key_sub(kw[q])); }
-            }
-            if (hit >= 0) sc = pick(hit, want);
-        } else if (tl >= 0) open = true;                           // another strip's list
+        for (int q = 0; q < 4; ++q) {
+            const int at = b + q * step, sq2 = wb_key_sq(kw[q]);
+            const int inside = (at >= 0 ? 1 : 0) & (at < n ? 1 : 0);
+            const int beyond = (inside ^ 1) | (fwd ? (sq2 >= target ? 1 : 0) : (sq2 <= target ? 1 : 0));       // at or beyond the target, seen from the segment
+            const int found = undecided & inside & (sq2 == target ? 1 : 0);
+            hit = found ? at - (fwd ? 0 : wb_key_sub(kw[q])) : hit;                        // (the square's first segment)
+            hcs = found ? wb_key_case(kw[q]) : hcs;                                          // (both segments of a square carry its case)
+            undecided &= beyond ^ 1;
+        }
+        bool open = (there & ((tl == ls ? 0 : 1) | undecided)) != 0;                       // another strip's list, or further away than the window
+        const int f0 = (hit >= 0 ? 1 : 0) & (wb_seg_from(hcs, 0) == want ? 1 : 0);
+        const int f1 = (hit >= 0 ? 1 : 0) & (f0 ^ 1) & (wb_case_nseg(hcs) == 2 ? 1 : 0) & (wb_seg_from(hcs, 1) == want ? 1 : 0);
+        uint32_t sc = f0 ? (uint32_t)hit : (f1 ? (uint32_t)hit + 1u : (uint32_t)WB_F_NIL);
         const int slot = wb_append_slot(&ctr[6], open);
         if (open) {
             if (slot < QMAX) queue[slot] = (uint16_t)g;
@@ -340,6 +358,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
             if (sc != WB_F_NIL) wb_atomic_or(&hp[sc >> 5], 1u << (sc & 31u));
         }
     WB_END_PFOR
+    WB_FSTAMP_FINE(a.ctl, 12);                   // (fine stamps: 12 the successors' main loop, 1 the queue; 13 splitters, 14 first walk, 15 loops' splitters + walk; 16 raw points into the buckets' counters, 8 the rest of the buckets; 17 dedupe scan, 18 compaction counts, 19 compaction, 9 the rest)
     {
         const int nq = ctr[6] < QMAX ? ctr[6] : QMAX;
         WB_PFOR32(qi, nq)
@@ -383,6 +402,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_SINGLE
     ctr[1] = S1;
     WB_END_SINGLE
+    WB_FSTAMP_FINE(a.ctl, 13);
     auto walk = [&](int o) {
         int j = (int)ndseg[o], cntw = 0;
         uint32_t end = WB_F_NIL, w = S[j];
@@ -411,6 +431,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_PFOR32(o, S1)
         walk((int)o);
     WB_END_PFOR
+    WB_FSTAMP_FINE(a.ctl, 14);
     // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
     const int S2 = ctr[1];
     if (ctr[0] || S2 > fa.smax) { WB_F_NOTE(max_splitters, S2 + fa.smax / 8); WB_F_DECLINE(); }
@@ -431,6 +452,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_END_PFOR
     const int NSP = ctr[1];
     if (ctr[0] || NSP > fa.smax) { WB_F_NOTE(max_splitters, NSP + fa.smax / 8); WB_F_DECLINE(); }
+    WB_FSTAMP_FINE(a.ctl, 15);
     // C4: the splitters' own list: next splitter, previous splitter
     const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
     WB_PFOR32(o, NSP)
@@ -443,16 +465,28 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 3);
     // C5: pointer jumping over the splitters along the PREVIOUS links.  One 64-bit word per node:
-    // bits 0..15 J (jump pointer), 16..31 D (segments in front of the node), 32..47 H (first node of the chain), 48..63 M (smallest ordinal seen: names a loop)
-#define WB_FQ(j, d, h, m) ((unsigned long long)(uint16_t)(j) | (unsigned long long)(uint16_t)(d) << 16 | (unsigned long long)(uint16_t)(h) << 32 | (unsigned long long)(uint16_t)(m) << 48)
+    //   J (10 bits) jump pointer: the node 2^k nodes in front, or none;  D (13) segments between that node's start and this node's --
+    //   once J is none: the segments in front of the node in its chain;  H (10) first node of the chain;
+    //   M (10) smallest ordinal among the node and the 2^k - 1 in front of it, DM (13) segments between THAT node's start and this one's.
+    // An open chain ends with J = none, named by H, positions from D.  On a loop J stays alive; once the window has gone around,
+    // M is the loop's smallest ordinal -- its name -- and DM the node's place in the loop cut in front of that node (the nearest
+    // occurrence wins a tie, and D, which then counts laps and overflows its field, is not read any more): ONE ranking serves
+    // both, where the loops used to be cut at their raster-last segment and ranked again (another 2 x 9 barriers).
+#define WB_FQ_NN 0x3FFu
+#define WB_FQ(j, h, m, d, dm) ((unsigned long long)((j) & 0x3FFu) | (unsigned long long)((h) & 0x3FFu) << 10 | (unsigned long long)((m) & 0x3FFu) << 20 | (unsigned long long)((d) & 0x1FFFu) << 30 | (unsigned long long)((dm) & 0x1FFFu) << 43)
+#define WB_FQ_J(w) ((uint32_t)(w) & 0x3FFu)
+#define WB_FQ_H(w) ((uint32_t)((w) >> 10) & 0x3FFu)
+#define WB_FQ_M(w) ((uint32_t)((w) >> 20) & 0x3FFu)
+#define WB_FQ_D(w) ((uint32_t)((w) >> 30) & 0x1FFFu)
+#define WB_FQ_DM(w) ((uint32_t)((w) >> 43) & 0x1FFFu)
     int rounds = 0;
     while ((1 << rounds) < NSP) ++rounds;
     // In place: a thread holds the new words of its nodes (at most WB_F_QREG: smax <= 1023) across a barrier -- a second array of
     // words was 3 KB of the job's LDS, and the LDS decides how many jobs a CU holds.
-    auto rank_nodes = [&]() {
+    {
         WB_PFOR32(o, NSP)
             const uint16_t p = ncp[o];
-            Q[o] = WB_FQ(p, p != NN ? nlen[p] : 0, o, o);
+            Q[o] = WB_FQ(p == NN ? WB_FQ_NN : (uint32_t)p, (uint32_t)o, (uint32_t)o, p != NN ? (uint32_t)nlen[p] : 0u, 0u);
         WB_END_PFOR
         for (int it = 0; it < rounds; ++it) {
             unsigned long long nwq[WB_F_QREG];
@@ -461,12 +495,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
                 const int o = WB_TID + u * WB_NT;
                 if (o >= NSP) break;
                 const unsigned long long w = Q[o];
-                const uint16_t j = (uint16_t)w;
+                const uint32_t j = WB_FQ_J(w);
                 unsigned long long nw = w;
-                if (j != NN) {
+                if (j != WB_FQ_NN) {
                     const unsigned long long wj = Q[j];
-                    const uint16_t m1 = (uint16_t)(w >> 48), m2 = (uint16_t)(wj >> 48);
-                    nw = WB_FQ((uint16_t)wj, (uint16_t)(w >> 16) + (uint16_t)(wj >> 16), (uint16_t)(wj >> 32), m1 < m2 ? m1 : m2);
+                    const uint32_t d = WB_FQ_D(w), m1 = WB_FQ_M(w), m2 = WB_FQ_M(wj);
+                    const bool far = m2 < m1;
+                    nw = WB_FQ(WB_FQ_J(wj), WB_FQ_H(wj), far ? m2 : m1, d + WB_FQ_D(wj), far ? WB_FQ_DM(wj) + d : WB_FQ_DM(w));
                 }
                 nwq[u] = nw;
             }
@@ -479,53 +514,45 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
             }
             WB_SYNC();
         }
-    };
-    rank_nodes();
+    }
     // chains: an open chain is named by its first node, a loop (jump pointer still alive) by its smallest ordinal
     WB_PFOR32(o, NSP)
         const unsigned long long w = Q[o];
-        const bool loop = (uint16_t)w != NN;
-        const uint16_t id = loop ? (uint16_t)(w >> 48) : (uint16_t)(w >> 32);
-        cix[o] = id == (uint16_t)o ? 1 : 0;
-        if (loop) ctr[3] = 1;
+        const bool loop = WB_FQ_J(w) != WB_FQ_NN;
+        const uint32_t id = loop ? WB_FQ_M(w) : WB_FQ_H(w);
+        cix[o] = id == (uint32_t)o ? 1 : 0;
     WB_END_PFOR
     const int C = wb_block_scan_excl(cix, NSP);               // cix[o] (for a naming node): the chain's index
     if (C > cmax) { WB_F_NOTE(max_chains, C); WB_F_DECLINE(); }
-    const bool any_loop = ctr[3] != 0;
     // every node learns its chain's index (the naming node's entry is read before anything overwrites it: two steps)
     WB_PFOR32(o, NSP)
         const unsigned long long w = Q[o];
-        const bool loop = (uint16_t)w != NN;
-        const uint16_t id = loop ? (uint16_t)(w >> 48) : (uint16_t)(w >> 32);
+        const bool loop = WB_FQ_J(w) != WB_FQ_NN;
+        const uint32_t id = loop ? WB_FQ_M(w) : WB_FQ_H(w);
         nnext[o] = (uint16_t)cix[id];                          // (nnext is done with: chain index of the node, for now)
-        if (id == (uint16_t)o) { cloop[cix[o]] = loop ? 1 : 0; cmin[cix[o]] = 0xFFFFFFFFu; cmaxk[cix[o]] = 0u; ctot[cix[o]] = 0; }
+        if (id == (uint32_t)o) { cloop[cix[o]] = loop ? 1 : 0; cmin[cix[o]] = 0xFFFFFFFFu; cmaxk[cix[o]] = 0ull; ctot[cix[o]] = 0; }
     WB_END_PFOR
+    // ... and its chain the number of its segments: the largest (segments in front of a node + its own)
     WB_PFOR32(o, NSP)
-        cix[o] = (int)nnext[o];
+        const unsigned long long w = Q[o];
+        const int ch = (int)nnext[o];
+        cix[o] = ch;
+        wb_atomic_max(&ctot[ch], (int)(WB_FQ_J(w) != WB_FQ_NN ? WB_FQ_DM(w) : WB_FQ_D(w)) + (int)nlen[o]);
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 4);
-    // keys again (coalesced, from the lists): every chain's smallest key (it numbers the contours), every loop's largest
+    // the keys again: every chain's smallest key (it numbers the contours: contour_index.py:103, find_contours' list order) and every
+    // loop's largest WITH its segment -- the loop's raster-last segment: the contour starts behind it
     WB_PFOR32(g, n)
         const uint32_t key = K[g] & 0x07FFFFFFu;
         const int ch = cix[WB_F_OWN(g)];
         wb_atomic_min(&cmin[ch], key);
-        if (cloop[ch]) wb_atomic_max(&cmaxk[ch], key);
+        if (cloop[ch]) wb_atomic_max(&cmaxk[ch], (unsigned long long)key << 16 | (unsigned long long)g);
     WB_END_PFOR
-    if (any_loop) {
-        // the loop's raster-last segment: the contour starts behind it.  Cut the splitters' loop in
-        // front of the node that holds it and rank again; the segments' positions are rotated below.
-        WB_PFOR32(g, n)
-            const int o = WB_F_OWN(g), ch = cix[o];
-            if (cloop[ch] && (K[g] & 0x07FFFFFFu) == cmaxk[ch]) { lnode[ch] = (uint16_t)o; lpos[ch] = (uint16_t)WB_F_LP(g); }
-        WB_END_PFOR
-        WB_PFOR32(ch, C)
-            if (cloop[ch]) ncp[lnode[ch]] = NN;
-        WB_END_PFOR
-        rank_nodes();
-    }
-    // chain lengths
-    WB_PFOR32(o, NSP)
-        wb_atomic_max(&ctot[cix[o]], (int)(uint16_t)(Q[o] >> 16) + (int)nlen[o]);
+    WB_PFOR32(ch, C)
+        if (cloop[ch]) {                                       // the place of that segment in the loop as the ranking cut it
+            const int g = (int)(cmaxk[ch] & 0xFFFFull);
+            lpos[ch] = (uint16_t)((int)WB_FQ_DM(Q[WB_F_OWN(g)]) + WB_F_LP(g));
+        }
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 5);
     // ---- D: contours in the order of their raster-first segments (contour_index.py:103: find_contours' list order)
@@ -547,11 +574,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // Reads region A (own / lp) and the ranking's tables, writes region B.
     WB_PFOR32(g, n)
         const int o = WB_F_OWN(g), ch = cix[o];
-        int q = (int)(uint16_t)(Q[o] >> 16) + WB_F_LP(g);       // position along the chain, from 1 (dest is S's storage: read, then written, by this thread)
-        if (cloop[ch]) {
+        const unsigned long long w = Q[o];
+        int q = WB_F_LP(g);                                      // position along the chain, from 1 (dest is S's storage: read, then written, by this thread)
+        if (cloop[ch]) {                                         // (a loop: rotated so that it starts behind its raster-last segment)
             const int pl = (int)lpos[ch], tot = ctot[ch];
+            q += (int)WB_FQ_DM(w);
             q = q > pl ? q - pl : q - pl + tot;
-        }
+        } else q += (int)WB_FQ_D(w);
         dest[g] = (uint16_t)((rawbase[cnum[ch]] + q) | (q == 1 ? 0x8000 : 0));
     WB_END_PFOR
     if (R >= 0x8000) WB_F_DECLINE();                            // (cannot happen: n < 8191, C <= cmax)
@@ -573,29 +602,74 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         while (rawbase[c + 1] <= p) ++c;
         return ((uint32_t)c << sh) | ((uint32_t)wb_pt_y(pt) << xb) | (uint32_t)wb_pt_x(pt);
     };
-    {
-        uint32_t keya[WB_PFOR_B_WIDTH];
-        double va[WB_PFOR_B_WIDTH][4];
-        WB_PFOR_B32(g, gc, u, n)                                  // (a segment's key and the four corner values of its square, four segments' worth requested together)
-            const int i = wb_f_locate_run(sbase, (int)gc, &srun);
-            const size_t e = ((size_t)job * NS + srun) * a.cap_strip + (size_t)i;
-            keya[u] = a.stg_k[e];
-            if (a.dtype == 0) { const float* v = (const float*)a.stg_v + e * 4; va[u][0] = (double)v[0]; va[u][1] = (double)v[1]; va[u][2] = (double)v[2]; va[u][3] = (double)v[3]; }
-            else { const double* v = (const double*)a.stg_v + e * 4; va[u][0] = v[0]; va[u][1] = v[1]; va[u][2] = v[2]; va[u][3] = v[3]; }
-        WB_PFOR_B32_USE(g, u)
-            const uint32_t key = keya[u];
-            const double ul = va[u][0], ur = va[u][1], ll = va[u][2], lr = va[u][3];
-            // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
-            if (ul == level || ur == level || ll == level || lr == level) ctr[0] = 1;
+    // The lattice point of a crossing is base + (0 or 1) along its edge: the reference rounds base + f, f = (level - a) / (b - a) in
+    // float64 (wb_crossing_point), and unless f is within 1e-3 of one half a float32 quotient says on which side of base + 1/2 that
+    // sum lies (|error| < 1e-6: the two differences are exact or correctly rounded float64, f lies in [0, 1] on an edge the contour
+    // crosses).  The exact arithmetic -- a float64 division, a sixth of this kernel's instructions -- is kept for the quotients near
+    // one half, infinite or tiny differences and whatever else fails the test (NaN fails every comparison).
+    auto crossing = [&](const int side, const int r, const int c, const double ul, const double ur, const double ll, const double lr) -> uint32_t {
+        const bool horiz = side == WB_TOP || side == WB_BOTTOM;           // the crossing moves along a row: its column is the fraction
+        const double va = (side == WB_TOP || side == WB_LEFT) ? ul : (side == WB_BOTTOM ? ll : ur);
+        const double vb = side == WB_TOP ? ur : (side == WB_LEFT ? ll : lr);
+        const int base = horiz ? c : r, other = side == WB_TOP ? r : (side == WB_BOTTOM ? r + 1 : (side == WB_LEFT ? c : c + 1));
+        const float numf = (float)(level - va), denf = (float)(vb - va);
+        const float fa = numf * wb_rcp_f32(denf);
+        int along;
+        if (fabsf(fa - 0.5f) > 1e-3f && fa > -0.01f && fa < 1.01f && fabsf(denf) > 1e-30f && fabsf(denf) < 1e30f) along = base + (fa > 0.5f ? 1 : 0);
+        else along = wb_f_along_exact(base, va, vb, level);
+        return horiz ? ((uint32_t)along | ((uint32_t)other << 16)) : ((uint32_t)other | ((uint32_t)along << 16));
+    };
+    int* const firsts = tcount;                                   // (at most one per contour: wb_fused_layout sizes the threads' counters for that too)
+    auto crossings = [&](auto tag) {
+        typedef decltype(tag) T;
+        struct alignas(16) V4 { T v[4]; };
+        const V4* const V = (const V4*)a.stg_v;
+        constexpr int BW = 8;                                        // (a segment's key and the four corner values of its square, eight segments' worth requested together)
+        for (int g0 = 0; g0 < n; g0 += BW * WB_NT) {
+            uint32_t keya[BW];
+            V4 va[BW];
+#pragma unroll
+            for (int u = 0; u < BW; ++u) {
+                const int g = g0 + u * WB_NT + WB_TID, gc = g < n ? g : n - 1;
+                const int i = wb_f_locate_run(sbase, gc, &srun);
+                const size_t e = ((size_t)job * NS + srun) * a.cap_strip + (size_t)i;
+                keya[u] = a.stg_k[e];
+                va[u] = V[e];
+            }
+#pragma unroll
+            for (int u = 0; u < BW; ++u) {
+                const int g = g0 + u * WB_NT + WB_TID;
+                if (g >= n) break;
+                const uint32_t key = keya[u];
+                const double ul = (double)va[u].v[0], ur = (double)va[u].v[1], ll = (double)va[u].v[2], lr = (double)va[u].v[3];
+                // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
+                if (ul == level || ur == level || ll == level || lr == level) ctr[0] = 1;
+                const int sq = wb_key_sq(key), cs = wb_key_case(key), sub = wb_key_sub(key);
+                int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;
+                if (c < 0) { --r; c += W; } else if (c >= W) { ++r; c -= W; }
+                const uint16_t d = dest[g];
+                const int p = (int)(d & 0x7FFFu);
+                rawpt[p] = pack(p, crossing(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr));
+                if (d & 0x8000u) firsts[wb_atomic_add(&ctr[7], 1)] = g;      // (a contour's first segment: its start point goes in front, below)
+            }
+        }
+        WB_SYNC();
+        WB_PFOR32(f, ctr[7])
+            const int g = firsts[f];
+            int s1 = 0;
+            const int i = wb_f_locate_run(sbase, g, &s1);
+            const size_t e = ((size_t)job * NS + s1) * a.cap_strip + (size_t)i;
+            const uint32_t key = a.stg_k[e];
+            const V4 v = V[e];
             const int sq = wb_key_sq(key), cs = wb_key_case(key), sub = wb_key_sub(key);
             int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;
             if (c < 0) { --r; c += W; } else if (c >= W) { ++r; c -= W; }
-            const uint16_t d = dest[g];
-            const int p = (int)(d & 0x7FFFu);
-            rawpt[p] = pack(p, wb_crossing_point(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr, level));
-            if (d & 0x8000u) rawpt[p - 1] = pack(p - 1, wb_crossing_point(wb_seg_from(cs, sub), r, c, ul, ur, ll, lr, level));
-        WB_END_PFOR_B
-    }
+            const int p = (int)(dest[g] & 0x7FFFu) - 1;
+            rawpt[p] = pack(p, crossing(wb_seg_from(cs, sub), r, c, (double)v.v[0], (double)v.v[1], (double)v.v[2], (double)v.v[3]));
+        WB_END_PFOR
+    };
+
+    if (a.dtype == 0) crossings(0.0f); else crossings(0.0);
     if (ctr[0]) WB_F_DECLINE();
 
     WB_FSTAMP(a.ctl, 7);
@@ -629,6 +703,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
             if (x < xminc[c]) wb_atomic_min(&xminc[c], x);
         }
     WB_END_PFOR
+    WB_FSTAMP_FINE(a.ctl, 16);
     const int U = wb_block_scan_excl(cnt, NB);                  // cnt[b]: first entry of bucket b
     WB_PFOR32(p, R)
         if (!((dupb[p >> 5] >> (p & 31)) & 1u)) {
@@ -667,6 +742,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         if (first) { wb_atomic_or(&keepb[p >> 5], 1u << (p & 31)); wb_atomic_add(&sumyc[c], (int)((pw >> xb) & ymask)); }
         if (firsty) wb_atomic_add(&setc[c], 1);
     WB_END_PFOR
+    WB_FSTAMP_FINE(a.ctl, 17);
     // compaction: a thread owns a run of consecutive raw points; the kept ones go to the job's output array (the points of
     // contours that turn out too short included, as the finish kernel of wb_trace.h lays them out)
     uint32_t* const cpts = a.cpts + 2 * jb;
@@ -678,6 +754,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         tcount[t] = k;
     WB_END_PFOR
     const int NK = wb_block_scan_excl(tcount, WB_NT);
+    WB_FSTAMP_FINE(a.ctl, 18);
     WB_PFOR32(t, WB_NT)
         const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
         int q = tcount[t];
@@ -688,6 +765,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
             if ((keepb[p >> 5] >> (p & 31)) & 1u) cpts[q++] = (pw & xmask) | (((pw >> xb) & ymask) << 16);
         }
     WB_END_PFOR
+    WB_FSTAMP_FINE(a.ctl, 19);
     WB_SINGLE
     newstart[C] = NK;
     WB_END_SINGLE
@@ -785,6 +863,12 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
 #undef WB_F_DECLINE
 #undef WB_F_NOTE
 #undef WB_FQ
+#undef WB_FQ_NN
+#undef WB_FQ_J
+#undef WB_FQ_H
+#undef WB_FQ_M
+#undef WB_FQ_D
+#undef WB_FQ_DM
 #undef WB_F_OWN
 #undef WB_F_LP
 #undef WB_F_BUCKET
