@@ -84,6 +84,7 @@ static inline int wb_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 static inline int wb_popc64(uint64_t v) { return __builtin_popcountll(v); }
 // base[idx] += val (no return value); on the GPU lanes of a wave that hit the same idx are combined first
 static inline void wb_atomic_add_agg(int* base, int idx, int val) { base[idx] += val; }
+static inline void wb_atomic_add_wave(int* base, int idx, int val) { base[idx] += val; }
 static inline void wb_atomic_min_first(int* addr, bool want, int val) { if (want && val < *addr) *addr = val; }
 // the block's sum of v, returned to every thread, added in a fixed order (butterfly inside a wave, then the waves in turn):
 // the same bits on every run; lw: LDS scratch of 16 doubles; all threads of the block call it
@@ -230,6 +231,17 @@ __device__ inline void wb_atomic_min_first(int* addr, bool want, int val) {
     const unsigned long long m = __ballot(want);
     if (want && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicMin(addr, val);
 }
+// base[idx] += val for every lane of a wave, ALL of which must be at the call (top level of a kernel, behind a loop): one atomic
+// for the wave when its lanes name the same entry -- sixty-four atomics on one address are served one after the other
+__device__ inline void wb_atomic_add_wave(int* base, int idx, int val) {
+    const int first = __builtin_amdgcn_readfirstlane(idx);
+    if (__ballot(idx != first) == 0ull) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+        if ((threadIdx.x & 63) == 0 && val) atomicAdd(&base[first], val);
+    } else if (val) atomicAdd(&base[idx], val);
+}
+// base[idx] += val (0 <= val < 65536), the lanes that name the same entry combined into ONE atomic.  Call from code every
 // participating lane reaches it; inactive lanes are simply not in the ballot.
 __device__ inline void wb_atomic_add_agg(int* base, int idx, int val) {
     unsigned long long todo = __ballot(1);

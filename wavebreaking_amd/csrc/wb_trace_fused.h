@@ -108,7 +108,11 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     L.g2_dropped = g2; g2 += wb_f_al(C1);
     L.g2_ckept = g2; g2 += wb_f_al(2 * C1);
     L.g2_fin = g2; g2 += wb_f_al(4 * C1);
-    L.g2_tcount = g2; g2 += wb_f_al(4 * ((size_t)(nthreads > cmax ? nthreads : cmax) + 2));
+    {   // the threads' counters; also one entry per contour (its first segment), and one per word of the keep bits (the compaction's scan)
+        size_t tc = (size_t)(nthreads > cmax ? nthreads : cmax);
+        if ((R + 31) / 32 + 2 > tc) tc = (R + 31) / 32 + 2;
+        L.g2_tcount = g2; g2 += wb_f_al(4 * (tc + 2));
+    }
     L.g2_cand = g2; g2 += wb_f_al(4 * 2 * WB_F_NCAND);
     L.total = L.oT + (g1 > g2 ? g1 : g2);
     return L;
@@ -399,6 +403,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // C2: a thread walks from its splitter to the next one (no two walks meet: successors are one-to-one).  The longest walk
     // sets the phase's duration: after WB_F_WALK segments the walk makes the next segment a splitter of its own and goes on as
     // that one.  A visited segment's link word becomes owner | position (the walk has read the successor before).
+    // (The splitter flag read off the next segment's own link word -- flagged while unvisited, position 0 once visited -- instead of
+    // the separate bit array: one LDS read less per step, and the walks took 44 ms of workgroup time per launch instead of 36.)
     WB_SINGLE
     ctr[1] = S1;
     WB_END_SINGLE
@@ -718,57 +724,120 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // one or two entries each.  By x mod nlon alone -- needed while the distinct x were counted here too, -> exp_lon, :154 -- a
     // bucket held every crossing of a meridian by every contour of the job and its copy one period east, forty entries, and this
     // scan was a fifth of the kernel.)
-    WB_PFOR32(e, U)
-        const int p = (int)order[e];
-        const uint32_t pw = rawpt[p];
-        const uint32_t c = pw >> sh, xm = WB_F_XM(pw), cy = pw >> xb;     // cy: contour and y
-        const int bk = WB_F_BUCKET(pw), b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk];
-        bool first = true, firsty = true;
-        for (int e2 = b0; e2 < b1; e2 += 4) {                   // (four entries' positions, then their points: two LDS latencies per four)
-            int p2[4];
-            uint32_t w2[4];
+    // A thread takes a BUCKET, not a point: its entries' points (up to eight; a longer bucket is scanned entry by entry) go to
+    // registers once and are compared there -- two LDS reads per entry and three round trips per bucket, where every point used to
+    // read its whole bucket (five round trips per point).  The sums of the thread's first contour -- with a full-span contour in the
+    // job: nearly every point's -- are kept in registers and added once per WAVE (wb_atomic_add_wave): one address per contour is
+    // what sixty-four lanes' atomics would queue on.
+    (void)U;
+    {
+        int c0 = -1, accy = 0, accs = 0;
+        auto tally = [&](const uint32_t pw, const bool first, const bool firsty, const int p) {
+            const int c = (int)(pw >> sh), y = (int)((pw >> xb) & ymask);
+            if (first) wb_atomic_or(&keepb[p >> 5], 1u << (p & 31));
+            if (c0 < 0) c0 = c;
+            if (c == c0) { accy += first ? y : 0; accs += firsty ? 1 : 0; }
+            else {
+                if (first) wb_atomic_add(&sumyc[c], y);
+                if (firsty) wb_atomic_add(&setc[c], 1);
+            }
+        };
+        WB_PFOR32(bk, NBP)
+            const int b0 = bk > 0 ? cnt[bk - 1] : 0, b1 = cnt[bk], m = b1 - b0;
+            if (m > 0 && m <= 8) {
+                int pp[8];
+                uint32_t ww[8], cy[8], xm[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) p2[q] = (int)order[e2 + q < b1 ? e2 + q : b1 - 1];
+                for (int i = 0; i < 8; ++i) pp[i] = (int)order[b0 + (i < m ? i : m - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w2[q] = rawpt[p2[q]];
+                for (int i = 0; i < 8; ++i) { ww[i] = rawpt[pp[i]]; cy[i] = ww[i] >> xb; xm[i] = WB_F_XM(ww[i]); }
+                uint32_t nf = 0u, ny = 0u;                       // bit i: entry i is not the first occurrence of its point in its contour / of its (x mod nlon, y) in the bucket
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (p2[q] < p && w2[q] == pw) first = false;
-                if (e2 + q < (int)e) {
-                    if ((w2[q] >> xb) == cy && WB_F_XM(w2[q]) == xm) firsty = false;
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int j = i + 1; j < 8; ++j) {
+                        const uint32_t vj = j < m ? 1u : 0u;
+                        const uint32_t eqw = ww[i] == ww[j] ? vj : 0u;
+                        const uint32_t eqy = (cy[i] == cy[j] ? vj : 0u) & (xm[i] == xm[j] ? 1u : 0u);
+                        nf |= eqw << (pp[i] < pp[j] ? j : i);
+                        ny |= eqy << j;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < m) tally(ww[i], !((nf >> i) & 1u), !((ny >> i) & 1u), pp[i]);
+            } else if (m > 8) {
+                // (one bucket in a hundred of the bench batch, up to nineteen entries: left to the wave that finds it, its m x m
+                // LDS reads were the whole phase -- queued, and scanned below an ENTRY per thread)
+                const int slot = m <= 32 ? wb_atomic_add(&ctr[3], 1) : WB_F_NCAND;
+                if (slot < WB_F_NCAND) { cand[2 * slot] = b0; cand[2 * slot + 1] = m; }
+                else {
+                    for (int e = b0; e < b1; ++e) {
+                        const int p = (int)order[e];
+                        const uint32_t pw = rawpt[p];
+                        bool first = true, firsty = true;
+                        for (int e2 = b0; e2 < b1; ++e2) {
+                            const int p2 = (int)order[e2];
+                            const uint32_t w2 = rawpt[p2];
+                            if (p2 < p && w2 == pw) first = false;
+                            if (e2 < e && (w2 >> xb) == (pw >> xb) && WB_F_XM(w2) == WB_F_XM(pw)) firsty = false;
+                        }
+                        tally(pw, first, firsty, p);
+                    }
                 }
             }
-        }
-        if (first) { wb_atomic_or(&keepb[p >> 5], 1u << (p & 31)); wb_atomic_add(&sumyc[c], (int)((pw >> xb) & ymask)); }
-        if (firsty) wb_atomic_add(&setc[c], 1);
-    WB_END_PFOR
+        WB_END_PFOR
+        const int nbig = ctr[3] < WB_F_NCAND ? ctr[3] : WB_F_NCAND;
+        WB_PFOR32(t, nbig * 32)
+            const int b0 = cand[2 * ((int)t >> 5)], m = cand[2 * ((int)t >> 5) + 1], i = (int)t & 31;
+            if (i < m) {
+                const int e = b0 + i, b1 = b0 + m, p = (int)order[e];
+                const uint32_t pw = rawpt[p], cyp = pw >> xb, xmp = WB_F_XM(pw);
+                bool first = true, firsty = true;
+                for (int e2 = b0; e2 < b1; e2 += 4) {           // (four entries' positions, then their points: two LDS latencies per four)
+                    int p2[4];
+                    uint32_t w2[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p2[q] = (int)order[e2 + q < b1 ? e2 + q : b1 - 1];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w2[q] = rawpt[p2[q]];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (p2[q] < p && w2[q] == pw) first = false;
+                        if (e2 + q < e && (w2[q] >> xb) == cyp && WB_F_XM(w2[q]) == xmp) firsty = false;
+                    }
+                }
+                tally(pw, first, firsty, p);
+            }
+        WB_END_PFOR
+        wb_atomic_add_wave(sumyc, c0 < 0 ? 0 : c0, accy);
+        wb_atomic_add_wave(setc, c0 < 0 ? 0 : c0, accs);
+        WB_SYNC();
+    }
     WB_FSTAMP_FINE(a.ctl, 17);
-    // compaction: a thread owns a run of consecutive raw points; the kept ones go to the job's output array (the points of
-    // contours that turn out too short included, as the finish kernel of wb_trace.h lays them out)
+    // compaction: the kept points go to the job's output array in their order (the points of contours that turn out too short
+    // included, as the finish kernel of wb_trace.h lays them out); a point's place = the kept points in front of it, from the
+    // keep bits: a scan over their words' counts + a count inside its word
     uint32_t* const cpts = a.cpts + 2 * jb;
-    const int chunk = (R + WB_NT - 1) / WB_NT;
-    WB_PFOR32(t, WB_NT)
-        const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
-        int k = 0;
-        for (int p = p0; p < p1; ++p) k += (int)((keepb[p >> 5] >> (p & 31)) & 1u);
-        tcount[t] = k;
+    const int kwords = (R + 31) / 32 + 1;
+    WB_PFOR32(w, kwords)
+        tcount[w] = wb_popc32(keepb[w]);
     WB_END_PFOR
-    const int NK = wb_block_scan_excl(tcount, WB_NT);
+    const int NK = wb_block_scan_excl(tcount, kwords);
     WB_FSTAMP_FINE(a.ctl, 18);
-    WB_PFOR32(t, WB_NT)
-        const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
-        int q = tcount[t];
-        for (int p = p0; p < p1; ++p) {
+    WB_PFOR32(p, R)
+        const uint32_t bits = keepb[p >> 5];
+        if ((bits >> (p & 31)) & 1u) {
             const uint32_t pw = rawpt[p];
-            const int c = (int)(pw >> sh);
-            if (p == rawbase[c]) newstart[c] = q;
-            if ((keepb[p >> 5] >> (p & 31)) & 1u) cpts[q++] = (pw & xmask) | (((pw >> xb) & ymask) << 16);
+            cpts[tcount[p >> 5] + wb_popc32(bits & ((1u << (p & 31)) - 1u))] = (pw & xmask) | (((pw >> xb) & ymask) << 16);
         }
     WB_END_PFOR
+    WB_PFOR32(c, C + 1)
+        const int p = rawbase[c];                               // (rawbase[C] = R: all the kept points)
+        newstart[c] = tcount[p >> 5] + wb_popc32(keepb[p >> 5] & ((1u << (p & 31)) - 1u));
+    WB_END_PFOR
+    (void)NK;
     WB_FSTAMP_FINE(a.ctl, 19);
-    WB_SINGLE
-    newstart[C] = NK;
-    WB_END_SINGLE
     // contours with at least four points stay (contour_index.py:113-117)
     WB_PFOR32(c, C)
         nuxc[c] = nuxc[c] - xminc[c] + 1;                          // distinct x (xminc lies in kid[])
