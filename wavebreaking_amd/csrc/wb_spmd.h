@@ -67,6 +67,8 @@ extern long long wb_hostsim_path[4];
 #define WB_SINGLE {
 #define WB_END_SINGLE }
 #define WB_SYNC() ((void)0)
+#define WB_WAVE 1                     // lanes that run in lockstep (work a wave does by itself, between two workgroup barriers)
+static inline bool wb_wave_any(bool v) { return v; }
 #define WB_SHARED(type, name, n) type name[n]
 // arrays in the launch's dynamic LDS (WB_LAUNCH_LDS), carved in the order of their declarations, 8-byte aligned
 #include <vector>
@@ -187,6 +189,8 @@ static inline double wb_block_cumsum_f64(double* a, int n, double carry) {
     }                 \
     __syncthreads();
 #define WB_SYNC() __syncthreads()
+#define WB_WAVE 64
+__device__ inline bool wb_wave_any(bool v) { return __ballot(v) != 0ull; }      // (over the lanes that are at the call)
 #define WB_SHARED(type, name, n) __shared__ type name[n]
 // arrays in the launch's dynamic LDS (WB_LAUNCH_LDS), carved in the order of their declarations, 8-byte aligned
 #define WB_DYN_SHARED_BEGIN extern __shared__ __attribute__((aligned(16))) unsigned char wb_dyn_lds_[]; size_t wb_dyn_off_ = 0;

@@ -56,7 +56,7 @@ struct WbFusedLayout {
     size_t t_rawbase, t_closed;      // per contour, from the numbering to the end
     // group 1 (link + ranking) and group 2 (finish) share what follows
     size_t g1_hp, g1_wpre, g1_ndseg, g1_nlen, g1_ncp, g1_nnext, g1_cix, g1_q0, g1_cmin, g1_cmaxk, g1_lpos, g1_ctot, g1_cloop, g1_cnum;
-    size_t g2_cnt, g2_keep, g2_dup, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_nuxc, g2_sumyc, g2_setc, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
+    size_t g2_cnt, g2_keep, g2_blk, g2_newstart, g2_kid, g2_nux, g2_sumy, g2_setsize, g2_nuxc, g2_sumyc, g2_setc, g2_dropped, g2_ckept, g2_fin, g2_tcount, g2_cand;
 };
 WB_HD inline size_t wb_f_al(size_t v) { return (v + 7) & ~(size_t)7; }
 // buckets of the raw points: the largest power of two <= nlon (+ 1: see phase F)
@@ -95,7 +95,6 @@ WB_HD inline WbFusedLayout wb_fused_layout(int nmax, int smax, int cmax, int nlo
     size_t g2 = t;
     L.g2_cnt = g2; g2 += wb_f_al(4 * ((size_t)wb_f_nbuckets(nlon) + 3));
     L.g2_keep = g2; g2 += wb_f_al(4 * ((R + 31) / 32 + 1));
-    L.g2_dup = g2; g2 += wb_f_al(4 * ((R + 31) / 32 + 1));
     L.g2_blk = g2; g2 += wb_f_al(2 * ((R + 31) / 32 + 2));
     L.g2_newstart = g2; g2 += wb_f_al(4 * C1);
     L.g2_kid = g2; g2 += wb_f_al(4 * C1);
@@ -198,7 +197,6 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     uint16_t* const cnum = (uint16_t*)(T + L.g1_cnum);
     int* const cnt = (int*)(T + L.g2_cnt);
     uint32_t* const keepb = (uint32_t*)(T + L.g2_keep);
-    uint32_t* const dupb = (uint32_t*)(T + L.g2_dup);
     uint16_t* const blk = (uint16_t*)(T + L.g2_blk);
     int* const newstart = (int*)(T + L.g2_newstart);
     int* const kid = (int*)(T + L.g2_kid);
@@ -260,16 +258,25 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_FSTAMP_BEGIN                              // development stamps: 0 keys, 1 link, 2 splitters + first walk, 3 loops' walk + splitter links, 4 splitter ranking + chains, 5 key pass + loops, 6 numbering + destinations, 7 crossing points, 8 buckets, 9 dedupe + compaction, 10 per-contour counts, 11 duplicate rule + table
     // ---- A: keys to LDS
     int srun = 0;                                               // (wb_f_locate_run: the list of this thread's previous element)
-    uint32_t ka[WB_PFOR_B_WIDTH];                               // (WB_PFOR_B: four elements' loads requested, then used)
-    WB_PFOR_B32(g, gc, u, n)
-        const int i = wb_f_locate_run(sbase, (int)gc, &srun);
-        ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
-    WB_PFOR_B32_USE(g, u)
-        K[g] = ka[u];
-    WB_END_PFOR_B
-    WB_PFOR32(w, (n + 31) / 32 + 1)
-        hp[w] = 0u;
-    WB_END_PFOR
+    {
+        constexpr int BW = 16;                                  // (a thread's keys -- fifteen of a bench job's 3 800 -- requested together: one memory latency, not four)
+        for (int g0 = 0; g0 < n; g0 += BW * WB_NT) {
+            uint32_t ka[BW];
+#pragma unroll
+            for (int u = 0; u < BW; ++u) {
+                const int g = g0 + u * WB_NT + WB_TID;
+                const int i = wb_f_locate_run(sbase, g < n ? g : n - 1, &srun);
+                ka[u] = a.stg_k[((size_t)job * NS + srun) * a.cap_strip + i];
+            }
+#pragma unroll
+            for (int u = 0; u < BW; ++u) {
+                const int g = g0 + u * WB_NT + WB_TID;
+                if (g < n) K[g] = ka[u];
+            }
+        }
+        for (int w = WB_TID; w < (n + 31) / 32 + 1; w += WB_NT) hp[w] = 0u;
+        WB_SYNC();
+    }
 
     WB_FSTAMP(a.ctl, 0);
     // ---- B: successor of every segment = the segment of the neighbouring square that starts on the edge this one ends on.
@@ -392,6 +399,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
 #define WB_F_NOTE(field, v) do { if (WB_TID == 0) wb_atomic_max(&a.ctl->field, (int)(v)); } while (0)
     if (S1 > fa.smax || fa.smax > 1023) { WB_F_NOTE(max_splitters, S1 + S1 / 8); WB_F_DECLINE(); }
     WB_PFOR32(w, nwords)
+        if (w == 0) ctr[1] = S1;                                  // (the walks append splitters of their own behind these)
         uint32_t f = spb[w];
         int o = wpre[w];
         while (f) {
@@ -405,9 +413,6 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // that one.  A visited segment's link word becomes owner | position (the walk has read the successor before).
     // (The splitter flag read off the next segment's own link word -- flagged while unvisited, position 0 once visited -- instead of
     // the separate bit array: one LDS read less per step, and the walks took 44 ms of workgroup time per launch instead of 36.)
-    WB_SINGLE
-    ctr[1] = S1;
-    WB_END_SINGLE
     WB_FSTAMP_FINE(a.ctl, 13);
     auto walk = [&](int o) {
         int j = (int)ndseg[o], cntw = 0;
@@ -441,15 +446,19 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
     const int S2 = ctr[1];
     if (ctr[0] || S2 > fa.smax) { WB_F_NOTE(max_splitters, S2 + fa.smax / 8); WB_F_DECLINE(); }
-    WB_PFOR32(g, n)
-        bool want = false;
-        const uint32_t w = S[g];
-        if (w & WB_F_UNVISITED) {
-            const uint32_t nx = w & WB_F_NIL;
-            want = nx == WB_F_NIL || (K[g] & 0x07FFFFFFu) > (K[nx] & 0x07FFFFFFu);
+    const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
+    WB_PFOR32(g, n > fa.smax + 2 ? n : fa.smax + 2)
+        if (g < fa.smax + 2) ncp[g] = NN;                         // (C4's previous-splitter links start empty: no loop of their own for that)
+        if (g < n) {
+            bool want = false;
+            const uint32_t w = S[g];
+            if (w & WB_F_UNVISITED) {
+                const uint32_t nx = w & WB_F_NIL;
+                want = nx == WB_F_NIL || (K[g] & 0x07FFFFFFu) > (K[nx] & 0x07FFFFFFu);
+            }
+            const int slot = wb_append_slot(&ctr[1], want);
+            if (want && slot < fa.smax) { ndseg[slot] = (uint16_t)g; wb_atomic_or(&spb[g >> 5], 1u << (g & 31)); }
         }
-        const int slot = wb_append_slot(&ctr[1], want);
-        if (want && slot < fa.smax) { ndseg[slot] = (uint16_t)g; wb_atomic_or(&spb[g >> 5], 1u << (g & 31)); }
     WB_END_PFOR
     const int S3 = ctr[1];
     if (S3 > fa.smax) { WB_F_NOTE(max_splitters, S3); WB_F_DECLINE(); }
@@ -460,14 +469,11 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     if (ctr[0] || NSP > fa.smax) { WB_F_NOTE(max_splitters, NSP + fa.smax / 8); WB_F_DECLINE(); }
     WB_FSTAMP_FINE(a.ctl, 15);
     // C4: the splitters' own list: next splitter, previous splitter
-    const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
     WB_PFOR32(o, NSP)
         const uint16_t e = ndend[o];
-        nnext[o] = e == (uint16_t)WB_F_NIL ? NN : (uint16_t)WB_F_OWN(e);     // (in place: ndend is nnext's storage)
-        ncp[o] = NN;
-    WB_END_PFOR
-    WB_PFOR32(o, NSP)
-        if (nnext[o] != NN) ncp[nnext[o]] = (uint16_t)o;
+        const uint16_t nx = e == (uint16_t)WB_F_NIL ? NN : (uint16_t)WB_F_OWN(e);
+        nnext[o] = nx;                                         // (in place: ndend is nnext's storage)
+        if (nx != NN) ncp[nx] = (uint16_t)o;
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 3);
     // C5: pointer jumping over the splitters along the PREVIOUS links.  One 64-bit word per node:
@@ -488,7 +494,9 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     int rounds = 0;
     while ((1 << rounds) < NSP) ++rounds;
     // In place: a thread holds the new words of its nodes (at most WB_F_QREG: smax <= 1023) across a barrier -- a second array of
-    // words was 3 KB of the job's LDS, and the LDS decides how many jobs a CU holds.
+    // words was 3 KB of the job's LDS, and the LDS decides how many jobs a CU holds.  (ONE wave ranking all the nodes without any
+    // workgroup barrier -- a wave's LDS operations are served in order -- took 31 ms of workgroup time per launch instead of 20:
+    // five nodes per lane and round, two dependent reads each.)
     {
         WB_PFOR32(o, NSP)
             const uint16_t p = ncp[o];
@@ -567,18 +575,14 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         int num = 0;
         for (int c2 = 0; c2 < C; ++c2) num += cmin[c2] < mine ? 1 : 0;
         cnum[ch] = (uint16_t)num;
-    WB_END_PFOR
-    WB_PFOR32(ch, C)
-        rawbase[cnum[ch]] = ctot[ch] + 1;                      // raw points of the contour: its segments' end points + the first start point
-        closedn[cnum[ch]] = cloop[ch];
+        rawbase[num] = ctot[ch] + 1;                           // raw points of the contour: its segments' end points + the first start point
+        closedn[num] = cloop[ch];
     WB_END_PFOR
     const int R = wb_block_scan_excl(rawbase, C);
-    WB_SINGLE
-    rawbase[C] = R;
-    WB_END_SINGLE
     // where every segment's end point goes (bit 15: the segment is its contour's first -- its start point goes in front).
     // Reads region A (own / lp) and the ranking's tables, writes region B.
     WB_PFOR32(g, n)
+        if (g == 0) rawbase[C] = R;
         const int o = WB_F_OWN(g), ch = cix[o];
         const unsigned long long w = Q[o];
         int q = WB_F_LP(g);                                      // position along the chain, from 1 (dest is S's storage: read, then written, by this thread)
@@ -614,16 +618,19 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // crosses).  The exact arithmetic -- a float64 division, a sixth of this kernel's instructions -- is kept for the quotients near
     // one half, infinite or tiny differences and whatever else fails the test (NaN fails every comparison).
     auto crossing = [&](const int side, const int r, const int c, const double ul, const double ur, const double ll, const double lr) -> uint32_t {
-        const bool horiz = side == WB_TOP || side == WB_BOTTOM;           // the crossing moves along a row: its column is the fraction
-        const double va = (side == WB_TOP || side == WB_LEFT) ? ul : (side == WB_BOTTOM ? ll : ur);
-        const double vb = side == WB_TOP ? ur : (side == WB_LEFT ? ll : lr);
-        const int base = horiz ? c : r, other = side == WB_TOP ? r : (side == WB_BOTTOM ? r + 1 : (side == WB_LEFT ? c : c + 1));
+        // (flags and selections, no branch but the rare exact evaluation: see the successors' loop)
+        const int top = side == WB_TOP ? 1 : 0, bot = side == WB_BOTTOM ? 1 : 0, lef = side == WB_LEFT ? 1 : 0;
+        const int horiz = top | bot;                                   // the crossing moves along a row: its column is the fraction
+        const double va = (top | lef) ? ul : (bot ? ll : ur);
+        const double vb = top ? ur : (lef ? ll : lr);
+        const int base = horiz ? c : r, other = horiz ? r + bot : c + (lef ^ 1);
         const float numf = (float)(level - va), denf = (float)(vb - va);
-        const float fa = numf * wb_rcp_f32(denf);
-        int along;
-        if (fabsf(fa - 0.5f) > 1e-3f && fa > -0.01f && fa < 1.01f && fabsf(denf) > 1e-30f && fabsf(denf) < 1e30f) along = base + (fa > 0.5f ? 1 : 0);
-        else along = wb_f_along_exact(base, va, vb, level);
-        return horiz ? ((uint32_t)along | ((uint32_t)other << 16)) : ((uint32_t)other | ((uint32_t)along << 16));
+        const float fa = numf * wb_rcp_f32(denf), ad = fabsf(denf);
+        const int fast = (fabsf(fa - 0.5f) > 1e-3f ? 1 : 0) & (fa > -0.01f ? 1 : 0) & (fa < 1.01f ? 1 : 0) & (ad > 1e-30f ? 1 : 0) & (ad < 1e30f ? 1 : 0);
+        int along = base + (fa > 0.5f ? 1 : 0);
+        if (!fast) along = wb_f_along_exact(base, va, vb, level);
+        const uint32_t lo = horiz ? (uint32_t)along : (uint32_t)other, hi = horiz ? (uint32_t)other : (uint32_t)along;
+        return lo | (hi << 16);
     };
     int* const firsts = tcount;                                   // (at most one per contour: wb_fused_layout sizes the threads' counters for that too)
     auto crossings = [&](auto tag) {
@@ -649,10 +656,11 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
                 const uint32_t key = keya[u];
                 const double ul = (double)va[u].v[0], ur = (double)va[u].v[1], ll = (double)va[u].v[2], lr = (double)va[u].v[3];
                 // a corner equal to the level puts crossings ON grid vertices (skimage joins those by coordinate): the chain of wb_trace.h
-                if (ul == level || ur == level || ll == level || lr == level) ctr[0] = 1;
+                if ((ul == level ? 1 : 0) | (ur == level ? 1 : 0) | (ll == level ? 1 : 0) | (lr == level ? 1 : 0)) ctr[0] = 1;
                 const int sq = wb_key_sq(key), cs = wb_key_case(key), sub = wb_key_sub(key);
                 int r = (int)(((float)sq + 0.5f) * invW), c = sq - r * W;
-                if (c < 0) { --r; c += W; } else if (c >= W) { ++r; c -= W; }
+                const int adj = (c >= W ? 1 : 0) - (c < 0 ? 1 : 0);
+                r += adj; c -= adj * W;
                 const uint16_t d = dest[g];
                 const int p = (int)(d & 0x7FFFu);
                 rawpt[p] = pack(p, crossing(wb_seg_to(cs, sub), r, c, ul, ur, ll, lr));
@@ -684,37 +692,60 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     // same lattice point): it stays out.
     const int NBP = wb_f_nbuckets(nlon);                         // buckets: the largest power of two the counters hold
     const int NB = NBP + 1;
-    WB_PFOR32(x, NB + 1)
-        cnt[x] = 0;
-    WB_END_PFOR
-    WB_PFOR32(w, (R + 31) / 32 + 1)
-        keepb[w] = 0u;
-        dupb[w] = 0u;
-    WB_END_PFOR
-    WB_PFOR32(c, C + 1)
-        newstart[c] = 0; nuxl[c] = 0; sumyl[c] = 0; setsize[c] = 0; dropped[c] = 0; nuxc[c] = -1; xminc[c] = 0x7FFFFFFF; sumyc[c] = 0; setc[c] = 0;
-    WB_END_PFOR
+    {
+        const int kw0 = (R + 31) / 32 + 1, n0 = NB + 1 > kw0 ? (NB + 1 > C + 1 ? NB + 1 : C + 1) : (kw0 > C + 1 ? kw0 : C + 1);
+        WB_PFOR32(x, n0)                                          // (one loop, one barrier: the bucket counters, the keep bits, the contours' counters)
+            if (x < NB + 1) cnt[x] = 0;
+            if (x < kw0) keepb[x] = 0u;
+            if (x < C + 1) { newstart[x] = 0; nuxl[x] = 0; sumyl[x] = 0; setsize[x] = 0; dropped[x] = 0; nuxc[x] = -1; xminc[x] = 0x7FFFFFFF; sumyc[x] = 0; setc[x] = 0; }
+        WB_END_PFOR
+    }
 #define WB_F_XM(pw) (((pw) & xmask) >= (uint32_t)nlon ? ((pw) & xmask) - (uint32_t)nlon : ((pw) & xmask))   /* x mod nlon: x < W <= 2 nlon */
 #define WB_F_BUCKET(pw) ((int)((WB_F_XM(pw) + (((pw) >> xb) & ymask) * 347u) & (uint32_t)(NBP - 1)))    /* by (x mod nlon, y) only: what the dedupe, the (x mod nlon, y) sets and in_set compare */
-    WB_PFOR32(p, R)
-        const uint32_t pw = rawpt[p];
-        const bool dup = p > 0 && pw == rawpt[p > 0 ? p - 1 : 0];        // (equal words: the same contour and the same lattice point)
-        if (dup) wb_atomic_or(&dupb[p >> 5], 1u << (p & 31));
-        else {
-            wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);
-            // the contour's extent in x: its points form a lattice path (consecutive crossings of the marching squares lie on the
-            // edges of one cell and round to corners of that cell: |dx| <= 1), so its distinct x are the integers xmin .. xmax
-            const int c = (int)(pw >> sh), x = (int)(pw & xmask);
-            if (x > nuxc[c]) wb_atomic_max(&nuxc[c], x);
-            if (x < xminc[c]) wb_atomic_min(&xminc[c], x);
+    // A thread owns a RUN of consecutive raw points (fifteen of a bench job's): the predecessor is the word it read last (a point equal to
+    // its predecessor stays out of the buckets: no flag array), and the extent in x of the contour it is in is kept in registers and
+    // goes to LDS when the run leaves the contour -- one LDS read per point where a point per thread and step read four.
+    const int chunk = (R + WB_NT - 1) / WB_NT;
+    WB_PFOR32(t, WB_NT)
+        const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
+        if (p0 < p1) {
+            uint32_t prev = p0 > 0 ? rawpt[p0 - 1] : 0u;
+            int curc = -1, xmax = 0, xmin = 0;
+#pragma unroll 4
+            for (int p = p0; p < p1; ++p) {
+                const uint32_t pw = rawpt[p];
+                const bool dup = p > 0 && pw == prev;                     // (equal words: the same contour and the same lattice point)
+                prev = pw;
+                if (!dup) {
+                    wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);
+                    // the contour's extent in x: its points form a lattice path (consecutive crossings of the marching squares lie on
+                    // the edges of one cell and round to corners of that cell: |dx| <= 1), so its distinct x are the integers xmin .. xmax
+                    const int c = (int)(pw >> sh), x = (int)(pw & xmask);
+                    if (c != curc) {
+                        if (curc >= 0) { wb_atomic_max(&nuxc[curc], xmax); wb_atomic_min(&xminc[curc], xmin); }
+                        curc = c; xmax = x; xmin = x;
+                    } else { xmax = x > xmax ? x : xmax; xmin = x < xmin ? x : xmin; }
+                }
+            }
+            if (curc >= 0) { wb_atomic_max(&nuxc[curc], xmax); wb_atomic_min(&xminc[curc], xmin); }
         }
     WB_END_PFOR
     WB_FSTAMP_FINE(a.ctl, 16);
     const int U = wb_block_scan_excl(cnt, NB);                  // cnt[b]: first entry of bucket b
-    WB_PFOR32(p, R)
-        if (!((dupb[p >> 5] >> (p & 31)) & 1u)) {
-            const int e = wb_atomic_add(&cnt[WB_F_BUCKET(rawpt[p])], 1);          // (afterwards cnt[b] = END of bucket b = start of bucket b + 1)
-            order[e] = (uint16_t)p;
+    WB_PFOR32(t, WB_NT)
+        const int p0 = (int)t * chunk, p1 = p0 + chunk < R ? p0 + chunk : R;
+        if (p0 < p1) {
+            uint32_t prev = p0 > 0 ? rawpt[p0 - 1] : 0u;
+#pragma unroll 4
+            for (int p = p0; p < p1; ++p) {
+                const uint32_t pw = rawpt[p];
+                const bool dup = p > 0 && pw == prev;
+                prev = pw;
+                if (!dup) {
+                    const int e = wb_atomic_add(&cnt[WB_F_BUCKET(pw)], 1);          // (afterwards cnt[b] = END of bucket b = start of bucket b + 1)
+                    order[e] = (uint16_t)p;
+                }
+            }
         }
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 8);
@@ -810,9 +841,8 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
                 tally(pw, first, firsty, p);
             }
         WB_END_PFOR
-        wb_atomic_add_wave(sumyc, c0 < 0 ? 0 : c0, accy);
+        wb_atomic_add_wave(sumyc, c0 < 0 ? 0 : c0, accy);     // (read behind the compaction's barriers)
         wb_atomic_add_wave(setc, c0 < 0 ? 0 : c0, accs);
-        WB_SYNC();
     }
     WB_FSTAMP_FINE(a.ctl, 17);
     // compaction: the kept points go to the job's output array in their order (the points of contours that turn out too short
@@ -825,16 +855,18 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_END_PFOR
     const int NK = wb_block_scan_excl(tcount, kwords);
     WB_FSTAMP_FINE(a.ctl, 18);
-    WB_PFOR32(p, R)
-        const uint32_t bits = keepb[p >> 5];
-        if ((bits >> (p & 31)) & 1u) {
-            const uint32_t pw = rawpt[p];
-            cpts[tcount[p >> 5] + wb_popc32(bits & ((1u << (p & 31)) - 1u))] = (pw & xmask) | (((pw >> xb) & ymask) << 16);
+    WB_PFOR32(p, R > C + 1 ? R : C + 1)
+        if (p < R) {
+            const uint32_t bits = keepb[p >> 5];
+            if ((bits >> (p & 31)) & 1u) {
+                const uint32_t pw = rawpt[p];
+                cpts[tcount[p >> 5] + wb_popc32(bits & ((1u << (p & 31)) - 1u))] = (pw & xmask) | (((pw >> xb) & ymask) << 16);
+            }
         }
-    WB_END_PFOR
-    WB_PFOR32(c, C + 1)
-        const int p = rawbase[c];                               // (rawbase[C] = R: all the kept points)
-        newstart[c] = tcount[p >> 5] + wb_popc32(keepb[p >> 5] & ((1u << (p & 31)) - 1u));
+        if (p < C + 1) {                                        // (the same loop: the kept points in front of a contour's first raw point)
+            const int pc = rawbase[p];                          // (rawbase[C] = R: all the kept points)
+            newstart[p] = tcount[pc >> 5] + wb_popc32(keepb[pc >> 5] & ((1u << (pc & 31)) - 1u));
+        }
     WB_END_PFOR
     (void)NK;
     WB_FSTAMP_FINE(a.ctl, 19);
@@ -845,15 +877,11 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         fin[c] = kid[c];
     WB_END_PFOR
     const int Ck = wb_block_scan_excl(kid, C);                  // kid[c]: number among the kept ones; fin[c]: kept flag
-    WB_PFOR32(c, C)
-        if (fin[c]) ckept[kid[c]] = (uint16_t)c;
-    WB_END_PFOR
-    WB_FSTAMP(a.ctl, 9);
     // ---- G: the kept contours' counters, by their number among the kept ones
     WB_PFOR32(c, C)
-        if (fin[c]) { const int f = kid[c]; nuxl[f] = nuxc[c]; setsize[f] = setc[c]; sumyl[f] = sumyc[c]; }
+        if (fin[c]) { const int f = kid[c]; ckept[f] = (uint16_t)c; nuxl[f] = nuxc[c]; setsize[f] = setc[c]; sumyl[f] = sumyc[c]; }
     WB_END_PFOR
-    WB_FSTAMP(a.ctl, 10);
+    WB_FSTAMP(a.ctl, 9);
     // ---- periodic duplicate rule (contour_index.py:119-147): for every ordered pair (i1, i2) with set(i1) a subset of set(i2)
     // (points taken x mod nlon): equal array lengths -> drop max(i1, i2), else drop the shorter.  Almost every pair fails on the
     // first point of i1; the few that pass it are queued and checked by the whole workgroup.
@@ -884,25 +912,22 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         if (sub) dropped[drop_of(i1, i2)] = 1;
     WB_END_PFOR
     {
+        // a candidate per WAVE (its lanes over the points of i1, a ballot for the verdict): no workgroup barrier per candidate -- there
+        // were three, and a job of the bench batch has a few candidates (the loops of the first 480 columns and their copies)
         const int nc = ctr[4] < WB_F_NCAND ? ctr[4] : WB_F_NCAND;
-        for (int q = 0; q < nc; ++q) {
+        const int wv = WB_TID / WB_WAVE, nwv = WB_NT / WB_WAVE > 0 ? WB_NT / WB_WAVE : 1, ln = WB_TID % WB_WAVE;
+        for (int q = wv; q < nc; q += nwv) {
             const int i1 = cand[2 * q], i2 = cand[2 * q + 1];
             const int c1 = (int)ckept[i1], c2 = (int)ckept[i2];
             const int pa = rawbase[c1], pb = rawbase[c1 + 1];
-            WB_SINGLE
-            ctr[5] = 0;
-            WB_END_SINGLE
-            WB_PFOR32(p, pb - pa)
-                if (!in_set(rawpt[pa + p], c2)) ctr[5] = 1;
-            WB_END_PFOR
-            if (ctr[5] == 0) {
-                WB_SINGLE
-                dropped[drop_of(i1, i2)] = 1;
-                WB_END_SINGLE
-            } else {
-                WB_SYNC();                                      // keep the barrier count of the two branches equal
+            bool miss = false;
+            for (int p0 = pa; p0 < pb && !miss; p0 += WB_WAVE) {
+                const int p = p0 + ln;
+                miss = wb_wave_any(p < pb && !in_set(rawpt[p], c2));
             }
+            if (!miss && ln == 0) dropped[drop_of(i1, i2)] = 1;
         }
+        WB_SYNC();
     }
     // ---- H: final table = kept and not dropped, order preserved (fin: the kept flag by contour until here, by kept contour from here)
     WB_PFOR32(f, Ck)
@@ -922,13 +947,13 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_END_PFOR
     WB_FSTAMP(a.ctl, 11);
     WB_FSTAMP_FLUSH(a.ctl);
-    WB_SINGLE
+    if (WB_TID == 0) {
     a.ncont[job] = Cf;
     a.nseg[job] = n;
     fa.fdone[job] = 1;
     wb_atomic_max(&a.ctl->max_chains, C);                       // (size the next batch's launch: wb_fused_layout)
     wb_atomic_max(&a.ctl->max_splitters, NSP);
-    WB_END_SINGLE
+    }
 #undef WB_F_DECLINE
 #undef WB_F_NOTE
 #undef WB_FQ
