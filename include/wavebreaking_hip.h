@@ -180,7 +180,10 @@ int wb_get_event_rows(wb_batch* b, int kind, wb_event_table* out);
 int wb_get_status(wb_batch* b, const uint32_t** status, int64_t* njobs);   /* per (step, level) */
 /* counters of the last wb_indices by name: "box_bound" -- overturning boxes whose centre-of-mass sums (index_utils.py:91-102,
    pandas' compensated sums) followed from the EXACT totals of their terms because no rounding boundary lay within the summation's
-   error bound (csrc/wb_props.h, wb_k_box_com); the others took the chained evaluation in the reference's order */
+   error bound (csrc/wb_props.h, wb_k_box_com); the others took the chained evaluation in the reference's order.  Of wb_contours:
+   "fused_declined" -- (step, level) jobs the one-launch trace kernel left to the three-kernel chain (a cell equal to the level, or
+   more segments / contours than the launch's LDS admitted: a context sizes it by what its batches have asked for, and the next
+   launch has grown), "fused_lds_bytes", "fused_jobs_per_cu" */
 int wb_get_counter(wb_batch* b, const char* name, int64_t* value);
 int wb_get_band_hits(wb_batch* b, int64_t* geo, int64_t* cont);            /* threshold guard-band re-evaluations */
 /* calculate_properties truncates x_com / areas and y_com / areas (index_utils.py:105-110); events whose quotient lies

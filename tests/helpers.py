@@ -365,6 +365,38 @@ def half_way_crossing_field(seed, dlon=2.5, dtype=np.float32, level=2.0):
     return pv, lat, lon
 
 
+def fused_growth_case(ctx, gpu=False):
+    from oracle import synth
+    lat, lon = synth.grid(2.5)
+    smooth = synth.pv_field(3, 2, lat, lon, eps=0.0)
+    noisy = synth.pv_field(7, 2, lat, lon, eps=0.0)
+    rng = np.random.RandomState(5)                              # four rows of noise around the level: a hundred small loops per job of level 2
+    noisy[:, 8:12, :] = (2.0 + rng.uniform(-0.5, 0.5, size=(2, 4, lon.size))).astype(noisy.dtype)
+
+    def counters(pv):
+        b = ctx.contours(pv, lat, lon, [-2.0, 2.0], 2.5, 2.5)
+        c = (b.counter("fused_declined"), b.counter("fused_lds_bytes"), b.counter("fused_jobs_per_cu"))
+        b.close()
+        return c
+
+    first, second = counters(smooth), counters(smooth)
+    # the second launch is sized by what the first one saw (a few chains, forty splitters): less LDS, nothing declined
+    assert first[0] == 0 and second[0] == 0 and second[1] < first[1], (first, second)
+    if gpu:
+        assert second[2] >= 4, second
+    seen = [counters(noisy)]
+    assert seen[0][0] > 0, seen                                 # more segments, splitters and chains than that launch admits
+    full_parity(ctx, noisy, lat, lon, synth.times(2), [-2.0, 2.0])          # ... taken by the three-kernel chain: the oracle's tables
+    for _ in range(8):
+        seen.append(counters(noisy))
+        if seen[-1][0] == 0:
+            break
+    assert seen[-1][0] == 0 and seen[-1][1] > second[1], seen  # the launch has grown until it holds them
+    assert all(a[0] >= b[0] for a, b in zip(seen, seen[1:])), seen
+    full_parity(ctx, noisy, lat, lon, synth.times(2), [-2.0, 2.0])
+    assert counters(smooth)[0] == 0
+
+
 def not_simple_polygon_case(ctx):
     """A cutoff whose polygon crosses itself (a bow tie handed in as a closed contour) next to a simple one: the event
     table flags the first, the oracle's winding numbers agree, cells follow the non-zero winding rule."""

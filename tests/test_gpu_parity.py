@@ -366,6 +366,17 @@ def test_crossings_at_one_half_of_their_edges(ctx, dtype):
     assert total > 30
 
 
+def test_fused_trace_grows_with_what_the_batches_ask_for():
+    """wb_k_trace_fused's LDS follows what the context's batches have asked for (four jobs per CU on the smooth bench field): a rough
+    field behind a smooth one is declined where it asks for more chains, taken by the three-kernel chain (tables = the oracle's), and
+    not declined the second time"""
+    c = _hip.Context(0)
+    try:
+        helpers.fused_growth_case(c, gpu=True)
+    finally:
+        c.close()
+
+
 def test_device_geometry_equals_host_geometry(ctx):
     """transform_polygons (index_utils.py:129-184): the rings wb_indices leaves in pinned host memory (cut at the last meridian,
     truncated and mapped to lon / lat by the device, csrc/wb_geom.h) against the host function on the same events -- ring for

@@ -416,6 +416,13 @@ def test_crossings_at_one_half_of_their_edges(sim, dtype):
     assert total > 20
 
 
+def test_fused_trace_grows_with_what_the_batches_ask_for():
+    """the fused trace kernel's LDS follows the context's batches: a rough field behind a smooth one asks for more chains than the
+    launch admits -- those jobs are declined (counted), the three-kernel chain takes them, the tables equal the oracle's; the same
+    field again finds a launch that has grown and is not declined"""
+    helpers.fused_growth_case(_hip.Context(0, helpers.hostsim_library()))
+
+
 def test_reference_own_code_fixture_through_the_abi(sim, golden_dir):
     """the contour table, the overturning boxes and the contour selection / cutoff filter against outputs of the reference's
     own statements (tests/golden/reference_rules.npz)"""

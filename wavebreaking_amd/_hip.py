@@ -763,7 +763,8 @@ class Batch:
         return int(a.value), int(c.value), int(o.value)
 
     def counter(self, name):
-        """a named counter of the last indices() call (wb_get_counter): "box_bound", "box_bound_mismatch" """
+        """a named counter (wb_get_counter) -- of the last indices() call: "box_bound", "box_bound_mismatch"; of contours():
+        "fused_declined" (jobs the one-launch trace kernel left to the three-kernel chain), "fused_lds_bytes", "fused_jobs_per_cu" """
         v = C.c_int64()
         f = self.ctx.L.lib.wb_get_counter
         f.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]

@@ -61,6 +61,8 @@ struct wb_batch {
     long long pair_stats[3] = {0, 0, 0};    // base-point pairs covered by the all-pairs test / candidates found / pairs evaluated
     WbCtl* d_ctl = nullptr;                 // device control block of the batch
     WbCtl h_ctl;                            // its phase-1 values (host copy)
+    int fused_declined = 0, fused_per_cu = -1;      // wb_k_trace_fused: jobs it declined, jobs a CU holds at the launch's LDS (wb_get_counter)
+    long long fused_lds = 0;
     std::vector<std::pair<void*, size_t>> hres;   // pinned host blocks of the result copies
     // device-resident result of the last wb_indices (kept when the context option "keep_device" is set): packed rows and
     // polygon vertices for the device-to-device gather of a time-sharded run
@@ -589,7 +591,7 @@ static int run_phase1(wb_batch* b) {
             if (cmax > 256 && ctx->trace_cmax <= 0) cmax = 256;
             fa.nmax = nmax; fa.cmax = cmax;
             const int s_grid = nmax / 16 + 128, s_seen = (seen_s + seen_s / (tight ? 16 : 8) + 16 + 7) & ~7;
-            fa.smax = (ctx->trace_nmax > 0 || seen_s <= 0 || s_seen > s_grid) ? s_grid : s_seen;
+            fa.smax = (ctx->trace_nmax > 0 || seen_s <= 0) ? s_grid : (s_seen > 1016 ? 1016 : s_seen);        // (the kernel's link words hold 10-bit splitter ordinals)
             L = wb_fused_layout(fa.nmax, fa.smax, fa.cmax, p.nlon, WB_FUSED_THREADS);
             while (L.total > lds_cu / 2 && fa.nmax > 1024) {        // never more than half a CU's LDS: smaller jobs only
                 fa.nmax -= 256; fa.smax = fa.nmax / 16 + 128;
@@ -615,6 +617,7 @@ static int run_phase1(wb_batch* b) {
             WB_LAUNCH_LDS(wb_k_trace_fused, J, WB_FUSED_THREADS, L.total, fa);
             b->timer.end(ctx);
             if (phase1_summary(b)) return 1;
+            b->fused_declined = b->h_ctl.n_unfused; b->fused_lds = (long long)L.total; b->fused_per_cu = (int)(lds_cu / (L.total + 512));
             if (b->h_ctl.max_nseg > ctx->fused_seen) ctx->fused_seen = b->h_ctl.max_nseg;
             if (b->h_ctl.max_chains > ctx->fused_seen_c) ctx->fused_seen_c = b->h_ctl.max_chains;
             if (b->h_ctl.max_splitters > ctx->fused_seen_s) ctx->fused_seen_s = b->h_ctl.max_splitters;
@@ -794,11 +797,16 @@ extern "C" int wb_get_com_rechecks(wb_batch* b, int64_t* events, int64_t* boxes,
 
 // counters of the last wb_indices by name: "box_bound" (queued overturning boxes whose centre-of-mass sums followed from the exact
 // totals of their terms, no chain), "box_bound_mismatch" (test builds with -DWB_BOXCOM_BOUND=2 only: boxes on which that and the
-// chained evaluation disagree -- must be 0)
+// chained evaluation disagree -- must be 0); of wb_contours: "fused_declined" (jobs wb_k_trace_fused left to the three-kernel chain:
+// a cell equal to the level, or more segments / chains / splitters than the launch's LDS admitted -- the context's next launch has
+// grown), "fused_lds_bytes", "fused_jobs_per_cu" (-1: the fused kernel was not launched)
 extern "C" int wb_get_counter(wb_batch* b, const char* name, int64_t* value) {
     if (!b || !name || !value) return 1;
     if (!strcmp(name, "box_bound")) { *value = b->box_bound; return 0; }
     if (!strcmp(name, "box_bound_mismatch")) { *value = b->box_bound_mismatch; return 0; }
+    if (!strcmp(name, "fused_declined")) { *value = b->fused_declined; return 0; }
+    if (!strcmp(name, "fused_lds_bytes")) { *value = b->fused_lds; return 0; }
+    if (!strcmp(name, "fused_jobs_per_cu")) { *value = b->fused_per_cu; return 0; }
     return wb_fail(b->ctx, std::string("wb_get_counter: unknown counter ") + name);
 }
 extern "C" int wb_get_pair_stats(wb_batch* b, int64_t* point_pairs, int64_t* candidate_pairs) {

@@ -397,7 +397,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     const int S1 = wb_block_scan_excl(wpre, nwords);
     // (what a job asked for sizes the context's next launch -- also when this one declines it)
 #define WB_F_NOTE(field, v) do { if (WB_TID == 0) wb_atomic_max(&a.ctl->field, (int)(v)); } while (0)
-    if (S1 > fa.smax || fa.smax > 1023) { WB_F_NOTE(max_splitters, S1 + S1 / 8); WB_F_DECLINE(); }
+    if (S1 > fa.smax || fa.smax > 1023) { WB_F_NOTE(max_splitters, S1 + S1 / 4 + 16); WB_F_DECLINE(); }
     WB_PFOR32(w, nwords)
         if (w == 0) ctr[1] = S1;                                  // (the walks append splitters of their own behind these)
         uint32_t f = spb[w];
@@ -445,7 +445,7 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
     WB_FSTAMP_FINE(a.ctl, 14);
     // C3: segments no walk reached lie on closed loops without a splitter: their key descents become splitters
     const int S2 = ctr[1];
-    if (ctr[0] || S2 > fa.smax) { WB_F_NOTE(max_splitters, S2 + fa.smax / 8); WB_F_DECLINE(); }
+    if (ctr[0] || S2 > fa.smax) { WB_F_NOTE(max_splitters, 2 * fa.smax); WB_F_DECLINE(); }      // (how many the walks would have added is not known: twice as many next time)
     const uint16_t NN = (uint16_t)0xFFFF;                      // "no node"
     WB_PFOR32(g, n > fa.smax + 2 ? n : fa.smax + 2)
         if (g < fa.smax + 2) ncp[g] = NN;                         // (C4's previous-splitter links start empty: no loop of their own for that)
@@ -461,12 +461,12 @@ WB_KERNEL_LB(wb_k_trace_fused, WB_FUSED_THREADS, WB_FUSED_OCC, WbFusedArgs fa) {
         }
     WB_END_PFOR
     const int S3 = ctr[1];
-    if (S3 > fa.smax) { WB_F_NOTE(max_splitters, S3); WB_F_DECLINE(); }
+    if (S3 > fa.smax) { WB_F_NOTE(max_splitters, S3 + S3 / 8); WB_F_DECLINE(); }
     WB_PFOR32(o, S3 - S2)
         walk(S2 + (int)o);
     WB_END_PFOR
     const int NSP = ctr[1];
-    if (ctr[0] || NSP > fa.smax) { WB_F_NOTE(max_splitters, NSP + fa.smax / 8); WB_F_DECLINE(); }
+    if (ctr[0] || NSP > fa.smax) { WB_F_NOTE(max_splitters, 2 * fa.smax); WB_F_DECLINE(); }
     WB_FSTAMP_FINE(a.ctl, 15);
     // C4: the splitters' own list: next splitter, previous splitter
     WB_PFOR32(o, NSP)
