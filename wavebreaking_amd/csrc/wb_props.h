@@ -122,7 +122,7 @@ WB_DEV inline bool wb_near_segment(int x, int y, int ax, int ay, int bx, int by,
 // "eight loads in flight" were one, and the sums were 70 % of the kernel (seen in the ISA, round 3).
 template <class T, bool BM>
 WB_DEV inline void wb_props_field_sums_t(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
-                                         double* out) {
+                                         double* out_v, double* out_i) {
     const T* data = (const T*)a.data + tbase;
     const bool has_i = a.intensity != nullptr;
     const T* inten = has_i ? (const T*)a.intensity + tbase : data;    // (no intensity: the same cells again, dropped below)
@@ -160,18 +160,17 @@ WB_DEV inline void wb_props_field_sums_t(const WbPropsArgs& a, size_t tbase, int
             acci += (((member >> q) & 1u) && has_i) ? pi : 0.0;
         }
     }
-    out[2 * WB_TID] = accv;
-    out[2 * WB_TID + 1] = acci;
-    WB_SYNC();
+    *out_v = accv;                     // (the lane's own partial sums: they stay in its registers -- as a table in LDS they were 1 KB of the
+    *out_i = acci;                     //  wave's 11, and at 10 KB a CU holds the sixteen waves the launch is sized for instead of fourteen)
 }
 WB_DEV inline void wb_props_field_sums(const WbPropsArgs& a, size_t tbase, int x0, int y0, int rows, int cols, const uint32_t* bm, int wb,
-                                       double* out) {
+                                       double* out_v, double* out_i) {
     if (a.dtype == 0) {
-        if (bm) wb_props_field_sums_t<float, true>(a, tbase, x0, y0, rows, cols, bm, wb, out);
-        else wb_props_field_sums_t<float, false>(a, tbase, x0, y0, rows, cols, bm, wb, out);
+        if (bm) wb_props_field_sums_t<float, true>(a, tbase, x0, y0, rows, cols, bm, wb, out_v, out_i);
+        else wb_props_field_sums_t<float, false>(a, tbase, x0, y0, rows, cols, bm, wb, out_v, out_i);
     } else {
-        if (bm) wb_props_field_sums_t<double, true>(a, tbase, x0, y0, rows, cols, bm, wb, out);
-        else wb_props_field_sums_t<double, false>(a, tbase, x0, y0, rows, cols, bm, wb, out);
+        if (bm) wb_props_field_sums_t<double, true>(a, tbase, x0, y0, rows, cols, bm, wb, out_v, out_i);
+        else wb_props_field_sums_t<double, false>(a, tbase, x0, y0, rows, cols, bm, wb, out_v, out_i);
     }
 }
 // The raster of an event in LDS: per row of its bounding box a short list of signed scanline crossings (sorted by the
@@ -198,7 +197,6 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
     WB_SHARED(int, xcnt, WB_PROPS_LROWS);
     WB_SHARED(uint32_t, bm, WB_PROPS_BM);
     WB_SHARED(int, ovf, 1);
-    WB_SHARED(double, lred, 2 * 64);                                  // per-lane partial sums of (data, intensity) * weight
     WB_SHARED(int, longe, WB_PROPS_LONG);
     WB_SHARED(int, nlong, 1);
     WB_SHARED(int, bb, 4);
@@ -230,6 +228,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
         const uint32_t* pts = a.cpts + 2 * jb + a.c_off[jb + cont];
         const int n = (kind == WB_EV_STREAMER) ? (d[4] - d[3] + 1) : (kind == WB_EV_CUTOFF ? a.c_len[jb + cont] : 4);
         const size_t tbase = (size_t)(a.job_step ? a.job_step[job] : job / a.nlev) * a.nlat * a.nlon;
+        double lane_v = 0.0, lane_i = 0.0;                      // this lane's share of the field sums (wb_props_field_sums)
 
         WB_SINGLE
         bb[0] = 0x7FFFFFFF; bb[1] = 0x7FFFFFFF; bb[2] = -1; bb[3] = -1;
@@ -482,7 +481,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 WB_ACC(0, y0 + (int)rr) = (double)cols;
                 WB_ACC(1, y0 + (int)rr) = (double)((long long)cols * x0 + (long long)cols * (cols - 1) / 2);
             WB_END_PFOR
-            wb_props_field_sums(a, tbase, x0, y0, rows, cols, nullptr, 0, lred);
+            wb_props_field_sums(a, tbase, x0, y0, rows, cols, nullptr, 0, &lane_v, &lane_i);
         } else if (use_bm) {
             // D': integer counts per row from the bitmap (a lane per row) ...
             WB_PFOR(rr, rows)
@@ -502,7 +501,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
             // Round 6 measured what that wastes -- the members are 50 % of a streamer's box, 65 % of a cutoff's, all of an overturning
             // box: 62 M member cells of 78 M box cells per 0.25 degree year -- and tried sums over the rows' member spans instead:
             // they never held less than half a box, and the search for a cell's row cost more than the loads it saved.)
-            wb_props_field_sums(a, tbase, x0, y0, rows, cols, bm, wb, lred);
+            wb_props_field_sums(a, tbase, x0, y0, rows, cols, bm, wb, &lane_v, &lane_i);
         } else {
         // D: per-row counts and sums
         WB_PFOR(rr, rows)
@@ -556,7 +555,7 @@ WB_KERNEL(wb_k_props, WbPropsArgs a) {
                 if (!lane_sums) { pv = pv + w * WB_ACC(2, y); pi = pi + w * WB_ACC(3, y); }
                 pn += cnt;
             }
-            if (lane_sums) { pv = lred[2 * WB_TID]; pi = lred[2 * WB_TID + 1]; }
+            if (lane_sums) { pv = lane_v; pi = lane_i; }
             WB_SYNC();
             // the lanes' shares added by butterfly (a fixed order: the same bits on every run); lane 0 adding 64 x 6 values
             // from LDS one after the other was 10 us per event
