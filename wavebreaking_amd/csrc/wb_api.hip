@@ -445,6 +445,7 @@ static int run_phase1(wb_batch* b) {
             const int wps = !(p.dtype == 0 && vec) ? 4 : ((variant == 1 || variant == 4 || variant == 5) ? 5 : (variant == 2 ? 4 : (variant == 3 ? 8 : 6)));
             int wg_per_cu = (wps * 4) / b->nwork_strips;
             if (wg_per_cu < 1) wg_per_cu = 1;
+            if (ctx->scan_wg_per_cu > 0 && ctx->scan_wg_per_cu < wg_per_cu) wg_per_cu = ctx->scan_wg_per_cu;   // (option "scan_wg_per_cu": fewer resident workgroups than fit -- room beside them for the other batch's kernels)
             const long long slots = (long long)ncu * wg_per_cu;
             // bands: about six work items per resident workgroup, so that the last round of the persistent grid is nearly full
             int nbands = (int)((6 * slots + p.nt - 1) / p.nt);
@@ -2423,6 +2424,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "scan_f64_fast")) { ctx->scan_f64_fast = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_debug")) { ctx->scan_debug = value; return 0; }
     if (!strcmp(name, "scan_grid_mult")) { ctx->scan_grid_mult = value; return 0; }
+    if (!strcmp(name, "scan_wg_per_cu")) { ctx->scan_wg_per_cu = value > 0 ? (int)value : 0; return 0; }
     if (!strcmp(name, "scan_dynamic")) { ctx->scan_dynamic = value ? 1 : 0; return 0; }
     if (!strcmp(name, "pairs_lds")) { ctx->pairs_lds = value ? 1 : 0; return 0; }
     if (!strcmp(name, "p2_budget_kb")) { ctx->p2_budget_kb = value; ctx->p2_budget = 0; return 0; }

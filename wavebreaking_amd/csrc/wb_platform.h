@@ -58,6 +58,7 @@ struct wb_ctx {
     int cu_first = 0, cu_count = 0;           // option "cu_mask": the context's main and side streams own the compute units [cu_first, cu_first + cu_count) only (0: the whole device)
     int boxcom_cu_first = 0, boxcom_cu_count = 0;   // option "boxcom_cu_mask": wb_k_box_com runs on those compute units only (its single waves otherwise take slots on every CU from the 1024-thread workgroups of the streamer chain beside it)
     int scan_cu_first = 0, scan_cu_count = 0; // option "scan_cu_mask": ... and the field scan's stream those
+    int scan_wg_per_cu = 0;                   // option "scan_wg_per_cu": resident workgroups of the streaming scan per CU (0: as many as fit -- two at 0.25 degree)
     int scan_exclusive = 0;                   // 1: a context's field scan waits (on the device) for the scan another context of the same device launched before it
     int index_polygons = 0;                   // 1: wb_indices packs the events' polygons in grid indices into pinned host memory (13.5 MB per year of 0.25 degree over PCIe); 0 (default since round 6): wb_get_events packs them when it is first asked for them -- the drop-in functions build their frames from the lon / lat rings and never ask
     int geometry_async = 1;                   // 1: the geometry kernels of wb_indices (PCIe-bound: 27 MB of doubles per year of 0.25 degree) are not waited for by wb_indices -- they finish beside the next pass's field scan, wb_get_event_geometry waits for them; 0: wb_indices returns when they are done
