@@ -1879,7 +1879,14 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.begin(ctx, "fill_events");
         WB_LAUNCH(wb_k_event_offsets, 1, WB_LIST_THREADS, fa);
         if (nsel_b + ncut_b > 0) WB_LAUNCH(wb_k_fill_events, nsel_b + ncut_b, 64, fa);
-        WB_LAUNCH(wb_k_poly_offsets, 1, WB_LIST_THREADS, fa);
+        b->timer.end(ctx);
+        // The events' descriptors stand: the property kernel goes out AT ONCE, on the main stream.  The polygons' offsets (one workgroup
+        // scanning 19 000 lengths: 35 us), the buffers of the results and the three geometry kernels are launched behind it from the
+        // point marked here, on the side stream -- until round 6 wb_k_props waited for the offsets it does not read and for the host
+        // to have set all that up (70 us of a pass one batch at a time).
+        side_mark(ctx);
+        b->timer.begin(ctx, "props");
+        WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
         b->timer.end(ctx);
         // descriptors are complete: the vertices go out on the side stream (straight into the batch's pinned host arrays,
         // sized for the capacity -- the counts are only known on the device), properties on the main one; then ONE kernel
@@ -1963,7 +1970,8 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             }
 #endif
         };
-        side_begin(ctx);
+        side_begin_marked(ctx);
+        WB_LAUNCH(wb_k_poly_offsets, 1, WB_LIST_THREADS, fa);
         if (polys_now || d_px) {
             b->timer.begin(ctx, "polygons");
             WB_LAUNCH(wb_k_pack_polys, ctx->polys_grid, 256, ctl, cap, fa.ev, fa.poff, b->c_off, b->cpts, b->poly_x, b->poly_y, d_px, d_py);
@@ -1976,7 +1984,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             // them: nobody waits for them here -- neither the main stream nor the host.  They finish beside whatever the device runs
             // next (the next pass's HBM-bound field scan), and wb_get_event_geometry / wb_free_batch / the batch's next wb_indices wait
             // for the event recorded behind them (wb_geom_settle)
-            side_begin(ctx);
+            side_begin_marked(ctx);                            // (still from the point marked above: beside wb_k_props, behind the polygons' offsets)
             launch_geometry();
 #if !defined(WB_HOSTSIM)
             if (!b->g_event) (void)hipEventCreateWithFlags(&b->g_event, hipEventDisableTiming);
@@ -1984,10 +1992,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
 #endif
             side_leave(ctx);
         }
-        b->timer.begin(ctx, "props");
-        WB_LAUNCH(wb_k_props, pa.nslots, 64, pa);
-        b->timer.end(ctx);
-        side_join(ctx);                                        // (the vertices; synchronous geometry: the control block carries its totals)
+        side_join(ctx);                                        // (the polygons' offsets, the vertices; synchronous geometry: the control block carries its totals)
         b->timer.begin(ctx, "results");
         WB_LAUNCH(wb_k_pack_results, cap_ne < 64 * 256 ? (cap_ne + 255) / 256 + 1 : 64, 256, ctl, fa.ev, fa.poff, pa.ev_sums, pa.ev_ncells, pa.ev_flags,
                   pa.ev_cell_off, rb, T->base + T->o_lonval, T->base + T->o_lat, p.nlon, p.nlat);

@@ -411,6 +411,23 @@ static void side_begin(wb_ctx* ctx) {
     (void)ctx;
 #endif
 }
+// the fork in two steps: side_mark records the point of the main stream the side stream will start from, side_begin_marked -- after
+// MORE has been launched on the main stream -- starts the side section there (what was launched in between does not hold it up)
+static void side_mark(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    (void)hipEventRecord(ctx->fork, ctx->stream);
+#else
+    (void)ctx;
+#endif
+}
+static void side_begin_marked(wb_ctx* ctx) {
+#if !defined(WB_HOSTSIM)
+    (void)hipStreamWaitEvent(ctx->stream2, ctx->fork, 0);
+    std::swap(ctx->stream, ctx->stream2);
+#else
+    (void)ctx;
+#endif
+}
 static void side_end(wb_ctx* ctx) {
 #if !defined(WB_HOSTSIM)
     (void)hipEventRecord(ctx->join, ctx->stream);
