@@ -68,6 +68,8 @@ def parse():
                     help="1: streaming scan (patch capture) + list build kernel; 0: single classify-and-emit kernel")
     ap.add_argument("--scan-variant", type=int, default=int(os.environ.get("WB_BENCH_SCAN_VARIANT", 2)),
                     help="streaming scan: ring depth x waves per SIMD (0: 8x6, 1: 10x5, 2: 13x4, 3: 6x8)")
+    ap.add_argument("--stage-steps", type=int, default=int(os.environ.get("WB_BENCH_STAGE_STEPS", 0)),
+                    help="passes with every stage timed, after the timed region (0: ten when --stagger-steps > 0, else none)")
     ap.add_argument("--stagger-steps", type=int, default=int(os.environ.get("WB_BENCH_STAGGER_STEPS", 20)),
                     help="passes of the staggered-phases measurement after the timed region (N = 1, two batches in flight); 0 = skip")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("WB_BENCH_STREAMS", 2)),
@@ -308,6 +310,28 @@ def main():
     run_record(a.steps, True)                 # (returns when the last gather of the record has landed on rank 0)
     barrier()
     dt = time.perf_counter() - tic
+    # The other stages' durations: a few more passes with an event pair around EVERY stage (context option timers = 2).  The library's
+    # default, and the timed region's, is the pair around the field scan alone -- the roofline's kernel --: the packets and the
+    # dependency gaps of a dozen pairs per pass cost 2.7 % of it (profiles/r06_ab_sessions.txt).  After the timed region; never `value`.
+    scan_timed = list(stage_ms.get("scan", []))
+    stage_passes = 0
+    if a.stagger_steps > 0 or a.stage_steps > 0:
+        stage_passes = a.stage_steps if a.stage_steps > 0 else 10
+        for c in pipe.contexts:
+            c.set_option("timers", 2)
+        main_wall0 = {k: list(v) for k, v in wall.items()}
+        main_counts0 = dict(counts)
+        stage_ms.clear()
+        run_record(2, False)
+        tic_t = time.perf_counter()
+        run_record(stage_passes, True)
+        barrier()
+        dt_t = time.perf_counter() - tic_t
+        for c in pipe.contexts:
+            c.set_option("timers", 1)
+        stage_ms["scan"] = scan_timed                          # (the scan's launches of the timed region: what `roofline` is quoted on)
+        wall.clear(); wall.update(main_wall0)
+        counts.clear(); counts.update(main_counts0)
     # the same passes with the phases staggered (one batch's scan + trace kernels beside the other's index kernels, never
     # two scans at once): what the HBM-bound kernel keeps of the roofline when it does not share HBM with its twin, and
     # what that ordering costs the whole job.  After the timed region; reported next to it, never as `value`.
@@ -435,6 +459,8 @@ def main():
                          "frac_alone": nt * bytes_per_ts / (solo_scan_ms * 1e-3) / HBM_PEAK,
                          "pipeline_frac_of_hbm_roofline": value / world * bytes_per_ts / HBM_PEAK},
             "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items()},
+            "stage_ms_from": ("scan: the timed region; the other stages: %d more passes with an event pair around every stage (context option timers = 2; "
+                              "%.0f timesteps/s in those passes)" % (stage_passes, world * nt * stage_passes / dt_t)) if stage_passes else "the timed region (scan only: the library's default)",
             # the all-pairs streamer test, reported separately: base-point pairs COVERED per second of its kernel
             # (N (N - 1) / 2 per contour; most are excluded as whole blocks) and pairs whose great-circle term is EVALUATED
             "pair_evaluations_per_s": counts["pair_stats"][0] / (float(np.mean(stage_ms["streamer_pairs"])) * 1e-3)
@@ -497,6 +523,7 @@ def float64_scan(ctx, lat, lon, levels, nt, par, eps, bytes_per_ts_f32):
     try:
         ctx.synth_fill(d, np.float64, 0, nt, lat, lon, par, eps, synth.SEED)
         out = {}
+        ctx.set_option("timers", 2)                            # (this leg quotes the build and trace kernels too)
         for fast in (1, 0):
             ctx.set_option("scan_f64_fast", fast)
             ms = []
@@ -515,6 +542,7 @@ def float64_scan(ctx, lat, lon, levels, nt, par, eps, bytes_per_ts_f32):
         return out
     finally:
         ctx.set_option("scan_f64_fast", 1)
+        ctx.set_option("timers", 1)
         ctx.free(d)
 
 

@@ -202,7 +202,9 @@ int wb_get_evaluated_pairs(wb_batch* b, int64_t* evaluated);
    last bit in the last wb_indices call: there the survivor is the member that comes first in the reference's CPython set */
 int wb_get_group_ties(wb_batch* b, int64_t* ties);
 /* per-stage device times of the last wb_contours / wb_indices calls, measured with HIP events on the
-   context's stream: names is a NUL-separated list */
+   context's stream: names is a NUL-separated list.  Which stages are timed is the context option "timers": 1 (the default) the
+   field scan only -- the other stages keep their names and read 0 ms --, 2 every stage (an event pair per stage: a dozen
+   dependency gaps per pass, 3-5 % of it), 0 none */
 int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);
 /* Time-sharded runs (one process per GPU): with the context option "keep_device" = 1, wb_indices also leaves its result ON
    THE DEVICE -- one row of WB_ROW_WIDTH doubles per event (step + the offset set by wb_set_step_offset, level, contour

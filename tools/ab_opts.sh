@@ -7,7 +7,7 @@ REPS=$1; shift
 for rep in $(seq 1 $REPS); do
   for cfg in "$@"; do
     label=${cfg%%:*}; envs=${cfg#*:}
-    env $envs timeout 300 python bench.py --steps ${AB_STEPS:-40} --warmup 6 --cpu-sample 0 --e2e-steps 0 --stagger-steps 0 ${AB_ARGS:-} > /tmp/ab.json 2> /tmp/ab.err || tail -3 /tmp/ab.err
+    env $envs timeout 300 python bench.py --steps ${AB_STEPS:-40} --warmup 6 --cpu-sample 0 --e2e-steps 0 --stagger-steps 0 --stage-steps ${AB_STAGE:-6} ${AB_ARGS:-} > /tmp/ab.json 2> /tmp/ab.err || tail -3 /tmp/ab.err
     python - "$label" <<'PY'
 import json, sys
 try:

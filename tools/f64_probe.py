@@ -5,6 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wavebreaking_amd import _hip, synthetic as synth
 ctx = _hip.Context(0)
+ctx.set_option("timers", 2)              # (every stage timed: the library times the field scan only by default)
 nt = 1460
 lat, lon = synth.grid(0.25)
 d = ctx.alloc(nt * lat.size * lon.size * 8)

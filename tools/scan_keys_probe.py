@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from wavebreaking_amd import _hip
 from wavebreaking_amd import synthetic as synth
 ctx = _hip.Context(0)
+ctx.set_option("timers", 2)              # (every stage timed: the library times the field scan only by default)
 lat, lon = synth.grid(0.25)
 nt = 1460
 nlat, nlon = lat.size, lon.size

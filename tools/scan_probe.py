@@ -3,6 +3,7 @@ import sys, numpy as np, time
 sys.path.insert(0, '/root/repo')
 from wavebreaking_amd import _hip, synthetic as synth
 ctx = _hip.Context(0)
+ctx.set_option("timers", 2)              # (every stage timed: the library times the field scan only by default)
 lat, lon = synth.grid(0.25)
 nt = 1460
 d = ctx.alloc(nt * lat.size * lon.size * 4)

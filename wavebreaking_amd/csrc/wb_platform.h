@@ -77,7 +77,8 @@ struct wb_ctx {
     int scan_pad = 0;                         // streaming scan: elements added to the stride of the patch lists' arrays (WbScanArgs.cap_vs)
     int scan_bands = 0;                       // streaming scan: row bands per time step (0: chosen from the grid and the device)
     int polys_grid = 2048;                    // workgroups of wb_k_pack_polys (it writes over PCIe: more of them only hold wave slots)
-    int timers = 2;                           // stage timers: 2 all, 1 the scan only, 0 none (WbTimer)
+    int timers = 1;                           // stage timers (WbTimer): 2 every stage, 1 the field scan only (the default since round 6: a pair of event packets per stage and
+                                              // the dependency gaps behind them cost 2.7 % of a pass with two batches in flight, 5 % one batch at a time), 0 none
     int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
     int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
@@ -600,7 +601,7 @@ struct WbTimer {
         ms.push_back(0.f);
 #if !defined(WB_HOSTSIM)
         hipEvent_t a = nullptr, b = nullptr;
-        // option "timers": 2 every stage (default), 1 the scan kernel only (what the roofline is quoted on), 0 none -- an event
+        // option "timers": 2 every stage, 1 the scan kernel only (the default: what the roofline is quoted on), 0 none -- an event
         // pair is two more packets on the stream per stage; the stage keeps its name and reads 0 ms
         if (c->timers >= 2 || (c->timers == 1 && !strcmp(name, "scan"))) {
             (void)hipEventCreate(&a);
