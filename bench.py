@@ -16,6 +16,9 @@ polygon vertices in GRID INDICES, which rounds 1-5 also copied to the host in ev
 option geometry = 0, the index-space figure that rounds 1-5 reported as `value`.  NOT in either: the upload of the fields over
 PCIe (`end_to_end` measures the drop-in calls from a host cube, upload included) and the construction of the (Geo)DataFrame;
 `stage_ms.geometry_host` is what the frame's property columns (:104-120) cost on the host per pass.
+`stage_ms`: the field scan's launches of the TIMED region (what `roofline` is quoted on) -- the library times that kernel only by
+default --; the other stages from ten more passes behind it with an event pair around every stage (context option timers = 2:
+those pairs cost 3 % of a pass, which is why they are off in the timed region; `stage_ms_from`).
 
 `--streams` passes (default 2) are in flight per GPU at any time, each on its own context = HIP stream +
 host thread (wavebreaking_amd/pipeline.py); all K timed passes complete inside the timed region.  The K passes are ONE
