@@ -31,7 +31,8 @@ batch (BatchPipeline.run_record).
 
 N > 1: time steps are sharded across ranks (weak scaling: every rank owns --nt steps of the synthetic
 40-year record, rank r starting at r*nt); the two exchanges of SURVEY 8e over RCCL: the one all-reduce(max) above and
-the gather of the event rows and polygon vertices to rank 0, device to device, batch by batch on a thread of its own
+the gather of the event rows and the rings in lon / lat to rank 0 (the polygons in grid indices stay on the ranks, as on one GPU:
+context option keep_device = 2), device to device, batch by batch on a thread of its own
 (the tables are staged, the batch is released, wavebreaking_amd.distributed.TableGatherer): rank 0's copy of N x
 16.5 MB per pass to pinned host memory overlaps the next batches instead of ending the record with one serial tail.
 Prints ONE JSON line on rank 0.
@@ -130,7 +131,10 @@ def main():
             c.set_option("scan_halo_lds", int(os.environ["WB_BENCH_HALO_LDS"]))
         if os.environ.get("WB_BENCH_SCAN_GRID"):
             c.set_option("scan_grid_mult", int(os.environ["WB_BENCH_SCAN_GRID"]))
-        c.set_option("keep_device", 1 if multi else 0)       # N > 1: event rows + polygon vertices stay on the device for the gather
+        # N > 1: the event rows (and, with geometry, the rings in lon / lat) stay on the device for the gather; the polygons in GRID
+        # INDICES stay descriptors on every rank, as they do on a single GPU since round 6 (keep_device = 2; WB_BENCH_GATHER_POLYGONS=1: they travel too)
+        ship_polygons = bool(int(os.environ.get("WB_BENCH_GATHER_POLYGONS", "0")))
+        c.set_option("keep_device", (1 if ship_polygons else 2) if multi else 0)
         for kv in filter(None, os.environ.get("WB_BENCH_OPTS", "").split(",")):   # development: "name=value,..." context options (A/B runs)
             name, _, val = kv.partition("=")
             if ":" in name:                                   # "k:name=value": context k only (CU masks differ per context)
@@ -261,7 +265,7 @@ def main():
         """on the gather thread, when batch k's catalogue stands in rank 0's pinned buffers"""
         if cat is None:
             return None
-        assert int(cat[0][:, 18].sum()) == cat[1].size == cat[2].size
+        assert cat[1].size == cat[2].size and cat[1].size in (0, int(cat[0][:, 18].sum()))     # (0: keep_device = 2, the rows travelled without their index polygons)
         if len(cat) > 3:                                   # the rings in lon / lat travelled too (geometry of every rank's own device)
             ring_off, vert_off, gx, gy = cat[3]
             assert ring_off.size == cat[0].shape[0] + 1 and vert_off.size == ring_off[-1] + 1 and gx.size == gy.size == vert_off[-1]
@@ -423,13 +427,13 @@ def main():
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         seen, ev_sum, vert_sum, ring_sum, gvert_sum = (int(v) for v in mine.cpu().tolist())
         verify = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "gather_path": gather_path, "ranks_seen_by_allreduce": seen,
-                  "events_sum_over_ranks": ev_sum, "polygon_vertices_sum_over_ranks": vert_sum,
+                  "events_sum_over_ranks": ev_sum, "polygon_vertices_sum_over_ranks": vert_sum, "index_polygons_gathered": ship_polygons,
                   "rings_sum_over_ranks": ring_sum, "ring_vertices_sum_over_ranks": gvert_sum,
                   "geometry_gather": "every rank's lon / lat rings (transform_polygons on its own device) to rank 0 beside the tables: torch.distributed gathers of the arrays the geometry kernels wrote" if main_geometry else "off"}
         if rank == 0:
             if seen != world or dist.get_world_size() != world:
                 raise SystemExit("bench.py: the collective saw %d ranks, WORLD_SIZE is %d" % (seen, world))
-            if counts.get("gathered_events") != ev_sum or counts.get("gathered_polygon_vertices") != vert_sum:
+            if counts.get("gathered_events") != ev_sum or counts.get("gathered_polygon_vertices") != (vert_sum if ship_polygons else 0):
                 raise SystemExit("bench.py: rank 0 gathered %s events / %s vertices, the ranks hold %d / %d"
                                  % (counts.get("gathered_events"), counts.get("gathered_polygon_vertices"), ev_sum, vert_sum))
             if main_geometry and (counts.get("gathered_rings") != ring_sum or counts.get("gathered_ring_vertices") != gvert_sum):

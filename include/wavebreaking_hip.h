@@ -210,7 +210,9 @@ int wb_get_timings(wb_batch* b, const char** names, const float** ms, int* n);
    THE DEVICE -- one row of WB_ROW_WIDTH doubles per event (step + the offset set by wb_set_step_offset, level, contour
    inside its (step, level), ind1, ind2, box[4], orientation, the five sums, cell count, kind, flags, polygon length, 0;
    streamers, then overturnings, then cutoffs: n[3]) and the polygon vertices -- so that the gather to rank 0 over RCCL
-   moves device buffers (no host staging).  Pointers are device pointers, valid until the next wb_indices / wb_free_batch. */
+   moves device buffers (no host staging).  Pointers are device pointers, valid until the next wb_indices / wb_free_batch.
+   "keep_device" = 2: the rows only (*nverts = 0) -- the polygons in grid indices stay descriptors on the rank that found them, as on
+   a single GPU (context option "index_polygons"); the gathered catalogue's geometry are the rings of wb_get_device_geometry. */
 #define WB_ROW_WIDTH 20
 int wb_set_step_offset(wb_batch* b, int64_t first_step);
 int wb_get_device_tables(wb_batch* b, const double** rows, int64_t n[3], const int32_t** poly_x, const int32_t** poly_y,

@@ -285,8 +285,9 @@ pv = synth.pv_field(first, max(count, 1), lat, lon, eps=0.2)
 if rank == 1:
     pv[2:4] = 0.0                        # rank 1's second batch holds no contour at all: it does NOT reach the full width
 pipe = BatchPipeline(0, depth=2, library=helpers.hostsim_library())
+KEEP = int(sys.argv[3])                  # 1: rows + index polygons + rings travel; 2: rows + rings (what bench.py --gpus N gathers)
 for c in pipe.contexts:
-    c.set_option("keep_device", 1)
+    c.set_option("keep_device", KEEP)
 nb = 2
 
 def phase1(c, k):
@@ -350,8 +351,11 @@ dist.destroy_process_group()
 '''
 
 
-def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_path):
-    """what bench.py --gpus N runs: every batch selected against the full width at once (BatchPipeline.run_record), ONE
+@pytest.mark.parametrize("keep", [1, 2])
+def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_path, keep):
+    """(keep = 2: the context option keep_device = 2 -- the rows travel without their polygons in grid indices, which stay
+    descriptors on the ranks as they do on a single GPU; the rings in lon / lat are the catalogue's geometry.)
+    what bench.py --gpus N runs: every batch selected against the full width at once (BatchPipeline.run_record), ONE
     all-reduce(max) per record that verifies it, every batch's tables staged and gathered by a thread of their own
     (distributed.TableGatherer) -- three ranks over gloo, one without time steps, one batch without any contour; rank 0's
     catalogue equals the single-process catalogue of the whole record"""
@@ -363,7 +367,7 @@ def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_
     procs = []
     for r in range(3):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out), str(keep)], env=env))
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
@@ -399,9 +403,12 @@ def test_record_with_one_deferred_maximum_and_gathers_off_the_critical_path(tmp_
         assert np.array_equal(rows[m, 1].astype(np.int32), ev["level_idx"])
         assert np.array_equal(rows[m, 10:15], ev["sums"])
         assert np.array_equal(rows[m, 5:9].astype(np.int32), ev["box"])
-        gx = np.concatenate([px[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
-        gy = np.concatenate([py[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
-        assert np.array_equal(gx, ev["poly_x"]) and np.array_equal(gy, ev["poly_y"])
+        if keep == 1:
+            gx = np.concatenate([px[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
+            gy = np.concatenate([py[start[i]:start[i] + npoly[i]] for i in m]) if m.size else np.zeros(0, np.int32)
+            assert np.array_equal(gx, ev["poly_x"]) and np.array_equal(gy, ev["poly_y"])
+        else:                                             # the rows still say how long each polygon is; no vertex travelled
+            assert px.size == 0 and py.size == 0 and np.array_equal(rows[m, 18].astype(np.int64), np.diff(ev["poly_offset"]))
         ro, vo, wx, wy = b.event_geometry(kind)
         for q, i in enumerate(m):
             assert ring_count[i] == ro[q + 1] - ro[q], (kind, q)

@@ -1904,7 +1904,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         if (!hblock || (polys_now && (!b->poly_x || !b->poly_y))) { release(); return wb_fail(ctx, "out of host memory"); }
         const WbResultBlock rb = wb_result_block(hblock, (size_t)cap_ne, p.want_cells != 0);
         int *d_px = nullptr, *d_py = nullptr;
-        if (ctx->keep_device) {                                // device copies of the vertices for the gather
+        if (ctx->keep_device == 1) {                           // device copies of the vertices for the gather (keep_device = 2: rows and rings only)
             d_px = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
             d_py = (int*)talloc((size_t)(cap_poly + 1) * sizeof(int));
             if (!d_py) { release(); return 1; }
@@ -1999,7 +1999,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         b->timer.end(ctx);
         if (ctx->keep_device) {
             // device rows for the gather, packed here; the vertex arrays are taken out of this attempt's scratch
-            if (b->dev_rows) { bfree_one(b, b->dev_rows); bfree_one(b, b->dev_px); bfree_one(b, b->dev_py); b->dev_rows = nullptr; }
+            if (b->dev_rows) { bfree_one(b, b->dev_rows); if (b->dev_px) bfree_one(b, b->dev_px); if (b->dev_py) bfree_one(b, b->dev_py); b->dev_rows = nullptr; b->dev_px = b->dev_py = nullptr; }
             b->dev_rows = balloc<double>(b, (size_t)(cap_ne + 1) * WB_ROW_WIDTH);
             if (!b->dev_rows) { release(); return 1; }
             if (!b->job_level.empty() && !b->d_job_level) b->d_job_level = upload(b, b->job_level);
@@ -2057,9 +2057,9 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
         h_ev = rb.ev; h_poff = rb.poff; h_sums = rb.sums; h_nc = rb.ncells; h_fl = rb.flags; h_coff = rb.cell_off;
         if (ctx->keep_device) {
             b->dev_px = d_px; b->dev_py = d_py;
-            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == (void*)d_px) { tmp.erase(tmp.begin() + i); break; }
-            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] == (void*)d_py) { tmp.erase(tmp.begin() + i); break; }
-            b->dev_nv = NV;
+            for (size_t i = 0; d_px && i < tmp.size(); ++i) if (tmp[i] == (void*)d_px) { tmp.erase(tmp.begin() + i); break; }
+            for (size_t i = 0; d_py && i < tmp.size(); ++i) if (tmp[i] == (void*)d_py) { tmp.erase(tmp.begin() + i); break; }
+            b->dev_nv = d_px ? NV : 0;                         // (keep_device = 2: the index polygons stay descriptors, as on a single GPU)
         }
         if (p.want_cells) {
             auto hbuf = [&](size_t bytes) -> void* { void* q = hmalloc(ctx, bytes ? bytes : 8, &got); if (q) b->hres.push_back({q, got}); return q; };
@@ -2423,7 +2423,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "scan_split")) { ctx->scan_split = value ? 1 : 0; return 0; }
     if (!strcmp(name, "eager_f2")) { ctx->eager_f2 = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "keep_device")) { ctx->keep_device = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "keep_device")) { ctx->keep_device = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
     if (!strcmp(name, "scan_variant")) { ctx->scan_variant = value; return 0; }
     if (!strcmp(name, "scan_keys_only")) { ctx->scan_keys_only = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_f64_fast")) { ctx->scan_f64_fast = value ? 1 : 0; return 0; }

@@ -79,7 +79,8 @@ struct wb_ctx {
     int polys_grid = 2048;                    // workgroups of wb_k_pack_polys (it writes over PCIe: more of them only hold wave slots)
     int timers = 1;                           // stage timers (WbTimer): 2 every stage, 1 the field scan only (the default since round 6: a pair of event packets per stage and
                                               // the dependency gaps behind them cost 2.7 % of a pass with two batches in flight, 5 % one batch at a time), 0 none
-    int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables)
+    int keep_device = 0;                      // 1: wb_indices keeps packed event rows + polygon vertices on the device (wb_get_device_tables); 2: the rows only (and, with
+                                              // geometry, the rings: wb_get_device_geometry) -- the index polygons stay descriptors, as they do on a single GPU since round 6
     int eager_f2 = 0;                         // 1: chord test for every candidate pair (wb_k_streamer_f2 + f34) instead of the lazy sweep
     int pairs_lds = 1;                        // 1: all-pairs test with the contour in LDS (wb_k_streamer_pairs2) where it applies; 0: tiled kernel only
     int ncu = 0;                              // compute units of the device (found once)

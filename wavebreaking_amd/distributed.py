@@ -165,6 +165,8 @@ def rows_to_events(rows, poly_x, poly_y):
     rows = np.asarray(rows, dtype=np.float64).reshape(-1, 20)
     poly_x, poly_y = np.asarray(poly_x), np.asarray(poly_y)
     npoly = rows[:, 18].astype(np.int64)
+    if poly_x.size == 0:                                               # (context option keep_device = 2: the rows travelled without
+        npoly = np.zeros_like(npoly)                                   #  their index polygons -- the rings in lon / lat are the geometry)
     start = np.cumsum(npoly) - npoly
     out = []
     for kind in (0, 1, 2):
