@@ -1805,7 +1805,7 @@ extern "C" int wb_indices(wb_batch* b, int gmax, int which) {
             b->timer.begin(ctx, "streamer_f1");
             WB_LAUNCH(wb_k_pairs_order, 1, WB_LIST_THREADS, st);
             // routine 1: inside wb_k_streamer_f234 (option f1_fused, the default), or its own persistent launch in front of the eager kernels
-            if (!st.f1_fused) { long long res = (2048LL / WB_F1_THREADS) * wb_num_cus(ctx) - ctx->persist_slack; if (res < 1) res = 1; WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
+            if (!st.f1_fused) { long long res = (2048LL / WB_F1_THREADS) * wb_num_cus(ctx) * ctx->f1_grid_x2 / 4 - ctx->persist_slack; if (res < 1) res = 1; WB_LAUNCH(wb_k_streamer_f1, nsel_b < res ? nsel_b : res, WB_F1_THREADS, st); }
             b->timer.end(ctx);
             if (ctx->eager_f2) {
                 // routine 2 for every candidate pair, then routines 3 + 4 on the survivors (option "eager_f2": the exhaustive
@@ -2435,6 +2435,7 @@ extern "C" int wb_set_option(wb_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "p2_budget_kb")) { ctx->p2_budget_kb = value; ctx->p2_budget = 0; return 0; }
     if (!strcmp(name, "p2_split")) { ctx->p2_split = value; return 0; }
     if (!strcmp(name, "p2_grid_x2")) { ctx->p2_grid_x2 = value > 0 ? value : 4; return 0; }
+    if (!strcmp(name, "f1_grid_x2")) { ctx->f1_grid_x2 = value > 0 ? (int)value : 4; return 0; }
     if (!strcmp(name, "scan_halo_lds")) { ctx->scan_halo_lds = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_exclusive")) { ctx->scan_exclusive = value ? 1 : 0; return 0; }
     if (!strcmp(name, "scan_priority")) { ctx->scan_priority = value ? 1 : 0; return 0; }

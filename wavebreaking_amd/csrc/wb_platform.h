@@ -86,6 +86,7 @@ struct wb_ctx {
     int ncu = 0;                              // compute units of the device (found once)
     size_t p2_budget = 0;                     // dynamic LDS a workgroup of wb_k_streamer_pairs2 may use (found once)
     int p2_grid_x2 = 4;                       // persistent grid of wb_k_streamer_pairs2 in half workgroups per CU (4 = two: every wave slot)
+    int f1_grid_x2 = 4;                       // ... of wb_k_streamer_f1 (4 = two workgroups of 1024 threads per CU)
     int p2_budget_kb = 0, p2_split = 0;       // development: overrides of that budget / of the workgroups per contour
 #if !defined(WB_HOSTSIM)
     hipStream_t stream = nullptr;
