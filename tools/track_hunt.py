@@ -29,6 +29,16 @@ def case(seed):
                 continue
             rings = pev.lattice_rings(ev)
             dates = np.asarray(ev["date"].values)
+            # events on several dates but no two within the time range: the reference raises (events.py:179-181) -- so must both sides
+            # (seed 8001169: two overturnings twelve hours apart)
+            try:
+                otrack.track_events(dates, rings=rings, time_range=6.0, method="by_overlap", overlap=0.0)
+            except ValueError as e_o:
+                try:
+                    wb.track_events(ev, time_range=6, method="by_overlap", overlap=0.0)
+                    return (seed, "FAIL " + fn.__name__ + ": the oracle raises (%s), the library does not" % e_o)
+                except ValueError:
+                    continue
             for ov in (0.0, float(rng.choice([0.05, 0.2, 0.5]))):
                 want, order, pairs, check = otrack.track_events(dates, rings=rings, time_range=6.0, method="by_overlap", overlap=ov)
                 got = wb.track_events(ev, time_range=6, method="by_overlap", overlap=ov)
