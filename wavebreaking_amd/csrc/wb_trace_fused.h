@@ -17,12 +17,18 @@
 //     few hundred splitters are ranked by pointer jumping -- O(n) work, ~20 barriers instead of ~50, 6 bytes of LDS per segment
 //     instead of 8 + 8;
 //   * closed loops: a loop that holds no splitter is found as the segments no walk visited and gets its key descents as
-//     splitters; the loop's raster-last segment is the maximum key of its chain, and the positions are rotated so that the
-//     contour starts behind it -- no second ranking of the segments;
-//   * first-occurrence dedupe (contour_index.py:110-112), distinct-x count (:154) and the periodic-duplicate rule (:119-147)
-//     without hash tables: the raw points are bucketed by x mod nlon (counting sort, 2 bytes per point); a bucket holds the
-//     handful of points of one meridian, and "was this lattice point seen before in this contour", "how many distinct x / (x mod
-//     nlon, y) has this contour", "does contour i2 hold this point of i1" are scans of one bucket.
+//     splitters; ONE ranking serves loops and open chains (round 6: the ranking word also carries the window's smallest ordinal
+//     and the distance to it, which on a loop is the node's place in the loop cut at that node); the loop's raster-last segment is
+//     the maximum key of its chain (a 64-bit atomic max of key | segment), and the positions are rotated so that the contour
+//     starts behind it;
+//   * first-occurrence dedupe (contour_index.py:110-112), distinct-x count (:154: a contour's points are a lattice path, so its
+//     distinct x are xmin .. xmax) and the periodic-duplicate rule (:119-147) without hash tables: the raw points are bucketed by a
+//     hash of (x mod nlon, y) (counting sort, 2 bytes per point); a bucket holds one or two points, a thread compares a bucket's
+//     points in registers, and "does contour i2 hold this point of i1" is a scan of one bucket.
+// Round 6: what sets this kernel's rate is the number of JOBS a CU holds -- the launch's LDS is sized by what the context's batches
+// have asked for (segments, chains, splitters: wb_api.hip; 36-40 KB = four jobs per CU on the 0.25 degree bench batch, where a
+// fixed 52 KB held three), and the body is written as data flow where the compiler would otherwise put an exec-mask branch around
+// every LDS load ("Round 6"; profiles/r06_ab_sessions.txt has the steps).
 // Development order: written in the WB_PFOR idiom so that the host simulation runs it (tests/test_hostsim_parity.py runs every
 // parity case with the option trace_fused = 1 and = 0).
 #pragma once
